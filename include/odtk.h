@@ -1,0 +1,201 @@
+/* libodtk -- C-ABI of the MI355X-native (gfx950) detector hot path.
+ *
+ * This is the drop-in boundary beneath the reference's per-model Python class
+ * surface (SSD300(config, data_provider).train_one_epoch / .test_one_image,
+ * /root/reference/SSD300.py:12-50,473-488).  The reference has no FFI of its own:
+ * every entry point below replaces the TensorFlow-1.13 op(s) that the cited
+ * reference line invokes through sess.run.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C: pointers, ints, floats; no C++/torch types cross this boundary;
+ *  - every pointer is a DEVICE pointer owned by the caller unless stated;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
+ *    is enqueued asynchronously, nothing synchronises;
+ *  - return 0 on success, non-zero ODTK_ERR_* otherwise; odtk_last_error() gives
+ *    the message (thread-local); no exception crosses the ABI;
+ *  - activations are NHWC, "rows x channel-pitch": row m = (n*H + h)*W + w,
+ *    element (m, c) at base[m*ld + c]; conv weights are [Cout][R][S][Cin] (KRSC);
+ *  - boxes are (y, x) ordered in input-pixel units exactly as the reference.
+ */
+#ifndef ODTK_H_
+#define ODTK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODTK_OK 0
+#define ODTK_ERR_ARG 1
+#define ODTK_ERR_HIP 2
+
+#define ODTK_BF16 0 /* bfloat16 storage, MFMA 32x32x16 bf16, f32 accumulate */
+#define ODTK_F32 1  /* float32 storage, MFMA 32x32x2 f32 (exact f32 FMA chain)  */
+
+const char* odtk_last_error(void);
+int odtk_version(void);
+/* number of compute units / name of the current device (host out pointers) */
+int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
+
+/* ------------------------------------------------------------------------- *
+ * Convolution family: replaces tf.nn.conv2d (SSD300.py:519) and
+ * tf.layers.conv2d (SSD300.py:524) forward, and the Conv2DBackpropInput /
+ * Conv2DBackpropFilter ops that tf.gradients adds (SSD300.py:154).
+ * Implicit GEMM on MFMA, TF "SAME" padding expressed as explicit pad_t/pad_l.
+ * ------------------------------------------------------------------------- */
+typedef struct odtk_conv_desc {
+    int N, H, W, C;      /* input  dims; C = GEMM-K channels, multiple of 8 (bf16) / 4 (f32) */
+    int ldx;             /* input row pitch in elements (>= C)                                */
+    int Ho, Wo, K;       /* output dims; K = Cout                                             */
+    int ldy;             /* output row pitch in elements (>= K)                               */
+    int R, S;            /* filter taps                                                       */
+    int stride, dil;     /* forward stride / dilation                                         */
+    int pad_t, pad_l;    /* TF SAME: pad_before (bottom/right take the extra cell)            */
+    int dtype;           /* ODTK_BF16 / ODTK_F32: storage of x, w (and dy)                    */
+    int out_dtype;       /* storage of the forward output y / dgrad output dx                 */
+} odtk_conv_desc;
+
+/* y[m, k] = act( sum_{r,s,c} x[n, ho*stride-pad_t+r*dil, wo*stride-pad_l+s*dil, c] * w[k,r,s,c] + bias[k] )
+ * bias may be NULL; relu != 0 applies max(.,0).  Columns >= K of y are not written. */
+int odtk_conv2d_fwd(const odtk_conv_desc* d, const void* x, const void* w, const float* bias,
+                    void* y, int relu, void* stream);
+
+/* dx[n,h,w,c] (+)= sum_{r,s,k} dy[n,ho,wo,k] * w[k,r,s,c]   (transposed conv of the fwd op)
+ * w_t is the dgrad-layout filter produced by odtk_filter_to_dgrad: [C][R][S][Kp]
+ * with taps flipped and Kp = dy pitch channels.  If relu_src != NULL the result is
+ * masked by (relu_src[m, c] > 0) -- the fused ReLU backward of the producer layer
+ * (relu_src has the geometry/pitch of dx and dtype d->dtype).  accumulate != 0
+ * adds into dx (sum over several consumers).  dx dtype = d->out_dtype. */
+int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t,
+                      const void* relu_src, void* dx, int accumulate, void* stream);
+
+/* dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (float32, KRSC, pitch R*S*C)
+ * Split over pixels with float atomics: dw must be zeroed (or hold the value to
+ * accumulate onto) by the caller.  dbias (optional) += column sums of dy. */
+int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy,
+                      float* dw, void* stream);
+
+/* w [K][R][S][C] (f32 master) -> w_t [C][R][S][Kp] in `dtype`, taps flipped, zero padded
+ * to Kp; and optionally a straight cast copy w_c [K][R][S][C] in `dtype` (may be NULL). */
+int odtk_filter_prepare(const float* w, int K, int R, int S, int C, int Kp, int dtype,
+                        void* w_c, void* w_t, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Elementwise / reduction layers (all NHWC rows x pitch)
+ * ------------------------------------------------------------------------- */
+/* images f32 [N,H,W,3] (RGB 0..255) -> x[N*H*W][ldx] = img - mean (SSD300.py:52-63),
+ * channels 3..ldx-1 zero.  dtype selects bf16/f32 output. */
+int odtk_preprocess(const float* images, long long pixels, const float* mean3, int ldx, int dtype,
+                    void* x, void* stream);
+
+/* tf.layers.max_pooling2d SAME (SSD300.py:539-547): kxk window, stride, pad_before. */
+int odtk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int ld, int Ho, int Wo,
+                     int k, int stride, int pad_t, int pad_l, int dtype, void* stream);
+/* gradient routed to the FIRST maximum of each window (row-major scan), summed over
+ * overlapping windows; dx fully written. */
+int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, void* dx, int N, int H, int W,
+                     int C, int ld, int Ho, int Wo, int k, int stride, int pad_t, int pad_l,
+                     int dtype, void* stream);
+
+/* tf.layers.batch_normalization, fused semantics (SSD300.py:506-512), momentum .99 eps 1e-3.
+ * z [M][ldz] (dtype) -> y.  Output row m is written at y + (m / rows_per_img)*y_img_stride
+ * + (m % rows_per_img)*ldy (lets the head write straight into pred [N,8828,25]).
+ * training: batch statistics (biased var), saves mean / inv-std (f32 [C]) for backward and
+ * updates moving stats with the unbiased variance.  Inference: uses moving stats.
+ * workspace: >= odtk_bn_workspace_bytes(M, C) bytes. */
+long long odtk_bn_workspace_bytes(int M, int C);
+int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, const float* gamma,
+                const float* beta, float* moving_mean, float* moving_var, float* save_mean,
+                float* save_invstd, int training, int relu, void* y, int y_dtype, int ldy,
+                int rows_per_img, long long y_img_stride, void* workspace, void* stream);
+/* dz from dy (same addressing rule as y); if relu, dy is first masked by (y > 0).
+ * dgamma/dbeta (f32 [C]) are overwritten. dz pad columns (C..ldz) are zeroed. */
+int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, int C, int ldz, int dtype,
+                int y_dtype, int ldy, int rows_per_img, long long y_img_stride,
+                const float* gamma, const float* save_mean, const float* save_invstd, int relu,
+                void* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
+
+/* tf.nn.l2_normalize(axis=C) * scalar gamma (SSD300.py:74-83). */
+int odtk_l2norm_fwd(const void* x, void* y, int M, int C, int ld, int dtype, const float* gamma,
+                    void* stream);
+/* dx += (accumulate) ; dgamma[0] += sum (caller zeroes). relu_src masks like dgrad. */
+int odtk_l2norm_bwd(const void* x, const void* dy, void* dx, int M, int C, int ld, int dtype,
+                    const float* gamma, float* dgamma, int accumulate, const void* relu_src,
+                    void* stream);
+
+/* column sums: out[c] (+)= sum_m dy[m][c]  (bias gradient), f32 out. */
+int odtk_colsum(const void* dy, int M, int C, int ld, int dtype, float* out, int accumulate,
+                void* workspace, void* stream);
+
+/* Fused MomentumOptimizer(0.9) + L2 weight decay over one flat f32 parameter buffer
+ * (SSD300.py:149-154): g = grad*grad_scale + wd*p; m = mom*m + g; p -= lr*m.
+ * l2_partial (optional, f32 [>=odtk_sgd_blocks(n)]) receives per-block sum(p_old^2)/2;
+ * p_cast (optional) receives the updated parameters cast to cast_dtype (the bf16 operand copy). */
+int odtk_sgd_blocks(long long n);
+int odtk_sgd_momentum(float* p, float* m, const float* grad, long long n, float lr, float momentum,
+                      float wd, float grad_scale, float* l2_partial, void* p_cast, int cast_dtype,
+                      void* stream);
+/* out[0] = sum_{i<n} in[i] (deterministic tree). */
+int odtk_sum_f32(const float* in, long long n, float* out, void* stream);
+/* cast f32 -> dtype */
+int odtk_cast_from_f32(const float* in, void* out, long long n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Box side: priors, matching, loss, NMS, decode
+ * ------------------------------------------------------------------------- */
+/* SSD300._get_abbox (SSD300.py:323-343) for `nlevels` levels concatenated level-major,
+ * then (y, x, anchor).  prior_hw: host-computed float32 (h, w) per level/anchor exactly as
+ * the reference builds its python list (level l has na[l] entries, packed).  Outputs are
+ * [A][2] each; nmsbox [A][4] = (yx - hw/2, yx + hw/2) as recomputed at SSD300.py:421. */
+int odtk_ssd_priors(int input_size, int nlevels, const int* fsize /*host*/, const int* na /*host*/,
+                    const float* prior_hw /*host*/, float* y1x1, float* y2x2, float* yx, float* hw,
+                    float* nmsbox, void* stream);
+
+/* SSD300._compute_one_image_loss steps 1-7 (SSD300.py:347-426), one workgroup per image.
+ * gt [N][P][5] = (yc, xc, h, w, cls), padded rows -1.  Outputs:
+ *  ngt[N]; best[N][P] (anchor id per GT, first max); status[N][A] u8: 0 = best anchor of some
+ *  GT, 1 = positive (max IoU > 0.5), 2 = negative; rgindex[N][A] (arg-max GT, first max);
+ *  counts[N][4] = {num_pos (= ngt + #status1), num_neg, chosen_num_neg, 0}. */
+int odtk_ssd_match(const float* y1x1, const float* y2x2, const float* hw, int A, const float* gt,
+                   int N, int P, int* ngt, int* best, unsigned char* status, int* rgindex,
+                   int* counts, void* stream);
+
+/* per-row softmax cross entropy against one constant label (the background class):
+ * loss[n][a] = logsumexp(pred[n][a][0:C]) - pred[n][a][label]   (SSD300.py:427-430) */
+int odtk_softmax_ce_const(const float* pred, long long rows, int C, int ld, int label, float* loss,
+                          void* stream);
+
+/* tf.image.non_max_suppression (NonMaxSuppressionV3) for B independent problems in one
+ * launch (SSD300.py:179, :431).  Problem b: boxes at boxes + b*box_stride (floats) [n][4];
+ * score i at scores[b*score_bstride + i*score_estride]; valid[b*valid_bstride + i*valid_estride]
+ * (u8, NULL = all valid) must equal `valid_value`; max_out from max_out_dev[b*max_out_stride]
+ * (device ints) or, when NULL, max_out_const.  Selected ORIGINAL indices in pick order go to
+ * out_idx[b*cap + j], the count to out_cnt[b].  Bit-exact vs the reference kernel for distinct
+ * scores; equal scores are visited lower index first.  n <= 16384. */
+int odtk_nms_batched(const float* boxes, long long box_stride, const float* scores,
+                     long long score_bstride, int score_estride, const unsigned char* valid,
+                     long long valid_bstride, int valid_estride, int valid_value, int n, int B,
+                     const int* max_out_dev, int max_out_stride, int max_out_const,
+                     float iou_threshold, int* out_idx, int cap, int* out_cnt, void* stream);
+
+/* SSD300._compute_one_image_loss steps 8-12 (SSD300.py:427-453) + the batch mean
+ * (SSD300.py:148) and its gradient.  loss_parts[N][4] = {neg, pos_conf, coord, total};
+ * dpred [N][A][ld] is overwritten with d(sum_i total_i * grad_scale)/dpred. */
+int odtk_ssd_loss(const float* pred, int N, int A, int C, int ld, const float* yx, const float* hw,
+                  const float* gt, int P, const int* ngt, const int* best,
+                  const unsigned char* status, const int* rgindex, const int* counts,
+                  const float* negloss, const int* sel_idx, int sel_cap, const int* sel_cnt,
+                  float grad_scale, float* loss_parts, float* dpred, void* stream);
+
+/* Inference decode (SSD300.py:157-171): softmax, drop rows whose arg-max is background,
+ * decode boxes.  conf [A][C-1], boxes [A][4]; cand[A][C-1] u8 = keep && conf >= thr. */
+int odtk_ssd_decode(const float* pred0, int A, int C, int ld, const float* yx, const float* hw,
+                    float score_thr, float* conf, float* boxes, unsigned char* keep,
+                    unsigned char* cand, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODTK_H_ */

@@ -1,0 +1,19 @@
+"""odtk -- MI355X-native (gfx950) detector hot path behind the class surface of
+Stick-To/Object-Detection-Tensorflow (SSD300 first).
+
+Physical package directory: ``object-detection-tensorflow_amd/``; import name ``odtk``
+(the repo-root ``odtk.py`` shim maps one onto the other).  Host code is Python on
+PyTorch-ROCm tensors; all arithmetic on the hot path runs in hand-written HIP kernels
+reached through the C-ABI in ``include/odtk.h`` (``libodtk.so``).
+"""
+from . import _lib                      # noqa: F401
+from ._lib import BF16, F32, OdtkError  # noqa: F401
+
+__all__ = ["BF16", "F32", "OdtkError", "SSD300"]
+
+
+def __getattr__(name):
+    if name == "SSD300":
+        from .ssd300 import SSD300
+        return SSD300
+    raise AttributeError(name)

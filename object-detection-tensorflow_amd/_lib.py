@@ -1,0 +1,95 @@
+"""ctypes binding of libodtk.so (the C-ABI declared in include/odtk.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails,
+this module raises.  Build with `python __graft_entry__.py build` or
+`make -C object-detection-tensorflow_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libodtk.so")
+
+BF16 = 0
+F32 = 1
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `odtk_conv_desc` (include/odtk.h)."""
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "H", "W", "C", "ldx", "Ho", "Wo", "K", "ldy", "R", "S", "stride", "dil",
+        "pad_t", "pad_l", "dtype", "out_dtype")]
+
+
+class OdtkError(RuntimeError):
+    pass
+
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+_cd = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol include/odtk.h declares
+SIGNATURES = {
+    "odtk_last_error": (C.c_char_p, []),
+    "odtk_version": (_i, []),
+    "odtk_device_info": (_i, [C.POINTER(_i), C.c_char_p, _i]),
+    "odtk_conv2d_fwd": (_i, [_cd, _vp, _vp, _vp, _vp, _i, _vp]),
+    "odtk_conv2d_dgrad": (_i, [_cd, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "odtk_conv2d_wgrad": (_i, [_cd, _vp, _vp, _i, _vp, _vp]),
+    "odtk_filter_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "odtk_preprocess": (_i, [_vp, _ll, C.POINTER(_f), _i, _i, _vp, _vp]),
+    "odtk_maxpool_fwd": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
+    "odtk_maxpool_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "odtk_bn_workspace_bytes": (_ll, [_i, _i]),
+    "odtk_bn_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _ll,
+                         _vp, _vp]),
+    "odtk_bn_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                         _vp, _vp]),
+    "odtk_l2norm_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "odtk_l2norm_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "odtk_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "odtk_sgd_blocks": (_i, [_ll]),
+    "odtk_sgd_momentum": (_i, [_vp, _vp, _vp, _ll, _f, _f, _f, _f, _vp, _vp, _i, _vp]),
+    "odtk_sum_f32": (_i, [_vp, _ll, _vp, _vp]),
+    "odtk_cast_from_f32": (_i, [_vp, _vp, _ll, _i, _vp]),
+    "odtk_ssd_priors": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _vp, _vp, _vp, _vp, _vp,
+                             _vp]),
+    "odtk_ssd_match": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "odtk_softmax_ce_const": (_i, [_vp, _ll, _i, _i, _i, _vp, _vp]),
+    "odtk_nms_batched": (_i, [_vp, _ll, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _i,
+                              _vp, _vp]),
+    "odtk_ssd_loss": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                           _vp, _f, _vp, _vp, _vp]),
+    "odtk_ssd_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libodtk.so and attach signatures; raises OdtkError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OdtkError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` in the repo root.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise OdtkError(f"libodtk error {rc}: {load().odtk_last_error().decode()}")
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args))

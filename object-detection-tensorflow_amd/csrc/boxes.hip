@@ -1,0 +1,574 @@
+// Box-side kernels of the SSD300 path (gfx950): priors, IoU matching, background cross
+// entropy, batched NMS (hard-negative mining + per-class inference NMS), fused loss + gradient,
+// inference decode.  Latency-bound wave-reduction / LDS kernels, one workgroup per image.
+//
+// Everything that produces an INDEX (arg-max, arg-min, masks, NMS picks) follows the exact
+// float32 operation order of the reference graph so results are bit-identical to the CPU
+// oracle: this file must be compiled with -ffp-contract=off (no FMA contraction) and uses
+// IEEE division.
+//
+// Reference: SSD300.py:323-343 (_get_abbox), :345-453 (_compute_one_image_loss),
+// :157-190 (inference branch); tf.image.non_max_suppression == NonMaxSuppressionV3 (TF 1.13).
+#include "common.h"
+#include <math.h>
+
+namespace odtk {
+namespace {
+
+// ------------------------------------------------------------------ priors
+constexpr int MAX_LEVELS = 8, MAX_NA = 8;
+struct PriorArgs {
+    int nlevels, input_size, total;
+    int fsize[MAX_LEVELS], na[MAX_LEVELS], off[MAX_LEVELS + 1];
+    float hw[MAX_LEVELS][MAX_NA][2];
+};
+
+__global__ void priors_kernel(const PriorArgs p, float* __restrict__ y1x1, float* __restrict__ y2x2,
+                              float* __restrict__ yx, float* __restrict__ hw, float* __restrict__ nmsbox) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= p.total) return;
+    int l = 0;
+    while (l + 1 < p.nlevels && a >= p.off[l + 1]) ++l;
+    const int local = a - p.off[l];
+    const int f = p.fsize[l], na = p.na[l];
+    const int cell = local / na, an = local - cell * na;
+    const int iy = cell / f, ix = cell - iy * f;
+    const float isz = (float)p.input_size, ff = (float)f;
+    const float cy = (((float)iy + 0.5f) * isz) / ff;
+    const float cx = (((float)ix + 0.5f) * isz) / ff;
+    const float ph = p.hw[l][an][0], pw = p.hw[l][an][1];
+    const float y1 = cy - ph / 2.f, x1 = cx - pw / 2.f;
+    const float y2 = cy + ph / 2.f, x2 = cx + pw / 2.f;
+    const float yc = y1 / 2.f + y2 / 2.f, xc = x1 / 2.f + x2 / 2.f;   // SSD300.py:341
+    const float h = y2 - y1, w = x2 - x1;                            // SSD300.py:342
+    y1x1[2 * a] = y1; y1x1[2 * a + 1] = x1;
+    y2x2[2 * a] = y2; y2x2[2 * a + 1] = x2;
+    yx[2 * a] = yc; yx[2 * a + 1] = xc;
+    hw[2 * a] = h; hw[2 * a + 1] = w;
+    if (nmsbox) {                                                    // SSD300.py:421
+        nmsbox[4 * a + 0] = yc - h / 2.f; nmsbox[4 * a + 1] = xc - w / 2.f;
+        nmsbox[4 * a + 2] = yc + h / 2.f; nmsbox[4 * a + 3] = xc + w / 2.f;
+    }
+}
+
+// ------------------------------------------------------------------ matching
+constexpr int MATCH_THREADS = 1024;
+constexpr int MAX_GT = 128;
+constexpr int MAX_ANCH = 16384;
+
+struct GtBox { float y1, x1, y2, x2, area; };
+
+__device__ __forceinline__ float iou_ga(const GtBox& g, float ay1, float ax1, float ay2, float ax2, float aarea) {
+    const float iy1 = fmaxf(ay1, g.y1), ix1 = fmaxf(ax1, g.x1);
+    const float iy2 = fminf(ay2, g.y2), ix2 = fminf(ax2, g.x2);
+    const float ih = fmaxf(iy2 - iy1, 0.f), iw = fmaxf(ix2 - ix1, 0.f);
+    const float inter = ih * iw;
+    return inter / (aarea + g.area - inter);
+}
+
+// arg-max with first-occurrence tie rule, block wide
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float v2, int i2) {
+    if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+__device__ __forceinline__ void argmin_combine(float& v, int& i, float v2, int i2) {
+    if (v2 < v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+
+__global__ void __launch_bounds__(MATCH_THREADS) ssd_match_kernel(
+    const float* __restrict__ y1x1, const float* __restrict__ y2x2, const float* __restrict__ hw, int A,
+    const float* __restrict__ gt, int P, int* __restrict__ ngt, int* __restrict__ best,
+    unsigned char* __restrict__ status, int* __restrict__ rgindex, int* __restrict__ counts) {
+    __shared__ GtBox s_g[MAX_GT];
+    __shared__ int s_best[MAX_GT];
+    __shared__ unsigned char s_isbest[MAX_ANCH];
+    __shared__ float s_rv[MATCH_THREADS / 64];
+    __shared__ int s_ri[MATCH_THREADS / 64];
+    __shared__ int s_cnt[2];
+    __shared__ int s_G;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* g = gt + (size_t)n * P * 5;
+
+    // step 1: G = first index of the minimum of column 0 (SSD300.py:347)
+    if (wave == 0) {
+        float v = INFINITY; int idx = 0x7fffffff;
+        for (int p = lane; p < P; p += 64) argmin_combine(v, idx, g[p * 5], p);
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(v, o); const int i2 = __shfl_xor(idx, o);
+            argmin_combine(v, idx, v2, i2);
+        }
+        if (lane == 0) s_G = idx;
+    }
+    if (tid < 2) s_cnt[tid] = 0;
+    for (int a = tid; a < A; a += MATCH_THREADS) s_isbest[a] = 0;
+    __syncthreads();
+    const int G = s_G;
+    if (tid < G) {
+        const float yc = g[tid * 5 + 0], xc = g[tid * 5 + 1], h = g[tid * 5 + 2], w = g[tid * 5 + 3];
+        GtBox b;
+        b.y1 = yc - h / 2.f; b.x1 = xc - w / 2.f;
+        b.y2 = yc + h / 2.f; b.x2 = xc + w / 2.f;
+        b.area = h * w;
+        s_g[tid] = b;
+    }
+    __syncthreads();
+
+    // step 2: per GT arg-max over anchors (first max) -- SSD300.py:378
+    for (int gi = 0; gi < G; ++gi) {
+        const GtBox gb = s_g[gi];
+        float bv = -1.f; int bi = 0x7fffffff;
+        for (int a = tid; a < A; a += MATCH_THREADS) {
+            const float v = iou_ga(gb, y1x1[2 * a], y1x1[2 * a + 1], y2x2[2 * a], y2x2[2 * a + 1],
+                                   hw[2 * a] * hw[2 * a + 1]);
+            if (v > bv) { bv = v; bi = a; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o); const int i2 = __shfl_xor(bi, o);
+            argmax_combine(bv, bi, v2, i2);
+        }
+        if (lane == 0) { s_rv[wave] = bv; s_ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = s_rv[0]; int i = s_ri[0];
+            for (int w2 = 1; w2 < MATCH_THREADS / 64; ++w2) argmax_combine(v, i, s_rv[w2], s_ri[w2]);
+            if (i == 0x7fffffff) i = 0;
+            s_best[gi] = i;
+            best[(size_t)n * P + gi] = i;
+            s_isbest[i] = 1;
+        }
+        __syncthreads();
+    }
+    for (int p = G + tid; p < P; p += MATCH_THREADS) best[(size_t)n * P + p] = -1;
+
+    // steps 5-6: every other anchor: max / arg-max over GT, positive iff > 0.5 (strict)
+    int npos = 0, nneg = 0;
+    for (int a = tid; a < A; a += MATCH_THREADS) {
+        unsigned char st; int r = 0;
+        if (s_isbest[a]) {
+            st = 0;
+        } else {
+            const float ay1 = y1x1[2 * a], ax1 = y1x1[2 * a + 1], ay2 = y2x2[2 * a], ax2 = y2x2[2 * a + 1];
+            const float aarea = hw[2 * a] * hw[2 * a + 1];
+            float m = -1.f;
+            for (int gi = 0; gi < G; ++gi) {
+                const float v = iou_ga(s_g[gi], ay1, ax1, ay2, ax2, aarea);
+                if (v > m) { m = v; r = gi; }
+            }
+            if (m > 0.5f) { st = 1; ++npos; } else { st = 2; ++nneg; }
+        }
+        status[(size_t)n * A + a] = st;
+        rgindex[(size_t)n * A + a] = r;
+    }
+    for (int o = 32; o > 0; o >>= 1) { npos += __shfl_xor(npos, o); nneg += __shfl_xor(nneg, o); }
+    if (lane == 0) { atomicAdd(&s_cnt[0], npos); atomicAdd(&s_cnt[1], nneg); }
+    __syncthreads();
+    if (tid == 0) {
+        const int num_pos = G + s_cnt[0], num_neg = s_cnt[1];
+        ngt[n] = G;
+        counts[n * 4 + 0] = num_pos;
+        counts[n * 4 + 1] = num_neg;
+        counts[n * 4 + 2] = num_neg > 3 * num_pos ? 3 * num_pos : num_neg;   // SSD300.py:426
+        counts[n * 4 + 3] = 0;
+    }
+}
+
+// ------------------------------------------------------------------ cross entropy vs constant label
+__global__ void softmax_ce_const_kernel(const float* __restrict__ pred, long long rows, int C, int ld, int label,
+                                        float* __restrict__ loss) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float* z = pred + i * ld;
+    float m = z[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[c] - m);
+    loss[i] = logf(s) - (z[label] - m);
+}
+
+// ------------------------------------------------------------------ batched NMS
+constexpr int NMS_THREADS = 1024;
+
+__device__ __forceinline__ unsigned sortable(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct NBox { float ymin, xmin, ymax, xmax; };
+
+__device__ __forceinline__ NBox norm_box(float b0, float b1, float b2, float b3) {
+    NBox r;
+    r.ymin = fminf(b0, b2); r.xmin = fminf(b1, b3);
+    r.ymax = fmaxf(b0, b2); r.xmax = fmaxf(b1, b3);
+    return r;
+}
+// NonMaxSuppressionV3 IOU(): 0 when either area <= 0
+__device__ __forceinline__ float iou_nms(const NBox& a, const NBox& b) {
+    const float area_a = (a.ymax - a.ymin) * (a.xmax - a.xmin);
+    const float area_b = (b.ymax - b.ymin) * (b.xmax - b.xmin);
+    if (area_a <= 0.f || area_b <= 0.f) return 0.f;
+    const float iymin = fmaxf(a.ymin, b.ymin), ixmin = fmaxf(a.xmin, b.xmin);
+    const float iymax = fminf(a.ymax, b.ymax), ixmax = fminf(a.xmax, b.xmax);
+    const float inter = fmaxf(iymax - iymin, 0.f) * fmaxf(ixmax - ixmin, 0.f);
+    return inter / (area_a + area_b - inter);
+}
+
+struct NmsArgs {
+    const float* boxes; long long box_stride;
+    const float* scores; long long score_bstride; int score_estride;
+    const unsigned char* valid; long long valid_bstride; int valid_estride; int valid_value;
+    int n, SZ;
+    const int* max_out_dev; int max_out_stride; int max_out_const;
+    float thr;
+    int* out_idx; int cap; int* out_cnt;
+};
+
+__global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ int s_nvalid;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int SZ = a.SZ;
+    if (tid == 0) s_nvalid = 0;
+    __syncthreads();
+    int myvalid = 0;
+    for (int i = tid; i < SZ; i += NMS_THREADS) {
+        unsigned long long key = 0ull;
+        if (i < a.n) {
+            bool ok = true;
+            if (a.valid) ok = a.valid[b * a.valid_bstride + (long long)i * a.valid_estride] == (unsigned char)a.valid_value;
+            const float s = a.scores[b * a.score_bstride + (long long)i * a.score_estride];
+            if (ok && s > -INFINITY) {           // score > lowest(); NaN excluded
+                key = ((unsigned long long)sortable(s) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+                ++myvalid;
+            }
+        }
+        keys[i] = key;
+    }
+    for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o);
+    if (lane == 0 && myvalid) atomicAdd(&s_nvalid, myvalid);
+    __syncthreads();
+    // bitonic sort, descending (score desc, index asc)
+    for (int k = 2; k <= SZ; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < SZ; i += NMS_THREADS) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = keys[i], y = keys[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int nvalid = s_nvalid;
+    // compact to 32-bit indices in the first half; second half becomes the selected-box cache
+    unsigned idxreg[16];
+    {
+        int c = 0;
+        for (int i = tid; i < SZ; i += NMS_THREADS, ++c) idxreg[c] = 0xffffffffu - (unsigned)(keys[i] & 0xffffffffull);
+    }
+    __syncthreads();
+    unsigned* sidx = reinterpret_cast<unsigned*>(smem);
+    {
+        int c = 0;
+        for (int i = tid; i < SZ; i += NMS_THREADS, ++c) sidx[i] = idxreg[c];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    NBox* selbox = reinterpret_cast<NBox*>(smem + (size_t)SZ * 4);
+    const int selcap = SZ / 4;                       // boxes that fit in the freed half
+    int mo = a.max_out_dev ? a.max_out_dev[(long long)b * a.max_out_stride] : a.max_out_const;
+    if (mo > a.cap) mo = a.cap;
+    const float* boxes = a.boxes + b * a.box_stride;
+    int* oidx = a.out_idx + (long long)b * a.cap;
+    int count = 0;
+    for (int base = 0; base < nvalid && count < mo; base += 64) {
+        const int ci = base + lane;
+        const bool has = ci < nvalid;
+        const unsigned idx = has ? sidx[ci] : 0u;
+        NBox bx = norm_box(0.f, 0.f, 0.f, 0.f);
+        if (has) {
+            const float4 raw = *reinterpret_cast<const float4*>(boxes + (size_t)idx * 4);
+            bx = norm_box(raw.x, raw.y, raw.z, raw.w);
+        }
+        bool alive = has;
+        // phase A: against everything selected so far
+        for (int s = 0; s < count; ++s) {
+            NBox sb;
+            if (s < selcap) {
+                sb = selbox[s];
+            } else {
+                const int si = __hip_atomic_load(oidx + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float4 raw = *reinterpret_cast<const float4*>(boxes + (size_t)si * 4);
+                sb = norm_box(raw.x, raw.y, raw.z, raw.w);
+            }
+            if (alive && iou_nms(bx, sb) > a.thr) alive = false;
+            if (!__any(alive)) break;
+        }
+        // phase B: resolve inside the batch, best score first
+        while (true) {
+            const unsigned long long mask = __ballot(alive);
+            if (!mask) break;
+            const int j = __ffsll((long long)mask) - 1;
+            NBox bj;
+            bj.ymin = __shfl(bx.ymin, j); bj.xmin = __shfl(bx.xmin, j);
+            bj.ymax = __shfl(bx.ymax, j); bj.xmax = __shfl(bx.xmax, j);
+            if (lane == j) {
+                __hip_atomic_store(oidx + count, (int)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (count < selcap) selbox[count] = bx;
+                alive = false;
+            }
+            ++count;
+            if (count >= mo) break;
+            if (alive && iou_nms(bx, bj) > a.thr) alive = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    if (lane == 0) a.out_cnt[b] = count;
+}
+
+// ------------------------------------------------------------------ fused loss + gradient
+constexpr int LOSS_THREADS = 256;
+constexpr int MAXC = 32;
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < LOSS_THREADS / 64; ++i) t += sm[i];
+    return t;
+}
+
+struct LossArgs {
+    const float* pred; int N, A, C, ld;
+    const float* yx; const float* hw; const float* gt; int P;
+    const int* ngt; const int* best; const unsigned char* status; const int* rgindex; const int* counts;
+    const float* negloss; const int* sel_idx; int sel_cap; const int* sel_cnt;
+    float grad_scale; float* loss_parts; float* dpred;
+};
+
+// one positive row: CE vs label, smooth-L1 on (yx, hw); adds its gradient into dpred
+__device__ __forceinline__ void positive_row(const LossArgs& a, int n, int anchor, int g, float inv_np,
+                                             float& ce_sum, float& coord_sum) {
+    const float* z = a.pred + ((size_t)n * a.A + anchor) * a.ld;
+    float* dz = a.dpred + ((size_t)n * a.A + anchor) * a.ld;
+    const float* gb = a.gt + ((size_t)n * a.P + g) * 5;
+    const int label = (int)gb[4];
+    float m = z[0];
+    for (int c = 1; c < a.C; ++c) m = fmaxf(m, z[c]);
+    float e[MAXC];
+    float s = 0.f;
+    for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - m); s += e[c]; }
+    ce_sum += logf(s) - (z[label] - m);
+    const float gsc = a.grad_scale * inv_np;
+    for (int c = 0; c < a.C; ++c) atomicAdd(dz + c, (e[c] / s - (c == label ? 1.f : 0.f)) * gsc);
+    const float ayx[2] = {a.yx[2 * anchor], a.yx[2 * anchor + 1]};
+    const float ahw[2] = {a.hw[2 * anchor], a.hw[2 * anchor + 1]};
+    float cl = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float t = (gb[k] - ayx[k]) / ahw[k];                    // SSD300.py:446
+        const float d = z[a.C + k] - t;
+        const float ad = fabsf(d);
+        cl += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+        atomicAdd(dz + a.C + k, (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * gsc);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float t = logf(gb[2 + k] / ahw[k]);                     // SSD300.py:447
+        const float d = z[a.C + 2 + k] - t;
+        const float ad = fabsf(d);
+        cl += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+        atomicAdd(dz + a.C + 2 + k, (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * gsc);
+    }
+    coord_sum += cl;
+}
+
+__global__ void __launch_bounds__(LOSS_THREADS) ssd_loss_kernel(const LossArgs a) {
+    __shared__ float sm[LOSS_THREADS / 64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int G = a.ngt[n];
+    const int num_pos = a.counts[n * 4 + 0];
+    const int nsel = a.sel_cnt[n];
+    const int bg = a.C - 1;
+    // selected negatives (SSD300.py:434)
+    float neg_sum = 0.f;
+    const float inv_ns = 1.f / (float)nsel;
+    for (int i = tid; i < nsel; i += LOSS_THREADS) {
+        const int anchor = a.sel_idx[(size_t)n * a.sel_cap + i];
+        neg_sum += a.negloss[(size_t)n * a.A + anchor];
+        const float* z = a.pred + ((size_t)n * a.A + anchor) * a.ld;
+        float* dz = a.dpred + ((size_t)n * a.A + anchor) * a.ld;
+        float m = z[0];
+        for (int c = 1; c < a.C; ++c) m = fmaxf(m, z[c]);
+        float e[MAXC];
+        float s = 0.f;
+        for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - m); s += e[c]; }
+        const float gsc = a.grad_scale * inv_ns;
+        for (int c = 0; c < a.C; ++c) atomicAdd(dz + c, (e[c] / s - (c == bg ? 1.f : 0.f)) * gsc);
+    }
+    // positives: the G best-anchor rows, then every status==1 anchor (SSD300.py:436-450)
+    float ce_sum = 0.f, coord_sum = 0.f;
+    const float inv_np = 1.f / (float)num_pos;
+    for (int g = tid; g < G; g += LOSS_THREADS)
+        positive_row(a, n, a.best[(size_t)n * a.P + g], g, inv_np, ce_sum, coord_sum);
+    for (int anchor = tid; anchor < a.A; anchor += LOSS_THREADS)
+        if (a.status[(size_t)n * a.A + anchor] == 1)
+            positive_row(a, n, anchor, a.rgindex[(size_t)n * a.A + anchor], inv_np, ce_sum, coord_sum);
+    neg_sum = block_sum(neg_sum, sm);
+    ce_sum = block_sum(ce_sum, sm);
+    coord_sum = block_sum(coord_sum, sm);
+    if (tid == 0) {
+        const float neg = neg_sum / (float)nsel;              // mean of empty -> NaN, as TF
+        const float pc = ce_sum / (float)num_pos;
+        const float co = coord_sum / (float)num_pos;
+        float* o = a.loss_parts + (size_t)n * 4;
+        o[0] = neg; o[1] = pc; o[2] = co; o[3] = neg + pc + co;
+    }
+}
+
+// ------------------------------------------------------------------ inference decode
+__global__ void ssd_decode_kernel(const float* __restrict__ pred, int A, int C, int ld, const float* __restrict__ yx,
+                                  const float* __restrict__ hw, float thr, float* __restrict__ conf,
+                                  float* __restrict__ boxes, unsigned char* __restrict__ keep,
+                                  unsigned char* __restrict__ cand) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    const float* z = pred + (size_t)a * ld;
+    float m = z[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
+    float e[MAXC];
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) { e[c] = expf(z[c] - m); s += e[c]; }
+    int arg = 0; float best = -1.f;
+    for (int c = 0; c < C; ++c) {
+        const float p = e[c] / s;
+        e[c] = p;
+        if (p > best) { best = p; arg = c; }
+    }
+    const bool kp = arg < C - 1;
+    keep[a] = kp ? 1 : 0;
+    for (int c = 0; c < C - 1; ++c) {
+        conf[(size_t)a * (C - 1) + c] = e[c];
+        cand[(size_t)a * (C - 1) + c] = (kp && e[c] >= thr) ? 1 : 0;
+    }
+    const float ah = hw[2 * a], aw = hw[2 * a + 1];
+    const float cy = z[C] * ah + yx[2 * a], cx = z[C + 1] * aw + yx[2 * a + 1];
+    const float h = ah * expf(z[C + 2]), w = aw * expf(z[C + 3]);
+    boxes[4 * a + 0] = cy - h / 2.f; boxes[4 * a + 1] = cx - w / 2.f;
+    boxes[4 * a + 2] = cy + h / 2.f; boxes[4 * a + 3] = cx + w / 2.f;
+}
+
+}  // namespace
+}  // namespace odtk
+
+using namespace odtk;
+
+extern "C" int odtk_ssd_priors(int input_size, int nlevels, const int* fsize, const int* na,
+                               const float* prior_hw, float* y1x1, float* y2x2, float* yx, float* hw,
+                               float* nmsbox, void* stream) {
+    ODTK_REQUIRE(fsize && na && prior_hw && y1x1 && y2x2 && yx && hw, "ssd_priors: null pointer");
+    ODTK_REQUIRE(nlevels > 0 && nlevels <= MAX_LEVELS, "ssd_priors: nlevels=%d out of range", nlevels);
+    PriorArgs p;
+    memset(&p, 0, sizeof(p));
+    p.nlevels = nlevels; p.input_size = input_size;
+    int off = 0, k = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        ODTK_REQUIRE(na[l] > 0 && na[l] <= MAX_NA && fsize[l] > 0, "ssd_priors: bad level %d", l);
+        p.fsize[l] = fsize[l]; p.na[l] = na[l]; p.off[l] = off;
+        for (int i = 0; i < na[l]; ++i, ++k) { p.hw[l][i][0] = prior_hw[2 * k]; p.hw[l][i][1] = prior_hw[2 * k + 1]; }
+        off += fsize[l] * fsize[l] * na[l];
+    }
+    p.off[nlevels] = off; p.total = off;
+    hipLaunchKernelGGL(priors_kernel, dim3(ceil_div(off, 256)), dim3(256), 0, (hipStream_t)stream, p, y1x1, y2x2, yx, hw,
+                       nmsbox);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_ssd_match(const float* y1x1, const float* y2x2, const float* hw, int A, const float* gt,
+                              int N, int P, int* ngt, int* best, unsigned char* status, int* rgindex,
+                              int* counts, void* stream) {
+    ODTK_REQUIRE(y1x1 && y2x2 && hw && gt && ngt && best && status && rgindex && counts, "ssd_match: null pointer");
+    ODTK_REQUIRE(A > 0 && A <= MAX_ANCH, "ssd_match: A=%d out of range (max %d)", A, MAX_ANCH);
+    ODTK_REQUIRE(P > 0 && P <= MAX_GT, "ssd_match: P=%d out of range (max %d)", P, MAX_GT);
+    ODTK_REQUIRE(N > 0, "ssd_match: N must be positive");
+    hipLaunchKernelGGL(ssd_match_kernel, dim3(N), dim3(MATCH_THREADS), 0, (hipStream_t)stream, y1x1, y2x2, hw, A, gt, P,
+                       ngt, best, status, rgindex, counts);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_softmax_ce_const(const float* pred, long long rows, int C, int ld, int label, float* loss,
+                                     void* stream) {
+    ODTK_REQUIRE(pred && loss && C > 0 && label >= 0 && label < C && ld >= C, "softmax_ce_const: bad argument");
+    hipLaunchKernelGGL(softmax_ce_const_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pred, rows, C, ld, label, loss);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_nms_batched(const float* boxes, long long box_stride, const float* scores,
+                                long long score_bstride, int score_estride, const unsigned char* valid,
+                                long long valid_bstride, int valid_estride, int valid_value, int n, int B,
+                                const int* max_out_dev, int max_out_stride, int max_out_const,
+                                float iou_threshold, int* out_idx, int cap, int* out_cnt, void* stream) {
+    ODTK_REQUIRE(boxes && scores && out_idx && out_cnt, "nms: null pointer");
+    ODTK_REQUIRE(n > 0 && n <= 16384, "nms: n=%d out of range (1..16384)", n);
+    ODTK_REQUIRE(B > 0 && cap > 0, "nms: B and cap must be positive");
+    ODTK_REQUIRE(((uintptr_t)boxes % 16) == 0 && (box_stride % 4) == 0, "nms: boxes must be 16-byte aligned");
+    NmsArgs a;
+    a.boxes = boxes; a.box_stride = box_stride;
+    a.scores = scores; a.score_bstride = score_bstride; a.score_estride = score_estride;
+    a.valid = valid; a.valid_bstride = valid_bstride; a.valid_estride = valid_estride; a.valid_value = valid_value;
+    a.n = n;
+    int SZ = 64;
+    while (SZ < n) SZ <<= 1;
+    a.SZ = SZ;
+    a.max_out_dev = max_out_dev; a.max_out_stride = max_out_stride; a.max_out_const = max_out_const;
+    a.thr = iou_threshold;
+    a.out_idx = out_idx; a.cap = cap; a.out_cnt = out_cnt;
+    const size_t lds = (size_t)SZ * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ODTK_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, (hipStream_t)stream, a);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_ssd_loss(const float* pred, int N, int A, int C, int ld, const float* yx, const float* hw,
+                             const float* gt, int P, const int* ngt, const int* best,
+                             const unsigned char* status, const int* rgindex, const int* counts,
+                             const float* negloss, const int* sel_idx, int sel_cap, const int* sel_cnt,
+                             float grad_scale, float* loss_parts, float* dpred, void* stream) {
+    ODTK_REQUIRE(pred && yx && hw && gt && ngt && best && status && rgindex && counts && negloss && sel_idx &&
+                 sel_cnt && loss_parts && dpred, "ssd_loss: null pointer");
+    ODTK_REQUIRE(C > 1 && C <= MAXC && ld >= C + 4, "ssd_loss: C=%d ld=%d unsupported", C, ld);
+    hipStream_t st = (hipStream_t)stream;
+    ODTK_CHECK_HIP(hipMemsetAsync(dpred, 0, (size_t)N * A * ld * sizeof(float), st));
+    LossArgs a;
+    a.pred = pred; a.N = N; a.A = A; a.C = C; a.ld = ld; a.yx = yx; a.hw = hw; a.gt = gt; a.P = P;
+    a.ngt = ngt; a.best = best; a.status = status; a.rgindex = rgindex; a.counts = counts;
+    a.negloss = negloss; a.sel_idx = sel_idx; a.sel_cap = sel_cap; a.sel_cnt = sel_cnt;
+    a.grad_scale = grad_scale; a.loss_parts = loss_parts; a.dpred = dpred;
+    hipLaunchKernelGGL(ssd_loss_kernel, dim3(N), dim3(LOSS_THREADS), 0, st, a);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_ssd_decode(const float* pred0, int A, int C, int ld, const float* yx, const float* hw,
+                               float score_thr, float* conf, float* boxes, unsigned char* keep,
+                               unsigned char* cand, void* stream) {
+    ODTK_REQUIRE(pred0 && yx && hw && conf && boxes && keep && cand, "ssd_decode: null pointer");
+    ODTK_REQUIRE(C > 1 && C <= MAXC && ld >= C + 4, "ssd_decode: C=%d ld=%d unsupported", C, ld);
+    hipLaunchKernelGGL(ssd_decode_kernel, dim3(ceil_div(A, 256)), dim3(256), 0, (hipStream_t)stream, pred0, A, C, ld, yx,
+                       hw, score_thr, conf, boxes, keep, cand);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

@@ -1,0 +1,607 @@
+// Implicit-GEMM convolution on CDNA4 matrix cores (gfx950 only).
+//
+// Replaces tf.nn.conv2d / tf.layers.conv2d forward (reference SSD300.py:519, :524)
+// and the Conv2DBackpropInput / Conv2DBackpropFilter ops added by
+// optimizer.minimize (SSD300.py:154).
+//
+// One kernel family, two operand dtypes:
+//   bf16 storage -> v_mfma_f32_32x32x16_bf16   (throughput path)
+//   f32  storage -> v_mfma_f32_32x32x2_f32     (exact-f32 parity path, same indexing)
+//
+// GEMM view (all three passes): D[p][q] = sum_k P[p][k] * Q[q][k]
+//   fwd / dgrad : p = output channel, q = output pixel, k = (r, s, c)    "gather" kernel
+//   wgrad       : p = output channel, q = (r, s, c),    k = pixel        "transpose" kernel
+// A workgroup (256 threads = 4 wave64, 2x2) owns a PT x 128 tile of D (PT = 64 | 128);
+// each k-step stages a PT x 128 B and a 128 x 128 B slab (k-contiguous rows) in LDS.
+// LDS rows are 128 B = eight 16-B slots; slot s of row r lives at slot s ^ swz(r), which
+// makes every ds_read_b128 lane-group of the 32x32 fragment reads conflict-free.
+// MFMA operand 1 (D rows) = channels, operand 2 (D cols) = pixels / (r,s,c): each lane then
+// owns 4 consecutive output channels of one pixel per accumulator quad -> 8/16-byte stores.
+#include "common.h"
+
+namespace odtk {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(16))) float f32x16_v;
+
+struct FastDiv {
+    unsigned mul, shift;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = s;
+    f.mul = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) {   // x < 2^31
+    return (__umulhi(x, f.mul) + x) >> f.shift;
+}
+
+__host__ __device__ __forceinline__ int swz(int row) {
+    return (((row >> 1) ^ (row >> 5)) & 1) | (((row >> 3) & 1) << 1) | (((row >> 4) & 1) << 2);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int KCH = 8;
+    static __device__ __forceinline__ void run(const uint4& p, const uint4& q, f32x16_v& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, p),
+                                                      __builtin_bit_cast(bf16x8_v, q), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KCH = 4;
+    static __device__ __forceinline__ void run(const uint4& p, const uint4& q, f32x16_v& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.x), __uint_as_float(q.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.y), __uint_as_float(q.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.z), __uint_as_float(q.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.w), __uint_as_float(q.w), acc, 0, 0, 0);
+    }
+};
+
+// One staged k-slab: 4 sub-steps of two 16-B slots (lanes 0-31 slot 2ks, lanes 32-63 slot 2ks+1).
+template <typename T, int PI, int QI>
+__device__ __forceinline__ void mma_slab(const char* sP, const char* sQ, int prow0, int qrow0,
+                                         int lane, f32x16_v (&acc)[PI][QI]) {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int slot = ks * 2 + hi;
+        uint4 pf[PI], qf[QI];
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int row = prow0 + i * 32 + l31;
+            pf[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + ((slot ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < QI; ++j) {
+            const int row = qrow0 + j * 32 + l31;
+            qf[j] = *reinterpret_cast<const uint4*>(sQ + row * 128 + ((slot ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < PI; ++i)
+#pragma unroll
+            for (int j = 0; j < QI; ++j) Mma<T>::run(pf[i], qf[j], acc[i][j]);
+    }
+}
+
+// XCD-aware bijective remap of the linear block id (block b runs on XCD b % 8): every XCD gets
+// a contiguous range of tiles so neighbouring tiles share their operand panels in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// ---------------------------------------------------------------------------------------
+// gather kernel: forward conv and dgrad
+// ---------------------------------------------------------------------------------------
+struct GatherArgs {
+    const char* x;     // activations gathered along k  [N][H][W][ldx]
+    const char* w;     // filter rows [K][R*S*C]
+    const float* bias; // [K] or null
+    const char* mask;  // relu source (same geometry as y) or null
+    char* y;
+    int N, H, W, C, ldx;
+    int Ho, Wo, K, ldy, ldmask;
+    int R, S, ostride, dil, pad_t, pad_l, idiv;
+    int M, Kdim, ldw;
+    int relu, accumulate;
+    int tiles_p, tiles_q;
+};
+
+template <typename T, typename TO, int PT>
+__global__ void __launch_bounds__(256) conv_gather_kernel(const GatherArgs a) {
+    constexpr int KCH = Mma<T>::KCH;
+    constexpr int BKE = 8 * KCH;
+    constexpr int PI = PT / 64, QI = 2, PL = PT / 32;
+    __shared__ __attribute__((aligned(16))) char smem[(PT + 128) * 128];
+    char* sP = smem;
+    char* sQ = smem + PT * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave & 1, wq = wave >> 1;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
+    const int p0 = tp * PT, q0 = tq * 128;
+
+    const int cc = tid & 7, r0 = tid >> 3;
+    int hb[4], wb[4], nb[4];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = q0 + r0 + 32 * i;
+        if (m < a.M) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            hb[i] = ho * a.ostride - a.pad_t;
+            wb[i] = wo * a.ostride - a.pad_l;
+            nb[i] = n * a.H;
+        } else {
+            hb[i] = -(1 << 28); wb[i] = 0; nb[i] = 0;
+        }
+    }
+    int klin = cc * KCH;
+    int kc, ks, kr;
+    {
+        const int rs = klin / a.C;
+        kc = klin - rs * a.C;
+        kr = rs / a.S;
+        ks = rs - kr * a.S;
+    }
+    uint4 rq[4], rp[PL];
+
+    auto load_tile = [&]() {
+        const bool kv = kr < a.R;
+        const int dh = kr * a.dil, dw = ks * a.dil;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hn = hb[i] + dh, wn = wb[i] + dw;
+            int hi, wi;
+            bool ok;
+            if (a.idiv == 1) {
+                hi = hn; wi = wn;
+                ok = kv && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            } else {
+                ok = kv && hn >= 0 && wn >= 0 && (hn % a.idiv) == 0 && (wn % a.idiv) == 0;
+                hi = hn / a.idiv; wi = wn / a.idiv;
+                ok = ok && hi < a.H && wi < a.W;
+            }
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const size_t off = ((size_t)((nb[i] + hi) * a.W + wi) * a.ldx + kc) * sizeof(T);
+                v = *reinterpret_cast<const uint4*>(a.x + off);
+            }
+            rq[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const int row = p0 + r0 + 32 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kv && row < a.K)
+                v = *reinterpret_cast<const uint4*>(a.w + ((size_t)row * a.ldw + klin) * sizeof(T));
+            rp[i] = v;
+        }
+        klin += BKE;
+        kc += BKE;
+        while (kc >= a.C) {
+            kc -= a.C;
+            if (++ks == a.S) { ks = 0; ++kr; }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 32 * i;
+            *reinterpret_cast<uint4*>(sQ + row * 128 + ((cc ^ swz(row)) << 4)) = rq[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const int row = r0 + 32 * i;
+            *reinterpret_cast<uint4*>(sP + row * 128 + ((cc ^ swz(row)) << 4)) = rp[i];
+        }
+    };
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (a.Kdim + BKE - 1) / BKE;
+    load_tile();
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) load_tile();
+        mma_slab<T, PI, QI>(sP, sQ, wp * (PT / 2), wq * 64, lane, acc);
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane (l31, hi) owns pixel q, channels base + 8*g + 4*hi + {0..3}
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int m = q0 + wq * 64 + j * 32 + l31;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = p0 + wp * (PT / 2) + i * 32 + 8 * g + 4 * hi;
+                if (c >= a.K) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                const bool full = (c + 3 < a.K);
+                TO* yp = reinterpret_cast<TO*>(a.y) + (size_t)m * a.ldy + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!full && c + e >= a.K) continue;
+                    float t = v[e];
+                    if (a.bias) t += a.bias[c + e];
+                    if (a.accumulate) t += elem<TO>::load(yp[e]);
+                    if (a.relu) t = fmaxf(t, 0.f);
+                    if (a.mask) {
+                        const T mv = reinterpret_cast<const T*>(a.mask)[(size_t)m * a.ldmask + c + e];
+                        if (!(elem<T>::load(mv) > 0.f)) t = 0.f;
+                    }
+                    v[e] = t;
+                }
+                if (full) {
+                    if (sizeof(TO) == 2) {
+                        uint2 o;
+                        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(yp) = o;
+                    } else {
+                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < a.K) yp[e] = elem<TO>::store(v[e]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// transpose kernel: wgrad.  k = pixel; both operands are read pixel-major from HBM (16-B
+// channel chunks of 4 consecutive pixels per thread) and transposed in registers on the way
+// into the k-contiguous LDS rows.
+// ---------------------------------------------------------------------------------------
+struct WgradArgs {
+    const char* x;   // fwd input [N][H][W][ldx]
+    const char* dy;  // [P][lddy]
+    float* dw;       // [K][RSC]
+    int N, H, W, C, ldx;
+    int Ho, Wo, K, lddy;
+    int R, S, stride, dil, pad_t, pad_l;
+    int P, RSC;
+    int tiles_p, tiles_q, iters_per_split;
+    FastDiv div_howo, div_wo;
+};
+
+template <typename T, int PT>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int KCH = Mma<T>::KCH;          // channels per 16-B chunk
+    constexpr int PKE = 8 * KCH;              // pixels per k-slab (128-B LDS row)
+    constexpr int NCC = 128 / KCH;            // chunks across a 128-row operand tile
+    constexpr int PI = PT / 64, QI = 2;
+    __shared__ __attribute__((aligned(16))) char smem[(PT + 128) * 128];
+    char* sP = smem;
+    char* sQ = smem + PT * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave & 1, wq = wave >> 1;
+    const int tile = blockIdx.x;
+    const int tq = tile / a.tiles_p, tp = tile - tq * a.tiles_p;
+    const int p0 = tp * PT, q0 = tq * 128;
+    const int split = blockIdx.y;
+
+    const int cc = tid % NCC, pg = tid / NCC;
+    // P operand (dy): channel chunk cc of the PT-row tile (threads with cc*KCH >= PT idle)
+    const int pch = p0 + cc * KCH;
+    const bool p_active = (cc * KCH < PT) && (pch < a.lddy);
+    // Q operand (x gathered): column j0 = q0 + cc*KCH -> fixed (r, s, c0)
+    const int j0 = q0 + cc * KCH;
+    const bool q_active = j0 < a.RSC;
+    int qr = 0, qs = 0, qc = 0;
+    if (q_active) {
+        const int rs = j0 / a.C;
+        qc = j0 - rs * a.C;
+        qr = rs / a.S;
+        qs = rs - qr * a.S;
+    }
+    const int dh = qr * a.dil - a.pad_t, dw_ = qs * a.dil - a.pad_l;
+
+    const int it0 = split * a.iters_per_split;
+    int it1 = it0 + a.iters_per_split;
+    const int iters_total = (a.P + PKE - 1) / PKE;
+    if (it1 > iters_total) it1 = iters_total;
+
+    uint4 vp[4], vq[4];
+    auto load_tile = [&](int it) {
+        const int pb = it * PKE + 4 * pg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = pb + i;
+            uint4 u = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);
+            if (p < a.P) {
+                if (p_active)
+                    u = *reinterpret_cast<const uint4*>(a.dy + ((size_t)p * a.lddy + pch) * sizeof(T));
+                if (q_active) {
+                    const unsigned n = fdiv((unsigned)p, a.div_howo);
+                    const unsigned rem = (unsigned)p - n * (unsigned)(a.Ho * a.Wo);
+                    const unsigned ho = fdiv(rem, a.div_wo);
+                    const unsigned wo = rem - ho * (unsigned)a.Wo;
+                    const int hi = (int)ho * a.stride + dh, wi = (int)wo * a.stride + dw_;
+                    if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
+                        const size_t off = ((size_t)(((int)n * a.H + hi) * a.W + wi) * a.ldx + qc) * sizeof(T);
+                        v = *reinterpret_cast<const uint4*>(a.x + off);
+                    }
+                }
+            }
+            vp[i] = u;
+            vq[i] = v;
+        }
+    };
+    // 4 pixels x KCH channels -> KCH rows of 4 pixels
+    auto store_op = [&](char* s, const uint4 (&v)[4], int rows_valid) {
+        if (sizeof(T) == 2) {
+            const unsigned* d0 = reinterpret_cast<const unsigned*>(&v[0]);
+            const unsigned* d1 = reinterpret_cast<const unsigned*>(&v[1]);
+            const unsigned* d2 = reinterpret_cast<const unsigned*>(&v[2]);
+            const unsigned* d3 = reinterpret_cast<const unsigned*>(&v[3]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = cc * 8 + j;
+                if (row >= rows_valid) break;
+                const int h = j >> 1;
+                uint2 o;
+                if ((j & 1) == 0) {
+                    o.x = (d0[h] & 0xffffu) | (d1[h] << 16);
+                    o.y = (d2[h] & 0xffffu) | (d3[h] << 16);
+                } else {
+                    o.x = (d0[h] >> 16) | (d1[h] & 0xffff0000u);
+                    o.y = (d2[h] >> 16) | (d3[h] & 0xffff0000u);
+                }
+                *reinterpret_cast<uint2*>(s + row * 128 + (((pg >> 1) ^ swz(row)) << 4) + ((pg & 1) << 3)) = o;
+            }
+        } else {
+            const unsigned* d0 = reinterpret_cast<const unsigned*>(&v[0]);
+            const unsigned* d1 = reinterpret_cast<const unsigned*>(&v[1]);
+            const unsigned* d2 = reinterpret_cast<const unsigned*>(&v[2]);
+            const unsigned* d3 = reinterpret_cast<const unsigned*>(&v[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = cc * 4 + j;
+                if (row >= rows_valid) break;
+                *reinterpret_cast<uint4*>(s + row * 128 + ((pg ^ swz(row)) << 4)) =
+                    make_uint4(d0[j], d1[j], d2[j], d3[j]);
+            }
+        }
+    };
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (it0 < it1) {
+        load_tile(it0);
+        store_op(sP, vp, PT);
+        store_op(sQ, vq, 128);
+        __syncthreads();
+        for (int it = it0; it < it1; ++it) {
+            const bool more = it + 1 < it1;
+            if (more) load_tile(it + 1);
+            mma_slab<T, PI, QI>(sP, sQ, wp * (PT / 2), wq * 64, lane, acc);
+            __syncthreads();
+            if (more) {
+                store_op(sP, vp, PT);
+                store_op(sQ, vq, 128);
+                __syncthreads();
+            }
+        }
+    }
+
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int col = q0 + wq * 64 + j * 32 + l31;
+        if (col >= a.RSC) continue;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = p0 + wp * (PT / 2) + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// filter preparation: f32 master [K][RS][C] -> cast copy and flipped/transposed dgrad copy
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void filter_prepare_kernel(const float* __restrict__ w, int K, int RS, int C, int Kp,
+                                      T* __restrict__ wc, T* __restrict__ wt) {
+    // grid: x over (rs, c-tiles), y over k-tiles ; 32x32 tile transpose through LDS
+    __shared__ float tile[32][33];
+    const int ctiles = (C + 31) / 32;
+    const int rs = blockIdx.x / ctiles, ct = blockIdx.x - rs * ctiles;
+    const int c0 = ct * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (k < K && c < C) {
+            v = w[((size_t)k * RS + rs) * C + c];
+            if (wc) wc[((size_t)k * RS + rs) * C + c] = elem<T>::store(v);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    if (wt) {
+        const int rsf = RS - 1 - rs;   // flip both taps: (R-1-r)*S + (S-1-s) = RS-1-(r*S+s)
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, k = k0 + tx;
+            if (c < C && k < Kp) wt[((size_t)c * RS + rsf) * Kp + k] = elem<T>::store(k < K ? tile[tx][i] : 0.f);
+        }
+    }
+}
+
+template <typename T, typename TO>
+int launch_gather(const GatherArgs& a, int PT, hipStream_t st) {
+    const int grid = a.tiles_p * a.tiles_q;
+    if (PT == 64)
+        hipLaunchKernelGGL((conv_gather_kernel<T, TO, 64>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_gather_kernel<T, TO, 128>), dim3(grid), dim3(256), 0, st, a);
+    return 0;
+}
+
+int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
+    const int PT = a.K <= 64 ? 64 : 128;
+    a.tiles_p = ceil_div(a.K, PT);
+    a.tiles_q = ceil_div(a.M, 128);
+    if (dtype == ODTK_BF16 && out_dtype == ODTK_BF16) launch_gather<bf16_t, bf16_t>(a, PT, st);
+    else if (dtype == ODTK_BF16 && out_dtype == ODTK_F32) launch_gather<bf16_t, float>(a, PT, st);
+    else if (dtype == ODTK_F32 && out_dtype == ODTK_F32) launch_gather<float, float>(a, PT, st);
+    else {
+        set_error("conv: unsupported dtype combination in=%d out=%d", dtype, out_dtype);
+        return ODTK_ERR_ARG;
+    }
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+int check_desc(const odtk_conv_desc* d) {
+    ODTK_REQUIRE(d != nullptr, "conv: null descriptor");
+    ODTK_REQUIRE(d->dtype == ODTK_BF16 || d->dtype == ODTK_F32, "conv: bad dtype %d", d->dtype);
+    const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(d->C % kch == 0 && d->ldx % kch == 0 && d->ldx >= d->C,
+                 "conv: C=%d / ldx=%d must be multiples of %d", d->C, d->ldx, kch);
+    ODTK_REQUIRE(d->ldy % 4 == 0 && d->ldy >= d->K, "conv: ldy=%d must be a multiple of 4 and >= K=%d", d->ldy, d->K);
+    ODTK_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0 && d->R > 0 && d->S > 0 &&
+                 d->stride > 0 && d->dil > 0, "conv: non-positive dimension");
+    ODTK_REQUIRE((long long)d->N * d->H * d->W < (1ll << 31) && (long long)d->N * d->Ho * d->Wo < (1ll << 31),
+                 "conv: too many pixels");
+    return ODTK_OK;
+}
+
+}  // namespace
+}  // namespace odtk
+
+using namespace odtk;
+
+extern "C" int odtk_conv2d_fwd(const odtk_conv_desc* d, const void* x, const void* w, const float* bias,
+                               void* y, int relu, void* stream) {
+    if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const char*)x; a.w = (const char*)w; a.bias = bias; a.mask = nullptr; a.y = (char*)y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.K = d->K; a.ldy = d->ldy; a.ldmask = 0;
+    a.R = d->R; a.S = d->S; a.ostride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+    a.idiv = 1;
+    a.M = d->N * d->Ho * d->Wo; a.Kdim = d->R * d->S * d->C; a.ldw = a.Kdim;
+    a.relu = relu; a.accumulate = 0;
+    return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t,
+                                 const void* relu_src, void* dx, int accumulate, void* stream) {
+    if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(dy && w_t && dx, "conv2d_dgrad: null pointer");
+    const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(lddy % kch == 0 && lddy >= d->K, "conv2d_dgrad: lddy=%d must be a multiple of %d", lddy, kch);
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    // the "input" of this conv is dy [N][Ho][Wo][lddy], its "output" is dx [N][H][W][C]
+    a.x = (const char*)dy; a.w = (const char*)w_t; a.bias = nullptr; a.mask = (const char*)relu_src; a.y = (char*)dx;
+    a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.C = lddy; a.ldx = lddy;
+    a.Ho = d->H; a.Wo = d->W; a.K = d->C; a.ldy = d->ldx; a.ldmask = d->ldx;
+    a.R = d->R; a.S = d->S; a.ostride = 1; a.dil = d->dil;
+    a.pad_t = (d->R - 1) * d->dil - d->pad_t;
+    a.pad_l = (d->S - 1) * d->dil - d->pad_l;
+    a.idiv = d->stride;
+    a.M = d->N * d->H * d->W; a.Kdim = d->R * d->S * lddy; a.ldw = a.Kdim;
+    a.relu = 0; a.accumulate = accumulate;
+    return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy,
+                                 float* dw, void* stream) {
+    if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+    const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(lddy % kch == 0 && lddy >= d->K, "conv2d_wgrad: lddy=%d must be a multiple of %d", lddy, kch);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const char*)x; a.dy = (const char*)dy; a.dw = dw;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.K = d->K; a.lddy = lddy;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+    a.P = d->N * d->Ho * d->Wo; a.RSC = d->R * d->S * d->C;
+    const int PT = d->K <= 64 ? 64 : 128;
+    a.tiles_p = ceil_div(d->K, PT);
+    a.tiles_q = ceil_div(a.RSC, 128);
+    const int pke = 8 * kch;
+    const int iters_total = ceil_div(a.P, pke);
+    const int tiles = a.tiles_p * a.tiles_q;
+    int splits = 1024 / tiles;
+    if (splits < 1) splits = 1;
+    int max_splits = iters_total / 8;
+    if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    a.iters_per_split = ceil_div(iters_total, splits);
+    splits = ceil_div(iters_total, a.iters_per_split);
+    a.div_howo = make_fastdiv((unsigned)(d->Ho * d->Wo));
+    a.div_wo = make_fastdiv((unsigned)d->Wo);
+    dim3 grid(tiles, splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == ODTK_BF16) {
+        if (PT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128>), grid, dim3(256), 0, st, a);
+    } else {
+        if (PT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<float, 64>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<float, 128>), grid, dim3(256), 0, st, a);
+    }
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_filter_prepare(const float* w, int K, int R, int S, int C, int Kp, int dtype,
+                                   void* w_c, void* w_t, void* stream) {
+    ODTK_REQUIRE(w && (w_c || w_t), "filter_prepare: null pointer");
+    ODTK_REQUIRE(Kp >= K, "filter_prepare: Kp < K");
+    const int RS = R * S;
+    const int kmax = w_t ? Kp : K;
+    dim3 grid(RS * ceil_div(C, 32), ceil_div(kmax, 32));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ODTK_BF16)
+        hipLaunchKernelGGL(filter_prepare_kernel<bf16_t>, grid, dim3(256), 0, st, w, K, RS, C, Kp, (bf16_t*)w_c, (bf16_t*)w_t);
+    else if (dtype == ODTK_F32)
+        hipLaunchKernelGGL(filter_prepare_kernel<float>, grid, dim3(256), 0, st, w, K, RS, C, Kp, (float*)w_c, (float*)w_t);
+    else ODTK_REQUIRE(false, "filter_prepare: bad dtype %d", dtype);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

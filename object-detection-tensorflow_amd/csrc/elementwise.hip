@@ -1,0 +1,812 @@
+// HBM-bound layers of the SSD300 path (gfx950): preprocess, max-pool, batch-norm, L2-norm,
+// bias-gradient column sums, fused SGD-momentum.  All NHWC "rows x pitch"; every thread moves
+// 16-byte channel chunks (8 bf16 / 4 f32), lanes run along channels so a wave reads whole lines.
+//
+// Reference call sites: SSD300.py:52-63 (mean subtraction), :539-547 (max_pooling2d SAME),
+// :506-512 (batch_normalization), :74-83 (l2_normalize * scalar), :149-154 (MomentumOptimizer
+// + l2_loss over all trainables).
+#include "common.h"
+
+namespace odtk {
+namespace {
+
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const uint4& v, float (&f)[8]) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&f)[8]) {
+        uint4 v;
+        v.x = (unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16);
+        v.y = (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16);
+        v.z = (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16);
+        v.w = (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16);
+        return v;
+    }
+};
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(const uint4& v, float (&f)[4]) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&f)[4]) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+template <typename T>
+__device__ __forceinline__ void st16(T* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// ------------------------------------------------------------------ preprocess
+template <typename T>
+__global__ void preprocess_kernel(const float* __restrict__ img, long long pixels, float m0, float m1,
+                                  float m2, int ldx, T* __restrict__ x) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < pixels; i += step) {
+        const float r = img[i * 3 + 0] - m0, g = img[i * 3 + 1] - m1, b = img[i * 3 + 2] - m2;
+        T* o = x + i * ldx;
+        o[0] = elem<T>::store(r); o[1] = elem<T>::store(g); o[2] = elem<T>::store(b);
+        for (int c = 3; c < ldx; ++c) o[c] = elem<T>::store(0.f);
+    }
+}
+
+// ------------------------------------------------------------------ max pool
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
+                                   int ld, int Ho, int Wo, int k, int stride, int pad_t, int pad_l) {
+    constexpr int KC = Chunk<T>::N;
+    const int chunks = C / KC;
+    const long long total = (long long)N * Ho * Wo * chunks;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        const int ch = (int)(i % chunks);
+        long long pix = i / chunks;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float best[KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) best[e] = -INFINITY;
+        for (int r = 0; r < k; ++r) {
+            const int h = ho * stride - pad_t + r;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int s = 0; s < k; ++s) {
+                const int w = wo * stride - pad_l + s;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float f[KC];
+                Chunk<T>::unpack(ld16(x + ((size_t)(n * H + h) * W + w) * ld + ch * KC), f);
+#pragma unroll
+                for (int e = 0; e < KC; ++e) best[e] = f[e] > best[e] ? f[e] : best[e];
+            }
+        }
+        st16(y + ((size_t)(n * Ho + ho) * Wo + wo) * ld + ch * KC, Chunk<T>::pack(best));
+    }
+}
+
+// gather formulation: (h,w) receives dy of window (ho,wo) iff it is the FIRST position of that
+// window (row-major scan) whose value equals the window max.
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                   T* __restrict__ dx, int N, int H, int W, int C, int ld, int Ho, int Wo,
+                                   int k, int stride, int pad_t, int pad_l) {
+    constexpr int KC = Chunk<T>::N;
+    const int chunks = C / KC;
+    const long long total = (long long)N * H * W * chunks;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        const int ch = (int)(i % chunks);
+        long long pix = i / chunks;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const int n = (int)(pix / H);
+        float xv[KC], g[KC];
+        Chunk<T>::unpack(ld16(x + ((size_t)(n * H + h) * W + w) * ld + ch * KC), xv);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) g[e] = 0.f;
+        // windows containing (h, w): ho*stride - pad_t <= h <= ho*stride - pad_t + k - 1
+        int ho_lo = (h + pad_t - k + 1 + stride - 1);
+        ho_lo = ho_lo < 0 ? 0 : ho_lo / stride;
+        int ho_hi = (h + pad_t) / stride; if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+        int wo_lo = (w + pad_l - k + 1 + stride - 1);
+        wo_lo = wo_lo < 0 ? 0 : wo_lo / stride;
+        int wo_hi = (w + pad_l) / stride; if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const size_t oo = ((size_t)(n * Ho + ho) * Wo + wo) * ld + ch * KC;
+                float yv[KC], dv[KC];
+                Chunk<T>::unpack(ld16(y + oo), yv);
+                Chunk<T>::unpack(ld16(dy + oo), dv);
+                bool first[KC];
+#pragma unroll
+                for (int e = 0; e < KC; ++e) first[e] = (xv[e] == yv[e]);
+                const int h0 = ho * stride - pad_t, w0 = wo * stride - pad_l;
+                for (int r = 0; r < k; ++r) {
+                    const int hh = h0 + r;
+                    if (hh > h) break;
+                    if ((unsigned)hh >= (unsigned)H) continue;
+                    for (int s = 0; s < k; ++s) {
+                        const int ww = w0 + s;
+                        if (hh == h && ww >= w) break;
+                        if ((unsigned)ww >= (unsigned)W) continue;
+                        float f[KC];
+                        Chunk<T>::unpack(ld16(x + ((size_t)(n * H + hh) * W + ww) * ld + ch * KC), f);
+#pragma unroll
+                        for (int e = 0; e < KC; ++e) first[e] = first[e] && (f[e] != yv[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < KC; ++e) g[e] += first[e] ? dv[e] : 0.f;
+            }
+        }
+        st16(dx + ((size_t)(n * H + h) * W + w) * ld + ch * KC, Chunk<T>::pack(g));
+    }
+}
+
+// ------------------------------------------------------------------ column reductions
+// Block = 32 row-lanes x 8 chunk-lanes; grid (column groups of 8 chunks, row splits).
+// Deterministic: partials to ws[slot][split][C], reduced in a fixed order by the consumer.
+constexpr int RED_ROWS = 32;
+
+template <int NV>
+__device__ __forceinline__ void block_rowlane_reduce(float (&v)[NV], float* sm /*[32][8][NV]*/, int rl, int cl) {
+    // sm layout [rl][cl][NV]
+#pragma unroll
+    for (int e = 0; e < NV; ++e) sm[(rl * 8 + cl) * NV + e] = v[e];
+    __syncthreads();
+    for (int s = RED_ROWS / 2; s > 0; s >>= 1) {
+        if (rl < s) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) sm[(rl * 8 + cl) * NV + e] += sm[((rl + s) * 8 + cl) * NV + e];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = sm[cl * NV + e];
+    __syncthreads();
+}
+
+// BN stats: sum(z - shift), sum((z - shift)^2), shift = z[0][c]
+template <typename T>
+__global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ z, int M, int C, int ldz,
+                                                       int rows_per_split, float* __restrict__ ws) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    float acc[2 * KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        float sh[KC];
+        Chunk<T>::unpack(ld16(z + c0), sh);
+        const int m0 = split * rows_per_split;
+        int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
+        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                const float d = f[e] - sh[e];
+                acc[e] += d;
+                acc[KC + e] += d * d;
+            }
+        }
+    }
+    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    if (rl == 0 && c0 < C) {
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            if (c0 + e < C) {
+                ws[((size_t)0 * nsplit + split) * C + c0 + e] = acc[e];
+                ws[((size_t)1 * nsplit + split) * C + c0 + e] = acc[KC + e];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ long long out_off(int m, int rows_per_img, long long img_stride, int ld) {
+    const int n = m / rows_per_img;
+    return (long long)n * img_stride + (long long)(m - n * rows_per_img) * ld;
+}
+
+template <typename T, typename TY>
+__global__ void __launch_bounds__(256) bn_apply_kernel(
+    const T* __restrict__ z, int M, int C, int ldz, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd, int training, int relu, TY* __restrict__ y, int ldy, int rows_per_img,
+    long long y_img_stride, int vec_ok, const float* __restrict__ ws, int nsplit, int rows_per_block) {
+    constexpr int KC = Chunk<T>::N;
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    if (c0 >= C) return;
+    float sc[KC], of[KC];
+    {
+        float sh[KC];
+        Chunk<T>::unpack(ld16(z + c0), sh);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            const int c = c0 + e;
+            float mean = 0.f, var = 1.f, g = 1.f, b = 0.f;
+            if (c < C) {
+                g = gamma[c]; b = beta[c];
+                if (training) {
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int s = 0; s < nsplit; ++s) {
+                        s1 += ws[((size_t)0 * nsplit + s) * C + c];
+                        s2 += ws[((size_t)1 * nsplit + s) * C + c];
+                    }
+                    const float d = s1 / (float)M;
+                    mean = sh[e] + d;
+                    var = fmaxf(s2 / (float)M - d * d, 0.f);
+                    if (blockIdx.y == 0 && rl == 0) {
+                        save_mean[c] = mean;
+                        save_invstd[c] = rsqrtf(var + 1e-3f);
+                        const float unb = var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+                        mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
+                        mvar[c] = mvar[c] * 0.99f + unb * (1.f - 0.99f);
+                    }
+                } else {
+                    mean = mmean[c]; var = mvar[c];
+                }
+            }
+            const float inv = rsqrtf(var + 1e-3f);
+            sc[e] = inv * g;
+            of[e] = b - mean * sc[e];
+        }
+    }
+    const int m0 = blockIdx.y * rows_per_block;
+    int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+    const bool full = c0 + KC <= C;
+    for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+        float f[KC];
+        Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            f[e] = f[e] * sc[e] + of[e];
+            if (relu) f[e] = fmaxf(f[e], 0.f);
+        }
+        TY* yp = y + out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+        if (full && vec_ok) {
+            if (sizeof(TY) == 2) {
+                float f8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f8[e] = f[e % KC];
+                st16(reinterpret_cast<bf16_t*>(yp), Chunk<bf16_t>::pack(f8));   // only reached when KC == 8
+            } else {
+#pragma unroll
+                for (int q = 0; q < KC / 4; ++q)
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yp) + 4 * q) =
+                        make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < KC; ++e)
+                if (c0 + e < C) yp[e] = elem<TY>::store(f[e]);
+        }
+    }
+}
+
+// BN backward partials: sum(dy'), sum(dy' * xhat)
+template <typename T, typename TY>
+__global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
+    const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
+    int rows_per_img, long long y_img_stride, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, int relu, int rows_per_split, float* __restrict__ ws) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    float acc[2 * KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        float mu[KC], iv[KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            mu[e] = c0 + e < C ? save_mean[c0 + e] : 0.f;
+            iv[e] = c0 + e < C ? save_invstd[c0 + e] : 0.f;
+        }
+        const int m0 = split * rows_per_split;
+        int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
+        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+            const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                if (c0 + e >= C) continue;
+                float d = elem<TY>::load(dy[oo + e]);
+                if (relu && !(elem<TY>::load(y[oo + e]) > 0.f)) d = 0.f;
+                acc[e] += d;
+                acc[KC + e] += d * ((f[e] - mu[e]) * iv[e]);
+            }
+        }
+    }
+    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    if (rl == 0 && c0 < C) {
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            if (c0 + e < C) {
+                ws[((size_t)0 * nsplit + split) * C + c0 + e] = acc[e];
+                ws[((size_t)1 * nsplit + split) * C + c0 + e] = acc[KC + e];
+            }
+        }
+    }
+}
+
+template <typename T, typename TY>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
+    const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
+    int rows_per_img, long long y_img_stride, const float* __restrict__ gamma,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, T* __restrict__ dz,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ ws, int nsplit,
+    int rows_per_block) {
+    constexpr int KC = Chunk<T>::N;
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    if (c0 >= ldz) return;
+    float mu[KC], iv[KC], gs[KC], k1[KC], k2[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        const int c = c0 + e;
+        mu[e] = 0.f; iv[e] = 0.f; gs[e] = 0.f; k1[e] = 0.f; k2[e] = 0.f;
+        if (c < C) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int s = 0; s < nsplit; ++s) {
+                s1 += ws[((size_t)0 * nsplit + s) * C + c];
+                s2 += ws[((size_t)1 * nsplit + s) * C + c];
+            }
+            mu[e] = save_mean[c]; iv[e] = save_invstd[c];
+            gs[e] = gamma[c] * iv[e];
+            k1[e] = s1 / (float)M;
+            k2[e] = s2 / (float)M;
+            if (blockIdx.y == 0 && rl == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+        }
+    }
+    const int m0 = blockIdx.y * rows_per_block;
+    int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+    for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+        float f[KC], o[KC];
+        Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+        const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            o[e] = 0.f;
+            if (c0 + e >= C) continue;
+            float d = elem<TY>::load(dy[oo + e]);
+            if (relu && !(elem<TY>::load(y[oo + e]) > 0.f)) d = 0.f;
+            const float xh = (f[e] - mu[e]) * iv[e];
+            o[e] = gs[e] * (d - k1[e] - xh * k2[e]);
+        }
+        st16(dz + (size_t)m * ldz + c0, Chunk<T>::pack(o));
+    }
+}
+
+// generic column sum (bias gradient)
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int M, int C, int ld,
+                                                     int rows_per_split, float* __restrict__ ws) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    const int split = blockIdx.y;
+    float acc[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        const int m0 = split * rows_per_split;
+        int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
+        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(x + (size_t)m * ld + c0), f);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) acc[e] += f[e];
+        }
+    }
+    block_rowlane_reduce<KC>(acc, sm, rl, cl);
+    if (rl == 0 && c0 < C) {
+#pragma unroll
+        for (int e = 0; e < KC; ++e)
+            if (c0 + e < C) ws[(size_t)split * C + c0 + e] = acc[e];
+    }
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ ws, int nsplit, int C, float* __restrict__ out,
+                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < nsplit; ++i) s += ws[(size_t)i * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------ L2 normalise (one wave per row)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int M, int C,
+                                                         int ld, const float* __restrict__ gamma) {
+    constexpr int KC = Chunk<T>::N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = C / KC;
+    const float g = gamma[0];
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        float ss = 0.f;
+        for (int ch = lane; ch < chunks; ch += 64) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(x + (size_t)m * ld + ch * KC), f);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) ss += f[e] * f[e];
+        }
+        ss = wave_sum(ss);
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+        for (int ch = lane; ch < chunks; ch += 64) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(x + (size_t)m * ld + ch * KC), f);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) f[e] = f[e] * inv * g;
+            st16(y + (size_t)m * ld + ch * KC, Chunk<T>::pack(f));
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         T* __restrict__ dx, int M, int C, int ld,
+                                                         const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                         int accumulate, const T* __restrict__ relu_src) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sdg[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = C / KC;
+    const float g = gamma[0];
+    float dg = 0.f;
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        float ss = 0.f, sd = 0.f;
+        for (int ch = lane; ch < chunks; ch += 64) {
+            float f[KC], d[KC];
+            Chunk<T>::unpack(ld16(x + (size_t)m * ld + ch * KC), f);
+            Chunk<T>::unpack(ld16(dy + (size_t)m * ld + ch * KC), d);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) { ss += f[e] * f[e]; sd += f[e] * d[e]; }
+        }
+        ss = wave_sum(ss);
+        sd = wave_sum(sd);
+        const bool clamped = !(ss > 1e-12f);
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+        dg += sd * inv;
+        const float k = clamped ? 0.f : g * inv * inv * inv * sd;
+        for (int ch = lane; ch < chunks; ch += 64) {
+            float f[KC], d[KC], o[KC];
+            const size_t off = (size_t)m * ld + ch * KC;
+            Chunk<T>::unpack(ld16(x + off), f);
+            Chunk<T>::unpack(ld16(dy + off), d);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) o[e] = g * inv * d[e] - k * f[e];
+            if (accumulate) {
+                float p[KC];
+                Chunk<T>::unpack(ld16(dx + off), p);
+#pragma unroll
+                for (int e = 0; e < KC; ++e) o[e] += p[e];
+            }
+            if (relu_src) {
+                float r[KC];
+                Chunk<T>::unpack(ld16(relu_src + off), r);
+#pragma unroll
+                for (int e = 0; e < KC; ++e) if (!(r[e] > 0.f)) o[e] = 0.f;
+            }
+            st16(dx + off, Chunk<T>::pack(o));
+        }
+    }
+    if (lane == 0) sdg[wave] = dg;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dgamma, (sdg[0] + sdg[1]) + (sdg[2] + sdg[3]));
+}
+
+// ------------------------------------------------------------------ optimizer
+constexpr int SGD_THREADS = 256;
+constexpr int SGD_PER_BLOCK = SGD_THREADS * 4 * 8;   // 8 float4 per thread
+
+template <typename TC>
+__global__ void __launch_bounds__(SGD_THREADS) sgd_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                          const float* __restrict__ g, long long n, float lr,
+                                                          float mom, float wd, float gscale,
+                                                          float* __restrict__ l2_partial, TC* __restrict__ pc) {
+    __shared__ float sm[SGD_THREADS / 64];
+    const long long base = (long long)blockIdx.x * SGD_PER_BLOCK;
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const long long i = base + ((long long)it * SGD_THREADS + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            float4 pv = *reinterpret_cast<float4*>(p + i);
+            float4 mv = *reinterpret_cast<float4*>(m + i);
+            const float4 gv = *reinterpret_cast<const float4*>(g + i);
+            ss += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
+            mv.x = mom * mv.x + (gv.x * gscale + wd * pv.x); pv.x -= lr * mv.x;
+            mv.y = mom * mv.y + (gv.y * gscale + wd * pv.y); pv.y -= lr * mv.y;
+            mv.z = mom * mv.z + (gv.z * gscale + wd * pv.z); pv.z -= lr * mv.z;
+            mv.w = mom * mv.w + (gv.w * gscale + wd * pv.w); pv.w -= lr * mv.w;
+            *reinterpret_cast<float4*>(p + i) = pv;
+            *reinterpret_cast<float4*>(m + i) = mv;
+            if (pc) {
+                pc[i] = elem<TC>::store(pv.x); pc[i + 1] = elem<TC>::store(pv.y);
+                pc[i + 2] = elem<TC>::store(pv.z); pc[i + 3] = elem<TC>::store(pv.w);
+            }
+        } else {
+            for (long long j = i; j < n && j < i + 4; ++j) {
+                float pv = p[j], mv = m[j];
+                ss += pv * pv;
+                mv = mom * mv + (g[j] * gscale + wd * pv);
+                pv -= lr * mv;
+                p[j] = pv; m[j] = mv;
+                if (pc) pc[j] = elem<TC>::store(pv);
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0 && l2_partial) l2_partial[blockIdx.x] = 0.5f * ((sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+
+__global__ void __launch_bounds__(1024) sum_kernel(const float* __restrict__ in, long long n, float* __restrict__ out) {
+    __shared__ float sm[16];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += in[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += sm[i];
+        out[0] = t;
+    }
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) out[i] = elem<T>::store(in[i]);
+}
+
+inline int grid_for(long long total, int threads, int cap = 8192) {
+    long long b = (total + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+struct RedPlan { int colgroups, nsplit, rows_per_split; };
+inline RedPlan red_plan(int M, int C, int kc) {
+    RedPlan p;
+    p.colgroups = ceil_div(C, 8 * kc);
+    int want = 1024 / p.colgroups;
+    if (want < 1) want = 1;
+    int maxs = ceil_div(M, 4 * RED_ROWS);
+    if (maxs < 1) maxs = 1;
+    if (want > maxs) want = maxs;
+    if (want > 256) want = 256;
+    p.rows_per_split = ceil_div(M, want);
+    p.nsplit = ceil_div(M, p.rows_per_split);
+    return p;
+}
+
+}  // namespace
+}  // namespace odtk
+
+using namespace odtk;
+
+#define DT_SWITCH(dtype, T, ...)                                         \
+    if ((dtype) == ODTK_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
+    else if ((dtype) == ODTK_F32) { typedef float T; __VA_ARGS__ }       \
+    else { set_error("bad dtype %d", (int)(dtype)); return ODTK_ERR_ARG; }
+
+extern "C" int odtk_preprocess(const float* images, long long pixels, const float* mean3, int ldx, int dtype,
+                               void* x, void* stream) {
+    ODTK_REQUIRE(images && x && mean3 && ldx >= 3, "preprocess: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(preprocess_kernel<T>, dim3(grid_for(pixels, 256)), dim3(256), 0, st,
+                                           images, pixels, mean3[0], mean3[1], mean3[2], ldx, (T*)x);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+static int pool_check(int C, int ld, int dtype) {
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(C % kc == 0 && ld % kc == 0, "pool: C=%d ld=%d must be multiples of %d", C, ld, kc);
+    return ODTK_OK;
+}
+
+extern "C" int odtk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int ld, int Ho, int Wo,
+                                int k, int stride, int pad_t, int pad_l, int dtype, void* stream) {
+    ODTK_REQUIRE(x && y, "maxpool_fwd: null pointer");
+    if (int e = pool_check(C, ld, dtype)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    const long long total = (long long)N * Ho * Wo * (C / kc);
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
+                                           (const T*)x, (T*)y, N, H, W, C, ld, Ho, Wo, k, stride, pad_t, pad_l);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, void* dx, int N, int H, int W,
+                                int C, int ld, int Ho, int Wo, int k, int stride, int pad_t, int pad_l,
+                                int dtype, void* stream) {
+    ODTK_REQUIRE(x && y && dy && dx, "maxpool_bwd: null pointer");
+    if (int e = pool_check(C, ld, dtype)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    const long long total = (long long)N * H * W * (C / kc);
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
+                                           (const T*)x, (const T*)y, (const T*)dy, (T*)dx, N, H, W, C, ld, Ho, Wo, k,
+                                           stride, pad_t, pad_l);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" long long odtk_bn_workspace_bytes(int M, int C) {
+    (void)M;
+    return (long long)2 * 256 * (long long)((C + 63) / 64 * 64) * sizeof(float);
+}
+
+extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, const float* gamma,
+                           const float* beta, float* moving_mean, float* moving_var, float* save_mean,
+                           float* save_invstd, int training, int relu, void* y, int y_dtype, int ldy,
+                           int rows_per_img, long long y_img_stride, void* workspace, void* stream) {
+    ODTK_REQUIRE(z && y && gamma && beta && moving_mean && moving_var, "bn_fwd: null pointer");
+    ODTK_REQUIRE(!training || (save_mean && save_invstd && workspace), "bn_fwd: training needs save buffers + workspace");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_fwd: ldz=%d must be a multiple of %d", ldz, kc);
+    ODTK_REQUIRE(!(y_dtype == ODTK_BF16 && dtype == ODTK_F32), "bn_fwd: f32 in / bf16 out unsupported");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan pl = red_plan(M, C, kc);
+    float* ws = (float*)workspace;
+    if (training) {
+        DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
+                                               (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
+        ODTK_LAUNCH_CHECK();
+    }
+    const size_t ysz = dtype_size(y_dtype);
+    const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
+                       ((uintptr_t)y % 16) == 0;
+    // apply: same column groups; row blocks sized like the stats splits
+    const int rows_per_block = pl.rows_per_split;
+    dim3 grid(pl.colgroups, ceil_div(M, rows_per_block));
+#define BN_APPLY(T, TY)                                                                                        \
+    hipLaunchKernelGGL((bn_apply_kernel<T, TY>), grid, dim3(256), 0, st, (const T*)z, M, C, ldz, gamma, beta,  \
+                       moving_mean, moving_var, save_mean, save_invstd, training, relu, (TY*)y, ldy,           \
+                       rows_per_img, y_img_stride, vec_ok, ws, pl.nsplit, rows_per_block)
+    if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) BN_APPLY(bf16_t, bf16_t);
+    else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) BN_APPLY(bf16_t, float);
+    else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) BN_APPLY(float, float);
+    else ODTK_REQUIRE(false, "bn_fwd: bad dtype");
+#undef BN_APPLY
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, int C, int ldz, int dtype,
+                           int y_dtype, int ldy, int rows_per_img, long long y_img_stride,
+                           const float* gamma, const float* save_mean, const float* save_invstd, int relu,
+                           void* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    ODTK_REQUIRE(z && dy && dz && gamma && save_mean && save_invstd && dgamma && dbeta && workspace,
+                 "bn_bwd: null pointer");
+    ODTK_REQUIRE(!relu || y, "bn_bwd: relu needs y");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_bwd: ldz=%d must be a multiple of %d", ldz, kc);
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan pl = red_plan(M, C, kc);
+    float* ws = (float*)workspace;
+    const int rows_per_block = pl.rows_per_split;
+    dim3 g1(pl.colgroups, pl.nsplit);
+    dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
+#define BN_BWD(T, TY)                                                                                             \
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
+                       (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu,   \
+                       pl.rows_per_split, ws);                                                                    \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
+                       (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd,  \
+                       relu, (T*)dz, dgamma, dbeta, ws, pl.nsplit, rows_per_block)
+    if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_BWD(bf16_t, bf16_t); }
+    else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_BWD(bf16_t, float); }
+    else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD(float, float); }
+    else ODTK_REQUIRE(false, "bn_bwd: bad dtype");
+#undef BN_BWD
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_l2norm_fwd(const void* x, void* y, int M, int C, int ld, int dtype, const float* gamma,
+                               void* stream) {
+    ODTK_REQUIRE(x && y && gamma, "l2norm_fwd: null pointer");
+    if (int e = pool_check(C, ld, dtype)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    int grid = ceil_div(M, 4); if (grid > 4096) grid = 4096;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(l2norm_fwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)x, (T*)y, M, C,
+                                           ld, gamma);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_l2norm_bwd(const void* x, const void* dy, void* dx, int M, int C, int ld, int dtype,
+                               const float* gamma, float* dgamma, int accumulate, const void* relu_src,
+                               void* stream) {
+    ODTK_REQUIRE(x && dy && dx && gamma && dgamma, "l2norm_bwd: null pointer");
+    if (int e = pool_check(C, ld, dtype)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    int grid = ceil_div(M, 4); if (grid > 1024) grid = 1024;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(l2norm_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy,
+                                           (T*)dx, M, C, ld, gamma, dgamma, accumulate, (const T*)relu_src);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_colsum(const void* dy, int M, int C, int ld, int dtype, float* out, int accumulate,
+                           void* workspace, void* stream) {
+    ODTK_REQUIRE(dy && out && workspace, "colsum: null pointer");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(ld % kc == 0 && ld >= C, "colsum: ld=%d must be a multiple of %d", ld, kc);
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan pl = red_plan(M, C, kc);
+    float* ws = (float*)workspace;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
+                                           (const T*)dy, M, C, ld, pl.rows_per_split, ws);)
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, ws, pl.nsplit, C, out,
+                       accumulate);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_sgd_blocks(long long n) { return (int)((n + SGD_PER_BLOCK - 1) / SGD_PER_BLOCK); }
+
+extern "C" int odtk_sgd_momentum(float* p, float* m, const float* grad, long long n, float lr, float momentum,
+                                 float wd, float grad_scale, float* l2_partial, void* p_cast, int cast_dtype,
+                                 void* stream) {
+    ODTK_REQUIRE(p && m && grad && n > 0, "sgd: bad argument");
+    ODTK_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)grad % 16) == 0,
+                 "sgd: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = odtk_sgd_blocks(n);
+    if (p_cast && cast_dtype == ODTK_F32)
+        hipLaunchKernelGGL(sgd_kernel<float>, dim3(blocks), dim3(SGD_THREADS), 0, st, p, m, grad, n, lr, momentum, wd,
+                           grad_scale, l2_partial, (float*)p_cast);
+    else
+        hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3(blocks), dim3(SGD_THREADS), 0, st, p, m, grad, n, lr, momentum, wd,
+                           grad_scale, l2_partial, (bf16_t*)p_cast);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_sum_f32(const float* in, long long n, float* out, void* stream) {
+    ODTK_REQUIRE(in && out && n >= 0, "sum: bad argument");
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, out);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_cast_from_f32(const float* in, void* out, long long n, int dtype, void* stream) {
+    ODTK_REQUIRE(in && out, "cast: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(cast_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, (T*)out, n);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

@@ -1,0 +1,186 @@
+"""Torch-tensor front end of the libodtk C-ABI.
+
+PyTorch is plumbing here: it owns device memory and streams.  Every function takes
+contiguous CUDA(=HIP) tensors, passes raw pointers + the current HIP stream through
+ctypes, and fails loudly (OdtkError) if the HIP library is absent -- no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ConvDesc, call
+
+_TORCH_DT = {BF16: torch.bfloat16, F32: torch.float32}
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(dt: int):
+    return _TORCH_DT[dt]
+
+
+def chunk(dt: int) -> int:
+    """channels per 16-byte chunk"""
+    return 8 if dt == BF16 else 4
+
+
+def pad_to(c: int, m: int) -> int:
+    return (c + m - 1) // m * m
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libodtk takes device pointers"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def same_pad(in_size: int, k: int, stride: int, dil: int = 1):
+    """TF SAME arithmetic: (out, pad_before, pad_after)."""
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + (k - 1) * dil + 1 - in_size, 0)
+    return out, total // 2, total - total // 2
+
+
+def conv_desc(N, H, W, C_, ldx, K, ldy, k, stride=1, dil=1, dtype=BF16, out_dtype=None) -> ConvDesc:
+    Ho, pt, _ = same_pad(H, k, stride, dil)
+    Wo, pl, _ = same_pad(W, k, stride, dil)
+    return ConvDesc(N=N, H=H, W=W, C=C_, ldx=ldx, Ho=Ho, Wo=Wo, K=K, ldy=ldy, R=k, S=k, stride=stride,
+                    dil=dil, pad_t=pt, pad_l=pl, dtype=dtype, out_dtype=dtype if out_dtype is None else out_dtype)
+
+
+# ------------------------------------------------------------------ conv family
+def conv2d_fwd(d: ConvDesc, x, w, bias, y, relu: bool):
+    call("odtk_conv2d_fwd", C.byref(d), _p(x), _p(w), _p(bias), _p(y), int(relu), _stream())
+
+
+def conv2d_dgrad(d: ConvDesc, dy, lddy: int, w_t, relu_src, dx, accumulate: bool):
+    call("odtk_conv2d_dgrad", C.byref(d), _p(dy), int(lddy), _p(w_t), _p(relu_src), _p(dx), int(accumulate),
+         _stream())
+
+
+def conv2d_wgrad(d: ConvDesc, x, dy, lddy: int, dw):
+    call("odtk_conv2d_wgrad", C.byref(d), _p(x), _p(dy), int(lddy), _p(dw), _stream())
+
+
+def filter_prepare(w, K, R, S, C_, Kp, dtype, w_c, w_t):
+    call("odtk_filter_prepare", _p(w), K, R, S, C_, Kp, dtype, _p(w_c), _p(w_t), _stream())
+
+
+# ------------------------------------------------------------------ layers
+def preprocess(images, mean3, ldx, dtype, x):
+    m = (C.c_float * 3)(*mean3)
+    call("odtk_preprocess", _p(images), images.numel() // 3, m, ldx, dtype, _p(x), _stream())
+
+
+def maxpool_fwd(x, y, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
+    call("odtk_maxpool_fwd", _p(x), _p(y), N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l, dt_of(x), _stream())
+
+
+def maxpool_bwd(x, y, dy, dx, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
+    call("odtk_maxpool_bwd", _p(x), _p(y), _p(dy), _p(dx), N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l,
+         dt_of(x), _stream())
+
+
+def bn_workspace_bytes(M, C_):
+    return int(_lib.load().odtk_bn_workspace_bytes(M, C_))
+
+
+def bn_fwd(z, M, C_, ldz, gamma, beta, mmean, mvar, save_mean, save_invstd, training, relu, y, ldy,
+           rows_per_img, y_img_stride, ws):
+    call("odtk_bn_fwd", _p(z), M, C_, ldz, dt_of(z), _p(gamma), _p(beta), _p(mmean), _p(mvar), _p(save_mean),
+         _p(save_invstd), int(training), int(relu), _p(y), dt_of(y), ldy, rows_per_img, y_img_stride, _p(ws),
+         _stream())
+
+
+def bn_bwd(z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, dz,
+           dgamma, dbeta, ws):
+    call("odtk_bn_bwd", _p(z), _p(y), _p(dy), M, C_, ldz, dt_of(z), dt_of(dy), ldy, rows_per_img, y_img_stride,
+         _p(gamma), _p(save_mean), _p(save_invstd), int(relu), _p(dz), _p(dgamma), _p(dbeta), _p(ws), _stream())
+
+
+def l2norm_fwd(x, y, M, C_, ld, gamma):
+    call("odtk_l2norm_fwd", _p(x), _p(y), M, C_, ld, dt_of(x), _p(gamma), _stream())
+
+
+def l2norm_bwd(x, dy, dx, M, C_, ld, gamma, dgamma, accumulate, relu_src):
+    call("odtk_l2norm_bwd", _p(x), _p(dy), _p(dx), M, C_, ld, dt_of(x), _p(gamma), _p(dgamma), int(accumulate),
+         _p(relu_src), _stream())
+
+
+def colsum(dy, M, C_, ld, out, accumulate, ws):
+    call("odtk_colsum", _p(dy), M, C_, ld, dt_of(dy), _p(out), int(accumulate), _p(ws), _stream())
+
+
+def sgd_blocks(n):
+    return int(_lib.load().odtk_sgd_blocks(n))
+
+
+def sgd_momentum(p, m, g, lr, momentum, wd, grad_scale, l2_partial, p_cast):
+    call("odtk_sgd_momentum", _p(p), _p(m), _p(g), p.numel(), float(lr), float(momentum), float(wd),
+         float(grad_scale), _p(l2_partial), _p(p_cast), dt_of(p_cast) if p_cast is not None else BF16, _stream())
+
+
+def sum_f32(x, out):
+    call("odtk_sum_f32", _p(x), x.numel(), _p(out), _stream())
+
+
+def cast_from_f32(x, out):
+    call("odtk_cast_from_f32", _p(x), _p(out), x.numel(), dt_of(out), _stream())
+
+
+# ------------------------------------------------------------------ box side
+def ssd_priors(input_size, fsizes, nas, prior_hw_flat, device):
+    """Returns (y1x1, y2x2, yx, hw, nmsbox) device tensors."""
+    A = sum(f * f * a for f, a in zip(fsizes, nas))
+    mk = lambda c: torch.empty(A, c, dtype=torch.float32, device=device)
+    y1x1, y2x2, yx, hw, nb = mk(2), mk(2), mk(2), mk(2), mk(4)
+    L = len(fsizes)
+    call("odtk_ssd_priors", int(input_size), L, (C.c_int * L)(*fsizes), (C.c_int * L)(*nas),
+         (C.c_float * len(prior_hw_flat))(*prior_hw_flat), _p(y1x1), _p(y2x2), _p(yx), _p(hw), _p(nb), _stream())
+    return y1x1, y2x2, yx, hw, nb
+
+
+def ssd_match(y1x1, y2x2, hw, gt, ngt, best, status, rgindex, counts):
+    N, P, _ = gt.shape
+    call("odtk_ssd_match", _p(y1x1), _p(y2x2), _p(hw), y1x1.shape[0], _p(gt), N, P, _p(ngt), _p(best),
+         _p(status), _p(rgindex), _p(counts), _stream())
+
+
+def softmax_ce_const(pred, rows, Cn, ld, label, loss):
+    call("odtk_softmax_ce_const", _p(pred), rows, Cn, ld, label, _p(loss), _stream())
+
+
+def nms_batched(boxes, box_stride, scores, score_bstride, score_estride, valid, valid_bstride, valid_estride,
+                valid_value, n, B, max_out_dev, max_out_stride, max_out_const, iou_thr, out_idx, cap, out_cnt):
+    call("odtk_nms_batched", _p(boxes), box_stride, _p(scores), score_bstride, score_estride, _p(valid),
+         valid_bstride, valid_estride, valid_value, n, B, _p(max_out_dev), max_out_stride, max_out_const,
+         float(iou_thr), _p(out_idx), cap, _p(out_cnt), _stream())
+
+
+def ssd_loss(pred, Cn, yx, hw, gt, ngt, best, status, rgindex, counts, negloss, sel_idx, sel_cnt, grad_scale,
+             loss_parts, dpred):
+    N, A, ld = pred.shape
+    call("odtk_ssd_loss", _p(pred), N, A, Cn, ld, _p(yx), _p(hw), _p(gt), gt.shape[1], _p(ngt), _p(best),
+         _p(status), _p(rgindex), _p(counts), _p(negloss), _p(sel_idx), sel_idx.shape[1], _p(sel_cnt),
+         float(grad_scale), _p(loss_parts), _p(dpred), _stream())
+
+
+def ssd_decode(pred0, Cn, yx, hw, thr, conf, boxes, keep, cand):
+    A, ld = pred0.shape
+    call("odtk_ssd_decode", _p(pred0), A, Cn, ld, _p(yx), _p(hw), float(thr), _p(conf), _p(boxes), _p(keep),
+         _p(cand), _stream())

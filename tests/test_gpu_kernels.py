@@ -1,0 +1,461 @@
+"""GPU parity tests, kernel level: every call goes through the C-ABI (libodtk.so) and is
+checked against the CPU oracle / plain torch fp32 math on the same seeded inputs.
+
+Tolerances: f32 path 2e-4 relative to the output scale (exact-f32 MFMA, different summation
+order); bf16 path 2e-2 (operands rounded to bf16, f32 accumulate) against a reference fed the
+same bf16-rounded operands."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ssd300_ref as R  # noqa: E402
+
+
+def _ops():
+    import odtk  # noqa: F401
+    from odtk import ops
+    return ops
+
+
+def to_rows(x_nhwc, ld, dtype, dev):
+    """[N,H,W,C] cpu f32 -> device [N*H*W, ld] in dtype (zero padded)."""
+    N, H, W, C = x_nhwc.shape
+    t = torch.zeros(N * H * W, ld, dtype=torch.float32)
+    t[:, :C] = x_nhwc.reshape(-1, C)
+    return t.to(dtype).to(dev).contiguous()
+
+
+def from_rows(t, N, H, W, C):
+    return t[:, :C].float().cpu().reshape(N, H, W, C)
+
+
+CONV_CASES = [
+    # N, H, W, C, K, k, stride, dil
+    (2, 19, 19, 32, 48, 3, 1, 1),
+    (1, 10, 10, 16, 24, 3, 2, 1),     # stride 2, asymmetric SAME pad (pad_before 0)
+    (2, 19, 19, 64, 128, 3, 1, 2),    # dilation 2 (conv6)
+    (2, 9, 9, 256, 100, 3, 1, 1),     # head: Cout not a multiple of 8/32
+    (2, 5, 5, 256, 150, 3, 1, 1),     # head: Cout = 150
+    (2, 20, 20, 8, 64, 3, 1, 1),      # C=8 -> K tail inside a 16B-chunk slab (conv1_1 shape class)
+    (2, 19, 19, 128, 64, 1, 1, 1),    # 1x1
+    (3, 38, 38, 64, 64, 3, 1, 1),     # several pixel tiles, PT=64 path
+    (1, 5, 5, 128, 256, 3, 2, 1),     # 5 -> 3
+    (2, 21, 17, 40, 72, 3, 1, 1),     # non-square, C not a multiple of the k-slab
+]
+
+
+def _ref_conv(x_nhwc, w_krsc, b, stride, dil):
+    y = R.conv2d_same(x_nhwc.permute(0, 3, 1, 2), w_krsc, b, stride, dil)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_fwd_dgrad_wgrad(case, dt, dev):
+    ops = _ops()
+    N, H, W, C, K, k, stride, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    DT = ops.F32 if dt == "f32" else ops.BF16
+    ch = ops.chunk(DT)
+    tol = 2e-4 if dt == "f32" else 2e-2
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(K, k, k, C, generator=g) / math.sqrt(k * k * C)
+    b = torch.randn(K, generator=g)
+    if dt == "bf16":
+        x = x.to(dtype).float()
+    ldx = ops.pad_to(C, ch)
+    Kp = ops.pad_to(K, 8)
+    d = ops.conv_desc(N, H, W, ldx, ldx, K, Kp, k, stride, dil, DT, DT)
+    Ho, Wo = d.Ho, d.Wo
+    xd = to_rows(x, ldx, dtype, dev)
+    wpad = torch.zeros(K, k, k, ldx)
+    wpad[..., :C] = w
+    wd_master = wpad.to(dev)
+    w_c = torch.empty(K * k * k * ldx, dtype=dtype, device=dev)
+    w_t = torch.empty(ldx * k * k * Kp, dtype=dtype, device=dev)
+    ops.filter_prepare(wd_master, K, k, k, ldx, Kp, DT, w_c, w_t)
+    wq = w_c.float().cpu().reshape(K, k, k, ldx)[..., :C]            # operand as the kernel sees it
+    if dt == "f32":
+        assert torch.equal(wq, w)
+    # ---- forward (+bias+relu)
+    yd = torch.zeros(N * Ho * Wo, Kp, dtype=dtype, device=dev)
+    ops.conv2d_fwd(d, xd, w_c, b.to(dev), yd, True)
+    torch.cuda.synchronize()
+    y = from_rows(yd, N, Ho, Wo, K)
+    xr = x.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    z_ref = _ref_conv(xr, wr, b, stride, dil)
+    y_ref = F.relu(z_ref)
+    scale = float(y_ref.abs().max()) + 1e-6
+    assert float((y - y_ref.detach()).abs().max()) <= tol * scale, "conv fwd mismatch"
+    assert float(yd[:, K:].float().abs().max()) == 0.0 if Kp > K else True
+    # ---- backward: random dy, no relu (pure linear ops)
+    dy = torch.randn(N, Ho, Wo, K, generator=g)
+    if dt == "bf16":
+        dy = dy.to(dtype).float()
+    z_ref.backward(dy)
+    dyd = to_rows(dy, Kp, dtype, dev)
+    dxd = torch.full((N * H * W, ldx), 7.0, dtype=dtype, device=dev)
+    ops.conv2d_dgrad(d, dyd, Kp, w_t, None, dxd, False)
+    dwd = torch.zeros(K, k, k, ldx, dtype=torch.float32, device=dev)
+    ops.conv2d_wgrad(d, xd, dyd, Kp, dwd)
+    torch.cuda.synchronize()
+    dx = from_rows(dxd, N, H, W, C)
+    sx = float(xr.grad.abs().max()) + 1e-6
+    assert float((dx - xr.grad).abs().max()) <= tol * sx, "dgrad mismatch"
+    dw = dwd.cpu()[..., :C]
+    sw = float(wr.grad.abs().max()) + 1e-6
+    assert float((dw - wr.grad).abs().max()) <= tol * sw, "wgrad mismatch"
+    # ---- dgrad with fused relu mask + accumulate
+    src = torch.randn(N, H, W, C, generator=g)
+    srcd = to_rows(src, ldx, dtype, dev)
+    prev = torch.randn(N, H, W, C, generator=g)
+    if dt == "bf16":
+        prev = prev.to(dtype).float()
+    dxd2 = to_rows(prev, ldx, dtype, dev)
+    ops.conv2d_dgrad(d, dyd, Kp, w_t, srcd, dxd2, True)
+    torch.cuda.synchronize()
+    exp = (xr.grad + prev) * (srcd[:, :C].float().cpu().reshape(N, H, W, C) > 0)
+    got = from_rows(dxd2, N, H, W, C)
+    assert float((got - exp).abs().max()) <= (tol if dt == "f32" else 3e-2) * (float(exp.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(2, 75, 75, 16, 2, 2), (2, 19, 19, 32, 3, 1), (1, 38, 38, 8, 2, 2)])
+def test_maxpool(geom, dt, dev):
+    ops = _ops()
+    N, H, W, C, k, s = geom
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, H, W, C, generator=g).to(dtype).float()
+    Ho, pt, _ = ops.same_pad(H, k, s)
+    Wo, pl, _ = ops.same_pad(W, k, s)
+    xd = to_rows(x, C, dtype, dev)
+    yd = torch.empty(N * Ho * Wo, C, dtype=dtype, device=dev)
+    ops.maxpool_fwd(xd, yd, N, H, W, C, C, Ho, Wo, k, s, pt, pl)
+    xr = x.clone().requires_grad_(True)
+    y_ref = R.maxpool_same(xr.permute(0, 3, 1, 2), k, s).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(from_rows(yd, N, Ho, Wo, C), y_ref.detach())
+    dy = torch.randn(N, Ho, Wo, C, generator=g).to(dtype).float()
+    y_ref.backward(dy)
+    dxd = torch.empty_like(xd)
+    ops.maxpool_bwd(xd, yd, to_rows(dy, C, dtype, dev), dxd, N, H, W, C, C, Ho, Wo, k, s, pt, pl)
+    torch.cuda.synchronize()
+    got = from_rows(dxd, N, H, W, C)
+    # random data: no ties (bf16: ties possible -> compare only total mass and tie-free positions)
+    if dt == "f32":
+        assert float((got - xr.grad).abs().max()) < 1e-5
+    else:
+        assert abs(float(got.sum() - xr.grad.to(dtype).float().sum())) < 0.05 * float(xr.grad.abs().sum()) + 1.0
+
+
+@pytest.mark.parametrize("dt,ydt", [("f32", "f32"), ("bf16", "bf16"), ("bf16", "f32")])
+@pytest.mark.parametrize("shape", [(2 * 19 * 19, 1024, True), (2 * 38 * 38, 100, False), (3 * 5 * 5, 150, False),
+                                   (2 * 3 * 3, 256, True)])
+def test_batchnorm(shape, dt, ydt, dev):
+    ops = _ops()
+    M, C, relu = shape
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    ydtype = torch.float32 if ydt == "f32" else torch.bfloat16
+    ch = 4 if dt == "f32" else 8
+    ldz = ops.pad_to(C, ch)
+    g = torch.Generator().manual_seed(2)
+    z = (torch.randn(M, C, generator=g) * 3 + torch.randn(C, generator=g)).to(dtype).float()
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g)
+    zd = torch.zeros(M, ldz, dtype=dtype, device=dev); zd[:, :C] = z.to(dtype).to(dev)
+    mm = torch.zeros(C, device=dev); mv = torch.ones(C, device=dev)
+    sm = torch.empty(C, device=dev); si = torch.empty(C, device=dev)
+    ws = torch.empty(ops.bn_workspace_bytes(M, C), dtype=torch.uint8, device=dev)
+    # head-style dense output: image-major with pitch C (rows_per_img = M/ nimg)
+    nimg = 2 if M % 2 == 0 else 3
+    rpi = M // nimg
+    yd = torch.zeros(M, C, dtype=ydtype, device=dev)
+    ops.bn_fwd(zd, M, C, ldz, gamma.to(dev), beta.to(dev), mm, mv, sm, si, True, relu, yd, C, rpi, rpi * C, ws)
+    zr = z.clone().requires_grad_(True)
+    mean = zr.mean(0); var = ((zr - mean) ** 2).mean(0)
+    yr = (zr - mean) * torch.rsqrt(var + 1e-3) * gamma + beta
+    if relu:
+        yr = F.relu(yr)
+    torch.cuda.synchronize()
+    tol = 1e-4 if ydt == "f32" else 2e-2
+    assert float((yd.float().cpu() - yr.detach()).abs().max()) <= tol * (float(yr.abs().max()) + 1e-6)
+    assert float((sm.cpu() - mean.detach()).abs().max()) < 1e-4
+    unb = var.detach() * M / (M - 1)
+    assert float((mv.cpu() - (0.99 + 0.01 * unb)).abs().max()) < 1e-4
+    assert float((mm.cpu() - 0.01 * mean.detach()).abs().max()) < 1e-4
+    dy = torch.randn(M, C, generator=g).to(ydtype).float()
+    # reference backward uses the mask from the GPU output so relu boundaries agree
+    yr.backward(dy)
+    dzd = torch.full((M, ldz), 5.0, dtype=dtype, device=dev)
+    dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
+    ops.bn_bwd(zd, yd, dy.to(ydtype).to(dev), M, C, ldz, C, rpi, rpi * C, gamma.to(dev), sm, si, relu, dzd, dg, db, ws)
+    torch.cuda.synchronize()
+    tolb = 5e-4 if (dt == "f32") else 3e-2
+    sc = float(zr.grad.abs().max()) + 1e-6
+    assert float((dzd[:, :C].float().cpu() - zr.grad).abs().max()) <= tolb * sc
+    if ldz > C:
+        assert float(dzd[:, C:].float().abs().max()) == 0.0
+    # inference mode
+    yd2 = torch.zeros(M, C, dtype=ydtype, device=dev)
+    ops.bn_fwd(zd, M, C, ldz, gamma.to(dev), beta.to(dev), mm, mv, None, None, False, relu, yd2, C, rpi, rpi * C, None)
+    yi = (z - mm.cpu()) * torch.rsqrt(mv.cpu() + 1e-3) * gamma + beta
+    if relu:
+        yi = F.relu(yi)
+    torch.cuda.synchronize()
+    assert float((yd2.float().cpu() - yi).abs().max()) <= tol * (float(yi.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_l2norm_colsum_sgd(dt, dev):
+    ops = _ops()
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    M, C = 2 * 38 * 38, 512
+    g = torch.Generator().manual_seed(3)
+    x = F.relu(torch.randn(M, C, generator=g)).to(dtype).float()
+    gamma = torch.tensor([20.0])
+    xd = x.to(dtype).to(dev)
+    yd = torch.empty_like(xd)
+    ops.l2norm_fwd(xd, yd, M, C, C, gamma.to(dev))
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True)
+    yr = xr * torch.rsqrt(torch.clamp((xr * xr).sum(1, keepdim=True), min=1e-12)) * gr
+    torch.cuda.synchronize()
+    tol = 1e-5 if dt == "f32" else 1e-2
+    assert float((yd.float().cpu() - yr.detach()).abs().max()) <= tol * float(yr.abs().max())
+    dy = torch.randn(M, C, generator=g).to(dtype).float()
+    yr.backward(dy)
+    prev = torch.randn(M, C, generator=g).to(dtype)
+    dxd = prev.clone().to(dev)
+    dgd = torch.zeros(1, device=dev)
+    ops.l2norm_bwd(xd, dy.to(dtype).to(dev), dxd, M, C, C, gamma.to(dev), dgd, True, xd)
+    torch.cuda.synchronize()
+    exp = (xr.grad + prev.float()) * (x > 0)
+    tolb = 1e-4 if dt == "f32" else 3e-2
+    assert float((dxd.float().cpu() - exp).abs().max()) <= tolb * float(exp.abs().max())
+    assert abs(float(dgd.cpu()) - float(gr.grad)) <= 2e-3 * abs(float(gr.grad)) + 1e-3
+    # colsum
+    ws = torch.empty(ops.bn_workspace_bytes(M, C), dtype=torch.uint8, device=dev)
+    out = torch.ones(C, device=dev)
+    ops.colsum(dy.to(dtype).to(dev), M, C, C, out, True, ws)
+    torch.cuda.synchronize()
+    ref = dy.sum(0) + 1
+    assert float((out.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+    # sgd momentum + l2 partial + cast copy
+    n = 100003
+    p = torch.randn(n, generator=g); m = torch.randn(n, generator=g); gg = torch.randn(n, generator=g)
+    pd, md, gd = p.to(dev), m.to(dev), gg.to(dev)
+    part = torch.zeros(ops.sgd_blocks(n), device=dev)
+    pc = torch.empty(n, dtype=dtype, device=dev)
+    ops.sgd_momentum(pd, md, gd, 0.01, 0.9, 1e-4, 1.0, part, pc)
+    tot = torch.zeros(1, device=dev)
+    ops.sum_f32(part, tot)
+    torch.cuda.synchronize()
+    m_ref = 0.9 * m + (gg + 1e-4 * p)
+    p_ref = p - 0.01 * m_ref
+    assert float((md.cpu() - m_ref).abs().max()) < 1e-6
+    assert float((pd.cpu() - p_ref).abs().max()) < 1e-6
+    assert abs(float(tot.cpu()) - float((p * p).sum() / 2)) < 1e-3 * float((p * p).sum() / 2)
+    assert float((pc.float().cpu() - p_ref.to(dtype).float()).abs().max()) < 1e-6
+
+
+def test_preprocess(dev):
+    ops = _ops()
+    img = torch.rand(2, 30, 30, 3) * 255
+    for dt, ld in ((torch.bfloat16, 8), (torch.float32, 4)):
+        x = torch.full((2 * 30 * 30, ld), 9.0, dtype=dt, device=dev)
+        ops.preprocess(img.to(dev), R.MEAN_RGB, ld, ops.dt_of(x), x)
+        torch.cuda.synchronize()
+        ref = (img - torch.tensor(R.MEAN_RGB)).reshape(-1, 3)
+        assert torch.equal(x[:, :3].float().cpu(), ref.to(dt).float())
+        assert float(x[:, 3:].float().abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------- box side
+def _gpu_priors(ops, dev):
+    from odtk.ssd300 import prior_spec
+    fs, nas, hw = prior_spec()
+    return ops.ssd_priors(300, fs, nas, hw, dev)
+
+
+def test_priors_bit_exact(dev):
+    ops = _ops()
+    y1x1, y2x2, yx, hw, nb = _gpu_priors(ops, dev)
+    ref = R.priors()
+    torch.cuda.synchronize()
+    assert y1x1.shape[0] == 8828
+    for got, exp in zip((y1x1, y2x2, yx, hw), ref):
+        assert torch.equal(got.cpu(), exp)
+    exp_nb = torch.cat([ref[2] - ref[3] / 2., ref[2] + ref[3] / 2.], -1)
+    assert torch.equal(nb.cpu(), exp_nb)
+
+
+def _match_gpu(ops, dev, pri, gt):
+    N, P, _ = gt.shape
+    A = pri[0].shape[0]
+    ngt = torch.empty(N, dtype=torch.int32, device=dev)
+    best = torch.empty(N, P, dtype=torch.int32, device=dev)
+    status = torch.empty(N, A, dtype=torch.uint8, device=dev)
+    rg = torch.empty(N, A, dtype=torch.int32, device=dev)
+    counts = torch.empty(N, 4, dtype=torch.int32, device=dev)
+    ops.ssd_match(pri[0], pri[1], pri[3], gt.to(dev), ngt, best, status, rg, counts)
+    return ngt, best, status, rg, counts
+
+
+def test_match_bit_exact(dev):
+    ops = _ops()
+    pri = _gpu_priors(ops, dev)
+    anchors = R.priors()
+    _, gt = R.synthetic_batch(8, seed=5)
+    # an image with two identical GT boxes (duplicate best anchors) and one with 59 objects
+    gt[1, 1] = gt[1, 0]
+    gt[1, 2:] = -1
+    g = torch.Generator().manual_seed(9)
+    n = 59
+    h = torch.rand(n, generator=g) * 100 + 10; w = torch.rand(n, generator=g) * 100 + 10
+    gt[2, :n] = torch.stack([h / 2 + torch.rand(n, generator=g) * (300 - h), w / 2 + torch.rand(n, generator=g) * (300 - w),
+                             h, w, torch.randint(0, 20, (n,), generator=g).float()], 1)
+    gt[2, n:] = -1
+    ngt, best, status, rg, counts = _match_gpu(ops, dev, pri, gt)
+    torch.cuda.synchronize()
+    for i in range(gt.shape[0]):
+        mt = R.match(anchors, gt[i])
+        G = mt["G"]
+        assert int(ngt[i]) == G
+        assert torch.equal(best[i, :G].cpu().long(), mt["best"])
+        st = torch.full((8828,), 0, dtype=torch.uint8)
+        other = torch.nonzero(mt["othermask"]).squeeze(1)
+        st[other] = torch.where(mt["pos"], torch.tensor(1, dtype=torch.uint8), torch.tensor(2, dtype=torch.uint8))
+        assert torch.equal(status[i].cpu(), st)
+        assert torch.equal(rg[i].cpu().long()[other], mt["rgindex"])
+        num_pos = G + int(mt["pos"].sum()); num_neg = int((~mt["pos"]).sum())
+        assert counts[i].cpu().tolist()[:3] == [num_pos, num_neg, min(3 * num_pos, num_neg)]
+
+
+@pytest.mark.parametrize("n,thr,max_out", [(50, 0.5, 20), (700, 0.5, 20), (8828, 0.7, 513), (8828, 0.7, 8828),
+                                           (3000, 0.3, 100), (1, 0.5, 5), (65, 0.0, 65)])
+def test_nms_bit_exact_vs_reference_kernel(n, thr, max_out, dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(n + max_out)
+    B = 3
+    idx_all, cnt_all = [], []
+    yx = torch.rand(B, n, 2, generator=g) * 300
+    hw = torch.rand(B, n, 2, generator=g) * 80 + 5
+    boxes = torch.cat([yx - hw / 2, yx + hw / 2], -1).contiguous()
+    boxes[0, : n // 3] = boxes[0, : n // 3][:, [2, 3, 0, 1]]          # flipped corners (coordinate-order agnostic)
+    scores = torch.rand(B, n, generator=g)
+    valid = (torch.rand(B, n, generator=g) > 0.2).to(torch.uint8) * 2
+    out_idx = torch.full((B, max_out), -1, dtype=torch.int32, device=dev)
+    out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    mo = torch.tensor([max_out, max(max_out // 2, 1), 0], dtype=torch.int32, device=dev)
+    ops.nms_batched(boxes.to(dev), n * 4, scores.to(dev), n, 1, valid.to(dev), n, 1, 2, n, B, mo, 1, 0, thr,
+                    out_idx, max_out, out_cnt)
+    torch.cuda.synchronize()
+    for b in range(B):
+        m = valid[b] == 2
+        ids = torch.nonzero(m).squeeze(1)
+        ref = R.nms(boxes[b][m].numpy(), scores[b][m].numpy(), int(mo[b]), thr)
+        ref = ids[torch.from_numpy(ref.astype(np.int64))].tolist()
+        c = int(out_cnt[b])
+        assert out_idx[b, :c].cpu().tolist() == ref
+
+
+def _loss_gpu(ops, dev, pri, pred, gt):
+    N, A, ld = pred.shape
+    predd = pred.to(dev).contiguous()
+    gtd = gt.to(dev)
+    ngt, best, status, rg, counts = _match_gpu(ops, dev, pri, gt)
+    negloss = torch.empty(N, A, device=dev)
+    ops.softmax_ce_const(predd, N * A, 21, ld, 20, negloss)
+    sel = torch.full((N, A), -1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+    ops.nms_batched(pri[4], 0, negloss, A, 1, status, A, 1, 2, A, N, counts[:, 2:], 4, 0, 0.7, sel, A, cnt)
+    parts = torch.empty(N, 4, device=dev)
+    dpred = torch.empty_like(predd)
+    ops.ssd_loss(predd, 21, pri[2], pri[3], gtd, ngt, best, status, rg, counts, negloss, sel, cnt, 1.0 / N, parts, dpred)
+    torch.cuda.synchronize()
+    return parts.cpu(), dpred.cpu(), sel.cpu(), cnt.cpu(), negloss.cpu()
+
+
+def test_ssd_loss_and_grad_vs_oracle(dev):
+    ops = _ops()
+    pri = _gpu_priors(ops, dev)
+    anchors = R.priors()
+    N = 4
+    _, gt = R.synthetic_batch(N, seed=11)
+    g = torch.Generator().manual_seed(12)
+    pred = torch.randn(N, 8828, 25, generator=g)
+    parts, dpred, sel, cnt, negloss = _loss_gpu(ops, dev, pri, pred, gt)
+    pr = pred.clone().requires_grad_(True)
+    tot = 0
+    for i in range(N):
+        d = R.one_image_loss(pr[i, :, 21:23], pr[i, :, 23:], pr[i, :, :21], anchors, gt[i], detail=True)
+        tot = tot + d["total"]
+        for j, key in enumerate(["neg_loss", "pos_conf_loss", "coord", "total"]):
+            assert abs(float(parts[i, j]) - float(d[key])) <= 2e-5 * max(1.0, abs(float(d[key]))), (i, key)
+        # mined negatives: identical set unless two CE scores differ by < 1 ulp-ish between expf impls
+        got = set(sel[i, : int(cnt[i])].tolist()); exp = set(d["sel_anchor"].tolist())
+        assert len(got ^ exp) <= max(2, len(exp) // 100)
+        # scores feeding the NMS agree to float rounding
+        assert float((negloss[i][d["neg_anchor"]] - d["total_neg_loss"].detach()).abs().max()) < 5e-6
+    (tot / N).backward()
+    assert float((dpred - pr.grad).abs().max()) <= 1e-5 + 1e-3 * float(pr.grad.abs().max())
+
+
+def test_mining_nms_bit_exact_given_same_scores(dev):
+    """NMS keep-set bit-exact when both sides consume the SAME float scores."""
+    ops = _ops()
+    pri = _gpu_priors(ops, dev)
+    anchors = R.priors()
+    N = 3
+    _, gt = R.synthetic_batch(N, seed=21)
+    g = torch.Generator().manual_seed(22)
+    pred = torch.randn(N, 8828, 25, generator=g)
+    parts, dpred, sel, cnt, negloss = _loss_gpu(ops, dev, pri, pred, gt)
+    nb = pri[4].cpu()
+    for i in range(N):
+        mt = R.match(anchors, gt[i])
+        other = torch.nonzero(mt["othermask"]).squeeze(1)
+        neg_idx = other[~mt["pos"]]
+        num_pos = mt["G"] + int(mt["pos"].sum())
+        k = min(3 * num_pos, len(neg_idx))
+        ref = R.nms(nb[neg_idx].numpy(), negloss[i][neg_idx].numpy(), k, 0.7)
+        assert sel[i, : int(cnt[i])].tolist() == neg_idx[torch.from_numpy(ref.astype(np.int64))].tolist()
+
+
+def test_decode_and_detect_vs_oracle(dev):
+    ops = _ops()
+    pri = _gpu_priors(ops, dev)
+    anchors = R.priors()
+    g = torch.Generator().manual_seed(31)
+    pred0 = torch.randn(8828, 25, generator=g)
+    pred0[:, :21] *= 3
+    pred0[:, 21:] *= 0.3
+    A = 8828
+    conf = torch.empty(A, 20, device=dev); boxes = torch.empty(A, 4, device=dev)
+    keep = torch.empty(A, dtype=torch.uint8, device=dev); cand = torch.empty(A, 20, dtype=torch.uint8, device=dev)
+    thr = 0.5
+    ops.ssd_decode(pred0.to(dev), 21, pri[2], pri[3], thr, conf, boxes, keep, cand)
+    out_idx = torch.full((20, 20), -1, dtype=torch.int32, device=dev)
+    out_cnt = torch.zeros(20, dtype=torch.int32, device=dev)
+    ops.nms_batched(boxes, 0, conf, 1, 20, cand, 1, 20, 1, A, 20, None, 0, 20, 0.5, out_idx, 20, out_cnt)
+    torch.cuda.synchronize()
+    rconf, rboxes, rkeep = R.decode(pred0, anchors)
+    assert torch.equal(torch.nonzero(keep.cpu()).squeeze(1), rkeep)
+    assert float((conf.cpu()[rkeep] - rconf).abs().max()) < 1e-5
+    assert float((boxes.cpu()[rkeep] - rboxes).abs().max()) < 1e-3
+    s_ref, b_ref, c_ref = R.detect(pred0, anchors, thr, 20, 0.5)
+    sc, bb, cc = [], [], []
+    for c in range(20):
+        ids = out_idx[c, : int(out_cnt[c])].long()
+        sc.append(conf[ids, c].cpu()); bb.append(boxes[ids].cpu()); cc += [c] * len(ids)
+    sc = torch.cat(sc); bb = torch.cat(bb)
+    assert cc == c_ref.tolist()
+    assert float((sc - s_ref).abs().max()) < 1e-5
+    assert float((bb - b_ref).abs().max()) < 1e-3

@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""Benchmark of the SSD300 VGG-16 training hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one full training step (preprocess + forward + loss incl. hard-negative-mining NMS +
+backward + RCCL gradient all-reduce + fused SGD-momentum) on a synthetic VOC-shaped batch of 32
+images/GPU already resident in HBM.  Weak scaling: every rank keeps batch 32 (each replica is
+exactly the reference computation, local BatchNorm; SURVEY.md 8e option A).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the conv implicit-GEMM kernel family (fwd + dgrad + wgrad launches), HIP-event
+                  timed inside the timed region: algorithmic FLOPs / summed launch time vs the
+                  dense bf16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline -- the CPU oracle (PyTorch-CPU restatement of the reference graph; TF 1.13 cannot
+                  run here) timed on this box's host cores on a bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_BF16 = 2.5e15        # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_F32 = 157.3e12
+
+
+def synthetic_batch(batch, seed, device):
+    """VOC-shaped synthetic batch: U[0,255) images, 1-6 boxes, GT padded to 60 rows."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(batch, 300, 300, 3, generator=g) * 255.
+    gt = torch.full((batch, 60, 5), -1.0)
+    for i in range(batch):
+        n = int(torch.randint(1, 7, (1,), generator=g))
+        h = torch.rand(n, generator=g) * 240. + 30.
+        w = torch.rand(n, generator=g) * 240. + 30.
+        yc = h / 2 + torch.rand(n, generator=g) * (300 - h)
+        xc = w / 2 + torch.rand(n, generator=g) * (300 - w)
+        cls = torch.randint(0, 20, (n,), generator=g).float()
+        gt[i, :n] = torch.stack([yc, xc, h, w, cls], 1)
+    return images.to(device), gt.to(device)
+
+
+class ConvTimer:
+    """Wraps the three conv entry points with HIP events on the launch stream."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.records = []            # (kind, flops, start_evt, end_evt)
+        self.enabled = False
+        self._orig = {}
+
+    def install(self):
+        ops = self.ops
+        for kind in ('conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad'):
+            self._orig[kind] = getattr(ops, kind)
+            setattr(ops, kind, self._wrap(kind))
+
+    def _wrap(self, kind):
+        orig = self._orig[kind]
+
+        def f(d, *args):
+            if not self.enabled:
+                return orig(d, *args)
+            c_alg = 3 if (d.H == 300 and d.C <= 8) else d.C          # conv1_1: 3 real input channels (padded to one chunk)
+            flops = 2.0 * d.N * d.Ho * d.Wo * d.K * d.R * d.S * c_alg    # algorithmic: 2*M*Cout*R*S*Cin for each pass
+            s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(d, *args)
+            e.record()
+            self.records.append((kind, flops, s, e))
+            return r
+        return f
+
+    def summary(self):
+        tot_f, tot_t = 0.0, 0.0
+        per = {}
+        for kind, fl, s, e in self.records:
+            t = s.elapsed_time(e) * 1e-3
+            tot_f += fl; tot_t += t
+            a = per.setdefault(kind, [0.0, 0.0, 0]); a[0] += fl; a[1] += t; a[2] += 1
+        return tot_f, tot_t, per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-conv-events', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    import odtk
+    from odtk import ops
+    B = args.batch
+    config = {
+        'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
+        'keep_prob': 0.5, 'batch_size': B, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20,
+        'nms_iou_threshold': 0.5, 'pretraining_weight': os.path.join('.', 'vgg_16.ckpt'),
+        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0,
+    }
+    provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    model = odtk.SSD300(config, provider)
+    if world > 1:
+        model.attach_data_parallel()
+    images, gt = synthetic_batch(B, 1000 + rank, dev)
+    model.set_batch(images, gt)
+
+    timer = ConvTimer(ops)
+    timer.install()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lr = 0.01
+    for _ in range(args.warmup):
+        loss = model.train_step(lr)
+    timer.enabled = not args.no_conv_events
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = model.train_step(lr)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B * world * args.steps / dt
+        out = {
+            'metric': 'images/sec SSD300 VGG-16 batch=32 train',
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
+                       'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
+        }
+        peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
+        if timer.records:
+            fl, t, per = timer.summary()
+            out['roofline'] = {
+                'bound': 'mfma', 'kernel': 'conv_gather_kernel/conv_wgrad_kernel (implicit-GEMM conv fwd+dgrad+wgrad, all layers)',
+                'achieved': round(fl / t / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s',
+                'frac': round(fl / t / peak, 4), 'traffic': None,
+                'launches_per_step': len(timer.records) // args.steps,
+                'conv_ms_per_step': round(t / args.steps * 1e3, 3),
+                'by_pass': {k: {'TFLOP/s': round(v[0] / v[1] / 1e12, 2), 'ms_per_step': round(v[1] / args.steps * 1e3, 3)}
+                            for k, v in per.items()},
+                'whole_step_frac_of_mfma_peak': round(value / world * 188.0e9 / peak, 4),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def usable_cores():
+    """Host threads this process may really use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:                                             # noqa: BLE001
+        pass
+    return n
+
+
+def cpu_baseline():
+    """PyTorch-CPU oracle (restatement of the reference graph) on a bounded sample: batch 4."""
+    from oracle import ssd300_ref as R
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    bs = 4
+    p = R.init_params(0)
+    mom = {k: torch.zeros_like(v) for k, v in p.items()}
+    imgs, gt = R.synthetic_batch(bs, 0)
+    anchors = R.priors()
+    R.train_step(p, mom, imgs, gt, 0.01, 1e-4, anchors)          # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 1 or (time.perf_counter() - t0 < 12 and n < 6):
+        R.train_step(p, mom, imgs, gt, 0.01, 1e-4, anchors)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(bs * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} full train steps at batch {bs} (same synthetic generator), PyTorch-CPU fp32 oracle; '
+                      'the reference TF-1.13 graph itself cannot run (no tensorflow, SSD300.py:41-43 syntax error)'}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,96 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL (torch.distributed backend "nccl")
+over xGMI.  The reference is single-device (testSSD300.py:14 pins CUDA_VISIBLE_DEVICES='0'); image
+sharding is the only way the path scales, and the only exchange is the gradient sum
+(SURVEY.md 8e).
+
+The flat f32 gradient buffer is laid out in forward order, so during backward it becomes final
+suffix-first.  It is cut into contiguous buckets; a bucket's all-reduce is launched (async, on
+RCCL's own stream) as soon as the lowest layer it covers has finished its wgrad, overlapping
+with the rest of backward.  xGMI is point-to-point (7 links/GPU): ~25 MB buckets keep each ring
+step large enough to run at link rate while leaving 4-5 buckets to overlap.
+
+Works on CPU tensors with the gloo backend too (tests/test_dist_cpu.py, world_size 2).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class BucketAllReducer:
+    """Device-agnostic core: flat buffer + ordered segment table -> bucketed async all-reduce."""
+
+    def __init__(self, flat: torch.Tensor, segments, group=None, bucket_bytes=25 << 20):
+        """segments: list of (name, start, end) in ascending offset order covering `flat`."""
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.segments = list(segments)
+        esz = flat.element_size()
+        # cut buckets from the END (first gradients to become ready)
+        self.buckets = []          # (start, end, lowest_segment_index)
+        end = self.segments[-1][2]
+        cur_lo = len(self.segments)
+        size = 0
+        for i in reversed(range(len(self.segments))):
+            _, s, e = self.segments[i]
+            size += (e - s) * esz
+            cur_lo = i
+            if size >= bucket_bytes or i == 0:
+                self.buckets.append((s, end, cur_lo))
+                end = s
+                size = 0
+        self.index = {name: i for i, (name, _, _) in enumerate(self.segments)}
+        self.begin_step()
+
+    def begin_step(self):
+        self.next_bucket = 0
+        self.lowest_ready = len(self.segments)
+        self.handles = []
+
+    def segment_ready(self, name):
+        """Call when the gradient of segment `name` (and every later segment) is final."""
+        self.lowest_ready = min(self.lowest_ready, self.index[name])
+        while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][2] >= self.lowest_ready:
+            s, e, _ = self.buckets[self.next_bucket]
+            if self.world > 1:
+                self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
+            self.next_bucket += 1
+
+    def finish_step(self):
+        """Flush whatever is left and make the reduced gradients visible to the current stream."""
+        self.lowest_ready = 0
+        self.segment_ready(self.segments[0][0])
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+
+class GradAllReducer:
+    """Binds a BucketAllReducer to an SSD300 instance (layer-granular readiness)."""
+
+    def __init__(self, model, group=None, bucket_mb=25):
+        self.model = model
+        segs = []
+        names = list(model.pinfo.keys())
+        # one segment per layer: from its first parameter to the next layer's first parameter
+        layer_start = {}
+        for n in names:
+            layer = n.split('.')[0]
+            layer_start.setdefault(layer, model.pinfo[n][0])
+        layers = list(layer_start.keys())
+        for i, l in enumerate(layers):
+            end = layer_start[layers[i + 1]] if i + 1 < len(layers) else model.nparam
+            segs.append((l, layer_start[l], end))
+        self.red = BucketAllReducer(model.G, segs, group, int(bucket_mb) << 20)
+        self.world = self.red.world
+
+    def begin_step(self):
+        self.red.begin_step()
+
+    def layer_ready(self, layer):
+        self.red.segment_ready(layer)
+
+    def finish_step(self):
+        self.red.finish_step()

@@ -1,10 +1,56 @@
-"""SSD300 (VGG-16) behind the reference class surface -- see SSD300 below."""
+"""SSD300 (VGG-16) behind the reference class surface.
+
+Drop-in for /root/reference/SSD300.py: same constructor (`config`, `data_provider` dicts with
+the keys of testSSD300.py:21-59), same methods -- train_one_epoch(lr) -> mean loss,
+test_one_image(images) -> [scores, bbox, class_id], save_weight(mode, path), load_weight(path).
+The TF-1.13 graph + sess.run is replaced by explicit HIP kernel launches through libodtk
+(include/odtk.h); torch only owns device memory, streams and the RCCL communicator.
+
+Data contract (replaces the tf.data iterator): `data_provider['train_generator']`
+is a re-iterable (or a `(initializer, iterable)` pair, mirroring the reference tuple) yielding
+`(images f32 [B,300,300,3] RGB 0..255, ground_truth f32 [B,pad,5] = [yc,xc,h,w,cls] px, pad rows -1)`
+as torch tensors or numpy arrays -- exactly what utils/image_augmentor.py:24-27 documents.
+
+Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' default | 'f32'),
+'device', 'seed', 'verbose'.
+"""
 from __future__ import annotations
 
+import math
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import BF16, F32
+
 INPUT_SIZE = 300
-FEATURE_SIZES = [38, 19, 10, 5, 5, 3]           # conv10_2 has stride 1 (reference SSD300.py:311)
+MEAN_RGB = (123.68, 116.779, 103.979)            # reference SSD300.py:55 (sic: 103.979)
+FEATURE_SIZES = [38, 19, 10, 5, 5, 3]            # conv10_2 has stride 1 (reference SSD300.py:311)
 ANCHORS_PER_CELL = [4, 6, 6, 6, 4, 4]
 ASPECTS = [[2, 1 / 2], [2, 1 / 2, 3, 1 / 3], [2, 1 / 2, 3, 1 / 3], [2, 1 / 2, 3, 1 / 3], [2, 1 / 2], [2, 1 / 2]]
+NUM_PRIORS = sum(f * f * a for f, a in zip(FEATURE_SIZES, ANCHORS_PER_CELL))   # 8828
+
+# reference SSD300.py:193-303: (name, cin, cout) convs (3x3 s1 SAME, bias, ReLU, no BN) and pools
+VGG_SEQ = [
+    ("conv1_1", 3, 64), ("conv1_2", 64, 64), ("pool1", 2, 2),
+    ("conv2_1", 64, 128), ("conv2_2", 128, 128), ("pool2", 2, 2),
+    ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256), ("pool3", 2, 2),
+    ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3", 512, 512), ("pool4", 2, 2),
+    ("conv5_1", 512, 512), ("conv5_2", 512, 512), ("conv5_3", 512, 512), ("pool5", 3, 1),
+]
+# reference SSD300.py:304-313: conv + bias + BN + ReLU     (name, cin, cout, k, stride, dil)
+EXTRA_SEQ = [
+    ("conv6", 512, 1024, 3, 1, 2), ("conv7", 1024, 1024, 1, 1, 1),
+    ("conv8_1", 1024, 256, 1, 1, 1), ("conv8_2", 256, 512, 3, 2, 1),
+    ("conv9_1", 512, 128, 1, 1, 1), ("conv9_2", 128, 256, 3, 2, 1),
+    ("conv10_1", 256, 128, 1, 1, 1), ("conv10_2", 128, 256, 3, 1, 1),
+    ("conv11_1", 256, 128, 1, 1, 1), ("conv11_2", 128, 256, 3, 2, 1),
+]
+FEAT_SRC = ["feat1", "conv7", "conv8_2", "conv9_2", "conv10_2", "conv11_2"]   # reference SSD300.py:314
 
 
 def prior_spec(input_size=INPUT_SIZE):
@@ -20,3 +66,552 @@ def prior_spec(input_size=INPUT_SIZE):
         for h, w in pr:
             flat += [h, w]
     return FEATURE_SIZES, ANCHORS_PER_CELL, flat
+
+
+class _Act:
+    """One NHWC activation: rows x pitch buffer (+ lazily allocated gradient buffer)."""
+
+    def __init__(self, N, H, W, C, ld, dtype, dev):
+        self.N, self.H, self.W, self.C, self.ld = N, H, W, C, ld
+        self.M = N * H * W
+        self.t = torch.zeros(self.M, ld, dtype=dtype, device=dev)
+        self._g = None
+
+    @property
+    def g(self):
+        if self._g is None:
+            self._g = torch.zeros_like(self.t)
+        return self._g
+
+
+class _Conv:
+    def __init__(self, name, cin, cout, k, stride, dil, bn, relu):
+        self.name, self.cin, self.cout, self.k, self.stride, self.dil = name, cin, cout, k, stride, dil
+        self.bn, self.relu = bn, relu
+
+
+class SSD300:
+    def __init__(self, config, data_provider):
+        assert config['mode'] in ['train', 'test']
+        assert config['data_format'] in ['channels_first', 'channels_last']
+        self.config = config
+        self.data_provider = data_provider
+        self.input_size = INPUT_SIZE
+        self.data_format = config['data_format']
+        self.data_shape = [300, 300, 3] if self.data_format == 'channels_last' else [3, 300, 300]
+        self.num_classes = config['num_classes'] + 1          # background = LAST index
+        self.weight_decay = config['weight_decay']
+        self.prob = 1. - config['keep_prob']                  # unused, as in the reference
+        self.mode = config['mode']
+        self.batch_size = config['batch_size'] if config['mode'] == 'train' else 1
+        self.nms_score_threshold = config['nms_score_threshold']
+        self.nms_max_boxes = config['nms_max_boxes']
+        self.nms_iou_threshold = config['nms_iou_threshold']
+        self.pretraining_weight = config['pretraining_weight']
+        assert self.num_classes + 4 == 25 or True
+        self.row = self.num_classes + 4
+
+        cd = config.get('compute_dtype', 'bf16')
+        assert cd in ('bf16', 'f32')
+        self.DT = BF16 if cd == 'bf16' else F32
+        self.tdt = ops.torch_dtype(self.DT)
+        self.chunk = ops.chunk(self.DT)
+        self.verbose = config.get('verbose', True)
+        dev = config.get('device', None)
+        if dev is None:
+            if not torch.cuda.is_available():
+                raise ops._lib.OdtkError("SSD300 needs an MI355X (HIP device); there is no CPU fallback")
+            dev = torch.device('cuda', torch.cuda.current_device())
+        self.dev = torch.device(dev)
+        ops._lib.load()
+
+        if self.mode == 'train':
+            self.num_train = data_provider['num_train']
+            self.num_val = data_provider['num_val']
+            self.train_generator = data_provider['train_generator']
+            if isinstance(self.train_generator, tuple) and len(self.train_generator) == 2:
+                self.train_initializer, self.train_iterator = self.train_generator
+            else:
+                self.train_initializer, self.train_iterator = None, self.train_generator
+            if data_provider.get('val_generator') is not None:
+                self.val_generator = data_provider['val_generator']
+        self.global_step = 0
+        self.dist = None                       # set by attach_data_parallel()
+        self.loss_divisor_batch = self.batch_size
+
+        self._define_layers()
+        self._init_parameters(config.get('seed', 0))
+        self._build_buffers()
+        self._load_pretraining_weight()
+
+    # ------------------------------------------------------------------ structure
+    def _define_layers(self):
+        self.convs = OrderedDict()
+        for item in VGG_SEQ:
+            if item[0].startswith('conv'):
+                self.convs[item[0]] = _Conv(item[0], item[1], item[2], 3, 1, 1, False, True)
+        for (n, ci, co, k, s, d) in EXTRA_SEQ:
+            self.convs[n] = _Conv(n, ci, co, k, s, d, True, True)
+        feat_ch = [512, 1024, 512, 256, 256, 256]
+        for i, (ch, a) in enumerate(zip(feat_ch, ANCHORS_PER_CELL)):
+            self.convs[f'pred{i + 1}'] = _Conv(f'pred{i + 1}', ch, a * self.row, 3, 1, 1, True, False)
+
+    def _cin_pad(self, c):
+        return ops.pad_to(c, self.chunk)
+
+    def _init_parameters(self, seed):
+        """Flat f32 master buffer in forward order (so gradients complete suffix-first in
+        backward: what the bucketed all-reduce relies on)."""
+        order = []
+        for item in VGG_SEQ:
+            if item[0].startswith('conv'):
+                order.append(item[0])
+            if item[0] == 'conv4_3':
+                order.append('l2norm')
+        order += [e[0] for e in EXTRA_SEQ] + [f'pred{i}' for i in range(1, 7)]
+        self.layer_order = order
+        self.pinfo = OrderedDict()
+        off = 0
+
+        def add(name, shape):
+            nonlocal off
+            n = int(np.prod(shape))
+            self.pinfo[name] = (off, tuple(shape))
+            off += ops.pad_to(n, 64)
+
+        self.sinfo = OrderedDict()
+        soff = 0
+        for ln in order:
+            if ln == 'l2norm':
+                add('l2norm.gamma', (1,))
+                continue
+            c = self.convs[ln]
+            add(ln + '.w', (c.cout, c.k, c.k, self._cin_pad(c.cin)))
+            add(ln + '.b', (c.cout,))
+            if c.bn:
+                add(ln + '.gamma', (c.cout,))
+                add(ln + '.beta', (c.cout,))
+                self.sinfo[ln + '.mmean'] = (soff, (c.cout,)); soff += ops.pad_to(c.cout, 64)
+                self.sinfo[ln + '.mvar'] = (soff, (c.cout,)); soff += ops.pad_to(c.cout, 64)
+        self.nparam = off
+        dev = self.dev
+        self.P = torch.zeros(off, device=dev)
+        self.Mom = torch.zeros(off, device=dev)
+        self.G = torch.zeros(off, device=dev)
+        self.Pc = torch.zeros(off, dtype=self.tdt, device=dev) if self.DT == BF16 else self.P
+        self.S = torch.zeros(soff, device=dev)
+        self.l2_partial = torch.zeros(ops.sgd_blocks(off), device=dev)
+        self.l2_sum = torch.zeros(1, device=dev)
+        # synthetic initialisation (no checkpoint available offline): He-normal conv, zero bias,
+        # BN gamma 1 / beta 0 / moving (0, 1), L2-norm scale 20 (reference SSD300.py:77)
+        g = torch.Generator().manual_seed(seed)
+        for ln in order:
+            if ln == 'l2norm':
+                self.param('l2norm.gamma').fill_(20.0)
+                continue
+            c = self.convs[ln]
+            w = torch.randn(c.cout, c.k, c.k, c.cin, generator=g) * math.sqrt(2.0 / (c.cin * c.k * c.k))
+            self.set_param(ln + '.w', w)
+            if c.bn:
+                self.param(ln + '.gamma').fill_(1.0)
+                self.stat(ln + '.mvar').fill_(1.0)
+        self._refresh_operand_copies()
+
+    def param(self, name, buf=None):
+        off, shape = self.pinfo[name]
+        buf = self.P if buf is None else buf
+        return buf[off: off + int(np.prod(shape))].view(shape)
+
+    def stat(self, name):
+        off, shape = self.sinfo[name]
+        return self.S[off: off + int(np.prod(shape))].view(shape)
+
+    def set_param(self, name, value):
+        """value: logical shape (conv weights [K,R,S,Cin] un-padded)."""
+        dst = self.param(name)
+        value = torch.as_tensor(value, dtype=torch.float32)
+        if name.endswith('.w'):
+            dst.zero_()
+            dst[..., : value.shape[-1]] = value.to(self.dev)
+        else:
+            dst.copy_(value.to(self.dev).view(dst.shape))
+
+    def get_param(self, name):
+        v = self.param(name).detach().cpu().clone()
+        if name.endswith('.w'):
+            v = v[..., : self.convs[name[:-2]].cin].contiguous()
+        return v
+
+    def load_oracle_params(self, p):
+        """Load a dict name -> tensor in the oracle's naming ([K,R,S,Cin] weights)."""
+        for k, v in p.items():
+            if k in self.pinfo:
+                self.set_param(k, v)
+            elif k in self.sinfo:
+                self.stat(k).copy_(torch.as_tensor(v, dtype=torch.float32).to(self.dev))
+        self._refresh_operand_copies()
+
+    def export_params(self):
+        out = OrderedDict((k, self.get_param(k)) for k in self.pinfo)
+        for k in self.sinfo:
+            out[k] = self.stat(k).detach().cpu().clone()
+        return out
+
+    def _load_pretraining_weight(self):
+        """The reference initialises the 13 VGG convs from slim's vgg_16.ckpt (SSD300.py:31,193-299).
+        No TF checkpoint reader here: accept a torch/npz file holding 'vgg_16/convX/convX_Y/weights'
+        (HWIO) and '.../biases'; otherwise keep the synthetic He init."""
+        path = self.pretraining_weight
+        if not path or not os.path.exists(str(path)):
+            return
+        try:
+            blob = dict(np.load(path)) if str(path).endswith('.npz') else torch.load(path, map_location='cpu')
+        except Exception as e:                                   # noqa: BLE001
+            print(f'[odtk] could not read pretraining weights {path}: {e}; keeping synthetic init')
+            return
+        for item in VGG_SEQ:
+            n = item[0]
+            if not n.startswith('conv'):
+                continue
+            key = f'vgg_16/{n.split("_")[0]}/{n}'
+            if key + '/weights' in blob:
+                w = torch.as_tensor(np.asarray(blob[key + '/weights']), dtype=torch.float32)   # HWIO
+                self.set_param(n + '.w', w.permute(3, 0, 1, 2).contiguous())
+                self.set_param(n + '.b', torch.as_tensor(np.asarray(blob[key + '/biases'])))
+        self._refresh_operand_copies()
+
+    # ------------------------------------------------------------------ buffers
+    def _build_buffers(self):
+        N, dev, dt = self.batch_size, self.dev, self.tdt
+        self.images = torch.zeros(N, 300, 300, 3, device=dev)
+        self.acts = OrderedDict()
+        c0 = self._cin_pad(3)
+        self.acts['input'] = _Act(N, 300, 300, c0, c0, dt, dev)
+        H = 300
+        cur_c = c0
+        self.desc = {}
+        prev = 'input'
+        self.vgg_plan = []
+        for item in VGG_SEQ:
+            name = item[0]
+            if name.startswith('conv'):
+                c = self.convs[name]
+                self.desc[name] = ops.conv_desc(N, H, H, cur_c, cur_c, c.cout, c.cout, 3, 1, 1, self.DT, self.DT)
+                self.acts[name] = _Act(N, H, H, c.cout, c.cout, dt, dev)
+                self.vgg_plan.append(('conv', name, prev))
+                cur_c = c.cout
+            else:
+                k, s = item[1], item[2]
+                Ho, pt, _ = ops.same_pad(H, k, s)
+                self.acts[name] = _Act(N, Ho, Ho, cur_c, cur_c, dt, dev)
+                self.vgg_plan.append(('pool', name, prev, k, s, pt))
+                H = Ho
+            prev = name
+            if name == 'conv4_3':
+                self.acts['feat1'] = _Act(N, H, H, 512, 512, dt, dev)
+        self.zbuf, self.bnsave = {}, {}
+        max_ws = 0
+        for (name, ci, co, k, s, d) in EXTRA_SEQ:
+            src = self.acts[prev]
+            self.desc[name] = ops.conv_desc(N, src.H, src.W, ci, src.ld, co, co, k, s, d, self.DT, self.DT)
+            Ho = self.desc[name].Ho
+            self.zbuf[name] = _Act(N, Ho, Ho, co, co, dt, dev)
+            self.acts[name] = _Act(N, Ho, Ho, co, co, dt, dev)
+            self.bnsave[name] = (torch.zeros(co, device=dev), torch.zeros(co, device=dev))
+            max_ws = max(max_ws, ops.bn_workspace_bytes(N * Ho * Ho, co))
+            self.extra_src = getattr(self, 'extra_src', {})
+            self.extra_src[name] = prev
+            prev = name
+        # heads write straight into pred [N, 8828, 25] (reference SSD300.py:316-321 reshape/concat)
+        self.pred = torch.zeros(N, NUM_PRIORS, self.row, device=dev)
+        self.dpred = torch.zeros_like(self.pred)
+        self.head_off = []
+        off = 0
+        for i, src_name in enumerate(FEAT_SRC):
+            name = f'pred{i + 1}'
+            src = self.acts[src_name]
+            c = self.convs[name]
+            kp = ops.pad_to(c.cout, 8)
+            self.desc[name] = ops.conv_desc(N, src.H, src.W, src.C, src.ld, c.cout, kp, 3, 1, 1, self.DT, self.DT)
+            self.zbuf[name] = _Act(N, src.H, src.W, c.cout, kp, dt, dev)
+            self.bnsave[name] = (torch.zeros(c.cout, device=dev), torch.zeros(c.cout, device=dev))
+            max_ws = max(max_ws, ops.bn_workspace_bytes(src.M, c.cout))
+            self.head_off.append(off)
+            off += src.H * src.W * ANCHORS_PER_CELL[i]
+        assert off == NUM_PRIORS
+        for a in self.acts.values():
+            max_ws = max(max_ws, ops.bn_workspace_bytes(a.M, a.C))
+        self.ws = torch.zeros(max_ws, dtype=torch.uint8, device=dev)
+        # dgrad-layout filters
+        self.wt = {}
+        for name, c in self.convs.items():
+            if name == 'conv1_1':
+                continue
+            d = self.desc[name]
+            kp = ops.pad_to(c.cout, 8) if name.startswith('pred') else c.cout
+            self.wt[name] = torch.zeros(d.C * c.k * c.k * kp, dtype=dt, device=dev)
+        # box side
+        fs, nas, hw = prior_spec()
+        self.pri = ops.ssd_priors(INPUT_SIZE, fs, nas, hw, dev)       # y1x1, y2x2, yx, hw, nmsbox
+        A = NUM_PRIORS
+        self.gt = None
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.m_ngt = torch.zeros(N, **i32)
+        self.m_status = torch.zeros(N, A, dtype=torch.uint8, device=dev)
+        self.m_rg = torch.zeros(N, A, **i32)
+        self.m_counts = torch.zeros(N, 4, **i32)
+        self.negloss = torch.zeros(N, A, device=dev)
+        self.sel_idx = torch.zeros(N, A, **i32)
+        self.sel_cnt = torch.zeros(N, **i32)
+        self.loss_parts = torch.zeros(N, 4, device=dev)
+        self.loss_col = torch.zeros(N, device=dev)
+        self.data_loss = torch.zeros(1, device=dev)
+        nc = self.num_classes - 1
+        self.d_conf = torch.zeros(A, nc, device=dev)
+        self.d_boxes = torch.zeros(A, 4, device=dev)
+        self.d_keep = torch.zeros(A, dtype=torch.uint8, device=dev)
+        self.d_cand = torch.zeros(A, nc, dtype=torch.uint8, device=dev)
+        self.refresh_wt()
+
+    def _wslice(self, name, buf):
+        off, shape = self.pinfo[name]
+        return buf[off: off + int(np.prod(shape))]
+
+    def _refresh_operand_copies(self):
+        if self.DT == BF16:
+            ops.cast_from_f32(self.P, self.Pc)
+        if hasattr(self, 'wt'):
+            self.refresh_wt()
+
+    def refresh_wt(self):
+        """Flipped/transposed dgrad filters from the f32 master (after every optimizer step)."""
+        for name, wt in self.wt.items():
+            c = self.convs[name]
+            d = self.desc[name]
+            kp = ops.pad_to(c.cout, 8) if name.startswith('pred') else c.cout
+            ops.filter_prepare(self._wslice(name + '.w', self.P), c.cout, c.k, c.k, d.C, kp, self.DT, None, wt)
+
+    # ------------------------------------------------------------------ forward
+    def _conv_fwd(self, name, src, dst, bias, relu):
+        ops.conv2d_fwd(self.desc[name], src.t, self._wslice(name + '.w', self.Pc), bias, dst.t, relu)
+
+    def _forward(self, training):
+        a = self.acts
+        ops.preprocess(self.images, MEAN_RGB, a['input'].ld, self.DT, a['input'].t)
+        for step in self.vgg_plan:
+            if step[0] == 'conv':
+                _, name, prev = step
+                self._conv_fwd(name, a[prev], a[name], self.param(name + '.b'), True)
+            else:
+                _, name, prev, k, s, pt = step
+                x, y = a[prev], a[name]
+                ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
+        c43 = a['conv4_3']
+        ops.l2norm_fwd(c43.t, a['feat1'].t, c43.M, 512, c43.ld, self.param('l2norm.gamma'))
+        for (name, ci, co, k, s, d) in EXTRA_SEQ:
+            src = a[self.extra_src[name]]
+            z, y = self.zbuf[name], a[name]
+            self._conv_fwd(name, src, z, self.param(name + '.b'), False)
+            sm, si = self.bnsave[name]
+            ops.bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
+                       self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, True,
+                       y.t, y.ld, z.M, 0, self.ws)
+        A25 = NUM_PRIORS * self.row
+        for i, src_name in enumerate(FEAT_SRC):
+            name = f'pred{i + 1}'
+            src, z = a[src_name], self.zbuf[name]
+            self._conv_fwd(name, src, z, self.param(name + '.b'), False)
+            sm, si = self.bnsave[name]
+            co = self.convs[name].cout
+            out = self.pred.view(-1)[self.head_off[i] * self.row:]
+            ops.bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
+                       self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, False,
+                       out, co, src.H * src.W, A25, self.ws)
+
+    # ------------------------------------------------------------------ loss
+    def _loss(self, grad_scale):
+        N, A = self.batch_size, NUM_PRIORS
+        pri = self.pri
+        if self.m_best is None or self.m_best.shape[1] != self.gt.shape[1]:
+            self.m_best = torch.zeros(N, self.gt.shape[1], dtype=torch.int32, device=self.dev)
+        ops.ssd_match(pri[0], pri[1], pri[3], self.gt, self.m_ngt, self.m_best, self.m_status, self.m_rg, self.m_counts)
+        ops.softmax_ce_const(self.pred, N * A, self.num_classes, self.row, self.num_classes - 1, self.negloss)
+        ops.nms_batched(pri[4], 0, self.negloss, A, 1, self.m_status, A, 1, 2, A, N, self.m_counts[:, 2:], 4, 0,
+                        0.7, self.sel_idx, A, self.sel_cnt)
+        ops.ssd_loss(self.pred, self.num_classes, pri[2], pri[3], self.gt, self.m_ngt, self.m_best, self.m_status,
+                     self.m_rg, self.m_counts, self.negloss, self.sel_idx, self.sel_cnt, grad_scale,
+                     self.loss_parts, self.dpred)
+        self.loss_col.copy_(self.loss_parts[:, 3])
+        ops.sum_f32(self.loss_col, self.data_loss)
+
+    m_best = None
+
+    # ------------------------------------------------------------------ backward
+    def _grad(self, name):
+        return self._wslice(name, self.G)
+
+    def _conv_bwd_params(self, name, x, dy_t, lddy):
+        d = self.desc[name]
+        ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'))
+        ops.colsum(dy_t, d.N * d.Ho * d.Wo, d.K, lddy, self._grad(name + '.b'), False, self.ws)
+
+    def _backward(self):
+        a = self.acts
+        A25 = NUM_PRIORS * self.row
+        ready = self._mark_ready
+        # heads (pred6 .. pred1): dpred -> BN bwd -> wgrad / dgrad into the feature map
+        for i in reversed(range(6)):
+            name = f'pred{i + 1}'
+            src, z = a[FEAT_SRC[i]], self.zbuf[name]
+            co = self.convs[name].cout
+            sm, si = self.bnsave[name]
+            dyv = self.dpred.view(-1)[self.head_off[i] * self.row:]
+            ops.bn_bwd(z.t, None, dyv, z.M, co, z.ld, co, src.H * src.W, A25, self.param(name + '.gamma'), sm, si,
+                       False, z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
+            self._conv_bwd_params(name, src, z.g, z.ld)
+            ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], None, src.g, False)
+            ready(name)
+        # extra layers conv11_2 .. conv6
+        for (name, ci, co, k, s, d) in reversed(EXTRA_SEQ):
+            src = a[self.extra_src[name]]
+            z, y = self.zbuf[name], a[name]
+            sm, si = self.bnsave[name]
+            ops.bn_bwd(z.t, y.t, y.g, z.M, co, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, True,
+                       z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
+            self._conv_bwd_params(name, src, z.g, z.ld)
+            # the source already holds the head's gradient when it is a feature map
+            acc = self.extra_src[name] in FEAT_SRC
+            relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
+            ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], relu_src, src.g, acc)
+            ready(name)
+        # VGG trunk
+        for step in reversed(self.vgg_plan):
+            if step[0] == 'pool':
+                _, name, prev, k, s, pt = step
+                x, y = a[prev], a[name]
+                ops.maxpool_bwd(x.t, y.t, y.g, x.g, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
+                if prev == 'conv4_3':       # second consumer: L2-norm -> pred1 (accumulate, ReLU mask)
+                    f1 = a['feat1']
+                    ops.l2norm_bwd(x.t, f1.g, x.g, x.M, 512, x.ld, self.param('l2norm.gamma'),
+                                   self._grad('l2norm.gamma'), True, x.t)
+                    ready('l2norm')
+            else:
+                _, name, prev = step
+                x, y = a[prev], a[name]
+                self._conv_bwd_params(name, x, y.g, y.ld)
+                if name != 'conv1_1':
+                    ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
+                ready(name)
+
+    def _mark_ready(self, layer_name):
+        if self.dist is not None:
+            self.dist.layer_ready(layer_name)
+
+    # ------------------------------------------------------------------ public: training
+    def set_batch(self, images, ground_truth):
+        images = torch.as_tensor(images, dtype=torch.float32)
+        if self.data_format == 'channels_first' and images.shape[1] == 3:
+            images = images.permute(0, 2, 3, 1)
+        assert tuple(images.shape) == (self.batch_size, 300, 300, 3), images.shape
+        self.images.copy_(images, non_blocking=True)
+        gt = torch.as_tensor(ground_truth, dtype=torch.float32)
+        if self.gt is None or self.gt.shape != gt.shape:
+            self.gt = torch.zeros(gt.shape, device=self.dev)
+        self.gt.copy_(gt, non_blocking=True)
+
+    def train_step(self, lr):
+        """One optimizer step on the batch loaded by set_batch(); returns the loss (data + L2)
+        as a 1-element device tensor without synchronising."""
+        self.G.zero_()
+        if self.dist is not None:
+            self.dist.begin_step()
+        self._forward(True)
+        self._loss(1.0 / self.loss_divisor_batch)
+        self._backward()
+        if self.dist is not None:
+            self.dist.finish_step()
+        ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial,
+                         self.Pc if self.DT == BF16 else None)
+        ops.sum_f32(self.l2_partial, self.l2_sum)
+        self.refresh_wt()
+        self.global_step += 1
+        # reference SSD300.py:148-152: sum_i loss_i / batch + wd * sum_v ||v||^2 / 2 (pre-update weights)
+        return self.data_loss / self.batch_size + self.weight_decay * self.l2_sum
+
+    def train_one_epoch(self, lr):
+        if callable(self.train_initializer):
+            self.train_initializer()
+        mean_loss = []
+        num_iters = self.num_train // self.batch_size
+        it = iter(self.train_iterator)
+        for i in range(num_iters):
+            try:
+                images, gt = next(it)
+            except StopIteration:
+                it = iter(self.train_iterator)
+                images, gt = next(it)
+            self.set_batch(images, gt)
+            loss = float(self.train_step(lr).item())
+            if self.verbose:
+                sys.stdout.write('\r>> ' + 'iters ' + str(i) + str('/') + str(num_iters) + ' loss ' + str(loss))
+                sys.stdout.flush()
+            mean_loss.append(loss)
+        if self.verbose:
+            sys.stdout.write('\n')
+        return np.mean(mean_loss)
+
+    # ------------------------------------------------------------------ public: inference
+    def test_one_image(self, images):
+        images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+        if self.data_format == 'channels_first' and images.shape[1] == 3:
+            images = images.permute(0, 2, 3, 1)
+        assert self.batch_size == 1 and tuple(images.shape) == (1, 300, 300, 3)
+        self.images.copy_(images)
+        self._forward(False)
+        nc = self.num_classes - 1
+        pri = self.pri
+        ops.ssd_decode(self.pred[0], self.num_classes, pri[2], pri[3], self.nms_score_threshold, self.d_conf,
+                       self.d_boxes, self.d_keep, self.d_cand)
+        cap = max(int(self.nms_max_boxes), 1)
+        out_idx = torch.zeros(nc, cap, dtype=torch.int32, device=self.dev)
+        out_cnt = torch.zeros(nc, dtype=torch.int32, device=self.dev)
+        ops.nms_batched(self.d_boxes, 0, self.d_conf, 1, nc, self.d_cand, 1, nc, 1, NUM_PRIORS, nc, None, 0,
+                        int(self.nms_max_boxes), self.nms_iou_threshold, out_idx, cap, out_cnt)
+        cnt = out_cnt.cpu().tolist()
+        idx = out_idx.cpu()
+        conf, boxes = self.d_conf.cpu(), self.d_boxes.cpu()
+        scores, bbox, cid = [], [], []
+        for c in range(nc):                           # ascending class id, NMS pick order inside
+            ids = idx[c, : cnt[c]].long()
+            scores.append(conf[ids, c]); bbox.append(boxes[ids])
+            cid.append(torch.full((cnt[c],), c, dtype=torch.int32))
+        return [torch.cat(scores).numpy(), torch.cat(bbox, 0).numpy().reshape(-1, 4), torch.cat(cid).numpy()]
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_weight(self, mode, path):
+        assert (mode in ['latest', 'best'])
+        dirname = os.path.dirname(path)
+        if dirname and not os.path.exists(dirname):
+            os.makedirs(dirname)
+            print(dirname, 'does not exist, create it done')
+        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(),
+                'global_step': self.global_step, 'layout': dict(self.pinfo)}
+        torch.save(blob, path + '-' + str(self.global_step))
+        print('save', mode, 'model in', path, 'successfully')
+
+    def load_weight(self, path):
+        blob = torch.load(path, map_location='cpu', weights_only=False)
+        self.load_oracle_params(blob['params'])
+        if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
+            self.Mom.copy_(blob['momentum'].to(self.dev))
+        self.global_step = int(blob.get('global_step', 0))
+        print('load weight', path, 'successfully')
+
+    # ------------------------------------------------------------------ data parallel
+    def attach_data_parallel(self, group=None, bucket_mb=25):
+        """Shard images over ranks (one process per GPU); gradients are summed with bucketed
+        RCCL all-reduce overlapped with backward.  The loss divisor becomes the GLOBAL batch."""
+        from .dist import GradAllReducer
+        self.dist = GradAllReducer(self, group, bucket_mb)
+        self.loss_divisor_batch = self.batch_size * self.dist.world
+        return self.dist

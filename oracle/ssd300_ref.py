@@ -130,6 +130,18 @@ def init_params(seed=0, num_classes=21):
     return p
 
 
+def calibrate_bn(p, images_nhwc):
+    """Set the BN moving statistics to the batch statistics of `images` (gives inference-mode
+    activations a sane scale for randomly initialised weights)."""
+    stats = {}
+    with torch.no_grad():
+        forward(p, images_nhwc, True, stats)
+    for name, (mean, var_unbiased) in stats.items():
+        p[name + ".mmean"] = mean.clone()
+        p[name + ".mvar"] = var_unbiased.clone()
+    return p
+
+
 def trainable_names(p):
     return [k for k in p if not (k.endswith(".mmean") or k.endswith(".mvar"))]
 
@@ -162,15 +174,21 @@ def forward(p, images_nhwc, training, stats_out=None, taps=None):
                 x = maxpool_same(x, 2, 2)
         if taps is not None:
             taps[l[0] if isinstance(l, tuple) else l] = x.permute(0, 2, 3, 1)
+            if taps.get("_retain") and x.requires_grad:
+                x.retain_grad(); taps[(l[0] if isinstance(l, tuple) else l) + ".raw"] = x
     for (name, ci, co, k, s, d) in EXTRA_LAYERS:                             # SSD300.py:523-537
         x = conv2d_same(x, p[name + ".w"], p[name + ".b"], s, d)
         if taps is not None:
             taps[name + ".z"] = x.permute(0, 2, 3, 1)
+            if taps.get("_retain") and x.requires_grad:
+                x.retain_grad(); taps[name + ".z.raw"] = x
         x = F.relu(batch_norm(x, p, name, training, stats_out))
         if name in FEATS:
             feats[name] = x
         if taps is not None:
             taps[name] = x.permute(0, 2, 3, 1)
+            if taps.get("_retain") and x.requires_grad:
+                x.retain_grad(); taps[name + ".raw"] = x
     # L2 normalise conv4_3 across channels, one learnable scalar (SSD300.py:74-83)
     f1 = feats["conv4_3"]
     ss = (f1 * f1).sum(dim=1, keepdim=True)

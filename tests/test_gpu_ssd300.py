@@ -1,0 +1,122 @@
+"""GPU end-to-end parity of the SSD300 class surface against the CPU oracle (through libodtk)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ssd300_ref as R  # noqa: E402
+
+CONFIG = {
+    'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
+    'keep_prob': 0.5, 'batch_size': 2, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20,
+    'nms_iou_threshold': 0.5, 'pretraining_weight': './vgg_16.ckpt', 'verbose': False,
+}
+
+
+def _model(mode, dtype, batch, provider=None):
+    import odtk
+    cfg = dict(CONFIG, mode=mode, compute_dtype=dtype, batch_size=batch)
+    return odtk.SSD300(cfg, provider)
+
+
+def _provider(batch, n_batches=2, seed=0):
+    data = [R.synthetic_batch(batch, seed + i) for i in range(n_batches)]
+    return {'data_shape': [300, 300, 3], 'num_train': batch * n_batches, 'num_val': 0,
+            'train_generator': data, 'val_generator': None}, data
+
+
+def test_inference_parity_f32(dev):
+    torch.set_num_threads(16)
+    p = R.init_params(3)
+    imgs, _ = R.synthetic_batch(2, 7)
+    R.calibrate_bn(p, imgs)
+    m = _model('test', 'f32', 1)
+    m.load_oracle_params(p)
+    # head logits
+    m.images.copy_(imgs[:1]); m._forward(False)
+    with torch.no_grad():
+        taps = {}
+        pred_ref = R.forward(p, imgs[:1], False, taps=taps)
+    torch.cuda.synchronize()
+    pred = m.pred.cpu()
+    for name in ['conv1_1', 'conv2_2', 'conv4_3', 'conv5_3', 'pool5', 'conv7', 'conv9_2', 'conv11_2', 'feat1']:
+        got = m.acts[name].t.float().cpu()[:, : m.acts[name].C].reshape(taps[name].shape)
+        err = float((got - taps[name]).abs().max()) / (float(taps[name].abs().max()) + 1e-9)
+        assert err < 2e-4, (name, err)
+    assert float((pred - pred_ref).abs().max()) < 1e-3 * max(1.0, float(pred_ref.abs().max()))
+    # detections: lower the score threshold so that something is reported for random weights
+    for thr in (0.5, 0.2):
+        m.nms_score_threshold = thr
+        s, b, c = m.test_one_image(imgs[:1].numpy())
+        s_ref, b_ref, c_ref = R.test_one_image(p, imgs[:1], thr, 20, 0.5)
+        assert c.tolist() == c_ref.tolist()
+        if len(s_ref):
+            assert float(np.abs(s - s_ref).max()) < 1e-3
+            assert float(np.abs(b - b_ref).max()) < 1e-3 * 300          # 1e-3 of the image size
+    assert s.dtype == np.float32 and b.shape[1] == 4 and c.dtype == np.int32
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-3), ("bf16", 6e-2)])
+def test_train_step_parity(dtype, tol, dev):
+    torch.set_num_threads(16)
+    B = 2
+    p = R.init_params(5)
+    prov, data = _provider(B, 1, seed=40)
+    m = _model('train', dtype, B, prov)
+    m.load_oracle_params(p)
+    mom = {k: torch.zeros_like(v) for k, v in p.items()}
+    imgs, gt = data[0]
+    m.set_batch(imgs, gt)
+    loss = float(m.train_step(0.01).item())
+    torch.cuda.synchronize()
+    g_gpu = m.export_params()
+    loss_ref, data_ref = R.train_step(p, mom, imgs, gt, 0.01, 1e-4)
+    assert abs(loss - loss_ref) <= tol * abs(loss_ref), (loss, loss_ref)
+    # one SGD step from identical weights: the update equals -lr * (grad + wd*w) -> compares all
+    # gradients.  Frobenius norm: a single ReLU flip of a near-zero pre-activation (values differ by
+    # ~1e-5 between summation orders) moves one channel's BN gradient by a few %, so max-abs is not a
+    # meaningful bound for a discontinuous graph.
+    init = R.init_params(5)
+    worst = 0.0
+    for k in R.trainable_names(p):
+        bn_bias = k.endswith('.b') and (k[:-2] + '.gamma') in p        # exactly-zero gradient (BN removes it)
+        if bn_bias:
+            continue
+        upd_ref = p[k] - init[k]
+        upd = g_gpu[k] - init[k]
+        err = float((upd - upd_ref).norm()) / (float(upd_ref.norm()) + 1e-20)
+        worst = max(worst, err)
+        if dtype == 'f32':
+            assert err < 3e-2, (k, err)
+        else:
+            # bf16 at batch 2: BatchNorm over 18..722 samples + ReLU flips make the extra layers chaotic
+            # (forward error grows 1.8% -> 13% from conv6 to conv11_2), so only the head gradients are
+            # bounded tightly; the trunk must still point the same way.
+            cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm() + 1e-20))
+            if k.startswith('pred') and k.endswith('.w'):
+                assert err < 0.4, (k, err)
+            elif k.endswith('.w'):
+                assert cos > 0.4, (k, cos)
+    print('worst relative (Frobenius) update error', dtype, worst)
+    for k in p:
+        if k.endswith('.mmean') or k.endswith('.mvar'):
+            assert float((g_gpu[k] - p[k]).abs().max()) <= (1e-3 if dtype == 'f32' else 3e-2) * (float(p[k].abs().max()) + 0.05)
+
+
+def test_train_one_epoch_and_checkpoint(dev, tmp_path):
+    B = 2
+    prov, data = _provider(B, 2, seed=50)
+    m = _model('train', 'bf16', B, prov)
+    l0 = m.train_one_epoch(0.001)
+    l1 = m.train_one_epoch(0.001)
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert m.global_step == 4
+    path = str(tmp_path / 'ssd' / 'test')
+    m.save_weight('latest', path)
+    m2 = _model('test', 'bf16', 1)
+    m2.load_weight(path + '-4')
+    a, b = m.export_params(), m2.export_params()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    out = m2.test_one_image(data[0][0][:1].numpy())
+    assert len(out) == 3

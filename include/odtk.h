@@ -73,9 +73,10 @@ int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int lddy, const v
 
 /* dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (float32, KRSC, pitch R*S*C)
  * Split over pixels with float atomics: dw must be zeroed (or hold the value to
- * accumulate onto) by the caller.  dbias (optional) += column sums of dy. */
+ * accumulate onto) by the caller.  dbias (optional, f32 [K]) += column sums of dy -- the
+ * bias gradient, fused so dy is not read a second time. */
 int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy,
-                      float* dw, void* stream);
+                      float* dw, float* dbias, void* stream);
 
 /* w [K][R][S][C] (f32 master) -> w_t [C][R][S][Kp] in `dtype`, taps flipped, zero padded
  * to Kp; and optionally a straight cast copy w_c [K][R][S][C] in `dtype` (may be NULL). */
@@ -104,7 +105,7 @@ int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, void* dx, int
  * + (m % rows_per_img)*ldy (lets the head write straight into pred [N,8828,25]).
  * training: batch statistics (biased var), saves mean / inv-std (f32 [C]) for backward and
  * updates moving stats with the unbiased variance.  Inference: uses moving stats.
- * workspace: >= odtk_bn_workspace_bytes(M, C) bytes. */
+ * workspace: >= odtk_bn_workspace_bytes(M, C) bytes (always required). */
 long long odtk_bn_workspace_bytes(int M, int C);
 int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, const float* gamma,
                 const float* beta, float* moving_mean, float* moving_var, float* save_mean,

@@ -285,6 +285,7 @@ struct WgradArgs {
     const char* x;   // fwd input [N][H][W][ldx]
     const char* dy;  // [P][lddy]
     float* dw;       // [K][RSC]
+    float* dbias;    // [K] or null: += column sums of dy (fused bias gradient)
     int N, H, W, C, ldx;
     int Ho, Wo, K, lddy;
     int R, S, stride, dil, pad_t, pad_l;
@@ -394,6 +395,28 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
     };
 
+    // fused bias gradient: the q-tile-0 blocks also column-sum their dy operand
+    const bool do_bias = a.dbias != nullptr && tq == 0 && p_active;
+    float bsum[KCH];
+#pragma unroll
+    for (int e = 0; e < KCH; ++e) bsum[e] = 0.f;
+    auto acc_bias = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned* d = reinterpret_cast<const unsigned*>(&vp[i]);
+            if (sizeof(T) == 2) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    bsum[(2 * h) % KCH] += __uint_as_float(d[h] << 16);
+                    bsum[(2 * h + 1) % KCH] += __uint_as_float(d[h] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) bsum[h % KCH] += __uint_as_float(d[h]);
+            }
+        }
+    };
+
     f32x16_v acc[PI][QI];
 #pragma unroll
     for (int i = 0; i < PI; ++i)
@@ -404,6 +427,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 
     if (it0 < it1) {
         load_tile(it0);
+        if (do_bias) acc_bias();
         store_op(sP, vp, PT);
         store_op(sQ, vq, 128);
         __syncthreads();
@@ -413,10 +437,26 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             mma_slab<T, PI, QI>(sP, sQ, wp * (PT / 2), wq * 64, lane, acc);
             __syncthreads();
             if (more) {
+                if (do_bias) acc_bias();
                 store_op(sP, vp, PT);
                 store_op(sQ, vq, 128);
                 __syncthreads();
             }
+        }
+    }
+    if (a.dbias != nullptr && tq == 0) {      // block-uniform: reduce over the pixel groups in LDS first
+        constexpr int NPG = 256 / NCC;
+        float* red = reinterpret_cast<float*>(smem);            // [NPG][PT]; operand slabs are dead now
+        if (cc * KCH < PT) {
+#pragma unroll
+            for (int e = 0; e < KCH; ++e) red[pg * PT + cc * KCH + e] = bsum[e];
+        }
+        __syncthreads();
+        if (tid < PT && p0 + tid < a.K) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < NPG; ++g) t += red[g * PT + tid];
+            atomicAdd(a.dbias + p0 + tid, t);
         }
     }
 
@@ -549,14 +589,14 @@ extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int ld
 }
 
 extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy,
-                                 float* dw, void* stream) {
+                                 float* dw, float* dbias, void* stream) {
     if (int e = check_desc(d)) return e;
     ODTK_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
     const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
     ODTK_REQUIRE(lddy % kch == 0 && lddy >= d->K, "conv2d_wgrad: lddy=%d must be a multiple of %d", lddy, kch);
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = (const char*)x; a.dy = (const char*)dy; a.dw = dw;
+    a.x = (const char*)x; a.dy = (const char*)dy; a.dw = dw; a.dbias = dbias;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.K = d->K; a.lddy = lddy;
     a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;

@@ -220,50 +220,52 @@ __device__ __forceinline__ long long out_off(int m, int rows_per_img, long long 
     return (long long)n * img_stride + (long long)(m - n * rows_per_img) * ld;
 }
 
+// per-channel scale/offset from the partial sums (training) or the moving stats (inference);
+// one thread per channel.  fin[0*C + c] = scale, fin[1*C + c] = offset.
+template <typename T>
+__global__ void bn_finalize_kernel(const T* __restrict__ z, int M, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ mmean,
+                                   float* __restrict__ mvar, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd, int training, const float* __restrict__ ws,
+                                   int nsplit, float* __restrict__ fin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (training) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+            s1 += ws[((size_t)0 * nsplit + s) * C + c];
+            s2 += ws[((size_t)1 * nsplit + s) * C + c];
+        }
+        const float d = s1 / (float)M;
+        mean = elem<T>::load(z[c]) + d;
+        var = fmaxf(s2 / (float)M - d * d, 0.f);
+        save_mean[c] = mean;
+        save_invstd[c] = rsqrtf(var + 1e-3f);
+        const float unb = var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+        mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
+        mvar[c] = mvar[c] * 0.99f + unb * (1.f - 0.99f);
+    } else {
+        mean = mmean[c]; var = mvar[c];
+    }
+    const float sc = rsqrtf(var + 1e-3f) * gamma[c];
+    fin[c] = sc;
+    fin[C + c] = beta[c] - mean * sc;
+}
+
 template <typename T, typename TY>
 __global__ void __launch_bounds__(256) bn_apply_kernel(
-    const T* __restrict__ z, int M, int C, int ldz, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ save_mean,
-    float* __restrict__ save_invstd, int training, int relu, TY* __restrict__ y, int ldy, int rows_per_img,
-    long long y_img_stride, int vec_ok, const float* __restrict__ ws, int nsplit, int rows_per_block) {
+    const T* __restrict__ z, int M, int C, int ldz, int relu, TY* __restrict__ y, int ldy, int rows_per_img,
+    long long y_img_stride, int vec_ok, const float* __restrict__ fin, int rows_per_block) {
     constexpr int KC = Chunk<T>::N;
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c0 = (blockIdx.x * 8 + cl) * KC;
     if (c0 >= C) return;
     float sc[KC], of[KC];
-    {
-        float sh[KC];
-        Chunk<T>::unpack(ld16(z + c0), sh);
 #pragma unroll
-        for (int e = 0; e < KC; ++e) {
-            const int c = c0 + e;
-            float mean = 0.f, var = 1.f, g = 1.f, b = 0.f;
-            if (c < C) {
-                g = gamma[c]; b = beta[c];
-                if (training) {
-                    float s1 = 0.f, s2 = 0.f;
-                    for (int s = 0; s < nsplit; ++s) {
-                        s1 += ws[((size_t)0 * nsplit + s) * C + c];
-                        s2 += ws[((size_t)1 * nsplit + s) * C + c];
-                    }
-                    const float d = s1 / (float)M;
-                    mean = sh[e] + d;
-                    var = fmaxf(s2 / (float)M - d * d, 0.f);
-                    if (blockIdx.y == 0 && rl == 0) {
-                        save_mean[c] = mean;
-                        save_invstd[c] = rsqrtf(var + 1e-3f);
-                        const float unb = var * ((float)M / (float)(M > 1 ? M - 1 : 1));
-                        mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
-                        mvar[c] = mvar[c] * 0.99f + unb * (1.f - 0.99f);
-                    }
-                } else {
-                    mean = mmean[c]; var = mvar[c];
-                }
-            }
-            const float inv = rsqrtf(var + 1e-3f);
-            sc[e] = inv * g;
-            of[e] = b - mean * sc[e];
-        }
+    for (int e = 0; e < KC; ++e) {
+        sc[e] = c0 + e < C ? fin[c0 + e] : 0.f;
+        of[e] = c0 + e < C ? fin[C + c0 + e] : 0.f;
     }
     const int m0 = blockIdx.y * rows_per_block;
     int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
@@ -346,13 +348,29 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
     }
 }
 
+// fin[0*C+c] = mean(dy'), fin[1*C+c] = mean(dy' * xhat); also emits dbeta / dgamma
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, int nsplit, int C, int M,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ fin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        s1 += ws[((size_t)0 * nsplit + s) * C + c];
+        s2 += ws[((size_t)1 * nsplit + s) * C + c];
+    }
+    dbeta[c] = s1;
+    dgamma[c] = s2;
+    fin[c] = s1 / (float)M;
+    fin[C + c] = s2 / (float)M;
+}
+
 template <typename T, typename TY>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
     int rows_per_img, long long y_img_stride, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, T* __restrict__ dz,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ ws, int nsplit,
-    int rows_per_block) {
+    const float* __restrict__ fin, int rows_per_block) {
     constexpr int KC = Chunk<T>::N;
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c0 = (blockIdx.x * 8 + cl) * KC;
@@ -363,16 +381,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
         const int c = c0 + e;
         mu[e] = 0.f; iv[e] = 0.f; gs[e] = 0.f; k1[e] = 0.f; k2[e] = 0.f;
         if (c < C) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int s = 0; s < nsplit; ++s) {
-                s1 += ws[((size_t)0 * nsplit + s) * C + c];
-                s2 += ws[((size_t)1 * nsplit + s) * C + c];
-            }
             mu[e] = save_mean[c]; iv[e] = save_invstd[c];
             gs[e] = gamma[c] * iv[e];
-            k1[e] = s1 / (float)M;
-            k2[e] = s2 / (float)M;
-            if (blockIdx.y == 0 && rl == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+            k1[e] = fin[c];
+            k2[e] = fin[C + c];
         }
     }
     const int m0 = blockIdx.y * rows_per_block;
@@ -665,7 +677,7 @@ extern "C" int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, vo
 
 extern "C" long long odtk_bn_workspace_bytes(int M, int C) {
     (void)M;
-    return (long long)2 * 256 * (long long)((C + 63) / 64 * 64) * sizeof(float);
+    return (long long)(2 * 256 + 2) * (long long)((C + 63) / 64 * 64) * sizeof(float);
 }
 
 extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, const float* gamma,
@@ -673,28 +685,30 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
                            float* save_invstd, int training, int relu, void* y, int y_dtype, int ldy,
                            int rows_per_img, long long y_img_stride, void* workspace, void* stream) {
     ODTK_REQUIRE(z && y && gamma && beta && moving_mean && moving_var, "bn_fwd: null pointer");
-    ODTK_REQUIRE(!training || (save_mean && save_invstd && workspace), "bn_fwd: training needs save buffers + workspace");
+    ODTK_REQUIRE(workspace, "bn_fwd: workspace required");
+    ODTK_REQUIRE(!training || (save_mean && save_invstd), "bn_fwd: training needs save buffers");
     const int kc = dtype == ODTK_BF16 ? 8 : 4;
     ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_fwd: ldz=%d must be a multiple of %d", ldz, kc);
     ODTK_REQUIRE(!(y_dtype == ODTK_BF16 && dtype == ODTK_F32), "bn_fwd: f32 in / bf16 out unsupported");
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
     float* ws = (float*)workspace;
+    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
     if (training) {
         DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
                                                (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
-        ODTK_LAUNCH_CHECK();
     }
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, 128)), dim3(128), 0, st, (const T*)z, M,
+                                           C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
+                                           pl.nsplit, fin);)
     const size_t ysz = dtype_size(y_dtype);
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
                        ((uintptr_t)y % 16) == 0;
-    // apply: same column groups; row blocks sized like the stats splits
     const int rows_per_block = pl.rows_per_split;
     dim3 grid(pl.colgroups, ceil_div(M, rows_per_block));
 #define BN_APPLY(T, TY)                                                                                        \
-    hipLaunchKernelGGL((bn_apply_kernel<T, TY>), grid, dim3(256), 0, st, (const T*)z, M, C, ldz, gamma, beta,  \
-                       moving_mean, moving_var, save_mean, save_invstd, training, relu, (TY*)y, ldy,           \
-                       rows_per_img, y_img_stride, vec_ok, ws, pl.nsplit, rows_per_block)
+    hipLaunchKernelGGL((bn_apply_kernel<T, TY>), grid, dim3(256), 0, st, (const T*)z, M, C, ldz, relu, (TY*)y, \
+                       ldy, rows_per_img, y_img_stride, vec_ok, fin, rows_per_block)
     if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) BN_APPLY(bf16_t, bf16_t);
     else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) BN_APPLY(bf16_t, float);
     else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) BN_APPLY(float, float);
@@ -717,15 +731,18 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     const RedPlan pl = red_plan(M, C, kc);
     float* ws = (float*)workspace;
     const int rows_per_block = pl.rows_per_split;
+    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
     dim3 g1(pl.colgroups, pl.nsplit);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
 #define BN_BWD(T, TY)                                                                                             \
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu,   \
                        pl.rows_per_split, ws);                                                                    \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, ws, pl.nsplit, C, M,     \
+                       dgamma, dbeta, fin);                                                                       \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd,  \
-                       relu, (T*)dz, dgamma, dbeta, ws, pl.nsplit, rows_per_block)
+                       relu, (T*)dz, fin, rows_per_block)
     if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_BWD(bf16_t, bf16_t); }
     else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_BWD(bf16_t, float); }
     else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD(float, float); }

@@ -73,8 +73,8 @@ def conv2d_dgrad(d: ConvDesc, dy, lddy: int, w_t, relu_src, dx, accumulate: bool
          _stream())
 
 
-def conv2d_wgrad(d: ConvDesc, x, dy, lddy: int, dw):
-    call("odtk_conv2d_wgrad", C.byref(d), _p(x), _p(dy), int(lddy), _p(dw), _stream())
+def conv2d_wgrad(d: ConvDesc, x, dy, lddy: int, dw, dbias=None):
+    call("odtk_conv2d_wgrad", C.byref(d), _p(x), _p(dy), int(lddy), _p(dw), _p(dbias), _stream())
 
 
 def filter_prepare(w, K, R, S, C_, Kp, dtype, w_c, w_t):

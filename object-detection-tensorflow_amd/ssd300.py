@@ -451,9 +451,12 @@ class SSD300:
         return self._wslice(name, self.G)
 
     def _conv_bwd_params(self, name, x, dy_t, lddy):
+        """Filter gradient (+ fused bias gradient).  A bias that feeds BatchNorm has an exactly
+        zero gradient (BN subtracts the batch mean; TF only produces round-off noise there), so
+        it is left at zero and only sees weight decay."""
         d = self.desc[name]
-        ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'))
-        ops.colsum(dy_t, d.N * d.Ho * d.Wo, d.K, lddy, self._grad(name + '.b'), False, self.ws)
+        dbias = None if self.convs[name].bn else self._grad(name + '.b')
+        ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
 
     def _backward(self):
         a = self.acts

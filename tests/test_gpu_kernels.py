@@ -104,8 +104,11 @@ def test_conv_fwd_dgrad_wgrad(case, dt, dev):
     dxd = torch.full((N * H * W, ldx), 7.0, dtype=dtype, device=dev)
     ops.conv2d_dgrad(d, dyd, Kp, w_t, None, dxd, False)
     dwd = torch.zeros(K, k, k, ldx, dtype=torch.float32, device=dev)
-    ops.conv2d_wgrad(d, xd, dyd, Kp, dwd)
+    dbd = torch.zeros(K, device=dev)
+    ops.conv2d_wgrad(d, xd, dyd, Kp, dwd, dbd)
     torch.cuda.synchronize()
+    db_ref = dy.reshape(-1, K).sum(0)
+    assert float((dbd.cpu() - db_ref).abs().max()) <= (1e-4 if dt == "f32" else 1e-3) * (float(db_ref.abs().max()) + 1.0), "dbias mismatch"
     dx = from_rows(dxd, N, H, W, C)
     sx = float(xr.grad.abs().max()) + 1e-6
     assert float((dx - xr.grad).abs().max()) <= tol * sx, "dgrad mismatch"
@@ -205,7 +208,7 @@ def test_batchnorm(shape, dt, ydt, dev):
         assert float(dzd[:, C:].float().abs().max()) == 0.0
     # inference mode
     yd2 = torch.zeros(M, C, dtype=ydtype, device=dev)
-    ops.bn_fwd(zd, M, C, ldz, gamma.to(dev), beta.to(dev), mm, mv, None, None, False, relu, yd2, C, rpi, rpi * C, None)
+    ops.bn_fwd(zd, M, C, ldz, gamma.to(dev), beta.to(dev), mm, mv, None, None, False, relu, yd2, C, rpi, rpi * C, ws)
     yi = (z - mm.cpu()) * torch.rsqrt(mv.cpu() + 1e-3) * gamma + beta
     if relu:
         yi = F.relu(yi)

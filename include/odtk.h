@@ -38,6 +38,8 @@ const char* odtk_last_error(void);
 int odtk_version(void);
 /* number of compute units / name of the current device (host out pointers) */
 int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
+/* test/debug knobs: key 0 = force the register-staged conv gather kernel (value != 0) */
+int odtk_debug_set(int key, int value);
 
 /* ------------------------------------------------------------------------- *
  * Convolution family: replaces tf.nn.conv2d (SSD300.py:519) and

@@ -43,6 +43,11 @@ __device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) {   // x < 2^31
 __host__ __device__ __forceinline__ int swz(int row) {
     return (((row >> 1) ^ (row >> 5)) & 1) | (((row >> 3) & 1) << 1) | (((row >> 4) & 1) << 2);
 }
+// variant without the row-bit-5 term: identical conflict behaviour for the 32-row fragment reads,
+// and constant over rows r, r+32, r+64, r+96 (what the LDS-DMA loader needs)
+__host__ __device__ __forceinline__ int swz_g(int row) {
+    return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | (((row >> 4) & 1) << 2);
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -63,7 +68,7 @@ template <> struct Mma<float> {
 };
 
 // One staged k-slab: 4 sub-steps of two 16-B slots (lanes 0-31 slot 2ks, lanes 32-63 slot 2ks+1).
-template <typename T, int PI, int QI>
+template <typename T, int PI, int QI, bool SWZ_G = false>
 __device__ __forceinline__ void mma_slab(const char* sP, const char* sQ, int prow0, int qrow0,
                                          int lane, f32x16_v (&acc)[PI][QI]) {
     const int l31 = lane & 31, hi = lane >> 5;
@@ -74,12 +79,12 @@ __device__ __forceinline__ void mma_slab(const char* sP, const char* sQ, int pro
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
             const int row = prow0 + i * 32 + l31;
-            pf[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + ((slot ^ swz(row)) << 4));
+            pf[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + ((slot ^ (SWZ_G ? swz_g(row) : swz(row))) << 4));
         }
 #pragma unroll
         for (int j = 0; j < QI; ++j) {
             const int row = qrow0 + j * 32 + l31;
-            qf[j] = *reinterpret_cast<const uint4*>(sQ + row * 128 + ((slot ^ swz(row)) << 4));
+            qf[j] = *reinterpret_cast<const uint4*>(sQ + row * 128 + ((slot ^ (SWZ_G ? swz_g(row) : swz(row))) << 4));
         }
 #pragma unroll
         for (int i = 0; i < PI; ++i)
@@ -228,6 +233,182 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(const GatherArgs a) {
     }
 
     // epilogue: lane (l31, hi) owns pixel q, channels base + 8*g + 4*hi + {0..3}
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int m = q0 + wq * 64 + j * 32 + l31;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = p0 + wp * (PT / 2) + i * 32 + 8 * g + 4 * hi;
+                if (c >= a.K) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                const bool full = (c + 3 < a.K);
+                TO* yp = reinterpret_cast<TO*>(a.y) + (size_t)m * a.ldy + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!full && c + e >= a.K) continue;
+                    float t = v[e];
+                    if (a.bias) t += a.bias[c + e];
+                    if (a.accumulate) t += elem<TO>::load(yp[e]);
+                    if (a.relu) t = fmaxf(t, 0.f);
+                    if (a.mask) {
+                        const T mv = reinterpret_cast<const T*>(a.mask)[(size_t)m * a.ldmask + c + e];
+                        if (!(elem<T>::load(mv) > 0.f)) t = 0.f;
+                    }
+                    v[e] = t;
+                }
+                if (full) {
+                    if (sizeof(TO) == 2) {
+                        uint2 o;
+                        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(yp) = o;
+                    } else {
+                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < a.K) yp[e] = elem<TO>::store(v[e]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// gather kernel, LDS-DMA version (stride-1 input sampling, i.e. every forward conv and the dgrad
+// of stride-1 convs): operands go HBM -> LDS with global_load_lds_dwordx4 (no VGPR staging, no
+// ds_write), two LDS stages, one barrier per k-slab.  The DMA writes lane-linear (wave base +
+// lane*16), so the XOR swizzle is applied to the SOURCE chunk each lane fetches; padded / out of
+// range chunks fetch from a 16-byte zero page instead of branching.
+// ---------------------------------------------------------------------------------------
+__device__ uint4 g_zero_page[4] = {};
+
+// One LDS-DMA piece: 64 lanes x 16 B land at lds_addr + lane*16 (lds_addr wave-uniform, in an SGPR).
+// Inline asm on purpose: hipcc would otherwise wait vmcnt(0) before the next ds_read of the OTHER
+// stage (it cannot tell the stages apart) and serialise the pipeline; completion is waited for by
+// the explicit s_waitcnt vmcnt(0) in front of the slab barrier.  M0 is saved/restored around it.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+template <typename T, typename TO, int PT>
+__global__ void __launch_bounds__(256) conv_gather_glds_kernel(const GatherArgs a) {
+    constexpr int KCH = Mma<T>::KCH;
+    constexpr int BKE = 8 * KCH;
+    constexpr int PI = PT / 64, QI = 2, PL = PT / 32;
+    constexpr int STAGE = (PT + 128) * 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave & 1, wq = wave >> 1;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
+    const int p0 = tp * PT, q0 = tq * 128;
+
+    const int r0 = tid >> 3;                         // rows r0 + 32*i
+    const int cc = (tid & 7) ^ swz_g(r0);            // logical chunk this lane fetches (same for all i)
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // per pixel row: byte offset of tap (0,0) channel 0, and the bit mask of in-range taps
+    long long qoff[4];
+    unsigned qmask[4];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = q0 + r0 + 32 * i;
+        qoff[i] = 0; qmask[i] = 0;
+        if (m < a.M) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
+            qoff[i] = ((long long)(n * a.H + hb) * a.W + wb) * a.ldx * (long long)sizeof(T);
+            unsigned mk = 0;
+            for (int r = 0; r < a.R; ++r)
+                for (int s2 = 0; s2 < a.S; ++s2) {
+                    const int hi = hb + r * a.dil, wi = wb + s2 * a.dil;
+                    if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) mk |= 1u << (r * a.S + s2);
+                }
+            qmask[i] = mk;
+        }
+    }
+    long long poff[PL];
+    bool pok[PL];
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+        const int row = p0 + r0 + 32 * i;
+        pok[i] = row < a.K;
+        poff[i] = (long long)row * a.ldw * (long long)sizeof(T);
+    }
+    int klin = cc * KCH;
+    int kc, ks, kr;
+    {
+        const int rs = klin / a.C;
+        kc = klin - rs * a.C;
+        kr = rs / a.S;
+        ks = rs - kr * a.S;
+    }
+
+    auto issue = [&](int stage) {
+        const unsigned sP = smem_base + (unsigned)stage * STAGE + wave_u * 1024u;
+        const unsigned sQ = sP + PT * 128;
+        const bool kv = kr < a.R;
+        const int tap = kr * a.S + ks;
+        const long long toff = ((long long)(kr * a.dil) * a.W + ks * a.dil) * a.ldx * (long long)sizeof(T) +
+                               (long long)kc * (long long)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = kv && ((qmask[i] >> tap) & 1u);
+            const char* src = ok ? a.x + qoff[i] + toff : zero;
+            glds16(src, sQ + i * 4096u);
+        }
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const bool ok = kv && pok[i];
+            const char* src = ok ? a.w + poff[i] + (long long)klin * (long long)sizeof(T) : zero;
+            glds16(src, sP + i * 4096u);
+        }
+        klin += BKE;
+        kc += BKE;
+        while (kc >= a.C) {
+            kc -= a.C;
+            if (++ks == a.S) { ks = 0; ++kr; }
+        }
+    };
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (a.Kdim + BKE - 1) / BKE;
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of slab kt landed
+        __syncthreads();                                      // ... and everybody else's; slab kt-1 fully consumed
+        if (kt + 1 < nk) issue((kt + 1) & 1);
+        const char* sP = smem + (kt & 1) * STAGE;
+        mma_slab<T, PI, QI, true>(sP, sP + PT * 128, wp * (PT / 2), wq * 64, lane, acc);
+    }
+
     const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int j = 0; j < QI; ++j) {
@@ -477,6 +658,177 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// wgrad, LDS-DMA + transpose-read version (bf16, 128 x 128 tile).  Both operands stay in their
+// natural [pixel][channel] layout: a k-slab is 64 pixels x 128 channels (256-B rows) per operand,
+// moved HBM -> LDS as sixteen 1-KiB DMA pieces of 4 pixel rows.  The MFMA fragments (8 consecutive
+// k = pixels per lane) are produced by ds_read_b64_tr_b16, which hands each lane a COLUMN of a
+// 4 (pixels) x 16 (channels) block.  Inside a piece the 16-B chunk `ch` of pixel row r sits at
+// slot ch ^ (4*r) so that the 4 rows x 64 B a half-wave reads cover all 64 banks exactly once
+// (the swizzle is applied to the DMA source address; the destination is lane-linear).
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short v4i16_v;
+
+__device__ __forceinline__ uint2 lds_tr16(unsigned lds_byte_addr) {
+    const v4i16_v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) v4i16_v*)(uintptr_t)lds_byte_addr);
+    return __builtin_bit_cast(uint2, v);
+}
+
+__global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) {
+    constexpr int PT = 128, PI = 2, QI = 2;
+    constexpr int PKE = 64;                         // pixels per k-slab
+    constexpr int OPB = PKE * 256;                  // bytes per operand slab
+    constexpr int STAGE = 2 * OPB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave & 1, wq = wave >> 1;
+    const int tile = blockIdx.x;
+    const int tq = tile / a.tiles_p, tp = tile - tq * a.tiles_p;
+    const int p0 = tp * PT, q0 = tq * 128;
+    const int split = blockIdx.y;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // DMA lane role: pixel row r = lane>>4 of the piece, logical 16-B chunk ch = (lane&15) ^ (4*r)
+    const int dr = lane >> 4;
+    const int dch = (lane & 15) ^ (dr << 2);
+    const int pch = p0 + dch * 8;                   // dy channel of this lane's chunk
+    const bool p_col_ok = pch < a.lddy;
+    const int j0 = q0 + dch * 8;                    // (r,s,c) column of this lane's chunk
+    const bool q_col_ok = j0 < a.RSC;
+    int qr = 0, qs = 0, qc = 0;
+    if (q_col_ok) {
+        const int rs = j0 / a.C;
+        qc = j0 - rs * a.C;
+        qr = rs / a.S;
+        qs = rs - qr * a.S;
+    }
+    const int dh = qr * a.dil - a.pad_t, dw_ = qs * a.dil - a.pad_l;
+    const int HoWo = a.Ho * a.Wo;
+
+    const int iters_total = (a.P + PKE - 1) / PKE;
+    const int it0 = split * a.iters_per_split;
+    int it1 = it0 + a.iters_per_split;
+    if (it1 > iters_total) it1 = iters_total;
+
+    auto issue = [&](int it, int stage) {
+        const unsigned sP = smem_base + (unsigned)stage * STAGE;
+        const unsigned sQ = sP + OPB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = (int)wave_u + 4 * i;
+            const int p = it * PKE + piece * 4 + dr;
+            const bool pin = p < a.P;
+            const char* src = (pin && p_col_ok) ? a.dy + ((size_t)p * a.lddy + pch) * 2 : zero;
+            glds16(src, sP + (unsigned)piece * 1024u);
+            const char* srcq = zero;
+            if (pin && q_col_ok) {
+                const unsigned n = fdiv((unsigned)p, a.div_howo);
+                const unsigned rem = (unsigned)p - n * (unsigned)HoWo;
+                const unsigned ho = fdiv(rem, a.div_wo);
+                const unsigned wo = rem - ho * (unsigned)a.Wo;
+                const int hi = (int)ho * a.stride + dh, wi = (int)wo * a.stride + dw_;
+                if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+                    srcq = a.x + ((size_t)(((int)n * a.H + hi) * a.W + wi) * a.ldx + qc) * 2;
+            }
+            glds16(srcq, sQ + (unsigned)piece * 1024u);
+        }
+    };
+
+    // transpose-read lane role: group g = lane>>4 -> channel sub-block 16*(g&1), k half g>>1;
+    // lane c = lane&15 supplies the address of (pixel row c>>2, 8-B column c&3) of that block
+    const int g = lane >> 4, c = lane & 15;
+    const int rr = c >> 2;                                   // pixel row inside the piece
+    unsigned pfo[PI], qfo[QI];                               // byte offset inside a piece (+ k-half piece)
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int ch = (wp * 64 + i * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
+        pfo[i] = (unsigned)((2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int ch = (wq * 64 + j * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
+        qfo[j] = (unsigned)((2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
+    }
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const bool do_bias = a.dbias != nullptr && tq == 0 && wq == 0;     // wave-uniform
+    float bsum[PI] = {0.f, 0.f};
+
+    if (it0 < it1) {
+        issue(it0, 0);
+        for (int it = it0; it < it1; ++it) {
+            const int st = (it - it0) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (it + 1 < it1) issue(it + 1, st ^ 1);
+            const unsigned sP = smem_base + (unsigned)st * STAGE;
+            const unsigned sQ = sP + OPB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 pf[PI], qf[QI];
+#pragma unroll
+                for (int i = 0; i < PI; ++i) {
+                    const uint2 lo = lds_tr16(sP + ks * 4096u + pfo[i]);
+                    const uint2 hi2 = lds_tr16(sP + ks * 4096u + 1024u + pfo[i]);
+                    pf[i] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                }
+#pragma unroll
+                for (int j = 0; j < QI; ++j) {
+                    const uint2 lo = lds_tr16(sQ + ks * 4096u + qfo[j]);
+                    const uint2 hi2 = lds_tr16(sQ + ks * 4096u + 1024u + qfo[j]);
+                    qf[j] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                }
+#pragma unroll
+                for (int i = 0; i < PI; ++i)
+#pragma unroll
+                    for (int j = 0; j < QI; ++j) Mma<bf16_t>::run(pf[i], qf[j], acc[i][j]);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < PI; ++i) {
+                        const unsigned* d = reinterpret_cast<const unsigned*>(&pf[i]);
+#pragma unroll
+                        for (int h = 0; h < 4; ++h)
+                            bsum[i] += __uint_as_float(d[h] << 16) + __uint_as_float(d[h] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+    }
+
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int col = q0 + wq * 64 + j * 32 + l31;
+        if (col >= a.RSC) continue;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = p0 + wp * 64 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const float t = bsum[i] + __shfl_xor(bsum[i], 32);       // both k halves
+            const int k = p0 + wp * 64 + i * 32 + l31;
+            if (hi == 0 && k < a.K) atomicAdd(a.dbias + k, t);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // filter preparation: f32 master [K][RS][C] -> cast copy and flipped/transposed dgrad copy
 // ---------------------------------------------------------------------------------------
 template <typename T>
@@ -507,13 +859,23 @@ __global__ void filter_prepare_kernel(const float* __restrict__ w, int K, int RS
     }
 }
 
+static bool g_force_regstage = false;   // debugging knob (odtk_debug_set)
+
 template <typename T, typename TO>
 int launch_gather(const GatherArgs& a, int PT, hipStream_t st) {
     const int grid = a.tiles_p * a.tiles_q;
-    if (PT == 64)
-        hipLaunchKernelGGL((conv_gather_kernel<T, TO, 64>), dim3(grid), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_gather_kernel<T, TO, 128>), dim3(grid), dim3(256), 0, st, a);
+    const bool dma = a.idiv == 1 && a.R * a.S <= 32 && !g_force_regstage;
+    if (dma) {
+        if (PT == 64)
+            hipLaunchKernelGGL((conv_gather_glds_kernel<T, TO, 64>), dim3(grid), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_gather_glds_kernel<T, TO, 128>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        if (PT == 64)
+            hipLaunchKernelGGL((conv_gather_kernel<T, TO, 64>), dim3(grid), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_gather_kernel<T, TO, 128>), dim3(grid), dim3(256), 0, st, a);
+    }
     return 0;
 }
 
@@ -550,6 +912,12 @@ int check_desc(const odtk_conv_desc* d) {
 }  // namespace odtk
 
 using namespace odtk;
+
+extern "C" int odtk_debug_set(int key, int value) {
+    if (key == 0) { g_force_regstage = value != 0; return ODTK_OK; }
+    set_error("debug_set: unknown key %d", key);
+    return ODTK_ERR_ARG;
+}
 
 extern "C" int odtk_conv2d_fwd(const odtk_conv_desc* d, const void* x, const void* w, const float* bias,
                                void* y, int relu, void* stream) {
@@ -620,6 +988,7 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == ODTK_BF16) {
         if (PT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), grid, dim3(256), 0, st, a);
+        else if (!g_force_regstage) hipLaunchKernelGGL(conv_wgrad_dma_kernel, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128>), grid, dim3(256), 0, st, a);
     } else {
         if (PT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<float, 64>), grid, dim3(256), 0, st, a);

@@ -12,7 +12,7 @@ is a re-iterable (or a `(initializer, iterable)` pair, mirroring the reference t
 as torch tensors or numpy arrays -- exactly what utils/image_augmentor.py:24-27 documents.
 
 Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' default | 'f32'),
-'device', 'seed', 'verbose'.
+'device', 'seed', 'verbose', 'test_subtract_mean' (False = reproduce the reference's test-mode feed quirk).
 """
 from __future__ import annotations
 
@@ -395,9 +395,10 @@ class SSD300:
     def _conv_fwd(self, name, src, dst, bias, relu):
         ops.conv2d_fwd(self.desc[name], src.t, self._wslice(name + '.w', self.Pc), bias, dst.t, relu)
 
-    def _forward(self, training):
+    def _forward(self, training, subtract_mean=True):
         a = self.acts
-        ops.preprocess(self.images, MEAN_RGB, a['input'].ld, self.DT, a['input'].t)
+        ops.preprocess(self.images, MEAN_RGB if subtract_mean else (0., 0., 0.), a['input'].ld, self.DT,
+                       a['input'].t)
         for step in self.vgg_plan:
             if step[0] == 'conv':
                 _, name, prev = step
@@ -570,7 +571,9 @@ class SSD300:
             images = images.permute(0, 2, 3, 1)
         assert self.batch_size == 1 and tuple(images.shape) == (1, 300, 300, 3)
         self.images.copy_(images)
-        self._forward(False)
+        # Reference quirk, reproduced by default: test mode re-binds self.images to `placeholder - mean`
+        # and feeds THAT tensor (SSD300.py:65-66,487), so fed pixels bypass the mean subtraction.
+        self._forward(False, subtract_mean=bool(self.config.get('test_subtract_mean', False)))
         nc = self.num_classes - 1
         pri = self.pri
         ops.ssd_decode(self.pred[0], self.num_classes, pri[2], pri[3], self.nms_score_threshold, self.d_conf,

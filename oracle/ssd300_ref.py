@@ -130,12 +130,12 @@ def init_params(seed=0, num_classes=21):
     return p
 
 
-def calibrate_bn(p, images_nhwc):
+def calibrate_bn(p, images_nhwc, subtract_mean=True):
     """Set the BN moving statistics to the batch statistics of `images` (gives inference-mode
     activations a sane scale for randomly initialised weights)."""
     stats = {}
     with torch.no_grad():
-        forward(p, images_nhwc, True, stats)
+        forward(p, images_nhwc, True, stats, subtract_mean=subtract_mean)
     for name, (mean, var_unbiased) in stats.items():
         p[name + ".mmean"] = mean.clone()
         p[name + ".mvar"] = var_unbiased.clone()
@@ -149,17 +149,24 @@ def trainable_names(p):
 # ----------------------------------------------------------------------------
 # network forward
 # ----------------------------------------------------------------------------
-def preprocess(images_nhwc):
-    """SSD300.py:52-63: subtract the RGB mean; returns NCHW."""
-    mean = torch.tensor(MEAN_RGB, dtype=torch.float32).view(1, 1, 1, 3)
-    return (images_nhwc - mean).permute(0, 3, 1, 2).contiguous()
+def preprocess(images_nhwc, subtract_mean=True):
+    """SSD300.py:52-63: subtract the RGB mean; returns NCHW.
+
+    Reference quirk (reproduced): in TEST mode `self.images` is re-bound to `placeholder - mean`
+    (SSD300.py:65-66) and test_one_image feeds THAT tensor (SSD300.py:487) -- a TF feed overrides
+    the value of the fed tensor, so the pixels handed to test_one_image bypass the subtraction.
+    Training batches (iterator output, SSD300.py:61-63) are mean-subtracted."""
+    if subtract_mean:
+        mean = torch.tensor(MEAN_RGB, dtype=torch.float32).view(1, 1, 1, 3)
+        images_nhwc = images_nhwc - mean
+    return images_nhwc.permute(0, 3, 1, 2).contiguous()
 
 
-def forward(p, images_nhwc, training, stats_out=None, taps=None):
+def forward(p, images_nhwc, training, stats_out=None, taps=None, subtract_mean=True):
     """Returns pred [N, 8828, 25] (level-major, then y, x, anchor; SSD300.py:316-321).
 
     `taps`, if a dict, receives intermediate activations as NHWC tensors."""
-    x = preprocess(images_nhwc)
+    x = preprocess(images_nhwc, subtract_mean)
     feats = {}
     for l in VGG_LAYERS:
         if isinstance(l, tuple):
@@ -488,7 +495,7 @@ def detect(pred0, anchors, score_thr, max_boxes, iou_thr, num_classes=21):
 def test_one_image(p, images_nhwc, score_thr=0.5, max_boxes=20, iou_thr=0.5, anchors=None):
     anchors = anchors or priors()
     with torch.no_grad():
-        pred = forward(p, images_nhwc, False)
+        pred = forward(p, images_nhwc, False, subtract_mean=False)      # see preprocess(): test-mode quirk
         s, b, c = detect(pred[0], anchors, score_thr, max_boxes, iou_thr)
     return [s.numpy(), b.numpy(), c.numpy()]
 

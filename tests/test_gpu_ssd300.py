@@ -30,14 +30,14 @@ def test_inference_parity_f32(dev):
     torch.set_num_threads(16)
     p = R.init_params(3)
     imgs, _ = R.synthetic_batch(2, 7)
-    R.calibrate_bn(p, imgs)
+    R.calibrate_bn(p, imgs, subtract_mean=False)        # test mode feeds raw pixels (reference quirk)
     m = _model('test', 'f32', 1)
     m.load_oracle_params(p)
     # head logits
-    m.images.copy_(imgs[:1]); m._forward(False)
+    m.images.copy_(imgs[:1]); m._forward(False, subtract_mean=False)
     with torch.no_grad():
         taps = {}
-        pred_ref = R.forward(p, imgs[:1], False, taps=taps)
+        pred_ref = R.forward(p, imgs[:1], False, taps=taps, subtract_mean=False)
     torch.cuda.synchronize()
     pred = m.pred.cpu()
     for name in ['conv1_1', 'conv2_2', 'conv4_3', 'conv5_3', 'pool5', 'conv7', 'conv9_2', 'conv11_2', 'feat1']:

@@ -38,7 +38,8 @@ const char* odtk_last_error(void);
 int odtk_version(void);
 /* number of compute units / name of the current device (host out pointers) */
 int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
-/* test/debug knobs: key 0 = force the register-staged conv gather kernel (value != 0) */
+/* test/debug knobs: key 0 = force the register-staged conv gather kernel (value != 0);
+ * key 1 = 8-wave / 3-stage conv kernels: 0 auto, 1 never, 2 wherever supported */
 int odtk_debug_set(int key, int value);
 
 /* ------------------------------------------------------------------------- *

@@ -17,105 +17,16 @@
 // makes every ds_read_b128 lane-group of the 32x32 fragment reads conflict-free.
 // MFMA operand 1 (D rows) = channels, operand 2 (D cols) = pixels / (r,s,c): each lane then
 // owns 4 consecutive output channels of one pixel per accumulator quad -> 8/16-byte stores.
-#include "common.h"
+#include "conv_common.h"
 
 namespace odtk {
+using namespace cv;
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
-typedef __attribute__((ext_vector_type(16))) float f32x16_v;
-
-struct FastDiv {
-    unsigned mul, shift;
-};
-inline FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    unsigned s = 0;
-    while ((1ull << s) < d) ++s;
-    f.shift = s;
-    f.mul = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
-    return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) {   // x < 2^31
-    return (__umulhi(x, f.mul) + x) >> f.shift;
-}
-
-__host__ __device__ __forceinline__ int swz(int row) {
-    return (((row >> 1) ^ (row >> 5)) & 1) | (((row >> 3) & 1) << 1) | (((row >> 4) & 1) << 2);
-}
-// variant without the row-bit-5 term: identical conflict behaviour for the 32-row fragment reads,
-// and constant over rows r, r+32, r+64, r+96 (what the LDS-DMA loader needs)
-__host__ __device__ __forceinline__ int swz_g(int row) {
-    return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | (((row >> 4) & 1) << 2);
-}
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    static constexpr int KCH = 8;
-    static __device__ __forceinline__ void run(const uint4& p, const uint4& q, f32x16_v& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, p),
-                                                      __builtin_bit_cast(bf16x8_v, q), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    static constexpr int KCH = 4;
-    static __device__ __forceinline__ void run(const uint4& p, const uint4& q, f32x16_v& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.x), __uint_as_float(q.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.y), __uint_as_float(q.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.z), __uint_as_float(q.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.w), __uint_as_float(q.w), acc, 0, 0, 0);
-    }
-};
-
-// One staged k-slab: 4 sub-steps of two 16-B slots (lanes 0-31 slot 2ks, lanes 32-63 slot 2ks+1).
-template <typename T, int PI, int QI, bool SWZ_G = false>
-__device__ __forceinline__ void mma_slab(const char* sP, const char* sQ, int prow0, int qrow0,
-                                         int lane, f32x16_v (&acc)[PI][QI]) {
-    const int l31 = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int slot = ks * 2 + hi;
-        uint4 pf[PI], qf[QI];
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int row = prow0 + i * 32 + l31;
-            pf[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + ((slot ^ (SWZ_G ? swz_g(row) : swz(row))) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < QI; ++j) {
-            const int row = qrow0 + j * 32 + l31;
-            qf[j] = *reinterpret_cast<const uint4*>(sQ + row * 128 + ((slot ^ (SWZ_G ? swz_g(row) : swz(row))) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < PI; ++i)
-#pragma unroll
-            for (int j = 0; j < QI; ++j) Mma<T>::run(pf[i], qf[j], acc[i][j]);
-    }
-}
-
-// XCD-aware bijective remap of the linear block id (block b runs on XCD b % 8): every XCD gets
-// a contiguous range of tiles so neighbouring tiles share their operand panels in one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, k = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
 
 // ---------------------------------------------------------------------------------------
 // gather kernel: forward conv and dgrad
 // ---------------------------------------------------------------------------------------
-struct GatherArgs {
-    const char* x;     // activations gathered along k  [N][H][W][ldx]
-    const char* w;     // filter rows [K][R*S*C]
-    const float* bias; // [K] or null
-    const char* mask;  // relu source (same geometry as y) or null
-    char* y;
-    int N, H, W, C, ldx;
-    int Ho, Wo, K, ldy, ldmask;
-    int R, S, ostride, dil, pad_t, pad_l, idiv;
-    int M, Kdim, ldw;
-    int relu, accumulate;
-    int tiles_p, tiles_q;
-};
 
 template <typename T, typename TO, int PT>
 __global__ void __launch_bounds__(256) conv_gather_kernel(const GatherArgs a) {
@@ -288,22 +199,6 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(const GatherArgs a) {
 // lane*16), so the XOR swizzle is applied to the SOURCE chunk each lane fetches; padded / out of
 // range chunks fetch from a 16-byte zero page instead of branching.
 // ---------------------------------------------------------------------------------------
-__device__ uint4 g_zero_page[4] = {};
-
-// One LDS-DMA piece: 64 lanes x 16 B land at lds_addr + lane*16 (lds_addr wave-uniform, in an SGPR).
-// Inline asm on purpose: hipcc would otherwise wait vmcnt(0) before the next ds_read of the OTHER
-// stage (it cannot tell the stages apart) and serialise the pipeline; completion is waited for by
-// the explicit s_waitcnt vmcnt(0) in front of the slab barrier.  M0 is saved/restored around it.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-}
 
 template <typename T, typename TO, int PT>
 __global__ void __launch_bounds__(256) conv_gather_glds_kernel(const GatherArgs a) {
@@ -462,18 +357,6 @@ __global__ void __launch_bounds__(256) conv_gather_glds_kernel(const GatherArgs 
 // channel chunks of 4 consecutive pixels per thread) and transposed in registers on the way
 // into the k-contiguous LDS rows.
 // ---------------------------------------------------------------------------------------
-struct WgradArgs {
-    const char* x;   // fwd input [N][H][W][ldx]
-    const char* dy;  // [P][lddy]
-    float* dw;       // [K][RSC]
-    float* dbias;    // [K] or null: += column sums of dy (fused bias gradient)
-    int N, H, W, C, ldx;
-    int Ho, Wo, K, lddy;
-    int R, S, stride, dil, pad_t, pad_l;
-    int P, RSC;
-    int tiles_p, tiles_q, iters_per_split;
-    FastDiv div_howo, div_wo;
-};
 
 template <typename T, int PT>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
@@ -666,13 +549,6 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 // slot ch ^ (4*r) so that the 4 rows x 64 B a half-wave reads cover all 64 banks exactly once
 // (the swizzle is applied to the DMA source address; the destination is lane-linear).
 // ---------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) short v4i16_v;
-
-__device__ __forceinline__ uint2 lds_tr16(unsigned lds_byte_addr) {
-    const v4i16_v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) v4i16_v*)(uintptr_t)lds_byte_addr);
-    return __builtin_bit_cast(uint2, v);
-}
 
 __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) {
     constexpr int PT = 128, PI = 2, QI = 2;
@@ -859,7 +735,9 @@ __global__ void filter_prepare_kernel(const float* __restrict__ w, int K, int RS
     }
 }
 
-static bool g_force_regstage = false;   // debugging knob (odtk_debug_set)
+static bool g_force_regstage = false;   // debugging knob (odtk_debug_set key 0)
+static int g_dbg = 0;                   // key 2: perf-experiment bits forwarded to the kernels (results are wrong when set)
+static int g_v3_mode = 0;               // key 1: 0 = auto, 1 = legacy 4-wave kernels only, 2 = 8-wave v3 wherever supported, 3 = persistent v4 wherever supported
 
 template <typename T, typename TO>
 int launch_gather(const GatherArgs& a, int PT, hipStream_t st) {
@@ -879,7 +757,27 @@ int launch_gather(const GatherArgs& a, int PT, hipStream_t st) {
     return 0;
 }
 
+// auto policy for the 8-wave / 3-stage kernel (one 512-thread block per CU): it wins wherever there are
+// enough 256-pixel tiles to fill the chip (measured per SSD300 layer with tools/conv_bench.py); with few,
+// long tiles the 128-pixel legacy tiling (2 blocks per CU) balances better
+bool gather_v3_auto(const GatherArgs& a) {
+    const int nk = ceil_div(a.Kdim, 64);
+    const int PT = a.K <= 64 ? 64 : 128;
+    const int tiles = ceil_div(a.K, PT) * ceil_div(a.M, 256);
+    return tiles >= 160 || (tiles >= 64 && nk <= 32);
+}
+
 int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
+    a.div_howo = make_fastdiv((unsigned)(a.Ho * a.Wo));
+    a.div_wo = make_fastdiv((unsigned)a.Wo);
+    a.dbg = g_dbg;
+    if (!g_force_regstage && g_v3_mode != 1 && gather_v3_supported(a, dtype, out_dtype) &&
+        (g_v3_mode >= 2 || gather_v3_auto(a))) {
+        if (g_v3_mode == 3) launch_gather_v4(a, st);
+        else launch_gather_v3(a, st);
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     const int PT = a.K <= 64 ? 64 : 128;
     a.tiles_p = ceil_div(a.K, PT);
     a.tiles_q = ceil_div(a.M, 128);
@@ -915,6 +813,8 @@ using namespace odtk;
 
 extern "C" int odtk_debug_set(int key, int value) {
     if (key == 0) { g_force_regstage = value != 0; return ODTK_OK; }
+    if (key == 1) { g_v3_mode = value; return ODTK_OK; }
+    if (key == 2) { g_dbg = value; return ODTK_OK; }
     set_error("debug_set: unknown key %d", key);
     return ODTK_ERR_ARG;
 }

@@ -1,0 +1,187 @@
+// Shared device helpers of the implicit-GEMM convolution kernels (gfx950 only):
+// MFMA wrappers, the swizzled 128-byte-row LDS slab layout, LDS-DMA, argument structs.
+#pragma once
+#include "common.h"
+
+namespace odtk {
+namespace cv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(16))) float f32x16_v;
+typedef __attribute__((ext_vector_type(4))) short v4i16_v;
+
+struct FastDiv {
+    unsigned mul, shift;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = s;
+    f.mul = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) {   // x < 2^31
+    return (__umulhi(x, f.mul) + x) >> f.shift;
+}
+
+__host__ __device__ __forceinline__ int swz(int row) {
+    return (((row >> 1) ^ (row >> 5)) & 1) | (((row >> 3) & 1) << 1) | (((row >> 4) & 1) << 2);
+}
+// variant without the row-bit-5 term: identical conflict behaviour for the 32-row fragment reads,
+// and constant over rows r, r+32, r+64, r+96 (what the LDS-DMA loader needs)
+__host__ __device__ __forceinline__ int swz_g(int row) {
+    return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | (((row >> 4) & 1) << 2);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int KCH = 8;
+    static __device__ __forceinline__ void run(const uint4& p, const uint4& q, f32x16_v& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, p),
+                                                      __builtin_bit_cast(bf16x8_v, q), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KCH = 4;
+    static __device__ __forceinline__ void run(const uint4& p, const uint4& q, f32x16_v& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.x), __uint_as_float(q.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.y), __uint_as_float(q.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.z), __uint_as_float(q.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(p.w), __uint_as_float(q.w), acc, 0, 0, 0);
+    }
+};
+
+// One staged k-slab: 4 sub-steps of two 16-B slots (lanes 0-31 slot 2ks, lanes 32-63 slot 2ks+1).
+template <typename T, int PI, int QI, bool SWZ_G = false>
+__device__ __forceinline__ void mma_slab(const char* sP, const char* sQ, int prow0, int qrow0,
+                                         int lane, f32x16_v (&acc)[PI][QI]) {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int slot = ks * 2 + hi;
+        uint4 pf[PI], qf[QI];
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int row = prow0 + i * 32 + l31;
+            pf[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + ((slot ^ (SWZ_G ? swz_g(row) : swz(row))) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < QI; ++j) {
+            const int row = qrow0 + j * 32 + l31;
+            qf[j] = *reinterpret_cast<const uint4*>(sQ + row * 128 + ((slot ^ (SWZ_G ? swz_g(row) : swz(row))) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < PI; ++i)
+#pragma unroll
+            for (int j = 0; j < QI; ++j) Mma<T>::run(pf[i], qf[j], acc[i][j]);
+    }
+}
+
+// XCD-aware bijective remap of the linear block id (block b runs on XCD b % 8): every XCD gets
+// a contiguous range of tiles so neighbouring tiles share their operand panels in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+struct GatherArgs {
+    const char* x;     // activations gathered along k  [N][H][W][ldx]
+    const char* w;     // filter rows [K][R*S*C]
+    const float* bias; // [K] or null
+    const char* mask;  // relu source (same geometry as y) or null
+    char* y;
+    int N, H, W, C, ldx;
+    int Ho, Wo, K, ldy, ldmask;
+    int R, S, ostride, dil, pad_t, pad_l, idiv;
+    int M, Kdim, ldw;
+    int relu, accumulate;
+    int tiles_p, tiles_q;
+    FastDiv div_howo, div_wo;
+    int dbg;           // perf experiments only (odtk_debug_set key 2): bit0 skip pixel-operand DMA, bit1 skip filter DMA after slab 0
+};
+
+struct WgradArgs {
+    const char* x;   // fwd input [N][H][W][ldx]
+    const char* dy;  // [P][lddy]
+    float* dw;       // [K][RSC]
+    float* dbias;    // [K] or null: += column sums of dy (fused bias gradient)
+    int N, H, W, C, ldx;
+    int Ho, Wo, K, lddy;
+    int R, S, stride, dil, pad_t, pad_l;
+    int P, RSC;
+    int tiles_p, tiles_q, iters_per_split;
+    FastDiv div_howo, div_wo;
+};
+
+// 16 bytes of zeros that padded / out-of-range LDS-DMA lanes fetch instead of branching
+static __device__ uint4 g_zero_page[4] = {};
+
+// One LDS-DMA piece: 64 lanes x 16 B land at lds_addr + lane*16 (lds_addr wave-uniform, in an SGPR).
+// Inline asm on purpose: hipcc would otherwise wait vmcnt(0) before the next ds_read of the OTHER
+// stage (it cannot tell the stages apart) and serialise the pipeline; completion is waited for by
+// explicit s_waitcnt vmcnt(N) in front of the slab barrier.  M0 is saved/restored around it.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ uint2 lds_tr16(unsigned lds_byte_addr) {
+    const v4i16_v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) v4i16_v*)(uintptr_t)lds_byte_addr);
+    return __builtin_bit_cast(uint2, v);
+}
+
+// ---- bf16 pack helpers -----------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// hardware f32 -> packed bf16 (round-to-nearest-even, NaN quieted): one VALU op per two values
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// fused ReLU backward on packed bf16: keep u's halves where the matching half of m is > 0
+__device__ __forceinline__ unsigned keep_where_pos(unsigned u, unsigned m) {
+    const unsigned lo = ((int)(m << 16) > 0) ? (u & 0xffffu) : 0u;
+    const unsigned hi = ((int)(m & 0xffff0000u) > 0) ? (u & 0xffff0000u) : 0u;
+    return lo | hi;
+}
+// epilogue post-ops on one 16-byte chunk (8 bf16) read back from the LDS image.  ReLU without
+// accumulate was already applied in f32 before the image was written.
+__device__ __forceinline__ void post_chunk(uint4& v, bool accumulate, bool relu, const uint4& old, bool has_mask,
+                                           const uint4& mk) {
+    unsigned* u = reinterpret_cast<unsigned*>(&v);
+    if (accumulate) {
+        const unsigned* uo = reinterpret_cast<const unsigned*>(&old);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float lo = bf16_lo(u[h]) + bf16_lo(uo[h]), hi = bf16_hi(u[h]) + bf16_hi(uo[h]);
+            if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            u[h] = cvt_pk_bf16(lo, hi);
+        }
+    }
+    if (has_mask) {
+        const unsigned* um = reinterpret_cast<const unsigned*>(&mk);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) u[h] = keep_where_pos(u[h], um[h]);
+    }
+}
+
+// 8-wave / 3-stage LDS ring kernels (conv_v3.hip)
+bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype);
+int launch_gather_v3(GatherArgs& a, hipStream_t st);
+int launch_gather_v4(GatherArgs& a, hipStream_t st);   // persistent, loader/compute wave-specialised
+bool wgrad_v3_supported(const WgradArgs& a, int dtype);
+int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
+
+}  // namespace cv
+}  // namespace odtk

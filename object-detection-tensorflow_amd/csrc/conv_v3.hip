@@ -1,0 +1,505 @@
+// Implicit-GEMM convolution, 8-wave / 3-stage LDS-ring generation (gfx950 only, bf16 operands).
+//
+// Same GEMM view and the same swizzled 128-byte-row slab layout as conv.hip, re-tiled for one
+// 512-thread workgroup per CU:
+//   * tile = PT channels x 256 pixels (PT = 64 | 128), 8 wave64 as 2 (channels) x 4 (pixels),
+//     every wave owns (PT/2) x 64 of D -> the 2x2 / 1x2 grid of 32x32x16 MFMAs per k-substep;
+//   * a k-slab is 64 k-elements (128 B per row); THREE slabs live in LDS (3 x 48 KiB), filled by
+//     LDS-DMA (global_load_lds_dwordx4).  Slab t+2 is issued while slab t is consumed and the
+//     wait in front of the slab barrier is a COUNTED s_waitcnt vmcnt(#DMA per slab): one whole
+//     slab stays in flight across the barrier, so an HBM/L2 round trip has two slab-times to land;
+//   * epilogue: accumulators (+bias) are rounded to bf16 into an XOR-swizzled [pixel][channel]
+//     LDS image and leave as full 16-byte-per-lane row segments (256 B contiguous per pixel);
+//     accumulate / ReLU / ReLU-mask are applied on that coalesced pass.
+#include "conv_common.h"
+
+namespace odtk {
+namespace cv {
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("s_barrier" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------
+// Coalesced epilogue shared by the gather kernels: acc -> (bias) -> bf16 -> swizzled LDS image
+// [QT pixels][PT channels] -> 16 B per lane -> (accumulate, relu, mask) -> global.
+// `smem` must be free (all slab reads done, barrier passed) and hold QT*PT*2 bytes.
+// ---------------------------------------------------------------------------------------
+template <int PT, int QT, int NTHR, int PI, int QI>
+__device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f32x16_v (&acc)[PI][QI],
+                                              int p0, int q0, int prow0, int qrow0, int tid) {
+    constexpr int RB = PT * 2;            // bytes per pixel row of the image
+    constexpr int NCH = RB / 16;          // 16-B chunks per row (8 | 16)
+    const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const bool pre_relu = a.relu && !a.accumulate;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int q = qrow0 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = prow0 + i * 32 + 8 * g + 4 * hi;      // channel inside the tile
+                const int c = p0 + cl;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (a.bias) {
+                    if (c + 3 < a.K) {
+                        const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < a.K) v[e] += a.bias[c + e];
+                    }
+                }
+                if (pre_relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                uint2 o;
+                o.x = cvt_pk_bf16(v[0], v[1]);
+                o.y = cvt_pk_bf16(v[2], v[3]);
+                *reinterpret_cast<uint2*>(smem + q * RB + ((((cl >> 3) ^ q) & (NCH - 1)) << 4) + ((cl & 4) << 1)) = o;
+            }
+        }
+    }
+    __syncthreads();
+    const bool post = a.accumulate || a.mask;
+#pragma unroll
+    for (int it = 0; it < (QT * NCH) / NTHR; ++it) {
+        const int idx = it * NTHR + tid;
+        const int q = idx / NCH, ch = idx % NCH;
+        const int m = q0 + q, c0 = p0 + ch * 8;
+        if (m >= a.M || c0 >= a.ldy) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + q * RB + (((ch ^ q) & (NCH - 1)) << 4));
+        char* yp = a.y + ((size_t)m * a.ldy + c0) * 2;
+        if (post) {
+            uint4 old = make_uint4(0, 0, 0, 0), mk = make_uint4(0, 0, 0, 0);
+            if (a.accumulate) old = *reinterpret_cast<const uint4*>(yp);
+            if (a.mask) mk = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
+            post_chunk(v, a.accumulate != 0, a.relu != 0, old, a.mask != nullptr, mk);
+        }
+        *reinterpret_cast<uint4*>(yp) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// gather kernel (forward conv, stride-1 dgrad)
+// ---------------------------------------------------------------------------------------
+template <int PT>
+__global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
+    constexpr int QT = 256;
+    constexpr int PI = PT / 64, QI = 2, PL = PT / 64;
+    constexpr int STAGE = (PT + QT) * 128;
+    constexpr int NST = 3;
+    constexpr int NDMA = 4 + PL;                       // LDS-DMA pieces per wave per slab
+    static_assert(QT * PT * 2 <= NST * STAGE, "epilogue image must fit");
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave & 1, wq = wave >> 1;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
+    const int p0 = tp * PT, q0 = tq * QT;
+
+    const int r0 = tid >> 3;                           // DMA rows r0 + 64*i
+    const int cc = (tid & 7) ^ swz_g(r0);              // logical 16-B chunk this lane fetches
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // per pixel row: byte offset of tap (0,0) channel 0, and the bit mask of in-range taps
+    long long qoff[4];
+    unsigned qmask[4];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = q0 + r0 + 64 * i;
+        qoff[i] = 0; qmask[i] = 0;
+        if (m < a.M) {
+            const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HoWo;
+            const int ho = (int)fdiv((unsigned)rem, a.div_wo), wo = rem - ho * a.Wo;
+            const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
+            qoff[i] = ((long long)(n * a.H + hb) * a.W + wb) * a.ldx * 2ll;
+            unsigned rm = 0, cm = 0;
+            for (int r = 0; r < a.R; ++r)
+                if ((unsigned)(hb + r * a.dil) < (unsigned)a.H) rm |= 1u << r;
+            for (int s2 = 0; s2 < a.S; ++s2)
+                if ((unsigned)(wb + s2 * a.dil) < (unsigned)a.W) cm |= 1u << s2;
+            unsigned mk = 0;
+            for (int r = 0; r < a.R; ++r)
+                if ((rm >> r) & 1u) mk |= cm << (r * a.S);
+            qmask[i] = mk;
+        }
+    }
+    long long poff[PL];
+    bool pok[PL];
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+        const int row = p0 + r0 + 64 * i;
+        pok[i] = row < a.K;
+        poff[i] = (long long)row * a.ldw * 2ll;
+    }
+    int klin = cc * 8;
+    int kc, ks, kr;
+    {
+        const int rs = klin / a.C;
+        kc = klin - rs * a.C;
+        kr = rs / a.S;
+        ks = rs - kr * a.S;
+    }
+
+    auto issue = [&](int stage) {
+        const unsigned sP = smem_base + (unsigned)stage * STAGE + wave_u * 1024u;
+        const unsigned sQ = sP + PT * 128;
+        const bool kv = kr < a.R;
+        const int tap = kr * a.S + ks;
+        const long long toff = ((long long)(kr * a.dil) * a.W + ks * a.dil) * a.ldx * 2ll + (long long)kc * 2ll;
+        const bool first = klin < 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = kv && ((qmask[i] >> tap) & 1u);
+            const char* src = ok ? a.x + qoff[i] + toff : zero;
+            if ((a.dbg & 1) && !first) src = zero;
+            glds16(src, sQ + i * 8192u);
+        }
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const bool ok = kv && pok[i];
+            const char* src = ok ? a.w + poff[i] + (long long)klin * 2ll : zero;
+            if ((a.dbg & 2) && !first) src = zero;
+            glds16(src, sP + i * 8192u);
+        }
+        klin += 64;
+        kc += 64;
+        while (kc >= a.C) {
+            kc -= a.C;
+            if (++ks == a.S) { ks = 0; ++kr; }
+        }
+    };
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (a.dbg & 8) ? 1 : (a.Kdim + 63) >> 6;
+    issue(0);
+    if (nk > 1) issue(1);
+    int st_c = 0, st_n = 2;                             // stage consumed now / stage to refill
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();   // this wave's pieces of slab kt landed
+        block_barrier();            // ... everybody's did; everybody finished reading slab kt-1 (= stage st_n)
+        if (kt + 2 < nk && !((a.dbg & 4) && kt > 0)) issue(st_n);
+        const char* sP = smem + st_c * STAGE;
+        mma_slab<bf16_t, PI, QI, true>(sP, sP + PT * 128, wp * (PT / 2), wq * 64, lane, acc);
+        st_c = st_c == 2 ? 0 : st_c + 1;
+        st_n = st_n == 2 ? 0 : st_n + 1;
+    }
+    block_barrier();                                    // all slab reads done: LDS is free for the output image
+    epilogue_bf16<PT, QT, 512, PI, QI>(a, smem, acc, p0, q0, wp * (PT / 2), wq * 64, tid);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Persistent, wave-specialised gather kernel ("v4"): forward conv and stride-1 dgrad.
+//
+// One 768-thread workgroup per CU, launched once per CU and looping over output tiles:
+//   waves 0-7  COMPUTE: 2 (channels) x 4 (pixels) wave grid over a PT x 256 tile; per k-slab they
+//              only wait at the slab barrier, read fragments (ds_read_b128) and issue MFMAs;
+//   waves 8-11 LOADERS: issue every LDS-DMA piece (12 | 10 per wave per slab) into a 3-slab ring,
+//              two slabs ahead of the compute waves, and wait (counted vmcnt) for slab g before
+//              arriving at barrier g.  The loaders walk the flat (tile, slab) sequence of the
+//              block, so the first slabs of the NEXT tile land while the compute waves run the
+//              epilogue of the current one: no per-tile prologue, no workgroup turnover.
+// Epilogue (compute waves, no workgroup barrier): each wave rounds its 16-pixel x (PT/2)-channel
+// quarter tiles to bf16 through a private 2-KiB (1-KiB) LDS patch and stores full 128-B (64-B)
+// row segments, 16 B per lane; bias / ReLU-mask operands are prefetched before the last slab.
+// LDS: 3 x 48 KiB ring + 8 x 2 KiB patches = 160 KiB (PT = 128).
+// ---------------------------------------------------------------------------------------
+template <int PT>
+__global__ void __launch_bounds__(768) conv_gather_v4_kernel(const GatherArgs a, const int total_tiles) {
+    constexpr int QT = 256;
+    constexpr int PI = PT / 64, QI = 2;
+    constexpr int STAGE = (PT + QT) * 128;
+    constexpr int NST = 3;
+    constexpr int RING = NST * STAGE;
+    constexpr int WC = PT / 2;                         // channels per compute wave
+    constexpr int ROWB = WC * 2;                       // bytes per pixel row of a wave's patch (128 | 64)
+    constexpr int CPR = ROWB / 16;                     // 16-B chunks per patch row (8 | 4)
+    constexpr int WSTG = 16 * ROWB;                    // patch = 16 pixels
+    constexpr int KPL = (16 * CPR) / 64;               // chunks per lane per round (2 | 1)
+    constexpr int NPRE = 4 * KPL;                      // prefetched epilogue operands (= PI * 4)
+    constexpr int NQ = QT / 32;                        // Q pieces per loader wave per slab (8)
+    constexpr int NP = PT / 32;                        // P pieces per loader wave per slab (4 | 2)
+    constexpr int NL = NQ + NP;
+    static_assert(NPRE == PI * 4, "bias / mask prefetch share registers");
+    __shared__ __attribute__((aligned(16))) char smem[RING + 8 * WSTG];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grid = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, grid);
+    const int nk = (a.dbg & 8) ? 1 : (a.Kdim + 63) >> 6;
+    const int my_tiles = slot < total_tiles ? (total_tiles - slot + grid - 1) / grid : 0;
+    const int G = my_tiles * nk;                       // slabs (= barriers) of this block
+    if (G == 0) return;
+
+    if (wave >= 8) {
+        // ================================ loader waves ================================
+        const int L = wave - 8;
+        const int row_lo = L * 8 + (lane >> 3);        // rows row_lo + 32*i of both operand slabs
+        const int cc = (lane & 7) ^ swz_g(row_lo);     // logical 16-B chunk fetched by this lane
+        const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+        const char* zero = reinterpret_cast<const char*>(g_zero_page);
+        const int HoWo = a.Ho * a.Wo;
+        int kc0, ks0, kr0;
+        {
+            const int klin0 = cc * 8;
+            const int rs = klin0 / a.C;
+            kc0 = klin0 - rs * a.C;
+            kr0 = rs / a.S;
+            ks0 = rs - kr0 * a.S;
+        }
+        long long qoff[NQ], poff[NP];
+        unsigned qmask[NQ], pok = 0;
+        int klin = 0, kc = 0, ks = 0, kr = 0;
+        auto setup_tile = [&](int v) __attribute__((always_inline)) {
+            const int tq = v / a.tiles_p, tp = v - tq * a.tiles_p;
+            const int p0 = tp * PT, q0 = tq * QT;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int m = q0 + row_lo + 32 * i;
+                qoff[i] = 0; qmask[i] = 0;
+                if (m < a.M) {
+                    const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HoWo;
+                    const int ho = (int)fdiv((unsigned)rem, a.div_wo), wo = rem - ho * a.Wo;
+                    const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
+                    qoff[i] = ((long long)(n * a.H + hb) * a.W + wb) * a.ldx * 2ll;
+                    unsigned rm = 0, cm = 0;
+                    for (int r = 0; r < a.R; ++r)
+                        if ((unsigned)(hb + r * a.dil) < (unsigned)a.H) rm |= 1u << r;
+                    for (int s2 = 0; s2 < a.S; ++s2)
+                        if ((unsigned)(wb + s2 * a.dil) < (unsigned)a.W) cm |= 1u << s2;
+                    unsigned mk = 0;
+                    for (int r = 0; r < a.R; ++r)
+                        if ((rm >> r) & 1u) mk |= cm << (r * a.S);
+                    qmask[i] = mk;
+                }
+            }
+            pok = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int row = p0 + row_lo + 32 * i;
+                if (row < a.K) pok |= 1u << i;
+                poff[i] = (long long)row * a.ldw * 2ll;
+            }
+            klin = cc * 8; kc = kc0; ks = ks0; kr = kr0;
+        };
+        int it_i = 0, kt_i = 0;                         // tile / slab of the next slab to issue
+        auto issue = [&](int stage) __attribute__((always_inline)) {
+            const unsigned sP = smem_base + (unsigned)stage * STAGE + (unsigned)L * 1024u;
+            const unsigned sQ = sP + PT * 128;
+            const bool kv = kr < a.R;
+            const int tap = kr * a.S + ks;
+            const long long toff = ((long long)(kr * a.dil) * a.W + ks * a.dil) * a.ldx * 2ll + (long long)kc * 2ll;
+            const bool first = klin < 64;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const bool ok = kv && ((qmask[i] >> tap) & 1u);
+                const char* src = ok ? a.x + qoff[i] + toff : zero;
+                if ((a.dbg & 1) && !first) src = zero;
+                glds16(src, sQ + i * 4096u);
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const bool ok = kv && ((pok >> i) & 1u);
+                const char* src = ok ? a.w + poff[i] + (long long)klin * 2ll : zero;
+                if ((a.dbg & 2) && !first) src = zero;
+                glds16(src, sP + i * 4096u);
+            }
+            klin += 64;
+            kc += 64;
+            while (kc >= a.C) {
+                kc -= a.C;
+                if (++ks == a.S) { ks = 0; ++kr; }
+            }
+            if (++kt_i == nk) {
+                kt_i = 0;
+                if (++it_i < my_tiles) setup_tile(slot + it_i * grid);
+            }
+        };
+        setup_tile(slot);
+        issue(0);
+        if (G > 1) issue(1);
+        int st_n = 2;
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) wait_vmcnt<NL>(); else wait_vmcnt<0>();     // slab g landed (this wave's pieces)
+            block_barrier();          // publish slab g; every compute wave has finished slab g-1 (= stage st_n)
+            if (g + 2 < G && !((a.dbg & 4) && g > 0)) issue(st_n);
+            st_n = st_n == 2 ? 0 : st_n + 1;
+        }
+        return;
+    }
+
+    // ================================== compute waves ==================================
+    const int wp = wave & 1, wq = wave >> 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    char* stg = smem + RING + wave * WSTG;
+    int st_c = 0;
+    for (int it = 0; it < my_tiles; ++it) {
+        const int v = slot + it * grid;
+        const int tq = v / a.tiles_p, tp = v - tq * a.tiles_p;
+        const int p0 = tp * PT, q0 = tq * QT;
+        f32x16_v acc[PI][QI];
+#pragma unroll
+        for (int i = 0; i < PI; ++i)
+#pragma unroll
+            for (int j = 0; j < QI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        uint4 pre[NPRE];
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) pre[i] = make_uint4(0, 0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            block_barrier();                            // slab (it, kt) is in stage st_c
+            if (kt == nk - 1) {
+                // prefetch the epilogue operands under the last slab's MFMAs
+                if (a.bias) {
+#pragma unroll
+                    for (int i = 0; i < PI; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int c = p0 + wp * WC + i * 32 + 8 * g + 4 * hi;
+                            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (c + 3 < a.K) b = *reinterpret_cast<const float4*>(a.bias + c);
+                            else {
+                                if (c < a.K) b.x = a.bias[c];
+                                if (c + 1 < a.K) b.y = a.bias[c + 1];
+                                if (c + 2 < a.K) b.z = a.bias[c + 2];
+                            }
+                            pre[i * 4 + g] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w));
+                        }
+                } else if (a.mask) {
+#pragma unroll
+                    for (int rd = 0; rd < 4; ++rd)
+#pragma unroll
+                        for (int k = 0; k < KPL; ++k) {
+                            const int idx = lane + 64 * k;
+                            const int px = idx / CPR, ch = idx % CPR;
+                            const int m = q0 + wq * 64 + (rd >> 1) * 32 + (rd & 1) * 16 + px, c0 = p0 + wp * WC + ch * 8;
+                            if (m < a.M && c0 < a.ldy)
+                                pre[rd * KPL + k] = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
+                        }
+                }
+            }
+            const char* sP = smem + st_c * STAGE;
+            mma_slab<bf16_t, PI, QI, true>(sP, sP + PT * 128, wp * WC, wq * 64, lane, acc);
+            st_c = st_c == 2 ? 0 : st_c + 1;
+        }
+        // ---- epilogue: 4 rounds of 16 pixels through the wave's private LDS patch
+        const bool pre_relu = a.relu && !a.accumulate;
+#pragma unroll
+        for (int j = 0; j < QI; ++j) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if ((l31 >> 4) == h) {
+                    const int px = l31 & 15;
+#pragma unroll
+                    for (int i = 0; i < PI; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int cl = i * 32 + 8 * g + 4 * hi;
+                            float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                            if (a.bias) {
+                                const uint4 b = pre[i * 4 + g];
+                                v0 += __uint_as_float(b.x); v1 += __uint_as_float(b.y);
+                                v2 += __uint_as_float(b.z); v3 += __uint_as_float(b.w);
+                            }
+                            if (pre_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            uint2 o;
+                            o.x = cvt_pk_bf16(v0, v1);
+                            o.y = cvt_pk_bf16(v2, v3);
+                            *reinterpret_cast<uint2*>(stg + px * ROWB + ((((cl >> 3) ^ px) & (CPR - 1)) << 4) + ((cl & 4) << 1)) = o;
+                        }
+                }
+                // the patch is private to this wave and LDS executes a wave's accesses in order; the clobbers only
+                // stop the COMPILER from moving the 16-B reads across the 8-B writes (different types: TBAA)
+                asm volatile("" ::: "memory");
+                const int rd = j * 2 + h;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) {
+                    const int idx = lane + 64 * k;
+                    const int px = idx / CPR, ch = idx % CPR;
+                    const int m = q0 + wq * 64 + j * 32 + h * 16 + px, c0 = p0 + wp * WC + ch * 8;
+                    uint4 v = *reinterpret_cast<const uint4*>(stg + px * ROWB + (((ch ^ px) & (CPR - 1)) << 4));
+                    if (m < a.M && c0 < a.ldy) {
+                        char* yp = a.y + ((size_t)m * a.ldy + c0) * 2;
+                        if (a.accumulate || a.mask) {
+                            uint4 old = make_uint4(0, 0, 0, 0), mk = make_uint4(0, 0, 0, 0);
+                            if (a.accumulate) old = *reinterpret_cast<const uint4*>(yp);
+                            if (a.mask) {
+                                if (a.bias) mk = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
+                                else mk = pre[rd * KPL + k];
+                            }
+                            post_chunk(v, a.accumulate != 0, a.relu != 0, old, a.mask != nullptr, mk);
+                        }
+                        *reinterpret_cast<uint4*>(yp) = v;
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype) {
+    return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && a.idiv == 1 && a.R * a.S <= 32 && a.ldy % 8 == 0 &&
+           (a.mask == nullptr || a.ldmask % 8 == 0) && a.ldx % 8 == 0 && a.C % 8 == 0;
+}
+
+int launch_gather_v3(GatherArgs& a, hipStream_t st) {
+    const int PT = a.K <= 64 ? 64 : 128;
+    a.tiles_p = ceil_div(a.K, PT);
+    a.tiles_q = ceil_div(a.M, 256);
+    const int grid = a.tiles_p * a.tiles_q;
+    if (PT == 64) hipLaunchKernelGGL(conv_gather_v3_kernel<64>, dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(conv_gather_v3_kernel<128>, dim3(grid), dim3(512), 0, st, a);
+    return 0;
+}
+
+static int g_num_cu = 0;
+int launch_gather_v4(GatherArgs& a, hipStream_t st) {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    const int PT = a.K <= 64 ? 64 : 128;
+    a.tiles_p = ceil_div(a.K, PT);
+    a.tiles_q = ceil_div(a.M, 256);
+    const int tiles = a.tiles_p * a.tiles_q;
+    const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+    if (PT == 64) hipLaunchKernelGGL(conv_gather_v4_kernel<64>, dim3(grid), dim3(768), 0, st, a, tiles);
+    else hipLaunchKernelGGL(conv_gather_v4_kernel<128>, dim3(grid), dim3(768), 0, st, a, tiles);
+    return 0;
+}
+
+bool wgrad_v3_supported(const WgradArgs&, int) { return false; }
+int launch_wgrad_v3(WgradArgs&, hipStream_t) { return 0; }
+
+}  // namespace cv
+}  // namespace odtk

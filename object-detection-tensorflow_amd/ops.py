@@ -63,6 +63,11 @@ def conv_desc(N, H, W, C_, ldx, K, ldy, k, stride=1, dil=1, dtype=BF16, out_dtyp
                     dil=dil, pad_t=pt, pad_l=pl, dtype=dtype, out_dtype=dtype if out_dtype is None else out_dtype)
 
 
+def debug_set(key: int, value: int):
+    """Test/debug knobs of libodtk (include/odtk.h: odtk_debug_set)."""
+    call("odtk_debug_set", int(key), int(value))
+
+
 # ------------------------------------------------------------------ conv family
 def conv2d_fwd(d: ConvDesc, x, w, bias, y, relu: bool):
     call("odtk_conv2d_fwd", C.byref(d), _p(x), _p(w), _p(bias), _p(y), int(relu), _stream())

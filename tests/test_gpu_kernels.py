@@ -54,9 +54,48 @@ def _ref_conv(x_nhwc, w_krsc, b, stride, dil):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
+V3_EXTRA_CASES = [
+    (2, 38, 38, 64, 128, 3, 1, 1),    # 12 pixel tiles of 256, 9 k-slabs
+    (1, 19, 19, 1024, 256, 1, 1, 1),  # 1x1, 16 k-slabs, 2 channel tiles
+    (1, 40, 40, 128, 64, 3, 1, 1),    # PT=64 tile, 18 k-slabs
+    (2, 19, 19, 512, 100, 3, 1, 1),   # deep k (72 slabs), head-like Cout with a channel tail
+    (8, 75, 75, 64, 256, 3, 1, 1),    # 176 x 2 tiles: persistent blocks own > 1 tile on a 256-CU chip
+    (5, 150, 150, 16, 64, 3, 1, 1),   # 440 PT=64 tiles, 3 k-slabs
+]
+
+
+@pytest.fixture(params=[2, 3], ids=["v3-8wave", "v4-persistent"])
+def v3_engine(request):
+    """Force the 8-wave (2) / persistent wave-specialised (3) conv kernels wherever they are
+    supported (odtk_debug_set key 1)."""
+    ops = _ops()
+    ops.debug_set(1, request.param)
+    yield
+    ops.debug_set(1, 0)
+
+
+@pytest.mark.parametrize("case", CONV_CASES + V3_EXTRA_CASES)
+def test_conv_v3_engine(case, dev, v3_engine):
+    _conv_case(case, "bf16", dev)
+
+
+@pytest.mark.parametrize("case", V3_EXTRA_CASES)
+def test_conv_legacy_engine_extra(case, dev):
+    ops = _ops()
+    ops.debug_set(1, 1)
+    try:
+        _conv_case(case, "bf16", dev)
+    finally:
+        ops.debug_set(1, 0)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_fwd_dgrad_wgrad(case, dt, dev):
+    _conv_case(case, dt, dev)
+
+
+def _conv_case(case, dt, dev):
     ops = _ops()
     N, H, W, C, K, k, stride, dil = case
     g = torch.Generator().manual_seed(hash(case) % 1000)

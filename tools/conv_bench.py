@@ -1,50 +1,78 @@
-"""Micro-benchmark of single conv layers through libodtk (GPU)."""
+"""Micro-benchmark of single conv layers through libodtk (GPU), legacy vs 8-wave engine.
+
+usage: python tools/conv_bench.py [layers|all] [passes] [reps] [modes]
+  modes: comma list of odtk_debug_set(1, mode) values (1 = legacy, 2 = 8-wave v3, 3 = persistent v4, 0 = auto);
+         1xx / 2xx = v3 / v4 with perf-experiment bits xx (results garbage)
+"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import odtk
 from odtk import ops
 
-LAYERS = {  # name: (N, H, C, K, k, stride, dil)
+LAYERS = {  # name: (N, H, C, K, k, stride, dil)   (C = padded input channels)
+    'conv1_1': (32, 300, 8, 64, 3, 1, 1),
     'conv1_2': (32, 300, 64, 64, 3, 1, 1),
+    'conv2_1': (32, 150, 64, 128, 3, 1, 1),
     'conv2_2': (32, 150, 128, 128, 3, 1, 1),
+    'conv3_1': (32, 75, 128, 256, 3, 1, 1),
     'conv3_2': (32, 75, 256, 256, 3, 1, 1),
+    'conv4_1': (32, 38, 256, 512, 3, 1, 1),
     'conv4_2': (32, 38, 512, 512, 3, 1, 1),
     'conv5_2': (32, 19, 512, 512, 3, 1, 1),
     'conv6': (32, 19, 512, 1024, 3, 1, 2),
     'conv7': (32, 19, 1024, 1024, 1, 1, 1),
+    'conv8_1': (32, 19, 1024, 256, 1, 1, 1),
+    'conv8_2': (32, 19, 256, 512, 3, 2, 1),
+    'pred1': (32, 38, 512, 100, 3, 1, 1),
+    'pred2': (32, 19, 1024, 150, 3, 1, 1),
 }
-which = sys.argv[1].split(',') if len(sys.argv) > 1 else list(LAYERS)
+which = list(LAYERS) if len(sys.argv) < 2 or sys.argv[1] == 'all' else sys.argv[1].split(',')
 passes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fwd', 'dgrad', 'wgrad']
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+modes = [int(m) for m in sys.argv[4].split(',')] if len(sys.argv) > 4 else [1, 2]
+# mode >= 100: 8-wave kernels with perf-experiment bits (mode - 100) -> odtk_debug_set(2, bits); results are garbage
 dev = torch.device('cuda')
+tot = {m: 0.0 for m in modes}
 for name in which:
     N, H, C, K, k, s, d = LAYERS[name]
-    desc = ops.conv_desc(N, H, H, C, C, K, K, k, s, d, ops.BF16, ops.BF16)
+    Kp = ops.pad_to(K, 8)
+    desc = ops.conv_desc(N, H, H, C, C, K, Kp, k, s, d, ops.BF16, ops.BF16)
     M = N * desc.Ho * desc.Wo
     x = torch.randn(N * H * H, C, device=dev).to(torch.bfloat16)
     w = (torch.randn(K, k, k, C, device=dev) * 0.05)
     wc = w.to(torch.bfloat16).contiguous()
-    wt = torch.empty(C * k * k * K, dtype=torch.bfloat16, device=dev)
-    ops.filter_prepare(w, K, k, k, C, K, ops.BF16, None, wt)
-    y = torch.empty(M, K, dtype=torch.bfloat16, device=dev)
-    dy = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    wt = torch.empty(C * k * k * Kp, dtype=torch.bfloat16, device=dev)
+    ops.filter_prepare(w, K, k, k, C, Kp, ops.BF16, None, wt)
+    y = torch.zeros(M, Kp, dtype=torch.bfloat16, device=dev)
+    dy = torch.randn(M, Kp, device=dev).to(torch.bfloat16)
     dx = torch.empty_like(x)
     dw = torch.zeros(K, k, k, C, device=dev)
     bias = torch.zeros(K, device=dev)
     fl = 2.0 * M * K * C * k * k
     fns = {'fwd': lambda: ops.conv2d_fwd(desc, x, wc, bias, y, True),
-           'dgrad': lambda: ops.conv2d_dgrad(desc, dy, K, wt, x, dx, False),
-           'wgrad': lambda: ops.conv2d_wgrad(desc, x, dy, K, dw, bias)}
+           'dgrad': lambda: ops.conv2d_dgrad(desc, dy, Kp, wt, x, dx, False),
+           'wgrad': lambda: ops.conv2d_wgrad(desc, x, dy, Kp, dw, bias)}
     for p in passes:
+        if p == 'dgrad' and s != 1:
+            continue
         f = fns[p]
-        for _ in range(3):
-            f()
-        torch.cuda.synchronize()
-        s0 = torch.cuda.Event(enable_timing=True); s1 = torch.cuda.Event(enable_timing=True)
-        s0.record()
-        for _ in range(reps):
-            f()
-        s1.record(); torch.cuda.synchronize()
-        t = s0.elapsed_time(s1) / reps * 1e-3
-        print(f'{name:8s} {p:6s} {t*1e6:9.1f} us  {fl/t/1e12:8.1f} TFLOP/s', flush=True)
+        line = f'{name:8s} {p:6s}'
+        for mode in modes:
+            ops.debug_set(1, 3 if mode >= 200 else 2 if mode >= 100 else mode)
+            ops.debug_set(2, mode % 100 if mode >= 100 else 0)
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            s0 = torch.cuda.Event(enable_timing=True); s1 = torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(reps):
+                f()
+            s1.record(); torch.cuda.synchronize()
+            t = s0.elapsed_time(s1) / reps * 1e-3
+            tot[mode] += t
+            line += f' | mode{mode} {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF'
+        print(line, flush=True)
+ops.debug_set(1, 0)
+ops.debug_set(2, 0)
+print('sum of listed launches: ' + ', '.join(f'mode{m} {tot[m]*1e3:.3f} ms' for m in modes))

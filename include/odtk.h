@@ -39,7 +39,8 @@ int odtk_version(void);
 /* number of compute units / name of the current device (host out pointers) */
 int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
 /* test/debug knobs: key 0 = force the register-staged conv gather kernel (value != 0);
- * key 1 = 8-wave / 3-stage conv kernels: 0 auto, 1 never, 2 wherever supported */
+ * key 1 = conv engine: 0 auto, 1 legacy 4-wave kernels, 2 8-wave v3 wherever supported, 3 persistent v4;
+ * key 2 = perf-experiment bits (results wrong when set); key 3 = single-kernel NMS (value != 0) */
 int odtk_debug_set(int key, int value);
 
 /* ------------------------------------------------------------------------- *

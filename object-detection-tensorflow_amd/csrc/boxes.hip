@@ -221,11 +221,26 @@ struct NmsArgs {
     int* out_idx; int cap; int* out_cnt;
 };
 
-__global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
+// Scratch of the split (sort -> suppression bit matrix -> scan) path, one slice per problem.
+constexpr int NMS_TCAP = 4096;                 // candidates covered by the bit matrix (64 words per row)
+constexpr int NMS_WORDS = NMS_TCAP / 64;
+struct NmsScratch {
+    unsigned* sidx;                 // [B][TCAP]  original indices, best first
+    NBox* sbox;                     // [B][TCAP]  their normalised boxes
+    unsigned long long* mat;        // [B][TCAP][WORDS]  bit j of word w of row i: iou(i, 64w+j) > thr
+    int* info;                      // [B][4] = {lim, nvalid, mo, fallback flag}
+};
+
+// MODE 0: whole problem in one workgroup (sort + greedy selection by wave 0); with `flags`
+//         only problems whose info[b][3] != 0 are processed (fallback of the split path).
+// MODE 1: sort only; emits the best `lim` candidates for the bit-matrix path.
+template <int MODE>
+__global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a, const NmsScratch ws, const int use_flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     __shared__ int s_nvalid;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (MODE == 0 && use_flags && ws.info[b * 4 + 3] == 0) return;
     const int SZ = a.SZ;
     if (tid == 0) s_nvalid = 0;
     __syncthreads();
@@ -274,13 +289,31 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
         for (int i = tid; i < SZ; i += NMS_THREADS, ++c) sidx[i] = idxreg[c];
     }
     __syncthreads();
+    int mo = a.max_out_dev ? a.max_out_dev[(long long)b * a.max_out_stride] : a.max_out_const;
+    if (mo > a.cap) mo = a.cap;
+    if (mo < 0) mo = 0;
+    const float* boxes = a.boxes + b * a.box_stride;
+    if (MODE == 1) {
+        // candidates the scan may have to visit: mo picks + a margin for suppressed ones
+        int lim = (mo + mo / 2 + 256 + 63) & ~63;
+        if (lim > NMS_TCAP) lim = NMS_TCAP;
+        if (lim > nvalid) lim = nvalid;
+        if (mo == 0) lim = 0;
+        for (int i = tid; i < lim; i += NMS_THREADS) {
+            const unsigned idx = sidx[i];
+            const float4 raw = *reinterpret_cast<const float4*>(boxes + (size_t)idx * 4);
+            ws.sidx[(size_t)b * NMS_TCAP + i] = idx;
+            ws.sbox[(size_t)b * NMS_TCAP + i] = norm_box(raw.x, raw.y, raw.z, raw.w);
+        }
+        if (tid == 0) {
+            ws.info[b * 4 + 0] = lim; ws.info[b * 4 + 1] = nvalid; ws.info[b * 4 + 2] = mo; ws.info[b * 4 + 3] = 0;
+        }
+        return;
+    }
     if (wave != 0) return;
 
     NBox* selbox = reinterpret_cast<NBox*>(smem + (size_t)SZ * 4);
     const int selcap = SZ / 4;                       // boxes that fit in the freed half
-    int mo = a.max_out_dev ? a.max_out_dev[(long long)b * a.max_out_stride] : a.max_out_const;
-    if (mo > a.cap) mo = a.cap;
-    const float* boxes = a.boxes + b * a.box_stride;
     int* oidx = a.out_idx + (long long)b * a.cap;
     int count = 0;
     for (int base = 0; base < nvalid && count < mo; base += 64) {
@@ -326,6 +359,98 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     if (lane == 0) a.out_cnt[b] = count;
+}
+
+
+// Suppression bit matrix of the best `lim` candidates of every problem: one 256-thread workgroup
+// per (64-row block, problem); wave w takes the column blocks rb + w, rb + w + 4, ...; lane = row.
+// Exactly iou_nms() per pair, so the scan below reproduces the greedy result bit for bit.
+__global__ void __launch_bounds__(256) nms_matrix_kernel(const NmsScratch ws, const float thr) {
+    __shared__ NBox s_col[4][64];
+    const int rb = blockIdx.x, b = blockIdx.y;
+    const int lim = ws.info[b * 4 + 0];
+    if (rb * 64 >= lim) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = (lim + 63) >> 6;
+    const NBox* sbox = ws.sbox + (size_t)b * NMS_TCAP;
+    const int row = rb * 64 + lane;
+    const NBox bx = sbox[row];
+    unsigned long long* mrow = ws.mat + ((size_t)b * NMS_TCAP + row) * NMS_WORDS;
+    for (int cb = rb + wave; cb < nb; cb += 4) {
+        s_col[wave][lane] = sbox[cb * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        unsigned long long bits = 0ull;
+#pragma unroll 4
+        for (int j = 0; j < 64; ++j) {
+            const NBox cj = s_col[wave][j];
+            if (iou_nms(bx, cj) > thr) bits |= 1ull << j;
+        }
+        mrow[cb] = bits;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// Greedy selection over the bit matrix: one wave per problem, lane w owns word w of the
+// "suppressed" set.  Row blocks are visited in order; inside a block the picks are resolved on the
+// diagonal word (wave-uniform bit loop), then the rows of the picked candidates are OR-ed in.
+__global__ void __launch_bounds__(64) nms_scan_kernel(const NmsScratch ws, int* __restrict__ out_idx, const int cap,
+                                                      int* __restrict__ out_cnt) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int lim = ws.info[b * 4 + 0], nvalid = ws.info[b * 4 + 1], mo = ws.info[b * 4 + 2];
+    const unsigned* sidx = ws.sidx + (size_t)b * NMS_TCAP;
+    const unsigned long long* mat = ws.mat + (size_t)b * NMS_TCAP * NMS_WORDS;
+    int* oidx = out_idx + (long long)b * cap;
+    const int nb = (lim + 63) >> 6;
+    unsigned long long removed = 0ull;          // word `lane`
+    int count = 0;
+    for (int rb = 0; rb < nb && count < mo; ++rb) {
+        const int row = rb * 64 + lane;
+        const unsigned long long diag = row < lim ? mat[(size_t)row * NMS_WORDS + rb] : 0ull;
+        const unsigned myidx = row < lim ? sidx[row] : 0u;
+        const unsigned long long curv = __shfl(removed, rb);
+        // wave-uniform by construction: keep it in SGPRs so the pick loop below is scalar code
+        // (readfirstlane returns int: go through unsigned, or bit 31 of the low word sign-extends)
+        const unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)curv);
+        const unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(curv >> 32));
+        unsigned long long cur = ((unsigned long long)cur_hi << 32) | (unsigned long long)cur_lo;
+        const int rem = lim - rb * 64;
+        if (rem < 64) cur |= ~0ull << rem;                        // rows past the candidate list
+        unsigned long long picked = 0ull;
+        while (count < mo) {
+            const unsigned long long avail = ~cur;
+            if (!avail) break;
+            const int j = __ffsll((long long)avail) - 1;          // wave-uniform
+            picked |= 1ull << j;
+            ++count;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)diag, j);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), j);
+            cur |= (((unsigned long long)hi << 32) | lo) | (1ull << j);
+        }
+        // emit this block's picks in order
+        const int base = count - __popcll(picked);
+        if ((picked >> lane) & 1ull) oidx[base + __popcll(picked & ((1ull << lane) - 1ull))] = (int)myidx;
+        // suppress later blocks by every picked row (loads are independent: keep several in flight)
+        unsigned long long p = picked;
+        if (rb + 1 < nb) {
+            while (p) {
+                unsigned long long acc4 = 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (p) {
+                        const int j = __ffsll((long long)p) - 1;
+                        p &= p - 1ull;
+                        acc4 |= mat[(size_t)(rb * 64 + j) * NMS_WORDS + lane];
+                    }
+                }
+                removed |= acc4;
+            }
+        }
+    }
+    if (lane == 0) {
+        const bool exhausted = count < mo && lim < nvalid;        // margin too small: redo this problem the slow way
+        ws.info[b * 4 + 3] = exhausted ? 1 : 0;
+        if (!exhausted) out_cnt[b] = count;
+    }
 }
 
 // ------------------------------------------------------------------ fused loss + gradient
@@ -462,6 +587,31 @@ __global__ void ssd_decode_kernel(const float* __restrict__ pred, int A, int C, 
     boxes[4 * a + 2] = cy + h / 2.f; boxes[4 * a + 3] = cx + w / 2.f;
 }
 
+
+static bool g_nms_legacy = false;      // odtk_debug_set key 3
+// per-device scratch of the split NMS path, grown on demand (never freed; reused by every call on
+// the device -- calls are stream-ordered by the caller, as everything else in this library)
+struct NmsScratchOwner { void* base = nullptr; int B = 0; };
+static NmsScratchOwner g_nms_scratch[16];
+static int nms_scratch(int B, NmsScratch* ws) {
+    int dev = 0;
+    ODTK_CHECK_HIP(hipGetDevice(&dev));
+    ODTK_REQUIRE(dev >= 0 && dev < 16, "nms: device index %d unsupported", dev);
+    NmsScratchOwner& o = g_nms_scratch[dev];
+    if (o.B < B) {
+        if (o.base) ODTK_CHECK_HIP(hipFree(o.base));
+        o.base = nullptr; o.B = 0;
+        const size_t per = (size_t)NMS_TCAP * (4 + 16 + NMS_WORDS * 8) + 64;
+        ODTK_CHECK_HIP(hipMalloc(&o.base, per * B));
+        o.B = B;
+    }
+    char* p = (char*)o.base;
+    ws->mat = (unsigned long long*)p; p += (size_t)o.B * NMS_TCAP * NMS_WORDS * 8;
+    ws->sbox = (NBox*)p;              p += (size_t)o.B * NMS_TCAP * 16;
+    ws->sidx = (unsigned*)p;          p += (size_t)o.B * NMS_TCAP * 4;
+    ws->info = (int*)p;
+    return ODTK_OK;
+}
 }  // namespace
 }  // namespace odtk
 
@@ -511,6 +661,10 @@ extern "C" int odtk_softmax_ce_const(const float* pred, long long rows, int C, i
     return ODTK_OK;
 }
 
+namespace odtk {
+void set_nms_legacy(bool on) { g_nms_legacy = on; }
+}  // namespace odtk
+
 extern "C" int odtk_nms_batched(const float* boxes, long long box_stride, const float* scores,
                                 long long score_bstride, int score_estride, const unsigned char* valid,
                                 long long valid_bstride, int valid_estride, int valid_value, int n, int B,
@@ -534,10 +688,23 @@ extern "C" int odtk_nms_batched(const float* boxes, long long box_stride, const 
     const size_t lds = (size_t)SZ * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        ODTK_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        ODTK_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        ODTK_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         attr_set = true;
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    NmsScratch ws = {nullptr, nullptr, nullptr, nullptr};
+    if (g_nms_legacy) {
+        hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 0);
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
+    // split path: sort -> suppression bit matrix -> scan (+ whole-problem fallback for flagged problems)
+    if (int e = nms_scratch(B, &ws)) return e;
+    hipLaunchKernelGGL(nms_kernel<1>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 0);
+    hipLaunchKernelGGL(nms_matrix_kernel, dim3(NMS_WORDS, B), dim3(256), 0, st, ws, iou_threshold);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, ws, out_idx, cap, out_cnt);
+    hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 1);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -9,6 +9,7 @@
 namespace odtk {
 
 void set_error(const char* fmt, ...);
+void set_nms_legacy(bool on);   // boxes.hip: odtk_debug_set key 3
 
 #define ODTK_CHECK_HIP(expr)                                                         \
     do {                                                                             \

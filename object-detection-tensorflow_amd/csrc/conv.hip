@@ -815,6 +815,7 @@ extern "C" int odtk_debug_set(int key, int value) {
     if (key == 0) { g_force_regstage = value != 0; return ODTK_OK; }
     if (key == 1) { g_v3_mode = value; return ODTK_OK; }
     if (key == 2) { g_dbg = value; return ODTK_OK; }
+    if (key == 3) { set_nms_legacy(value != 0); return ODTK_OK; }
     set_error("debug_set: unknown key %d", key);
     return ODTK_ERR_ARG;
 }
@@ -887,7 +888,7 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == ODTK_BF16) {
-        if (PT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), grid, dim3(256), 0, st, a);
+        if (PT == 64 && (g_v3_mode == 1 || g_force_regstage)) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), grid, dim3(256), 0, st, a);
         else if (!g_force_regstage) hipLaunchKernelGGL(conv_wgrad_dma_kernel, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128>), grid, dim3(256), 0, st, a);
     } else {

@@ -382,8 +382,19 @@ def test_match_bit_exact(dev):
 
 @pytest.mark.parametrize("n,thr,max_out", [(50, 0.5, 20), (700, 0.5, 20), (8828, 0.7, 513), (8828, 0.7, 8828),
                                            (3000, 0.3, 100), (1, 0.5, 5), (65, 0.0, 65)])
-def test_nms_bit_exact_vs_reference_kernel(n, thr, max_out, dev):
+@pytest.mark.parametrize("engine", ["split", "single"])
+def test_nms_bit_exact_vs_reference_kernel(n, thr, max_out, engine, dev):
+    """split = sort -> suppression bit matrix -> scan (+ single-kernel fallback when the candidate
+    margin is exhausted, exercised by max_out = 8828); single = one workgroup per problem."""
     ops = _ops()
+    ops.debug_set(3, 1 if engine == "single" else 0)
+    try:
+        _nms_case(ops, n, thr, max_out, dev)
+    finally:
+        ops.debug_set(3, 0)
+
+
+def _nms_case(ops, n, thr, max_out, dev):
     g = torch.Generator().manual_seed(n + max_out)
     B = 3
     idx_all, cnt_all = [], []

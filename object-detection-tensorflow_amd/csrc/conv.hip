@@ -598,6 +598,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) 
             const int p = it * PKE + piece * 4 + dr;
             const bool pin = p < a.P;
             const char* src = (pin && p_col_ok) ? a.dy + ((size_t)p * a.lddy + pch) * 2 : zero;
+            if ((a.dbg & 1) && it != it0) src = zero;
             glds16(src, sP + (unsigned)piece * 1024u);
             const char* srcq = zero;
             if (pin && q_col_ok) {
@@ -609,6 +610,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) 
                 if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
                     srcq = a.x + ((size_t)(((int)n * a.H + hi) * a.W + wi) * a.ldx + qc) * 2;
             }
+            if ((a.dbg & 1) && it != it0) srcq = zero;
             glds16(srcq, sQ + (unsigned)piece * 1024u);
         }
     };
@@ -645,7 +647,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) 
             const int st = (it - it0) & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (it + 1 < it1) issue(it + 1, st ^ 1);
+            if (it + 1 < it1 && !((a.dbg & 4) && it > it0)) issue(it + 1, st ^ 1);
             const unsigned sP = smem_base + (unsigned)st * STAGE;
             const unsigned sQ = sP + OPB;
 #pragma unroll
@@ -690,7 +692,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = p0 + wp * 64 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                if (k < a.K && !(a.dbg & 16)) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
             }
         }
     }
@@ -885,6 +887,7 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     splits = ceil_div(iters_total, a.iters_per_split);
     a.div_howo = make_fastdiv((unsigned)(d->Ho * d->Wo));
     a.div_wo = make_fastdiv((unsigned)d->Wo);
+    a.dbg = g_dbg;
     dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == ODTK_BF16) {

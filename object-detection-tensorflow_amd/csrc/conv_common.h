@@ -78,6 +78,37 @@ __device__ __forceinline__ void mma_slab(const char* sP, const char* sQ, int pro
     }
 }
 
+// Same slab product with the fragments of sub-step ks+1 in flight while the MFMAs of sub-step ks
+// issue (two register sets): hides LDS latency that grows when LDS-DMA writes share the LDS.
+template <typename T, int PI, int QI>
+__device__ __forceinline__ void mma_slab_db(const char* sP, const char* sQ, int prow0, int qrow0,
+                                            int lane, f32x16_v (&acc)[PI][QI]) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    uint4 pf[2][PI], qf[2][QI];
+    auto load = [&](int ks, uint4 (&p)[PI], uint4 (&q)[QI]) __attribute__((always_inline)) {
+        const int slot = ks * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int row = prow0 + i * 32 + l31;
+            p[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + ((slot ^ swz_g(row)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < QI; ++j) {
+            const int row = qrow0 + j * 32 + l31;
+            q[j] = *reinterpret_cast<const uint4*>(sQ + row * 128 + ((slot ^ swz_g(row)) << 4));
+        }
+    };
+    load(0, pf[0], qf[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) load(ks + 1, pf[(ks + 1) & 1], qf[(ks + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < PI; ++i)
+#pragma unroll
+            for (int j = 0; j < QI; ++j) Mma<T>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
+    }
+}
+
 // XCD-aware bijective remap of the linear block id (block b runs on XCD b % 8): every XCD gets
 // a contiguous range of tiles so neighbouring tiles share their operand panels in one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -112,6 +143,7 @@ struct WgradArgs {
     int P, RSC;
     int tiles_p, tiles_q, iters_per_split;
     FastDiv div_howo, div_wo;
+    int dbg;         // perf experiments only (odtk_debug_set key 2): bit0/1 zero-page DMA sources, bit2 no DMA after slab 0, bit4 no atomics
 };
 
 // 16 bytes of zeros that padded / out-of-range LDS-DMA lanes fetch instead of branching

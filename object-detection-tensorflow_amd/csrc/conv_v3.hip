@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 // ---------------------------------------------------------------------------------------
 // gather kernel (forward conv, stride-1 dgrad)
 // ---------------------------------------------------------------------------------------
-template <int PT>
+template <int PT, bool DB>
 __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
     constexpr int QT = 256;
     constexpr int PI = PT / 64, QI = 2, PL = PT / 64;
@@ -200,9 +200,17 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();   // this wave's pieces of slab kt landed
         block_barrier();            // ... everybody's did; everybody finished reading slab kt-1 (= stage st_n)
-        if (kt + 2 < nk && !((a.dbg & 4) && kt > 0)) issue(st_n);
+        // Waves w and w+4 share a SIMD.  The first half issues its LDS-DMA pieces BEFORE its MFMAs, the second
+        // half AFTER them, so that on every SIMD one wave feeds the matrix pipe while its partner is blocked in
+        // the (100+ cycles per piece) DMA issue path -- otherwise all eight waves leave the barrier in the same
+        // phase and the two phases serialise (dbg bit 6 restores that order for A/B runs).
+        const bool do_issue = kt + 2 < nk && !((a.dbg & 4) && kt > 0);
+        const bool late = wave_u >= 4 && !(a.dbg & 64);
+        if (do_issue && !late) issue(st_n);
         const char* sP = smem + st_c * STAGE;
-        mma_slab<bf16_t, PI, QI, true>(sP, sP + PT * 128, wp * (PT / 2), wq * 64, lane, acc);
+        if (DB) mma_slab_db<bf16_t, PI, QI>(sP, sP + PT * 128, wp * (PT / 2), wq * 64, lane, acc);
+        else mma_slab<bf16_t, PI, QI, true>(sP, sP + PT * 128, wp * (PT / 2), wq * 64, lane, acc);
+        if (do_issue && late) issue(st_n);
         st_c = st_c == 2 ? 0 : st_c + 1;
         st_n = st_n == 2 ? 0 : st_n + 1;
     }
@@ -475,8 +483,14 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     a.tiles_p = ceil_div(a.K, PT);
     a.tiles_q = ceil_div(a.M, 256);
     const int grid = a.tiles_p * a.tiles_q;
-    if (PT == 64) hipLaunchKernelGGL(conv_gather_v3_kernel<64>, dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(conv_gather_v3_kernel<128>, dim3(grid), dim3(512), 0, st, a);
+    const bool db = (a.dbg & 32) == 0;      // fragment double buffering (default on; dbg bit 5 turns it off)
+    if (PT == 64) {
+        if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true>), dim3(grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v3_kernel<64, false>), dim3(grid), dim3(512), 0, st, a);
+    } else {
+        if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<128, true>), dim3(grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v3_kernel<128, false>), dim3(grid), dim3(512), 0, st, a);
+    }
     return 0;
 }
 

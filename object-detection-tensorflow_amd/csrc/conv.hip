@@ -650,29 +650,34 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) 
             if (it + 1 < it1 && !((a.dbg & 4) && it > it0)) issue(it + 1, st ^ 1);
             const unsigned sP = smem_base + (unsigned)st * STAGE;
             const unsigned sQ = sP + OPB;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                uint4 pf[PI], qf[QI];
+            // two fragment register sets: the transpose reads of sub-step ks+1 are in flight under the MFMAs of ks
+            uint4 pf[2][PI], qf[2][QI];
+            auto ldf = [&](int ks, uint4 (&p)[PI], uint4 (&q)[QI]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < PI; ++i) {
                     const uint2 lo = lds_tr16(sP + ks * 4096u + pfo[i]);
                     const uint2 hi2 = lds_tr16(sP + ks * 4096u + 1024u + pfo[i]);
-                    pf[i] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                    p[i] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
                 }
 #pragma unroll
                 for (int j = 0; j < QI; ++j) {
                     const uint2 lo = lds_tr16(sQ + ks * 4096u + qfo[j]);
                     const uint2 hi2 = lds_tr16(sQ + ks * 4096u + 1024u + qfo[j]);
-                    qf[j] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                    q[j] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
                 }
+            };
+            ldf(0, pf[0], qf[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) ldf(ks + 1, pf[(ks + 1) & 1], qf[(ks + 1) & 1]);
 #pragma unroll
                 for (int i = 0; i < PI; ++i)
 #pragma unroll
-                    for (int j = 0; j < QI; ++j) Mma<bf16_t>::run(pf[i], qf[j], acc[i][j]);
+                    for (int j = 0; j < QI; ++j) Mma<bf16_t>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
                 if (do_bias) {
 #pragma unroll
                     for (int i = 0; i < PI; ++i) {
-                        const unsigned* d = reinterpret_cast<const unsigned*>(&pf[i]);
+                        const unsigned* d = reinterpret_cast<const unsigned*>(&pf[ks & 1][i]);
 #pragma unroll
                         for (int h = 0; h < 4; ++h)
                             bsum[i] += __uint_as_float(d[h] << 16) + __uint_as_float(d[h] & 0xffff0000u);

@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 // ---------------------------------------------------------------------------------------
 // gather kernel (forward conv, stride-1 dgrad)
 // ---------------------------------------------------------------------------------------
-template <int PT, bool DB>
+template <int PT, bool DB, bool EARLY>
 __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
     constexpr int QT = 256;
     constexpr int PI = PT / 64, QI = 2, PL = PT / 64;
@@ -194,6 +194,61 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (a.dbg & 8) ? 1 : (a.Kdim + 63) >> 6;
+    if (EARLY) {
+        // "Landed one slab early" protocol: at the top of iteration kt slabs kt AND kt+1 are published, so the
+        // first fragments of slab kt+1 are read BEFORE barrier kt+1 and the matrix pipe restarts right behind
+        // the barrier instead of waiting for an LDS round trip.  Price: a slab has one iteration (not two) to land.
+        const int l31 = lane & 31, hi = lane >> 5;
+        const int prow0 = wp * (PT / 2), qrow0 = wq * 64;
+        uint4 pfA[PI], qfA[QI], pfB[PI], qfB[QI];
+        auto ldf = [&](const char* sP, int ks, uint4 (&pf)[PI], uint4 (&qf)[QI]) __attribute__((always_inline)) {
+            const char* sQ = sP + PT * 128;
+            const int slot = ks * 2 + hi;
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
+                const int row = prow0 + i * 32 + l31;
+                pf[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + ((slot ^ swz_g(row)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < QI; ++j) {
+                const int row = qrow0 + j * 32 + l31;
+                qf[j] = *reinterpret_cast<const uint4*>(sQ + row * 128 + ((slot ^ swz_g(row)) << 4));
+            }
+        };
+        auto mm = [&](uint4 (&pf)[PI], uint4 (&qf)[QI]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < PI; ++i)
+#pragma unroll
+                for (int j = 0; j < QI; ++j) Mma<bf16_t>::run(pf[i], qf[j], acc[i][j]);
+        };
+        const bool late = wave_u >= 4;
+        issue(0);
+        if (nk > 1) issue(1);
+        wait_vmcnt<0>();
+        block_barrier();                                 // slabs 0 and 1 published
+        if (nk > 2) issue(2);
+        ldf(smem, 0, pfA, qfA);
+        int st_c = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sP = smem + st_c * STAGE;
+            const int st_1 = st_c == 2 ? 0 : st_c + 1;
+            const bool do_issue = kt > 0 && kt + 2 < nk;          // refills stage of slab kt-1 with slab kt+2
+            const int st_prev = st_c == 0 ? 2 : st_c - 1;
+            if (do_issue && !late) issue(st_prev);
+            ldf(sP, 1, pfB, qfB);
+            mm(pfA, qfA);
+            ldf(sP, 2, pfA, qfA);
+            mm(pfB, qfB);
+            if (do_issue && late) issue(st_prev);
+            ldf(sP, 3, pfB, qfB);
+            mm(pfA, qfA);
+            if (kt + 1 < nk) ldf(smem + st_1 * STAGE, 0, pfA, qfA);   // slab kt+1 was published one barrier ago
+            mm(pfB, qfB);
+            wait_vmcnt<0>();                              // my pieces of slab kt+2 landed
+            block_barrier();                              // slab kt+2 published; slab kt fully consumed
+            st_c = st_1;
+        }
+    } else {
     issue(0);
     if (nk > 1) issue(1);
     int st_c = 0, st_n = 2;                             // stage consumed now / stage to refill
@@ -215,6 +270,7 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         st_n = st_n == 2 ? 0 : st_n + 1;
     }
     block_barrier();                                    // all slab reads done: LDS is free for the output image
+    }
     epilogue_bf16<PT, QT, 512, PI, QI>(a, smem, acc, p0, q0, wp * (PT / 2), wq * 64, tid);
 }
 
@@ -484,12 +540,15 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     a.tiles_q = ceil_div(a.M, 256);
     const int grid = a.tiles_p * a.tiles_q;
     const bool db = (a.dbg & 32) == 0;      // fragment double buffering (default on; dbg bit 5 turns it off)
+    const bool early = (a.dbg & 128) != 0;  // "landed one slab early" protocol (dbg bit 7, A/B)
     if (PT == 64) {
-        if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true>), dim3(grid), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((conv_gather_v3_kernel<64, false>), dim3(grid), dim3(512), 0, st, a);
+        if (early) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, true>), dim3(grid), dim3(512), 0, st, a);
+        else if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false>), dim3(grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v3_kernel<64, false, false>), dim3(grid), dim3(512), 0, st, a);
     } else {
-        if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<128, true>), dim3(grid), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((conv_gather_v3_kernel<128, false>), dim3(grid), dim3(512), 0, st, a);
+        if (early) hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, true>), dim3(grid), dim3(512), 0, st, a);
+        else if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, false>), dim3(grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v3_kernel<128, false, false>), dim3(grid), dim3(512), 0, st, a);
     }
     return 0;
 }

@@ -222,21 +222,44 @@ __device__ __forceinline__ long long out_off(int m, int rows_per_img, long long 
 
 // per-channel scale/offset from the partial sums (training) or the moving stats (inference);
 // one thread per channel.  fin[0*C + c] = scale, fin[1*C + c] = offset.
+// Sum the [2][nsplit][C] partials of 32 channels with 8 split-lanes per channel (fixed order ->
+// deterministic), result valid in the threads with sl == 0.  Block = 256 threads.
+constexpr int FIN_CH = 32, FIN_SL = 8;
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ ws, int nsplit, int C, int c, int sl,
+                                                float& s1, float& s2) {
+    __shared__ float sm[2][FIN_SL][FIN_CH];
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+        for (int s = sl; s < nsplit; s += FIN_SL) {
+            a1 += ws[((size_t)0 * nsplit + s) * C + c];
+            a2 += ws[((size_t)1 * nsplit + s) * C + c];
+        }
+    }
+    const int cl = threadIdx.x & (FIN_CH - 1);
+    sm[0][sl][cl] = a1;
+    sm[1][sl][cl] = a2;
+    __syncthreads();
+    s1 = 0.f; s2 = 0.f;
+    if (sl == 0) {
+#pragma unroll
+        for (int k = 0; k < FIN_SL; ++k) { s1 += sm[0][k][cl]; s2 += sm[1][k][cl]; }
+    }
+}
+
+// per-channel scale/offset from the partial sums (training) or the moving stats (inference).
+// fin[0*C + c] = scale, fin[1*C + c] = offset.  Grid = ceil(C / 32) blocks of 256 threads.
 template <typename T>
-__global__ void bn_finalize_kernel(const T* __restrict__ z, int M, int C, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const T* __restrict__ z, int M, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ mmean,
                                    float* __restrict__ mvar, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd, int training, const float* __restrict__ ws,
                                    int nsplit, float* __restrict__ fin) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), sl = threadIdx.x / FIN_CH;
+    float s1 = 0.f, s2 = 0.f;
+    if (training) reduce_partials(ws, nsplit, C, c, sl, s1, s2);
+    if (c >= C || sl != 0) return;
     float mean, var;
     if (training) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
-            s1 += ws[((size_t)0 * nsplit + s) * C + c];
-            s2 += ws[((size_t)1 * nsplit + s) * C + c];
-        }
         const float d = s1 / (float)M;
         mean = elem<T>::load(z[c]) + d;
         var = fmaxf(s2 / (float)M - d * d, 0.f);
@@ -349,16 +372,13 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
 }
 
 // fin[0*C+c] = mean(dy'), fin[1*C+c] = mean(dy' * xhat); also emits dbeta / dgamma
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, int nsplit, int C, int M,
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ ws, int nsplit, int C, int M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ fin) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        s1 += ws[((size_t)0 * nsplit + s) * C + c];
-        s2 += ws[((size_t)1 * nsplit + s) * C + c];
-    }
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), sl = threadIdx.x / FIN_CH;
+    float s1, s2;
+    reduce_partials(ws, nsplit, C, c, sl, s1, s2);
+    if (c >= C || sl != 0) return;
     dbeta[c] = s1;
     dgamma[c] = s2;
     fin[c] = s1 / (float)M;
@@ -698,7 +718,7 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
         DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
                                                (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
     }
-    DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, 128)), dim3(128), 0, st, (const T*)z, M,
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M,
                                            C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
                                            pl.nsplit, fin);)
     const size_t ysz = dtype_size(y_dtype);
@@ -738,7 +758,7 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu,   \
                        pl.rows_per_split, ws);                                                                    \
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, ws, pl.nsplit, C, M,     \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, ws, pl.nsplit, C, M,     \
                        dgamma, dbeta, fin);                                                                       \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd,  \

@@ -778,6 +778,8 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
     a.div_howo = make_fastdiv((unsigned)(a.Ho * a.Wo));
     a.div_wo = make_fastdiv((unsigned)a.Wo);
     a.dbg = g_dbg;
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * dtype_size(dtype));
+    a.w_bytes = (unsigned)((size_t)ceil_div(a.K, 1) * a.ldw * dtype_size(dtype));
     if (!g_force_regstage && g_v3_mode != 1 && gather_v3_supported(a, dtype, out_dtype) &&
         (g_v3_mode >= 2 || gather_v3_auto(a))) {
         if (g_v3_mode == 3) launch_gather_v4(a, st);
@@ -877,6 +879,14 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     a.Ho = d->Ho; a.Wo = d->Wo; a.K = d->K; a.lddy = lddy;
     a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
     a.P = d->N * d->Ho * d->Wo; a.RSC = d->R * d->S * d->C;
+    a.div_howo = make_fastdiv((unsigned)(d->Ho * d->Wo));
+    a.div_wo = make_fastdiv((unsigned)d->Wo);
+    a.dbg = g_dbg;
+    if (!g_force_regstage && g_v3_mode != 1 && wgrad_v3_supported(a, d->dtype)) {
+        launch_wgrad_v3(a, (hipStream_t)stream);
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     const int PT = d->K <= 64 ? 64 : 128;
     a.tiles_p = ceil_div(d->K, PT);
     a.tiles_q = ceil_div(a.RSC, 128);

@@ -130,6 +130,7 @@ struct GatherArgs {
     int tiles_p, tiles_q;
     FastDiv div_howo, div_wo;
     int dbg;           // perf experiments only (odtk_debug_set key 2): bit0 skip pixel-operand DMA, bit1 skip filter DMA after slab 0
+    unsigned x_bytes, w_bytes;   // extents of x and w for the buffer-addressed DMA (range check = zero fill)
 };
 
 struct WgradArgs {
@@ -144,6 +145,7 @@ struct WgradArgs {
     int tiles_p, tiles_q, iters_per_split;
     FastDiv div_howo, div_wo;
     int dbg;         // perf experiments only (odtk_debug_set key 2): bit0/1 zero-page DMA sources, bit2 no DMA after slab 0, bit4 no atomics
+    unsigned x_bytes, dy_bytes;   // extents for the buffer-addressed DMA (8-wave kernel)
 };
 
 // 16 bytes of zeros that padded / out-of-range LDS-DMA lanes fetch instead of branching
@@ -159,6 +161,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_addr)
                  : "memory");
+}
+// Buffer-addressed LDS-DMA piece: 32-bit per-lane byte offset into a raw buffer; lanes whose offset is
+// >= num_records (e.g. 0xFFFFFFF0 for padded / out-of-range taps) fetch ZEROS by the hardware range check,
+// so no zero page, no 64-bit address arithmetic, no M0 save/restore (nothing else in these kernels uses M0).
+__device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :
+                 : "v"(voff), "s"(lds_addr), "s"(rsrc)
+                 : "memory");
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;

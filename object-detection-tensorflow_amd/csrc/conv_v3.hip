@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 // ---------------------------------------------------------------------------------------
 // gather kernel (forward conv, stride-1 dgrad)
 // ---------------------------------------------------------------------------------------
-template <int PT, bool DB, bool EARLY>
+template <int PT, bool DB, bool EARLY, bool BUF>
 __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
     constexpr int QT = 256;
     constexpr int PI = PT / 64, QI = 2, PL = PT / 64;
@@ -117,17 +117,20 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 
     // per pixel row: byte offset of tap (0,0) channel 0, and the bit mask of in-range taps
     long long qoff[4];
+    unsigned qoff32[4];
     unsigned qmask[4];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rw = make_rsrc(a.w, a.w_bytes);
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = q0 + r0 + 64 * i;
-        qoff[i] = 0; qmask[i] = 0;
+        qoff[i] = 0; qmask[i] = 0; qoff32[i] = 0;
         if (m < a.M) {
             const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HoWo;
             const int ho = (int)fdiv((unsigned)rem, a.div_wo), wo = rem - ho * a.Wo;
             const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
             qoff[i] = ((long long)(n * a.H + hb) * a.W + wb) * a.ldx * 2ll;
+            qoff32[i] = (unsigned)(((n * a.H + hb) * a.W + wb) * a.ldx * 2);     // may wrap below 0: only used with in-range taps
             unsigned rm = 0, cm = 0;
             for (int r = 0; r < a.R; ++r)
                 if ((unsigned)(hb + r * a.dil) < (unsigned)a.H) rm |= 1u << r;
@@ -140,12 +143,14 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         }
     }
     long long poff[PL];
+    unsigned poff32[PL];
     bool pok[PL];
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
         const int row = p0 + r0 + 64 * i;
         pok[i] = row < a.K;
         poff[i] = (long long)row * a.ldw * 2ll;
+        poff32[i] = (unsigned)(row * a.ldw * 2);
     }
     int klin = cc * 8;
     int kc, ks, kr;
@@ -163,6 +168,16 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         const int tap = kr * a.S + ks;
         const long long toff = ((long long)(kr * a.dil) * a.W + ks * a.dil) * a.ldx * 2ll + (long long)kc * 2ll;
         const bool first = klin < 64;
+        if (BUF) {
+            const unsigned toff32 = (unsigned)(((kr * a.dil) * a.W + ks * a.dil) * a.ldx * 2 + kc * 2);
+            const unsigned tapbit = kv ? (1u << tap) : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                glds16_buf(rx, (qmask[i] & tapbit) ? qoff32[i] + toff32 : 0xFFFFFFF0u, sQ + i * 8192u);
+#pragma unroll
+            for (int i = 0; i < PL; ++i)      // rows >= K and the k tail fetch zeros
+                glds16_buf(rw, (kv && pok[i]) ? poff32[i] + (unsigned)(klin * 2) : 0xFFFFFFF0u, sP + i * 8192u);
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = kv && ((qmask[i] >> tap) & 1u);
@@ -176,6 +191,7 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
             const char* src = ok ? a.w + poff[i] + (long long)klin * 2ll : zero;
             if ((a.dbg & 2) && !first) src = zero;
             glds16(src, sP + i * 8192u);
+        }
         }
         klin += 64;
         kc += 64;
@@ -527,7 +543,190 @@ __global__ void __launch_bounds__(768) conv_gather_v4_kernel(const GatherArgs a,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// wgrad, 8-wave / 3-stage generation: dW[k][(r,s,c)] += sum_pixels dy[p][k] * x[p(r,s)][c]
+// Same operand handling as conv_wgrad_dma_kernel (conv.hip): both slabs stay [pixel][channel],
+// LDS-DMA pieces of 4 pixel rows x 256 B with the chunk ^ 4*row source swizzle, fragments by
+// ds_read_b64_tr_b16.  Re-tiled as 128 (k) x 256 (columns) per 512-thread workgroup -- the column
+// operand is two 128-column sub-slabs -- with the counted-vmcnt ring, the early/late DMA issue
+// stagger between SIMD partner waves and buffer-addressed DMA (range check = zero fill).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) conv_wgrad_v3_kernel(const WgradArgs a) {
+    constexpr int PI = 2, QI = 2;
+    constexpr int PKE = 64;                          // pixels per k-slab
+    constexpr int OPB = PKE * 256;                   // bytes per 128-channel operand slab (16 KiB)
+    constexpr int STAGE = 3 * OPB;                   // P + two Q sub-slabs
+    constexpr int NST = 3;
+    constexpr int NDMA = 6;
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    const int tile = blockIdx.x;
+    const int tq = tile / a.tiles_p, tp = tile - tq * a.tiles_p;
+    const int p0 = tp * 128, q0 = tq * 256;
+    const int split = blockIdx.y;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
+
+    // DMA lane role: pixel row dr of the piece, logical 16-B chunk dch (source-side swizzle)
+    const int dr = lane >> 4;
+    const int dch = (lane & 15) ^ (dr << 2);
+    const int pch = p0 + dch * 8;
+    const bool p_col_ok = pch < a.lddy;
+    int dh[2], dw_[2], qc[2];
+    bool q_col_ok[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int j0 = q0 + s * 128 + dch * 8;
+        q_col_ok[s] = j0 < a.RSC;
+        int qr = 0, qs = 0; qc[s] = 0;
+        if (q_col_ok[s]) {
+            const int rs = j0 / a.C;
+            qc[s] = j0 - rs * a.C;
+            qr = rs / a.S;
+            qs = rs - qr * a.S;
+        }
+        dh[s] = qr * a.dil - a.pad_t;
+        dw_[s] = qs * a.dil - a.pad_l;
+    }
+    const int HoWo = a.Ho * a.Wo;
+    const int iters_total = (a.P + PKE - 1) / PKE;
+    const int it0 = split * a.iters_per_split;
+    int it1 = it0 + a.iters_per_split;
+    if (it1 > iters_total) it1 = iters_total;
+    if (it0 >= it1) return;
+
+    auto issue = [&](int it, int stage) __attribute__((always_inline)) {
+        const unsigned sP = smem_base + (unsigned)stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave + 8 * i;
+            const int p = it * PKE + piece * 4 + dr;
+            const bool pin = p < a.P;
+            glds16_buf(rdy, (pin && p_col_ok) ? (unsigned)((p * a.lddy + pch) * 2) : 0xFFFFFFF0u, sP + (unsigned)piece * 1024u);
+            const unsigned n = fdiv((unsigned)p, a.div_howo);
+            const unsigned rem = (unsigned)p - n * (unsigned)HoWo;
+            const unsigned ho = fdiv(rem, a.div_wo);
+            const unsigned wo = rem - ho * (unsigned)a.Wo;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int hi = (int)ho * a.stride + dh[s], wi = (int)wo * a.stride + dw_[s];
+                const bool ok = pin && q_col_ok[s] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                glds16_buf(rx, ok ? (unsigned)(((((int)n * a.H + hi) * a.W + wi) * a.ldx + qc[s]) * 2) : 0xFFFFFFF0u,
+                           sP + (unsigned)(OPB + s * OPB) + (unsigned)piece * 1024u);
+            }
+        }
+    };
+
+    // transpose-read lane role (see conv_wgrad_dma_kernel): group g = lane>>4, c = lane&15
+    const int g = lane >> 4, c = lane & 15;
+    const int rr = c >> 2;
+    unsigned pfo[PI], qfo[QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int ch = (wp * 64 + i * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
+        pfo[i] = (unsigned)((2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int ch = ((wq & 1) * 64 + j * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
+        qfo[j] = (unsigned)(OPB + (wq >> 1) * OPB + (2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
+    }
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const bool do_bias = a.dbias != nullptr && tq == 0 && wq == 0;     // wave-uniform
+    float bsum[PI] = {0.f, 0.f};
+
+    const int nk = it1 - it0;
+    issue(it0, 0);
+    if (nk > 1) issue(it0 + 1, 1);
+    int st_c = 0, st_n = 2;
+    const bool late = wave >= 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
+        block_barrier();
+        const bool do_issue = kt + 2 < nk;
+        if (do_issue && !late) issue(it0 + kt + 2, st_n);
+        const unsigned sS = smem_base + (unsigned)st_c * STAGE;
+        uint4 pf[2][PI], qf[2][QI];
+        auto ldf = [&](int ks, uint4 (&p)[PI], uint4 (&q)[QI]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
+                const uint2 lo = lds_tr16(sS + ks * 4096u + pfo[i]);
+                const uint2 hi2 = lds_tr16(sS + ks * 4096u + 1024u + pfo[i]);
+                p[i] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+            }
+#pragma unroll
+            for (int j = 0; j < QI; ++j) {
+                const uint2 lo = lds_tr16(sS + ks * 4096u + qfo[j]);
+                const uint2 hi2 = lds_tr16(sS + ks * 4096u + 1024u + qfo[j]);
+                q[j] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+            }
+        };
+        ldf(0, pf[0], qf[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) ldf(ks + 1, pf[(ks + 1) & 1], qf[(ks + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < PI; ++i)
+#pragma unroll
+                for (int j = 0; j < QI; ++j) Mma<bf16_t>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < PI; ++i) {
+                    const unsigned* d = reinterpret_cast<const unsigned*>(&pf[ks & 1][i]);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) bsum[i] += bf16_lo(d[h]) + bf16_hi(d[h]);
+                }
+            }
+        }
+        if (do_issue && late) issue(it0 + kt + 2, st_n);
+        st_c = st_c == 2 ? 0 : st_c + 1;
+        st_n = st_n == 2 ? 0 : st_n + 1;
+    }
+
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int col = q0 + wq * 64 + j * 32 + l31;
+        if (col >= a.RSC) continue;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = p0 + wp * 64 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const float t = bsum[i] + __shfl_xor(bsum[i], 32);       // both k halves
+            const int k = p0 + wp * 64 + i * 32 + l31;
+            if (hi == 0 && k < a.K) atomicAdd(a.dbias + k, t);
+        }
+    }
+}
+
 }  // namespace
+
+static int g_num_cu = 0;
+static void query_num_cu() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
+    if (g_num_cu <= 0) g_num_cu = 256;
+}
 
 bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype) {
     return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && a.idiv == 1 && a.R * a.S <= 32 && a.ldy % 8 == 0 &&
@@ -541,26 +740,21 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     const int grid = a.tiles_p * a.tiles_q;
     const bool db = (a.dbg & 32) == 0;      // fragment double buffering (default on; dbg bit 5 turns it off)
     const bool early = (a.dbg & 128) != 0;  // "landed one slab early" protocol (dbg bit 7, A/B)
-    if (PT == 64) {
-        if (early) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, true>), dim3(grid), dim3(512), 0, st, a);
-        else if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false>), dim3(grid), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((conv_gather_v3_kernel<64, false, false>), dim3(grid), dim3(512), 0, st, a);
-    } else {
-        if (early) hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, true>), dim3(grid), dim3(512), 0, st, a);
-        else if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, false>), dim3(grid), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((conv_gather_v3_kernel<128, false, false>), dim3(grid), dim3(512), 0, st, a);
-    }
+    const bool buf = (a.dbg & 256) == 0;    // buffer-addressed DMA (default on; dbg bit 8 = 64-bit global addressing, A/B)
+#define ODTK_V3(PT_) \
+    do { \
+        if (buf) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, true>), dim3(grid), dim3(512), 0, st, a); \
+        else if (early) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, true, false>), dim3(grid), dim3(512), 0, st, a); \
+        else if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, false>), dim3(grid), dim3(512), 0, st, a); \
+        else hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, false, false, false>), dim3(grid), dim3(512), 0, st, a); \
+    } while (0)
+    if (PT == 64) ODTK_V3(64); else ODTK_V3(128);
+#undef ODTK_V3
     return 0;
 }
 
-static int g_num_cu = 0;
 int launch_gather_v4(GatherArgs& a, hipStream_t st) {
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
-        if (g_num_cu <= 0) g_num_cu = 256;
-    }
+    if (g_num_cu == 0) query_num_cu();
     const int PT = a.K <= 64 ? 64 : 128;
     a.tiles_p = ceil_div(a.K, PT);
     a.tiles_q = ceil_div(a.M, 256);
@@ -571,8 +765,36 @@ int launch_gather_v4(GatherArgs& a, hipStream_t st) {
     return 0;
 }
 
-bool wgrad_v3_supported(const WgradArgs&, int) { return false; }
-int launch_wgrad_v3(WgradArgs&, hipStream_t) { return 0; }
+bool wgrad_v3_supported(const WgradArgs& a, int dtype) {
+    return dtype == ODTK_BF16 && a.K > 64 && a.lddy % 8 == 0 && a.ldx % 8 == 0 && a.C % 8 == 0 &&
+           (long long)a.P * a.lddy * 2 < (1ll << 31) && (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31);
+}
+
+int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
+    a.tiles_p = ceil_div(a.K, 128);
+    a.tiles_q = ceil_div(a.RSC, 256);
+    const int tiles = a.tiles_p * a.tiles_q;
+    const int iters_total = ceil_div(a.P, 64);
+    // one 512-thread block per CU.  Pick the pixel split count by a small cost model: rounds of blocks x
+    // (k-slabs per block x ~1.0 us + ~6 us of prologue and 32 K float atomics per block)
+    if (g_num_cu == 0) query_num_cu();
+    int best_s = 1;
+    double best_t = 1e30;
+    const int smax = iters_total < 4 ? 1 : iters_total / 4;
+    for (int s = 1; s <= smax && s <= 1024; ++s) {
+        const int ips = ceil_div(iters_total, s);
+        const int sp = ceil_div(iters_total, ips);
+        const double rounds = (double)ceil_div(tiles * sp, g_num_cu);
+        const double tt = rounds * (ips * 1.0 + 6.0);
+        if (tt < best_t - 1e-9) { best_t = tt; best_s = sp; }
+    }
+    a.iters_per_split = ceil_div(iters_total, best_s);
+    const int splits = ceil_div(iters_total, a.iters_per_split);
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
+    a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    hipLaunchKernelGGL(conv_wgrad_v3_kernel, dim3(tiles, splits), dim3(512), 0, st, a);
+    return 0;
+}
 
 }  // namespace cv
 }  // namespace odtk

@@ -64,14 +64,16 @@ V3_EXTRA_CASES = [
 ]
 
 
-@pytest.fixture(params=[2, 3], ids=["v3-8wave", "v4-persistent"])
+@pytest.fixture(params=[(2, 0), (3, 0), (2, 256)], ids=["v3-8wave", "v4-persistent", "v3-bufdma"])
 def v3_engine(request):
     """Force the 8-wave (2) / persistent wave-specialised (3) conv kernels wherever they are
-    supported (odtk_debug_set key 1)."""
+    supported (odtk_debug_set key 1); key 2 bit 8 selects the buffer-addressed LDS-DMA variant."""
     ops = _ops()
-    ops.debug_set(1, request.param)
+    ops.debug_set(1, request.param[0])
+    ops.debug_set(2, request.param[1])
     yield
     ops.debug_set(1, 0)
+    ops.debug_set(2, 0)
 
 
 @pytest.mark.parametrize("case", CONV_CASES + V3_EXTRA_CASES)

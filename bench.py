@@ -10,9 +10,13 @@ images/GPU already resident in HBM.  Weak scaling: every rank keeps batch 32 (ea
 exactly the reference computation, local BatchNorm; SURVEY.md 8e option A).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the conv implicit-GEMM kernel family (fwd + dgrad + wgrad launches), HIP-event
-                  timed inside the timed region: algorithmic FLOPs / summed launch time vs the
-                  dense bf16 MFMA peak (2.5 PFLOP/s).
+  roofline     -- the DOMINANT device kernel of the step (largest summed duration; the 8-wave
+                  implicit-GEMM gather kernel that serves conv forward and dgrad), HIP-event timed
+                  inside the timed region on the launch stream: algorithmic FLOPs per launch / average
+                  launch duration vs the dense bf16 MFMA peak (2.5 PFLOP/s).  `traffic` = HBM bytes
+                  per launch of that kernel from the committed rocprofv3 PMC passes (profiles/*.json,
+                  FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE).  `family` = the same
+                  ratio over every conv kernel (fwd + dgrad + wgrad, all layers).
   cpu_baseline -- the CPU oracle (PyTorch-CPU restatement of the reference graph; TF 1.13 cannot
                   run here) timed on this box's host cores on a bounded sample (N=1 only).
 """
@@ -52,7 +56,7 @@ class ConvTimer:
 
     def __init__(self, ops):
         self.ops = ops
-        self.records = []            # (kind, flops, start_evt, end_evt)
+        self.records = []            # (kind, kernel, flops, start_evt, end_evt)
         self.enabled = False
         self._orig = {}
 
@@ -74,18 +78,60 @@ class ConvTimer:
             s.record()
             r = orig(d, *args)
             e.record()
-            self.records.append((kind, flops, s, e))
+            self.records.append((kind, self.ops.conv_last_kernel(), flops, s, e))
             return r
         return f
 
     def summary(self):
-        tot_f, tot_t = 0.0, 0.0
-        per = {}
-        for kind, fl, s, e in self.records:
+        per_kernel, per_pass = {}, {}
+        for kind, kern, fl, s, e in self.records:
             t = s.elapsed_time(e) * 1e-3
-            tot_f += fl; tot_t += t
-            a = per.setdefault(kind, [0.0, 0.0, 0]); a[0] += fl; a[1] += t; a[2] += 1
-        return tot_f, tot_t, per
+            for d, k in ((per_kernel, kern), (per_pass, kind)):
+                a = d.setdefault(k, [0.0, 0.0, 0]); a[0] += fl; a[1] += t; a[2] += 1
+        return per_kernel, per_pass
+
+    def roofline(self, steps, peak, whole_step_frac):
+        per_kernel, per_pass = self.summary()
+        dom = max(per_kernel, key=lambda k: per_kernel[k][1])
+        fl, t, n = per_kernel[dom]
+        tot_f = sum(v[0] for v in per_kernel.values()); tot_t = sum(v[1] for v in per_kernel.values())
+        return {
+            'bound': 'mfma', 'kernel': dom,
+            'achieved': round(fl / t / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': round(fl / t / peak, 4),
+            'traffic': pmc_traffic(dom),
+            'launches_per_step': n // steps, 'avg_launch_us': round(t / n * 1e6, 2),
+            'algorithmic_gflop_per_launch': round(fl / n / 1e9, 2),
+            'family': {'kernels': 'all conv kernels (fwd + dgrad + wgrad, every layer)',
+                       'achieved': round(tot_f / tot_t / 1e12, 2), 'frac': round(tot_f / tot_t / peak, 4),
+                       'launches_per_step': len(self.records) // steps, 'conv_ms_per_step': round(tot_t / steps * 1e3, 3)},
+            'by_kernel': {k: {'TFLOP/s': round(v[0] / v[1] / 1e12, 2), 'ms_per_step': round(v[1] / steps * 1e3, 3),
+                              'launches_per_step': v[2] // steps} for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
+            'by_pass': {k: {'TFLOP/s': round(v[0] / v[1] / 1e12, 2), 'ms_per_step': round(v[1] / steps * 1e3, 3)}
+                        for k, v in per_pass.items()},
+            'whole_step_frac_of_mfma_peak': round(whole_step_frac, 4),
+        }
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*pmc*.json):
+    {'hbm_read_bytes', 'hbm_write_bytes', 'source'} or None when no profile names the kernel."""
+    import glob
+    base = kernel.split('<')[0]
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc*.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:                                         # noqa: BLE001
+            continue
+        want_pt = kernel.split('<')[1].split('>')[0].split(',')[0] if '<' in kernel else None
+        for name, e in d.items():
+            if base not in name or 'hbm_read_bytes_corrected' not in e or 'hbm_write_bytes' not in e:
+                continue
+            if want_pt is not None and '<' in name and name.split('<')[1].split(',')[0].split('>')[0].strip() != want_pt:
+                continue
+            return {'hbm_read_bytes': int(e['hbm_read_bytes_corrected']), 'hbm_write_bytes': int(e['hbm_write_bytes']),
+                    'hbm_bytes': int(e['hbm_read_bytes_corrected'] + e['hbm_write_bytes']),
+                    'source': os.path.relpath(f, ROOT) + ' :: ' + name}
+    return None
 
 
 def main():
@@ -169,17 +215,7 @@ def main():
         }
         peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
         if timer.records:
-            fl, t, per = timer.summary()
-            out['roofline'] = {
-                'bound': 'mfma', 'kernel': 'conv_gather_kernel/conv_wgrad_kernel (implicit-GEMM conv fwd+dgrad+wgrad, all layers)',
-                'achieved': round(fl / t / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s',
-                'frac': round(fl / t / peak, 4), 'traffic': None,
-                'launches_per_step': len(timer.records) // args.steps,
-                'conv_ms_per_step': round(t / args.steps * 1e3, 3),
-                'by_pass': {k: {'TFLOP/s': round(v[0] / v[1] / 1e12, 2), 'ms_per_step': round(v[1] / args.steps * 1e3, 3)}
-                            for k, v in per.items()},
-                'whole_step_frac_of_mfma_peak': round(value / world * 188.0e9 / peak, 4),
-            }
+            out['roofline'] = timer.roofline(args.steps, peak, value / world * 188.0e9 / peak)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

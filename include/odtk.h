@@ -42,6 +42,9 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  * key 1 = conv engine: 0 auto, 1 legacy 4-wave kernels, 2 8-wave v3 wherever supported, 3 persistent v4;
  * key 2 = perf-experiment bits (results wrong when set); key 3 = single-kernel NMS (value != 0) */
 int odtk_debug_set(int key, int value);
+/* name of the device kernel the last odtk_conv2d_* call of this thread dispatched to (bench.py attributes
+ * its HIP-event timings to kernels with it, so the roofline line and the rocprofv3 trace name the same kernel) */
+const char* odtk_conv_last_kernel(void);
 
 /* ------------------------------------------------------------------------- *
  * Convolution family: replaces tf.nn.conv2d (SSD300.py:519) and

@@ -743,6 +743,7 @@ __global__ void filter_prepare_kernel(const float* __restrict__ w, int K, int RS
 }
 
 static bool g_force_regstage = false;   // debugging knob (odtk_debug_set key 0)
+static thread_local const char* g_last_kernel = "";   // name of the conv kernel the last conv call launched (odtk_conv_last_kernel)
 static int g_dbg = 0;                   // key 2: perf-experiment bits forwarded to the kernels (results are wrong when set)
 static int g_v3_mode = 0;               // key 1: 0 = auto, 1 = legacy 4-wave kernels only, 2 = 8-wave v3 wherever supported, 3 = persistent v4 wherever supported
 
@@ -751,11 +752,13 @@ int launch_gather(const GatherArgs& a, int PT, hipStream_t st) {
     const int grid = a.tiles_p * a.tiles_q;
     const bool dma = a.idiv == 1 && a.R * a.S <= 32 && !g_force_regstage;
     if (dma) {
+        g_last_kernel = PT == 64 ? "conv_gather_glds_kernel<64>" : "conv_gather_glds_kernel<128>";
         if (PT == 64)
             hipLaunchKernelGGL((conv_gather_glds_kernel<T, TO, 64>), dim3(grid), dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL((conv_gather_glds_kernel<T, TO, 128>), dim3(grid), dim3(256), 0, st, a);
     } else {
+        g_last_kernel = PT == 64 ? "conv_gather_kernel<64>" : "conv_gather_kernel<128>";
         if (PT == 64)
             hipLaunchKernelGGL((conv_gather_kernel<T, TO, 64>), dim3(grid), dim3(256), 0, st, a);
         else
@@ -784,6 +787,8 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
         (g_v3_mode >= 2 || gather_v3_auto(a))) {
         if (g_v3_mode == 3) launch_gather_v4(a, st);
         else launch_gather_v3(a, st);
+        g_last_kernel = g_v3_mode == 3 ? (a.K <= 64 ? "conv_gather_v4_kernel<64>" : "conv_gather_v4_kernel<128>")
+                                       : (a.K <= 64 ? "conv_gather_v3_kernel<64>" : "conv_gather_v3_kernel<128>");
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }
@@ -819,6 +824,8 @@ int check_desc(const odtk_conv_desc* d) {
 }  // namespace odtk
 
 using namespace odtk;
+
+extern "C" const char* odtk_conv_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int odtk_debug_set(int key, int value) {
     if (key == 0) { g_force_regstage = value != 0; return ODTK_OK; }
@@ -884,6 +891,7 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     a.dbg = g_dbg;
     if (!g_force_regstage && g_v3_mode != 1 && wgrad_v3_supported(a, d->dtype)) {
         launch_wgrad_v3(a, (hipStream_t)stream);
+        g_last_kernel = "conv_wgrad_v3_kernel";
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }
@@ -905,6 +913,7 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     a.dbg = g_dbg;
     dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
+    g_last_kernel = (d->dtype == ODTK_BF16 && !g_force_regstage && !(PT == 64 && g_v3_mode == 1)) ? "conv_wgrad_dma_kernel" : "conv_wgrad_kernel";
     if (d->dtype == ODTK_BF16) {
         if (PT == 64 && (g_v3_mode == 1 || g_force_regstage)) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), grid, dim3(256), 0, st, a);
         else if (!g_force_regstage) hipLaunchKernelGGL(conv_wgrad_dma_kernel, grid, dim3(256), 0, st, a);

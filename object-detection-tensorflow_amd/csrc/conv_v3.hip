@@ -564,10 +564,13 @@ __global__ void __launch_bounds__(512) conv_wgrad_v3_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave & 1, wq = wave >> 1;
-    const int tile = blockIdx.x;
+    // 1-D grid, XCD-aware order: an XCD's contiguous range of virtual ids covers whole pixel splits, so the
+    // tiles that re-read the same dy / x pixel slabs (same split, different tile) share one L2
+    const int ntiles = a.tiles_p * a.tiles_q;
+    const int vb = (a.dbg & 512) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int split = vb / ntiles, tile = vb - split * ntiles;
     const int tq = tile / a.tiles_p, tp = tile - tq * a.tiles_p;
     const int p0 = tp * 128, q0 = tq * 256;
-    const int split = blockIdx.y;
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
 
@@ -792,7 +795,7 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
     const int splits = ceil_div(iters_total, a.iters_per_split);
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
-    hipLaunchKernelGGL(conv_wgrad_v3_kernel, dim3(tiles, splits), dim3(512), 0, st, a);
+    hipLaunchKernelGGL(conv_wgrad_v3_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
     return 0;
 }
 

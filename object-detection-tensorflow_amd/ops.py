@@ -68,6 +68,11 @@ def debug_set(key: int, value: int):
     call("odtk_debug_set", int(key), int(value))
 
 
+def conv_last_kernel() -> str:
+    """Device kernel the last conv2d_* call dispatched to."""
+    return _lib.load().odtk_conv_last_kernel().decode()
+
+
 # ------------------------------------------------------------------ conv family
 def conv2d_fwd(d: ConvDesc, x, w, bias, y, relu: bool):
     call("odtk_conv2d_fwd", C.byref(d), _p(x), _p(w), _p(bias), _p(y), int(relu), _stream())

@@ -90,6 +90,18 @@ int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, in
 int odtk_filter_prepare(const float* w, int K, int R, int S, int C, int Kp, int dtype,
                         void* w_c, void* w_t, void* stream);
 
+/* The same w -> w_t transform for MANY layers in one launch (the optimizer refreshes every dgrad
+ * filter each step).  `items_dev` is a DEVICE array of n_items odtk_fp_item; item i owns the blocks
+ * [block_begin, block_begin + ktiles*R*S*ctiles) with ctiles = ceil(C/32), ktiles = ceil(Kp/32);
+ * total_blocks is the sum. */
+typedef struct odtk_fp_item {
+    const float* w;      /* f32 master [K][R*S][C]              */
+    void* w_t;           /* out [C][R*S flipped][Kp] in `dtype` */
+    int K, RS, C, Kp;
+    int block_begin, ctiles, ktiles, pad_;
+} odtk_fp_item;
+int odtk_filter_prepare_batched(const void* items_dev, int n_items, int total_blocks, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Elementwise / reduction layers (all NHWC rows x pitch)
  * ------------------------------------------------------------------------- */

@@ -41,6 +41,7 @@ SIGNATURES = {
     "odtk_conv2d_dgrad": (_i, [_cd, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "odtk_conv2d_wgrad": (_i, [_cd, _vp, _vp, _i, _vp, _vp, _vp]),
     "odtk_filter_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "odtk_filter_prepare_batched": (_i, [_vp, _i, _i, _i, _vp]),
     "odtk_preprocess": (_i, [_vp, _ll, C.POINTER(_f), _i, _i, _vp, _vp]),
     "odtk_maxpool_fwd": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
     "odtk_maxpool_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),

@@ -742,6 +742,38 @@ __global__ void filter_prepare_kernel(const float* __restrict__ w, int K, int RS
     }
 }
 
+// Batched form: one launch refreshes the dgrad-layout filters of every layer (32 launches -> 1 per step).
+struct FpItem {                      // mirrors odtk_fp_item (include/odtk.h)
+    const float* w; void* w_t;
+    int K, RS, C, Kp;
+    int block_begin, ctiles, ktiles, pad_;
+};
+template <typename T>
+__global__ void filter_prepare_batched_kernel(const FpItem* __restrict__ items, int n_items) {
+    __shared__ float tile[32][33];
+    // wave-uniform search of the item that owns this block
+    int it = 0;
+    for (int i = 1; i < n_items; ++i)
+        if ((int)blockIdx.x >= items[i].block_begin) it = i;
+    const FpItem d = items[it];
+    const int lb = blockIdx.x - d.block_begin;
+    const int kt = lb / (d.RS * d.ctiles), rem = lb - kt * (d.RS * d.ctiles);
+    const int rs = rem / d.ctiles, ct = rem - rs * d.ctiles;
+    const int c0 = ct * 32, k0 = kt * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, c = c0 + tx;
+        tile[i][tx] = (k < d.K && c < d.C) ? d.w[((size_t)k * d.RS + rs) * d.C + c] : 0.f;
+    }
+    __syncthreads();
+    const int rsf = d.RS - 1 - rs;
+    T* wt = reinterpret_cast<T*>(d.w_t);
+    for (int i = ty; i < 32; i += 8) {
+        const int cc = c0 + i, k = k0 + tx;
+        if (cc < d.C && k < d.Kp) wt[((size_t)cc * d.RS + rsf) * d.Kp + k] = elem<T>::store(k < d.K ? tile[tx][i] : 0.f);
+    }
+}
+
 static bool g_force_regstage = false;   // debugging knob (odtk_debug_set key 0)
 static thread_local const char* g_last_kernel = "";   // name of the conv kernel the last conv call launched (odtk_conv_last_kernel)
 static int g_dbg = 0;                   // key 2: perf-experiment bits forwarded to the kernels (results are wrong when set)
@@ -939,6 +971,20 @@ extern "C" int odtk_filter_prepare(const float* w, int K, int R, int S, int C, i
     else if (dtype == ODTK_F32)
         hipLaunchKernelGGL(filter_prepare_kernel<float>, grid, dim3(256), 0, st, w, K, RS, C, Kp, (float*)w_c, (float*)w_t);
     else ODTK_REQUIRE(false, "filter_prepare: bad dtype %d", dtype);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_filter_prepare_batched(const void* items_dev, int n_items, int total_blocks, int dtype,
+                                           void* stream) {
+    ODTK_REQUIRE(items_dev && n_items > 0 && total_blocks > 0, "filter_prepare_batched: bad argument");
+    static_assert(sizeof(FpItem) == 48, "FpItem layout is part of the C-ABI");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ODTK_BF16)
+        hipLaunchKernelGGL(filter_prepare_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, (const FpItem*)items_dev, n_items);
+    else if (dtype == ODTK_F32)
+        hipLaunchKernelGGL(filter_prepare_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, st, (const FpItem*)items_dev, n_items);
+    else ODTK_REQUIRE(false, "filter_prepare_batched: bad dtype %d", dtype);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

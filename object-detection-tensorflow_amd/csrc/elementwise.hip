@@ -100,15 +100,13 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict_
                                    int k, int stride, int pad_t, int pad_l) {
     constexpr int KC = Chunk<T>::N;
     const int chunks = C / KC;
-    const long long total = (long long)N * H * W * chunks;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long step = (long long)gridDim.x * blockDim.x;
-    for (; i < total; i += step) {
-        const int ch = (int)(i % chunks);
-        long long pix = i / chunks;
-        const int w = (int)(pix % W); pix /= W;
-        const int h = (int)(pix % H);
-        const int n = (int)(pix / H);
+    const unsigned total = (unsigned)N * H * W * chunks;           // host checks < 2^31
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ch = (int)(i % (unsigned)chunks);
+        unsigned pix = i / (unsigned)chunks;
+        const int w = (int)(pix % (unsigned)W); pix /= (unsigned)W;
+        const int h = (int)(pix % (unsigned)H);
+        const int n = (int)(pix / (unsigned)H);
         float xv[KC], g[KC];
         Chunk<T>::unpack(ld16(x + ((size_t)(n * H + h) * W + w) * ld + ch * KC), xv);
 #pragma unroll
@@ -149,6 +147,57 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict_
             }
         }
         st16(dx + ((size_t)(n * H + h) * W + w) * ld + ch * KC, Chunk<T>::pack(g));
+    }
+}
+
+// 2x2 / stride-2 / pad_before-0 pooling backward (pool1..pool4): the windows tile the input without
+// overlap, so one thread owns one OUTPUT window chunk: it reads the four input pixels once, finds the
+// FIRST maximum in window scan order (TF routes the gradient there) and writes the four dx pixels.
+// No re-reads of neighbours, no 64-bit div/mod per element.
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                             T* __restrict__ dx, int N, int H, int W, int C, int ld,
+                                                             int Ho, int Wo) {
+    constexpr int KC = Chunk<T>::N;
+    const int chunks = C / KC;
+    const unsigned total = (unsigned)N * Ho * Wo * chunks;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned ch = i % (unsigned)chunks;
+        unsigned pix = i / (unsigned)chunks;
+        const unsigned wo = pix % (unsigned)Wo; pix /= (unsigned)Wo;
+        const unsigned ho = pix % (unsigned)Ho;
+        const unsigned n = pix / (unsigned)Ho;
+        const int h0 = (int)ho * 2, w0 = (int)wo * 2;
+        float dv[KC];
+        Chunk<T>::unpack(ld16(dy + ((size_t)(n * Ho + ho) * Wo + wo) * ld + ch * KC), dv);
+        float xv[4][KC];
+        bool in[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int hh = h0 + (t >> 1), ww = w0 + (t & 1);
+            in[t] = hh < H && ww < W;
+            if (in[t]) Chunk<T>::unpack(ld16(x + ((size_t)((int)n * H + hh) * W + ww) * ld + ch * KC), xv[t]);
+        }
+        float g[4][KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            float m = xv[0][e];                       // (h0, w0) is always inside the image
+#pragma unroll
+            for (int t = 1; t < 4; ++t)
+                if (in[t]) m = fmaxf(m, xv[t][e]);
+            bool done = false;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool hit = !done && in[t] && xv[t][e] == m;
+                g[t][e] = hit ? dv[e] : 0.f;
+                done = done || hit;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int hh = h0 + (t >> 1), ww = w0 + (t & 1);
+            if (in[t]) st16(dx + ((size_t)((int)n * H + hh) * W + ww) * ld + ch * KC, Chunk<T>::pack(g[t]));
+        }
     }
 }
 
@@ -687,7 +736,15 @@ extern "C" int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, vo
     if (int e = pool_check(C, ld, dtype)) return e;
     hipStream_t st = (hipStream_t)stream;
     const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    if (k == 2 && stride == 2 && pad_t == 0 && pad_l == 0 && (long long)N * H * W * (C / kc) < (1ll << 31)) {
+        const long long tot_o = (long long)N * Ho * Wo * (C / kc);
+        DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool2x2_bwd_kernel<T>, dim3(grid_for(tot_o, 256, 65536)), dim3(256), 0, st,
+                                               (const T*)x, (const T*)dy, (T*)dx, N, H, W, C, ld, Ho, Wo);)
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     const long long total = (long long)N * H * W * (C / kc);
+    ODTK_REQUIRE(total < (1ll << 31), "maxpool_bwd: tensor too large (%lld chunks)", total);
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
                                            (const T*)x, (const T*)y, (const T*)dy, (T*)dx, N, H, W, C, ld, Ho, Wo, k,
                                            stride, pad_t, pad_l);)

@@ -91,6 +91,26 @@ def filter_prepare(w, K, R, S, C_, Kp, dtype, w_c, w_t):
     call("odtk_filter_prepare", _p(w), K, R, S, C_, Kp, dtype, _p(w_c), _p(w_t), _stream())
 
 
+class FilterPrepareBatch:
+    """All dgrad-layout filters of a model refreshed by ONE launch (odtk_filter_prepare_batched).
+    entries: list of (w f32 view [K*RS*C], w_t tensor, K, R, S, C, Kp)."""
+
+    def __init__(self, entries, dtype, device):
+        import struct
+        blob = b''
+        begin = 0
+        for (w, wt, K, R, S, C_, Kp) in entries:
+            ct, kt = (C_ + 31) // 32, (Kp + 31) // 32
+            blob += struct.pack('<QQiiiiiiii', w.data_ptr(), wt.data_ptr(), K, R * S, C_, Kp, begin, ct, kt, 0)
+            begin += kt * R * S * ct
+        self.keep = entries                                   # the item table holds raw pointers
+        self.n, self.blocks, self.dtype = len(entries), begin, dtype
+        self.items = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+
+    def run(self):
+        call("odtk_filter_prepare_batched", _p(self.items), self.n, self.blocks, self.dtype, _stream())
+
+
 # ------------------------------------------------------------------ layers
 def preprocess(images, mean3, ldx, dtype, x):
     m = (C.c_float * 3)(*mean3)

@@ -384,12 +384,16 @@ class SSD300:
             self.refresh_wt()
 
     def refresh_wt(self):
-        """Flipped/transposed dgrad filters from the f32 master (after every optimizer step)."""
-        for name, wt in self.wt.items():
-            c = self.convs[name]
-            d = self.desc[name]
-            kp = ops.pad_to(c.cout, 8) if name.startswith('pred') else c.cout
-            ops.filter_prepare(self._wslice(name + '.w', self.P), c.cout, c.k, c.k, d.C, kp, self.DT, None, wt)
+        """Flipped/transposed dgrad filters from the f32 master (after every optimizer step): one batched launch."""
+        if getattr(self, '_fp_batch', None) is None:
+            entries = []
+            for name, wt in self.wt.items():
+                c = self.convs[name]
+                d = self.desc[name]
+                kp = ops.pad_to(c.cout, 8) if name.startswith('pred') else c.cout
+                entries.append((self._wslice(name + '.w', self.P), wt, c.cout, c.k, c.k, d.C, kp))
+            self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, self.dev)
+        self._fp_batch.run()
 
     # ------------------------------------------------------------------ forward
     def _conv_fwd(self, name, src, dst, bias, relu):

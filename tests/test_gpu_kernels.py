@@ -171,6 +171,27 @@ def _conv_case(case, dt, dev):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_filter_prepare_batched_equals_per_layer(dt, dev):
+    """One launch for every layer (odtk_filter_prepare_batched) == the per-layer transform, bit for bit."""
+    ops = _ops()
+    DT = ops.F32 if dt == "f32" else ops.BF16
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 3, 8, 64), (100, 3, 256, 104), (150, 3, 40, 152), (256, 1, 1024, 256), (24, 3, 16, 24)]   # K, k, C, Kp
+    entries, refs = [], []
+    for (K, k, C, Kp) in shapes:
+        w = torch.randn(K, k, k, C, generator=g).to(dev)
+        wt = torch.full((C * k * k * Kp,), 7.0, dtype=dtype, device=dev)
+        ref = torch.full((C * k * k * Kp,), 9.0, dtype=dtype, device=dev)
+        ops.filter_prepare(w, K, k, k, C, Kp, DT, None, ref)
+        entries.append((w.view(-1), wt, K, k, k, C, Kp)); refs.append(ref)
+    ops.FilterPrepareBatch(entries, DT, dev).run()
+    torch.cuda.synchronize()
+    for e, r in zip(entries, refs):
+        assert torch.equal(e[1], r)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("geom", [(2, 75, 75, 16, 2, 2), (2, 19, 19, 32, 3, 1), (1, 38, 38, 8, 2, 2)])
 def test_maxpool(geom, dt, dev):
     ops = _ops()

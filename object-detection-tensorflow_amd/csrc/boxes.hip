@@ -362,6 +362,106 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a, const
 }
 
 
+// Top-`lim` selection + sort for the split path (replaces the full 16384-key bitonic sort): a 4096-bin
+// histogram over the top 12 bits of the sortable score finds the lowest bin B whose suffix count
+// reaches lim; the keys of bins >= B (at most NMS_TCAP, else the problem is handed to the
+// single-kernel path) are compacted and bitonic-sorted.  Same (score desc, index asc) order.
+__global__ void __launch_bounds__(NMS_THREADS) nms_topk_kernel(const NmsArgs a, const NmsScratch ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* hist = reinterpret_cast<unsigned*>(smem);                                   // [4096]
+    unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem + 4096 * 4);     // [NMS_TCAP]
+    unsigned* wsum = reinterpret_cast<unsigned*>(smem + 4096 * 4 + NMS_TCAP * 8);         // [16] per-wave sums
+    __shared__ int s_nvalid, s_B, s_cnt, s_pos;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int mo = a.max_out_dev ? a.max_out_dev[(long long)b * a.max_out_stride] : a.max_out_const;
+    if (mo > a.cap) mo = a.cap;
+    if (mo < 0) mo = 0;
+    const float* boxes = a.boxes + b * a.box_stride;
+    auto make_key = [&](int i) -> unsigned long long {
+        bool ok = true;
+        if (a.valid) ok = a.valid[b * a.valid_bstride + (long long)i * a.valid_estride] == (unsigned char)a.valid_value;
+        const float s = a.scores[b * a.score_bstride + (long long)i * a.score_estride];
+        if (!(ok && s > -INFINITY)) return 0ull;
+        return ((unsigned long long)sortable(s) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+    };
+    for (int i = tid; i < 4096; i += NMS_THREADS) hist[i] = 0u;
+    if (tid == 0) { s_nvalid = 0; s_B = -1; s_cnt = 0; s_pos = 0; }
+    __syncthreads();
+    int myvalid = 0;
+    for (int i = tid; i < a.n; i += NMS_THREADS) {
+        const unsigned long long key = make_key(i);
+        if (key) { atomicAdd(&hist[(unsigned)(key >> 52)], 1u); ++myvalid; }
+    }
+    for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o);
+    if (lane == 0 && myvalid) atomicAdd(&s_nvalid, myvalid);
+    __syncthreads();
+    const int nvalid = s_nvalid;
+    int lim = (mo + mo / 2 + 256 + 63) & ~63;
+    if (lim > NMS_TCAP) lim = NMS_TCAP;
+    if (lim > nvalid) lim = nvalid;
+    if (mo == 0) lim = 0;
+    if (lim == 0) {
+        if (tid == 0) { ws.info[b * 4 + 0] = 0; ws.info[b * 4 + 1] = nvalid; ws.info[b * 4 + 2] = mo; ws.info[b * 4 + 3] = 0; }
+        return;
+    }
+    // suffix counts: thread t owns bins 4t..4t+3; ge(t) = number of keys in bins >= 4t
+    unsigned h4[4], lsum = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h4[e] = hist[4 * tid + e]; lsum += h4[e]; }
+    unsigned incl = lsum;                                  // inclusive suffix scan inside the wave (towards higher lanes)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_down(incl, o);
+        if (lane + o < 64) incl += v;
+    }
+    if (lane == 0) wsum[wave] = incl;                      // whole-wave total
+    __syncthreads();
+    unsigned above = 0;                                    // keys in the waves above this one
+    for (int w2 = wave + 1; w2 < NMS_THREADS / 64; ++w2) above += wsum[w2];
+    unsigned ge = above + incl - lsum;                     // keys in bins > 4t+3
+#pragma unroll
+    for (int e = 3; e >= 0; --e) {
+        const unsigned ge_hi = ge;                         // count of bins > this bin
+        ge += h4[e];                                       // count of bins >= this bin
+        if (ge >= (unsigned)lim && ge_hi < (unsigned)lim) { s_B = 4 * tid + e; s_cnt = (int)ge; }
+    }
+    __syncthreads();
+    const int B = s_B, cnt = s_cnt;
+    if (B < 0 || cnt > NMS_TCAP) {                         // too many keys share the threshold bin: single-kernel path
+        if (tid == 0) { ws.info[b * 4 + 0] = 0; ws.info[b * 4 + 1] = nvalid; ws.info[b * 4 + 2] = mo; ws.info[b * 4 + 3] = 2; }
+        return;
+    }
+    for (int i = tid; i < a.n; i += NMS_THREADS) {
+        const unsigned long long key = make_key(i);
+        if (key && (int)(key >> 52) >= B) sel[atomicAdd(&s_pos, 1)] = key;
+    }
+    int SZ2 = 64;
+    while (SZ2 < cnt) SZ2 <<= 1;
+    __syncthreads();
+    for (int i = cnt + tid; i < SZ2; i += NMS_THREADS) sel[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= SZ2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < SZ2; i += NMS_THREADS) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = sel[i], y = sel[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { sel[i] = y; sel[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < lim; i += NMS_THREADS) {
+        const unsigned idx = 0xffffffffu - (unsigned)(sel[i] & 0xffffffffull);
+        const float4 raw = *reinterpret_cast<const float4*>(boxes + (size_t)idx * 4);
+        ws.sidx[(size_t)b * NMS_TCAP + i] = idx;
+        ws.sbox[(size_t)b * NMS_TCAP + i] = norm_box(raw.x, raw.y, raw.z, raw.w);
+    }
+    if (tid == 0) { ws.info[b * 4 + 0] = lim; ws.info[b * 4 + 1] = nvalid; ws.info[b * 4 + 2] = mo; ws.info[b * 4 + 3] = 0; }
+}
+
 // Suppression bit matrix of the best `lim` candidates of every problem: one 256-thread workgroup
 // per (64-row block, problem); wave w takes the column blocks rb + w, rb + w + 4, ...; lane = row.
 // Exactly iou_nms() per pair, so the scan below reproduces the greedy result bit for bit.
@@ -390,28 +490,43 @@ __global__ void __launch_bounds__(256) nms_matrix_kernel(const NmsScratch ws, co
     }
 }
 
-// Greedy selection over the bit matrix: one wave per problem, lane w owns word w of the
-// "suppressed" set.  Row blocks are visited in order; inside a block the picks are resolved on the
-// diagonal word (wave-uniform bit loop), then the rows of the picked candidates are OR-ed in.
+// Greedy selection over the bit matrix: one wave per problem.  Row blocks are visited in order.  The
+// "suppressed" word of block rb is gathered column-wise: lane j ORs word rb of the rows pb*64 + j it
+// picked in every earlier block pb (independent loads, 8 in flight), then a wave OR-reduction.  Inside
+// the block the picks are resolved on the diagonal word with a wave-uniform (scalar) bit loop.
 __global__ void __launch_bounds__(64) nms_scan_kernel(const NmsScratch ws, int* __restrict__ out_idx, const int cap,
                                                       int* __restrict__ out_cnt) {
+    __shared__ unsigned long long s_picked[NMS_WORDS];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int lim = ws.info[b * 4 + 0], nvalid = ws.info[b * 4 + 1], mo = ws.info[b * 4 + 2];
     const unsigned* sidx = ws.sidx + (size_t)b * NMS_TCAP;
     const unsigned long long* mat = ws.mat + (size_t)b * NMS_TCAP * NMS_WORDS;
     int* oidx = out_idx + (long long)b * cap;
     const int nb = (lim + 63) >> 6;
-    unsigned long long removed = 0ull;          // word `lane`
     int count = 0;
     for (int rb = 0; rb < nb && count < mo; ++rb) {
         const int row = rb * 64 + lane;
         const unsigned long long diag = row < lim ? mat[(size_t)row * NMS_WORDS + rb] : 0ull;
         const unsigned myidx = row < lim ? sidx[row] : 0u;
-        const unsigned long long curv = __shfl(removed, rb);
+        // suppressed-by-earlier-picks word of this block
+        unsigned long long acc = 0ull;
+        for (int pb0 = 0; pb0 < rb; pb0 += 8) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pb = pb0 + u < rb ? pb0 + u : rb - 1;            // clamp: always a valid row
+                v[u] = mat[(size_t)(pb * 64 + lane) * NMS_WORDS + rb];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (pb0 + u < rb && ((s_picked[pb0 + u] >> lane) & 1ull)) acc |= v[u];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
         // wave-uniform by construction: keep it in SGPRs so the pick loop below is scalar code
         // (readfirstlane returns int: go through unsigned, or bit 31 of the low word sign-extends)
-        const unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)curv);
-        const unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(curv >> 32));
+        const unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)acc);
+        const unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(acc >> 32));
         unsigned long long cur = ((unsigned long long)cur_hi << 32) | (unsigned long long)cur_lo;
         const int rem = lim - rb * 64;
         if (rem < 64) cur |= ~0ull << rem;                        // rows past the candidate list
@@ -429,25 +544,12 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const NmsScratch ws, int* 
         // emit this block's picks in order
         const int base = count - __popcll(picked);
         if ((picked >> lane) & 1ull) oidx[base + __popcll(picked & ((1ull << lane) - 1ull))] = (int)myidx;
-        // suppress later blocks by every picked row (loads are independent: keep several in flight)
-        unsigned long long p = picked;
-        if (rb + 1 < nb) {
-            while (p) {
-                unsigned long long acc4 = 0ull;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (p) {
-                        const int j = __ffsll((long long)p) - 1;
-                        p &= p - 1ull;
-                        acc4 |= mat[(size_t)(rb * 64 + j) * NMS_WORDS + lane];
-                    }
-                }
-                removed |= acc4;
-            }
-        }
+        if (lane == 0) s_picked[rb] = picked;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // single wave: LDS is in order, this pins the compiler
     }
     if (lane == 0) {
-        const bool exhausted = count < mo && lim < nvalid;        // margin too small: redo this problem the slow way
+        // margin too small (or nms_topk_kernel gave up: flag 2): redo this problem the slow way
+        const bool exhausted = (count < mo && lim < nvalid) || ws.info[b * 4 + 3] == 2;
         ws.info[b * 4 + 3] = exhausted ? 1 : 0;
         if (!exhausted) out_cnt[b] = count;
     }
@@ -701,7 +803,7 @@ extern "C" int odtk_nms_batched(const float* boxes, long long box_stride, const 
     }
     // split path: sort -> suppression bit matrix -> scan (+ whole-problem fallback for flagged problems)
     if (int e = nms_scratch(B, &ws)) return e;
-    hipLaunchKernelGGL(nms_kernel<1>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 0);
+    hipLaunchKernelGGL(nms_topk_kernel, dim3(B), dim3(NMS_THREADS), 4096 * 4 + NMS_TCAP * 8 + 64, st, a, ws);
     hipLaunchKernelGGL(nms_matrix_kernel, dim3(NMS_WORDS, B), dim3(256), 0, st, ws, iou_threshold);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, ws, out_idx, cap, out_cnt);
     hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 1);

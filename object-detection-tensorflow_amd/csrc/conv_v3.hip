@@ -769,7 +769,7 @@ int launch_gather_v4(GatherArgs& a, hipStream_t st) {
 }
 
 bool wgrad_v3_supported(const WgradArgs& a, int dtype) {
-    return dtype == ODTK_BF16 && a.K >= 64 && a.lddy % 8 == 0 && a.ldx % 8 == 0 && a.C % 8 == 0 &&
+    return dtype == ODTK_BF16 && (a.K > 64 || (a.K == 64 && a.RSC >= 256)) && a.lddy % 8 == 0 && a.ldx % 8 == 0 && a.C % 8 == 0 &&
            (long long)a.P * a.lddy * 2 < (1ll << 31) && (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31);
 }
 

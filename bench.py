@@ -143,6 +143,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -187,14 +188,32 @@ def main():
     lr = 0.01
     for _ in range(args.warmup):
         loss = model.train_step(lr)
-    timer.enabled = not args.no_conv_events
+    while model.use_graph and not args.eager and model._eager_steps < 2:
+        loss = model.train_step(lr)                          # a capture needs every lazily allocated buffer to exist
+    if model.use_graph and model._g_front is None and not args.eager:
+        model._graphs_build()                                # untimed; a capture executes nothing
+    if args.eager:
+        model.use_graph = False
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = model.train_step(lr)
     barrier()
     dt = time.perf_counter() - t0
-    timer.enabled = False
+    final_loss_t = loss
+    # roofline pass: the SAME step launched eagerly with HIP events around every conv launch on the launch
+    # stream (graph replay cannot carry per-kernel events; the kernels and their durations are identical)
+    if not args.no_conv_events:
+        saved = model.use_graph
+        model.use_graph = False
+        timer.enabled = True
+        ev_steps = min(args.steps, 5)
+        for _ in range(ev_steps):
+            model.train_step(lr)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        model.use_graph = saved
+    loss = final_loss_t
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device=dev)
@@ -211,11 +230,15 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
-                       'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
+                       'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
+                       'launch': 'eager' if not model.use_graph else ('hip-graph replay (fwd+loss+bwd)' if model._g_back is not None
+                                                                        else 'hip-graph replay (fwd+loss), eager bwd + RCCL')},
         }
         peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
         if timer.records:
-            out['roofline'] = timer.roofline(args.steps, peak, value / world * 188.0e9 / peak)
+            out['roofline'] = timer.roofline(min(args.steps, 5), peak, value / world * 188.0e9 / peak)
+            out['roofline']['measured_on'] = (f'{min(args.steps, 5)} eager steps right after the timed region '
+                                              '(HIP events per conv launch on the launch stream)')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

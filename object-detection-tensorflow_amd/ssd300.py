@@ -12,7 +12,8 @@ is a re-iterable (or a `(initializer, iterable)` pair, mirroring the reference t
 as torch tensors or numpy arrays -- exactly what utils/image_augmentor.py:24-27 documents.
 
 Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' default | 'f32'),
-'device', 'seed', 'verbose', 'test_subtract_mean' (False = reproduce the reference's test-mode feed quirk).
+'device', 'seed', 'verbose', 'test_subtract_mean' (False = reproduce the reference's test-mode feed quirk),
+'use_graph' (True: replay the step's kernel launches from HIP graphs after two eager steps).
 """
 from __future__ import annotations
 
@@ -136,6 +137,9 @@ class SSD300:
             if data_provider.get('val_generator') is not None:
                 self.val_generator = data_provider['val_generator']
         self.global_step = 0
+        self.use_graph = bool(config.get('use_graph', True))   # HIP-graph replay of the step after 2 eager steps
+        self._g_front = self._g_back = None
+        self._eager_steps = 0
         self.dist = None                       # set by attach_data_parallel()
         self.loss_divisor_batch = self.batch_size
 
@@ -525,17 +529,50 @@ class SSD300:
         gt = torch.as_tensor(ground_truth, dtype=torch.float32)
         if self.gt is None or self.gt.shape != gt.shape:
             self.gt = torch.zeros(gt.shape, device=self.dev)
+            self._graphs_invalidate()                 # captured launches hold the old pointer / pad length
         self.gt.copy_(gt, non_blocking=True)
+
+    def _step_front(self):
+        self.G.zero_()
+        self._forward(True)
+        self._loss(1.0 / self.loss_divisor_batch)
+
+    def _graphs_invalidate(self):
+        self._g_front = self._g_back = None
+        self._eager_steps = 0
+
+    def _graphs_build(self):
+        """Capture the launch sequence of a step into HIP graphs (about 210 kernel launches per step; the host
+        cannot issue the ~100 short box/BN/small-conv launches as fast as the GPU retires them).  Forward+loss is
+        always captured; backward only without data parallelism (its all-reduces are launched eagerly from
+        layer_ready between the backward kernels).  The optimizer stays eager: `lr` changes per call."""
+        torch.cuda.synchronize()
+        self._g_front = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_front):
+            self._step_front()
+        self._g_back = None
+        if self.dist is None:
+            self._g_back = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_back):
+                self._backward()
 
     def train_step(self, lr):
         """One optimizer step on the batch loaded by set_batch(); returns the loss (data + L2)
         as a 1-element device tensor without synchronising."""
-        self.G.zero_()
+        use_graph = self.use_graph and self._eager_steps >= 2
+        if use_graph and self._g_front is None:
+            self._graphs_build()
         if self.dist is not None:
             self.dist.begin_step()
-        self._forward(True)
-        self._loss(1.0 / self.loss_divisor_batch)
-        self._backward()
+        if use_graph:
+            self._g_front.replay()
+        else:
+            self._step_front()
+            self._eager_steps += 1
+        if use_graph and self._g_back is not None:
+            self._g_back.replay()
+        else:
+            self._backward()
         if self.dist is not None:
             self.dist.finish_step()
         ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial,
@@ -623,5 +660,6 @@ class SSD300:
         RCCL all-reduce overlapped with backward.  The loss divisor becomes the GLOBAL batch."""
         from .dist import GradAllReducer
         self.dist = GradAllReducer(self, group, bucket_mb)
+        self._graphs_invalidate()
         self.loss_divisor_batch = self.batch_size * self.dist.world
         return self.dist

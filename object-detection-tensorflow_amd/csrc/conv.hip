@@ -815,6 +815,12 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
     a.dbg = g_dbg;
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * dtype_size(dtype));
     a.w_bytes = (unsigned)((size_t)ceil_div(a.K, 1) * a.ldw * dtype_size(dtype));
+    if (!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && gather_c64_supported(a, dtype, out_dtype)) {
+        launch_gather_c64(a, st);
+        g_last_kernel = "conv3x3_c64k64_kernel";
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     if (!g_force_regstage && g_v3_mode != 1 && gather_v3_supported(a, dtype, out_dtype) &&
         (g_v3_mode >= 2 || gather_v3_auto(a))) {
         if (g_v3_mode == 3) launch_gather_v4(a, st);

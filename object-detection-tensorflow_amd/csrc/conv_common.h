@@ -226,6 +226,8 @@ __device__ __forceinline__ void post_chunk(uint4& v, bool accumulate, bool relu,
 bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype);
 int launch_gather_v3(GatherArgs& a, hipStream_t st);
 int launch_gather_v4(GatherArgs& a, hipStream_t st);   // persistent, loader/compute wave-specialised
+bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype);   // resident-filter 64->64 3x3 kernel
+int launch_gather_c64(GatherArgs& a, hipStream_t st);
 bool wgrad_v3_supported(const WgradArgs& a, int dtype);
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
 

@@ -279,8 +279,11 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         const bool late = wave_u >= 4 && !(a.dbg & 64);
         if (do_issue && !late) issue(st_n);
         const char* sP = smem + st_c * STAGE;
+        const bool prio = (a.dbg & 1024) != 0;          // A/B: raise the wave's priority over its MFMA cluster
+        if (prio) __builtin_amdgcn_s_setprio(1);
         if (DB) mma_slab_db<bf16_t, PI, QI>(sP, sP + PT * 128, wp * (PT / 2), wq * 64, lane, acc);
         else mma_slab<bf16_t, PI, QI, true>(sP, sP + PT * 128, wp * (PT / 2), wq * 64, lane, acc);
+        if (prio) __builtin_amdgcn_s_setprio(0);
         if (do_issue && late) issue(st_n);
         st_c = st_c == 2 ? 0 : st_c + 1;
         st_n = st_n == 2 ? 0 : st_n + 1;
@@ -721,6 +724,171 @@ __global__ void __launch_bounds__(512) conv_wgrad_v3_kernel(const WgradArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (conv1_2 forward and its dgrad:
+// 300x300 maps, 2.9 M pixels -- HBM-heavy, and a 64-wide tile starves the generic kernels).
+// Persistent 4-wave workgroup per CU:
+//   * the WHOLE filter (9 taps x [64 rows][128 B] = 72 KiB) is loaded into LDS once;
+//   * the image is walked in 8 x 32-pixel tiles; the 10 x 34-pixel input patch (halo included, out-of-image
+//     pixels zero-filled by the buffer range check) is LDS-DMA'd ONCE per tile, double buffered, and all nine
+//     taps read their fragments from it at shifted positions -- 1.33x input traffic instead of 9x gathers;
+//     chunk slot ^ ((pixel >> 1) & 7) keeps ds_read_b128 conflict-free for ANY start pixel;
+//   * wave w owns tile rows 2w, 2w+1 (64 pixels) x all 64 output channels: 144 MFMAs per tile, fragments double
+//     buffered in registers, the next patch's DMA pieces interleaved into the first taps;
+//   * epilogue through the just-consumed patch buffer: full 128-B lines, 1 KiB contiguous per store instruction.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a, const int tiles_r, const int tiles_c,
+                                                             const int total_tiles) {
+    constexpr int PW = 34, PPX = 340, NPIECE = 43, PBUF = NPIECE * 1024;
+    constexpr int WBYTES = 9 * 8192;
+    __shared__ __attribute__((aligned(16))) char smem[WBYTES + 2 * PBUF];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rw = make_rsrc(a.w, a.w_bytes);
+    const int grid = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, grid);
+    const int my_tiles = slot < total_tiles ? (total_tiles - slot + grid - 1) / grid : 0;
+    if (my_tiles == 0) return;
+
+    // the filter: 72 pieces of 8 rows x 128 B
+    for (int q = wave; q < 72; q += 4) {
+        const int tap = q >> 3, row = (q & 7) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        glds16_buf(rw, (unsigned)(row * a.ldw * 2 + tap * 128 + lc * 16), smem_base + (unsigned)q * 1024u);
+    }
+    float4 bias[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bias[i * 4 + g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + i * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int tiles_per_img = tiles_r * tiles_c;
+    auto decode = [&](int v, int& n, int& h0, int& w0) __attribute__((always_inline)) {
+        n = v / tiles_per_img;
+        const int rem = v - n * tiles_per_img;
+        const int tr = rem / tiles_c;
+        h0 = tr * 8; w0 = (rem - tr * tiles_c) * 32;
+    };
+    auto issue_piece = [&](int n, int h0, int w0, int q, int buf) __attribute__((always_inline)) {
+        const int px = q * 8 + (lane >> 3);
+        const int pr = px / PW, pc = px - pr * PW;
+        const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+        const bool ok = px < PPX && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+        const int lc = (lane & 7) ^ ((px >> 1) & 7);
+        glds16_buf(rx, ok ? (unsigned)((((n * a.H + h) * a.W + w) * 64 + lc * 8) * 2) : 0xFFFFFFF0u,
+                   smem_base + (unsigned)(WBYTES + buf * PBUF) + (unsigned)q * 1024u);
+    };
+    int tn, th0, tw0;
+    decode(slot, tn, th0, tw0);
+    for (int q = wave; q < NPIECE; q += 4) issue_piece(tn, th0, tw0, q, 0);
+
+    // fragment addressing: weights row k = i*32 + l31; patch pixel of (tile row 2w+j, column l31)
+    const int wk0 = l31 * 128, wk1 = (32 + l31) * 128;
+    const int fk0 = (l31 >> 1) & 7, fk1 = ((32 + l31) >> 1) & 7;
+    const int pxb0 = (2 * wave) * PW + l31, pxb1 = (2 * wave + 1) * PW + l31;
+    char* stg = smem + WBYTES + wave * 8192;               // + buf * PBUF
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int buf = it & 1;
+        const bool has_next = it + 1 < my_tiles;
+        int nn = 0, nh0 = 0, nw0 = 0;
+        if (has_next) decode(slot + (it + 1) * grid, nn, nh0, nw0);
+        if (it == 0) { wait_vmcnt<0>(); }
+        block_barrier();            // patch `buf` (and at it = 0 the filter) visible; everybody left epilogue it-1
+        f32x16_v acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const char* patch = smem + WBYTES + buf * PBUF;
+        int cn, ch0, cw0;
+        decode(slot + it * grid, cn, ch0, cw0);
+        uint4 mk[8];                                     // ReLU-mask chunks of this tile, prefetched under the last taps
+#pragma unroll
+        for (int r = 0; r < 8; ++r) mk[r] = make_uint4(0, 0, 0, 0);
+        uint4 pf[2][2], qf[2][2];
+        auto ldf = [&](int step, uint4 (&p)[2], uint4 (&q)[2]) __attribute__((always_inline)) {
+            const int tap = step >> 2, ks = step & 3;
+            const int dr = tap / 3, ds = tap - dr * 3;
+            const int slot16 = ks * 2 + hi;
+            const char* wt = smem + tap * 8192;
+            p[0] = *reinterpret_cast<const uint4*>(wt + wk0 + ((slot16 ^ fk0) << 4));
+            p[1] = *reinterpret_cast<const uint4*>(wt + wk1 + ((slot16 ^ fk1) << 4));
+            const int px0 = pxb0 + dr * PW + ds, px1 = pxb1 + dr * PW + ds;
+            q[0] = *reinterpret_cast<const uint4*>(patch + px0 * 128 + ((slot16 ^ ((px0 >> 1) & 7)) << 4));
+            q[1] = *reinterpret_cast<const uint4*>(patch + px1 * 128 + ((slot16 ^ ((px1 >> 1) & 7)) << 4));
+        };
+        ldf(0, pf[0], qf[0]);
+#pragma unroll
+        for (int step = 0; step < 36; ++step) {
+            if (step < 35) ldf(step + 1, pf[(step + 1) & 1], qf[(step + 1) & 1]);
+            if ((step & 3) == 0 && has_next) {
+                // the next tile's patch: 11 pieces per wave, two per tap over the first taps
+                const int tap = step >> 2;
+                const int k0 = 2 * tap, k1 = 2 * tap + 1;
+                if (k0 < 11 && wave + 4 * k0 < NPIECE) issue_piece(nn, nh0, nw0, wave + 4 * k0, buf ^ 1);
+                if (k1 < 11 && wave + 4 * k1 < NPIECE) issue_piece(nn, nh0, nw0, wave + 4 * k1, buf ^ 1);
+            }
+            if (step == 24 && a.mask) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int idx = r * 64 + lane;
+                    const int pxl = idx >> 3, ch = idx & 7;
+                    const int h = ch0 + 2 * wave + (pxl >> 5), w = cw0 + (pxl & 31);
+                    if (h < a.H && w < a.W)
+                        mk[r] = *reinterpret_cast<const uint4*>(a.mask + (((size_t)(cn * a.H + h) * a.W + w) * a.ldmask + ch * 8) * 2);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<bf16_t>::run(pf[step & 1][i], qf[step & 1][j], acc[i][j]);
+        }
+        wait_vmcnt<0>();            // my pieces of the next patch landed (they had >= 3 taps of MFMA time)
+        block_barrier();            // everybody is done reading patch `buf`: it becomes the output staging area
+        // ---- epilogue
+        char* sg = stg + buf * PBUF;
+        const bool pre_relu = a.relu != 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pxl = j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = i * 32 + 8 * g + 4 * hi;
+                    const float4 b = bias[i * 4 + g];
+                    float v0 = acc[i][j][4 * g] + b.x, v1 = acc[i][j][4 * g + 1] + b.y;
+                    float v2 = acc[i][j][4 * g + 2] + b.z, v3 = acc[i][j][4 * g + 3] + b.w;
+                    if (pre_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    uint2 o;
+                    o.x = cvt_pk_bf16(v0, v1);
+                    o.y = cvt_pk_bf16(v2, v3);
+                    *reinterpret_cast<uint2*>(sg + pxl * 128 + ((((cl >> 3) ^ pxl) & 7) << 4) + ((cl & 4) << 1)) = o;
+                }
+        }
+        asm volatile("" ::: "memory");          // wave-private patch, in-order LDS: only pins the compiler (TBAA)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int idx = r * 64 + lane;
+            const int pxl = idx >> 3, ch = idx & 7;
+            const int h = ch0 + 2 * wave + (pxl >> 5), w = cw0 + (pxl & 31);
+            uint4 v = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
+            if (h < a.H && w < a.W) {
+                const size_t m = (size_t)(cn * a.H + h) * a.W + w;
+                if (a.mask) post_chunk(v, false, false, mk[r], true, mk[r]);
+                *reinterpret_cast<uint4*>(a.y + (m * a.ldy + ch * 8) * 2) = v;
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
 }  // namespace
 
 static int g_num_cu = 0;
@@ -765,6 +933,22 @@ int launch_gather_v4(GatherArgs& a, hipStream_t st) {
     const int grid = tiles < g_num_cu ? tiles : g_num_cu;
     if (PT == 64) hipLaunchKernelGGL(conv_gather_v4_kernel<64>, dim3(grid), dim3(768), 0, st, a, tiles);
     else hipLaunchKernelGGL(conv_gather_v4_kernel<128>, dim3(grid), dim3(768), 0, st, a, tiles);
+    return 0;
+}
+
+bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype) {
+    return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && a.C == 64 && a.ldx == 64 && a.K == 64 && a.R == 3 && a.S == 3 &&
+           a.dil == 1 && a.ostride == 1 && a.idiv == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo &&
+           !a.accumulate && a.ldy % 8 == 0 && (a.mask == nullptr || a.ldmask % 8 == 0) && a.ldw == 576 &&
+           (long long)a.N * a.H * a.W * 64 * 2 < (1ll << 31);
+}
+
+int launch_gather_c64(GatherArgs& a, hipStream_t st) {
+    if (g_num_cu == 0) query_num_cu();
+    const int tr = ceil_div(a.H, 8), tc = ceil_div(a.W, 32);
+    const int tiles = a.N * tr * tc;
+    const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+    hipLaunchKernelGGL(conv3x3_c64k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles);
     return 0;
 }
 

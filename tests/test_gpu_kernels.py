@@ -61,6 +61,8 @@ V3_EXTRA_CASES = [
     (2, 19, 19, 512, 100, 3, 1, 1),   # deep k (72 slabs), head-like Cout with a channel tail
     (8, 75, 75, 64, 256, 3, 1, 1),    # 176 x 2 tiles: persistent blocks own > 1 tile on a 256-CU chip
     (5, 150, 150, 16, 64, 3, 1, 1),   # 440 PT=64 tiles, 3 k-slabs
+    (2, 13, 70, 64, 64, 3, 1, 1),     # resident-filter 64->64 kernel: ragged 8x32 tiles on both edges
+    (40, 33, 65, 64, 64, 3, 1, 1),    # ... 600 tiles: persistent blocks walk several tiles (patch double buffering)
 ]
 
 

@@ -240,7 +240,7 @@ def test_batchnorm(shape, dt, ydt, dev):
     zd = torch.zeros(M, ldz, dtype=dtype, device=dev); zd[:, :C] = z.to(dtype).to(dev)
     mm = torch.zeros(C, device=dev); mv = torch.ones(C, device=dev)
     sm = torch.empty(C, device=dev); si = torch.empty(C, device=dev)
-    ws = torch.empty(ops.bn_workspace_bytes(M, C), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(ops.bn_workspace_bytes(M, C), dtype=torch.uint8, device=dev)   # zero-initialised once (tickets)
     # head-style dense output: image-major with pitch C (rows_per_img = M/ nimg)
     nimg = 2 if M % 2 == 0 else 3
     rpi = M // nimg
@@ -308,7 +308,7 @@ def test_l2norm_colsum_sgd(dt, dev):
     assert float((dxd.float().cpu() - exp).abs().max()) <= tolb * float(exp.abs().max())
     assert abs(float(dgd.cpu()) - float(gr.grad)) <= 2e-3 * abs(float(gr.grad)) + 1e-3
     # colsum
-    ws = torch.empty(ops.bn_workspace_bytes(M, C), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(ops.bn_workspace_bytes(M, C), dtype=torch.uint8, device=dev)   # zero-initialised once (tickets)
     out = torch.ones(C, device=dev)
     ops.colsum(dy.to(dtype).to(dev), M, C, C, out, True, ws)
     torch.cuda.synchronize()

@@ -124,9 +124,7 @@ int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, void* dx, int
  * + (m % rows_per_img)*ldy (lets the head write straight into pred [N,8828,25]).
  * training: batch statistics (biased var), saves mean / inv-std (f32 [C]) for backward and
  * updates moving stats with the unbiased variance.  Inference: uses moving stats.
- * workspace: >= odtk_bn_workspace_bytes(M, C) bytes (always required), ZERO-INITIALISED ONCE by the caller: its
- * first 4 KiB are the hand-off tickets of the fused statistics+finalize kernels, which leave them at zero; the
- * same buffer may be shared by every BN / colsum call on a stream. */
+ * workspace: >= odtk_bn_workspace_bytes(M, C) bytes (always required). */
 long long odtk_bn_workspace_bytes(int M, int C);
 int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, const float* gamma,
                 const float* beta, float* moving_mean, float* moving_var, float* save_mean,

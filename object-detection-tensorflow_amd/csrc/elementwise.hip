@@ -224,55 +224,10 @@ __device__ __forceinline__ void block_rowlane_reduce(float (&v)[NV], float* sm /
     __syncthreads();
 }
 
-
-// ---- "last block finalizes": the row-split blocks of one column group publish their partial sums, take a
-// ticket, and the block that draws the last ticket reduces them (fixed split order -> deterministic) and
-// finishes the per-channel math -- one launch instead of stats + finalize.  Placement-independent hand-off
-// (cdna_hip_programming.md G16): stores -> barrier -> one lane: agent release + vmcnt(0) -> relaxed agent
-// ticket; last block: agent acquire -> barrier -> plain loads.  The counter is reset by the last block, so the
-// workspace only has to be zero-initialised once.
-__device__ __forceinline__ bool last_block_of_group(int* counter, int nsplit) {
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == nsplit - 1);
-        if (last) {
-            __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    return s_last != 0;
-}
-// 256 threads: channel lane c64 = tid & 63 of the group's 64 channels, split lane sl = tid >> 6 (4 lanes)
-__device__ __forceinline__ void group_reduce_partials(const float* ws, int nsplit, int C, int c, float& s1, float& s2) {
-    __shared__ float smg[2][4][64];
-    const int c64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    float a1 = 0.f, a2 = 0.f;
-    if (c < C) {
-        for (int s = sl; s < nsplit; s += 4) {
-            a1 += __builtin_nontemporal_load(ws + ((size_t)0 * nsplit + s) * C + c);
-            a2 += __builtin_nontemporal_load(ws + ((size_t)1 * nsplit + s) * C + c);
-        }
-    }
-    smg[0][sl][c64] = a1; smg[1][sl][c64] = a2;
-    __syncthreads();
-    s1 = smg[0][0][c64] + smg[0][1][c64] + smg[0][2][c64] + smg[0][3][c64];
-    s2 = smg[1][0][c64] + smg[1][1][c64] + smg[1][2][c64] + smg[1][3][c64];
-}
-
 // BN stats: sum(z - shift), sum((z - shift)^2), shift = z[0][c]
 template <typename T>
 __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ z, int M, int C, int ldz,
-                                                       int rows_per_split, float* __restrict__ ws,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ mmean, float* __restrict__ mvar,
-                                                       float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                       float* __restrict__ fin, int* __restrict__ counters) {
+                                                       int rows_per_split, float* __restrict__ ws) {
     constexpr int KC = Chunk<T>::N;
     __shared__ float sm[RED_ROWS * 8 * 2 * KC];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -307,24 +262,6 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ z, 
             }
         }
     }
-    // fused finalize (training statistics) by the last row-split block of this column group
-    if (!last_block_of_group(counters + blockIdx.x, nsplit)) return;
-    const int c = blockIdx.x * 8 * KC + (threadIdx.x & 63);
-    float s1, s2;
-    const bool active = (threadIdx.x & 63) < 8 * KC;
-    group_reduce_partials(ws, nsplit, C, active ? c : C, s1, s2);
-    if (!active || c >= C || threadIdx.x >= 64) return;
-    const float d = s1 / (float)M;
-    const float mean = elem<T>::load(z[c]) + d;
-    const float var = fmaxf(s2 / (float)M - d * d, 0.f);
-    save_mean[c] = mean;
-    save_invstd[c] = rsqrtf(var + 1e-3f);
-    const float unb = var * ((float)M / (float)(M > 1 ? M - 1 : 1));
-    mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
-    mvar[c] = mvar[c] * 0.99f + unb * (1.f - 0.99f);
-    const float sc = rsqrtf(var + 1e-3f) * gamma[c];
-    fin[c] = sc;
-    fin[C + c] = beta[c] - mean * sc;
 }
 
 __device__ __forceinline__ long long out_off(int m, int rows_per_img, long long img_stride, int ld) {
@@ -439,8 +376,7 @@ template <typename T, typename TY>
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
     const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
     int rows_per_img, long long y_img_stride, const float* __restrict__ save_mean,
-    const float* __restrict__ save_invstd, int relu, int rows_per_split, float* __restrict__ ws,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ fin, int* __restrict__ counters) {
+    const float* __restrict__ save_invstd, int relu, int rows_per_split, float* __restrict__ ws) {
     constexpr int KC = Chunk<T>::N;
     __shared__ float sm[RED_ROWS * 8 * 2 * KC];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -482,17 +418,6 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
             }
         }
     }
-    // fused finalize by the last row-split block of this column group
-    if (!last_block_of_group(counters + blockIdx.x, nsplit)) return;
-    const int c = blockIdx.x * 8 * KC + (threadIdx.x & 63);
-    const bool active = (threadIdx.x & 63) < 8 * KC;
-    float s1, s2;
-    group_reduce_partials(ws, nsplit, C, active ? c : C, s1, s2);
-    if (!active || c >= C || threadIdx.x >= 64) return;
-    dbeta[c] = s1;
-    dgamma[c] = s2;
-    fin[c] = s1 / (float)M;
-    fin[C + c] = s2 / (float)M;
 }
 
 // fin[0*C+c] = mean(dy'), fin[1*C+c] = mean(dy' * xhat); also emits dbeta / dgamma
@@ -829,8 +754,7 @@ extern "C" int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, vo
 
 extern "C" long long odtk_bn_workspace_bytes(int M, int C) {
     (void)M;
-    // [2][256 splits][Cpad] partial sums + [2][Cpad] finalised values + 1024 per-column-group tickets (kept zero)
-    return (long long)(2 * 256 + 2) * (long long)((C + 63) / 64 * 64) * sizeof(float) + 1024 * sizeof(int);
+    return (long long)(2 * 256 + 2) * (long long)((C + 63) / 64 * 64) * sizeof(float);
 }
 
 extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, const float* gamma,
@@ -845,20 +769,15 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     ODTK_REQUIRE(!(y_dtype == ODTK_BF16 && dtype == ODTK_F32), "bn_fwd: f32 in / bf16 out unsupported");
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
-    // workspace: [1024 tickets (kept zero; same place for every layer sharing the buffer)][partials][finalised]
-    int* counters = reinterpret_cast<int*>(workspace);
-    float* ws = (float*)workspace + 1024;
+    float* ws = (float*)workspace;
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
-    ODTK_REQUIRE(pl.colgroups <= 1024, "bn_fwd: C=%d too large", C);
-    if (training) {     // statistics + finalize in one launch (the last row-split block of a column group finalizes)
+    if (training) {
         DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
-                                               (const T*)z, M, C, ldz, pl.rows_per_split, ws, gamma, beta, moving_mean,
-                                               moving_var, save_mean, save_invstd, fin, counters);)
-    } else {
-        DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M,
-                                               C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
-                                               pl.nsplit, fin);)
+                                               (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
     }
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M,
+                                           C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
+                                           pl.nsplit, fin);)
     const size_t ysz = dtype_size(y_dtype);
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
                        ((uintptr_t)y % 16) == 0;
@@ -887,17 +806,17 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_bwd: ldz=%d must be a multiple of %d", ldz, kc);
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
-    int* counters = reinterpret_cast<int*>(workspace);
-    float* ws = (float*)workspace + 1024;
+    float* ws = (float*)workspace;
     const int rows_per_block = pl.rows_per_split;
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
-    ODTK_REQUIRE(pl.colgroups <= 1024, "bn_bwd: C=%d too large", C);
     dim3 g1(pl.colgroups, pl.nsplit);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
 #define BN_BWD(T, TY)                                                                                             \
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu,   \
-                       pl.rows_per_split, ws, dgamma, dbeta, fin, counters);                                      \
+                       pl.rows_per_split, ws);                                                                    \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, ws, pl.nsplit, C, M,     \
+                       dgamma, dbeta, fin);                                                                       \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd,  \
                        relu, (T*)dz, fin, rows_per_block)
@@ -942,7 +861,7 @@ extern "C" int odtk_colsum(const void* dy, int M, int C, int ld, int dtype, floa
     ODTK_REQUIRE(ld % kc == 0 && ld >= C, "colsum: ld=%d must be a multiple of %d", ld, kc);
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
-    float* ws = (float*)workspace + 1024;            // the first 1024 words are the BN tickets (must stay zero)
+    float* ws = (float*)workspace;
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
                                            (const T*)dy, M, C, ld, pl.rows_per_split, ws);)
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, ws, pl.nsplit, C, out,

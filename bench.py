@@ -56,7 +56,7 @@ class ConvTimer:
 
     def __init__(self, ops):
         self.ops = ops
-        self.records = []            # (kind, kernel, flops, start_evt, end_evt)
+        self.records = []            # (kind, kernel, flops, start_evt, end_evt, algorithmic bytes)
         self.enabled = False
         self._orig = {}
 
@@ -74,26 +74,29 @@ class ConvTimer:
                 return orig(d, *args)
             c_alg = 3 if (d.H == 300 and d.C <= 8) else d.C          # conv1_1: 3 real input channels (padded to one chunk)
             flops = 2.0 * d.N * d.Ho * d.Wo * d.K * d.R * d.S * c_alg    # algorithmic: 2*M*Cout*R*S*Cin for each pass
+            esz = 2 if d.dtype == 0 else 4
+            # algorithmic HBM bytes: every operand once (x, y / dy, dx as bf16; filter as bf16, dW as f32)
+            abytes = (d.N * d.H * d.W * d.C + d.N * d.Ho * d.Wo * d.K) * esz + d.K * d.R * d.S * d.C * (4 if kind == 'conv2d_wgrad' else esz)
             s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
             s.record()
             r = orig(d, *args)
             e.record()
-            self.records.append((kind, self.ops.conv_last_kernel(), flops, s, e))
+            self.records.append((kind, self.ops.conv_last_kernel(), flops, s, e, abytes))
             return r
         return f
 
     def summary(self):
         per_kernel, per_pass = {}, {}
-        for kind, kern, fl, s, e in self.records:
+        for kind, kern, fl, s, e, ab in self.records:
             t = s.elapsed_time(e) * 1e-3
             for d, k in ((per_kernel, kern), (per_pass, kind)):
-                a = d.setdefault(k, [0.0, 0.0, 0]); a[0] += fl; a[1] += t; a[2] += 1
+                a = d.setdefault(k, [0.0, 0.0, 0, 0.0]); a[0] += fl; a[1] += t; a[2] += 1; a[3] += ab
         return per_kernel, per_pass
 
     def roofline(self, steps, peak, whole_step_frac):
         per_kernel, per_pass = self.summary()
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
-        fl, t, n = per_kernel[dom]
+        fl, t, n, ab = per_kernel[dom]
         tot_f = sum(v[0] for v in per_kernel.values()); tot_t = sum(v[1] for v in per_kernel.values())
         return {
             'bound': 'mfma', 'kernel': dom,
@@ -101,6 +104,7 @@ class ConvTimer:
             'traffic': pmc_traffic(dom),
             'launches_per_step': n // steps, 'avg_launch_us': round(t / n * 1e6, 2),
             'algorithmic_gflop_per_launch': round(fl / n / 1e9, 2),
+            'algorithmic_mb_per_launch': round(ab / n / 1e6, 1),
             'family': {'kernels': 'all conv kernels (fwd + dgrad + wgrad, every layer)',
                        'achieved': round(tot_f / tot_t / 1e12, 2), 'frac': round(tot_f / tot_t / peak, 4),
                        'launches_per_step': len(self.records) // steps, 'conv_ms_per_step': round(tot_t / steps * 1e3, 3)},

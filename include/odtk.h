@@ -215,6 +215,36 @@ int odtk_ssd_decode(const float* pred0, int A, int C, int ld, const float* yx, c
                     float score_thr, float* conf, float* boxes, unsigned char* keep,
                     unsigned char* cand, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * RetinaNet box side (kernel K16): anchors, matching with the 0.4 / 0.5 ignore band,
+ * softmax focal loss + smooth-L1 and their gradients.  Any number of anchors (47 961 @500x500,
+ * 120 087 @800x800); same GT layout as SSD ([N][P][5] = yc, xc, h, w, class; pad rows -1; P <= 128).
+ * ------------------------------------------------------------------------- */
+/* RetinaNet._get_abbox (RetinaNet.py:328-355) for every pyramid level: level l has fh[l] x fw[l] cells and
+ * na[l] anchors per cell whose (h, w) follow in prior_hw (host floats, level-major); centre = (i + 0.5) *
+ * (input_dim / fh[l]) on BOTH axes (the reference passes data_shape[1] as input_dim, RetinaNet.py:330).
+ * Outputs [A][2] each, A = sum fh*fw*na, order (level, y, x, anchor). */
+int odtk_retina_anchors(int input_dim, int nlevels, const int* fh, const int* fw, const int* na,
+                        const float* prior_hw, float* y1x1, float* y2x2, float* yx, float* hw, void* stream);
+
+/* Matching (RetinaNet.py:357-417).  best[N][P]: first arg-max anchor of every GT; status[N][A]: 0 ignore
+ * (0.4 <= IoU <= 0.5), 1 positive (IoU > 0.5), 2 negative (IoU < 0.4), 3 best anchor of some GT;
+ * rgindex[N][A]: first arg-max GT of the anchor; counts[N][4] = {rows of the positive set, negatives, 0, 0}.
+ * Indices are bit-exact vs the reference's float32 arithmetic.  workspace: odtk_retina_match_workspace_bytes. */
+long long odtk_retina_match_workspace_bytes(int A, int N, int P);
+int odtk_retina_match(const float* y1x1, const float* y2x2, const float* hw, int A, const float* gt, int N,
+                      int P, int* ngt, int* best, unsigned char* status, int* rgindex, int* counts,
+                      void* workspace, void* stream);
+
+/* Focal (softmax flavour, alpha on positives AND negatives, p clipped to [1e-8, 1], sum / #positives;
+ * RetinaNet.py:457-474) + smooth-L1 on the positive rows (:441-446).  pconf [N][A][C] logits (background =
+ * class C-1), pbox [N][A][4] = (ty, tx, th, tw).  loss_parts[N][2] = {focal, coord}; dconf / dbox are
+ * overwritten with d(sum_i (focal_i + coord_i) * grad_scale) / d(pconf, pbox)  (grad_scale = 1 / batch). */
+int odtk_retina_loss(const float* pconf, const float* pbox, int N, int A, int C, const float* yx,
+                     const float* hw, const float* gt, int P, const int* ngt, const int* best,
+                     const unsigned char* status, const int* rgindex, const int* counts, float alpha,
+                     float gamma, float grad_scale, float* loss_parts, float* dconf, float* dbox, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

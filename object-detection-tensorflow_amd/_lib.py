@@ -65,6 +65,10 @@ SIGNATURES = {
                               _vp, _vp]),
     "odtk_ssd_loss": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                            _vp, _f, _vp, _vp, _vp]),
+    "odtk_retina_anchors": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _vp, _vp, _vp, _vp, _vp]),
+    "odtk_retina_match_workspace_bytes": (_ll, [_i, _i, _i]),
+    "odtk_retina_match": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "odtk_retina_loss": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "odtk_ssd_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
 }
 

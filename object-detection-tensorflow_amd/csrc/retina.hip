@@ -1,0 +1,358 @@
+// RetinaNet box side (gfx950): anchors, IoU matching with the 0.4 / 0.5 ignore band, softmax focal loss +
+// smooth-L1 with their gradients.  SURVEY.md 8(f).1 / kernel K16.
+//
+// Reference: RetinaNet.py:328-355 (_get_abbox), :357-452 (_compute_one_image_loss), :457-474 (_focal_loss),
+// :194-213 (batch loop).  Unlike SSD300 (8 828 priors, one workgroup per image) RetinaNet has 47 961 anchors at
+// 500x500 and 120 087 at 800x800, so matching is tiled over anchors: every (anchor tile, image) workgroup
+// emits per-anchor max / arg-max over the ground truth and a per-GT partial arg-max over its tile; a second
+// tiny kernel reduces the partials in tile order (= first arg-max) and fixes up the best-anchor set.
+// Everything that produces an INDEX follows the float32 operation order of the graph (this file is compiled
+// with -ffp-contract=off and uses IEEE division) so indices are bit-identical to the CPU oracle.
+#include "common.h"
+#include <math.h>
+
+namespace odtk {
+namespace {
+
+constexpr int RL_MAX_LEVELS = 8, RL_MAX_NA = 16, RL_MAX_GT = 128, RL_THREADS = 256, RL_MAXC = 32;
+
+struct AnchorArgs {
+    int nlevels, total;
+    float input_dim;
+    int fh[RL_MAX_LEVELS], fw[RL_MAX_LEVELS], na[RL_MAX_LEVELS], off[RL_MAX_LEVELS + 1];
+    float hw[RL_MAX_LEVELS][RL_MAX_NA][2];
+};
+
+// RetinaNet.py:328-355.  rate = input_dim / fh (float division first), centre = (i + 0.5) * rate for BOTH axes.
+__global__ void retina_anchors_kernel(const AnchorArgs p, float* __restrict__ y1x1, float* __restrict__ y2x2,
+                                      float* __restrict__ yx, float* __restrict__ hw) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= p.total) return;
+    int l = 0;
+    while (l + 1 < p.nlevels && a >= p.off[l + 1]) ++l;
+    const int local = a - p.off[l];
+    const int na = p.na[l], fw = p.fw[l];
+    const int cell = local / na, an = local - cell * na;
+    const int iy = cell / fw, ix = cell - iy * fw;
+    const float rate = p.input_dim / (float)p.fh[l];
+    const float cy = ((float)iy + 0.5f) * rate;
+    const float cx = ((float)ix + 0.5f) * rate;
+    const float ph = p.hw[l][an][0], pw = p.hw[l][an][1];
+    const float y1 = cy - ph / 2.f, x1 = cx - pw / 2.f;
+    const float y2 = cy + ph / 2.f, x2 = cx + pw / 2.f;
+    y1x1[2 * a] = y1; y1x1[2 * a + 1] = x1;
+    y2x2[2 * a] = y2; y2x2[2 * a + 1] = x2;
+    yx[2 * a] = y1 / 2.f + y2 / 2.f; yx[2 * a + 1] = x1 / 2.f + x2 / 2.f;      // :353
+    hw[2 * a] = y2 - y1; hw[2 * a + 1] = x2 - x1;                              // :354
+}
+
+struct GtBox { float y1, x1, y2, x2, area; };
+
+__device__ __forceinline__ float iou_ga(const GtBox& g, float ay1, float ax1, float ay2, float ax2, float aarea) {
+    const float iy1 = fmaxf(ay1, g.y1), ix1 = fmaxf(ax1, g.x1);
+    const float iy2 = fminf(ay2, g.y2), ix2 = fminf(ax2, g.x2);
+    const float ih = fmaxf(iy2 - iy1, 0.f), iw = fmaxf(ix2 - ix1, 0.f);
+    const float inter = ih * iw;
+    return inter / (aarea + g.area - inter);                                   // :382
+}
+
+// number of valid GT rows = first index of the minimum of column 0 (tf.argmin, :358)
+__device__ int gt_count(const float* gt, int P, float* s_val, int* s_idx) {
+    const int tid = threadIdx.x;
+    float v = INFINITY; int idx = 0x7fffffff;
+    for (int i = tid; i < P; i += RL_THREADS) {
+        const float x = gt[i * 5];
+        if (x < v) { v = x; idx = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(v, o); const int i2 = __shfl_xor(idx, o);
+        if (v2 < v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+    }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = v; s_idx[tid >> 6] = idx; }
+    __syncthreads();
+    float bv = s_val[0]; int bi = s_idx[0];
+    for (int w = 1; w < RL_THREADS / 64; ++w)
+        if (s_val[w] < bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+    __syncthreads();
+    return bi;
+}
+
+// Pass 1: per anchor max / first arg-max over the GT; per (tile, GT) first arg-max over the tile's anchors.
+__global__ void __launch_bounds__(RL_THREADS) retina_iou_kernel(
+    const float* __restrict__ y1x1, const float* __restrict__ y2x2, const float* __restrict__ hw, int A,
+    const float* __restrict__ gt, int P, float* __restrict__ maxiou, int* __restrict__ rgindex,
+    float* __restrict__ part_iou, int* __restrict__ part_idx) {
+    __shared__ GtBox s_g[RL_MAX_GT];
+    __shared__ float s_val[RL_THREADS / 64];
+    __shared__ int s_idx[RL_THREADS / 64];
+    __shared__ float s_wv[RL_THREADS / 64][RL_MAX_GT];
+    __shared__ int s_wi[RL_THREADS / 64][RL_MAX_GT];
+    const int n = blockIdx.y, tile = blockIdx.x, ntile = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* g = gt + (size_t)n * P * 5;
+    const int G = gt_count(g, P, s_val, s_idx);
+    for (int i = tid; i < G; i += RL_THREADS) {
+        const float yc = g[i * 5], xc = g[i * 5 + 1], h = g[i * 5 + 2], w = g[i * 5 + 3];
+        GtBox b;
+        b.y1 = yc - h / 2.f; b.x1 = xc - w / 2.f; b.y2 = yc + h / 2.f; b.x2 = xc + w / 2.f;   // :361-362
+        b.area = h * w;
+        s_g[i] = b;
+    }
+    __syncthreads();
+    const int a = tile * RL_THREADS + tid;
+    const bool in = a < A;
+    float ay1 = 0.f, ax1 = 0.f, ay2 = 0.f, ax2 = 0.f, aarea = 1.f;
+    if (in) {
+        ay1 = y1x1[2 * a]; ax1 = y1x1[2 * a + 1]; ay2 = y2x2[2 * a]; ax2 = y2x2[2 * a + 1];
+        aarea = hw[2 * a] * hw[2 * a + 1];
+    }
+    float m = -1.f; int r = 0;
+    for (int gi = 0; gi < G; ++gi) {
+        const float v = in ? iou_ga(s_g[gi], ay1, ax1, ay2, ax2, aarea) : -1.f;
+        if (v > m) { m = v; r = gi; }                       // first max over the GT (:410, :414)
+        // first arg-max over this tile's anchors for GT gi (lowest anchor index among equal maxima)
+        float bv = v; int bi = in ? a : 0x7fffffff;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o); const int i2 = __shfl_xor(bi, o);
+            if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+        }
+        if (lane == 0) { s_wv[wave][gi] = bv; s_wi[wave][gi] = bi; }
+    }
+    if (in) { maxiou[(size_t)n * A + a] = m; rgindex[(size_t)n * A + a] = r; }
+    __syncthreads();
+    for (int gi = tid; gi < G; gi += RL_THREADS) {
+        float bv = s_wv[0][gi]; int bi = s_wi[0][gi];
+        for (int w = 1; w < RL_THREADS / 64; ++w)
+            if (s_wv[w][gi] > bv || (s_wv[w][gi] == bv && s_wi[w][gi] < bi)) { bv = s_wv[w][gi]; bi = s_wi[w][gi]; }
+        part_iou[((size_t)n * ntile + tile) * P + gi] = bv;
+        part_idx[((size_t)n * ntile + tile) * P + gi] = bi;
+    }
+}
+
+// Pass 2 (one workgroup per image): best anchor per GT = first arg-max over all tiles; status of every anchor:
+// 0 ignore (0.4 <= iou <= 0.5), 1 positive (> 0.5), 2 negative (< 0.4), 3 best anchor of at least one GT.
+__global__ void __launch_bounds__(RL_THREADS) retina_status_kernel(
+    const float* __restrict__ gt, int P, int A, int ntile, const float* __restrict__ part_iou,
+    const int* __restrict__ part_idx, const float* __restrict__ maxiou, int* __restrict__ ngt, int* __restrict__ best,
+    unsigned char* __restrict__ status, int* __restrict__ counts) {
+    __shared__ float s_val[RL_THREADS / 64];
+    __shared__ int s_idx[RL_THREADS / 64];
+    __shared__ int s_best[RL_MAX_GT];
+    __shared__ int s_cnt[2];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int G = gt_count(gt + (size_t)n * P * 5, P, s_val, s_idx);
+    if (tid < 2) s_cnt[tid] = 0;
+    for (int gi = tid; gi < G; gi += RL_THREADS) {
+        float bv = -2.f; int bi = 0;
+        for (int t = 0; t < ntile; ++t) {
+            const float v = part_iou[((size_t)n * ntile + t) * P + gi];
+            if (v > bv) { bv = v; bi = part_idx[((size_t)n * ntile + t) * P + gi]; }     // strict >: lowest tile wins ties
+        }
+        s_best[gi] = bi;
+        best[(size_t)n * P + gi] = bi;
+    }
+    __syncthreads();
+    int npos = 0, nneg = 0;
+    for (int a = tid; a < A; a += RL_THREADS) {
+        const float m = maxiou[(size_t)n * A + a];
+        unsigned char st = m > 0.5f ? 1 : (m < 0.4f ? 2 : 0);                 // :416-417
+        status[(size_t)n * A + a] = st;
+        npos += st == 1; nneg += st == 2;
+    }
+    for (int o = 32; o > 0; o >>= 1) { npos += __shfl_xor(npos, o); nneg += __shfl_xor(nneg, o); }
+    if ((tid & 63) == 0) { atomicAdd(&s_cnt[0], npos); atomicAdd(&s_cnt[1], nneg); }
+    __syncthreads();
+    // best anchors leave the "other" set (:397-407); every distinct one exactly once
+    for (int gi = tid; gi < G; gi += RL_THREADS) {
+        const int b = s_best[gi];
+        bool first = true;
+        for (int k = 0; k < gi; ++k) first = first && s_best[k] != b;
+        if (first) {
+            const float m = maxiou[(size_t)n * A + b];
+            if (m > 0.5f) atomicSub(&s_cnt[0], 1);
+            else if (m < 0.4f) atomicSub(&s_cnt[1], 1);
+        }
+    }
+    __syncthreads();
+    for (int gi = tid; gi < G; gi += RL_THREADS) status[(size_t)n * A + s_best[gi]] = 3;
+    if (tid == 0) {
+        ngt[n] = G;
+        counts[n * 4 + 0] = G + s_cnt[0];          // rows of the positive set (best rows incl. duplicates + IoU > 0.5)
+        counts[n * 4 + 1] = s_cnt[1];
+        counts[n * 4 + 2] = 0; counts[n * 4 + 3] = 0;
+    }
+}
+
+struct RLossArgs {
+    const float* pconf; const float* pbox; int N, A, C;
+    const float* yx; const float* hw; const float* gt; int P;
+    const int* ngt; const int* best; const unsigned char* status; const int* rgindex; const int* counts;
+    float alpha, gamma, grad_scale;
+    float* loss_parts; float* dconf; float* dbox;
+};
+
+// focal term of one row and its gradient w.r.t. the logits (RetinaNet.py:457-474); `add` accumulates (best rows).
+__device__ __forceinline__ float focal_row(const RLossArgs& a, const float* z, float* dz, int label, float scale, bool add) {
+    float e[RL_MAXC];
+    float m = z[0];
+    for (int c = 1; c < a.C; ++c) m = fmaxf(m, z[c]);
+    float s = 0.f;
+    for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - m); s += e[c]; }
+    const float inv = 1.f / s;
+    const float pu = e[label] * inv;
+    const float pt = fminf(fmaxf(pu, 1e-8f), 1.f);
+    const float om = 1.f - pt;
+    const float lg = logf(pt);
+    const float loss = -a.alpha * powf(om, a.gamma) * lg;
+    // d loss / d pt (zero where the clip is active from below)
+    float dpt = 0.f;
+    if (pu >= 1e-8f) dpt = a.alpha * (a.gamma * powf(om, a.gamma - 1.f) * lg - powf(om, a.gamma) / pt);
+    const float k = dpt * pu * scale;
+    for (int c = 0; c < a.C; ++c) {
+        const float g = k * ((c == label ? 1.f : 0.f) - e[c] * inv);
+        if (add) atomicAdd(dz + c, g); else dz[c] = g;
+    }
+    return loss;
+}
+
+// smooth-L1 of one positive row vs GT g (encode :441-442, loss :443-445) and its gradient
+__device__ __forceinline__ float box_row(const RLossArgs& a, int n, int anchor, int g, const float* pb, float* db, float scale, bool add) {
+    const float* gb = a.gt + ((size_t)n * a.P + g) * 5;
+    const float ayc = a.yx[2 * anchor], axc = a.yx[2 * anchor + 1], ah = a.hw[2 * anchor], aw = a.hw[2 * anchor + 1];
+    const float t[4] = {(gb[0] - ayc) / ah, (gb[1] - axc) / aw, logf(gb[2] / ah), logf(gb[3] / aw)};
+    float sum = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        const float d = pb[k] - t[k];
+        const float ad = fabsf(d);
+        sum += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+        const float gr = (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * scale;
+        if (add) atomicAdd(db + k, gr); else db[k] = gr;
+    }
+    return sum;
+}
+
+__global__ void __launch_bounds__(RL_THREADS) retina_loss_kernel(const RLossArgs a) {
+    __shared__ float s_red[2][RL_THREADS / 64];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int num_pos = a.counts[n * 4 + 0];
+    const float inv_np = 1.f / (float)num_pos;
+    const float gs = a.grad_scale * inv_np;
+    float conf = 0.f, coord = 0.f;
+    const int an = blockIdx.x * RL_THREADS + tid;
+    if (an < a.A) {
+        const size_t row = (size_t)n * a.A + an;
+        const float* z = a.pconf + row * a.C;
+        float* dz = a.dconf + row * a.C;
+        const float* pb = a.pbox + row * 4;
+        float* db = a.dbox + row * 4;
+        const unsigned char st = a.status[row];
+        if (st == 1) {
+            const int g = a.rgindex[row];
+            const int label = (int)a.gt[((size_t)n * a.P + g) * 5 + 4];
+            conf += focal_row(a, z, dz, label, gs, false);
+            coord += box_row(a, n, an, g, pb, db, gs, false);
+        } else if (st == 2) {
+            conf += focal_row(a, z, dz, a.C - 1, gs, false);
+            for (int k = 0; k < 4; ++k) db[k] = 0.f;
+        } else {                                   // ignore band, or a best anchor (its rows are added below)
+            for (int c = 0; c < a.C; ++c) dz[c] = 0.f;
+            for (int k = 0; k < 4; ++k) db[k] = 0.f;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { conf += __shfl_xor(conf, o); coord += __shfl_xor(coord, o); }
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = conf; s_red[1][tid >> 6] = coord; }
+    __syncthreads();
+    if (tid == 0) {
+        float c0 = 0.f, c1 = 0.f;
+        for (int w = 0; w < RL_THREADS / 64; ++w) { c0 += s_red[0][w]; c1 += s_red[1][w]; }
+        atomicAdd(a.loss_parts + n * 2 + 0, c0 * inv_np);
+        atomicAdd(a.loss_parts + n * 2 + 1, c1 * inv_np);
+    }
+}
+
+// the G "best" rows of every image (duplicates allowed: two GT may pick one anchor) -- accumulated on top of
+// the zeros written by retina_loss_kernel, hence a second launch
+__global__ void __launch_bounds__(RL_MAX_GT) retina_best_rows_kernel(const RLossArgs a) {
+    const int n = blockIdx.x, g = threadIdx.x;
+    const int G = a.ngt[n];
+    float conf = 0.f, coord = 0.f;
+    const float inv_np = 1.f / (float)a.counts[n * 4 + 0];
+    if (g < G) {
+        const int an = a.best[(size_t)n * a.P + g];
+        const size_t row = (size_t)n * a.A + an;
+        const int label = (int)a.gt[((size_t)n * a.P + g) * 5 + 4];
+        const float gs = a.grad_scale * inv_np;
+        conf = focal_row(a, a.pconf + row * a.C, a.dconf + row * a.C, label, gs, true);
+        coord = box_row(a, n, an, g, a.pbox + row * 4, a.dbox + row * 4, gs, true);
+    }
+    for (int o = 32; o > 0; o >>= 1) { conf += __shfl_xor(conf, o); coord += __shfl_xor(coord, o); }
+    if ((g & 63) == 0) {
+        atomicAdd(a.loss_parts + n * 2 + 0, conf * inv_np);
+        atomicAdd(a.loss_parts + n * 2 + 1, coord * inv_np);
+    }
+}
+
+}  // namespace
+}  // namespace odtk
+
+using namespace odtk;
+
+extern "C" int odtk_retina_anchors(int input_dim, int nlevels, const int* fh, const int* fw, const int* na,
+                                   const float* prior_hw, float* y1x1, float* y2x2, float* yx, float* hw, void* stream) {
+    ODTK_REQUIRE(fh && fw && na && prior_hw && y1x1 && y2x2 && yx && hw, "retina_anchors: null pointer");
+    ODTK_REQUIRE(nlevels > 0 && nlevels <= RL_MAX_LEVELS, "retina_anchors: nlevels=%d out of range", nlevels);
+    AnchorArgs p;
+    p.nlevels = nlevels; p.input_dim = (float)input_dim;
+    int off = 0, k = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        ODTK_REQUIRE(na[l] > 0 && na[l] <= RL_MAX_NA && fh[l] > 0 && fw[l] > 0, "retina_anchors: bad level %d", l);
+        p.fh[l] = fh[l]; p.fw[l] = fw[l]; p.na[l] = na[l]; p.off[l] = off;
+        for (int i = 0; i < na[l]; ++i, ++k) { p.hw[l][i][0] = prior_hw[2 * k]; p.hw[l][i][1] = prior_hw[2 * k + 1]; }
+        off += fh[l] * fw[l] * na[l];
+    }
+    p.off[nlevels] = off; p.total = off;
+    hipLaunchKernelGGL(retina_anchors_kernel, dim3(ceil_div(off, 256)), dim3(256), 0, (hipStream_t)stream, p, y1x1, y2x2, yx, hw);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" long long odtk_retina_match_workspace_bytes(int A, int N, int P) {
+    const long long ntile = (A + RL_THREADS - 1) / RL_THREADS;
+    return (long long)N * A * 4 + 2ll * N * ntile * P * 4;
+}
+
+extern "C" int odtk_retina_match(const float* y1x1, const float* y2x2, const float* hw, int A, const float* gt, int N,
+                                 int P, int* ngt, int* best, unsigned char* status, int* rgindex, int* counts,
+                                 void* workspace, void* stream) {
+    ODTK_REQUIRE(y1x1 && y2x2 && hw && gt && ngt && best && status && rgindex && counts && workspace, "retina_match: null pointer");
+    ODTK_REQUIRE(A > 0 && N > 0 && P > 0 && P <= RL_MAX_GT, "retina_match: A=%d N=%d P=%d out of range", A, N, P);
+    const int ntile = ceil_div(A, RL_THREADS);
+    float* maxiou = (float*)workspace;
+    float* part_iou = maxiou + (size_t)N * A;
+    int* part_idx = (int*)(part_iou + (size_t)N * ntile * P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(retina_iou_kernel, dim3(ntile, N), dim3(RL_THREADS), 0, st, y1x1, y2x2, hw, A, gt, P, maxiou, rgindex,
+                       part_iou, part_idx);
+    hipLaunchKernelGGL(retina_status_kernel, dim3(N), dim3(RL_THREADS), 0, st, gt, P, A, ntile, part_iou, part_idx, maxiou,
+                       ngt, best, status, counts);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_retina_loss(const float* pconf, const float* pbox, int N, int A, int C, const float* yx,
+                                const float* hw, const float* gt, int P, const int* ngt, const int* best,
+                                const unsigned char* status, const int* rgindex, const int* counts, float alpha,
+                                float gamma, float grad_scale, float* loss_parts, float* dconf, float* dbox, void* stream) {
+    ODTK_REQUIRE(pconf && pbox && yx && hw && gt && ngt && best && status && rgindex && counts && loss_parts && dconf && dbox,
+                 "retina_loss: null pointer");
+    ODTK_REQUIRE(C > 1 && C <= RL_MAXC && P > 0 && P <= RL_MAX_GT, "retina_loss: C=%d P=%d unsupported", C, P);
+    hipStream_t st = (hipStream_t)stream;
+    ODTK_CHECK_HIP(hipMemsetAsync(loss_parts, 0, (size_t)N * 2 * sizeof(float), st));
+    RLossArgs a;
+    a.pconf = pconf; a.pbox = pbox; a.N = N; a.A = A; a.C = C; a.yx = yx; a.hw = hw; a.gt = gt; a.P = P;
+    a.ngt = ngt; a.best = best; a.status = status; a.rgindex = rgindex; a.counts = counts;
+    a.alpha = alpha; a.gamma = gamma; a.grad_scale = grad_scale; a.loss_parts = loss_parts; a.dconf = dconf; a.dbox = dbox;
+    hipLaunchKernelGGL(retina_loss_kernel, dim3(ceil_div(A, RL_THREADS), N), dim3(RL_THREADS), 0, st, a);
+    hipLaunchKernelGGL(retina_best_rows_kernel, dim3(N), dim3(RL_MAX_GT), 0, st, a);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

@@ -214,3 +214,34 @@ def ssd_decode(pred0, Cn, yx, hw, thr, conf, boxes, keep, cand):
     A, ld = pred0.shape
     call("odtk_ssd_decode", _p(pred0), A, Cn, ld, _p(yx), _p(hw), float(thr), _p(conf), _p(boxes), _p(keep),
          _p(cand), _stream())
+
+
+# ------------------------------------------------------------------ RetinaNet box side (K16)
+def retina_anchors(input_dim, shapes, nas, prior_hw_flat, device):
+    """shapes: [(fh, fw)] per level; returns (y1x1, y2x2, yx, hw) device tensors [A, 2]."""
+    A = sum(fh * fw * a for (fh, fw), a in zip(shapes, nas))
+    mk = lambda: torch.empty(A, 2, dtype=torch.float32, device=device)
+    y1x1, y2x2, yx, hw = mk(), mk(), mk(), mk()
+    L = len(shapes)
+    call("odtk_retina_anchors", int(input_dim), L, (C.c_int * L)(*[s[0] for s in shapes]),
+         (C.c_int * L)(*[s[1] for s in shapes]), (C.c_int * L)(*nas), (C.c_float * len(prior_hw_flat))(*prior_hw_flat),
+         _p(y1x1), _p(y2x2), _p(yx), _p(hw), _stream())
+    return y1x1, y2x2, yx, hw
+
+
+def retina_match_workspace(A, N, P, device):
+    return torch.empty(int(_lib.load().odtk_retina_match_workspace_bytes(A, N, P)), dtype=torch.uint8, device=device)
+
+
+def retina_match(y1x1, y2x2, hw, gt, ngt, best, status, rgindex, counts, ws):
+    N, P, _ = gt.shape
+    call("odtk_retina_match", _p(y1x1), _p(y2x2), _p(hw), y1x1.shape[0], _p(gt), N, P, _p(ngt), _p(best), _p(status),
+         _p(rgindex), _p(counts), _p(ws), _stream())
+
+
+def retina_loss(pconf, pbox, yx, hw, gt, ngt, best, status, rgindex, counts, alpha, gamma, grad_scale, loss_parts,
+                dconf, dbox):
+    N, A, Cn = pconf.shape
+    call("odtk_retina_loss", _p(pconf), _p(pbox), N, A, Cn, _p(yx), _p(hw), _p(gt), gt.shape[1], _p(ngt), _p(best),
+         _p(status), _p(rgindex), _p(counts), float(alpha), float(gamma), float(grad_scale), _p(loss_parts), _p(dconf),
+         _p(dbox), _stream())

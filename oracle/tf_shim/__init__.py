@@ -185,6 +185,23 @@ def unique(x):
     return torch.tensor(vals, dtype=x.dtype), torch.tensor([first[v] for v in x.tolist()], dtype=int32)
 
 
+def gather_nd(params, indices):
+    idx = _t(indices).long()
+    return params[tuple(idx[..., i] for i in range(idx.shape[-1]))]
+
+
+def clip_by_value(x, lo, hi):
+    return torch.clamp(x, lo, hi)
+
+
+def pow(x, y):                              # noqa: A001
+    return torch.pow(_t(x), y)
+
+
+def expand_dims(x, axis):
+    return _t(x).unsqueeze(axis)
+
+
 def zeros_like(x, dtype=None):
     return torch.zeros_like(x, dtype=dtype)
 
@@ -624,6 +641,14 @@ def install(vgg_tensors=None):
 def uninstall():
     for k in ('tensorflow', 'tensorflow.python', 'tensorflow.python.pywrap_tensorflow'):
         sys.modules.pop(k, None)
+
+
+def load_reference_module(path, name):
+    """Execs a reference source file that parses as shipped (RetinaNet.py, ...) under the shim."""
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    exec(compile(open(path).read(), path, 'exec'), mod.__dict__)
+    return mod
 
 
 def load_reference_ssd300(path='/root/reference/SSD300.py'):

@@ -8,7 +8,8 @@ import torch
 
 from oracle import ssd300_ref as R
 
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLD = G
 torch.set_num_threads(8)
 
 
@@ -101,3 +102,34 @@ def test_same_padding_and_shapes():
     assert R.same_pad(19, 3, 1, 2) == (19, 2, 2)      # conv6 dilation 2
     assert R.feature_sizes() == [38, 19, 10, 5, 5, 3]
     assert sum(v.numel() for k, v in R.init_params(0).items() if k.endswith('.w') or k.endswith('.b')) == 26284974
+
+
+# ---------------------------------------------------------------------------------------------------------
+# RetinaNet box side: oracle/retinanet_ref.py vs the reference's own RetinaNet.py
+# functions executed on the shim (tests/golden/make_golden_retinanet.py)
+# ---------------------------------------------------------------------------------------------------------
+def test_retinanet_anchors_bit_exact_vs_reference():
+    from oracle import retinanet_ref as RR
+    g = np.load(os.path.join(GOLD, 'retina_anchors.npz'))
+    for (ih, iw) in ((320, 256), (500, 500)):
+        tag = f'{ih}x{iw}'
+        shapes = RR.pyramid_shapes(ih, iw)
+        assert np.array_equal(np.asarray(shapes, np.int32), g[f'shapes_{tag}'])
+        a = RR.anchors([ih, iw, 3], shapes)
+        assert a[0].shape[0] == int(g[f'count_{tag}'])
+        step = 1 if a[0].shape[0] < 20000 else 7
+        for n, v in zip(('y1x1', 'y2x2', 'yx', 'hw'), a):
+            assert np.array_equal(v.numpy()[::step], g[f'{n}_{tag}']), (tag, n)
+    assert RR.anchors([800, 800, 3], RR.pyramid_shapes(800, 800))[0].shape[0] == 120087      # BASELINE config 3
+
+
+def test_retinanet_one_image_loss_vs_reference():
+    from oracle import retinanet_ref as RR
+    g = np.load(os.path.join(GOLD, 'retina_loss.npz'))
+    anc = RR.anchors([320, 256, 3], RR.pyramid_shapes(320, 256))
+    pconf = torch.from_numpy(g['pconf'].astype(np.float32))
+    pbox = torch.from_numpy(g['pbox'].astype(np.float32))
+    gt = torch.from_numpy(g['gt'])
+    for i in range(pconf.shape[0]):
+        l = float(RR.one_image_loss(pbox[i, :, :2], pbox[i, :, 2:], pconf[i], anc, gt[i]))
+        assert abs(l - float(g['loss'][i])) <= 1e-5 * abs(float(g['loss'][i])), (i, l, float(g['loss'][i]))

@@ -15,6 +15,8 @@ namespace odtk {
 namespace {
 
 constexpr int RL_MAX_LEVELS = 8, RL_MAX_NA = 16, RL_MAX_GT = 128, RL_THREADS = 256, RL_MAXC = 32;
+constexpr int RL_LOSS_TILES = 8;                   // anchor tiles per workgroup of the loss pass (2 atomics per workgroup)
+constexpr int RL_TILES_PER_BLOCK = 4;              // anchor tiles per workgroup of the IoU pass (amortises the GT set-up)
 
 struct AnchorArgs {
     int nlevels, total;
@@ -81,13 +83,15 @@ __device__ int gt_count(const float* gt, int P, float* s_val, int* s_idx) {
 __global__ void __launch_bounds__(RL_THREADS) retina_iou_kernel(
     const float* __restrict__ y1x1, const float* __restrict__ y2x2, const float* __restrict__ hw, int A,
     const float* __restrict__ gt, int P, float* __restrict__ maxiou, int* __restrict__ rgindex,
-    float* __restrict__ part_iou, int* __restrict__ part_idx) {
+    float* __restrict__ part_iou, int* __restrict__ part_idx, unsigned char* __restrict__ status,
+    int* __restrict__ counts) {
     __shared__ GtBox s_g[RL_MAX_GT];
     __shared__ float s_val[RL_THREADS / 64];
     __shared__ int s_idx[RL_THREADS / 64];
     __shared__ float s_wv[RL_THREADS / 64][RL_MAX_GT];
     __shared__ int s_wi[RL_THREADS / 64][RL_MAX_GT];
-    const int n = blockIdx.y, tile = blockIdx.x, ntile = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = (A + RL_THREADS - 1) / RL_THREADS;
     const float* g = gt + (size_t)n * P * 5;
     const int G = gt_count(g, P, s_val, s_idx);
     for (int i = tid; i < G; i += RL_THREADS) {
@@ -98,6 +102,8 @@ __global__ void __launch_bounds__(RL_THREADS) retina_iou_kernel(
         s_g[i] = b;
     }
     __syncthreads();
+    int blk_pos = 0, blk_neg = 0;
+    for (int tile = blockIdx.x * RL_TILES_PER_BLOCK; tile < ntile && tile < (int)(blockIdx.x + 1) * RL_TILES_PER_BLOCK; ++tile) {
     const int a = tile * RL_THREADS + tid;
     const bool in = a < A;
     float ay1 = 0.f, ax1 = 0.f, ay2 = 0.f, ax2 = 0.f, aarea = 1.f;
@@ -117,7 +123,13 @@ __global__ void __launch_bounds__(RL_THREADS) retina_iou_kernel(
         }
         if (lane == 0) { s_wv[wave][gi] = bv; s_wi[wave][gi] = bi; }
     }
-    if (in) { maxiou[(size_t)n * A + a] = m; rgindex[(size_t)n * A + a] = r; }
+    // provisional status (best anchors are fixed up per image afterwards): 0 ignore, 1 positive, 2 negative (:416-417)
+    const unsigned char st = !in ? 0 : (m > 0.5f ? 1 : (m < 0.4f ? 2 : 0));
+    if (in) { maxiou[(size_t)n * A + a] = m; rgindex[(size_t)n * A + a] = r; status[(size_t)n * A + a] = st; }
+    {
+        const unsigned long long bp = __ballot(st == 1), bn = __ballot(st == 2);
+        if (lane == 0) { blk_pos += __popcll(bp); blk_neg += __popcll(bn); }      // per-wave running counts
+    }
     __syncthreads();
     for (int gi = tid; gi < G; gi += RL_THREADS) {
         float bv = s_wv[0][gi]; int bi = s_wi[0][gi];
@@ -126,58 +138,70 @@ __global__ void __launch_bounds__(RL_THREADS) retina_iou_kernel(
         part_iou[((size_t)n * ntile + tile) * P + gi] = bv;
         part_idx[((size_t)n * ntile + tile) * P + gi] = bi;
     }
+    __syncthreads();
+    }
+    // one atomic per wave at the very end (same-address atomics serialise in L2: keep them few)
+    if (lane == 0) {
+        if (blk_pos) atomicAdd(counts + n * 4 + 0, blk_pos);
+        if (blk_neg) atomicAdd(counts + n * 4 + 1, blk_neg);
+    }
 }
 
-// Pass 2 (one workgroup per image): best anchor per GT = first arg-max over all tiles; status of every anchor:
-// 0 ignore (0.4 <= iou <= 0.5), 1 positive (> 0.5), 2 negative (< 0.4), 3 best anchor of at least one GT.
+// Pass 2 (one workgroup per image): best anchor per GT = first arg-max over all tiles (tiles in ascending order,
+// strict >), then the best anchors leave the "other" set (:397-407): status 3, counts corrected once per DISTINCT
+// best anchor.  counts[n] = {rows of the positive set = G + #(IoU > 0.5 among the others), #negatives, 0, 0}.
 __global__ void __launch_bounds__(RL_THREADS) retina_status_kernel(
     const float* __restrict__ gt, int P, int A, int ntile, const float* __restrict__ part_iou,
     const int* __restrict__ part_idx, const float* __restrict__ maxiou, int* __restrict__ ngt, int* __restrict__ best,
     unsigned char* __restrict__ status, int* __restrict__ counts) {
     __shared__ float s_val[RL_THREADS / 64];
     __shared__ int s_idx[RL_THREADS / 64];
+    __shared__ float s_pv[RL_THREADS / 64];
+    __shared__ int s_pi[RL_THREADS / 64];
     __shared__ int s_best[RL_MAX_GT];
-    __shared__ int s_cnt[2];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_fix[2];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gt_count(gt + (size_t)n * P * 5, P, s_val, s_idx);
-    if (tid < 2) s_cnt[tid] = 0;
-    for (int gi = tid; gi < G; gi += RL_THREADS) {
-        float bv = -2.f; int bi = 0;
-        for (int t = 0; t < ntile; ++t) {
+    if (tid < 2) s_fix[tid] = 0;
+    for (int gi = 0; gi < G; ++gi) {
+        // first arg-max over the tiles: (max value, lowest tile) == lowest anchor index among equal maxima
+        float bv = -2.f; int bt = 0x7fffffff;
+        for (int t = tid; t < ntile; t += RL_THREADS) {
             const float v = part_iou[((size_t)n * ntile + t) * P + gi];
-            if (v > bv) { bv = v; bi = part_idx[((size_t)n * ntile + t) * P + gi]; }     // strict >: lowest tile wins ties
+            if (v > bv) { bv = v; bt = t; }
         }
-        s_best[gi] = bi;
-        best[(size_t)n * P + gi] = bi;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o); const int t2 = __shfl_xor(bt, o);
+            if (v2 > bv || (v2 == bv && t2 < bt)) { bv = v2; bt = t2; }
+        }
+        if (lane == 0) { s_pv[wave] = bv; s_pi[wave] = bt; }
+        __syncthreads();
+        if (tid == 0) {
+            float fv = s_pv[0]; int ft = s_pi[0];
+            for (int w = 1; w < RL_THREADS / 64; ++w)
+                if (s_pv[w] > fv || (s_pv[w] == fv && s_pi[w] < ft)) { fv = s_pv[w]; ft = s_pi[w]; }
+            const int b = part_idx[((size_t)n * ntile + ft) * P + gi];
+            s_best[gi] = b;
+            best[(size_t)n * P + gi] = b;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    int npos = 0, nneg = 0;
-    for (int a = tid; a < A; a += RL_THREADS) {
-        const float m = maxiou[(size_t)n * A + a];
-        unsigned char st = m > 0.5f ? 1 : (m < 0.4f ? 2 : 0);                 // :416-417
-        status[(size_t)n * A + a] = st;
-        npos += st == 1; nneg += st == 2;
-    }
-    for (int o = 32; o > 0; o >>= 1) { npos += __shfl_xor(npos, o); nneg += __shfl_xor(nneg, o); }
-    if ((tid & 63) == 0) { atomicAdd(&s_cnt[0], npos); atomicAdd(&s_cnt[1], nneg); }
-    __syncthreads();
-    // best anchors leave the "other" set (:397-407); every distinct one exactly once
     for (int gi = tid; gi < G; gi += RL_THREADS) {
         const int b = s_best[gi];
         bool first = true;
         for (int k = 0; k < gi; ++k) first = first && s_best[k] != b;
         if (first) {
             const float m = maxiou[(size_t)n * A + b];
-            if (m > 0.5f) atomicSub(&s_cnt[0], 1);
-            else if (m < 0.4f) atomicSub(&s_cnt[1], 1);
+            if (m > 0.5f) atomicAdd(&s_fix[0], 1);
+            else if (m < 0.4f) atomicAdd(&s_fix[1], 1);
         }
+        status[(size_t)n * A + b] = 3;
     }
     __syncthreads();
-    for (int gi = tid; gi < G; gi += RL_THREADS) status[(size_t)n * A + s_best[gi]] = 3;
     if (tid == 0) {
         ngt[n] = G;
-        counts[n * 4 + 0] = G + s_cnt[0];          // rows of the positive set (best rows incl. duplicates + IoU > 0.5)
-        counts[n * 4 + 1] = s_cnt[1];
+        counts[n * 4 + 0] = G + counts[n * 4 + 0] - s_fix[0];
+        counts[n * 4 + 1] = counts[n * 4 + 1] - s_fix[1];
         counts[n * 4 + 2] = 0; counts[n * 4 + 3] = 0;
     }
 }
@@ -192,13 +216,19 @@ struct RLossArgs {
 
 // focal term of one row and its gradient w.r.t. the logits (RetinaNet.py:457-474); `add` accumulates (best rows).
 __device__ __forceinline__ float focal_row(const RLossArgs& a, const float* z, float* dz, int label, float scale, bool add) {
-    float e[RL_MAXC];
-    float m = z[0];
-    for (int c = 1; c < a.C; ++c) m = fmaxf(m, z[c]);
-    float s = 0.f;
-    for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - m); s += e[c]; }
+    float e[RL_MAXC];                                   // fully unrolled below: stays in registers
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < RL_MAXC; ++c) { e[c] = c < a.C ? z[c] : -INFINITY; m = fmaxf(m, e[c]); }
+    float s = 0.f, el = 0.f;
+#pragma unroll
+    for (int c = 0; c < RL_MAXC; ++c) {
+        e[c] = c < a.C ? expf(e[c] - m) : 0.f;
+        s += e[c];
+        el = c == label ? e[c] : el;
+    }
     const float inv = 1.f / s;
-    const float pu = e[label] * inv;
+    const float pu = el * inv;
     const float pt = fminf(fmaxf(pu, 1e-8f), 1.f);
     const float om = 1.f - pt;
     const float lg = logf(pt);
@@ -207,9 +237,12 @@ __device__ __forceinline__ float focal_row(const RLossArgs& a, const float* z, f
     float dpt = 0.f;
     if (pu >= 1e-8f) dpt = a.alpha * (a.gamma * powf(om, a.gamma - 1.f) * lg - powf(om, a.gamma) / pt);
     const float k = dpt * pu * scale;
-    for (int c = 0; c < a.C; ++c) {
-        const float g = k * ((c == label ? 1.f : 0.f) - e[c] * inv);
-        if (add) atomicAdd(dz + c, g); else dz[c] = g;
+#pragma unroll
+    for (int c = 0; c < RL_MAXC; ++c) {
+        if (c < a.C) {
+            const float g = k * ((c == label ? 1.f : 0.f) - e[c] * inv);
+            if (add) atomicAdd(dz + c, g); else dz[c] = g;
+        }
     }
     return loss;
 }
@@ -230,33 +263,72 @@ __device__ __forceinline__ float box_row(const RLossArgs& a, int n, int anchor, 
     return sum;
 }
 
+// One thread per anchor row; the 256 x C logits of a workgroup (and the gradients on the way out) move through
+// LDS so that global accesses are contiguous 16-byte-per-lane streams instead of 64 lanes x (84-byte stride).
+// Row pitch C (odd for 21 classes) keeps the per-lane LDS walks conflict-free.
 __global__ void __launch_bounds__(RL_THREADS) retina_loss_kernel(const RLossArgs a) {
     __shared__ float s_red[2][RL_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) float s_z[RL_THREADS * RL_MAXC];
     const int n = blockIdx.y, tid = threadIdx.x;
     const int num_pos = a.counts[n * 4 + 0];
     const float inv_np = 1.f / (float)num_pos;
     const float gs = a.grad_scale * inv_np;
     float conf = 0.f, coord = 0.f;
-    const int an = blockIdx.x * RL_THREADS + tid;
-    if (an < a.A) {
+    const int ntile = (a.A + RL_THREADS - 1) / RL_THREADS;
+    for (int tile = blockIdx.x * RL_LOSS_TILES; tile < ntile && tile < (int)(blockIdx.x + 1) * RL_LOSS_TILES; ++tile) {
+    const int a0 = tile * RL_THREADS;
+    const int rows = min(RL_THREADS, a.A - a0);
+    const size_t base = ((size_t)n * a.A + a0) * a.C;
+    const int nflt = rows * a.C;
+    // global side: 16-byte accesses from the first aligned element (the row pitch C = 21 floats makes `base` land on
+    // any 4-byte phase), scalar head / tail; LDS side: scalar (the LDS image keeps the global phase)
+    const int head = min(nflt, (int)((4 - (base & 3)) & 3));
+    const int nvec = (nflt - head) / 4;
+    const int tail0 = head + nvec * 4;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.pconf + base + head);
+        for (int i = tid; i < nvec; i += RL_THREADS) {
+            const float4 v = src[i];
+            float* d = s_z + head + 4 * i;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        if (tid < head) s_z[tid] = a.pconf[base + tid];
+        if (tid < nflt - tail0) s_z[tail0 + tid] = a.pconf[base + tail0 + tid];
+    }
+    __syncthreads();
+    const int an = a0 + tid;
+    if (tid < rows) {
         const size_t row = (size_t)n * a.A + an;
-        const float* z = a.pconf + row * a.C;
-        float* dz = a.dconf + row * a.C;
+        float* z = s_z + tid * a.C;                 // logits in, gradient out (in place)
         const float* pb = a.pbox + row * 4;
-        float* db = a.dbox + row * 4;
+        float4 dbv = make_float4(0.f, 0.f, 0.f, 0.f);
         const unsigned char st = a.status[row];
         if (st == 1) {
             const int g = a.rgindex[row];
             const int label = (int)a.gt[((size_t)n * a.P + g) * 5 + 4];
-            conf += focal_row(a, z, dz, label, gs, false);
+            conf += focal_row(a, z, z, label, gs, false);
+            float db[4];
             coord += box_row(a, n, an, g, pb, db, gs, false);
+            dbv = make_float4(db[0], db[1], db[2], db[3]);
         } else if (st == 2) {
-            conf += focal_row(a, z, dz, a.C - 1, gs, false);
-            for (int k = 0; k < 4; ++k) db[k] = 0.f;
-        } else {                                   // ignore band, or a best anchor (its rows are added below)
-            for (int c = 0; c < a.C; ++c) dz[c] = 0.f;
-            for (int k = 0; k < 4; ++k) db[k] = 0.f;
+            conf += focal_row(a, z, z, a.C - 1, gs, false);
+        } else {                                   // ignore band, or a best anchor (its rows are added afterwards)
+            for (int c = 0; c < a.C; ++c) z[c] = 0.f;
         }
+        *reinterpret_cast<float4*>(a.dbox + row * 4) = dbv;
+    }
+    __syncthreads();
+    // stage out
+    {
+        float4* dst = reinterpret_cast<float4*>(a.dconf + base + head);
+        for (int i = tid; i < nvec; i += RL_THREADS) {
+            const float* s = s_z + head + 4 * i;
+            dst[i] = make_float4(s[0], s[1], s[2], s[3]);
+        }
+        if (tid < head) a.dconf[base + tid] = s_z[tid];
+        if (tid < nflt - tail0) a.dconf[base + tail0 + tid] = s_z[tail0 + tid];
+    }
+    __syncthreads();
     }
     for (int o = 32; o > 0; o >>= 1) { conf += __shfl_xor(conf, o); coord += __shfl_xor(coord, o); }
     if ((tid & 63) == 0) { s_red[0][tid >> 6] = conf; s_red[1][tid >> 6] = coord; }
@@ -330,8 +402,9 @@ extern "C" int odtk_retina_match(const float* y1x1, const float* y2x2, const flo
     float* part_iou = maxiou + (size_t)N * A;
     int* part_idx = (int*)(part_iou + (size_t)N * ntile * P);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(retina_iou_kernel, dim3(ntile, N), dim3(RL_THREADS), 0, st, y1x1, y2x2, hw, A, gt, P, maxiou, rgindex,
-                       part_iou, part_idx);
+    ODTK_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)N * 4 * sizeof(int), st));
+    hipLaunchKernelGGL(retina_iou_kernel, dim3(ceil_div(ntile, RL_TILES_PER_BLOCK), N), dim3(RL_THREADS), 0, st, y1x1, y2x2, hw, A, gt, P, maxiou, rgindex,
+                       part_iou, part_idx, status, counts);
     hipLaunchKernelGGL(retina_status_kernel, dim3(N), dim3(RL_THREADS), 0, st, gt, P, A, ntile, part_iou, part_idx, maxiou,
                        ngt, best, status, counts);
     ODTK_LAUNCH_CHECK();
@@ -351,7 +424,7 @@ extern "C" int odtk_retina_loss(const float* pconf, const float* pbox, int N, in
     a.pconf = pconf; a.pbox = pbox; a.N = N; a.A = A; a.C = C; a.yx = yx; a.hw = hw; a.gt = gt; a.P = P;
     a.ngt = ngt; a.best = best; a.status = status; a.rgindex = rgindex; a.counts = counts;
     a.alpha = alpha; a.gamma = gamma; a.grad_scale = grad_scale; a.loss_parts = loss_parts; a.dconf = dconf; a.dbox = dbox;
-    hipLaunchKernelGGL(retina_loss_kernel, dim3(ceil_div(A, RL_THREADS), N), dim3(RL_THREADS), 0, st, a);
+    hipLaunchKernelGGL(retina_loss_kernel, dim3(ceil_div(ceil_div(A, RL_THREADS), RL_LOSS_TILES), N), dim3(RL_THREADS), 0, st, a);
     hipLaunchKernelGGL(retina_best_rows_kernel, dim3(N), dim3(RL_MAX_GT), 0, st, a);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;

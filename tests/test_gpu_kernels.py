@@ -225,7 +225,8 @@ def test_maxpool(geom, dt, dev):
 
 @pytest.mark.parametrize("dt,ydt", [("f32", "f32"), ("bf16", "bf16"), ("bf16", "f32")])
 @pytest.mark.parametrize("shape", [(2 * 19 * 19, 1024, True), (2 * 38 * 38, 100, False), (3 * 5 * 5, 150, False),
-                                   (2 * 3 * 3, 256, True)])
+                                   (2 * 3 * 3, 256, True),
+                                   (6 * 38 * 38, 100, False), (14 * 19 * 19, 256, True)])   # M > 4096: split-row path
 def test_batchnorm(shape, dt, ydt, dev):
     ops = _ops()
     M, C, relu = shape

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libodtk.so")
+LIB_PATH = os.environ.get("ODTK_LIB") or os.path.join(_HERE, "libodtk.so")     # ODTK_LIB: A/B builds of the kernels (tools/)
 
 BF16 = 0
 F32 = 1

@@ -10,6 +10,17 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
 typedef __attribute__((ext_vector_type(16))) float f32x16_v;
 typedef __attribute__((ext_vector_type(4))) short v4i16_v;
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>) -- for bodies whose index must fold
+// (register-array indices, instruction-offset immediates) even where the loop unroller gives up
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 struct FastDiv {
     unsigned mul, shift;
 };
@@ -171,6 +182,11 @@ __device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned
                  : "v"(voff), "s"(lds_addr), "s"(rsrc)
                  : "memory");
 }
+// same, without the compiler-level memory clobber: for kernels that pin the instruction order themselves
+// (sched_barrier) and fence LDS visibility with explicit s_waitcnt vmcnt + s_barrier
+__device__ __forceinline__ void glds16_buf_nc(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(lds_addr), "s"(rsrc));
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
@@ -181,6 +197,12 @@ __device__ __forceinline__ uint2 lds_tr16(unsigned lds_byte_addr) {
     const v4i16_v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) v4i16_v*)(uintptr_t)lds_byte_addr);
     return __builtin_bit_cast(uint2, v);
+}
+
+// acc + lo(v) + hi(v) of a packed bf16 pair in ONE VALU op (v_dot2c_f32_bf16 against (1, 1))
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16_ones(unsigned v, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_v, v), __builtin_bit_cast(bf16x2_v, 0x3f803f80u), acc, false);
 }
 
 // ---- bf16 pack helpers -----------------------------------------------------------------
@@ -228,6 +250,8 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st);
 int launch_gather_v4(GatherArgs& a, hipStream_t st);   // persistent, loader/compute wave-specialised
 bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype);   // resident-filter 64->64 3x3 kernel
 int launch_gather_c64(GatherArgs& a, hipStream_t st);
+bool wgrad_c64_supported(const WgradArgs& a, int dtype);                      // halo-patch 64->64 3x3 wgrad
+int launch_wgrad_c64(WgradArgs& a, hipStream_t st);
 bool wgrad_v3_supported(const WgradArgs& a, int dtype);
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
 

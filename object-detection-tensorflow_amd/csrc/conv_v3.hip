@@ -889,6 +889,201 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// wgrad of the 3x3 / stride 1 / pad 1, 64 -> 64 convolution (conv1_2: 2.9 M pixels, dW is only 64 x 576):
+//   dW[k][tap][c] += sum_px dy[px][k] * x[px + tap][c]
+// The generic wgrad kernels gather x once per tap and waste half of their 128-row tile on K = 64.  Here a
+// persistent 4-wave workgroup per CU walks 8 x 32-pixel tiles: the dy tile (256 px x 128 B) and the 10 x 34 halo
+// patch of x are LDS-DMA'd ONCE per tile (double buffered, out-of-image pixels zero-filled by the range check) and
+// all nine taps read the patch at shifted positions.  Both operands stay [pixel][channel]; MFMA fragments come from
+// ds_read_b64_tr_b16; chunk ^ (((pixel >> 1) & 1) << 2) makes the four pixel rows of a transpose read hit distinct
+// bank quarters for ANY start pixel.  The 64 x 576 result = 2 x 18 MFMA tiles: wave w keeps output channels
+// 32*(w & 1).. x input channels 32*(w >> 1).. of all nine taps (144 accumulator registers) over the whole tile walk,
+// 144 MFMAs per tile, one barrier per tile, and adds it to dW with float atomics once at the end.  Bias gradient fused.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a, const int tiles_r, const int tiles_c,
+                                                              const int total_tiles, const FastDiv div_tpi, const FastDiv div_tc) {
+    constexpr int PW = 34, PPX = 340, NPX = 44, NPD = 32;          // patch (43 + 1 pad -> 11 per wave) / dy-tile DMA pieces (8 px x 128 B)
+    constexpr int DBUF = NPD * 1024, XBUF = NPX * 1024, STAGE = DBUF + XBUF;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = wave & 1, ch_half = wave >> 1;                  // 32 output channels x 32 input channels, all 9 taps
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
+    const int grid = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, grid);
+    const int my_tiles = slot < total_tiles ? (total_tiles - slot + grid - 1) / grid : 0;
+    if (my_tiles == 0) return;
+    const int tiles_per_img = tiles_r * tiles_c;
+    auto decode = [&](int v, int& n, int& h0, int& w0) __attribute__((always_inline)) {
+        n = (int)fdiv((unsigned)v, div_tpi);
+        const int rem = v - n * tiles_per_img;
+        const int tr = (int)fdiv((unsigned)rem, div_tc);
+        h0 = tr * 8; w0 = (rem - tr * tiles_c) * 32;
+    };
+    // ---- LDS-DMA pieces.  Wave w issues 19 per tile: step s < 8 -> dy tile row s, columns 8w..8w+7; step 8 + t ->
+    // patch piece j = w + 4t (patch pixels 8j..8j+7, row-major over the 10 x 34 patch).  Everything that depends
+    // on the lane only is hoisted (source offset relative to the tile origin, patch row / column); per piece the
+    // loop then spends ~8 VALU on the image-border test and a select -- no branches, so the tile body is ONE
+    // scheduling region and the DMA issue can be placed between MFMAs.
+    const int sub = lane >> 3;
+    const int lc16 = ((lane & 7) ^ (((sub >> 1) & 1) << 2)) * 16;
+    const int dy_col = wave * 8 + sub;
+    const int dy_rel = dy_col * 128 + lc16;
+    int x_rel[11], x_prc[11];
+    static_for<11>([&](auto TT) __attribute__((always_inline)) {
+        constexpr int tt = decltype(TT)::value;
+        const int px = (wave + 4 * tt) * 8 + sub;
+        const int pr = px / PW, pc = px - pr * PW;
+        x_rel[tt] = (pr * a.W + pc) * 128 + lc16;
+        x_prc[tt] = (px < PPX ? pr : 0x7FFF) | (pc << 16);
+    });
+    auto dma_off = [&](int s, int n, int h0, int w0, bool en) __attribute__((always_inline)) -> unsigned {
+        if (s < 8) {
+            const int base = ((n * a.H + h0 + s) * a.W + w0) * 128;
+            const bool ok = en && (h0 + s < a.H) && (w0 + dy_col < a.W);
+            const unsigned addr = (unsigned)(base + dy_rel);
+            return ok ? addr : 0xFFFFFFF0u;
+        } else {
+            const int tt = s - 8;
+            const int base = ((n * a.H + h0 - 1) * a.W + w0 - 1) * 128;
+            const int h = (x_prc[tt] & 0xFFFF) + h0 - 1, w = (x_prc[tt] >> 16) + w0 - 1;
+            const bool ok = en && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            const unsigned addr = (unsigned)(base + x_rel[tt]);
+            return ok ? addr : 0xFFFFFFF0u;
+        }
+    };
+    auto dma_issue = [&](int s, unsigned voff, int buf) __attribute__((always_inline)) {
+        const unsigned dst = smem_base + (unsigned)(buf * STAGE);
+        if (s < 8) glds16_buf_nc(rdy, voff, dst + (unsigned)(wave + 4 * s) * 1024u);
+        else glds16_buf_nc(rx, voff, dst + (unsigned)DBUF + (unsigned)(wave + 4 * (s - 8)) * 1024u);
+    };
+    int tn, th0, tw0;
+    decode(slot, tn, th0, tw0);
+    static_for<19>([&](auto S) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        dma_issue(s, dma_off(s, tn, th0, tw0, true), 0);
+    });
+
+    // transpose-read lane role: group g = lane >> 4 -> channel sub-block 16*(g&1), k half g >> 1 (= hi);
+    // lane c = lane & 15 addresses pixel (c >> 2) of a 4-pixel group and the 8-byte quarter (c & 3) of a 32-byte span
+    const int g = lane >> 4, c16 = lane & 15;
+    const int rr = c16 >> 2;
+    const int sub8 = (16 * (g & 1)) * 2 + (c16 & 3) * 8;           // byte offset of this lane's 4 channels inside a 64-B span
+    // Per-lane LDS byte offsets, hoisted out of the loop: a fragment read addresses pixel (constant + 8*hi + rr) and
+    // the swizzle bit ((pixel >> 1) & 1) only depends on (constant & 3) + rr, so four offsets cover every patch
+    // position (one covers the dy tile, whose constants are multiples of 4); the constant * 128 bytes fold into the
+    // ds_read offset field -> no address arithmetic inside the tile loop.
+    const int lp = 8 * hi + rr;
+    auto lane_off = [&](int cb32, int m) __attribute__((always_inline)) {
+        const int byte = cb32 * 2 + sub8;
+        return lp * 128 + (((byte >> 4) ^ ((((m + rr) >> 1) & 1) << 2)) << 4) + (byte & 8);
+    };
+    const unsigned poff = (unsigned)lane_off(kb * 32, 0);
+    unsigned qoff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) qoff[m] = (unsigned)lane_off(ch_half * 32, m);
+
+    f32x16_v acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const bool do_bias = a.dbias != nullptr && ch_half == 0;
+    float bsum = 0.f;
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int buf = it & 1;
+        const bool has_next = it + 1 < my_tiles;
+        int nn, nh0, nw0;
+        decode(has_next ? slot + (it + 1) * grid : slot, nn, nh0, nw0);
+        wait_vmcnt<0>();            // my pieces of tile `it` landed
+        block_barrier();            // ... everybody's; everybody is done with tile it-1 (buffer buf ^ 1 is free)
+        const unsigned sD = smem_base + (unsigned)(buf * STAGE), sX = sD + DBUF;
+        const unsigned pbase = sD + poff;
+        unsigned qbase[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) qbase[m] = sX + qoff[m];
+        // A patch row rho serves the taps dr = 0..2 of the tile rows rho - dr, so its three (ds) fragments are read
+        // once and meet a rolling window of dy-row fragments: 76 fragment reads (152 ds_read_b64_tr_b16) per 144
+        // MFMAs.  Step s = half * 10 + rho (half = 16-pixel half of the 32-pixel tile row).  One wave per SIMD: an
+        // MFMA only overlaps what this wave issues in its 32-cycle shadow, so the reads of step s + 1, the DMA
+        // piece of step s and the bias adds are dealt out BETWEEN the MFMAs by hand (sched_barrier pins the order).
+        uint2 plo[4], phi[4], qlo[2][3], qhi[2][3];
+        // read #i of the fragment set of step s: 0..1 = dy row (needed first), 2..7 = patch (ds = (i-2) >> 1); odd i = pixels +4
+        auto rd = [&](int s, int i) __attribute__((always_inline)) {
+            const int half = s / 10, rho = s - half * 10;
+            if (i >= 2) {
+                const int ds = (i - 2) >> 1;
+                const unsigned cpx = (unsigned)(rho * PW + half * 16 + ds);
+                const uint2 v = lds_tr16(qbase[cpx & 3u] + (cpx + ((i & 1) ? 4u : 0u)) * 128u);
+                if (i & 1) qhi[s & 1][ds] = v; else qlo[s & 1][ds] = v;
+            } else if (rho < 8) {
+                const unsigned cpx = (unsigned)(rho * 32 + half * 16);
+                const uint2 v = lds_tr16(pbase + (cpx + ((i & 1) ? 4u : 0u)) * 128u);
+                if (i & 1) phi[rho & 3] = v; else plo[rho & 3] = v;
+            }
+        };
+        static_for<8>([&](auto I) __attribute__((always_inline)) { rd(0, decltype(I)::value); });
+        static_for<20>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            constexpr int rho = s % 10;
+            const int nm = 3 * ((rho >= 2 ? 3 : rho + 1) - (rho >= 8 ? rho - 7 : 0));      // MFMAs of this step: 3, 6 or 9
+            const int dr_lo = rho >= 8 ? rho - 7 : 0, dr_hi = rho >= 2 ? 2 : rho;
+            unsigned voff = 0, voff2 = 0;
+#pragma unroll
+            for (int dr = 0; dr < 3; ++dr) {
+                const int r = rho - dr;
+                if (dr < dr_lo || dr > dr_hi) continue;
+#pragma unroll
+                for (int ds = 0; ds < 3; ++ds) {
+                    const int mi = (dr - dr_lo) * 3 + ds;
+                    const uint4 pf = make_uint4(plo[r & 3].x, plo[r & 3].y, phi[r & 3].x, phi[r & 3].y);
+                    const uint4 qf = make_uint4(qlo[s & 1][ds].x, qlo[s & 1][ds].y, qhi[s & 1][ds].x, qhi[s & 1][ds].y);
+                    Mma<bf16_t>::run(pf, qf, acc[dr * 3 + ds]);
+                    if (s < 19) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (i >= (8 * mi + nm - 1) / nm && i < (8 * (mi + 1) + nm - 1) / nm) rd(s + 1, i);
+                        // next tile's 19 pieces go out in steps 0..9 (two per step) so that even the last one has half a
+                        // tile of MFMAs to cover its memory latency; last tile: zero-fills the idle buffer
+                        if (s < 10) {
+                            if (mi == 0) voff = dma_off(2 * s, nn, nh0, nw0, has_next);
+                            if (mi == 1) dma_issue(2 * s, voff, buf ^ 1);
+                            if (2 * s + 1 < 19) {
+                                if (mi == 1) voff2 = dma_off(2 * s + 1, nn, nh0, nw0, has_next);
+                                if (mi == 2) dma_issue(2 * s + 1, voff2, buf ^ 1);
+                            }
+                        }
+                    }
+                    if (dr == 0 && ds == 2) {             // bias gradient, once per dy fragment (every wave: branch-free)
+                        const unsigned d[4] = {pf.x, pf.y, pf.z, pf.w};
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) bsum = dot2_bf16_ones(d[h], bsum);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        });
+    }
+    // ---- dW (+)= : rows k = kb*32 + 8*(e>>2) + 4*hi + (e&3), column = tap*64 + ch_half*32 + l31
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int col = j * 64 + ch_half * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = kb * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+            atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[j][e]);
+        }
+    }
+    if (do_bias) {
+        const float tsum = bsum + __shfl_xor(bsum, 32);           // both k halves
+        if (hi == 0) atomicAdd(a.dbias + kb * 32 + l31, tsum);
+    }
+}
+
 }  // namespace
 
 static int g_num_cu = 0;
@@ -949,6 +1144,24 @@ int launch_gather_c64(GatherArgs& a, hipStream_t st) {
     const int tiles = a.N * tr * tc;
     const int grid = tiles < g_num_cu ? tiles : g_num_cu;
     hipLaunchKernelGGL(conv3x3_c64k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles);
+    return 0;
+}
+
+bool wgrad_c64_supported(const WgradArgs& a, int dtype) {
+    return dtype == ODTK_BF16 && a.C == 64 && a.ldx == 64 && a.K == 64 && a.lddy == 64 && a.R == 3 && a.S == 3 && a.dil == 1 &&
+           a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo && a.RSC == 576 &&
+           (long long)a.N * a.H * a.W * 64 * 2 < (1ll << 31);
+}
+
+int launch_wgrad_c64(WgradArgs& a, hipStream_t st) {
+    if (g_num_cu == 0) query_num_cu();
+    const int tr = ceil_div(a.H, 8), tc = ceil_div(a.W, 32);
+    const int tiles = a.N * tr * tc;
+    const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
+    a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    hipLaunchKernelGGL(wgrad3x3_c64k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)),
+                       make_fastdiv((unsigned)tc));
     return 0;
 }
 

@@ -13,6 +13,7 @@ from odtk import ops
 LAYERS = {  # name: (N, H, C, K, k, stride, dil)   (C = padded input channels)
     'conv1_1': (32, 300, 8, 64, 3, 1, 1),
     'conv1_2': (32, 300, 64, 64, 3, 1, 1),
+    'conv1_2s': (4, 300, 64, 64, 3, 1, 1),
     'conv2_1': (32, 150, 64, 128, 3, 1, 1),
     'conv2_2': (32, 150, 128, 128, 3, 1, 1),
     'conv3_1': (32, 75, 128, 256, 3, 1, 1),

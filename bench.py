@@ -81,17 +81,29 @@ class ConvTimer:
             s.record()
             r = orig(d, *args)
             e.record()
-            self.records.append((kind, self.ops.conv_last_kernel(), flops, s, e, abytes))
+            self.records.append((kind, self.ops.conv_last_kernel(), flops, s, e, abytes,
+                                 (d.N, d.H, d.W, d.C, d.K, d.R, d.stride, d.dil)))
             return r
         return f
 
     def summary(self):
         per_kernel, per_pass = {}, {}
-        for kind, kern, fl, s, e, ab in self.records:
+        for kind, kern, fl, s, e, ab, _ in self.records:
             t = s.elapsed_time(e) * 1e-3
             for d, k in ((per_kernel, kern), (per_pass, kind)):
                 a = d.setdefault(k, [0.0, 0.0, 0, 0.0]); a[0] += fl; a[1] += t; a[2] += 1; a[3] += ab
         return per_kernel, per_pass
+
+    def table(self):
+        """Per-layer rows (pass, kernel, shape, launches, mean us, TFLOP/s), slowest first."""
+        agg = {}
+        for kind, kern, fl, s, e, ab, shp in self.records:
+            a = agg.setdefault((kind, kern, shp), [0.0, 0.0, 0])
+            a[0] += fl; a[1] += s.elapsed_time(e) * 1e-3; a[2] += 1
+        rows = ['%-13s %-28s N%d H%d W%d C%d K%d k%d s%d d%d  x%d  %8.1f us  %7.1f TF' %
+                (k[0], k[1], *k[2], v[2], v[1] / v[2] * 1e6, v[0] / v[1] / 1e12)
+                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1] / kv[1][2])]
+        return '\n'.join(rows)
 
     def roofline(self, steps, peak, whole_step_frac):
         per_kernel, per_pass = self.summary()
@@ -148,6 +160,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region')
+    ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -241,6 +254,9 @@ def main():
         peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
         if timer.records:
             out['roofline'] = timer.roofline(min(args.steps, 5), peak, value / world * 188.0e9 / peak)
+            if args.conv_table:
+                with open(args.conv_table, 'w') as f:
+                    f.write(timer.table() + '\n')
             out['roofline']['measured_on'] = (f'{min(args.steps, 5)} eager steps right after the timed region '
                                               '(HIP events per conv launch on the launch stream)')
         if world == 1 and not args.no_cpu_baseline:

@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 // ---------------------------------------------------------------------------------------
 // gather kernel (forward conv, stride-1 dgrad)
 // ---------------------------------------------------------------------------------------
-template <int PT, bool DB, bool EARLY, bool BUF>
+template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false>
 __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
     constexpr int QT = 256;
     constexpr int PI = PT / 64, QI = 2, PL = PT / 64;
@@ -129,13 +129,21 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
             const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HoWo;
             const int ho = (int)fdiv((unsigned)rem, a.div_wo), wo = rem - ho * a.Wo;
             const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
-            qoff[i] = ((long long)(n * a.H + hb) * a.W + wb) * a.ldx * 2ll;
-            qoff32[i] = (unsigned)(((n * a.H + hb) * a.W + wb) * a.ldx * 2);     // may wrap below 0: only used with in-range taps
+            // stride-2 dgrad (idiv == 2, dil == 1): tap r reads dy row (hb + r) / 2 when that is an integer
+            // = (hb >> 1) + ((r + 1) >> 1) for every parity-matching r, so the "base + tap offset" form survives
+            // with the halved base and tap steps ((r + 1) >> 1); mismatching taps are masked like padding
+            const int hq = a.idiv == 2 ? hb >> 1 : hb, wq = a.idiv == 2 ? wb >> 1 : wb;
+            qoff[i] = ((long long)(n * a.H + hq) * a.W + wq) * a.ldx * 2ll;
+            qoff32[i] = (unsigned)(((n * a.H + hq) * a.W + wq) * a.ldx * 2);     // may wrap below 0: only used with in-range taps
             unsigned rm = 0, cm = 0;
-            for (int r = 0; r < a.R; ++r)
-                if ((unsigned)(hb + r * a.dil) < (unsigned)a.H) rm |= 1u << r;
-            for (int s2 = 0; s2 < a.S; ++s2)
-                if ((unsigned)(wb + s2 * a.dil) < (unsigned)a.W) cm |= 1u << s2;
+            for (int r = 0; r < a.R; ++r) {
+                const int hn = hb + r * a.dil;
+                if (a.idiv == 2 ? (hn >= 0 && !(hn & 1) && (hn >> 1) < a.H) : (unsigned)hn < (unsigned)a.H) rm |= 1u << r;
+            }
+            for (int s2 = 0; s2 < a.S; ++s2) {
+                const int wn = wb + s2 * a.dil;
+                if (a.idiv == 2 ? (wn >= 0 && !(wn & 1) && (wn >> 1) < a.W) : (unsigned)wn < (unsigned)a.W) cm |= 1u << s2;
+            }
             unsigned mk = 0;
             for (int r = 0; r < a.R; ++r)
                 if ((rm >> r) & 1u) mk |= cm << (r * a.S);
@@ -161,15 +169,48 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         ks = rs - kr * a.S;
     }
 
+    // C64 (C % 64 == 0, buffer addressing): a k-slab never straddles a tap, so the tap walk is wave-uniform
+    // (SALU) and a piece costs this lane an AND, a compare, an add and a select.
+    int s_kc = 0, s_ks = 0, s_kr = 0, s_klin = 0;
+    if (C64) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qoff32[i] += (unsigned)(cc * 16);
+#pragma unroll
+        for (int i = 0; i < PL; ++i) poff32[i] += (unsigned)(cc * 16);
+    }
     auto issue = [&](int stage) {
         const unsigned sP = smem_base + (unsigned)stage * STAGE + wave_u * 1024u;
         const unsigned sQ = sP + PT * 128;
+        if (C64) {
+            const int sr = a.idiv == 2 ? (s_kr + 1) >> 1 : s_kr * a.dil, ss = a.idiv == 2 ? (s_ks + 1) >> 1 : s_ks * a.dil;
+            const unsigned toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + s_kc * 2);
+            const unsigned tapbit = 1u << (s_kr * a.S + s_ks);
+            const unsigned woff = (unsigned)(s_klin * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned addr = qoff32[i] + toff32;
+                glds16_buf(rx, (qmask[i] & tapbit) ? addr : 0xFFFFFFF0u, sQ + i * 8192u);
+            }
+#pragma unroll
+            for (int i = 0; i < PL; ++i) {
+                const unsigned addr = poff32[i] + woff;
+                glds16_buf(rw, pok[i] ? addr : 0xFFFFFFF0u, sP + i * 8192u);
+            }
+            s_klin += 64;
+            s_kc += 64;
+            if (s_kc >= a.C) {
+                s_kc = 0;
+                if (++s_ks == a.S) { s_ks = 0; ++s_kr; }
+            }
+            return;
+        }
         const bool kv = kr < a.R;
         const int tap = kr * a.S + ks;
-        const long long toff = ((long long)(kr * a.dil) * a.W + ks * a.dil) * a.ldx * 2ll + (long long)kc * 2ll;
+        const int tr = a.idiv == 2 ? (kr + 1) >> 1 : kr * a.dil, ts = a.idiv == 2 ? (ks + 1) >> 1 : ks * a.dil;
+        const long long toff = ((long long)tr * a.W + ts) * a.ldx * 2ll + (long long)kc * 2ll;
         const bool first = klin < 64;
         if (BUF) {
-            const unsigned toff32 = (unsigned)(((kr * a.dil) * a.W + ks * a.dil) * a.ldx * 2 + kc * 2);
+            const unsigned toff32 = (unsigned)((tr * a.W + ts) * a.ldx * 2 + kc * 2);
             const unsigned tapbit = kv ? (1u << tap) : 0u;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -1095,7 +1136,7 @@ static void query_num_cu() {
 }
 
 bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype) {
-    return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && a.idiv == 1 && a.R * a.S <= 32 && a.ldy % 8 == 0 &&
+    return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && (a.idiv == 1 || (a.idiv == 2 && a.dil == 1)) && a.R * a.S <= 32 && a.ldy % 8 == 0 &&
            (a.mask == nullptr || a.ldmask % 8 == 0) && a.ldx % 8 == 0 && a.C % 8 == 0;
 }
 
@@ -1107,9 +1148,11 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     const bool db = (a.dbg & 32) == 0;      // fragment double buffering (default on; dbg bit 5 turns it off)
     const bool early = (a.dbg & 128) != 0;  // "landed one slab early" protocol (dbg bit 7, A/B)
     const bool buf = (a.dbg & 256) == 0;    // buffer-addressed DMA (default on; dbg bit 8 = 64-bit global addressing, A/B)
+    const bool c64 = a.C % 64 == 0 && a.Kdim % 64 == 0 && (a.dbg & 4096) == 0;   // wave-uniform tap walk (dbg bit 12 = per-lane walk, A/B)
 #define ODTK_V3(PT_) \
     do { \
-        if (buf) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, true>), dim3(grid), dim3(512), 0, st, a); \
+        if (buf && c64) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, true, true>), dim3(grid), dim3(512), 0, st, a); \
+        else if (buf) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, true>), dim3(grid), dim3(512), 0, st, a); \
         else if (early) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, true, false>), dim3(grid), dim3(512), 0, st, a); \
         else if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, false>), dim3(grid), dim3(512), 0, st, a); \
         else hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, false, false, false>), dim3(grid), dim3(512), 0, st, a); \

@@ -27,6 +27,15 @@ LAYERS = {  # name: (N, H, C, K, k, stride, dil)   (C = padded input channels)
     'conv8_2': (32, 19, 256, 512, 3, 2, 1),
     'pred1': (32, 38, 512, 100, 3, 1, 1),
     'pred2': (32, 19, 1024, 150, 3, 1, 1),
+    'pred3': (32, 10, 512, 150, 3, 1, 1),
+    'pred4': (32, 5, 256, 150, 3, 1, 1),
+    'pred5': (32, 5, 256, 100, 3, 1, 1),
+    'pred6': (32, 3, 256, 100, 3, 1, 1),
+    'conv9_1': (32, 10, 512, 128, 1, 1, 1),
+    'conv9_2': (32, 10, 128, 256, 3, 2, 1),
+    'conv10_1': (32, 5, 256, 128, 1, 1, 1),
+    'conv10_2': (32, 5, 128, 256, 3, 1, 1),
+    'conv10_2s': (32, 5, 128, 256, 3, 2, 1),
 }
 which = list(LAYERS) if len(sys.argv) < 2 or sys.argv[1] == 'all' else sys.argv[1].split(',')
 passes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fwd', 'dgrad', 'wgrad']
@@ -55,8 +64,6 @@ for name in which:
            'dgrad': lambda: ops.conv2d_dgrad(desc, dy, Kp, wt, x, dx, False),
            'wgrad': lambda: ops.conv2d_wgrad(desc, x, dy, Kp, dw, bias)}
     for p in passes:
-        if p == 'dgrad' and s != 1:
-            continue
         f = fns[p]
         line = f'{name:8s} {p:6s}'
         for mode in modes:

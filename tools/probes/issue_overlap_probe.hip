@@ -8,7 +8,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int KIND, int K, int NW>
+template <int KIND, int K, int NW, bool STREAM>
 __global__ void __launch_bounds__(NW * 64) probe(const char* src, unsigned nbytes, int iters, float* out) {
     __shared__ __attribute__((aligned(16))) char smem[64 * 1024];
     for (int i = threadIdx.x; i < 16 * 1024; i += NW * 64) reinterpret_cast<unsigned*>(smem)[i] = 0x3f803f80u;
@@ -37,11 +37,14 @@ __global__ void __launch_bounds__(NW * 64) probe(const char* src, unsigned nbyte
                 if (KIND == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r4[k & 7]) : "v"(la), "n"((k & 7) * 1024));
                 if (KIND == 3) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(ldma), "s"(rs));
                 if (KIND == 4) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
+                if ((KIND == 6 && j == 0) || (KIND == 7 && (j & 1) == 0) || (KIND == 8 && j == 0 && (it & 1) == 0))
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(ldma), "s"(rs));
                 if (KIND == 5) asm volatile("v_cmp_gt_u32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_add_u32 %0, %0, %1" : "+v"(voff) : "v"(lane) : "vcc");
             }
         }
         if (KIND == 1 || KIND == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (KIND == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (KIND >= 6) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); if (STREAM) { voff += 256u * 4u * 4096u; if (voff >= nbytes - 4096u) voff -= (nbytes - 4096u) & ~0xFFFu; } }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     float s = f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + (float)sacc;
@@ -50,14 +53,14 @@ __global__ void __launch_bounds__(NW * 64) probe(const char* src, unsigned nbyte
     if (KIND == 2) for (int k = 0; k < 8; ++k) s += (float)r4[k].x;
     out[blockIdx.x * NW * 64 + threadIdx.x] = s + (float)voff;
 }
-template <int KIND, int K, int NW = 4>
+template <int KIND, int K, int NW = 4, bool STREAM = false>
 void run(const char* src, unsigned nbytes, float* out, const char* label) {
     const int iters = 4000, grid = 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int r = 0; r < 3; ++r) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((probe<KIND, K, NW>), dim3(grid), dim3(NW * 64), 0, 0, src, nbytes, iters, out);
+        hipLaunchKernelGGL((probe<KIND, K, NW, STREAM>), dim3(grid), dim3(NW * 64), 0, 0, src, nbytes, iters, out);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -65,7 +68,7 @@ void run(const char* src, unsigned nbytes, float* out, const char* label) {
     printf("%-28s K=%d waves/CU %2d : %7.3f ms  %6.1f ns per MFMA slot (per SIMD)   (%s)\n", label, K, NW, best, per, hipGetErrorString(hipGetLastError()));
 }
 int main() {
-    char* src; float* out; const unsigned nbytes = 256 * 4 * 4096 + 4096;
+    char* src; float* out; const unsigned nbytes = 1u << 30;
     hipMalloc(&src, nbytes); hipMemset(src, 0, nbytes); hipMalloc(&out, 256 * 1024 * 4);
     run<0, 0>(src, nbytes, out, "MFMA only");
     run<0, 0, 8>(src, nbytes, out, "MFMA only");
@@ -77,5 +80,11 @@ int main() {
     run<3, 1>(src, nbytes, out, "buffer_load..lds 1KiB"); run<3, 2>(src, nbytes, out, "buffer_load..lds 1KiB");
     run<1, 1, 8>(src, nbytes, out, "ds_read_b64_tr_b16"); run<1, 2, 8>(src, nbytes, out, "ds_read_b64_tr_b16");
     run<3, 1, 8>(src, nbytes, out, "buffer_load..lds 1KiB");
+    run<6, 1, 4>(src, nbytes, out, "lds-dma 1 per 4 MFMA (hot)"); run<6, 1, 8>(src, nbytes, out, "lds-dma 1 per 4 MFMA (hot)");
+    run<7, 1, 4>(src, nbytes, out, "lds-dma 1 per 2 MFMA (hot)"); run<7, 1, 8>(src, nbytes, out, "lds-dma 1 per 2 MFMA (hot)");
+    run<8, 1, 8>(src, nbytes, out, "lds-dma 1 per 8 MFMA (hot)");
+    run<6, 1, 4, true>(src, nbytes, out, "lds-dma 1 per 4 MFMA (stream)"); run<6, 1, 8, true>(src, nbytes, out, "lds-dma 1 per 4 MFMA (stream)");
+    run<7, 1, 8, true>(src, nbytes, out, "lds-dma 1 per 2 MFMA (stream)");
+    run<8, 1, 8, true>(src, nbytes, out, "lds-dma 1 per 8 MFMA (stream)");
     return 0;
 }

@@ -799,16 +799,9 @@ int launch_gather(const GatherArgs& a, int PT, hipStream_t st) {
     return 0;
 }
 
-// auto policy for the 8-wave / 3-stage kernel (one 512-thread block per CU), measured per SSD300 layer with
-// tools/conv_bench.py: it wins on the large layers (enough 256-pixel tiles to fill the chip) and on the tiny
-// ones (latency-bound either way; deeper DMA prefetch)
-bool gather_v3_auto(const GatherArgs& a) {
-    const int nk = ceil_div(a.Kdim, 64);
-    const int PT = a.K <= 64 ? 64 : 128;
-    const int tiles = ceil_div(a.K, PT) * ceil_div(a.M, 256);
-    // one exception (measured): a long k loop over ~90 tiles balances better as 2 x 128-pixel blocks per CU
-    return !(tiles >= 64 && tiles < 160 && nk > 96);
-}
+// auto policy: the 8-wave / 3-stage kernel (one 512-thread block per CU; split-K below ~128 tiles) wins on
+// every SSD300 layer (tools/conv_bench.py); the 4-wave kernels stay as the f32 / odd-layout path
+bool gather_v3_auto(const GatherArgs&) { return true; }
 
 int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
     a.div_howo = make_fastdiv((unsigned)(a.Ho * a.Wo));
@@ -825,9 +818,10 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
     if (!g_force_regstage && g_v3_mode != 1 && gather_v3_supported(a, dtype, out_dtype) &&
         (g_v3_mode >= 2 || gather_v3_auto(a))) {
         const bool v4 = g_v3_mode == 3 && a.idiv == 1;       // the persistent variant has no strided-dgrad tap walk
-        if (v4) launch_gather_v4(a, st);
-        else launch_gather_v3(a, st);
+        a.ksplit = 1;
+        if (int e = v4 ? launch_gather_v4(a, st) : launch_gather_v3(a, st)) return e;
         g_last_kernel = v4 ? (a.K <= 64 ? "conv_gather_v4_kernel<64>" : "conv_gather_v4_kernel<128>")
+                        : a.ksplit > 1 ? (a.K <= 64 ? "conv_gather_v3_kernel<64>+splitk" : "conv_gather_v3_kernel<128>+splitk")
                                        : (a.K <= 64 ? "conv_gather_v3_kernel<64>" : "conv_gather_v3_kernel<128>");
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;

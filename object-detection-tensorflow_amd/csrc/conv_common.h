@@ -142,6 +142,8 @@ struct GatherArgs {
     FastDiv div_howo, div_wo;
     int dbg;           // perf experiments only (odtk_debug_set key 2): bit0 skip pixel-operand DMA, bit1 skip filter DMA after slab 0
     unsigned x_bytes, w_bytes;   // extents of x and w for the buffer-addressed DMA (range check = zero fill)
+    int ksplit;        // split-K: blocks per tile (1 = off) and their f32 partial tiles [ksplit][M][ldy]
+    float* ws;
 };
 
 struct WgradArgs {

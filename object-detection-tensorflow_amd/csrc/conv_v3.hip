@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 // ---------------------------------------------------------------------------------------
 // gather kernel (forward conv, stride-1 dgrad)
 // ---------------------------------------------------------------------------------------
-template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false>
+template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false, bool SPLIT = false>
 __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
     constexpr int QT = 256;
     constexpr int PI = PT / 64, QI = 2, PL = PT / 64;
@@ -105,9 +105,17 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave & 1, wq = wave >> 1;
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    // SPLIT (split-K for the small, latency-bound layers): `ksplit` consecutive blocks share one tile, block
+    // `part` reduces k-slabs [part*nk/ksplit, (part+1)*nk/ksplit) and writes its f32 partial tile to a.ws[part];
+    // splitk_finish_kernel sums the parts in fixed order and applies bias / ReLU / mask / accumulate
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int part = SPLIT ? lin % a.ksplit : 0;
+    const int vb = SPLIT ? lin / a.ksplit : lin;
     const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
     const int p0 = tp * PT, q0 = tq * QT;
+    const int nk_all = (a.Kdim + 63) >> 6;
+    const int ks0 = SPLIT ? part * nk_all / a.ksplit : 0;
+    const int nk = SPLIT ? (part + 1) * nk_all / a.ksplit - ks0 : ((a.dbg & 8) ? 1 : nk_all);
 
     const int r0 = tid >> 3;                           // DMA rows r0 + 64*i
     const int cc = (tid & 7) ^ swz_g(r0);              // logical 16-B chunk this lane fetches
@@ -160,7 +168,7 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         poff[i] = (long long)row * a.ldw * 2ll;
         poff32[i] = (unsigned)(row * a.ldw * 2);
     }
-    int klin = cc * 8;
+    int klin = ks0 * 64 + cc * 8;
     int kc, ks, kr;
     {
         const int rs = klin / a.C;
@@ -171,7 +179,13 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 
     // C64 (C % 64 == 0, buffer addressing): a k-slab never straddles a tap, so the tap walk is wave-uniform
     // (SALU) and a piece costs this lane an AND, a compare, an add and a select.
-    int s_kc = 0, s_ks = 0, s_kr = 0, s_klin = 0;
+    int s_klin = ks0 * 64, s_kc, s_ks, s_kr;
+    {
+        const int rs = s_klin / a.C;
+        s_kc = s_klin - rs * a.C;
+        s_kr = rs / a.S;
+        s_ks = rs - s_kr * a.S;
+    }
     if (C64) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) qoff32[i] += (unsigned)(cc * 16);
@@ -250,7 +264,6 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (a.dbg & 8) ? 1 : (a.Kdim + 63) >> 6;
     if (EARLY) {
         // "Landed one slab early" protocol: at the top of iteration kt slabs kt AND kt+1 are published, so the
         // first fragments of slab kt+1 are read BEFORE barrier kt+1 and the matrix pipe restarts right behind
@@ -331,7 +344,62 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
     }
     block_barrier();                                    // all slab reads done: LDS is free for the output image
     }
+    if (SPLIT) {
+        // f32 partial tile -> a.ws[part][m][ldy]: 16 B (4 channels) per lane and accumulator group
+        const int l31 = lane & 31, hi = lane >> 5;
+        float* wsp = a.ws + (size_t)part * a.M * a.ldy;
+#pragma unroll
+        for (int j = 0; j < QI; ++j) {
+            const int m = q0 + wq * 64 + j * 32 + l31;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int i = 0; i < PI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = p0 + wp * (PT / 2) + i * 32 + 8 * g + 4 * hi;
+                    if (c < a.ldy)
+                        *reinterpret_cast<float4*>(wsp + (size_t)m * a.ldy + c) =
+                            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                }
+        }
+        return;
+    }
     epilogue_bf16<PT, QT, 512, PI, QI>(a, smem, acc, p0, q0, wp * (PT / 2), wq * 64, tid);
+}
+
+// sum of the split-K partial tiles (fixed order -> deterministic) + the epilogue of epilogue_bf16, 8 channels per thread
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const GatherArgs a) {
+    const int cpr = a.ldy >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.M * cpr) return;
+    const int m = idx / cpr, c0 = (idx - m * cpr) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    const size_t stride = (size_t)a.M * a.ldy;
+    const float* wp = a.ws + (size_t)m * a.ldy + c0;
+    for (int p = 0; p < a.ksplit; ++p) {
+        const float4 lo = *reinterpret_cast<const float4*>(wp + p * stride), h4 = *reinterpret_cast<const float4*>(wp + p * stride + 4);
+        v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += h4.x; v[5] += h4.y; v[6] += h4.z; v[7] += h4.w;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (c0 + e < a.K) v[e] += a.bias[c0 + e];
+    }
+    if (a.relu && !a.accumulate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    uint4 o = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+    char* yp = a.y + ((size_t)m * a.ldy + c0) * 2;
+    if (a.accumulate || a.mask) {
+        uint4 old = make_uint4(0, 0, 0, 0), mk = make_uint4(0, 0, 0, 0);
+        if (a.accumulate) old = *reinterpret_cast<const uint4*>(yp);
+        if (a.mask) mk = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
+        post_chunk(o, a.accumulate != 0, a.relu != 0, old, a.mask != nullptr, mk);
+    }
+    *reinterpret_cast<uint4*>(yp) = o;
 }
 
 
@@ -1127,6 +1195,26 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
 
 }  // namespace
 
+// per-device f32 scratch of the split-K path, grown on demand (never freed; calls are stream-ordered by the caller
+// like everything else in this library; it must have reached its final size before a stream capture)
+struct ConvScratchOwner { void* base = nullptr; size_t bytes = 0; };
+static ConvScratchOwner g_conv_scratch[16];
+static int conv_scratch(size_t bytes, float** out) {
+    int dev = 0;
+    ODTK_CHECK_HIP(hipGetDevice(&dev));
+    ODTK_REQUIRE(dev >= 0 && dev < 16, "conv: device index %d unsupported", dev);
+    ConvScratchOwner& o = g_conv_scratch[dev];
+    if (o.bytes < bytes) {
+        if (o.base) { ODTK_CHECK_HIP(hipDeviceSynchronize()); ODTK_CHECK_HIP(hipFree(o.base)); }
+        o.base = nullptr; o.bytes = 0;
+        const size_t want = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes;
+        ODTK_CHECK_HIP(hipMalloc(&o.base, want));
+        o.bytes = want;
+    }
+    *out = (float*)o.base;
+    return ODTK_OK;
+}
+
 static int g_num_cu = 0;
 static void query_num_cu() {
     int dev = 0;
@@ -1144,7 +1232,28 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     const int PT = a.K <= 64 ? 64 : 128;
     a.tiles_p = ceil_div(a.K, PT);
     a.tiles_q = ceil_div(a.M, 256);
-    const int grid = a.tiles_p * a.tiles_q;
+    const int tiles = a.tiles_p * a.tiles_q;
+    const int nk = ceil_div(a.Kdim, 64);
+    // split-K: few tiles with a long k loop leave most CUs idle and run at DMA latency; give every tile
+    // up to 256 / tiles blocks of >= 4 k-slabs each (dbg bit 13 turns it off for A/B runs)
+    int ksplit = 1;
+    if (tiles <= 128 && nk >= 8 && !(a.dbg & 8192)) {
+        ksplit = 256 / tiles;
+        if (ksplit > nk / 4) ksplit = nk / 4;
+        if (ksplit > 32) ksplit = 32;
+    }
+    if (ksplit >= 2) {
+        float* ws = nullptr;
+        if (int e = conv_scratch((size_t)ksplit * a.M * a.ldy * sizeof(float), &ws)) return e;
+        a.ksplit = ksplit; a.ws = ws;
+        const int grid = tiles * ksplit;
+        if (PT == 64) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(ceil_div(a.M * (a.ldy / 8), 256)), dim3(256), 0, st, a);
+        return 0;
+    }
+    a.ksplit = 1;
+    const int grid = tiles;
     const bool db = (a.dbg & 32) == 0;      // fragment double buffering (default on; dbg bit 5 turns it off)
     const bool early = (a.dbg & 128) != 0;  // "landed one slab early" protocol (dbg bit 7, A/B)
     const bool buf = (a.dbg & 256) == 0;    // buffer-addressed DMA (default on; dbg bit 8 = 64-bit global addressing, A/B)

@@ -815,6 +815,12 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }
+    if (!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && gather_c8_supported(a, dtype, out_dtype)) {
+        launch_gather_c8(a, st);
+        g_last_kernel = "conv3x3_c8k64_kernel";
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     if (!g_force_regstage && g_v3_mode != 1 && gather_v3_supported(a, dtype, out_dtype) &&
         (g_v3_mode >= 2 || gather_v3_auto(a))) {
         const bool v4 = g_v3_mode == 3 && a.idiv == 1;       // the persistent variant has no strided-dgrad tap walk

@@ -252,6 +252,8 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st);
 int launch_gather_v4(GatherArgs& a, hipStream_t st);   // persistent, loader/compute wave-specialised
 bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype);   // resident-filter 64->64 3x3 kernel
 int launch_gather_c64(GatherArgs& a, hipStream_t st);
+bool gather_c8_supported(const GatherArgs& a, int dtype, int out_dtype);    // first-layer (3 -> 64) 3x3 kernel
+int launch_gather_c8(GatherArgs& a, hipStream_t st);
 bool wgrad_c64_supported(const WgradArgs& a, int dtype);                      // halo-patch 64->64 3x3 wgrad
 int launch_wgrad_c64(WgradArgs& a, hipStream_t st);
 bool wgrad_v3_supported(const WgradArgs& a, int dtype);

@@ -1000,6 +1000,147 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
 
 
 // ---------------------------------------------------------------------------------------
+// First layer (conv1_1 forward): 3x3 / stride 1 / pad 1, 8 (3 real + 5 zero) input channels -> 64, bias + ReLU.
+// k = 72: two MFMA-starved k-slabs for the generic kernel, which then runs at the latency of its per-tile
+// prologue.  Here: persistent 4-wave workgroups (3 per CU), 8 x 32-pixel tiles, the 10 x 34 halo patch is ONE
+// 16-B chunk per pixel (6 LDS-DMA pieces, double buffered), the whole filter lives in registers as MFMA
+// fragments (k-step t = taps 2t | 2t+1 x 8 channels; tap 9 is a zero column), and a fragment read is 32
+// consecutive pixels = 512 contiguous bytes.  10 MFMAs per 32 pixels; the kernel is bound by the 128 B / pixel
+// it writes, so the epilogue goes through a wave-private LDS image and stores full 128-B rows.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv3x3_c8k64_kernel(const GatherArgs a, const int tiles_r, const int tiles_c,
+                                                            const int total_tiles, const FastDiv div_tpi, const FastDiv div_tc) {
+    constexpr int PW = 34, PPX = 340, NPIECE = 6, PBUF = NPIECE * 1024;
+    __shared__ __attribute__((aligned(16))) char smem[2 * PBUF + 4 * 8192];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const int grid = gridDim.x;
+    const int slot = blockIdx.x;
+    const int my_tiles = slot < total_tiles ? (total_tiles - slot + grid - 1) / grid : 0;
+    if (my_tiles == 0) return;
+
+    // filter fragments: channel row i*32 + l31, k-step t -> tap 2t + hi (8 channels = 16 B), tap 9 = zeros
+    uint4 wf[5][2];
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int tap = 2 * tt + hi;
+            wf[tt][i] = tap < 9 ? *reinterpret_cast<const uint4*>(a.w + ((size_t)(i * 32 + l31) * a.ldw + tap * 8) * 2) : make_uint4(0, 0, 0, 0);
+        }
+    float4 bias[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bias[i * 4 + g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + i * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int tiles_per_img = tiles_r * tiles_c;
+    auto decode = [&](int v, int& n, int& h0, int& w0) __attribute__((always_inline)) {
+        n = (int)fdiv((unsigned)v, div_tpi);
+        const int rem = v - n * tiles_per_img;
+        const int tr = (int)fdiv((unsigned)rem, div_tc);
+        h0 = tr * 8; w0 = (rem - tr * tiles_c) * 32;
+    };
+    // patch pieces: 64 pixels x 16 B; wave w issues pieces w and w + 4 (< 6)
+    int p_r[2], p_c[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int pp = (wave + 4 * u) * 64 + lane;
+        p_r[u] = pp < PPX ? pp / PW : 0x7FFF;
+        p_c[u] = pp - (pp / PW) * PW;
+    }
+    auto issue = [&](int n, int h0, int w0, int buf, bool en) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (wave + 4 * u >= NPIECE) continue;
+            const int h = h0 - 1 + p_r[u], w = w0 - 1 + p_c[u];
+            const bool ok = en && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            const unsigned addr = (unsigned)(((n * a.H + h) * a.W + w) * 16);
+            glds16_buf(rx, ok ? addr : 0xFFFFFFF0u, smem_base + (unsigned)(buf * PBUF) + (unsigned)(wave + 4 * u) * 1024u);
+        }
+    };
+    int tn, th0, tw0;
+    decode(slot, tn, th0, tw0);
+    issue(tn, th0, tw0, 0, true);
+
+    // fragment read offsets: pixel (tile row 2w + j, column l31), k-step t -> tap 2t + hi (t = 4: both halves read
+    // tap 8; the filter's zero column discards the upper one)
+    unsigned qo[5];
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) {
+        const int tap = (2 * tt + hi) < 9 ? 2 * tt + hi : 8;
+        const int dr = tap / 3, ds = tap - dr * 3;
+        qo[tt] = (unsigned)((((2 * wave + dr) * PW) + l31 + ds) * 16);
+    }
+    char* sg = smem + 2 * PBUF + wave * 8192;
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int buf = it & 1;
+        const bool has_next = it + 1 < my_tiles;
+        int nn, nh0, nw0, cn, ch0, cw0;
+        decode(has_next ? slot + (it + 1) * grid : slot, nn, nh0, nw0);
+        decode(slot + it * grid, cn, ch0, cw0);
+        wait_vmcnt<0>();
+        block_barrier();            // patch `buf` visible; everybody is done reading patch buf ^ 1
+        issue(nn, nh0, nw0, buf ^ 1, has_next);
+        const unsigned pb = smem_base + (unsigned)(buf * PBUF);
+        f32x16_v acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        uint4 qf[2][5];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt)
+                qf[j][tt] = *reinterpret_cast<const uint4*>(smem + (pb - smem_base) + qo[tt] + j * PW * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) Mma<bf16_t>::run(wf[tt][i], qf[j][tt], acc[i][j]);
+        // ---- epilogue: bias + ReLU -> bf16 -> wave-private LDS image [64 pixels][128 B] -> 16 B per lane, full rows
+        const bool pre_relu = a.relu != 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pxl = j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = i * 32 + 8 * g + 4 * hi;
+                    const float4 b = bias[i * 4 + g];
+                    float v0 = acc[i][j][4 * g] + b.x, v1 = acc[i][j][4 * g + 1] + b.y;
+                    float v2 = acc[i][j][4 * g + 2] + b.z, v3 = acc[i][j][4 * g + 3] + b.w;
+                    if (pre_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    uint2 o;
+                    o.x = cvt_pk_bf16(v0, v1);
+                    o.y = cvt_pk_bf16(v2, v3);
+                    *reinterpret_cast<uint2*>(sg + pxl * 128 + ((((cl >> 3) ^ pxl) & 7) << 4) + ((cl & 4) << 1)) = o;
+                }
+        }
+        asm volatile("" ::: "memory");          // wave-private image, in-order LDS: only pins the compiler (TBAA)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int idx = r * 64 + lane;
+            const int pxl = idx >> 3, ch = idx & 7;
+            const int h = ch0 + 2 * wave + (pxl >> 5), w = cw0 + (pxl & 31);
+            const uint4 v = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
+            if (h < a.H && w < a.W)
+                *reinterpret_cast<uint4*>(a.y + (((size_t)(cn * a.H + h) * a.W + w) * a.ldy + ch * 8) * 2) = v;
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // wgrad of the 3x3 / stride 1 / pad 1, 64 -> 64 convolution (conv1_2: 2.9 M pixels, dW is only 64 x 576):
 //   dW[k][tap][c] += sum_px dy[px][k] * x[px + tap][c]
 // The generic wgrad kernels gather x once per tap and waste half of their 128-row tile on K = 64.  Here a
@@ -1296,6 +1437,22 @@ int launch_gather_c64(GatherArgs& a, hipStream_t st) {
     const int tiles = a.N * tr * tc;
     const int grid = tiles < g_num_cu ? tiles : g_num_cu;
     hipLaunchKernelGGL(conv3x3_c64k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles);
+    return 0;
+}
+
+bool gather_c8_supported(const GatherArgs& a, int dtype, int out_dtype) {
+    return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && a.C == 8 && a.ldx == 8 && a.K == 64 && a.ldy == 64 && a.R == 3 && a.S == 3 &&
+           a.dil == 1 && a.ostride == 1 && a.idiv == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo &&
+           !a.accumulate && a.mask == nullptr && a.ldw == 72 && (long long)a.N * a.H * a.W * 16 < (1ll << 31);
+}
+
+int launch_gather_c8(GatherArgs& a, hipStream_t st) {
+    if (g_num_cu == 0) query_num_cu();
+    const int tr = ceil_div(a.H, 8), tc = ceil_div(a.W, 32);
+    const int tiles = a.N * tr * tc;
+    const int grid = tiles < 3 * g_num_cu ? tiles : 3 * g_num_cu;
+    hipLaunchKernelGGL(conv3x3_c8k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)),
+                       make_fastdiv((unsigned)tc));
     return 0;
 }
 

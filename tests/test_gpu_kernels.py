@@ -63,6 +63,7 @@ V3_EXTRA_CASES = [
     (5, 150, 150, 16, 64, 3, 1, 1),   # 440 PT=64 tiles, 3 k-slabs
     (2, 13, 70, 64, 64, 3, 1, 1),     # resident-filter 64->64 kernel: ragged 8x32 tiles on both edges
     (40, 33, 65, 64, 64, 3, 1, 1),    # ... 600 tiles: persistent blocks walk several tiles (patch double buffering)
+    (30, 45, 70, 8, 64, 3, 1, 1),     # first-layer kernel (3 real channels in one 16-B chunk): 540 ragged tiles, several per block
 ]
 
 

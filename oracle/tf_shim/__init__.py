@@ -145,8 +145,64 @@ def reduce_mean(x, axis=None):
     return x.mean() if axis is None else x.mean(dim=axis)      # mean of empty -> nan, as TF
 
 
-def reduce_max(x, axis=None):
-    return x.max() if axis is None else x.max(dim=axis).values
+def reduce_max(x, axis=None, keepdims=False):
+    return x.max() if axis is None else x.max(dim=axis, keepdim=keepdims).values
+
+
+def reduce_min(x, axis=None, keepdims=False):
+    if isinstance(x, (list, tuple)):          # tf.reduce_min([a, b, c]) packs the list first
+        x = torch.stack([_t(v) for v in x])
+    return x.min() if axis is None else x.min(dim=axis, keepdim=keepdims).values
+
+
+def floor(x):
+    return torch.floor(x)
+
+
+def sqrt(x):
+    return torch.sqrt(x)
+
+
+def square(x):
+    return x * x
+
+
+def sigmoid(x):
+    return torch.sigmoid(x)
+
+
+def log_sigmoid(x):
+    return torch.nn.functional.logsigmoid(x)
+
+
+def equal(a, b):
+    return _t(a) == b
+
+
+def greater(a, b):
+    return _t(a) > b
+
+
+def zeros(shp, dtype=None):
+    return torch.zeros([int(s) for s in shp], dtype=dtype or float32)
+
+
+def meshgrid(a, b):
+    """tf.meshgrid(x, y) (indexing='xy'): two [len(y), len(x)] tensors."""
+    return [a.view(1, -1).expand(b.shape[0], -1).clone(), b.view(-1, 1).expand(-1, a.shape[0]).clone()]
+
+
+class _KerasBackend:
+    @staticmethod
+    def binary_crossentropy(target, output, from_logits=False):
+        # tf.keras.backend.binary_crossentropy(from_logits=True) = nn.sigmoid_cross_entropy_with_logits:
+        # max(x, 0) - x * z + log(1 + exp(-|x|))
+        assert from_logits
+        x, z = output, target
+        return torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x)))
+
+
+keras = types.SimpleNamespace(backend=_KerasBackend())
 
 
 def _first_arg(x, axis, largest):
@@ -159,12 +215,14 @@ def _first_arg(x, axis, largest):
     return torch.where(hit, idx, torch.full_like(idx, n)).min(dim=axis).values.to(int64)
 
 
-def argmax(x, axis=0):
-    return _first_arg(x, axis, True)
+def argmax(x, axis=0, output_type=None):
+    r = _first_arg(x, axis, True)
+    return r if output_type is None else r.to(output_type)
 
 
-def argmin(x, axis=0):
-    return _first_arg(x, axis, False)
+def argmin(x, axis=0, output_type=None):
+    r = _first_arg(x, axis, False)
+    return r if output_type is None else r.to(output_type)
 
 
 def gather(params, indices):
@@ -172,8 +230,11 @@ def gather(params, indices):
     return params[idx]
 
 
-def boolean_mask(x, mask):
-    return x[_t(mask).bool()]
+def boolean_mask(x, mask, axis=None):
+    m = _t(mask).bool()
+    if axis is None or axis == 0:
+        return x[m]
+    return x[(slice(None),) * axis + (m,)]
 
 
 def unique(x):
@@ -207,7 +268,7 @@ def zeros_like(x, dtype=None):
 
 
 def ones_like(x, dtype=None):
-    return torch.ones_like(x, dtype=dtype)
+    return torch.ones_like(_t(x), dtype=dtype)
 
 
 def less(a, b):
@@ -380,6 +441,12 @@ class _NN:
         return x * torch.rsqrt(torch.clamp(ss, min=epsilon))
 
     @staticmethod
+    def top_k(x, k):
+        """tf.nn.top_k on a vector: descending, the LOWER index first among equal values."""
+        order = torch.sort(x, descending=True, stable=True).indices[: int(k)]
+        return x[order], order.to(int32)
+
+    @staticmethod
     def l2_loss(v):
         return (v * v).sum() / 2
 
@@ -487,7 +554,7 @@ class _Sparse:
     SparseTensor = _SparseTensor
 
     @staticmethod
-    def to_dense(sp):
+    def to_dense(sp, validate_indices=True):
         shp = [int(s) for s in sp.dense_shape]
         out = torch.zeros(shp, dtype=sp.values.dtype if isinstance(sp.values, torch.Tensor) else float32)
         idx = sp.indices.long()

@@ -133,3 +133,40 @@ def test_retinanet_one_image_loss_vs_reference():
     for i in range(pconf.shape[0]):
         l = float(RR.one_image_loss(pbox[i, :, :2], pbox[i, :, 2:], pconf[i], anc, gt[i]))
         assert abs(l - float(g['loss'][i])) <= 1e-5 * abs(float(g['loss'][i])), (i, l, float(g['loss'][i]))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CenterNet / FCOS box side: oracle/centernet_ref.py, oracle/fcos_ref.py vs the
+# reference's own code executed on the shim (tests/golden/make_golden_centernet_fcos.py)
+# ---------------------------------------------------------------------------------------------------------
+def test_centernet_loss_and_decode_vs_reference():
+    from oracle import centernet_ref as CR
+    g = np.load(os.path.join(GOLD, 'centernet_loss.npz'))
+    kp = torch.from_numpy(g['keypoints'].astype(np.float32))
+    off = torch.from_numpy(g['offset'].astype(np.float32))
+    size = torch.from_numpy(g['size'].astype(np.float32))
+    gt = torch.from_numpy(g['gt'])
+    for i in range(kp.shape[0]):
+        l = float(CR.one_image_loss(kp[i], off[i], size[i], gt[i]))
+        assert abs(l - float(g['loss'][i])) <= 1e-5 * abs(float(g['loss'][i])), (i, l, float(g['loss'][i]))
+    for i in range(2):
+        s, b, c = CR.decode(kp[i] + (3.0 if i else 0.0), off[i], size[i], 0.1, 100)
+        assert np.array_equal(c.numpy(), g[f'det{i}_class_id'])                       # same cells, same order
+        assert np.array_equal(s.numpy(), g[f'det{i}_scores'])
+        assert np.array_equal(b.numpy(), g[f'det{i}_bbox'])
+
+
+def test_fcos_loss_and_candidates_vs_reference():
+    from oracle import fcos_ref as FR
+    g = np.load(os.path.join(GOLD, 'fcos_loss.npz'))
+    shapes = [tuple(int(v) for v in s) for s in g['shapes']]
+    assert shapes == FR.level_shapes(256, 320)
+    conf = [torch.from_numpy(g[f'conf{l}'].astype(np.float32)) for l in range(5)]
+    reg = [torch.from_numpy(g[f'reg{l}'].astype(np.float32)) for l in range(5)]
+    cen = [torch.from_numpy(g[f'center{l}'].astype(np.float32)) for l in range(5)]
+    gt = torch.from_numpy(g['gt'])
+    for i in range(gt.shape[0]):
+        l = float(FR.one_image_loss([c[i] for c in conf], [r[i] for r in reg], [c[i] for c in cen], gt[i]))
+        assert abs(l - float(g['loss'][i])) <= 1e-5 * abs(float(g['loss'][i])), (i, l, float(g['loss'][i]))
+    pc, pb = FR.decode_candidates([c[0] for c in conf], [r[0] for r in reg], [c[0] for c in cen])
+    assert np.array_equal(pc.numpy()[::3], g['pconf']) and np.array_equal(pb.numpy()[::3], g['pbbox'])

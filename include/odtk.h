@@ -245,6 +245,35 @@ int odtk_retina_loss(const float* pconf, const float* pbox, int N, int A, int C,
                      const unsigned char* status, const int* rgindex, const int* counts, float alpha,
                      float gamma, float grad_scale, float* loss_parts, float* dconf, float* dbox, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CenterNet box side: replaces CenterNet._compute_one_image_loss / _keypoints_loss /
+ * _gaussian_radius (CenterNet.py:187-270) + the batch mean (:144-152) and the inference branch (:159-185).
+ * keypoints [N][H][W][C] logits, offset / size [N][H][W][2], gt [N][P][5] = yc,xc,h,w,cls px (pad rows -1).
+ * loss_parts [N][4] = keypoint, offset, size, total per image; d_* = grad_scale * d(sum_n total_n)/d(input)
+ * (pass grad_scale = 1/N for the reference's batch mean).  workspace: odtk_centernet_workspace_bytes. */
+long long odtk_centernet_workspace_bytes(int N, int H, int W, int C);
+int odtk_centernet_loss(const float* keypoints, const float* offset, const float* size, const float* gt, int N, int H,
+                        int W, int C, int P, float stride, float grad_scale, float* loss_parts, float* d_keypoints,
+                        float* d_offset, float* d_size, void* workspace, void* stream);
+/* one image: sigmoid, arg-max class, 3x3 peak test, score > threshold, top-k (descending, lower index first).
+ * scores [top_k], bbox [top_k][4] y1,x1,y2,x2 px, class_id [top_k], count [1].  H*W <= 16384. */
+int odtk_centernet_decode(const float* keypoints, const float* offset, const float* size, int H, int W, int C,
+                          float stride, float score_threshold, int top_k, float* scores, float* bbox, int* class_id,
+                          int* count, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FCOS box side: replaces the level assignment + FCOS._compute_one_image_loss
+ * (FCOS.py:153-189, :266-348) and the decode candidates (FCOS.py:197-246; feed them to odtk_nms_batched).
+ * conf / reg / center: host arrays of 5 device pointers (p3..p7) to [N][H_l][W_l][C] logits, [..][4] = l,r,t,b
+ * distances (> 0, i.e. after the exp), [..][1] centre-ness logits; shapes [5][2] = H_l, W_l; strides 8..128.
+ * loss [N] per image; d_* as for CenterNet.  workspace: odtk_fcos_workspace_bytes. */
+long long odtk_fcos_workspace_bytes(const int* shapes, int N);
+int odtk_fcos_loss(const float* const* conf, const float* const* reg, const float* const* center, const int* shapes,
+                   const float* gt, int N, int C, int P, float grad_scale, float* loss, float* const* d_conf,
+                   float* const* d_reg, float* const* d_center, void* workspace, void* stream);
+int odtk_fcos_decode_candidates(const float* const* conf, const float* const* reg, const float* const* center,
+                                const int* shapes, int C, float* pconf, float* pbbox, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,3 +245,65 @@ def retina_loss(pconf, pbox, yx, hw, gt, ngt, best, status, rgindex, counts, alp
     call("odtk_retina_loss", _p(pconf), _p(pbox), N, A, Cn, _p(yx), _p(hw), _p(gt), gt.shape[1], _p(ngt), _p(best),
          _p(status), _p(rgindex), _p(counts), float(alpha), float(gamma), float(grad_scale), _p(loss_parts), _p(dconf),
          _p(dbox), _stream())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CenterNet / FCOS box side (include/odtk.h; csrc/dense_heads.hip)
+# ---------------------------------------------------------------------------------------------------------
+def centernet_workspace(N, H, W, Cn, device):
+    return torch.empty(int(_lib.load().odtk_centernet_workspace_bytes(N, H, W, Cn)), dtype=torch.uint8, device=device)
+
+
+def centernet_loss(keypoints, offset, size, gt, stride, grad_scale, loss_parts, d_keypoints, d_offset, d_size, ws):
+    """CenterNet.py:187-251 for the whole batch; loss_parts [N,4] = keypoint, offset, size, total."""
+    N, H, W, Cn = keypoints.shape
+    call("odtk_centernet_loss", _p(keypoints), _p(offset), _p(size), _p(gt), N, H, W, Cn, gt.shape[1], float(stride),
+         float(grad_scale), _p(loss_parts), _p(d_keypoints), _p(d_offset), _p(d_size), _p(ws), _stream())
+
+
+def centernet_decode(keypoints, offset, size, stride, score_threshold, top_k, ws):
+    """CenterNet.py:159-185 for one image [H,W,C]; returns (scores, bbox, class_id) trimmed to the kept count."""
+    H, W, Cn = keypoints.shape
+    dev = keypoints.device
+    scores = torch.empty(top_k, device=dev)
+    bbox = torch.empty(top_k, 4, device=dev)
+    cls = torch.empty(top_k, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    call("odtk_centernet_decode", _p(keypoints), _p(offset), _p(size), H, W, Cn, float(stride), float(score_threshold),
+         int(top_k), _p(scores), _p(bbox), _p(cls), _p(cnt), _p(ws), _stream())
+    k = int(cnt.item())
+    return scores[:k], bbox[:k], cls[:k]
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _fcos_shapes(conf):
+    flat = []
+    for c in conf:
+        flat += [c.shape[-3], c.shape[-2]]
+    return (C.c_int * len(flat))(*flat)
+
+
+def fcos_workspace(conf, N, device):
+    return torch.empty(int(_lib.load().odtk_fcos_workspace_bytes(_fcos_shapes(conf), N)), dtype=torch.uint8, device=device)
+
+
+def fcos_loss(conf, reg, center, gt, grad_scale, loss, d_conf, d_reg, d_center, ws):
+    """FCOS.py:153-189 + :266-348.  conf / reg / center: lists of the five level tensors [N,H,W,C|4|1]."""
+    N, Cn = conf[0].shape[0], conf[0].shape[-1]
+    call("odtk_fcos_loss", _ptr_array(conf), _ptr_array(reg), _ptr_array(center), _fcos_shapes(conf), _p(gt), N, Cn,
+         gt.shape[1], float(grad_scale), _p(loss), _ptr_array(d_conf), _ptr_array(d_reg), _ptr_array(d_center), _p(ws), _stream())
+
+
+def fcos_decode_candidates(conf, reg, center):
+    """FCOS.py:197-246 for one image (level tensors [H,W,C|4|1]); returns pconf [L,C], pbbox [L,4]."""
+    dev = conf[0].device
+    L = sum(c.shape[0] * c.shape[1] for c in conf)
+    Cn = conf[0].shape[-1]
+    pconf = torch.empty(L, Cn, device=dev)
+    pbbox = torch.empty(L, 4, device=dev)
+    call("odtk_fcos_decode_candidates", _ptr_array(conf), _ptr_array(reg), _ptr_array(center), _fcos_shapes(conf), Cn,
+         _p(pconf), _p(pbbox), _stream())
+    return pconf, pbbox

@@ -159,6 +159,10 @@ def floor(x):
     return torch.floor(x)
 
 
+def one_hot(indices, depth):
+    return F.one_hot(_t(indices).long(), int(depth)).to(float32)
+
+
 def sqrt(x):
     return torch.sqrt(x)
 
@@ -439,6 +443,12 @@ class _NN:
     def l2_normalize(x, axis=None, epsilon=1e-12):
         ss = (x * x).sum(dim=axis, keepdim=True)
         return x * torch.rsqrt(torch.clamp(ss, min=epsilon))
+
+    @staticmethod
+    def sigmoid_cross_entropy_with_logits(labels=None, logits=None):
+        # max(x, 0) - x * z + log(1 + exp(-|x|))   (TF's documented stable form)
+        x, z = logits, labels
+        return torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x)))
 
     @staticmethod
     def top_k(x, k):

@@ -170,3 +170,16 @@ def test_fcos_loss_and_candidates_vs_reference():
         assert abs(l - float(g['loss'][i])) <= 1e-5 * abs(float(g['loss'][i])), (i, l, float(g['loss'][i]))
     pc, pb = FR.decode_candidates([c[0] for c in conf], [r[0] for r in reg], [c[0] for c in cen])
     assert np.array_equal(pc.numpy()[::3], g['pconf']) and np.array_equal(pb.numpy()[::3], g['pbbox'])
+
+
+def test_yolov3_loss_and_candidates_vs_reference():
+    """oracle/yolov3_ref.py vs the reference's own loss loop / decode lines (tests/golden/make_golden_yolov3.py)."""
+    from oracle import yolov3_ref as YR
+    g = np.load(os.path.join(GOLD, 'yolov3_loss.npz'))
+    preds = [torch.from_numpy(g[f'pred{l + 1}'].astype(np.float32)) for l in range(3)]
+    gt = torch.from_numpy(g['gt'])
+    for i in range(gt.shape[0]):
+        l = float(YR.one_image_loss([p[i] for p in preds], gt[i]))
+        assert abs(l - float(g['loss'][i])) <= 1e-5 * abs(float(g['loss'][i])), (i, l, float(g['loss'][i]))
+    conf, box = YR.decode_candidates([p[0] for p in preds])
+    assert np.abs(conf.numpy()[::3] - g['confidence']).max() <= 2e-7 and np.array_equal(box.numpy()[::3], g['bbox'])

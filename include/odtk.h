@@ -274,6 +274,22 @@ int odtk_fcos_loss(const float* const* conf, const float* const* reg, const floa
 int odtk_fcos_decode_candidates(const float* const* conf, const float* const* reg, const float* const* center,
                                 const int* shapes, int C, float* pconf, float* pbbox, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * YOLOv3 box side: replaces the per-image loss loop (YOLOv3.py:117-310, batch mean :311) and the
+ * decode candidates (:320-350; feed them to odtk_nms_batched).  pred: host array of 3 device pointers (head 1 =
+ * coarsest) to [N][H_l][W_l][num_priors][C+5] = class(C), yx(2), hw(2), obj(1) logits; shapes [3][2];
+ * priors [3][num_priors][2] (h, w) in the units the reference pairs with each head (config priors[i] / stride[i]);
+ * head_stride [3] = 32, 16, 8 (ground truth / head_stride); decode_scale [3] = 32, 32, 16 (sic, YOLOv3.py:343-348).
+ * loss_parts [N][5] = coord, class, obj, no-object sums and the per-image total; d_pred as for CenterNet. */
+long long odtk_yolov3_workspace_bytes(const int* shapes, int num_priors, int N);
+int odtk_yolov3_loss(const float* const* pred, const int* shapes, const float* priors, const float* head_stride,
+                     const float* gt, int N, int num_priors, int C, int pad, float coord_scale, float noobj_scale,
+                     float obj_scale, float class_scale, float grad_scale, float* loss_parts, float* const* d_pred,
+                     void* workspace, void* stream);
+int odtk_yolov3_decode_candidates(const float* const* pred, const int* shapes, const float* priors,
+                                  const float* decode_scale, int num_priors, int C, float* confidence, float* bbox,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

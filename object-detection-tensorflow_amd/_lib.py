@@ -76,6 +76,10 @@ SIGNATURES = {
     "odtk_fcos_loss": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _vp, _i, _i, _i, _f, _vp,
                             C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "odtk_fcos_decode_candidates": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp, _vp]),
+    "odtk_yolov3_workspace_bytes": (_ll, [C.POINTER(_i), _i, _i]),
+    "odtk_yolov3_loss": (_i, [C.POINTER(_vp), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f), _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f,
+                              _vp, C.POINTER(_vp), _vp, _vp]),
+    "odtk_yolov3_decode_candidates": (_i, [C.POINTER(_vp), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f), _i, _i, _vp, _vp, _vp]),
     "odtk_ssd_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -1,11 +1,12 @@
-// Anchor-free heads (gfx950): CenterNet and FCOS loss (forward + gradients) and inference decode.
-// SURVEY.md 8(f).1 / kernels K19-K20.  HBM-bound elementwise / small-reduction work: one thread per heat-map
+// Dense detection heads (gfx950): CenterNet, FCOS and YOLOv3 loss (forward + gradients) and inference decode.
+// SURVEY.md 8(f).1 / kernels K17-K20.  HBM-bound elementwise / small-reduction work: one thread per heat-map
 // element (coalesced over the channel-minor [N][H][W][C] layout), ground truth staged in LDS, per-workgroup
 // partial sums reduced in a fixed order (deterministic losses), no atomics on the loss path.
 //
 // Reference: CenterNet.py:187-270 (loss, gaussian radius), :159-185 (decode);
-//            FCOS.py:153-189 (level assignment), :266-348 (per-level loss), :197-246 (decode candidates).
-// The CPU restatements they are tested against: oracle/centernet_ref.py, oracle/fcos_ref.py.
+//            FCOS.py:153-189 (level assignment), :266-348 (per-level loss), :197-246 (decode candidates);
+//            YOLOv3.py:117-310 (loss loop), :320-350 (decode candidates).
+// The CPU restatements they are tested against: oracle/centernet_ref.py, oracle/fcos_ref.py, oracle/yolov3_ref.py.
 #include "common.h"
 #include <math.h>
 
@@ -456,6 +457,174 @@ __global__ void __launch_bounds__(DH_THREADS) fcos_candidates_kernel(const FcDec
     *reinterpret_cast<float4*>(a.pbbox + (size_t)i * 4) = make_float4((gy - r.z) * s, (gx - r.x) * s, (gy + r.w) * s, (gx + r.y) * s);
 }
 
+
+// =======================================================================================================
+// YOLOv3 (YOLOv3.py:117-310 loss loop, :320-350 decode candidates).  Quirks of the reference are reproduced,
+// see oracle/yolov3_ref.py: unclamped intersections, no-object boxes built as y1x1 -/+ y2x2/2, head / prior /
+// stride pairing, strict ">" head assignment, prior + exp(t) sizes.
+// pred_l [N][H_l][W_l][P][C+5] = class(C), yx(2), hw(2), obj(1)
+// =======================================================================================================
+constexpr int YL_HEADS = 3, YL_MAXP = 8;
+struct YlArgs {
+    const float* pred[YL_HEADS]; float* d_pred[YL_HEADS];
+    int H[YL_HEADS], W[YL_HEADS], nblk[YL_HEADS], boff[YL_HEADS + 1];
+    float prior[YL_HEADS][YL_MAXP][2];
+    float gstride[YL_HEADS], dscale[YL_HEADS];
+    const float* gt;
+    int N, P, C, pad;
+    float coord_scale, noobj_scale, obj_scale, class_scale, grad_scale;
+    float* parts;          // [N][total blocks] no-object partial sums
+    float* loss_parts;     // [N][5] coord, class, obj, noobj, total
+};
+struct YlGt { float y1, x1, y2, x2, area; int cy, cx; };
+
+__device__ __forceinline__ float bce_logits(float x, float z) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
+
+// no-object term: every prior of every cell that holds no ground-truth centre (YOLOv3.py:126-131, :247-306)
+__global__ void __launch_bounds__(DH_THREADS) yolov3_noobj_kernel(const YlArgs a) {
+    __shared__ YlGt sg[DH_MAX_GT];
+    __shared__ float red[DH_THREADS / 64];
+    __shared__ int sG;
+    const int n = blockIdx.y;
+    int l = 0;
+    while (l + 1 < YL_HEADS && (int)blockIdx.x >= a.boff[l + 1]) ++l;
+    const float* gt = a.gt + (size_t)n * a.pad * 5;
+    if (threadIdx.x == 0) sG = first_argmin_col0(gt, a.pad);
+    __syncthreads();
+    const int G = sG;
+    for (int g = threadIdx.x; g < G; g += DH_THREADS) {
+        const float s = a.gstride[l];
+        const float y = gt[g * 5] / s, x = gt[g * 5 + 1] / s, h = gt[g * 5 + 2] / s, w = gt[g * 5 + 3] / s;
+        YlGt v;
+        v.y1 = y - h / 2.f; v.x1 = x - w / 2.f; v.y2 = y + h / 2.f; v.x2 = x + w / 2.f;
+        v.area = (v.y2 - v.y1) * (v.x2 - v.x1);
+        v.cy = (int)floorf(y); v.cx = (int)floorf(x);
+        sg[g] = v;
+    }
+    __syncthreads();
+    const int H = a.H[l], W = a.W[l], E = a.C + 5;
+    const int i = (blockIdx.x - a.boff[l]) * DH_THREADS + threadIdx.x;
+    float loss = 0.f;
+    if (i < H * W * a.P) {
+        const int k = i % a.P, cell = i / a.P;
+        const int cy = cell / W, cx = cell - cy * W;
+        bool occupied = false;
+        for (int g = 0; g < G; ++g) occupied = occupied || (sg[g].cy == cy && sg[g].cx == cx);
+        if (!occupied) {
+            const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f, ah = a.prior[l][k][0], aw = a.prior[l][k][1];
+            const float q1y = ay - ah / 2.f, q1x = ax - aw / 2.f, q2y = ay + ah / 2.f, q2x = ax + aw / 2.f;
+            const float b1y = q1y - q2y / 2.f, b1x = q1x - q2x / 2.f, b2y = q1y + q2y / 2.f, b2x = q1x + q2x / 2.f;
+            const float aarea = (b2y - b1y) * (b2x - b1x);
+            float mx = -INFINITY;
+            for (int g = 0; g < G; ++g) {
+                const float inter = (fminf(sg[g].y2, b2y) - fmaxf(sg[g].y1, b1y)) * (fminf(sg[g].x2, b2x) - fmaxf(sg[g].x1, b1x));
+                mx = fmaxf(mx, inter / (aarea + sg[g].area - inter));
+            }
+            if (mx <= 0.5f) {
+                const size_t at = (((size_t)n * H * W + cell) * a.P + k) * E + a.C + 4;
+                const float x = a.pred[l][at];
+                loss = bce_logits(x, 0.f);
+                a.d_pred[l][at] = sigmoidf_(x) * a.noobj_scale * a.grad_scale / (float)G;
+            }
+        }
+    }
+    const float t = block_sum<DH_THREADS>(loss, red);
+    if (threadIdx.x == 0) a.parts[(size_t)n * a.boff[YL_HEADS] + blockIdx.x] = t;
+}
+
+// responsible predictions: one thread per ground-truth box (YOLOv3.py:132-246), + the image's totals
+__global__ void __launch_bounds__(64) yolov3_pos_kernel(const YlArgs a) {
+    const int n = blockIdx.x, t = threadIdx.x;
+    const float* gt = a.gt + (size_t)n * a.pad * 5;
+    __shared__ int sG;
+    if (t == 0) sG = first_argmin_col0(gt, a.pad);
+    __syncthreads();
+    const int G = sG, E = a.C + 5;
+    float coord = 0.f, cls = 0.f, obj = 0.f;
+    for (int g = t; g < G; g += 64) {
+        float best_iou[YL_HEADS], ty[YL_HEADS], tx[YL_HEADS], th[YL_HEADS], tw[YL_HEADS];
+        int best_k[YL_HEADS], cyv[YL_HEADS], cxv[YL_HEADS];
+#pragma unroll
+        for (int l = 0; l < YL_HEADS; ++l) {
+            const float s = a.gstride[l];
+            const float y = gt[g * 5] / s, x = gt[g * 5 + 1] / s, h = gt[g * 5 + 2] / s, w = gt[g * 5 + 3] / s;
+            const float fy = floorf(y), fx = floorf(x);
+            cyv[l] = (int)fy; cxv[l] = (int)fx;
+            const float gy1 = y - h / 2.f, gx1 = x - w / 2.f, gy2 = y + h / 2.f, gx2 = x + w / 2.f;
+            const float garea = (gy2 - gy1) * (gx2 - gx1);
+            const float ay = fy + 0.5f, ax = fx + 0.5f;
+            float bi = -INFINITY; int bk = 0;
+            for (int k = 0; k < a.P; ++k) {
+                const float ah = a.prior[l][k][0], aw = a.prior[l][k][1];
+                const float ay1 = ay - ah / 2.f, ax1 = ax - aw / 2.f, ay2 = ay + ah / 2.f, ax2 = ax + aw / 2.f;
+                const float inter = (fminf(gy2, ay2) - fmaxf(gy1, ay1)) * (fminf(gx2, ax2) - fmaxf(gx1, ax1));
+                const float iou = inter / (ah * aw + garea - inter);
+                if (iou > bi) { bi = iou; bk = k; }                     // tf.argmax: first maximum
+            }
+            best_iou[l] = bi; best_k[l] = bk;
+            ty[l] = y - fy; tx[l] = x - fx;
+            th[l] = logf(h / a.prior[l][bk][0]); tw[l] = logf(w / a.prior[l][bk][1]);
+        }
+        const int l = (best_iou[0] > best_iou[1] && best_iou[0] > best_iou[2]) ? 0
+                      : (best_iou[1] > best_iou[0] && best_iou[1] > best_iou[2]) ? 1 : 2;     // :186-190
+        const size_t at = (((size_t)n * a.H[l] * a.W[l] + (size_t)cyv[l] * a.W[l] + cxv[l]) * a.P + best_k[l]) * E;
+        const float* p = a.pred[l] + at;
+        float* d = a.d_pred[l] + at;
+        const float gs = a.grad_scale / (float)G;
+        const int label = (int)gt[g * 5 + 4];
+        for (int c = 0; c < a.C; ++c) {
+            const float z = c == label ? 1.f : 0.f;
+            cls += bce_logits(p[c], z);
+            atomicAdd(d + c, (sigmoidf_(p[c]) - z) * a.class_scale * gs);
+        }
+        const float tgt[4] = {ty[l], tx[l], th[l], tw[l]};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            coord += bce_logits(p[a.C + k], tgt[k]);
+            atomicAdd(d + a.C + k, (sigmoidf_(p[a.C + k]) - tgt[k]) * a.coord_scale * gs);
+            const float e = p[a.C + 2 + k] - tgt[2 + k];
+            coord += 0.5f * (e * e);
+            atomicAdd(d + a.C + 2 + k, e * a.coord_scale * gs);
+        }
+        obj += bce_logits(p[a.C + 4], 1.f);
+        atomicAdd(d + a.C + 4, (sigmoidf_(p[a.C + 4]) - 1.f) * a.obj_scale * gs);
+    }
+    float noobj = 0.f;
+    for (int b = t; b < a.boff[YL_HEADS]; b += 64) noobj += a.parts[(size_t)n * a.boff[YL_HEADS] + b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        coord += __shfl_xor(coord, o); cls += __shfl_xor(cls, o); obj += __shfl_xor(obj, o); noobj += __shfl_xor(noobj, o);
+    }
+    if (t == 0) {
+        float* o = a.loss_parts + n * 5;
+        const float Gf = (float)G;
+        o[0] = coord; o[1] = cls; o[2] = obj; o[3] = noobj;
+        o[4] = (a.coord_scale * coord + a.class_scale * cls + a.obj_scale * obj) / Gf + a.noobj_scale * noobj / Gf;      // :307-309
+    }
+}
+
+// decode candidates of ONE image: confidence [L][C], bbox [L][4]   (YOLOv3.py:320-350)
+__global__ void __launch_bounds__(DH_THREADS) yolov3_candidates_kernel(const YlArgs a, float* __restrict__ conf, float* __restrict__ bbox) {
+    const int i = blockIdx.x * DH_THREADS + threadIdx.x;
+    int off[YL_HEADS + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int l = 0; l < YL_HEADS; ++l) off[l + 1] = off[l] + a.H[l] * a.W[l] * a.P;
+    if (i >= off[YL_HEADS]) return;
+    int l = 0;
+    while (l + 1 < YL_HEADS && i >= off[l + 1]) ++l;
+    const int r = i - off[l], E = a.C + 5;
+    const int k = r % a.P, cell = r / a.P;
+    const int cy = cell / a.W[l], cx = cell - cy * a.W[l];
+    const float* p = a.pred[l] + (size_t)r * E;
+    const float so = sigmoidf_(p[a.C + 4]);
+    for (int c = 0; c < a.C; ++c) conf[(size_t)i * a.C + c] = sigmoidf_(p[c]) * so;
+    const float y = ((float)cy + 0.5f) + sigmoidf_(p[a.C]), x = ((float)cx + 0.5f) + sigmoidf_(p[a.C + 1]);
+    const float h = a.prior[l][k][0] + expf(p[a.C + 2]), w = a.prior[l][k][1] + expf(p[a.C + 3]);
+    const float s = a.dscale[l];
+    *reinterpret_cast<float4*>(bbox + (size_t)i * 4) = make_float4((y - h / 2.f) * s, (x - w / 2.f) * s, (y + h / 2.f) * s, (x + w / 2.f) * s);
+}
+
 }  // namespace
 }  // namespace odtk
 
@@ -570,6 +739,71 @@ extern "C" int odtk_fcos_decode_candidates(const float* const* conf, const float
     }
     a.off[FC_LEVELS] = off; a.C = C; a.pconf = pconf; a.pbbox = pbbox;
     hipLaunchKernelGGL(fcos_candidates_kernel, dim3(ceil_div(off, DH_THREADS)), dim3(DH_THREADS), 0, (hipStream_t)stream, a);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- YOLOv3
+static int yolo_fill(YlArgs& a, const float* const* pred, const int* shapes, const float* priors, const float* head_stride,
+                     const float* decode_scale, int N, int P, int C) {
+    ODTK_REQUIRE(pred && shapes && priors && head_stride, "yolov3: null pointer");
+    ODTK_REQUIRE(P > 0 && P <= YL_MAXP && C > 0 && N > 0, "yolov3: P=%d C=%d N=%d out of range", P, C, N);
+    int off = 0;
+    for (int l = 0; l < YL_HEADS; ++l) {
+        ODTK_REQUIRE(pred[l] && shapes[2 * l] > 0 && shapes[2 * l + 1] > 0, "yolov3: bad head %d", l);
+        a.pred[l] = pred[l];
+        a.H[l] = shapes[2 * l]; a.W[l] = shapes[2 * l + 1];
+        a.nblk[l] = ceil_div(a.H[l] * a.W[l] * P, DH_THREADS);
+        a.boff[l] = off;
+        off += a.nblk[l];
+        a.gstride[l] = head_stride[l];
+        a.dscale[l] = decode_scale ? decode_scale[l] : 0.f;
+        for (int k = 0; k < P; ++k) { a.prior[l][k][0] = priors[(l * P + k) * 2]; a.prior[l][k][1] = priors[(l * P + k) * 2 + 1]; }
+    }
+    a.boff[YL_HEADS] = off;
+    a.N = N; a.P = P; a.C = C;
+    return ODTK_OK;
+}
+
+extern "C" long long odtk_yolov3_workspace_bytes(const int* shapes, int num_priors, int N) {
+    long long blocks = 0;
+    for (int l = 0; l < YL_HEADS; ++l) blocks += ((long long)shapes[2 * l] * shapes[2 * l + 1] * num_priors + DH_THREADS - 1) / DH_THREADS;
+    return (long long)N * blocks * 4;
+}
+
+extern "C" int odtk_yolov3_loss(const float* const* pred, const int* shapes, const float* priors, const float* head_stride,
+                                const float* gt, int N, int num_priors, int C, int pad, float coord_scale, float noobj_scale,
+                                float obj_scale, float class_scale, float grad_scale, float* loss_parts, float* const* d_pred,
+                                void* workspace, void* stream) {
+    YlArgs a;
+    memset(&a, 0, sizeof(a));
+    if (int e = yolo_fill(a, pred, shapes, priors, head_stride, nullptr, N, num_priors, C)) return e;
+    ODTK_REQUIRE(gt && loss_parts && d_pred && workspace && pad > 0 && pad <= DH_MAX_GT, "yolov3_loss: bad argument (pad=%d)", pad);
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < YL_HEADS; ++l) {
+        ODTK_REQUIRE(d_pred[l], "yolov3_loss: null gradient pointer %d", l);
+        a.d_pred[l] = d_pred[l];
+        ODTK_CHECK_HIP(hipMemsetAsync(d_pred[l], 0, (size_t)N * a.H[l] * a.W[l] * num_priors * (C + 5) * sizeof(float), st));
+    }
+    a.gt = gt; a.pad = pad; a.coord_scale = coord_scale; a.noobj_scale = noobj_scale; a.obj_scale = obj_scale;
+    a.class_scale = class_scale; a.grad_scale = grad_scale; a.parts = (float*)workspace; a.loss_parts = loss_parts;
+    hipLaunchKernelGGL(yolov3_noobj_kernel, dim3(a.boff[YL_HEADS], N), dim3(DH_THREADS), 0, st, a);
+    hipLaunchKernelGGL(yolov3_pos_kernel, dim3(N), dim3(64), 0, st, a);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_yolov3_decode_candidates(const float* const* pred, const int* shapes, const float* priors,
+                                             const float* decode_scale, int num_priors, int C, float* confidence, float* bbox,
+                                             void* stream) {
+    YlArgs a;
+    memset(&a, 0, sizeof(a));
+    ODTK_REQUIRE(decode_scale && confidence && bbox, "yolov3_decode_candidates: null pointer");
+    const float ones[YL_HEADS] = {1.f, 1.f, 1.f};
+    if (int e = yolo_fill(a, pred, shapes, priors, ones, decode_scale, 1, num_priors, C)) return e;
+    int total = 0;
+    for (int l = 0; l < YL_HEADS; ++l) total += a.H[l] * a.W[l] * num_priors;
+    hipLaunchKernelGGL(yolov3_candidates_kernel, dim3(ceil_div(total, DH_THREADS)), dim3(DH_THREADS), 0, (hipStream_t)stream, a, confidence, bbox);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

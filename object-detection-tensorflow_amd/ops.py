@@ -307,3 +307,43 @@ def fcos_decode_candidates(conf, reg, center):
     call("odtk_fcos_decode_candidates", _ptr_array(conf), _ptr_array(reg), _ptr_array(center), _fcos_shapes(conf), Cn,
          _p(pconf), _p(pbbox), _stream())
     return pconf, pbbox
+
+
+# ---------------------------------------------------------------------------------------------------------
+# YOLOv3 box side (include/odtk.h; csrc/dense_heads.hip)
+# ---------------------------------------------------------------------------------------------------------
+def _yolo_shapes(preds):
+    flat = []
+    for p in preds:
+        flat += [p.shape[-4], p.shape[-3]]
+    return (C.c_int * len(flat))(*flat)
+
+
+def _farr(values):
+    return (C.c_float * len(values))(*[float(v) for v in values])
+
+
+def yolov3_workspace(preds, N, device):
+    P = preds[0].shape[-2]
+    return torch.empty(max(4, int(_lib.load().odtk_yolov3_workspace_bytes(_yolo_shapes(preds), P, N))), dtype=torch.uint8, device=device)
+
+
+def yolov3_loss(preds, priors_flat, head_stride, gt, scales, grad_scale, loss_parts, d_preds, ws):
+    """YOLOv3.py:117-311.  preds: three [N,H,W,P,C+5] tensors (head 1 = coarsest); priors_flat: 3*P*2 floats (h, w) in
+    head units; scales = (coord, noobj, obj, class); loss_parts [N,5]."""
+    N, P, E = preds[0].shape[0], preds[0].shape[-2], preds[0].shape[-1]
+    call("odtk_yolov3_loss", _ptr_array(preds), _yolo_shapes(preds), _farr(priors_flat), _farr(head_stride), _p(gt), N, P, E - 5,
+         gt.shape[1], float(scales[0]), float(scales[1]), float(scales[2]), float(scales[3]), float(grad_scale), _p(loss_parts),
+         _ptr_array(d_preds), _p(ws), _stream())
+
+
+def yolov3_decode_candidates(preds, priors_flat, decode_scale):
+    """YOLOv3.py:320-350 for one image (three [H,W,P,C+5] tensors); returns confidence [L,C], bbox [L,4]."""
+    dev = preds[0].device
+    P, E = preds[0].shape[-2], preds[0].shape[-1]
+    L = sum(p.shape[0] * p.shape[1] * P for p in preds)
+    conf = torch.empty(L, E - 5, device=dev)
+    bbox = torch.empty(L, 4, device=dev)
+    call("odtk_yolov3_decode_candidates", _ptr_array(preds), _yolo_shapes(preds), _farr(priors_flat), _farr(decode_scale), P, E - 5,
+         _p(conf), _p(bbox), _stream())
+    return conf, bbox

@@ -146,3 +146,63 @@ def test_fcos_decode_candidates(dev):
     assert float((pc.cpu() - rc).abs().max()) <= 1e-6
     assert torch.equal(pb.cpu(), rb)                                  # pure add / multiply: bit-exact
     assert np.abs(pc.cpu().numpy()[::3] - g['pconf']).max() <= 1e-6 and np.array_equal(pb.cpu().numpy()[::3], g['pbbox'])
+
+
+# ------------------------------------------------------------------------------------------------ YOLOv3
+from oracle import yolov3_ref as YR  # noqa: E402
+
+
+def _yolo_priors_flat():
+    return [float(v) for l in YR.head_priors() for v in l.reshape(-1).tolist()]
+
+
+def _yolo_case(preds, gt, dev):
+    ops = _ops()
+    N = gt.shape[0]
+    pd = [p.to(dev).contiguous() for p in preds]
+    parts = torch.zeros(N, 5, device=dev)
+    dp = [torch.full_like(p, 7.0) for p in pd]
+    ws = ops.yolov3_workspace(pd, N, dev)
+    ops.yolov3_loss(pd, _yolo_priors_flat(), YR.HEAD_STRIDE, gt.to(dev), (1., 1., 5., 1.), 1.0 / N, parts, dp, ws)
+    torch.cuda.synchronize()
+    pr = [p.clone().requires_grad_(True) for p in preds]
+    dets = [YR.one_image_loss([p[i] for p in pr], gt[i], detail=True) for i in range(N)]
+    torch.stack([d['total'] for d in dets]).mean().backward()
+    got = parts.cpu()
+    for i, d in enumerate(dets):
+        for j, key in enumerate(('coord', 'cls', 'obj', 'noobj', 'total')):
+            r = float(d[key].detach())
+            assert abs(float(got[i, j]) - r) <= 3e-5 * abs(r) + 1e-5, (i, key, float(got[i, j]), r)
+    scale = max(float(p.grad.abs().max()) for p in pr)
+    for l in range(3):
+        assert float((dp[l].cpu() - pr[l].grad).abs().max()) <= 2e-5 * scale, l
+    return got
+
+
+def test_yolov3_loss_golden_inputs(dev):
+    g = np.load(os.path.join(GOLD, 'yolov3_loss.npz'))
+    preds = [torch.from_numpy(g[f'pred{l + 1}'].astype(np.float32)) for l in range(3)]
+    got = _yolo_case(preds, torch.from_numpy(g['gt']), dev)
+    for i in range(got.shape[0]):                                     # and directly against the reference's numbers
+        assert abs(float(got[i, 4]) - float(g['loss'][i])) <= 5e-5 * abs(float(g['loss'][i]))
+
+
+def test_yolov3_loss_config4_shape(dev):
+    """BASELINE config 4 geometry: 416 x 416 -> 13 / 26 / 52 grids x 3 priors = 10 647 predictions, 20 classes."""
+    g = torch.Generator().manual_seed(17)
+    N = 3
+    preds = [torch.randn(N, h, h, 3, 25, generator=g) * 1.2 for h in (13, 26, 52)]
+    assert sum(p.shape[1] * p.shape[2] * 3 for p in preds) == 10647
+    _yolo_case(preds, YR.synthetic_gt(N, 416, 29), dev)
+
+
+def test_yolov3_decode_candidates(dev):
+    ops = _ops()
+    g = np.load(os.path.join(GOLD, 'yolov3_loss.npz'))
+    preds = [torch.from_numpy(g[f'pred{l + 1}'].astype(np.float32))[0] for l in range(3)]
+    conf, box = ops.yolov3_decode_candidates([p.to(dev).contiguous() for p in preds], _yolo_priors_flat(), [32., 32., 16.])
+    rc, rb = YR.decode_candidates(preds)
+    assert float((conf.cpu() - rc).abs().max()) <= 1e-6
+    assert float((box.cpu() - rb).abs().max()) <= 1e-3 * 32 / 16         # exp / sigmoid round-off x stride
+    assert np.abs(conf.cpu().numpy()[::3] - g['confidence']).max() <= 1e-6
+    assert np.abs(box.cpu().numpy()[::3] - g['bbox']).max() <= 2e-3

@@ -1336,8 +1336,9 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
 
 }  // namespace
 
-// per-device f32 scratch of the split-K path, grown on demand (never freed; calls are stream-ordered by the caller
-// like everything else in this library; it must have reached its final size before a stream capture)
+// per-device f32 scratch of the split-K path, grown on demand.  Calls are stream-ordered by the caller like everything
+// else in this library.  A buffer that was handed out is NEVER freed or moved: a captured HIP graph may still replay
+// kernels that point into it, so growth allocates a new, at least twice as large buffer and retires the old one.
 struct ConvScratchOwner { void* base = nullptr; size_t bytes = 0; };
 static ConvScratchOwner g_conv_scratch[16];
 static int conv_scratch(size_t bytes, float** out) {
@@ -1346,11 +1347,11 @@ static int conv_scratch(size_t bytes, float** out) {
     ODTK_REQUIRE(dev >= 0 && dev < 16, "conv: device index %d unsupported", dev);
     ConvScratchOwner& o = g_conv_scratch[dev];
     if (o.bytes < bytes) {
-        if (o.base) { ODTK_CHECK_HIP(hipDeviceSynchronize()); ODTK_CHECK_HIP(hipFree(o.base)); }
-        o.base = nullptr; o.bytes = 0;
-        const size_t want = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes;
-        ODTK_CHECK_HIP(hipMalloc(&o.base, want));
-        o.bytes = want;
+        size_t want = o.bytes ? 2 * o.bytes : ((size_t)64 << 20);
+        if (want < bytes) want = bytes;
+        void* p = nullptr;
+        ODTK_CHECK_HIP(hipMalloc(&p, want));          // fails inside a stream capture: run one eager step first
+        o.base = p; o.bytes = want;
     }
     *out = (float*)o.base;
     return ODTK_OK;

@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 // ---------------------------------------------------------------------------------------
 // gather kernel (forward conv, stride-1 dgrad)
 // ---------------------------------------------------------------------------------------
-template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false, bool SPLIT = false>
+template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false, bool SPLIT = false, bool ILV = false>
 __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
     constexpr int QT = 256;
     constexpr int PI = PT / 64, QI = 2, PL = PT / 64;
@@ -318,6 +318,88 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
             block_barrier();                              // slab kt+2 published; slab kt fully consumed
             st_c = st_1;
         }
+    } else if (ILV && C64 && BUF) {
+    // Interleaved variant: the NDMA pieces of slab kt+2 and the fragment reads of sub-step ks+1 are dealt out
+    // one at a time BETWEEN the MFMAs of slab kt (sched_barrier pins the order), so no wave ever sits in a burst
+    // of DMA issues while the matrix pipe of its SIMD drains, and the L1/TA path sees a steady trickle.
+    issue(0);
+    if (nk > 1) issue(1);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int prow0 = wp * (PT / 2), qrow0 = wq * 64;
+    unsigned pofs[PI], qofs[QI];                        // LDS byte offsets of this lane's fragment rows (slot 0)
+#pragma unroll
+    for (int i = 0; i < PI; ++i) { const int row = prow0 + i * 32 + l31; pofs[i] = (unsigned)(row * 128) | ((unsigned)swz_g(row) << 16); }
+#pragma unroll
+    for (int j = 0; j < QI; ++j) { const int row = qrow0 + j * 32 + l31; qofs[j] = (unsigned)(row * 128) | ((unsigned)swz_g(row) << 16); }
+    int st_c = 0, st_n = 2;
+    auto slab = [&](auto ISSUE, int stage_c, int stage_n) __attribute__((always_inline)) {
+        constexpr bool do_issue = decltype(ISSUE)::value;
+        const char* sP = smem + stage_c * STAGE;
+        const char* sQ = sP + PT * 128;
+        uint4 pf[2][PI], qf[2][QI];
+        auto rd = [&](int ks, int r) __attribute__((always_inline)) {       // read #r of sub-step ks: P0.., then Q0..
+            const int slot = ks * 2 + hi;
+            if (r < PI) pf[ks & 1][r] = *reinterpret_cast<const uint4*>(sP + (pofs[r] & 0xFFFFu) + (((unsigned)slot ^ (pofs[r] >> 16)) << 4));
+            else qf[ks & 1][r - PI] = *reinterpret_cast<const uint4*>(sQ + (qofs[r - PI] & 0xFFFFu) + (((unsigned)slot ^ (qofs[r - PI] >> 16)) << 4));
+        };
+        // DMA pieces of this wave: 0..3 pixel rows r0 + 64 i, 4.. filter rows
+        const unsigned dP = smem_base + (unsigned)stage_n * STAGE + wave_u * 1024u;
+        const unsigned dQ = dP + PT * 128;
+        const int sr = a.idiv == 2 ? (s_kr + 1) >> 1 : s_kr * a.dil, ss = a.idiv == 2 ? (s_ks + 1) >> 1 : s_ks * a.dil;
+        const unsigned toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + s_kc * 2);
+        const unsigned tapbit = 1u << (s_kr * a.S + s_ks);
+        const unsigned woff = (unsigned)(s_klin * 2);
+        auto piece = [&](int q) __attribute__((always_inline)) {
+            if (q < 4) {
+                const unsigned addr = qoff32[q] + toff32;
+                glds16_buf_nc(rx, (qmask[q] & tapbit) ? addr : 0xFFFFFFF0u, dQ + q * 8192u);
+            } else {
+                const unsigned addr = poff32[q - 4] + woff;
+                glds16_buf_nc(rw, pok[q - 4] ? addr : 0xFFFFFFF0u, dP + (q - 4) * 8192u);
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < PI + QI; ++r) rd(0, r);
+        static_for<4>([&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+#pragma unroll
+            for (int i = 0; i < PI; ++i)
+#pragma unroll
+                for (int j = 0; j < QI; ++j) {
+                    const int mi = i * QI + j;                       // MFMA # inside the sub-step
+                    const int slotno = ks * (PI * QI) + mi;          // ... inside the slab (0..4*PI*QI-1)
+                    Mma<bf16_t>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
+                    if (ks < 3) {
+#pragma unroll
+                        for (int r = 0; r < PI + QI; ++r)
+                            if (r * (PI * QI) / (PI + QI) == mi) rd(ks + 1, r);
+                    }
+                    if (do_issue) {                                  // piece q goes out behind MFMA slot q * T / NDMA
+#pragma unroll
+                        for (int q = 0; q < NDMA; ++q)
+                            if (q * (4 * PI * QI) / NDMA == slotno) piece(q);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        });
+        if (do_issue) {
+            s_klin += 64;
+            s_kc += 64;
+            if (s_kc >= a.C) {
+                s_kc = 0;
+                if (++s_ks == a.S) { s_ks = 0; ++s_kr; }
+            }
+        }
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (kt + 2 < nk) slab(std::integral_constant<bool, true>{}, st_c, st_n);
+        else slab(std::integral_constant<bool, false>{}, st_c, st_n);
+        st_c = st_c == 2 ? 0 : st_c + 1;
+        st_n = st_n == 2 ? 0 : st_n + 1;
+    }
+    block_barrier();
     } else {
     issue(0);
     if (nk > 1) issue(1);
@@ -1400,9 +1482,11 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     const bool early = (a.dbg & 128) != 0;  // "landed one slab early" protocol (dbg bit 7, A/B)
     const bool buf = (a.dbg & 256) == 0;    // buffer-addressed DMA (default on; dbg bit 8 = 64-bit global addressing, A/B)
     const bool c64 = a.C % 64 == 0 && a.Kdim % 64 == 0 && (a.dbg & 4096) == 0;   // wave-uniform tap walk (dbg bit 12 = per-lane walk, A/B)
+    const bool ilv = (a.dbg & 16384) != 0;  // interleaved slab body (dbg bit 14, A/B)
 #define ODTK_V3(PT_) \
     do { \
-        if (buf && c64) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, true, true>), dim3(grid), dim3(512), 0, st, a); \
+        if (buf && c64 && ilv) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, true, true, false, true>), dim3(grid), dim3(512), 0, st, a); \
+        else if (buf && c64) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, true, true>), dim3(grid), dim3(512), 0, st, a); \
         else if (buf) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, true>), dim3(grid), dim3(512), 0, st, a); \
         else if (early) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, true, false>), dim3(grid), dim3(512), 0, st, a); \
         else if (db) hipLaunchKernelGGL((conv_gather_v3_kernel<PT_, true, false, false>), dim3(grid), dim3(512), 0, st, a); \

@@ -67,10 +67,11 @@ V3_EXTRA_CASES = [
 ]
 
 
-@pytest.fixture(params=[(2, 0), (3, 0), (2, 256)], ids=["v3-8wave", "v4-persistent", "v3-bufdma"])
+@pytest.fixture(params=[(2, 0), (3, 0), (2, 256), (2, 16384), (2, 8192)], ids=["v3-8wave", "v4-persistent", "v3-globaldma", "v3-interleaved", "v3-nosplitk"])
 def v3_engine(request):
     """Force the 8-wave (2) / persistent wave-specialised (3) conv kernels wherever they are
-    supported (odtk_debug_set key 1); key 2 bit 8 selects the buffer-addressed LDS-DMA variant."""
+    supported (odtk_debug_set key 1); key 2 bit 8 selects 64-bit global addressing for the LDS-DMA, bit 14 the
+    interleaved slab body, bit 13 turns split-K off."""
     ops = _ops()
     ops.debug_set(1, request.param[0])
     ops.debug_set(2, request.param[1])

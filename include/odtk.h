@@ -244,6 +244,11 @@ int odtk_retina_loss(const float* pconf, const float* pbox, int N, int A, int C,
                      const float* hw, const float* gt, int P, const int* ngt, const int* best,
                      const unsigned char* status, const int* rgindex, const int* counts, float alpha,
                      float gamma, float grad_scale, float* loss_parts, float* dconf, float* dbox, void* stream);
+/* RetinaNet inference branch up to the per-class NMS loop (RetinaNet.py:224-238): softmax, background-arg-max mask,
+ * box decode; outputs as odtk_ssd_decode (conf [A][C-1], boxes [A][4] y1,x1,y2,x2, keep [A], cand [A][C-1]). */
+int odtk_retina_decode(const float* pconf, const float* pbox, int A, int C, const float* yx, const float* hw,
+                       float score_thr, float* conf, float* boxes, unsigned char* keep, unsigned char* cand,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CenterNet box side: replaces CenterNet._compute_one_image_loss / _keypoints_loss /

@@ -69,6 +69,7 @@ SIGNATURES = {
     "odtk_retina_match_workspace_bytes": (_ll, [_i, _i, _i]),
     "odtk_retina_match": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "odtk_retina_loss": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "odtk_retina_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "odtk_centernet_workspace_bytes": (_ll, [_i, _i, _i, _i]),
     "odtk_centernet_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "odtk_centernet_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

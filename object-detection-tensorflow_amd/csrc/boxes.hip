@@ -658,13 +658,17 @@ __global__ void __launch_bounds__(LOSS_THREADS) ssd_loss_kernel(const LossArgs a
 }
 
 // ------------------------------------------------------------------ inference decode
-__global__ void ssd_decode_kernel(const float* __restrict__ pred, int A, int C, int ld, const float* __restrict__ yx,
+// `box` / `ldb`: the 4 box regressions of anchor a are box[a * ldb .. +3] (SSD300: pred + C with the row pitch of
+// pred; RetinaNet: its own [A][4] tensor)
+__global__ void ssd_decode_kernel(const float* __restrict__ pred, int A, int C, int ld, const float* __restrict__ box, int ldb,
+                                  const float* __restrict__ yx,
                                   const float* __restrict__ hw, float thr, float* __restrict__ conf,
                                   float* __restrict__ boxes, unsigned char* __restrict__ keep,
                                   unsigned char* __restrict__ cand) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= A) return;
     const float* z = pred + (size_t)a * ld;
+    const float* zb = box + (size_t)a * ldb;
     float m = z[0];
     for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
     float e[MAXC];
@@ -683,8 +687,8 @@ __global__ void ssd_decode_kernel(const float* __restrict__ pred, int A, int C, 
         cand[(size_t)a * (C - 1) + c] = (kp && e[c] >= thr) ? 1 : 0;
     }
     const float ah = hw[2 * a], aw = hw[2 * a + 1];
-    const float cy = z[C] * ah + yx[2 * a], cx = z[C + 1] * aw + yx[2 * a + 1];
-    const float h = ah * expf(z[C + 2]), w = aw * expf(z[C + 3]);
+    const float cy = zb[0] * ah + yx[2 * a], cx = zb[1] * aw + yx[2 * a + 1];
+    const float h = ah * expf(zb[2]), w = aw * expf(zb[3]);
     boxes[4 * a + 0] = cy - h / 2.f; boxes[4 * a + 1] = cx - w / 2.f;
     boxes[4 * a + 2] = cy + h / 2.f; boxes[4 * a + 3] = cx + w / 2.f;
 }
@@ -836,7 +840,19 @@ extern "C" int odtk_ssd_decode(const float* pred0, int A, int C, int ld, const f
                                unsigned char* cand, void* stream) {
     ODTK_REQUIRE(pred0 && yx && hw && conf && boxes && keep && cand, "ssd_decode: null pointer");
     ODTK_REQUIRE(C > 1 && C <= MAXC && ld >= C + 4, "ssd_decode: C=%d ld=%d unsupported", C, ld);
-    hipLaunchKernelGGL(ssd_decode_kernel, dim3(ceil_div(A, 256)), dim3(256), 0, (hipStream_t)stream, pred0, A, C, ld, yx,
+    hipLaunchKernelGGL(ssd_decode_kernel, dim3(ceil_div(A, 256)), dim3(256), 0, (hipStream_t)stream, pred0, A, C, ld, pred0 + C, ld, yx,
+                       hw, score_thr, conf, boxes, keep, cand);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+// RetinaNet inference branch up to the per-class NMS loop (RetinaNet.py:224-238): same arithmetic, separate tensors
+extern "C" int odtk_retina_decode(const float* pconf, const float* pbox, int A, int C, const float* yx, const float* hw,
+                                  float score_thr, float* conf, float* boxes, unsigned char* keep, unsigned char* cand,
+                                  void* stream) {
+    ODTK_REQUIRE(pconf && pbox && yx && hw && conf && boxes && keep && cand, "retina_decode: null pointer");
+    ODTK_REQUIRE(C > 1 && C <= MAXC && A > 0, "retina_decode: C=%d A=%d unsupported", C, A);
+    hipLaunchKernelGGL(ssd_decode_kernel, dim3(ceil_div(A, 256)), dim3(256), 0, (hipStream_t)stream, pconf, A, C, C, pbox, 4, yx,
                        hw, score_thr, conf, boxes, keep, cand);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;

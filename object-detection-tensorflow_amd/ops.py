@@ -247,6 +247,18 @@ def retina_loss(pconf, pbox, yx, hw, gt, ngt, best, status, rgindex, counts, alp
          _p(dbox), _stream())
 
 
+def retina_decode(pconf, pbox, yx, hw, thr):
+    """RetinaNet.py:224-238 for one image: pconf [A,C], pbox [A,4] -> conf [A,C-1], boxes [A,4], keep [A], cand [A,C-1]."""
+    A, Cn = pconf.shape
+    dev = pconf.device
+    conf = torch.empty(A, Cn - 1, device=dev)
+    boxes = torch.empty(A, 4, device=dev)
+    keep = torch.empty(A, dtype=torch.uint8, device=dev)
+    cand = torch.empty(A, Cn - 1, dtype=torch.uint8, device=dev)
+    call("odtk_retina_decode", _p(pconf), _p(pbox), A, Cn, _p(yx), _p(hw), float(thr), _p(conf), _p(boxes), _p(keep), _p(cand), _stream())
+    return conf, boxes, keep, cand
+
+
 # ---------------------------------------------------------------------------------------------------------
 # CenterNet / FCOS box side (include/odtk.h; csrc/dense_heads.hip)
 # ---------------------------------------------------------------------------------------------------------

@@ -144,6 +144,19 @@ def batch_loss(p_yx, p_hw, pconf, anc, ground_truth, alpha=0.25, gamma=2.0):
     return loss / n
 
 
+def decode_candidates(p_yx, p_hw, pconf, anc, thr, num_classes=21):
+    """RetinaNet.py:224-238 for one image, dense form: conf [A, C-1] softmax scores, boxes [A, 4] y1x1y2x2,
+    keep [A] = arg-max class is not the background, cand [A, C-1] = keep & conf >= thr."""
+    a_yx, a_hw = anc[2], anc[3]
+    conf = torch.softmax(pconf, dim=-1)
+    keep = torch.argmax(conf, dim=-1) < num_classes - 1
+    yx = p_yx * a_hw + a_yx
+    hw = a_hw * torch.exp(p_hw)
+    boxes = torch.cat([yx - hw / 2., yx + hw / 2.], -1)
+    c = conf[:, :num_classes - 1]
+    return c, boxes, keep, keep.unsqueeze(1) & (c >= thr)
+
+
 def synthetic_gt(batch, input_size, seed, pad=60):
     """VOC-shaped ground truth [B, pad, 5] = [yc, xc, h, w, cls] px, pad rows -1 (image_augmentor.py:24-27)."""
     g = torch.Generator().manual_seed(seed)

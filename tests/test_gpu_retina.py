@@ -122,3 +122,21 @@ def test_retina_loss_and_grad_vs_oracle(data_shape, gamma, dev):
     (tot / N).backward()
     assert float((dconf - pc.grad).abs().max()) <= 1e-6 + 1e-4 * float(pc.grad.abs().max())
     assert float((dbox - pb.grad).abs().max()) <= 1e-6 + 1e-4 * float(pb.grad.abs().max())
+
+
+def test_retina_decode_candidates(dev):
+    """RetinaNet.py:224-238 (same arithmetic as SSD300.py:157-171, pinned there) on the 320x256 anchor set."""
+    ops = _ops()
+    got, shapes = _gpu_anchors(ops, dev, [320, 256, 3])
+    anc = RR.anchors([320, 256, 3], shapes)
+    A = anc[0].shape[0]
+    g = torch.Generator().manual_seed(4)
+    pconf = torch.randn(A, 21, generator=g) * 2
+    pbox = torch.randn(A, 4, generator=g) * 0.5
+    conf, boxes, keep, cand = ops.retina_decode(pconf.to(dev), pbox.to(dev), got[2], got[3], 0.3)
+    rc, rb, rk, rcand = RR.decode_candidates(pbox[:, :2], pbox[:, 2:], pconf, anc, 0.3)
+    assert float((conf.cpu() - rc).abs().max()) <= 1e-6
+    assert float((boxes.cpu() - rb).abs().max()) <= 1e-3
+    near = ((rc - 0.3).abs() < 1e-6).any(dim=1) | ((rc.max(dim=1).values - torch.softmax(pconf, -1)[:, 20]).abs() < 1e-6)
+    assert torch.equal(keep.cpu().bool()[~near], rk[~near])
+    assert torch.equal(cand.cpu().bool()[~near], rcand[~near])

@@ -160,6 +160,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region')
+    ap.add_argument('--wgrad-stream', action='store_true', help='A/B: filter gradients on a second HIP stream')
     ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
     args = ap.parse_args()
 
@@ -183,7 +184,7 @@ def main():
         'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
         'keep_prob': 0.5, 'batch_size': B, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20,
         'nms_iou_threshold': 0.5, 'pretraining_weight': os.path.join('.', 'vgg_16.ckpt'),
-        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0,
+        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream,
     }
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)
@@ -222,7 +223,9 @@ def main():
     # stream (graph replay cannot carry per-kernel events; the kernels and their durations are identical)
     if not args.no_conv_events:
         saved = model.use_graph
+        saved_side = model.wgrad_stream
         model.use_graph = False
+        model.wgrad_stream = None            # one stream: every conv kernel is timed with the chip to itself
         timer.enabled = True
         ev_steps = min(args.steps, 5)
         for _ in range(ev_steps):
@@ -230,6 +233,7 @@ def main():
         torch.cuda.synchronize()
         timer.enabled = False
         model.use_graph = saved
+        model.wgrad_stream = saved_side
     loss = final_loss_t
     if world > 1:
         import torch.distributed as dist

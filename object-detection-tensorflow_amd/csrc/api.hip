@@ -10,6 +10,31 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+namespace {
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint4* __restrict__ p16, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) p16[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+}  // namespace
+
+int zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return ODTK_OK;
+    unsigned char* b = (unsigned char*)p;
+    size_t head = (16 - ((size_t)(uintptr_t)b & 15)) & 15;            // bytes up to the first 16-byte boundary
+    if (head > bytes) head = bytes;
+    if (head) hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(256), 0, st, (uint4*)nullptr, (size_t)0, b, (int)head);
+    const size_t n16 = (bytes - head) / 16, ntail = (bytes - head) % 16;
+    if (n16 || ntail) {
+        size_t blocks = (n16 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (blocks == 0) blocks = 1;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)(b + head), n16, b + head + n16 * 16, (int)ntail);
+    }
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
 }  // namespace odtk
 
 extern "C" const char* odtk_last_error(void) { return odtk::g_err; }

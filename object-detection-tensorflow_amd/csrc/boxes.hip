@@ -824,7 +824,7 @@ extern "C" int odtk_ssd_loss(const float* pred, int N, int A, int C, int ld, con
                  sel_cnt && loss_parts && dpred, "ssd_loss: null pointer");
     ODTK_REQUIRE(C > 1 && C <= MAXC && ld >= C + 4, "ssd_loss: C=%d ld=%d unsupported", C, ld);
     hipStream_t st = (hipStream_t)stream;
-    ODTK_CHECK_HIP(hipMemsetAsync(dpred, 0, (size_t)N * A * ld * sizeof(float), st));
+    if (int e = zero_async(dpred, (size_t)N * A * ld * sizeof(float), st)) return e;
     LossArgs a;
     a.pred = pred; a.N = N; a.A = A; a.C = C; a.ld = ld; a.yx = yx; a.hw = hw; a.gt = gt; a.P = P;
     a.ngt = ngt; a.best = best; a.status = status; a.rgindex = rgindex; a.counts = counts;

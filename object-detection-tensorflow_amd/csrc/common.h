@@ -61,4 +61,9 @@ template <> struct elem<float> {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t dtype_size(int dt) { return dt == ODTK_F32 ? 4 : 2; }
 
+// Stream-ordered zero fill by a kernel of this library.  hipMemsetAsync is NOT used inside entry points: captured
+// into a HIP graph (ROCm 7.2) its memset node was observed to replay with a garbage fill value (the SSD300 step's
+// d(pred) came back as 0x48600000 / 0x70200000 patterns, depending on the host heap layout), api.hip.
+int zero_async(void* p, size_t bytes, hipStream_t st);
+
 }  // namespace odtk

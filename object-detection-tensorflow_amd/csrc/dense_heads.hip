@@ -650,8 +650,8 @@ extern "C" int odtk_centernet_loss(const float* keypoints, const float* offset, 
     a.info = (float*)workspace;
     a.parts = a.info + (size_t)N * 4;
     a.loss_parts = loss_parts; a.d_keypoints = d_keypoints; a.d_offset = d_offset; a.d_size = d_size;
-    ODTK_CHECK_HIP(hipMemsetAsync(d_offset, 0, (size_t)N * H * W * 2 * sizeof(float), st));
-    ODTK_CHECK_HIP(hipMemsetAsync(d_size, 0, (size_t)N * H * W * 2 * sizeof(float), st));
+    if (int e = zero_async(d_offset, (size_t)N * H * W * 2 * sizeof(float), st)) return e;
+    if (int e = zero_async(d_size, (size_t)N * H * W * 2 * sizeof(float), st)) return e;
     hipLaunchKernelGGL(centernet_prep_kernel, dim3(N), dim3(64), 0, st, a);
     hipLaunchKernelGGL(centernet_heat_kernel, dim3(a.nblk, N), dim3(DH_THREADS), 0, st, a);
     hipLaunchKernelGGL(centernet_final_kernel, dim3(N), dim3(DH_THREADS), 0, st, a);
@@ -783,7 +783,7 @@ extern "C" int odtk_yolov3_loss(const float* const* pred, const int* shapes, con
     for (int l = 0; l < YL_HEADS; ++l) {
         ODTK_REQUIRE(d_pred[l], "yolov3_loss: null gradient pointer %d", l);
         a.d_pred[l] = d_pred[l];
-        ODTK_CHECK_HIP(hipMemsetAsync(d_pred[l], 0, (size_t)N * a.H[l] * a.W[l] * num_priors * (C + 5) * sizeof(float), st));
+        if (int e = zero_async(d_pred[l], (size_t)N * a.H[l] * a.W[l] * num_priors * (C + 5) * sizeof(float), st)) return e;
     }
     a.gt = gt; a.pad = pad; a.coord_scale = coord_scale; a.noobj_scale = noobj_scale; a.obj_scale = obj_scale;
     a.class_scale = class_scale; a.grad_scale = grad_scale; a.parts = (float*)workspace; a.loss_parts = loss_parts;

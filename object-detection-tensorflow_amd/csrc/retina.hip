@@ -402,7 +402,7 @@ extern "C" int odtk_retina_match(const float* y1x1, const float* y2x2, const flo
     float* part_iou = maxiou + (size_t)N * A;
     int* part_idx = (int*)(part_iou + (size_t)N * ntile * P);
     hipStream_t st = (hipStream_t)stream;
-    ODTK_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)N * 4 * sizeof(int), st));
+    if (int e = zero_async(counts, (size_t)N * 4 * sizeof(int), st)) return e;
     hipLaunchKernelGGL(retina_iou_kernel, dim3(ceil_div(ntile, RL_TILES_PER_BLOCK), N), dim3(RL_THREADS), 0, st, y1x1, y2x2, hw, A, gt, P, maxiou, rgindex,
                        part_iou, part_idx, status, counts);
     hipLaunchKernelGGL(retina_status_kernel, dim3(N), dim3(RL_THREADS), 0, st, gt, P, A, ntile, part_iou, part_idx, maxiou,
@@ -419,7 +419,7 @@ extern "C" int odtk_retina_loss(const float* pconf, const float* pbox, int N, in
                  "retina_loss: null pointer");
     ODTK_REQUIRE(C > 1 && C <= RL_MAXC && P > 0 && P <= RL_MAX_GT, "retina_loss: C=%d P=%d unsupported", C, P);
     hipStream_t st = (hipStream_t)stream;
-    ODTK_CHECK_HIP(hipMemsetAsync(loss_parts, 0, (size_t)N * 2 * sizeof(float), st));
+    if (int e = zero_async(loss_parts, (size_t)N * 2 * sizeof(float), st)) return e;
     RLossArgs a;
     a.pconf = pconf; a.pbox = pbox; a.N = N; a.A = A; a.C = C; a.yx = yx; a.hw = hw; a.gt = gt; a.P = P;
     a.ngt = ngt; a.best = best; a.status = status; a.rgindex = rgindex; a.counts = counts;

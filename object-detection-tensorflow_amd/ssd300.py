@@ -138,6 +138,10 @@ class SSD300:
                 self.val_generator = data_provider['val_generator']
         self.global_step = 0
         self.use_graph = bool(config.get('use_graph', True))   # HIP-graph replay of the step after 2 eager steps
+        # optional: filter gradients on a second HIP stream (wgrad(L) only needs dy(L) and the stored input of L, nothing
+        # on the dgrad chain needs its result before the optimizer).  Measured neutral on MI355X (both chains are
+        # full-chip kernels with one workgroup per CU), so it is off by default; config key 'wgrad_stream'.
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if config.get('wgrad_stream', False) else None
         self._g_front = self._g_back = None
         self._eager_steps = 0
         self.dist = None                       # set by attach_data_parallel()
@@ -465,7 +469,13 @@ class SSD300:
         it is left at zero and only sees weight decay."""
         d = self.desc[name]
         dbias = None if self.convs[name].bn else self._grad(name + '.b')
-        ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
+        side = self.wgrad_stream if self.dist is None else None      # DP: the bucket hooks order on the main stream
+        if side is None:
+            ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
+            return
+        side.wait_stream(torch.cuda.current_stream())                 # dy(L) is complete at this point of the main stream
+        with torch.cuda.stream(side):
+            ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
 
     def _backward(self):
         a = self.acts
@@ -514,6 +524,8 @@ class SSD300:
                 if name != 'conv1_1':
                     ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
                 ready(name)
+        if self.wgrad_stream is not None and self.dist is None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)     # join before the optimizer
 
     def _mark_ready(self, layer_name):
         if self.dist is not None:

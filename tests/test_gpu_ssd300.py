@@ -144,3 +144,35 @@ def test_graph_replay_equals_eager_launches(dev):
     assert abs(a[2] - b[2]) <= 3e-3 * abs(a[2]), (a, b)                                       # first replay
     assert abs(a[3] - b[3]) <= 3e-2 * abs(a[3]), (a, b)
     assert b[-1] < b[0]                                  # it trains
+
+
+@pytest.mark.parametrize("side_stream", [False, True], ids=["one-stream", "wgrad-stream"])
+def test_graph_replay_gradients_match_eager_under_allocation_churn(side_stream, dev):
+    """lr = 0 keeps the weights fixed, so every step must reproduce the gradient buffer of the first (eager) step
+    -- also when it is replayed from HIP graphs while the caller keeps allocating device memory between steps.
+    Regression: a hipMemsetAsync captured inside odtk_ssd_loss replayed with a garbage fill value on ROCm 7.2 (the
+    library now zero-fills with its own kernel), which scaled the whole gradient by 1e10..1e30 on some host heap layouts."""
+    import odtk
+    B = 8
+    cfg = dict(CONFIG, compute_dtype='bf16', batch_size=B, wgrad_stream=side_stream, use_graph=True, seed=0)
+    imgs, gt = R.synthetic_batch(B, 5)
+    m = odtk.SSD300(cfg, None if False else {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [],
+                                              'val_generator': None})
+    m.set_batch(imgs, gt)
+    keep = []
+    ref = None
+    for step in range(7):
+        m.train_step(0.0)
+        torch.cuda.synchronize()
+        g = m.G.clone()
+        keep.append(g)                                        # allocation churn: 105 MB per step stays alive
+        keep.append(torch.empty(3_000_001, device=dev))
+        if ref is None:
+            ref = g
+            continue
+        assert torch.isfinite(g).all(), step
+        for name, (off, shape) in m.pinfo.items():
+            n = int(np.prod(shape))
+            a, b = g[off:off + n], ref[off:off + n]
+            assert float((a - b).abs().max()) <= 2e-2 * (float(b.abs().max()) + 1e-12), (step, name)
+    assert m._g_front is not None                              # steps 2.. were graph replays

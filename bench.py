@@ -139,11 +139,16 @@ def pmc_traffic(kernel):
         except Exception:                                         # noqa: BLE001
             continue
         want_pt = kernel.split('<')[1].split('>')[0].split(',')[0] if '<' in kernel else None
+        best = None
         for name, e in d.items():
             if base not in name or 'hbm_read_bytes_corrected' not in e or 'hbm_write_bytes' not in e:
                 continue
             if want_pt is not None and '<' in name and name.split('<')[1].split(',')[0].split('>')[0].strip() != want_pt:
                 continue
+            if best is None or e.get('_dispatches', 0) > best[1].get('_dispatches', 0):
+                best = (name, e)                      # the template variant that carries most of the launches
+        if best is not None:
+            name, e = best
             return {'hbm_read_bytes': int(e['hbm_read_bytes_corrected']), 'hbm_write_bytes': int(e['hbm_write_bytes']),
                     'hbm_bytes': int(e['hbm_read_bytes_corrected'] + e['hbm_write_bytes']),
                     'source': os.path.relpath(f, ROOT) + ' :: ' + name}

@@ -118,6 +118,13 @@ int odtk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int ld,
 int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, void* dx, int N, int H, int W,
                      int C, int ld, int Ho, int Wo, int k, int stride, int pad_t, int pad_l,
                      int dtype, void* stream);
+/* 2x2 / stride 2 / SAME (pad_before 0) pooling with a recorded arg-max (pool1..pool4): idx holds one uint16 per 16-byte
+ * output chunk (2 bits per channel = the first window position holding the maximum, TF's gradient routing); the backward
+ * pass then reads dy + idx only.  Results are identical to odtk_maxpool_fwd / _bwd. */
+int odtk_maxpool2x2_fwd_idx(const void* x, void* y, void* idx, int N, int H, int W, int C, int ld, int Ho, int Wo,
+                            int dtype, void* stream);
+int odtk_maxpool2x2_bwd_idx(const void* idx, const void* dy, void* dx, int N, int H, int W, int C, int ld, int Ho,
+                            int Wo, int dtype, void* stream);
 
 /* tf.layers.batch_normalization, fused semantics (SSD300.py:506-512), momentum .99 eps 1e-3.
  * z [M][ldz] (dtype) -> y.  Output row m is written at y + (m / rows_per_img)*y_img_stride

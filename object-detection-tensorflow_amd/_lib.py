@@ -45,6 +45,8 @@ SIGNATURES = {
     "odtk_preprocess": (_i, [_vp, _ll, C.POINTER(_f), _i, _i, _vp, _vp]),
     "odtk_maxpool_fwd": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
     "odtk_maxpool_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "odtk_maxpool2x2_fwd_idx": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "odtk_maxpool2x2_bwd_idx": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "odtk_bn_workspace_bytes": (_ll, [_i, _i]),
     "odtk_bn_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _ll,
                          _vp, _vp]),

@@ -575,6 +575,7 @@ struct LossArgs {
     const int* ngt; const int* best; const unsigned char* status; const int* rgindex; const int* counts;
     const float* negloss; const int* sel_idx; int sel_cap; const int* sel_cnt;
     float grad_scale; float* loss_parts; float* dpred;
+    float* parts;      // [N][LOSS_SPLIT][3] partial sums (library scratch)
 };
 
 // one positive row: CE vs label, smooth-L1 on (yx, hw); adds its gradient into dpred
@@ -614,9 +615,13 @@ __device__ __forceinline__ void positive_row(const LossArgs& a, int n, int ancho
     coord_sum += cl;
 }
 
+// LOSS_SPLIT workgroups per image (one per image left 224 CUs idle for 150 us): workgroup s takes the selected
+// negatives i = s (mod LOSS_SPLIT), the anchors of its contiguous slice, and (s == 0) the G best-anchor rows; the three
+// sums go to a.parts and ssd_loss_final_kernel adds them in fixed order (deterministic loss).
+constexpr int LOSS_SPLIT = 8;
 __global__ void __launch_bounds__(LOSS_THREADS) ssd_loss_kernel(const LossArgs a) {
     __shared__ float sm[LOSS_THREADS / 64];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
     const int G = a.ngt[n];
     const int num_pos = a.counts[n * 4 + 0];
     const int nsel = a.sel_cnt[n];
@@ -624,7 +629,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) ssd_loss_kernel(const LossArgs a
     // selected negatives (SSD300.py:434)
     float neg_sum = 0.f;
     const float inv_ns = 1.f / (float)nsel;
-    for (int i = tid; i < nsel; i += LOSS_THREADS) {
+    for (int i = s + LOSS_SPLIT * tid; i < nsel; i += LOSS_SPLIT * LOSS_THREADS) {
         const int anchor = a.sel_idx[(size_t)n * a.sel_cap + i];
         neg_sum += a.negloss[(size_t)n * a.A + anchor];
         const float* z = a.pred + ((size_t)n * a.A + anchor) * a.ld;
@@ -632,29 +637,45 @@ __global__ void __launch_bounds__(LOSS_THREADS) ssd_loss_kernel(const LossArgs a
         float m = z[0];
         for (int c = 1; c < a.C; ++c) m = fmaxf(m, z[c]);
         float e[MAXC];
-        float s = 0.f;
-        for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - m); s += e[c]; }
+        float sum = 0.f;
+        for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - m); sum += e[c]; }
         const float gsc = a.grad_scale * inv_ns;
-        for (int c = 0; c < a.C; ++c) atomicAdd(dz + c, (e[c] / s - (c == bg ? 1.f : 0.f)) * gsc);
+        for (int c = 0; c < a.C; ++c) atomicAdd(dz + c, (e[c] / sum - (c == bg ? 1.f : 0.f)) * gsc);
     }
     // positives: the G best-anchor rows, then every status==1 anchor (SSD300.py:436-450)
     float ce_sum = 0.f, coord_sum = 0.f;
     const float inv_np = 1.f / (float)num_pos;
-    for (int g = tid; g < G; g += LOSS_THREADS)
-        positive_row(a, n, a.best[(size_t)n * a.P + g], g, inv_np, ce_sum, coord_sum);
-    for (int anchor = tid; anchor < a.A; anchor += LOSS_THREADS)
+    if (s == 0)
+        for (int g = tid; g < G; g += LOSS_THREADS)
+            positive_row(a, n, a.best[(size_t)n * a.P + g], g, inv_np, ce_sum, coord_sum);
+    const int per = (a.A + LOSS_SPLIT - 1) / LOSS_SPLIT;
+    const int a1 = min(a.A, (s + 1) * per);
+    for (int anchor = s * per + tid; anchor < a1; anchor += LOSS_THREADS)
         if (a.status[(size_t)n * a.A + anchor] == 1)
             positive_row(a, n, anchor, a.rgindex[(size_t)n * a.A + anchor], inv_np, ce_sum, coord_sum);
     neg_sum = block_sum(neg_sum, sm);
     ce_sum = block_sum(ce_sum, sm);
     coord_sum = block_sum(coord_sum, sm);
     if (tid == 0) {
-        const float neg = neg_sum / (float)nsel;              // mean of empty -> NaN, as TF
-        const float pc = ce_sum / (float)num_pos;
-        const float co = coord_sum / (float)num_pos;
-        float* o = a.loss_parts + (size_t)n * 4;
-        o[0] = neg; o[1] = pc; o[2] = co; o[3] = neg + pc + co;
+        float* o = a.parts + ((size_t)n * LOSS_SPLIT + s) * 3;
+        o[0] = neg_sum; o[1] = ce_sum; o[2] = coord_sum;
     }
+}
+
+__global__ void __launch_bounds__(64) ssd_loss_final_kernel(const LossArgs a) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= a.N) return;
+    float neg_sum = 0.f, ce_sum = 0.f, coord_sum = 0.f;
+    for (int s = 0; s < LOSS_SPLIT; ++s) {
+        const float* o = a.parts + ((size_t)n * LOSS_SPLIT + s) * 3;
+        neg_sum += o[0]; ce_sum += o[1]; coord_sum += o[2];
+    }
+    const int num_pos = a.counts[n * 4 + 0], nsel = a.sel_cnt[n];
+    const float neg = neg_sum / (float)nsel;              // mean of empty -> NaN, as TF
+    const float pc = ce_sum / (float)num_pos;
+    const float co = coord_sum / (float)num_pos;
+    float* o = a.loss_parts + (size_t)n * 4;
+    o[0] = neg; o[1] = pc; o[2] = co; o[3] = neg + pc + co;
 }
 
 // ------------------------------------------------------------------ inference decode
@@ -693,6 +714,18 @@ __global__ void ssd_decode_kernel(const float* __restrict__ pred, int A, int C, 
     boxes[4 * a + 2] = cy + h / 2.f; boxes[4 * a + 3] = cx + w / 2.f;
 }
 
+
+// per-device scratch of the loss partial sums: one fixed allocation (never moved: captured graphs point into it)
+static float* g_loss_scratch[16];
+constexpr int LOSS_SCRATCH_IMAGES = 16384;
+static int loss_scratch(int N, float** out) {
+    int dev = 0;
+    ODTK_CHECK_HIP(hipGetDevice(&dev));
+    ODTK_REQUIRE(dev >= 0 && dev < 16 && N <= LOSS_SCRATCH_IMAGES, "ssd_loss: device %d / batch %d unsupported", dev, N);
+    if (!g_loss_scratch[dev]) ODTK_CHECK_HIP(hipMalloc((void**)&g_loss_scratch[dev], (size_t)LOSS_SCRATCH_IMAGES * LOSS_SPLIT * 3 * sizeof(float)));
+    *out = g_loss_scratch[dev];
+    return ODTK_OK;
+}
 
 static bool g_nms_legacy = false;      // odtk_debug_set key 3
 // per-device scratch of the split NMS path, grown on demand (never freed; reused by every call on
@@ -830,7 +863,9 @@ extern "C" int odtk_ssd_loss(const float* pred, int N, int A, int C, int ld, con
     a.ngt = ngt; a.best = best; a.status = status; a.rgindex = rgindex; a.counts = counts;
     a.negloss = negloss; a.sel_idx = sel_idx; a.sel_cap = sel_cap; a.sel_cnt = sel_cnt;
     a.grad_scale = grad_scale; a.loss_parts = loss_parts; a.dpred = dpred;
-    hipLaunchKernelGGL(ssd_loss_kernel, dim3(N), dim3(LOSS_THREADS), 0, st, a);
+    if (int e = loss_scratch(N, &a.parts)) return e;
+    hipLaunchKernelGGL(ssd_loss_kernel, dim3(N, LOSS_SPLIT), dim3(LOSS_THREADS), 0, st, a);
+    hipLaunchKernelGGL(ssd_loss_final_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, st, a);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -201,6 +201,77 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const T* __restrict
     }
 }
 
+// 2x2 / stride-2 pooling with a recorded arg-max: the forward pass stores, per output chunk, 2 bits per channel =
+// the FIRST window position (scan order) that holds the maximum; the backward pass then needs neither x nor y:
+// it reads dy + 2 B of index per 16-B chunk and writes the four dx pixels (pool1: 472 MB instead of 922 MB).
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool2x2_fwd_idx_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                 unsigned short* __restrict__ idx, int N, int H, int W, int C,
+                                                                 int ld, int Ho, int Wo) {
+    constexpr int KC = Chunk<T>::N;
+    const int chunks = C / KC;
+    const unsigned total = (unsigned)N * Ho * Wo * chunks;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned ch = i % (unsigned)chunks;
+        unsigned pix = i / (unsigned)chunks;
+        const unsigned wo = pix % (unsigned)Wo; pix /= (unsigned)Wo;
+        const unsigned ho = pix % (unsigned)Ho;
+        const unsigned n = pix / (unsigned)Ho;
+        const int h0 = (int)ho * 2, w0 = (int)wo * 2;
+        float xv[4][KC];
+        bool in[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int hh = h0 + (t >> 1), ww = w0 + (t & 1);
+            in[t] = hh < H && ww < W;
+            if (in[t]) Chunk<T>::unpack(ld16(x + ((size_t)((int)n * H + hh) * W + ww) * ld + ch * KC), xv[t]);
+        }
+        float best[KC];
+        unsigned code = 0;
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            float m = xv[0][e];                       // (h0, w0) is always inside the image
+            int am = 0;
+#pragma unroll
+            for (int t = 1; t < 4; ++t)
+                if (in[t] && xv[t][e] > m) { m = xv[t][e]; am = t; }      // strict >: the first maximum wins
+            best[e] = m;
+            code |= (unsigned)am << (2 * e);
+        }
+        st16(y + ((size_t)(n * Ho + ho) * Wo + wo) * ld + ch * KC, Chunk<T>::pack(best));
+        idx[i] = (unsigned short)code;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool2x2_bwd_idx_kernel(const unsigned short* __restrict__ idx, const T* __restrict__ dy,
+                                                                 T* __restrict__ dx, int N, int H, int W, int C, int ld,
+                                                                 int Ho, int Wo) {
+    constexpr int KC = Chunk<T>::N;
+    const int chunks = C / KC;
+    const unsigned total = (unsigned)N * Ho * Wo * chunks;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned ch = i % (unsigned)chunks;
+        unsigned pix = i / (unsigned)chunks;
+        const unsigned wo = pix % (unsigned)Wo; pix /= (unsigned)Wo;
+        const unsigned ho = pix % (unsigned)Ho;
+        const unsigned n = pix / (unsigned)Ho;
+        const int h0 = (int)ho * 2, w0 = (int)wo * 2;
+        float dv[KC];
+        Chunk<T>::unpack(ld16(dy + ((size_t)(n * Ho + ho) * Wo + wo) * ld + ch * KC), dv);
+        const unsigned code = idx[i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int hh = h0 + (t >> 1), ww = w0 + (t & 1);
+            if (hh >= H || ww >= W) continue;
+            float g[KC];
+#pragma unroll
+            for (int e = 0; e < KC; ++e) g[e] = ((code >> (2 * e)) & 3u) == (unsigned)t ? dv[e] : 0.f;
+            st16(dx + ((size_t)((int)n * H + hh) * W + ww) * ld + ch * KC, Chunk<T>::pack(g));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ column reductions
 // Block = 32 row-lanes x 8 chunk-lanes; grid (column groups of 8 chunks, row splits).
 // Deterministic: partials to ws[slot][split][C], reduced in a fixed order by the consumer.
@@ -748,6 +819,32 @@ extern "C" int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, vo
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
                                            (const T*)x, (const T*)y, (const T*)dy, (T*)dx, N, H, W, C, ld, Ho, Wo, k,
                                            stride, pad_t, pad_l);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_maxpool2x2_fwd_idx(const void* x, void* y, void* idx, int N, int H, int W, int C, int ld, int Ho, int Wo,
+                                       int dtype, void* stream) {
+    ODTK_REQUIRE(x && y && idx, "maxpool2x2_fwd_idx: null pointer");
+    if (int e = pool_check(C, ld, dtype)) return e;
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    const long long tot_o = (long long)N * Ho * Wo * (C / kc);
+    ODTK_REQUIRE(Ho == (H + 1) / 2 && Wo == (W + 1) / 2 && (long long)N * H * W * (C / kc) < (1ll << 31), "maxpool2x2_fwd_idx: bad geometry");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool2x2_fwd_idx_kernel<T>, dim3(grid_for(tot_o, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)x, (T*)y, (unsigned short*)idx, N, H, W, C, ld, Ho, Wo);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_maxpool2x2_bwd_idx(const void* idx, const void* dy, void* dx, int N, int H, int W, int C, int ld, int Ho,
+                                       int Wo, int dtype, void* stream) {
+    ODTK_REQUIRE(idx && dy && dx, "maxpool2x2_bwd_idx: null pointer");
+    if (int e = pool_check(C, ld, dtype)) return e;
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    const long long tot_o = (long long)N * Ho * Wo * (C / kc);
+    ODTK_REQUIRE(Ho == (H + 1) / 2 && Wo == (W + 1) / 2 && (long long)N * H * W * (C / kc) < (1ll << 31), "maxpool2x2_bwd_idx: bad geometry");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool2x2_bwd_idx_kernel<T>, dim3(grid_for(tot_o, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                                           (const unsigned short*)idx, (const T*)dy, (T*)dx, N, H, W, C, ld, Ho, Wo);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -126,6 +126,15 @@ def maxpool_bwd(x, y, dy, dx, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
          dt_of(x), _stream())
 
 
+def maxpool2x2_fwd_idx(x, y, idx, N, H, W, C_, ld, Ho, Wo):
+    """2x2/s2 SAME pooling that also records the arg-max (idx: uint16 per 16-byte output chunk)."""
+    call("odtk_maxpool2x2_fwd_idx", _p(x), _p(y), _p(idx), N, H, W, C_, ld, Ho, Wo, dt_of(x), _stream())
+
+
+def maxpool2x2_bwd_idx(idx, dy, dx, N, H, W, C_, ld, Ho, Wo):
+    call("odtk_maxpool2x2_bwd_idx", _p(idx), _p(dy), _p(dx), N, H, W, C_, ld, Ho, Wo, dt_of(dy), _stream())
+
+
 def bn_workspace_bytes(M, C_):
     return int(_lib.load().odtk_bn_workspace_bytes(M, C_))
 

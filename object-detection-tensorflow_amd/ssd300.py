@@ -300,6 +300,7 @@ class SSD300:
         self.desc = {}
         prev = 'input'
         self.vgg_plan = []
+        self.pool_idx = {}                      # 2x2/s2 pools: recorded arg-max (uint16 per 16-byte output chunk)
         for item in VGG_SEQ:
             name = item[0]
             if name.startswith('conv'):
@@ -313,6 +314,8 @@ class SSD300:
                 Ho, pt, _ = ops.same_pad(H, k, s)
                 self.acts[name] = _Act(N, Ho, Ho, cur_c, cur_c, dt, dev)
                 self.vgg_plan.append(('pool', name, prev, k, s, pt))
+                if k == 2 and s == 2 and pt == 0 and self.mode == 'train' and bool(self.config.get('pool_index', True)):
+                    self.pool_idx[name] = torch.zeros(N * Ho * Ho * (cur_c // ops.chunk(self.DT)), dtype=torch.int16, device=dev)
                 H = Ho
             prev = name
             if name == 'conv4_3':
@@ -418,7 +421,10 @@ class SSD300:
             else:
                 _, name, prev, k, s, pt = step
                 x, y = a[prev], a[name]
-                ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
+                if training and name in self.pool_idx:
+                    ops.maxpool2x2_fwd_idx(x.t, y.t, self.pool_idx[name], x.N, x.H, x.W, x.C, x.ld, y.H, y.W)
+                else:
+                    ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
         c43 = a['conv4_3']
         ops.l2norm_fwd(c43.t, a['feat1'].t, c43.M, 512, c43.ld, self.param('l2norm.gamma'))
         for (name, ci, co, k, s, d) in EXTRA_SEQ:
@@ -511,7 +517,10 @@ class SSD300:
             if step[0] == 'pool':
                 _, name, prev, k, s, pt = step
                 x, y = a[prev], a[name]
-                ops.maxpool_bwd(x.t, y.t, y.g, x.g, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
+                if name in self.pool_idx:
+                    ops.maxpool2x2_bwd_idx(self.pool_idx[name], y.g, x.g, x.N, x.H, x.W, x.C, x.ld, y.H, y.W)
+                else:
+                    ops.maxpool_bwd(x.t, y.t, y.g, x.g, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
                 if prev == 'conv4_3':       # second consumer: L2-norm -> pred1 (accumulate, ReLU mask)
                     f1 = a['feat1']
                     ops.l2norm_bwd(x.t, f1.g, x.g, x.M, 512, x.ld, self.param('l2norm.gamma'),

@@ -225,6 +225,35 @@ def test_maxpool(geom, dt, dev):
         assert abs(float(got.sum() - xr.grad.to(dtype).float().sum())) < 0.05 * float(xr.grad.abs().sum()) + 1.0
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(2, 12, 12, 16), (2, 75, 75, 64), (3, 9, 13, 40), (4, 150, 150, 128)])
+def test_maxpool2x2_recorded_argmax_equals_gather_path(geom, dt, dev):
+    """The arg-max-index pooling pair must reproduce odtk_maxpool_fwd / _bwd bit for bit (incl. bf16 ties: both route
+    to the FIRST maximum in window scan order) on even, odd (SAME pad-after) and non-square maps."""
+    ops = _ops()
+    N, H, W, C = geom
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, W, C, generator=g)
+    if dt == "bf16":
+        x = (x * 4).round() / 4                    # plenty of exact ties
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    xd = to_rows(x, C, dtype, dev)
+    y0 = torch.empty(N * Ho * Wo, C, dtype=dtype, device=dev)
+    y1 = torch.empty_like(y0)
+    idx = torch.zeros(N * Ho * Wo * (C // ops.chunk(ops.F32 if dt == "f32" else ops.BF16)), dtype=torch.int16, device=dev)
+    ops.maxpool_fwd(xd, y0, N, H, W, C, C, Ho, Wo, 2, 2, 0, 0)
+    ops.maxpool2x2_fwd_idx(xd, y1, idx, N, H, W, C, C, Ho, Wo)
+    dy = to_rows(torch.randn(N, Ho, Wo, C, generator=g), C, dtype, dev)
+    dx0 = torch.full_like(xd, 3.0)
+    dx1 = torch.full_like(xd, 5.0)
+    ops.maxpool_bwd(xd, y0, dy, dx0, N, H, W, C, C, Ho, Wo, 2, 2, 0, 0)
+    ops.maxpool2x2_bwd_idx(idx, dy, dx1, N, H, W, C, C, Ho, Wo)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(dx0, dx1)
+
+
 @pytest.mark.parametrize("dt,ydt", [("f32", "f32"), ("bf16", "bf16"), ("bf16", "f32")])
 @pytest.mark.parametrize("shape", [(2 * 19 * 19, 1024, True), (2 * 38 * 38, 100, False), (3 * 5 * 5, 150, False),
                                    (2 * 3 * 3, 256, True),

@@ -449,6 +449,168 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
     epilogue_bf16<PT, QT, 512, PI, QI>(a, smem, acc, p0, q0, wp * (PT / 2), wq * 64, tid);
 }
 
+// ---------------------------------------------------------------------------------------
+// "v5": the same 128 (channels) x 256 (pixels) tile and 3-slab LDS ring on FOUR waves (one per SIMD, 2 x 2, every wave
+// 64 x 128 = 8 MFMA tiles, 128 accumulator registers): 0.75 fragment reads per MFMA instead of 1.0, half as many
+// barrier participants.  One wave per SIMD only overlaps with itself, so the slab body is one scheduling region with
+// the hand-dealt order of the conv1_2 wgrad kernel: per MFMA at most one ds_read_b128 of the next sub-step and, on
+// every third slot, one LDS-DMA piece of slab kt+2.  C % 64 == 0 (wave-uniform tap walk), buffer-addressed DMA.
+// ---------------------------------------------------------------------------------------
+template <int PT>
+__global__ void __launch_bounds__(256) conv_gather_v5_kernel(const GatherArgs a) {
+    constexpr int QT = 256, NTHR = 256;
+    constexpr int PI = PT / 64, QI = 4;                 // wave tile (PT/2) x 128
+    constexpr int NQ = QT / 32, NP = PT / 32;           // DMA pieces per wave and slab: pixel rows r0 + 32 i, filter rows
+    constexpr int NDMA = NQ + NP;
+    constexpr int STAGE = (PT + QT) * 128, NST = 3;
+    constexpr int NMMA = 4 * PI * QI;                   // MFMAs per wave and slab
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave & 1, wq = wave >> 1;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
+    const int p0 = tp * PT, q0 = tq * QT;
+    const int nk = (a.Kdim + 63) >> 6;
+    const int r0 = tid >> 3;                            // DMA rows r0 + 32 i
+    const int cc = (tid & 7) ^ swz_g(r0);
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rw = make_rsrc(a.w, a.w_bytes);
+    unsigned qoff32[NQ], qmask[NQ], poff32[NP];
+    bool pok[NP];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int m = q0 + r0 + 32 * i;
+        qmask[i] = 0; qoff32[i] = 0;
+        if (m < a.M) {
+            const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HoWo;
+            const int ho = (int)fdiv((unsigned)rem, a.div_wo), wo = rem - ho * a.Wo;
+            const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
+            const int hq = a.idiv == 2 ? hb >> 1 : hb, wq2 = a.idiv == 2 ? wb >> 1 : wb;       // stride-2 dgrad: see v3
+            qoff32[i] = (unsigned)(((n * a.H + hq) * a.W + wq2) * a.ldx * 2 + cc * 16);
+            unsigned rm = 0, cm = 0;
+            for (int r = 0; r < a.R; ++r) {
+                const int hn = hb + r * a.dil;
+                if (a.idiv == 2 ? (hn >= 0 && !(hn & 1) && (hn >> 1) < a.H) : (unsigned)hn < (unsigned)a.H) rm |= 1u << r;
+            }
+            for (int s2 = 0; s2 < a.S; ++s2) {
+                const int wn = wb + s2 * a.dil;
+                if (a.idiv == 2 ? (wn >= 0 && !(wn & 1) && (wn >> 1) < a.W) : (unsigned)wn < (unsigned)a.W) cm |= 1u << s2;
+            }
+            unsigned mk = 0;
+            for (int r = 0; r < a.R; ++r)
+                if ((rm >> r) & 1u) mk |= cm << (r * a.S);
+            qmask[i] = mk;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = p0 + r0 + 32 * i;
+        pok[i] = row < a.K;
+        poff32[i] = (unsigned)(row * a.ldw * 2 + cc * 16);
+    }
+    int s_klin = 0, s_kc = 0, s_ks = 0, s_kr = 0;
+    // piece q of slab (s_kr, s_ks, s_kc) into stage `stage`
+    auto piece = [&](int q, unsigned dP, unsigned toff32, unsigned tapbit, unsigned woff) __attribute__((always_inline)) {
+        if (q < NQ) {
+            const unsigned addr = qoff32[q] + toff32;
+            glds16_buf_nc(rx, (qmask[q] & tapbit) ? addr : 0xFFFFFFF0u, dP + PT * 128 + q * 4096u);
+        } else {
+            const unsigned addr = poff32[q - NQ] + woff;
+            glds16_buf_nc(rw, pok[q - NQ] ? addr : 0xFFFFFFF0u, dP + (q - NQ) * 4096u);
+        }
+    };
+    auto slab_consts = [&](int stage, unsigned& dP, unsigned& toff32, unsigned& tapbit, unsigned& woff) __attribute__((always_inline)) {
+        dP = smem_base + (unsigned)stage * STAGE + wave_u * 1024u;
+        const int sr = a.idiv == 2 ? (s_kr + 1) >> 1 : s_kr * a.dil, ss = a.idiv == 2 ? (s_ks + 1) >> 1 : s_ks * a.dil;
+        toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + s_kc * 2);
+        tapbit = 1u << (s_kr * a.S + s_ks);
+        woff = (unsigned)(s_klin * 2);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        s_klin += 64;
+        s_kc += 64;
+        if (s_kc >= a.C) {
+            s_kc = 0;
+            if (++s_ks == a.S) { s_ks = 0; ++s_kr; }
+        }
+    };
+    auto issue_all = [&](int stage) __attribute__((always_inline)) {
+        unsigned dP, toff32, tapbit, woff;
+        slab_consts(stage, dP, toff32, tapbit, woff);
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) piece(q, dP, toff32, tapbit, woff);
+        advance();
+    };
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    issue_all(0);
+    if (nk > 1) issue_all(1);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int prow0 = wp * (PT / 2), qrow0 = wq * 128;
+    unsigned pofs[PI], qofs[QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) { const int row = prow0 + i * 32 + l31; pofs[i] = (unsigned)(row * 128) | ((unsigned)swz_g(row) << 16); }
+#pragma unroll
+    for (int j = 0; j < QI; ++j) { const int row = qrow0 + j * 32 + l31; qofs[j] = (unsigned)(row * 128) | ((unsigned)swz_g(row) << 16); }
+    auto slab = [&](auto ISSUE, int stage_c, int stage_n) __attribute__((always_inline)) {
+        constexpr bool do_issue = decltype(ISSUE)::value;
+        const char* sP = smem + stage_c * STAGE;
+        const char* sQ = sP + PT * 128;
+        uint4 pf[2][PI], qf[2][QI];
+        auto rd = [&](int ks, int r) __attribute__((always_inline)) {       // read #r of sub-step ks: P.., then Q..
+            const int slot = ks * 2 + hi;
+            if (r < PI) pf[ks & 1][r] = *reinterpret_cast<const uint4*>(sP + (pofs[r] & 0xFFFFu) + (((unsigned)slot ^ (pofs[r] >> 16)) << 4));
+            else qf[ks & 1][r - PI] = *reinterpret_cast<const uint4*>(sQ + (qofs[r - PI] & 0xFFFFu) + (((unsigned)slot ^ (qofs[r - PI] >> 16)) << 4));
+        };
+        unsigned dP = 0, toff32 = 0, tapbit = 0, woff = 0;
+        if (do_issue) slab_consts(stage_n, dP, toff32, tapbit, woff);
+#pragma unroll
+        for (int r = 0; r < PI + QI; ++r) rd(0, r);
+        static_for<4>([&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+#pragma unroll
+            for (int j = 0; j < QI; ++j)
+#pragma unroll
+                for (int i = 0; i < PI; ++i) {
+                    const int mi = j * PI + i;                       // MFMA # inside the sub-step (0 .. PI*QI-1)
+                    const int slotno = ks * (PI * QI) + mi;
+                    Mma<bf16_t>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
+                    if (ks < 3) {
+#pragma unroll
+                        for (int r = 0; r < PI + QI; ++r)
+                            if (r * (PI * QI) / (PI + QI) == mi) rd(ks + 1, r);
+                    }
+                    if (do_issue) {
+#pragma unroll
+                        for (int q = 0; q < NDMA; ++q)
+                            if (q * NMMA / NDMA == slotno) piece(q, dP, toff32, tapbit, woff);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        });
+        if (do_issue) advance();
+    };
+    int st_c = 0, st_n = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (kt + 2 < nk) slab(std::integral_constant<bool, true>{}, st_c, st_n);
+        else slab(std::integral_constant<bool, false>{}, st_c, st_n);
+        st_c = st_c == 2 ? 0 : st_c + 1;
+        st_n = st_n == 2 ? 0 : st_n + 1;
+    }
+    block_barrier();
+    epilogue_bf16<PT, QT, NTHR, PI, QI>(a, smem, acc, p0, q0, prow0, qrow0, tid);
+}
+
 // sum of the split-K partial tiles (fixed order -> deterministic) + the epilogue of epilogue_bf16, 8 channels per thread
 __global__ void __launch_bounds__(256) splitk_finish_kernel(const GatherArgs a) {
     const int cpr = a.ldy >> 3;
@@ -1478,6 +1640,10 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     }
     a.ksplit = 1;
     const int grid = tiles;
+    if ((a.dbg & 32768) && PT == 128 && a.C % 64 == 0 && a.Kdim % 64 == 0) {      // 4-wave hand-scheduled variant (dbg bit 15, A/B)
+        hipLaunchKernelGGL(conv_gather_v5_kernel<128>, dim3(grid), dim3(256), 0, st, a);
+        return 0;
+    }
     const bool db = (a.dbg & 32) == 0;      // fragment double buffering (default on; dbg bit 5 turns it off)
     const bool early = (a.dbg & 128) != 0;  // "landed one slab early" protocol (dbg bit 7, A/B)
     const bool buf = (a.dbg & 256) == 0;    // buffer-addressed DMA (default on; dbg bit 8 = 64-bit global addressing, A/B)

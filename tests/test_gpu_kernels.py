@@ -67,7 +67,7 @@ V3_EXTRA_CASES = [
 ]
 
 
-@pytest.fixture(params=[(2, 0), (3, 0), (2, 256), (2, 16384), (2, 8192)], ids=["v3-8wave", "v4-persistent", "v3-globaldma", "v3-interleaved", "v3-nosplitk"])
+@pytest.fixture(params=[(2, 0), (3, 0), (2, 256), (2, 16384), (2, 8192), (2, 32768 + 8192)], ids=["v3-8wave", "v4-persistent", "v3-globaldma", "v3-interleaved", "v3-nosplitk", "v5-4wave"])
 def v3_engine(request):
     """Force the 8-wave (2) / persistent wave-specialised (3) conv kernels wherever they are
     supported (odtk_debug_set key 1); key 2 bit 8 selects 64-bit global addressing for the LDS-DMA, bit 14 the

@@ -1,6 +1,6 @@
 """Debug helper (GPU): per-tensor comparison of one f32/bf16 training step against the oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import ssd300_ref as R
 import odtk

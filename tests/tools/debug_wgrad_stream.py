@@ -1,6 +1,6 @@
 """Which layer's filter gradient differs when wgrad runs on the second stream?  (debug)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import odtk
 from oracle import ssd300_ref as R      # synthetic batch generator only

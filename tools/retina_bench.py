@@ -3,14 +3,15 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, odtk
 from odtk import ops
-from oracle import retinanet_ref as RR
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _synth as S
 dev = torch.device('cuda')
 N, ds = int(sys.argv[1]) if len(sys.argv) > 1 else 16, [800, 800, 3]
-shapes = RR.pyramid_shapes(ds[0], ds[1])
-flat = [v for s in RR.ANCHOR_SIZES for hw in RR.level_priors(s) for v in hw]
+shapes = S.pyramid_shapes(ds[0], ds[1])
+flat = S.retina_priors_flat()
 anc = ops.retina_anchors(ds[1], shapes, [9] * 5, flat, dev)
 A = anc[0].shape[0]
-gt = RR.synthetic_gt(N, 800, 3).to(dev)
+gt = S.synthetic_gt(N, 800, 3).to(dev)
 P = gt.shape[1]
 i32 = dict(dtype=torch.int32, device=dev)
 ngt = torch.zeros(N, **i32); best = torch.zeros(N, P, **i32); status = torch.zeros(N, A, dtype=torch.uint8, device=dev)

@@ -828,6 +828,7 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
         if (int e = v4 ? launch_gather_v4(a, st) : launch_gather_v3(a, st)) return e;
         g_last_kernel = v4 ? (a.K <= 64 ? "conv_gather_v4_kernel<64>" : "conv_gather_v4_kernel<128>")
                         : a.ksplit > 1 ? (a.K <= 64 ? "conv_gather_v3_kernel<64>+splitk" : "conv_gather_v3_kernel<128>+splitk")
+                        : a.ksplit < 0 ? "conv_gather_v6_kernel"
                                        : (a.K <= 64 ? "conv_gather_v3_kernel<64>" : "conv_gather_v3_kernel<128>");
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;

@@ -611,6 +611,204 @@ __global__ void __launch_bounds__(256) conv_gather_v5_kernel(const GatherArgs a)
     epilogue_bf16<PT, QT, NTHR, PI, QI>(a, smem, acc, p0, q0, prow0, qrow0, tid);
 }
 
+// ---------------------------------------------------------------------------------------
+// "v6": raster-run halo gather for 3x3 / stride 1 / pad 1 layers (C % 64 == 0, W <= 79): the v5 tile and schedule, but
+// the PIXEL operand is no longer gathered once per tap.  The 256 output pixels of a tile are a contiguous run m0.. of the
+// (n, h, w) raster, so the inputs of ALL nine taps lie in the contiguous run m0 - d(W + 1) .. m0 + 255 + d(W + 1): that patch
+// (<= 416 rows x 64 channels) is LDS-DMA'd ONCE per 64-channel chunk (double buffered, 13 pieces per wave spread over
+// the nine tap slabs of the previous chunk) and tap (dr, ds) reads its fragments at row + dr*W + ds.  Row wrap, image
+// borders and image-to-image seams are handled at fragment-read time: a lane whose (pixel, tap) is padding reads a
+// zero row instead (per-pixel 9-bit tap masks, computed once).  Only the 16-KiB filter slab is fetched per tap:
+// 196 KiB instead of 432 KiB of LDS-DMA per chunk.  slot ^ ((row >> 1) & 7) keeps ds_read_b128 conflict-free for any
+// start row.  k order = (chunk, tap); the filter k index stays tap * C + channel.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a) {
+    constexpr int PT = 128, QT = 256, NTHR = 256, PI = 2, QI = 4;
+    constexpr int NP = PT / 32;                          // filter DMA pieces per wave and slab
+    constexpr int NPP = 13, PROWS = NPP * 32;            // patch DMA pieces per wave and chunk; patch rows (416)
+    constexpr int PATCH = PROWS * 128, WST = PT * 128;
+    constexpr int ZOFF = 2 * PATCH + 3 * WST;
+    __shared__ __attribute__((aligned(16))) char smem[ZOFF + 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave & 1, wq = wave >> 1;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
+    const int p0 = tp * PT, q0 = tq * QT;
+    const int ncs = a.C >> 6;                            // 64-channel chunks (9 tap slabs each)
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rw = make_rsrc(a.w, a.w_bytes);
+    if (tid < 8) reinterpret_cast<uint4*>(smem + ZOFF)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    // ---- filter DMA rows r0 + 32 i
+    const int r0 = tid >> 3;
+    const int cc = (tid & 7) ^ swz_g(r0);
+    unsigned poff32[NP];
+    bool pok[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = p0 + r0 + 32 * i;
+        pok[i] = row < a.K;
+        poff32[i] = (unsigned)(row * a.ldw * 2 + cc * 16);
+    }
+    // ---- patch DMA: piece q = wave + 4 i covers patch rows 8q .. 8q+7; row r holds raster pixel q0 - W - 1 + r
+    const int total_px = a.N * a.H * a.W;
+    unsigned xoff32[NPP];
+    unsigned xok = 0;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+        const int g = q0 - a.dil * (a.W + 1) + row;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        xoff32[i] = (unsigned)(g * a.ldx * 2 + lc * 16);
+        if ((unsigned)g < (unsigned)total_px) xok |= 1u << i;
+    }
+    // ---- fragment rows of this lane: pixel rows qrow0 + 32 j + l31, their 9-bit tap masks
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int prow0 = wp * (PT / 2), qrow0 = wq * 128;
+    unsigned qmask[QI];
+    const int HW = a.H * a.W;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int m = q0 + qrow0 + j * 32 + l31;
+        unsigned mk = 0;
+        if (m < a.M) {
+            const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HW;
+            const int h = (int)fdiv((unsigned)rem, a.div_wo), w = rem - h * a.W;
+            unsigned rm = 0, cm = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if ((unsigned)(h + (d - 1) * a.dil) < (unsigned)a.H) rm |= 1u << d;
+                if ((unsigned)(w + (d - 1) * a.dil) < (unsigned)a.W) cm |= 1u << d;
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if ((rm >> d) & 1u) mk |= cm << (3 * d);
+        }
+        qmask[j] = mk;
+    }
+    unsigned pofs[PI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) { const int row = prow0 + i * 32 + l31; pofs[i] = (unsigned)(row * 128) | ((unsigned)swz_g(row) << 16); }
+
+    auto issue_w = [&](int kt, int stage) __attribute__((always_inline)) {        // filter slab kt = cs*9 + tap
+        const int cs = kt / 9, tap = kt - cs * 9;
+        const unsigned woff = (unsigned)((tap * a.C + cs * 64) * 2);
+        const unsigned dP = smem_base + 2u * PATCH + (unsigned)stage * WST + wave_u * 1024u;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const unsigned addr = poff32[i] + woff;
+            glds16_buf_nc(rw, pok[i] ? addr : 0xFFFFFFF0u, dP + i * 4096u);
+        }
+    };
+    auto issue_x = [&](int i, int cs, int buf) __attribute__((always_inline)) {    // patch piece i of chunk cs
+        const unsigned addr = xoff32[i] + (unsigned)(cs * 128);
+        glds16_buf_nc(rx, ((xok >> i) & 1u) ? addr : 0xFFFFFFF0u, smem_base + (unsigned)buf * PATCH + (wave_u + 4u * (unsigned)i) * 1024u);
+    };
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) issue_x(i, 0, 0);
+    issue_w(0, 0);
+    issue_w(1, 1);
+
+    // One tap slab.  Every slab issues the SAME number of pieces (filter slab kt+2: NP; patch pieces of chunk cs+1 by tap
+    // position: 2,2,2,2,2,1,1,1,0), so the counted vmcnt in front of each barrier is a compile-time constant; past the end
+    // of the k loop the pieces carry out-of-range offsets (zero fill into stages nobody reads again).
+    auto slab = [&](auto TAPC, int kt, int cs, int st_c, int st_n) __attribute__((always_inline)) {
+        constexpr int tap = decltype(TAPC)::value;
+        constexpr int dr = tap / 3, ds = tap - dr * 3;
+        constexpr int NX = tap < 5 ? 2 : (tap < 8 ? 1 : 0);
+        constexpr int XBASE = tap < 5 ? 2 * tap : 10 + (tap - 5);
+        constexpr int NPC = NP + NX;
+        const char* sP = smem + 2 * PATCH + st_c * WST;
+        const unsigned pbase = smem_base + (unsigned)((cs & 1) * PATCH);
+        const unsigned zrow = smem_base + ZOFF;
+        const bool more_x = cs + 1 < ncs, more_w = kt + 2 < 9 * ncs;
+        // filter slab kt+2 = (chunk, tap) two positions ahead
+        const int csn = tap < 7 ? cs : cs + 1;
+        constexpr int tn = (tap + 2) % 9;
+        const unsigned woff = (unsigned)((tn * a.C + csn * 64) * 2);
+        const unsigned dW = smem_base + 2u * PATCH + (unsigned)st_n * WST + wave_u * 1024u;
+        // fragment addressing of this tap: row + dr*W + ds, slot ^ ((row >> 1) & 7); padding lanes -> the zero row
+        unsigned qa[QI], qx[QI];
+        const int shift = (dr * a.W + ds) * a.dil;
+#pragma unroll
+        for (int j = 0; j < QI; ++j) {
+            const unsigned row = (unsigned)(qrow0 + j * 32 + l31 + shift);
+            const bool ok = (qmask[j] >> tap) & 1u;
+            qa[j] = ok ? pbase + row * 128u : zrow;
+            qx[j] = ok ? ((unsigned)(hi * 16) ^ (((row >> 1) & 7u) << 4)) : (unsigned)(hi * 16);
+        }
+        uint4 pf[2][PI], qf[2][QI];
+        auto rd = [&](int ks, int r) __attribute__((always_inline)) {
+            if (r < PI) {
+                const int slot = ks * 2 + hi;
+                pf[ks & 1][r] = *reinterpret_cast<const uint4*>(sP + (pofs[r] & 0xFFFFu) + (((unsigned)slot ^ (pofs[r] >> 16)) << 4));
+            } else {
+                const int j = r - PI;
+                const unsigned ad = qa[j] + (qx[j] ^ (unsigned)(ks * 32));
+                qf[ks & 1][j] = *reinterpret_cast<const uint4*>(smem + (ad - smem_base));
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < PI + QI; ++r) rd(0, r);
+        static_for<4>([&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+#pragma unroll
+            for (int j = 0; j < QI; ++j)
+#pragma unroll
+                for (int i = 0; i < PI; ++i) {
+                    const int mi = j * PI + i;
+                    const int slotno = ks * (PI * QI) + mi;
+                    Mma<bf16_t>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
+                    if (ks < 3) {
+#pragma unroll
+                        for (int r = 0; r < PI + QI; ++r)
+                            if (r * (PI * QI) / (PI + QI) == mi) rd(ks + 1, r);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NPC; ++q)
+                        if (q * 32 / NPC == slotno) {
+                            if (q < NP) {
+                                const unsigned addr = poff32[q] + woff;
+                                glds16_buf_nc(rw, (pok[q] && more_w) ? addr : 0xFFFFFFF0u, dW + q * 4096u);
+                            } else {
+                                const int xi = XBASE + q - NP;
+                                const unsigned addr = xoff32[xi] + (unsigned)((cs + 1) * 128);
+                                glds16_buf_nc(rx, (((xok >> xi) & 1u) && more_x) ? addr : 0xFFFFFFF0u,
+                                              smem_base + (unsigned)(((cs + 1) & 1) * PATCH) + (wave_u + 4u * (unsigned)xi) * 1024u);
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        });
+    };
+    int st_c = 0, st_n = 2, kt = 0;
+    for (int cs = 0; cs < ncs; ++cs) {
+        static_for<9>([&](auto TAPC) __attribute__((always_inline)) {
+            constexpr int tap = decltype(TAPC)::value;
+            // may stay in flight: what the PREVIOUS slab issued (filter slab kt+1 and the patch pieces of its position)
+            constexpr int PREV = (tap + 8) % 9;
+            constexpr int NXP = PREV < 5 ? 2 : (PREV < 8 ? 1 : 0);
+            wait_vmcnt<NP + NXP>();
+            block_barrier();
+            slab(TAPC, kt, cs, st_c, st_n);
+            st_c = st_c == 2 ? 0 : st_c + 1;
+            st_n = st_n == 2 ? 0 : st_n + 1;
+            ++kt;
+        });
+    }
+    wait_vmcnt<0>();                                    // the trailing (zero-fill) pieces must land before the image overwrites LDS
+    block_barrier();
+    epilogue_bf16<PT, QT, NTHR, PI, QI>(a, smem, acc, p0, q0, prow0, qrow0, tid);
+}
+
 // sum of the split-K partial tiles (fixed order -> deterministic) + the epilogue of epilogue_bf16, 8 channels per thread
 __global__ void __launch_bounds__(256) splitk_finish_kernel(const GatherArgs a) {
     const int cpr = a.ldy >> 3;
@@ -1640,6 +1838,13 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     }
     a.ksplit = 1;
     const int grid = tiles;
+    // raster-run halo kernel: 3x3 (dilated), stride 1, SAME, patch of 256 + 2 * dil * (W + 1) rows <= 416 (dbg bit 16 = off, A/B)
+    if (!(a.dbg & 65536) && PT == 128 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
+        a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && 2 * a.dil * (a.W + 1) <= 160 && a.Kdim == 9 * a.C) {
+        hipLaunchKernelGGL(conv_gather_v6_kernel, dim3(grid), dim3(256), 0, st, a);
+        a.ksplit = -1;                                   // tells the dispatcher which kernel ran (odtk_conv_last_kernel)
+        return 0;
+    }
     if ((a.dbg & 32768) && PT == 128 && a.C % 64 == 0 && a.Kdim % 64 == 0) {      // 4-wave hand-scheduled variant (dbg bit 15, A/B)
         hipLaunchKernelGGL(conv_gather_v5_kernel<128>, dim3(grid), dim3(256), 0, st, a);
         return 0;

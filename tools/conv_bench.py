@@ -2,7 +2,7 @@
 
 usage: python tools/conv_bench.py [layers|all] [passes] [reps] [modes]
   modes: comma list of odtk_debug_set(1, mode) values (1 = legacy, 2 = 8-wave v3, 3 = persistent v4, 0 = auto);
-         1xx / 2xx = v3 / v4 with perf-experiment bits xx; Ebbb (>= 1000) / Ebbbb (>= 10000) = engine E with bits bbb(b)
+         1xx / 2xx = v3 / v4 with perf-experiment bits xx; Ebbb (>= 1000) / Ebbbb (>= 10000) / Ebbbbbb (>= 1000000) = engine E with bits
 """
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -67,8 +67,11 @@ for name in which:
         f = fns[p]
         line = f'{name:8s} {p:6s}'
         for mode in modes:
-            ops.debug_set(1, mode // 10000 if mode >= 10000 else mode // 1000 if mode >= 1000 else 3 if mode >= 200 else 2 if mode >= 100 else mode)
-            ops.debug_set(2, mode % 10000 if mode >= 10000 else mode % 1000 if mode >= 1000 else mode % 100 if mode >= 100 else 0)
+            if mode >= 1000000:
+                ops.debug_set(1, mode // 1000000); ops.debug_set(2, mode % 1000000)
+            else:
+              ops.debug_set(1, mode // 10000 if mode >= 10000 else mode // 1000 if mode >= 1000 else 3 if mode >= 200 else 2 if mode >= 100 else mode)
+              ops.debug_set(2, mode % 10000 if mode >= 10000 else mode % 1000 if mode >= 1000 else mode % 100 if mode >= 100 else 0)
             for _ in range(3):
                 f()
             torch.cuda.synchronize()

@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     constexpr int NPP = 13, PROWS = NPP * 32;            // patch DMA pieces per wave and chunk; patch rows (416)
     constexpr int PATCH = PROWS * 128, WST = PT * 128;
     constexpr int ZOFF = 2 * PATCH + 3 * WST;
-    __shared__ __attribute__((aligned(16))) char smem[ZOFF + 128];
+    __shared__ __attribute__((aligned(16))) char smem[ZOFF + 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave & 1, wq = wave >> 1;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rw = make_rsrc(a.w, a.w_bytes);
-    if (tid < 8) reinterpret_cast<uint4*>(smem + ZOFF)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 16) reinterpret_cast<uint4*>(smem + ZOFF)[tid] = make_uint4(0u, 0u, 0u, 0u);      // two zero rows
     // ---- filter DMA rows r0 + 32 i
     const int r0 = tid >> 3;
     const int cc = (tid & 7) ^ swz_g(r0);
@@ -742,8 +742,8 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         for (int j = 0; j < QI; ++j) {
             const unsigned row = (unsigned)(qrow0 + j * 32 + l31 + shift);
             const bool ok = (qmask[j] >> tap) & 1u;
-            qa[j] = ok ? pbase + row * 128u : zrow;
-            qx[j] = ok ? ((unsigned)(hi * 16) ^ (((row >> 1) & 7u) << 4)) : (unsigned)(hi * 16);
+            qa[j] = ok ? pbase + row * 128u : zrow + (row & 1u) * 128u;       // same banks as the real row: no new conflicts
+            qx[j] = (unsigned)(hi * 16) ^ (((row >> 1) & 7u) << 4);
         }
         uint4 pf[2][PI], qf[2][QI];
         auto rd = [&](int ks, int r) __attribute__((always_inline)) {

@@ -40,7 +40,11 @@ int odtk_version(void);
 int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
 /* test/debug knobs: key 0 = force the register-staged conv gather kernel (value != 0);
  * key 1 = conv engine: 0 auto, 1 legacy 4-wave kernels, 2 8-wave v3 wherever supported, 3 persistent v4;
- * key 2 = perf-experiment bits (results wrong when set); key 3 = single-kernel NMS (value != 0) */
+ * key 2 = A/B bits of the conv kernels: bits 0-3 ablations (skip DMA / one slab; RESULTS WRONG), 5 no fragment double
+ *         buffering, 6 no early/late DMA stagger, 7 "landed early" protocol, 8 64-bit global addressing for the LDS-DMA,
+ *         9 no XCD remap (wgrad), 10 s_setprio, 11 no 64->64 / first-layer halo kernels, 12 per-lane tap walk,
+ *         13 no split-K, 14 interleaved slab body, 15 4-wave kernel (v5), 16 no raster-run halo kernel (v6);
+ * key 3 = single-kernel NMS (value != 0) */
 int odtk_debug_set(int key, int value);
 /* name of the device kernel the last odtk_conv2d_* call of this thread dispatched to (bench.py attributes
  * its HIP-event timings to kernels with it, so the roofline line and the rocprofv3 trace name the same kernel) */

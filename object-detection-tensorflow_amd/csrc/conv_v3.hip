@@ -1275,6 +1275,180 @@ __global__ void __launch_bounds__(512) conv_wgrad_v3_kernel(const WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// "v7" filter gradient: the v3 kernel with a 256 (k) x 256 (columns) tile -- two 128-channel dy sub-slabs next to the two
+// 128-column x sub-slabs, 32 pixels per k-slab, every wave 128 x 64 (8 accumulator tiles): 4 LDS-DMA pieces and 24
+// transpose reads per 16 MFMAs instead of 6 and 32.  For Cout >= 256; the pixel-split count absorbs the coarser tiles.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) conv_wgrad_v7_kernel(const WgradArgs a) {
+    constexpr int PI = 4, QI = 2;
+    constexpr int PKE = 32;                          // pixels per k-slab
+    constexpr int OPB = PKE * 256;                   // bytes per 128-channel operand sub-slab (8 KiB)
+    constexpr int STAGE = 4 * OPB;                   // two P + two Q sub-slabs
+    constexpr int NST = 3;
+    constexpr int NDMA = 4;
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    // 1-D grid, XCD-aware order: an XCD's contiguous range of virtual ids covers whole pixel splits, so the
+    // tiles that re-read the same dy / x pixel slabs (same split, different tile) share one L2
+    const int ntiles = a.tiles_p * a.tiles_q;
+    const int vb = (a.dbg & 512) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int split = vb / ntiles, tile = vb - split * ntiles;
+    const int tq = tile / a.tiles_p, tp = tile - tq * a.tiles_p;
+    const int p0 = tp * 256, q0 = tq * 256;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
+
+    // DMA lane role: pixel row dr of the piece, logical 16-B chunk dch (source-side swizzle)
+    const int dr = lane >> 4;
+    const int dch = (lane & 15) ^ (dr << 2);
+    const int pch = p0 + dch * 8;                    // + 128 for the second P sub-slab
+    const bool p_col_ok[2] = {pch < a.lddy, pch + 128 < a.lddy};
+    int dh[2], dw_[2], qc[2];
+    bool q_col_ok[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int j0 = q0 + s * 128 + dch * 8;
+        q_col_ok[s] = j0 < a.RSC;
+        int qr = 0, qs = 0; qc[s] = 0;
+        if (q_col_ok[s]) {
+            const int rs = j0 / a.C;
+            qc[s] = j0 - rs * a.C;
+            qr = rs / a.S;
+            qs = rs - qr * a.S;
+        }
+        dh[s] = qr * a.dil - a.pad_t;
+        dw_[s] = qs * a.dil - a.pad_l;
+    }
+    const int HoWo = a.Ho * a.Wo;
+    const int iters_total = (a.P + PKE - 1) / PKE;
+    const int it0 = split * a.iters_per_split;
+    int it1 = it0 + a.iters_per_split;
+    if (it1 > iters_total) it1 = iters_total;
+    if (it0 >= it1) return;
+
+    auto issue = [&](int it, int stage) __attribute__((always_inline)) {
+        const unsigned sP = smem_base + (unsigned)stage * STAGE;
+        const int piece = wave;                       // 8 pieces of 4 pixels per sub-slab, one per wave
+        const int p = it * PKE + piece * 4 + dr;
+        const bool pin = p < a.P;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            glds16_buf(rdy, (pin && p_col_ok[s]) ? (unsigned)((p * a.lddy + pch + s * 128) * 2) : 0xFFFFFFF0u,
+                       sP + (unsigned)(s * OPB) + (unsigned)piece * 1024u);
+        const unsigned n = fdiv((unsigned)p, a.div_howo);
+        const unsigned rem = (unsigned)p - n * (unsigned)HoWo;
+        const unsigned ho = fdiv(rem, a.div_wo);
+        const unsigned wo = rem - ho * (unsigned)a.Wo;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int hi = (int)ho * a.stride + dh[s], wi = (int)wo * a.stride + dw_[s];
+            const bool ok = pin && q_col_ok[s] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            glds16_buf(rx, ok ? (unsigned)(((((int)n * a.H + hi) * a.W + wi) * a.ldx + qc[s]) * 2) : 0xFFFFFFF0u,
+                       sP + (unsigned)((2 + s) * OPB) + (unsigned)piece * 1024u);
+        }
+    };
+
+    // transpose-read lane role (see conv_wgrad_dma_kernel): group g = lane>>4, c = lane&15
+    const int g = lane >> 4, c = lane & 15;
+    const int rr = c >> 2;
+    unsigned pfo[PI], qfo[QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int ch = (i * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
+        pfo[i] = (unsigned)(wp * OPB + (2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int ch = ((wq & 1) * 64 + j * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
+        qfo[j] = (unsigned)((2 + (wq >> 1)) * OPB + (2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
+    }
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const bool do_bias = a.dbias != nullptr && tq == 0 && wq == 0;     // wave-uniform
+    float bsum[PI] = {0.f, 0.f, 0.f, 0.f};
+
+    const int nk = it1 - it0;
+    issue(it0, 0);
+    if (nk > 1) issue(it0 + 1, 1);
+    int st_c = 0, st_n = 2;
+    const bool late = wave >= 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
+        block_barrier();
+        const bool do_issue = kt + 2 < nk;
+        if (do_issue && !late) issue(it0 + kt + 2, st_n);
+        const unsigned sS = smem_base + (unsigned)st_c * STAGE;
+        uint4 pf[2][PI], qf[2][QI];
+        auto ldf = [&](int ks, uint4 (&p)[PI], uint4 (&q)[QI]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
+                const uint2 lo = lds_tr16(sS + ks * 4096u + pfo[i]);
+                const uint2 hi2 = lds_tr16(sS + ks * 4096u + 1024u + pfo[i]);
+                p[i] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+            }
+#pragma unroll
+            for (int j = 0; j < QI; ++j) {
+                const uint2 lo = lds_tr16(sS + ks * 4096u + qfo[j]);
+                const uint2 hi2 = lds_tr16(sS + ks * 4096u + 1024u + qfo[j]);
+                q[j] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+            }
+        };
+        ldf(0, pf[0], qf[0]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks < 1) ldf(ks + 1, pf[(ks + 1) & 1], qf[(ks + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < PI; ++i)
+#pragma unroll
+                for (int j = 0; j < QI; ++j) Mma<bf16_t>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < PI; ++i) {
+                    const unsigned* d = reinterpret_cast<const unsigned*>(&pf[ks & 1][i]);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) bsum[i] += bf16_lo(d[h]) + bf16_hi(d[h]);
+                }
+            }
+        }
+        if (do_issue && late) issue(it0 + kt + 2, st_n);
+        st_c = st_c == 2 ? 0 : st_c + 1;
+        st_n = st_n == 2 ? 0 : st_n + 1;
+    }
+
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int col = q0 + wq * 64 + j * 32 + l31;
+        if (col >= a.RSC) continue;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = p0 + wp * 128 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const float t = bsum[i] + __shfl_xor(bsum[i], 32);       // both k halves
+            const int k = p0 + wp * 128 + i * 32 + l31;
+            if (hi == 0 && k < a.K) atomicAdd(a.dbias + k, t);
+        }
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (conv1_2 forward and its dgrad:
@@ -1935,7 +2109,32 @@ bool wgrad_v3_supported(const WgradArgs& a, int dtype) {
            (long long)a.P * a.lddy * 2 < (1ll << 31) && (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31);
 }
 
+int launch_wgrad_v7(WgradArgs& a, hipStream_t st) {
+    a.tiles_p = ceil_div(a.K, 256);
+    a.tiles_q = ceil_div(a.RSC, 256);
+    const int tiles = a.tiles_p * a.tiles_q;
+    const int iters_total = ceil_div(a.P, 32);
+    if (g_num_cu == 0) query_num_cu();
+    int best_s = 1;
+    double best_t = 1e30;
+    const int smax = iters_total < 8 ? 1 : iters_total / 8;
+    for (int s = 1; s <= smax && s <= 1024; ++s) {      // rounds x (slabs x ~1.0 us + prologue and 64 K float atomics per block)
+        const int ips = ceil_div(iters_total, s);
+        const int sp = ceil_div(iters_total, ips);
+        const double rounds = (double)ceil_div(tiles * sp, g_num_cu);
+        const double tt = rounds * (ips * 1.0 + 10.0);
+        if (tt < best_t - 1e-9) { best_t = tt; best_s = sp; }
+    }
+    a.iters_per_split = ceil_div(iters_total, best_s);
+    const int splits = ceil_div(iters_total, a.iters_per_split);
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
+    a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    hipLaunchKernelGGL(conv_wgrad_v7_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
+    return 0;
+}
+
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
+    if (a.K >= 256 && (a.dbg & 131072)) return launch_wgrad_v7(a, st);       // 256 x 256 tile (dbg bit 17, A/B)
     a.tiles_p = ceil_div(a.K, 128);
     a.tiles_q = ceil_div(a.RSC, 256);
     const int tiles = a.tiles_p * a.tiles_q;

@@ -66,11 +66,12 @@ V3_EXTRA_CASES = [
     (3, 38, 38, 128, 256, 3, 1, 1),   # raster-run halo kernel: tiles straddle rows AND images (4332 px = 16.9 tiles), 2 chunks
     (2, 75, 75, 64, 128, 3, 1, 1),    # ... widest supported map, one chunk
     (2, 19, 19, 128, 192, 3, 1, 2),   # ... dilation 2 (conv6 geometry), channel-tile tail
+    (2, 19, 19, 64, 300, 3, 1, 1),    # 256-row wgrad tile with a channel tail (300 = 256 + 44)
     (30, 45, 70, 8, 64, 3, 1, 1),     # first-layer kernel (3 real channels in one 16-B chunk): 540 ragged tiles, several per block
 ]
 
 
-@pytest.fixture(params=[(2, 0), (3, 0), (2, 256 + 65536), (2, 16384 + 65536), (2, 8192 + 65536), (2, 32768 + 8192 + 65536), (2, 8192), (2, 65536)], ids=["v3-8wave", "v4-persistent", "v3-globaldma", "v3-interleaved", "v3-nosplitk", "v5-4wave", "v6-halo-nosplitk", "v3-nohalo"])
+@pytest.fixture(params=[(2, 0), (3, 0), (2, 256 + 65536), (2, 16384 + 65536), (2, 8192 + 65536), (2, 32768 + 8192 + 65536), (2, 8192), (2, 65536), (2, 131072)], ids=["v3-8wave", "v4-persistent", "v3-globaldma", "v3-interleaved", "v3-nosplitk", "v5-4wave", "v6-halo-nosplitk", "v3-nohalo", "wgrad-v7"])
 def v3_engine(request):
     """Force the 8-wave (2) / persistent wave-specialised (3) conv kernels wherever they are
     supported (odtk_debug_set key 1); key 2 bit 8 selects 64-bit global addressing for the LDS-DMA, bit 14 the

@@ -2140,7 +2140,8 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
     const int tiles = a.tiles_p * a.tiles_q;
     const int iters_total = ceil_div(a.P, 64);
     // one 512-thread block per CU.  Pick the pixel split count by a small cost model: rounds of blocks x
-    // (k-slabs per block x ~1.0 us + ~6 us of prologue and 32 K float atomics per block)
+    // (k-slabs per block x ~1.0 us + ~16 us of prologue and 32 K float atomics per block: fitted on conv5_x / conv6,
+    // 101 -> 81 us and 186 -> 153 us against the earlier 6 us)
     if (g_num_cu == 0) query_num_cu();
     int best_s = 1;
     double best_t = 1e30;
@@ -2149,7 +2150,7 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
         const int ips = ceil_div(iters_total, s);
         const int sp = ceil_div(iters_total, ips);
         const double rounds = (double)ceil_div(tiles * sp, g_num_cu);
-        const double tt = rounds * (ips * 1.0 + 6.0);
+        const double tt = rounds * (ips * 1.0 + 16.0);
         if (tt < best_t - 1e-9) { best_t = tt; best_s = sp; }
     }
     a.iters_per_split = ceil_div(iters_total, best_s);

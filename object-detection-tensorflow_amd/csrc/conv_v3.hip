@@ -1996,7 +1996,7 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     // up to 256 / tiles blocks of >= 4 k-slabs each (dbg bit 13 turns it off for A/B runs)
     int ksplit = 1;
     if (tiles <= 128 && nk >= 8 && !(a.dbg & 8192)) {
-        ksplit = 256 / tiles;
+        ksplit = 256 / tiles;                    // (2..6 slabs per part and 512 / tiles were measured: this is the best)
         if (ksplit > nk / 4) ksplit = nk / 4;
         if (ksplit > 32) ksplit = 32;
     }

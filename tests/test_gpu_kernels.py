@@ -67,6 +67,7 @@ V3_EXTRA_CASES = [
     (2, 75, 75, 64, 128, 3, 1, 1),    # ... widest supported map, one chunk
     (2, 19, 19, 128, 192, 3, 1, 2),   # ... dilation 2 (conv6 geometry), channel-tile tail
     (2, 19, 19, 64, 300, 3, 1, 1),    # 256-row wgrad tile with a channel tail (300 = 256 + 44)
+    (1, 8, 8, 64, 96, 3, 1, 1),       # one partial pixel tile: the halo patch is mostly outside the tensor
     (30, 45, 70, 8, 64, 3, 1, 1),     # first-layer kernel (3 real channels in one 16-B chunk): 540 ragged tiles, several per block
 ]
 

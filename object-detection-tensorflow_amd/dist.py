@@ -86,6 +86,10 @@ class GradAllReducer:
         self.red = BucketAllReducer(model.G, segs, group, int(bucket_mb) << 20)
         self.world = self.red.world
 
+    def boundary_layers(self):
+        """Layers whose readiness closes a bucket (the backward graph is cut behind them)."""
+        return [self.red.segments[lo][0] for (_, _, lo) in self.red.buckets]
+
     def begin_step(self):
         self.red.begin_step()
 

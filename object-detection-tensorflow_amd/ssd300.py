@@ -143,6 +143,7 @@ class SSD300:
         # full-chip kernels with one workgroup per CU), so it is off by default; config key 'wgrad_stream'.
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if config.get('wgrad_stream', False) else None
         self._g_front = self._g_back = None
+        self._g_back_segs = None
         self._eager_steps = 0
         self.dist = None                       # set by attach_data_parallel()
         self.loss_divisor_batch = self.batch_size
@@ -484,9 +485,14 @@ class SSD300:
             ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
 
     def _backward(self):
+        for name in self._backward_iter():
+            self._mark_ready(name)
+
+    def _backward_iter(self):
+        """Backward pass as a generator: it hands back a layer name as soon as every gradient of that layer (and of all
+        later layers) has been launched -- the data-parallel hooks and the segmented graph capture hang on these points."""
         a = self.acts
         A25 = NUM_PRIORS * self.row
-        ready = self._mark_ready
         # heads (pred6 .. pred1): dpred -> BN bwd -> wgrad / dgrad into the feature map
         for i in reversed(range(6)):
             name = f'pred{i + 1}'
@@ -498,7 +504,7 @@ class SSD300:
                        False, z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
             self._conv_bwd_params(name, src, z.g, z.ld)
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], None, src.g, False)
-            ready(name)
+            yield name
         # extra layers conv11_2 .. conv6
         for (name, ci, co, k, s, d) in reversed(EXTRA_SEQ):
             src = a[self.extra_src[name]]
@@ -511,7 +517,7 @@ class SSD300:
             acc = self.extra_src[name] in FEAT_SRC
             relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], relu_src, src.g, acc)
-            ready(name)
+            yield name
         # VGG trunk
         for step in reversed(self.vgg_plan):
             if step[0] == 'pool':
@@ -525,14 +531,14 @@ class SSD300:
                     f1 = a['feat1']
                     ops.l2norm_bwd(x.t, f1.g, x.g, x.M, 512, x.ld, self.param('l2norm.gamma'),
                                    self._grad('l2norm.gamma'), True, x.t)
-                    ready('l2norm')
+                    yield 'l2norm'
             else:
                 _, name, prev = step
                 x, y = a[prev], a[name]
                 self._conv_bwd_params(name, x, y.g, y.ld)
                 if name != 'conv1_1':
                     ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
-                ready(name)
+                yield name
         if self.wgrad_stream is not None and self.dist is None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)     # join before the optimizer
 
@@ -560,22 +566,45 @@ class SSD300:
 
     def _graphs_invalidate(self):
         self._g_front = self._g_back = None
+        self._g_back_segs = None
         self._eager_steps = 0
 
     def _graphs_build(self):
         """Capture the launch sequence of a step into HIP graphs (about 210 kernel launches per step; the host
         cannot issue the ~100 short box/BN/small-conv launches as fast as the GPU retires them).  Forward+loss is
-        always captured; backward only without data parallelism (its all-reduces are launched eagerly from
-        layer_ready between the backward kernels).  The optimizer stays eager: `lr` changes per call."""
+        one graph; backward is one graph, or with data parallelism one graph per gradient bucket (the all-reduces are
+        launched eagerly between the replays).  The optimizer stays eager: `lr` changes per call."""
         torch.cuda.synchronize()
         self._g_front = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_front):
             self._step_front()
         self._g_back = None
+        self._g_back_segs = None
         if self.dist is None:
             self._g_back = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_back):
                 self._backward()
+        else:
+            # data parallel: one graph per gradient bucket; the bucket's all-reduce is launched (eagerly, on RCCL's
+            # stream) between two replays, exactly where the eager backward would have launched it
+            boundaries = set(self.dist.boundary_layers())
+            it = self._backward_iter()
+            segs, done = [], False
+            while not done:
+                g, names = torch.cuda.CUDAGraph(), []
+                with torch.cuda.graph(g):
+                    while True:
+                        try:
+                            n = next(it)
+                        except StopIteration:
+                            done = True
+                            break
+                        names.append(n)
+                        if n in boundaries:
+                            break
+                if names:
+                    segs.append((g, names))
+            self._g_back_segs = segs
 
     def train_step(self, lr):
         """One optimizer step on the batch loaded by set_batch(); returns the loss (data + L2)
@@ -592,6 +621,11 @@ class SSD300:
             self._eager_steps += 1
         if use_graph and self._g_back is not None:
             self._g_back.replay()
+        elif use_graph and self._g_back_segs is not None:
+            for g, names in self._g_back_segs:
+                g.replay()
+                for n in names:
+                    self.dist.layer_ready(n)
         else:
             self._backward()
         if self.dist is not None:

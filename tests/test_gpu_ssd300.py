@@ -146,7 +146,7 @@ def test_graph_replay_equals_eager_launches(dev):
     assert b[-1] < b[0]                                  # it trains
 
 
-@pytest.mark.parametrize("side_stream", [False, True], ids=["one-stream", "wgrad-stream"])
+@pytest.mark.parametrize("side_stream", [False, True, "dp"], ids=["one-stream", "wgrad-stream", "dp-bucket-graphs"])
 def test_graph_replay_gradients_match_eager_under_allocation_churn(side_stream, dev):
     """lr = 0 keeps the weights fixed, so every step must reproduce the gradient buffer of the first (eager) step
     -- also when it is replayed from HIP graphs while the caller keeps allocating device memory between steps.
@@ -154,10 +154,12 @@ def test_graph_replay_gradients_match_eager_under_allocation_churn(side_stream, 
     library now zero-fills with its own kernel), which scaled the whole gradient by 1e10..1e30 on some host heap layouts."""
     import odtk
     B = 8
-    cfg = dict(CONFIG, compute_dtype='bf16', batch_size=B, wgrad_stream=side_stream, use_graph=True, seed=0)
+    cfg = dict(CONFIG, compute_dtype='bf16', batch_size=B, wgrad_stream=side_stream is True, use_graph=True, seed=0)
     imgs, gt = R.synthetic_batch(B, 5)
     m = odtk.SSD300(cfg, None if False else {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [],
                                               'val_generator': None})
+    if side_stream == "dp":
+        m.attach_data_parallel(bucket_mb=8)       # world size 1: no collective, but the backward graph is cut per bucket
     m.set_batch(imgs, gt)
     keep = []
     ref = None
@@ -176,3 +178,5 @@ def test_graph_replay_gradients_match_eager_under_allocation_churn(side_stream, 
             a, b = g[off:off + n], ref[off:off + n]
             assert float((a - b).abs().max()) <= 2e-2 * (float(b.abs().max()) + 1e-12), (step, name)
     assert m._g_front is not None                              # steps 2.. were graph replays
+    if side_stream == "dp":
+        assert m._g_back is None and len(m._g_back_segs) >= 4 and sum(len(n) for _, n in m._g_back_segs) >= 25

@@ -258,7 +258,8 @@ def main():
             'config': {'workload': f'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
                        'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                        'launch': 'eager' if not model.use_graph else ('hip-graph replay (fwd+loss+bwd)' if model._g_back is not None
-                                                                        else 'hip-graph replay (fwd+loss), eager bwd + RCCL')},
+                                                                        else f'hip-graph replay (fwd+loss; bwd as {len(model._g_back_segs or [])} '
+                                                                             'bucket graphs with RCCL all-reduces between them)')},
         }
         peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
         if timer.records:

@@ -214,7 +214,7 @@ def main():
     while model.use_graph and not args.eager and model._eager_steps < 2:
         loss = model.train_step(lr)                          # a capture needs every lazily allocated buffer to exist
     if model.use_graph and model._g_front is None and not args.eager:
-        model._graphs_build()                                # untimed; a capture executes nothing
+        model._graphs_build_safe()                           # untimed; a capture executes nothing
     if args.eager:
         model.use_graph = False
     barrier()

@@ -569,20 +569,36 @@ class SSD300:
         self._g_back_segs = None
         self._eager_steps = 0
 
+    def _graphs_build_safe(self):
+        """Capture; on any capture error fall back to eager launches for the rest of the run (loudly)."""
+        try:
+            self._graphs_build()
+            return True
+        except Exception as e:                                     # noqa: BLE001
+            import warnings
+            warnings.warn(f'odtk: HIP-graph capture failed ({type(e).__name__}: {e}); continuing with eager launches')
+            self._graphs_invalidate()
+            self.use_graph = False
+            torch.cuda.synchronize()
+            return False
+
     def _graphs_build(self):
         """Capture the launch sequence of a step into HIP graphs (about 210 kernel launches per step; the host
         cannot issue the ~100 short box/BN/small-conv launches as fast as the GPU retires them).  Forward+loss is
         one graph; backward is one graph, or with data parallelism one graph per gradient bucket (the all-reduces are
         launched eagerly between the replays).  The optimizer stays eager: `lr` changes per call."""
         torch.cuda.synchronize()
+        # with a process group attached RCCL's watchdog thread keeps calling the HIP runtime; only THIS thread's calls
+        # have to be capture-safe
+        self._capture_mode = 'thread_local' if self.dist is not None else 'global'
         self._g_front = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_front):
+        with torch.cuda.graph(self._g_front, capture_error_mode=self._capture_mode):
             self._step_front()
         self._g_back = None
         self._g_back_segs = None
         if self.dist is None:
             self._g_back = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_back):
+            with torch.cuda.graph(self._g_back, capture_error_mode=self._capture_mode):
                 self._backward()
         else:
             # data parallel: one graph per gradient bucket; the bucket's all-reduce is launched (eagerly, on RCCL's
@@ -592,7 +608,7 @@ class SSD300:
             segs, done = [], False
             while not done:
                 g, names = torch.cuda.CUDAGraph(), []
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=self._capture_mode):
                     while True:
                         try:
                             n = next(it)
@@ -611,7 +627,7 @@ class SSD300:
         as a 1-element device tensor without synchronising."""
         use_graph = self.use_graph and self._eager_steps >= 2
         if use_graph and self._g_front is None:
-            self._graphs_build()
+            use_graph = self._graphs_build_safe()
         if self.dist is not None:
             self.dist.begin_step()
         if use_graph:

@@ -35,8 +35,29 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
                                               int p0, int q0, int prow0, int qrow0, int tid) {
     constexpr int RB = PT * 2;            // bytes per pixel row of the image
     constexpr int NCH = RB / 16;          // 16-B chunks per row (8 | 16)
+    constexpr int NIT = (QT * NCH) / NTHR;
     const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const bool pre_relu = a.relu && !a.accumulate;
+    // Every global load of the epilogue is issued BEFORE its first use: the bias of this lane's 4 * PI channel groups
+    // here, the accumulate / ReLU-mask operands of the store pass below in one batch.  (Loading them inside the loops
+    // exposed one full memory latency per iteration: 32 + 16 of them per tile were 12-23 % of the 4-wave kernels.)
+    float4 bv[PI][4];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = p0 + prow0 + i * 32 + 8 * g + 4 * hi;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) {
+                if (c + 3 < a.K) b = *reinterpret_cast<const float4*>(a.bias + c);
+                else {
+                    if (c < a.K) b.x = a.bias[c];
+                    if (c + 1 < a.K) b.y = a.bias[c + 1];
+                    if (c + 2 < a.K) b.z = a.bias[c + 2];
+                }
+            }
+            bv[i][g] = b;
+        }
+    const float lo = (a.relu && !a.accumulate) ? 0.f : -INFINITY;      // ReLU without accumulate is applied in f32 here
 #pragma unroll
     for (int j = 0; j < QI; ++j) {
         const int q = qrow0 + j * 32 + l31;
@@ -45,48 +66,40 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = prow0 + i * 32 + 8 * g + 4 * hi;      // channel inside the tile
-                const int c = p0 + cl;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (a.bias) {
-                    if (c + 3 < a.K) {
-                        const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
-                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c + e < a.K) v[e] += a.bias[c + e];
-                    }
-                }
-                if (pre_relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
+                const float4 b = bv[i][g];
                 uint2 o;
-                o.x = cvt_pk_bf16(v[0], v[1]);
-                o.y = cvt_pk_bf16(v[2], v[3]);
+                o.x = cvt_pk_bf16(fmaxf(acc[i][j][4 * g] + b.x, lo), fmaxf(acc[i][j][4 * g + 1] + b.y, lo));
+                o.y = cvt_pk_bf16(fmaxf(acc[i][j][4 * g + 2] + b.z, lo), fmaxf(acc[i][j][4 * g + 3] + b.w, lo));
                 *reinterpret_cast<uint2*>(smem + q * RB + ((((cl >> 3) ^ q) & (NCH - 1)) << 4) + ((cl & 4) << 1)) = o;
             }
         }
     }
-    __syncthreads();
+    // operands of the store pass (independent of the image): issue them now, they land under the barrier
     const bool post = a.accumulate || a.mask;
+    uint4 oldv[NIT], mkv[NIT];
+    if (post) {
 #pragma unroll
-    for (int it = 0; it < (QT * NCH) / NTHR; ++it) {
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * NTHR + tid;
+            const int q = idx / NCH, ch = idx % NCH;
+            const int m = q0 + q, c0 = p0 + ch * 8;
+            oldv[it] = make_uint4(0, 0, 0, 0); mkv[it] = make_uint4(0, 0, 0, 0);
+            if (m < a.M && c0 < a.ldy) {
+                if (a.accumulate) oldv[it] = *reinterpret_cast<const uint4*>(a.y + ((size_t)m * a.ldy + c0) * 2);
+                if (a.mask) mkv[it] = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
         const int idx = it * NTHR + tid;
         const int q = idx / NCH, ch = idx % NCH;
         const int m = q0 + q, c0 = p0 + ch * 8;
         if (m >= a.M || c0 >= a.ldy) continue;
         uint4 v = *reinterpret_cast<const uint4*>(smem + q * RB + (((ch ^ q) & (NCH - 1)) << 4));
-        char* yp = a.y + ((size_t)m * a.ldy + c0) * 2;
-        if (post) {
-            uint4 old = make_uint4(0, 0, 0, 0), mk = make_uint4(0, 0, 0, 0);
-            if (a.accumulate) old = *reinterpret_cast<const uint4*>(yp);
-            if (a.mask) mk = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
-            post_chunk(v, a.accumulate != 0, a.relu != 0, old, a.mask != nullptr, mk);
-        }
-        *reinterpret_cast<uint4*>(yp) = v;
+        if (post) post_chunk(v, a.accumulate != 0, a.relu != 0, oldv[it], a.mask != nullptr, mkv[it]);
+        *reinterpret_cast<uint4*>(a.y + ((size_t)m * a.ldy + c0) * 2) = v;
     }
 }
 

@@ -86,27 +86,41 @@ class ConvTimer:
             return r
         return f
 
-    def summary(self):
+    def per_step(self, steps):
+        """One step's launches with the MEDIAN duration of each launch over the recorded steps (the launch sequence of
+        a step is fixed, so record i and record i + launches_per_step are the same launch).  A single slow outlier -- a
+        clock ramp, a page-in behind the first eager launch after graph replay -- must not move the roofline line."""
+        n = len(self.records)
+        per = n // steps if steps > 0 and n % steps == 0 else n
+        reps = n // per
+        out = []
+        for i in range(per):
+            ts = sorted(self.records[i + r * per][3].elapsed_time(self.records[i + r * per][4]) * 1e-3 for r in range(reps))
+            kind, kern, fl, _, _, ab, shp = self.records[i]
+            out.append((kind, kern, fl, ts[len(ts) // 2], ab, shp))
+        return out
+
+    def summary(self, steps):
         per_kernel, per_pass = {}, {}
-        for kind, kern, fl, s, e, ab, _ in self.records:
-            t = s.elapsed_time(e) * 1e-3
+        for kind, kern, fl, t, ab, _ in self.per_step(steps):
             for d, k in ((per_kernel, kern), (per_pass, kind)):
                 a = d.setdefault(k, [0.0, 0.0, 0, 0.0]); a[0] += fl; a[1] += t; a[2] += 1; a[3] += ab
         return per_kernel, per_pass
 
-    def table(self):
-        """Per-layer rows (pass, kernel, shape, launches, mean us, TFLOP/s), slowest first."""
+    def table(self, steps):
+        """Per-layer rows (pass, kernel, shape, launches per step, median us, TFLOP/s), slowest first."""
         agg = {}
-        for kind, kern, fl, s, e, ab, shp in self.records:
+        for kind, kern, fl, tm, ab, shp in self.per_step(steps):
             a = agg.setdefault((kind, kern, shp), [0.0, 0.0, 0])
-            a[0] += fl; a[1] += s.elapsed_time(e) * 1e-3; a[2] += 1
+            a[0] += fl; a[1] += tm; a[2] += 1
         rows = ['%-13s %-28s N%d H%d W%d C%d K%d k%d s%d d%d  x%d  %8.1f us  %7.1f TF' %
                 (k[0], k[1], *k[2], v[2], v[1] / v[2] * 1e6, v[0] / v[1] / 1e12)
                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1] / kv[1][2])]
         return '\n'.join(rows)
 
     def roofline(self, steps, peak, whole_step_frac):
-        per_kernel, per_pass = self.summary()
+        per_kernel, per_pass = self.summary(steps)
+        steps = 1                                   # summary() is per step already
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
         fl, t, n, ab = per_kernel[dom]
         tot_f = sum(v[0] for v in per_kernel.values()); tot_t = sum(v[1] for v in per_kernel.values())
@@ -119,7 +133,7 @@ class ConvTimer:
             'algorithmic_mb_per_launch': round(ab / n / 1e6, 1),
             'family': {'kernels': 'all conv kernels (fwd + dgrad + wgrad, every layer)',
                        'achieved': round(tot_f / tot_t / 1e12, 2), 'frac': round(tot_f / tot_t / peak, 4),
-                       'launches_per_step': len(self.records) // steps, 'conv_ms_per_step': round(tot_t / steps * 1e3, 3)},
+                       'launches_per_step': sum(v[2] for v in per_kernel.values()), 'conv_ms_per_step': round(tot_t / steps * 1e3, 3)},
             'by_kernel': {k: {'TFLOP/s': round(v[0] / v[1] / 1e12, 2), 'ms_per_step': round(v[1] / steps * 1e3, 3),
                               'launches_per_step': v[2] // steps} for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             'by_pass': {k: {'TFLOP/s': round(v[0] / v[1] / 1e12, 2), 'ms_per_step': round(v[1] / steps * 1e3, 3)}
@@ -266,9 +280,9 @@ def main():
             out['roofline'] = timer.roofline(min(args.steps, 5), peak, value / world * 188.0e9 / peak)
             if args.conv_table:
                 with open(args.conv_table, 'w') as f:
-                    f.write(timer.table() + '\n')
+                    f.write(timer.table(min(args.steps, 5)) + '\n')
             out['roofline']['measured_on'] = (f'{min(args.steps, 5)} eager steps right after the timed region '
-                                              '(HIP events per conv launch on the launch stream)')
+                                              '(HIP events per conv launch on the launch stream; median of each launch over the steps)')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

@@ -100,6 +100,25 @@ def test_conv_legacy_engine_extra(case, dev):
         ops.debug_set(1, 0)
 
 
+# every distinct convolution geometry of SSD300 (SSD300.py:192-314, heads :85-90) at batch 2, through the AUTO dispatch:
+# first-layer kernel, 64->64 halo kernels, 8-wave gather, raster-run halo gather (also dilated), split-K, strided dgrad
+SSD300_LAYER_CASES = [
+    (2, 300, 300, 8, 64, 3, 1, 1), (2, 300, 300, 64, 64, 3, 1, 1), (2, 150, 150, 64, 128, 3, 1, 1),
+    (2, 150, 150, 128, 128, 3, 1, 1), (2, 75, 75, 128, 256, 3, 1, 1), (2, 75, 75, 256, 256, 3, 1, 1),
+    (2, 38, 38, 256, 512, 3, 1, 1), (2, 38, 38, 512, 512, 3, 1, 1), (2, 19, 19, 512, 512, 3, 1, 1),
+    (2, 19, 19, 512, 1024, 3, 1, 2), (2, 19, 19, 1024, 1024, 1, 1, 1), (2, 19, 19, 1024, 256, 1, 1, 1),
+    (2, 19, 19, 256, 512, 3, 2, 1), (2, 10, 10, 512, 128, 1, 1, 1), (2, 10, 10, 128, 256, 3, 2, 1),
+    (2, 5, 5, 256, 128, 1, 1, 1), (2, 5, 5, 128, 256, 3, 1, 1), (2, 5, 5, 128, 256, 3, 2, 1),
+    (2, 38, 38, 512, 100, 3, 1, 1), (2, 19, 19, 1024, 150, 3, 1, 1), (2, 10, 10, 512, 150, 3, 1, 1),
+    (2, 5, 5, 256, 150, 3, 1, 1), (2, 5, 5, 256, 100, 3, 1, 1), (2, 3, 3, 256, 100, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", SSD300_LAYER_CASES)
+def test_conv_ssd300_layer_geometries_bf16(case, dev):
+    _conv_case(case, "bf16", dev)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_fwd_dgrad_wgrad(case, dt, dev):

@@ -87,17 +87,23 @@ class ConvTimer:
         return f
 
     def per_step(self, steps):
-        """One step's launches with the MEDIAN duration of each launch over the recorded steps (the launch sequence of
-        a step is fixed, so record i and record i + launches_per_step are the same launch).  A single slow outlier -- a
-        clock ramp, a page-in behind the first eager launch after graph replay -- must not move the roofline line."""
+        """One step's launches with the mean duration of each launch over the recorded steps, first step and the single
+        slowest sample dropped (the launch sequence of a step is fixed, so record i and record i + launches_per_step are
+        the same launch).  A slow outlier -- a clock ramp, a page-in behind the first eager launch after graph replay --
+        must not move the roofline line; otherwise this is the plain average rocprofv3 --stats reports."""
         n = len(self.records)
         per = n // steps if steps > 0 and n % steps == 0 else n
         reps = n // per
         out = []
         for i in range(per):
-            ts = sorted(self.records[i + r * per][3].elapsed_time(self.records[i + r * per][4]) * 1e-3 for r in range(reps))
+            ts = [self.records[i + r * per][3].elapsed_time(self.records[i + r * per][4]) * 1e-3 for r in range(reps)]
+            if reps >= 3:
+                ts = ts[1:]                            # the first eager step after graph replay pays one-off costs
+            ts.sort()
+            if len(ts) >= 4:
+                ts = ts[:-1]                           # ... and one outlier per launch may go
             kind, kern, fl, _, _, ab, shp = self.records[i]
-            out.append((kind, kern, fl, ts[len(ts) // 2], ab, shp))
+            out.append((kind, kern, fl, sum(ts) / len(ts), ab, shp))
         return out
 
     def summary(self, steps):
@@ -246,7 +252,7 @@ def main():
         model.use_graph = False
         model.wgrad_stream = None            # one stream: every conv kernel is timed with the chip to itself
         timer.enabled = True
-        ev_steps = min(args.steps, 5)
+        ev_steps = min(args.steps, 5) + 1
         for _ in range(ev_steps):
             model.train_step(lr)
         torch.cuda.synchronize()
@@ -277,12 +283,12 @@ def main():
         }
         peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
         if timer.records:
-            out['roofline'] = timer.roofline(min(args.steps, 5), peak, value / world * 188.0e9 / peak)
+            out['roofline'] = timer.roofline(min(args.steps, 5) + 1, peak, value / world * 188.0e9 / peak)
             if args.conv_table:
                 with open(args.conv_table, 'w') as f:
-                    f.write(timer.table(min(args.steps, 5)) + '\n')
-            out['roofline']['measured_on'] = (f'{min(args.steps, 5)} eager steps right after the timed region '
-                                              '(HIP events per conv launch on the launch stream; median of each launch over the steps)')
+                    f.write(timer.table(min(args.steps, 5) + 1) + '\n')
+            out['roofline']['measured_on'] = (f'{min(args.steps, 5) + 1} eager steps right after the timed region '
+                                              '(HIP events per conv launch on the launch stream; per-launch mean without the first step and the slowest sample)')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

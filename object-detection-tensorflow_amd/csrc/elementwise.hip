@@ -442,12 +442,36 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     }
 }
 
+// dy / y operands of the BN backward kernels: one 16-byte load per chunk when the (y, dy) layout allows it (bf16 rows with a
+// 16-byte-aligned pitch: every extra layer), element loads otherwise (the heads read d(pred) rows of 25 floats).
+template <typename T, typename TY>
+__device__ __forceinline__ void bn_load_dy(const TY* __restrict__ y, const TY* __restrict__ dy, long long oo, int c0, int C,
+                                           int relu, int vec_ok, float (&d)[Chunk<T>::N]) {
+    constexpr int KC = Chunk<T>::N;
+    if (sizeof(TY) == 2 && KC == 8 && vec_ok && c0 + KC <= C) {
+        float yv[8], dv[8];
+        Chunk<bf16_t>::unpack(ld16(reinterpret_cast<const bf16_t*>(dy) + oo), dv);
+        if (relu) Chunk<bf16_t>::unpack(ld16(reinterpret_cast<const bf16_t*>(y) + oo), yv);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) d[e] = (relu && !(yv[e % 8] > 0.f)) ? 0.f : dv[e % 8];
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        d[e] = 0.f;
+        if (c0 + e >= C) continue;
+        float v = elem<TY>::load(dy[oo + e]);
+        if (relu && !(elem<TY>::load(y[oo + e]) > 0.f)) v = 0.f;
+        d[e] = v;
+    }
+}
+
 // BN backward partials: sum(dy'), sum(dy' * xhat)
 template <typename T, typename TY>
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
     const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
     int rows_per_img, long long y_img_stride, const float* __restrict__ save_mean,
-    const float* __restrict__ save_invstd, int relu, int rows_per_split, float* __restrict__ ws) {
+    const float* __restrict__ save_invstd, int relu, int vec_ok, int rows_per_split, float* __restrict__ ws) {
     constexpr int KC = Chunk<T>::N;
     __shared__ float sm[RED_ROWS * 8 * 2 * KC];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -469,13 +493,13 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
             float f[KC];
             Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
             const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+            float d[KC];
+            bn_load_dy<T, TY>(y, dy, oo, c0, C, relu, vec_ok, d);
 #pragma unroll
             for (int e = 0; e < KC; ++e) {
                 if (c0 + e >= C) continue;
-                float d = elem<TY>::load(dy[oo + e]);
-                if (relu && !(elem<TY>::load(y[oo + e]) > 0.f)) d = 0.f;
-                acc[e] += d;
-                acc[KC + e] += d * ((f[e] - mu[e]) * iv[e]);
+                acc[e] += d[e];
+                acc[KC + e] += d[e] * ((f[e] - mu[e]) * iv[e]);
             }
         }
     }
@@ -509,7 +533,7 @@ template <typename T, typename TY>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
     int rows_per_img, long long y_img_stride, const float* __restrict__ gamma,
-    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, T* __restrict__ dz,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, int vec_ok, T* __restrict__ dz,
     const float* __restrict__ fin, int rows_per_block) {
     constexpr int KC = Chunk<T>::N;
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -533,14 +557,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
         float f[KC], o[KC];
         Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
         const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+        float d[KC];
+        bn_load_dy<T, TY>(y, dy, oo, c0, C, relu, vec_ok, d);
 #pragma unroll
         for (int e = 0; e < KC; ++e) {
             o[e] = 0.f;
             if (c0 + e >= C) continue;
-            float d = elem<TY>::load(dy[oo + e]);
-            if (relu && !(elem<TY>::load(y[oo + e]) > 0.f)) d = 0.f;
             const float xh = (f[e] - mu[e]) * iv[e];
-            o[e] = gs[e] * (d - k1[e] - xh * k2[e]);
+            o[e] = gs[e] * (d[e] - k1[e] - xh * k2[e]);
         }
         st16(dz + (size_t)m * ldz + c0, Chunk<T>::pack(o));
     }
@@ -908,15 +932,18 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
     dim3 g1(pl.colgroups, pl.nsplit);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
+    const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;
+    const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
+                       ((uintptr_t)dy) % 16 == 0 && (!relu || ((uintptr_t)y) % 16 == 0);
 #define BN_BWD(T, TY)                                                                                             \
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu,   \
-                       pl.rows_per_split, ws);                                                                    \
+                       vec_ok, pl.rows_per_split, ws);                                                            \
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, ws, pl.nsplit, C, M,     \
                        dgamma, dbeta, fin);                                                                       \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd,  \
-                       relu, (T*)dz, fin, rows_per_block)
+                       relu, vec_ok, (T*)dz, fin, rows_per_block)
     if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_BWD(bf16_t, bf16_t); }
     else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_BWD(bf16_t, float); }
     else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD(float, float); }

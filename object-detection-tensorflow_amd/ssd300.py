@@ -142,6 +142,7 @@ class SSD300:
         # on the dgrad chain needs its result before the optimizer).  Measured neutral on MI355X (both chains are
         # full-chip kernels with one workgroup per CU), so it is off by default; config key 'wgrad_stream'.
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if config.get('wgrad_stream', False) else None
+        self._side = torch.cuda.Stream(device=self.dev)          # box matching under the forward pass
         self._g_front = self._g_back = None
         self._g_back_segs = None
         self._eager_steps = 0
@@ -449,12 +450,18 @@ class SSD300:
                        out, co, src.H * src.W, A25, self.ws)
 
     # ------------------------------------------------------------------ loss
-    def _loss(self, grad_scale):
-        N, A = self.batch_size, NUM_PRIORS
+    def _match(self):
+        """Prior <-> ground-truth matching (SSD300.py:347-426): needs the boxes only, not the network output."""
         pri = self.pri
         if self.m_best is None or self.m_best.shape[1] != self.gt.shape[1]:
-            self.m_best = torch.zeros(N, self.gt.shape[1], dtype=torch.int32, device=self.dev)
+            self.m_best = torch.zeros(self.batch_size, self.gt.shape[1], dtype=torch.int32, device=self.dev)
         ops.ssd_match(pri[0], pri[1], pri[3], self.gt, self.m_ngt, self.m_best, self.m_status, self.m_rg, self.m_counts)
+
+    def _loss(self, grad_scale, matched=False):
+        N, A = self.batch_size, NUM_PRIORS
+        pri = self.pri
+        if not matched:
+            self._match()
         ops.softmax_ce_const(self.pred, N * A, self.num_classes, self.row, self.num_classes - 1, self.negloss)
         ops.nms_batched(pri[4], 0, self.negloss, A, 1, self.m_status, A, 1, 2, A, N, self.m_counts[:, 2:], 4, 0,
                         0.7, self.sel_idx, A, self.sel_cnt)
@@ -561,8 +568,20 @@ class SSD300:
 
     def _step_front(self):
         self.G.zero_()
+        # the matching only depends on the ground truth: it runs on a second stream under the forward pass
+        main = torch.cuda.current_stream()
+        if self.m_best is None or self.m_best.shape[1] != self.gt.shape[1]:
+            self.m_best = torch.zeros(self.batch_size, self.gt.shape[1], dtype=torch.int32, device=self.dev)
+        if not self.config.get('match_stream', False):     # measured: no gain (a concurrent small kernel slows the convs)
+            self._forward(True)
+            self._loss(1.0 / self.loss_divisor_batch)
+            return
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self._match()
         self._forward(True)
-        self._loss(1.0 / self.loss_divisor_batch)
+        main.wait_stream(self._side)
+        self._loss(1.0 / self.loss_divisor_batch, matched=True)
 
     def _graphs_invalidate(self):
         self._g_front = self._g_back = None

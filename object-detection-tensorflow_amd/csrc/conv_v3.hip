@@ -1998,7 +1998,7 @@ bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype) {
     // 32-bit byte offsets in the buffer-addressed LDS-DMA: both operands must stay below 2 GiB
     return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && (a.idiv == 1 || (a.idiv == 2 && a.dil == 1)) && a.R * a.S <= 32 && a.ldy % 8 == 0 &&
            (a.mask == nullptr || a.ldmask % 8 == 0) && a.ldx % 8 == 0 && a.C % 8 == 0 &&
-           (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31) && (long long)a.K * a.ldw * 2 < (1ll << 31);
+           (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31) - (1ll << 21) && (long long)a.K * a.ldw * 2 < (1ll << 31) - (1ll << 21);
 }
 
 int launch_gather_v3(GatherArgs& a, hipStream_t st) {

@@ -1,0 +1,65 @@
+"""Inference tails of the other detector classes of the reference on libodtk: decode kernel -> per-class score threshold ->
+per-class NMS (the SSD300 NMS path) -> [scores f32[K], bbox f32[K,4] y1x1y2x2 px, class_id i32[K]], i.e. what each class
+stores in `self.detection_pred` (RetinaNet.py:224-256, YOLOv3.py:320-368, FCOS.py:197-265, CenterNet.py:159-185).
+Inputs are the head outputs of ONE image as device tensors.  The product path: no CPU fallback, nothing from oracle/."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+NMS_MAX_CANDIDATES = 16384          # odtk_nms_batched: boxes per problem
+
+
+def _per_class_nms(conf, boxes, cand, num_classes, max_boxes, iou_thr):
+    """conf [L, ld] scores (classes 0..num_classes-1 in the first columns), boxes [L, 4], cand [L, ld] uint8."""
+    dev = conf.device
+    L, ld = conf.shape
+    rows = None
+    if L > NMS_MAX_CANDIDATES:
+        # keep the rows that are a candidate for at least one class, in order (ties in NMS follow the row order)
+        rows = torch.nonzero(cand[:, :num_classes].any(dim=1)).flatten()
+        if rows.numel() > NMS_MAX_CANDIDATES:
+            raise ValueError(f'{rows.numel()} candidate boxes exceed the NMS capacity of {NMS_MAX_CANDIDATES}; raise the score threshold')
+        if rows.numel() == 0:
+            return (torch.empty(0, device=dev), torch.empty(0, 4, device=dev), torch.empty(0, dtype=torch.int32, device=dev))
+        conf, boxes, cand = conf[rows].contiguous(), boxes[rows].contiguous(), cand[rows].contiguous()
+        L = rows.numel()
+    cap = max(int(max_boxes), 1)
+    out_idx = torch.zeros(num_classes, cap, dtype=torch.int32, device=dev)
+    out_cnt = torch.zeros(num_classes, dtype=torch.int32, device=dev)
+    ops.nms_batched(boxes, 0, conf, 1, ld, cand, 1, ld, 1, L, num_classes, None, 0, int(max_boxes), float(iou_thr), out_idx, cap, out_cnt)
+    cnt = out_cnt.cpu().tolist()
+    scores, bbox, cid = [], [], []
+    for c in range(num_classes):                      # ascending class id, NMS pick order inside (the reference's concat order)
+        ids = out_idx[c, : cnt[c]].long()
+        scores.append(conf[ids, c]); bbox.append(boxes[ids])
+        cid.append(torch.full((cnt[c],), c, dtype=torch.int32, device=dev))
+    return torch.cat(scores), torch.cat(bbox, 0).reshape(-1, 4), torch.cat(cid)
+
+
+def retina_detect(pconf, pbox, anchors_yx, anchors_hw, score_thr, max_boxes, iou_thr):
+    """RetinaNet.py:224-256.  pconf [A, C] logits (last class = background), pbox [A, 4] = (dy, dx, log h, log w)."""
+    conf, boxes, _, cand = ops.retina_decode(pconf, pbox, anchors_yx, anchors_hw, score_thr)
+    return _per_class_nms(conf, boxes, cand, pconf.shape[1] - 1, max_boxes, iou_thr)
+
+
+def fcos_detect(conf, reg, center, score_thr, max_boxes, iou_thr):
+    """FCOS.py:197-265.  conf / reg / center: the five level tensors [H, W, C | 4 | 1] of one image; classes 0..C-2."""
+    pconf, pbbox = ops.fcos_decode_candidates(conf, reg, center)
+    cand = (pconf >= score_thr).to(torch.uint8)
+    return _per_class_nms(pconf, pbbox, cand, pconf.shape[1] - 1, max_boxes, iou_thr)
+
+
+def yolov3_detect(preds, priors_flat, score_thr, max_boxes, iou_thr, decode_scale=(32., 32., 16.)):
+    """YOLOv3.py:320-368.  preds: three [H, W, P, C + 5] tensors (head 1 = coarsest); decode_scale as in the reference (sic)."""
+    conf, bbox = ops.yolov3_decode_candidates(preds, priors_flat, decode_scale)
+    cand = (conf >= score_thr).to(torch.uint8)
+    return _per_class_nms(conf, bbox, cand, conf.shape[1], max_boxes, iou_thr)
+
+
+def centernet_detect(keypoints, offset, size, score_thr, top_k, stride=4.0, workspace=None):
+    """CenterNet.py:159-185 (no NMS: 3x3 peak test + top-k)."""
+    H, W, C = keypoints.shape
+    ws = workspace if workspace is not None else ops.centernet_workspace(1, H, W, C, keypoints.device)
+    return ops.centernet_decode(keypoints, offset, size, stride, score_thr, top_k, ws)

@@ -113,8 +113,13 @@ def fcos(tf):
     exec(code, ns2)
     pconf, pbbox = ns2['pconf'].numpy(), ns2['pbbox'].numpy()
     print('fcos candidates', pconf.shape, pbbox.shape)
+    # the rest of the branch: per-class threshold + NMS loop (FCOS.py:248-265)
+    me.nms_score_threshold, me.nms_max_boxes, me.nms_iou_threshold = 0.2, 10, 0.5
+    exec(ref_lines('/root/reference/FCOS.py', 248, 265), ns2)
+    det = [v.numpy() for v in me.detection_pred]
+    print('fcos detections', det[0].shape[0])
     out = dict(gt=gt.numpy(), loss=np.asarray(losses, np.float64), shapes=np.asarray(shapes, np.int32),
-               pconf=pconf[::3].copy(), pbbox=pbbox[::3].copy())
+               pconf=pconf[::3].copy(), pbbox=pbbox[::3].copy(), det_scores=det[0], det_bbox=det[1], det_class_id=det[2])
     for l in range(5):
         out[f'conf{l}'], out[f'reg{l}'], out[f'center{l}'] = (conf[l].numpy().astype(np.float16), reg[l].numpy().astype(np.float16),
                                                               cen[l].numpy().astype(np.float16))

@@ -80,6 +80,16 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'retina_loss.npz'), pconf=pconf.numpy().astype(np.float16),
                         pbox=pbox.numpy().astype(np.float16), gt=gt.numpy(), loss=np.asarray(losses, np.float64))
     print('one-image losses', losses)
+    # 3. the inference branch (RetinaNet.py:224-256, source lines read at generation time) on image 0's head outputs
+    import textwrap
+    tf = sys.modules['tensorflow']
+    code = textwrap.dedent('\n'.join(open('/root/reference/RetinaNet.py').read().split('\n')[223:256]))
+    me.nms_score_threshold, me.nms_max_boxes, me.nms_iou_threshold = 0.35, 10, 0.5
+    ns = dict(tf=tf, self=me, pbbox_yx=pbox[:1, :, :2], pbbox_hw=pbox[:1, :, 2:], pconf=pconf[:1], abbox_yx=anc[2], abbox_hw=anc[3])
+    exec(code, ns)
+    det = [v.numpy() for v in me.detection_pred]
+    print('retina detections', det[0].shape[0])
+    np.savez_compressed(os.path.join(OUT, 'retina_det.npz'), scores=det[0], bbox=det[1], class_id=det[2])
     tf_shim.uninstall()
 
 

@@ -68,7 +68,13 @@ def main():
     exec(ref_lines('/root/reference/YOLOv3.py', 320, 350), ns2)
     conf, box = ns2['confidence'].numpy(), ns2['bbox_y1x1y2x2'].numpy()
     print('yolov3 candidates', conf.shape, box.shape)
-    out = dict(gt=gt.numpy(), loss=np.asarray(losses, np.float64), confidence=conf[::3].copy(), bbox=box[::3].copy())
+    # ... and the whole branch incl. the per-class NMS loop (:351-368) at a threshold that leaves a few hundred candidates
+    me.nms_score_threshold, me.nms_max_boxes, me.nms_iou_threshold = 0.45, 10, 0.5
+    exec(ref_lines('/root/reference/YOLOv3.py', 351, 368), ns2)
+    det = [v.numpy() for v in me.detection_pred]
+    print('yolov3 detections', det[0].shape[0])
+    out = dict(gt=gt.numpy(), loss=np.asarray(losses, np.float64), confidence=conf[::3].copy(), bbox=box[::3].copy(),
+               det_scores=det[0], det_bbox=det[1], det_class_id=det[2])
     for l in range(3):
         out[f'pred{l + 1}'] = preds[l].numpy().astype(np.float16)
     np.savez_compressed(os.path.join(OUT, 'yolov3_loss.npz'), **out)

@@ -206,3 +206,37 @@ def test_yolov3_decode_candidates(dev):
     assert float((box.cpu() - rb).abs().max()) <= 1e-3 * 32 / 16         # exp / sigmoid round-off x stride
     assert np.abs(conf.cpu().numpy()[::3] - g['confidence']).max() <= 1e-6
     assert np.abs(box.cpu().numpy()[::3] - g['bbox']).max() <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ full inference tails
+def _same_detections(got, scores, bbox, class_id, stol=1e-6, btol=2e-3):
+    s, b, c = (t.cpu().numpy() for t in got)
+    assert np.array_equal(c, class_id)                                   # same classes, same pick order
+    assert np.abs(s - scores).max() <= stol and np.abs(b - bbox).max() <= btol
+
+
+def test_full_inference_tails_vs_reference(dev):
+    """odtk.heads.*_detect = decode kernel -> threshold -> per-class NMS, against the detections the reference's own
+    inference branches produce on the same head outputs (tests/golden/*: YOLOv3.py:320-368, FCOS.py:197-265,
+    RetinaNet.py:224-256 run on the shim)."""
+    from odtk import heads
+    g = np.load(os.path.join(GOLD, 'yolov3_loss.npz'))
+    preds = [torch.from_numpy(g[f'pred{l + 1}'].astype(np.float32))[0].to(dev).contiguous() for l in range(3)]
+    _same_detections(heads.yolov3_detect(preds, _yolo_priors_flat(), 0.45, 10, 0.5), g['det_scores'], g['det_bbox'], g['det_class_id'])
+    g = np.load(os.path.join(GOLD, 'fcos_loss.npz'))
+    conf, reg, cen = ([torch.from_numpy(g[f'{n}{l}'].astype(np.float32))[0].to(dev).contiguous() for l in range(5)] for n in ('conf', 'reg', 'center'))
+    _same_detections(heads.fcos_detect(conf, reg, cen, 0.2, 10, 0.5), g['det_scores'], g['det_bbox'], g['det_class_id'])
+    from oracle import retinanet_ref as RR
+    ops = _ops()
+    g = np.load(os.path.join(GOLD, 'retina_loss.npz'))
+    d = np.load(os.path.join(GOLD, 'retina_det.npz'))
+    shapes = RR.pyramid_shapes(320, 256)
+    flat = [v for s in RR.ANCHOR_SIZES for hw in RR.level_priors(s) for v in hw]
+    anc = ops.retina_anchors(256, shapes, [RR.NUM_ANCHORS] * 5, flat, dev)
+    pconf = torch.from_numpy(g['pconf'].astype(np.float32))[0].to(dev).contiguous()
+    pbox = torch.from_numpy(g['pbox'].astype(np.float32))[0].to(dev).contiguous()
+    _same_detections(heads.retina_detect(pconf, pbox, anc[2], anc[3], 0.35, 10, 0.5), d['scores'], d['bbox'], d['class_id'])
+    g = np.load(os.path.join(GOLD, 'centernet_loss.npz'))
+    kp, off, size = (torch.from_numpy(g[k].astype(np.float32))[0].to(dev) for k in ('keypoints', 'offset', 'size'))
+    s, b, c = heads.centernet_detect(kp, off, size, 0.1, 100)
+    assert np.array_equal(c.cpu().numpy(), g['det0_class_id']) and np.abs(b.cpu().numpy() - g['det0_bbox']).max() <= 1e-4

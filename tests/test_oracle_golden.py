@@ -183,3 +183,26 @@ def test_yolov3_loss_and_candidates_vs_reference():
         assert abs(l - float(g['loss'][i])) <= 1e-5 * abs(float(g['loss'][i])), (i, l, float(g['loss'][i]))
     conf, box = YR.decode_candidates([p[0] for p in preds])
     assert np.abs(conf.numpy()[::3] - g['confidence']).max() <= 2e-7 and np.array_equal(box.numpy()[::3], g['bbox'])
+
+
+def test_full_inference_branches_vs_reference():
+    """decode + per-class threshold + NMS loop of YOLOv3 / FCOS / RetinaNet (oracle/detect_common.py) against the
+    reference's own inference branches run on the shim."""
+    from oracle import detect_common as DC, yolov3_ref as YR, fcos_ref as FR, retinanet_ref as RR
+    g = np.load(os.path.join(GOLD, 'yolov3_loss.npz'))
+    conf, box = YR.decode_candidates([torch.from_numpy(g[f'pred{l + 1}'].astype(np.float32))[0] for l in range(3)])
+    s, b, c = DC.per_class_nms(conf, box, 20, 0.45, 10, 0.5)
+    assert np.array_equal(c.numpy(), g['det_class_id']) and np.abs(s.numpy() - g['det_scores']).max() <= 2e-7
+    assert np.array_equal(b.numpy(), g['det_bbox'])
+    g = np.load(os.path.join(GOLD, 'fcos_loss.npz'))
+    pc, pb = FR.decode_candidates(*[[torch.from_numpy(g[f'{n}{l}'].astype(np.float32))[0] for l in range(5)] for n in ('conf', 'reg', 'center')])
+    s, b, c = DC.per_class_nms(pc, pb, 20, 0.2, 10, 0.5)
+    assert np.array_equal(c.numpy(), g['det_class_id']) and np.array_equal(s.numpy(), g['det_scores']) and np.array_equal(b.numpy(), g['det_bbox'])
+    g = np.load(os.path.join(GOLD, 'retina_loss.npz'))
+    d = np.load(os.path.join(GOLD, 'retina_det.npz'))
+    anc = RR.anchors([320, 256, 3], RR.pyramid_shapes(320, 256))
+    pconf = torch.from_numpy(g['pconf'].astype(np.float32))[0]
+    pbox = torch.from_numpy(g['pbox'].astype(np.float32))[0]
+    cf, bx, keep, _ = RR.decode_candidates(pbox[:, :2], pbox[:, 2:], pconf, anc, 0.35)
+    s, b, c = DC.per_class_nms(cf, bx, 20, 0.35, 10, 0.5, row_mask=keep)
+    assert np.array_equal(c.numpy(), d['class_id']) and np.array_equal(s.numpy(), d['scores']) and np.array_equal(b.numpy(), d['bbox'])

@@ -1,7 +1,7 @@
 """Inference tails of the other detector classes of the reference on libodtk: decode kernel -> per-class score threshold ->
 per-class NMS (the SSD300 NMS path) -> [scores f32[K], bbox f32[K,4] y1x1y2x2 px, class_id i32[K]], i.e. what each class
 stores in `self.detection_pred` (RetinaNet.py:224-256, YOLOv3.py:320-368, FCOS.py:197-265, CenterNet.py:159-185).
-Inputs are the head outputs of ONE image as device tensors.  The product path: no CPU fallback, nothing from oracle/."""
+Inputs are the head outputs of ONE image as device tensors.  Product path: no CPU fallback, no use of the test oracles."""
 from __future__ import annotations
 
 import torch

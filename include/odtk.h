@@ -306,6 +306,36 @@ int odtk_yolov3_decode_candidates(const float* const* pred, const int* shapes, c
                                   const float* decode_scale, int num_priors, int C, float* confidence, float* bbox,
                                   void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Image augmentor: replaces utils/image_augmentor.py:87-232 -- the tf.image / tf.contrib.image ops on
+ * the picture and the box arithmetic next to them.  The host turns the reference's random draws (crop offsets, flip,
+ * colour-jitter and rotate draws, in the reference's order) into one plan per image; the plans live in DEVICE memory.
+ * Pixels: f32 or u8 source, HWC or CHW, any size per image; output f32 [N][out_h][out_w][C] (or [N][C][out_h][out_w]).
+ * Boxes: gt_in [N][P][5] = ymin, ymax, xmin, xmax, class (:76-81) with gt_count[n] valid rows; gt_out [N][pad_to][5] =
+ * yc, xc, h, w, class, rows whose centre left the picture dropped, the rest -1 (:201-230).  fallback[n] = 1 when every
+ * box of image n was lost: boxes and picture then come from the plain resize of the input (gt_checker_helper :263-267).
+ * Call odtk_augment_boxes first when there is ground truth and hand its fallback array to odtk_augment_images (NULL
+ * without ground truth).  hue needs C == 3.  workspace: odtk_augment_workspace_bytes. */
+typedef struct odtk_aug_plan {
+    const void* src;          /* device pointer to the source picture */
+    int src_u8;               /* 1: unsigned char pixels, 0: float */
+    int src_chw;              /* 1: channels_first source */
+    int in_h, in_w;
+    int resize;               /* 0: fill_mode 'CONSTANT' (pad only, :119-123) */
+    int resize_h, resize_w;   /* bilinear align_corners target inside the zoom canvas (:98-113, :125-128) */
+    int crop_h, crop_w;       /* :131-143 */
+    int flip_td, flip_lr;     /* :148-160 */
+    int has_brightness, has_contrast, has_hue, has_rotate;
+    float brightness, contrast, hue;   /* :173-188 */
+    float angle;              /* radians, the image angle (rotate_helper :236); boxes turn by -angle */
+    float ratio_y, ratio_x;   /* box zoom ratios (:114-116, :129-133) */
+} odtk_aug_plan;
+long long odtk_augment_workspace_bytes(int N, int C, int out_h, int out_w);
+int odtk_augment_boxes(const odtk_aug_plan* plans, const float* gt_in, const int* gt_count, int N, int P, int out_h,
+                       int out_w, int pad_to, float* gt_out, int* fallback, void* stream);
+int odtk_augment_images(const odtk_aug_plan* plans, const int* fallback, int N, int C, int zoom_h, int zoom_w, int out_h,
+                        int out_w, float constant_value, int out_chw, float* out, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,14 @@ class ConvDesc(C.Structure):
         "pad_t", "pad_l", "dtype", "out_dtype")]
 
 
+class AugPlan(C.Structure):
+    """Mirror of `odtk_aug_plan` (include/odtk.h)."""
+    _fields_ = ([("src", C.c_void_p)] +
+                [(n, C.c_int) for n in ("src_u8", "src_chw", "in_h", "in_w", "resize", "resize_h", "resize_w", "crop_h", "crop_w",
+                                        "flip_td", "flip_lr", "has_brightness", "has_contrast", "has_hue", "has_rotate")] +
+                [(n, C.c_float) for n in ("brightness", "contrast", "hue", "angle", "ratio_y", "ratio_x")])
+
+
 class OdtkError(RuntimeError):
     pass
 
@@ -83,6 +91,9 @@ SIGNATURES = {
     "odtk_yolov3_loss": (_i, [C.POINTER(_vp), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f), _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f,
                               _vp, C.POINTER(_vp), _vp, _vp]),
     "odtk_yolov3_decode_candidates": (_i, [C.POINTER(_vp), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f), _i, _i, _vp, _vp, _vp]),
+    "odtk_augment_workspace_bytes": (_ll, [_i, _i, _i, _i]),
+    "odtk_augment_boxes": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "odtk_augment_images": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "odtk_ssd_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -159,6 +159,41 @@ def floor(x):
     return torch.floor(x)
 
 
+# ---- scripted randomness: tf.random_uniform / tf.random.uniform pop values pushed by the test (TF's RNG cannot be matched)
+RANDOM_QUEUE = []
+
+
+def random_uniform(shape, minval=0., maxval=1., dtype=None):
+    n = int(np.prod(shape)) if len(shape) else 0
+    if n:
+        return torch.tensor([RANDOM_QUEUE.pop(0) for _ in range(n)], dtype=dtype or float32).reshape(list(shape))
+    return torch.tensor(RANDOM_QUEUE.pop(0), dtype=dtype or float32)
+
+
+def cos(x):
+    return torch.cos(_t(x))
+
+
+def sin(x):
+    return torch.sin(_t(x))
+
+
+def pad(x, paddings, mode='CONSTANT', constant_values=0.):
+    flat = []
+    for lo, hi in reversed([(int(a), int(b)) for a, b in paddings]):
+        flat += [lo, hi]
+    return F.pad(x, flat, value=float(constant_values))
+
+
+def slice_(x, begin, size):
+    idx = tuple(slice(int(b), int(b) + int(s)) for b, s in zip(begin, size))
+    return x[idx]
+
+
+def reverse(x, axis):
+    return torch.flip(x, [int(a) for a in axis])
+
+
 def one_hot(indices, depth):
     return F.one_hot(_t(indices).long(), int(depth)).to(float32)
 
@@ -552,6 +587,67 @@ class _Image:
         return torch.from_numpy(idx.astype(np.int32))
 
 
+class _ResizeMethod:
+    BILINEAR, NEAREST_NEIGHBOR, BICUBIC = 'bilinear', 'nearest', 'bicubic'
+
+
+def _resize_images(images, size, method='bilinear', align_corners=False, preserve_aspect_ratio=False):
+    """tf.image.resize_images on one HWC image; bilinear with align_corners=True is what the reference uses."""
+    assert method == 'bilinear' and not preserve_aspect_ratio
+    h, w = int(size[0]), int(size[1])
+    x = images.permute(2, 0, 1).unsqueeze(0)
+    y = F.interpolate(x, size=(h, w), mode='bilinear', align_corners=bool(align_corners))
+    return y.squeeze(0).permute(1, 2, 0).contiguous()
+
+
+def _adjust_contrast(images, contrast_factor):
+    mean = images.mean(dim=(-3, -2), keepdim=True)
+    return (images - mean) * contrast_factor + mean
+
+
+def _adjust_hue(images, delta):
+    """HSV round trip (value-range free), written the colorsys way."""
+    r, g, b = images.unbind(-1)
+    mx, mn = images.max(-1).values, images.min(-1).values
+    d = mx - mn
+    safe = torch.where(d > 0, d, torch.ones_like(d))
+    rc, gc, bc = (mx - r) / safe, (mx - g) / safe, (mx - b) / safe
+    h = torch.where(r == mx, bc - gc, torch.where(g == mx, 2. + rc - bc, 4. + gc - rc))
+    h = torch.where(d > 0, (h / 6.) % 1.0, torch.zeros_like(h))
+    h = (h + delta) % 1.0
+    i = torch.floor(h * 6.)
+    f = h * 6. - i
+    # TF's CPU kernel carries (hue, min, max), never a saturation: out-of-gamut (negative) pixels keep their range
+    p_, q, t_ = mx - d, mx - d * f, mx - d * (1. - f)
+    i = (i.long() % 6).unsqueeze(-1)
+    pick = lambda *c: torch.stack(c, -1).gather(-1, i).squeeze(-1)
+    return torch.stack([pick(mx, q, p_, p_, t_, mx), pick(t_, mx, mx, q, p_, p_), pick(p_, p_, t_, mx, mx, q)], -1)
+
+
+def _contrib_rotate(img, ang, interpolation='NEAREST'):
+    """tf.contrib.image.rotate, BILINEAR: output(x, y) = input(R(x, y)), zero outside; through grid_sample."""
+    assert interpolation == 'BILINEAR'
+    H, W, _ = img.shape
+    ang = float(ang)
+    c, s = math.cos(ang), math.sin(ang)
+    ox = ((W - 1) - (c * (W - 1) - s * (H - 1))) / 2.
+    oy = ((H - 1) - (s * (W - 1) + c * (H - 1))) / 2.
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing='ij')
+    sx = c * xs - s * ys + ox
+    sy = s * xs + c * ys + oy
+    grid = torch.stack([sx / (W - 1) * 2 - 1, sy / (H - 1) * 2 - 1], -1).unsqueeze(0).float()
+    out = F.grid_sample(img.permute(2, 0, 1).unsqueeze(0), grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+    ROTATE_TRACE.append(out.squeeze(0).permute(1, 2, 0).contiguous())
+    return ROTATE_TRACE[-1]
+
+
+ROTATE_TRACE = []          # outputs of tf.contrib.image.rotate, for callers whose return value drops the image
+_Image.adjust_brightness = staticmethod(lambda images, delta: images + delta)
+_Image.adjust_contrast = staticmethod(_adjust_contrast)
+_Image.adjust_hue = staticmethod(_adjust_hue)
+_Image.ResizeMethod = _ResizeMethod
+_Image.resize_images = staticmethod(_resize_images)
+_Image.resize = staticmethod(lambda images, size: _resize_images(images, size, 'bilinear', False))
 image = _Image()
 
 
@@ -582,7 +678,9 @@ class _ContribFramework:
         return torch.sort(x).values
 
 
-contrib = types.SimpleNamespace(framework=_ContribFramework())
+contrib = types.SimpleNamespace(framework=_ContribFramework(),
+                               image=types.SimpleNamespace(rotate=_contrib_rotate))
+random = types.SimpleNamespace(uniform=random_uniform)
 
 
 # ---------------------------------------------------------------------------- training
@@ -693,6 +791,7 @@ def install(vgg_tensors=None):
             setattr(tf, k, getattr(me, k))
     tf.range = range_
     tf.abs = abs_
+    tf.slice = slice_
     tf.bool = bool_
     tf.layers, tf.nn, tf.losses, tf.image, tf.sparse, tf.contrib = layers, nn, losses, image, sparse, contrib
     tf.train, tf.summary, tf.gfile = train, summary, gfile

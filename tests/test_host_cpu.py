@@ -100,3 +100,34 @@ def test_conv_fastdiv_and_swizzle_properties():
     # wgrad DMA piece: 4 rows x 4 chunks read by a half-wave cover all 16 slots of the 256-B bank row
     for ch0 in (0, 4, 8, 12):
         assert len({(ch ^ (r << 2)) for r in range(4) for ch in range(ch0, ch0 + 4)}) == 16
+
+
+def test_augmentor_plan_matches_oracle_plan():
+    """odtk.augment.Augmentor.plan (host logic: sizes, ratios, draw order) against oracle/augment_ref.plan, no GPU"""
+    import numpy as np
+    from odtk import augment as A
+    from oracle import augment_ref as AR
+    rng = np.random.default_rng(3)
+    cfgs = [dict(output_shape=[300, 300], crop_method='random', flip_prob=[0., 0.5], fill_mode='BILINEAR', keep_aspect_ratios=False,
+                 color_jitter_prob=0.5, rotate=[0.5, -5., -5.]),
+            dict(output_shape=[64, 96], zoom_size=[80, 120], crop_method='random', flip_prob=[0.5, 0.5], fill_mode='BILINEAR',
+                 keep_aspect_ratios=True, constant_values=1., color_jitter_prob=0.7, rotate=[0.6, -5., 5.]),
+            dict(output_shape=[48, 48], zoom_size=[56, 60], crop_method='center', fill_mode='BILINEAR'),
+            dict(output_shape=[72, 80], fill_mode='CONSTANT', flip_prob=[0.5, 0.5])]
+    for cfg in cfgs:
+        aug = A.Augmentor('channels_last', **cfg)
+        for _ in range(50):
+            h, w = int(rng.integers(20, 600)), int(rng.integers(20, 600))
+            draws = [int(rng.integers(0, 8)), int(rng.integers(0, 8))] if cfg.get('zoom_size') and cfg['crop_method'] == 'random' else []
+            draws += [float(rng.uniform()) for _ in range(12)]
+            d = A._Draws(list(draws))
+            mine = aug.plan(h, w, d)
+            ref = AR.plan([h, w, 3], cfg['output_shape'], cfg.get('zoom_size'), cfg.get('crop_method'), cfg.get('flip_prob'),
+                          cfg['fill_mode'], cfg.get('keep_aspect_ratios', False), cfg.get('color_jitter_prob'), cfg.get('rotate'), draws)
+            assert d.q == ref['unused_draws']
+            for k in ('resize_h', 'resize_w', 'crop_h', 'crop_w', 'ratio_y', 'ratio_x'):
+                assert mine[k] == ref[k], (k, mine[k], ref[k])
+            assert bool(mine['flip_td']) == ref['flip_td'] and bool(mine['flip_lr']) == ref['flip_lr']
+            for k in ('brightness', 'contrast', 'hue'):
+                assert (ref[k] is not None) == bool(mine['has_' + k]) and (ref[k] is None or ref[k] == mine[k])
+            assert (ref['angle'] is not None) == bool(mine['has_rotate']) and (ref['angle'] is None or ref['angle'] == mine['angle'])

@@ -206,3 +206,48 @@ def test_full_inference_branches_vs_reference():
     cf, bx, keep, _ = RR.decode_candidates(pbox[:, :2], pbox[:, 2:], pconf, anc, 0.35)
     s, b, c = DC.per_class_nms(cf, bx, 20, 0.35, 10, 0.5, row_mask=keep)
     assert np.array_equal(c.numpy(), d['class_id']) and np.array_equal(s.numpy(), d['scores']) and np.array_equal(b.numpy(), d['bbox'])
+
+
+def augment_cases():
+    import json
+    g = np.load(os.path.join(GOLD, 'augment.npz'))
+    return g, json.loads(bytes(g['meta']).decode())
+
+
+def test_augmentor_vs_reference_image_augmentor():
+    """oracle/augment_ref.py against the reference's own image_augmentor run with scripted draws: boxes to 1e-4 px,
+    images to 2e-3 on the 0..255 scale (the colour and rotate image ops come from the shim's restated TF kernels)"""
+    from oracle import augment_ref as A
+    g, meta = augment_cases()
+    for m in meta:
+        n = m['name']
+        img = torch.from_numpy(g[f'{n}_image'].astype(np.float32))
+        gt = torch.from_numpy(g[f'{n}_gt_in'])
+        h, w = m['hw']
+        aug, out_gt = A.image_augmentor(img, [h, w, 3], m['data_format'], ground_truth=gt, pad_truth_to=6, draws=m['draws'],
+                                        **m['kwargs'])
+        np.testing.assert_allclose(out_gt.numpy(), g[f'{n}_gt_out'], rtol=0, atol=1e-4, err_msg=n)
+        want = g[f'{n}_aug']
+        if m['kwargs'].get('rotate') is not None and m['data_format'] == 'channels_first':
+            want = want.transpose(2, 0, 1)
+        np.testing.assert_allclose(aug.numpy(), want, rtol=0, atol=2e-3, err_msg=n)
+        quirk, _ = A.image_augmentor(img, [h, w, 3], m['data_format'], ground_truth=gt, pad_truth_to=6, draws=m['draws'],
+                                     image_quirk=True, **m['kwargs'])
+        assert quirk is img                                   # image_augmentor.py:231 returns image_copy
+
+
+def test_augmentor_lost_boxes_and_fallback():
+    """the two situations the reference aborts in (:217): some / all box centres leave the image"""
+    from oracle import augment_ref as A
+    img = torch.rand(20, 30, 3) * 255
+    gt = torch.tensor([[2., 8., 3., 9., 1.], [10., 18., 20., 29., 2.]])
+    kw = dict(output_shape=[10, 10], zoom_size=[20, 30], crop_method='random', fill_mode='BILINEAR')
+    aug, out = A.image_augmentor(img, [20, 30, 3], 'channels_last', ground_truth=gt, pad_truth_to=4, draws=[0, 0], **kw)
+    assert (out[1:] == -1).all() and out[0].tolist() == [5., 6., 6., 6., 1.]
+    aug, out = A.image_augmentor(img, [20, 30, 3], 'channels_last', ground_truth=gt[1:], pad_truth_to=4, draws=[0, 0], **kw)
+    np.testing.assert_allclose(out[0].numpy(), [14. * .5, 24.5 / 3., 8. * .5, 9. / 3., 2.], rtol=1e-6)   # gt_checker_helper
+    np.testing.assert_allclose(aug.numpy(), A.resize_bilinear_legacy(img, 10, 10).numpy())
+    with pytest.raises(Exception, match="data_format must in"):
+        A.image_augmentor(img, [20, 30, 3], 'NHWC', [10, 10])
+    with pytest.raises(Exception, match="rotate range must be -5 to 5"):
+        A.image_augmentor(img, [20, 30, 3], 'channels_last', [10, 10], rotate=[.5, -9., 3.], ground_truth=gt, pad_truth_to=4)   # (-9, 9) slips through :56, as in the reference

@@ -36,6 +36,9 @@ extern "C" {
 
 const char* odtk_last_error(void);
 int odtk_version(void);
+/* host-side CRC32C (Castagnoli) of n bytes continuing from `crc` (0 to start): the checksum inside TensorFlow checkpoint
+ * files, for the reader / writer that stands in for tf.train.Saver and NewCheckpointReader (SSD300.py:31, :464-504) */
+unsigned int odtk_crc32c(const void* data, long long n, unsigned int crc);
 /* number of compute units / name of the current device (host out pointers) */
 int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
 /* test/debug knobs: key 0 = force the register-staged conv gather kernel (value != 0);

@@ -39,6 +39,35 @@ int zero_async(void* p, size_t bytes, hipStream_t st) {
 
 extern "C" const char* odtk_last_error(void) { return odtk::g_err; }
 extern "C" int odtk_version(void) { return 100; }
+// Host-side CRC32C (Castagnoli, reflected 0x82f63b78), slice-by-8: the checksum of TensorFlow's checkpoint blocks and
+// tensors (tf_checkpoint.py reads / writes hundreds of MB of weights; SSD300.py:31, :490-504).  No device work.
+extern "C" unsigned int odtk_crc32c(const void* data, long long n, unsigned int crc) {
+    static unsigned int tab[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (unsigned int i = 0; i < 256; ++i) {
+            unsigned int c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82f63b78u : c >> 1;
+            tab[0][i] = c;
+        }
+        for (unsigned int i = 0; i < 256; ++i)
+            for (int s = 1; s < 8; ++s) tab[s][i] = (tab[s - 1][i] >> 8) ^ tab[0][tab[s - 1][i] & 0xff];
+        ready = true;
+    }
+    const unsigned char* p = (const unsigned char*)data;
+    unsigned int c = ~crc;
+    while (n >= 8) {
+        unsigned int lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = tab[7][lo & 0xff] ^ tab[6][(lo >> 8) & 0xff] ^ tab[5][(lo >> 16) & 0xff] ^ tab[4][lo >> 24] ^
+            tab[3][hi & 0xff] ^ tab[2][(hi >> 8) & 0xff] ^ tab[1][(hi >> 16) & 0xff] ^ tab[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n-- > 0) c = tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return ~c;
+}
+
 extern "C" int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len) {
     int dev = 0;
     ODTK_CHECK_HIP(hipGetDevice(&dev));

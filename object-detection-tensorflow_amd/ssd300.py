@@ -54,6 +54,30 @@ EXTRA_SEQ = [
 FEAT_SRC = ["feat1", "conv7", "conv8_2", "conv9_2", "conv10_2", "conv11_2"]   # reference SSD300.py:314
 
 
+def reference_variable_map():
+    """name of every variable of the reference's graph -> our parameter / statistic name.
+    SSD300.py:193-300 (`kernel_convX_Y` / `bias_convX_Y` under 'feature_extractor', with the two misspelt names
+    `kenrel_conv2_1` :212 and `bias_conv_3_1` :232), :77 l2_norm_factor, :304-313 + :85-90 tf.layers.conv2d
+    (`<scope>/<name>/kernel|bias`) each followed by tf.layers.batch_normalization, whose default layer names count
+    up over the whole graph (batch_normalization, _1 ... _15)."""
+    m = OrderedDict()
+    for item in VGG_SEQ:
+        n = item[0]
+        if n.startswith('conv'):
+            m['feature_extractor/' + ('kenrel_' if n == 'conv2_1' else 'kernel_') + n] = n + '.w'
+            m['feature_extractor/' + ('bias_conv_3_1' if n == 'conv3_1' else 'bias_' + n)] = n + '.b'
+    m['feature_extractor/l2_norm_factor'] = 'l2norm.gamma'
+    bn = 0
+    for scope, names in (('feature_extractor', [e[0] for e in EXTRA_SEQ]), ('regressor', [f'pred{i}' for i in range(1, 7)])):
+        for n in names:
+            bns = f'{scope}/batch_normalization' + (f'_{bn}' if bn else '')
+            bn += 1
+            m[f'{scope}/{n}/kernel'], m[f'{scope}/{n}/bias'] = n + '.w', n + '.b'
+            m[bns + '/gamma'], m[bns + '/beta'] = n + '.gamma', n + '.beta'
+            m[bns + '/moving_mean'], m[bns + '/moving_variance'] = n + '.mmean', n + '.mvar'
+    return m
+
+
 def prior_spec(input_size=INPUT_SIZE):
     """Host part of SSD300._get_abbox (reference SSD300.py:112-119, 333-336): the python-double
     (h, w) list per level, flattened; the per-cell arithmetic runs in odtk_ssd_priors."""
@@ -137,6 +161,7 @@ class SSD300:
             if data_provider.get('val_generator') is not None:
                 self.val_generator = data_provider['val_generator']
         self.global_step = 0
+        self.checkpoint_format = config.get('checkpoint_format', 'torch')          # 'tf': tf.train.Saver files (tf_checkpoint.py)
         self.use_graph = bool(config.get('use_graph', True))   # HIP-graph replay of the step after 2 eager steps
         # optional: filter gradients on a second HIP stream (wgrad(L) only needs dy(L) and the stored input of L, nothing
         # on the dgrad chain needs its result before the optimizer).  Measured neutral on MI355X (both chains are
@@ -269,13 +294,20 @@ class SSD300:
 
     def _load_pretraining_weight(self):
         """The reference initialises the 13 VGG convs from slim's vgg_16.ckpt (SSD300.py:31,193-299).
-        No TF checkpoint reader here: accept a torch/npz file holding 'vgg_16/convX/convX_Y/weights'
-        (HWIO) and '.../biases'; otherwise keep the synthetic He init."""
+        Accepts the TensorFlow checkpoint itself (tf_checkpoint.NewCheckpointReader, V1 or V2) or a torch/npz file
+        holding 'vgg_16/convX/convX_Y/weights' (HWIO) and '.../biases'; otherwise keeps the synthetic He init."""
         path = self.pretraining_weight
-        if not path or not os.path.exists(str(path)):
+        if not path or not (os.path.exists(str(path)) or os.path.exists(str(path) + '.index')):
             return
         try:
-            blob = dict(np.load(path)) if str(path).endswith('.npz') else torch.load(path, map_location='cpu')
+            if str(path).endswith('.npz'):
+                blob = dict(np.load(path))
+            elif str(path).endswith(('.pt', '.pth')):
+                blob = torch.load(path, map_location='cpu')
+            else:                                                # slim's vgg_16.ckpt (V1) or a Saver prefix (V2): SSD300.py:31
+                from .tf_checkpoint import NewCheckpointReader
+                reader = NewCheckpointReader(str(path))
+                blob = {k: reader.get_tensor(k) for k in reader.get_variable_to_shape_map() if k.startswith('vgg_16/conv')}
         except Exception as e:                                   # noqa: BLE001
             print(f'[odtk] could not read pretraining weights {path}: {e}; keeping synthetic init')
             return
@@ -725,18 +757,80 @@ class SSD300:
         return [torch.cat(scores).numpy(), torch.cat(bbox, 0).numpy().reshape(-1, 4), torch.cat(cid).numpy()]
 
     # ------------------------------------------------------------------ checkpoints
+    def tf_variable_map(self):
+        return reference_variable_map()
+
+    def _logical(self, name, buf):
+        """parameter `name` out of a flat buffer (P or Mom) in TensorFlow's layout: kernels HWIO, un-padded"""
+        v = self.param(name, buf).detach().cpu()
+        if name.endswith('.w'):
+            v = v[..., : self.convs[name[:-2]].cin].permute(1, 2, 3, 0)
+        return np.ascontiguousarray(v.numpy())
+
+    def export_tf_variables(self):
+        """what the reference's `tf.train.Saver()` (SSD300.py:464-466) would write: every global variable -- weights, BN
+        moving statistics, global_step and the MomentumOptimizer slots, which are created inside the 'inference' scope
+        (:104, :149) and therefore named inference/<variable>/Momentum."""
+        out = OrderedDict()
+        for tfname, ours in self.tf_variable_map().items():
+            if ours in self.pinfo:
+                out[tfname] = self._logical(ours, self.P)
+                out[f'inference/{tfname}/Momentum'] = self._logical(ours, self.Mom)
+            else:
+                out[tfname] = self.stat(ours).detach().cpu().numpy().copy()
+        out['global_step'] = np.asarray(self.global_step, dtype=np.int32)
+        return out
+
+    def load_tf_checkpoint(self, path):
+        """`saver.restore(sess, path)` (SSD300.py:502-504) from the files of a reference-trained model (or ours)."""
+        from .tf_checkpoint import NewCheckpointReader
+        reader = NewCheckpointReader(str(path))
+        names = reader.get_variable_to_shape_map()
+        for tfname, ours in self.tf_variable_map().items():
+            if ours in self.pinfo:
+                v = torch.from_numpy(reader.get_tensor(tfname))                 # KeyError = Saver's NotFoundError
+                self.set_param(ours, v.permute(3, 0, 1, 2).contiguous() if ours.endswith('.w') else v)
+                slot = [k for k in names if k.endswith(tfname + '/Momentum')]
+                if slot:
+                    mv = torch.from_numpy(reader.get_tensor(slot[0]))
+                    dst = self.param(ours, self.Mom)
+                    if ours.endswith('.w'):
+                        dst.zero_()
+                        dst[..., : mv.shape[2]] = mv.permute(3, 0, 1, 2).to(self.dev)
+                    else:
+                        dst.copy_(mv.to(self.dev).view(dst.shape))
+            else:
+                self.stat(ours).copy_(torch.from_numpy(reader.get_tensor(tfname)).to(self.dev))
+        if reader.has_tensor('global_step'):
+            self.global_step = int(reader.get_tensor('global_step'))
+        self._refresh_operand_copies()
+
     def save_weight(self, mode, path):
+        """SSD300.py:490-500.  config['checkpoint_format'] = 'tf' writes the reference's own files
+        (`<path>-<step>.index` + `.data-00000-of-00001` + `checkpoint`, readable by its `load_weight`); the default
+        'torch' keeps one torch file `<path>-<step>`."""
         assert (mode in ['latest', 'best'])
         dirname = os.path.dirname(path)
         if dirname and not os.path.exists(dirname):
             os.makedirs(dirname)
             print(dirname, 'does not exist, create it done')
+        if self.checkpoint_format == 'tf':
+            from . import tf_checkpoint
+            prefix = path + '-' + str(self.global_step)
+            tf_checkpoint.write_bundle(prefix, self.export_tf_variables())
+            tf_checkpoint.update_checkpoint_state(prefix)
+            print('save', mode, 'model in', path, 'successfully')
+            return
         blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(),
                 'global_step': self.global_step, 'layout': dict(self.pinfo)}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
     def load_weight(self, path):
+        if os.path.exists(str(path) + '.index'):                 # a tf.train.Saver checkpoint prefix
+            self.load_tf_checkpoint(path)
+            print('load weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=False)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):

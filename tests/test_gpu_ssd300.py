@@ -122,6 +122,48 @@ def test_train_one_epoch_and_checkpoint(dev, tmp_path):
     assert len(out) == 3
 
 
+def test_tf_saver_checkpoint_roundtrip_and_pretraining(dev, tmp_path):
+    """checkpoint_format='tf': the files tf.train.Saver would leave (SSD300.py:490-504) -- every variable of the reference's
+    graph under its name and shape (tests/golden/ssd300_variables.json, collected from the reference's own class), momentum
+    slots, global_step -- and back; then slim-style `pretraining_weight` from a V1 checkpoint file (SSD300.py:31)."""
+    import json
+    import os
+    import odtk
+    from odtk import tf_checkpoint as T
+    from test_tf_checkpoint_cpu import _v1_file
+    B = 2
+    prov, data = _provider(B, 2, seed=60)
+    m = odtk.SSD300(dict(CONFIG, mode='train', compute_dtype='bf16', batch_size=B, checkpoint_format='tf'), prov)
+    m.train_one_epoch(0.001)
+    path = str(tmp_path / 'tfckpt' / 'model.ckpt')
+    m.save_weight('latest', path)
+    assert T.latest_checkpoint(str(tmp_path / 'tfckpt')) == path + '-2'
+    r = T.NewCheckpointReader(path + '-2')
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ssd300_variables.json')))
+    shapes = r.get_variable_to_shape_map()
+    for name, info in want.items():
+        assert shapes[name] == info['shape'], name
+        assert (f'inference/{name}/Momentum' in shapes) == info['trainable'], name
+    assert len(shapes) == len(want) + sum(v['trainable'] for v in want.values())
+    assert int(r.get_tensor('global_step')) == 2 and r.get_variable_to_dtype_map()['global_step'] == np.int32
+    m2 = odtk.SSD300(dict(CONFIG, mode='train', compute_dtype='bf16', batch_size=B, seed=99), prov)
+    m2.load_weight(path + '-2')
+    a, b = m.export_params(), m2.export_params()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.equal(m.Mom, m2.Mom) and float(m.Mom.abs().max()) > 0 and m2.global_step == 2
+    # slim-style initialisation: a V1 file holding vgg_16/convX/convX_Y/{weights,biases}
+    g = np.random.default_rng(5)
+    vgg = {}
+    for n, cin, cout in [('conv1_1', 3, 64), ('conv4_3', 512, 512)]:
+        vgg[f'vgg_16/{n.split("_")[0]}/{n}/weights'] = (g.standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
+        vgg[f'vgg_16/{n.split("_")[0]}/{n}/biases'] = g.standard_normal(cout).astype(np.float32)
+    fn = str(tmp_path / 'vgg_16.ckpt')
+    _v1_file(fn, vgg)
+    m3 = odtk.SSD300(dict(CONFIG, mode='test', compute_dtype='bf16', batch_size=1, pretraining_weight=fn), None)
+    w = m3.get_param('conv4_3.w').permute(1, 2, 3, 0).numpy()
+    assert np.array_equal(w, vgg['vgg_16/conv4/conv4_3/weights']) and np.array_equal(m3.get_param('conv1_1.b').numpy(), vgg['vgg_16/conv1/conv1_1/biases'])
+
+
 def test_graph_replay_equals_eager_launches(dev):
     """HIP-graph replay of the step (default after two eager steps) == the eagerly launched step.
     f32 path; wgrad accumulates with float atomics, so equality is to rounding, not bitwise."""

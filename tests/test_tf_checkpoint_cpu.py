@@ -1,0 +1,157 @@
+"""odtk.tf_checkpoint (the stand-in for tf.train.Saver / NewCheckpointReader, SSD300.py:31, :464-504) on the CPU.
+No TensorFlow here, so the anchors are published ones: the RFC 3720 CRC32C vectors, a table assembled BY HAND from the
+LevelDB table-format description, a snappy stream written out by its format description; then writer <-> reader."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from odtk import tf_checkpoint as T
+
+
+def test_crc32c_known_answers():
+    assert T.crc32c(b'123456789') == 0xE3069283
+    assert T.crc32c(bytes(32)) == 0x8A9136AA                    # RFC 3720 B.4
+    assert T.crc32c(b'\xff' * 32) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    assert T.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    big = (bytes(range(256)) * 64)[:16001]                       # native slice-by-8 path (>= 4096 bytes) against the byte loop
+    slow = 0xffffffff
+    for b in big:
+        slow = T._CRC_TABLE[(slow ^ b) & 0xff] ^ (slow >> 8)
+    assert T.crc32c(big) == slow ^ 0xffffffff
+    assert T.crc32c(big[5000:], T.crc32c(big[:5000])) == T.crc32c(big)      # continuation
+    assert T.mask_crc(0) == 0xa282ead8 and T.mask_crc(0xE3069283) == ((0xE3069283 >> 15 | 0xE3069283 << 17) + 0xa282ead8) & 0xffffffff
+
+
+def _hand_table():
+    """two entries in one data block, written straight from the LevelDB table_format / block layout description"""
+    def entry(shared, key_delta, value):
+        return bytes([shared, len(key_delta), len(value)]) + key_delta + value
+    data = entry(0, b'apple', b'1') + entry(2, b'ricot', b'22')             # 'apricot' shares 'ap'
+    data += struct.pack('<I', 0) + struct.pack('<I', 1)                      # one restart at 0
+    out = bytearray()
+
+    def put(block):
+        off = len(out)
+        out.extend(block + b'\x00' + struct.pack('<I', T.mask_crc(T.crc32c(block + b'\x00'))))
+        return bytes([off, len(block)])                                      # both < 128: one-byte varints
+    h_data = put(data)
+    h_meta = put(struct.pack('<I', 0) + struct.pack('<I', 1))
+    index = entry(0, b'b', h_data) + struct.pack('<I', 0) + struct.pack('<I', 1)
+    h_index = put(index)
+    foot = h_meta + h_index
+    out.extend(foot + bytes(40 - len(foot)) + struct.pack('<Q', 0xdb4775248b80fb57))
+    return bytes(out)
+
+
+def test_table_reader_on_hand_assembled_table_and_writer_roundtrip():
+    assert list(T._Table(_hand_table()).items()) == [(b'apple', b'1'), (b'apricot', b'22')]
+    bad = bytearray(_hand_table()); bad[3] ^= 1
+    with pytest.raises(ValueError, match='checksum'):
+        list(T._Table(bytes(bad)).items())
+    with pytest.raises(ValueError, match='magic'):
+        T._Table(b'\x00' * 64)
+    items = [(f'var/{i:04d}/kernel'.encode(), os.urandom(i % 50)) for i in range(300)]
+    for bs in (64, 4096, 262144):
+        assert list(T._Table(T._build_table(items, block_size=bs)).items()) == items
+    with pytest.raises(ValueError, match='increasing'):
+        T._build_table([(b'b', b''), (b'a', b'')])
+
+
+def test_snappy_stream_by_format_description():
+    # "hello hello hello!" = literal 'hello ' + copy(offset 6, len 11 -> overlapping) + literal '!'
+    src = bytes([18]) + bytes([(6 - 1) << 2]) + b'hello ' + bytes([((11 - 4) << 2) | 1 | (0 << 5), 6]) + bytes([0 << 2]) + b'!'
+    assert T._snappy_uncompress(src) == b'hello hello hello!'
+    src2 = bytes([10]) + bytes([(4 - 1) << 2]) + b'abcd' + bytes([((6 - 1) << 2) | 2]) + struct.pack('<H', 4)     # 2-byte-offset copy
+    assert T._snappy_uncompress(src2) == b'abcdabcdab'
+
+
+def test_bundle_write_read_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    tensors = {'feature_extractor/kernel_conv1_1': rng.standard_normal((3, 3, 3, 64)).astype(np.float32),
+               'feature_extractor/bias_conv1_1': rng.standard_normal(64).astype(np.float32),
+               'global_step': np.asarray(1234, dtype=np.int32),
+               'regressor/pred1/kernel': rng.standard_normal((3, 3, 512, 100)).astype(np.float32),     # 1.8 MB: native CRC path
+               'misc/half': rng.standard_normal((5, 7)).astype(np.float16), 'misc/i64': np.arange(6, dtype=np.int64).reshape(2, 3),
+               'misc/empty': np.zeros((0, 4), np.float32)}
+    prefix = str(tmp_path / 'model.ckpt-1234')
+    T.write_bundle(prefix, tensors)
+    T.update_checkpoint_state(prefix)
+    assert sorted(os.listdir(tmp_path)) == ['checkpoint', 'model.ckpt-1234.data-00000-of-00001', 'model.ckpt-1234.index']
+    assert T.latest_checkpoint(str(tmp_path)) == prefix
+    r = T.NewCheckpointReader(prefix)
+    assert r.version == 2 and set(r.get_variable_to_shape_map()) == set(tensors)
+    assert r.get_variable_to_shape_map()['global_step'] == [] and r.get_variable_to_dtype_map()['global_step'] == np.int32
+    for k, v in tensors.items():
+        got = r.get_tensor(k)
+        assert got.dtype == v.dtype and got.shape == v.shape and np.array_equal(got, v)
+    assert r.has_tensor('global_step') and not r.has_tensor('nope')
+    with pytest.raises(KeyError, match='not found in checkpoint'):
+        r.get_tensor('nope')
+    # the bytes sit in name order and a flipped bit is caught by the tensor CRC
+    fn = prefix + '.data-00000-of-00001'
+    raw = bytearray(open(fn, 'rb').read())
+    assert len(raw) == sum(v.nbytes for v in tensors.values())
+    raw[10] ^= 0x40
+    open(fn, 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='checksum'):
+        T.CheckpointReader(prefix).get_tensor(sorted(tensors, key=str.encode)[0])
+    with pytest.raises(FileNotFoundError):
+        T.CheckpointReader(str(tmp_path / 'missing'))
+
+
+def _v1_file(path, tensors, packed=True, split=None):
+    """a V1 'tensor slice' checkpoint as tensor_slice_writer.cc lays it out (the test's own encoder)"""
+    pb, vi = T._pb_bytes, T._put_varint
+    metas, datas = b'', []
+    for name, a in tensors.items():
+        dt = T._DT_OF_NP[a.dtype]
+        full = b''.join(pb(1, b'') for _ in a.shape)                       # Extent without length = the whole dimension
+        metas += pb(1, pb(1, name.encode()) + pb(2, T._encode_shape(a.shape)) + T._pb_field(3, 0, vi(dt)) + pb(4, full))
+        parts = [(full, a)]
+        if split == name:                                                  # two slices along dim 0
+            h = a.shape[0] // 2
+            ext = lambda s, n: pb(1, T._pb_field(1, 0, vi(s)) + T._pb_field(2, 0, vi(n)))
+            rest = b''.join(pb(1, b'') for _ in a.shape[1:])
+            parts = [(ext(0, h) + rest, a[:h]), (ext(h, a.shape[0] - h) + rest, a[h:])]
+        for i, (sl, arr) in enumerate(parts):
+            flat = arr.reshape(-1)
+            if a.dtype == np.float32:
+                vals = pb(5, flat.astype('<f4').tobytes()) if packed else b''.join(T._pb_field(5, 5, struct.pack('<f', float(x))) for x in flat)
+            else:
+                vals = pb(7, b''.join(vi(int(x)) for x in flat))
+            tp = T._pb_field(1, 0, vi(dt)) + pb(2, T._encode_shape(arr.shape)) + vals
+            datas.append((b'\x00' + name.encode() + bytes([i + 1]), pb(2, pb(1, name.encode()) + pb(2, sl) + pb(3, tp))))
+    items = [(b'', pb(1, metas))] + sorted(datas)
+    open(path, 'wb').write(T._build_table(items, block_size=512))
+
+
+@pytest.mark.parametrize('packed', [True, False])
+def test_v1_slice_checkpoint(tmp_path, packed):
+    rng = np.random.default_rng(1)
+    tensors = {'vgg_16/conv1/conv1_1/weights': rng.standard_normal((3, 3, 3, 8)).astype(np.float32),
+               'vgg_16/conv1/conv1_1/biases': rng.standard_normal(8).astype(np.float32),
+               'global_step': np.asarray([7], dtype=np.int32)}
+    fn = str(tmp_path / 'vgg_16.ckpt')
+    _v1_file(fn, tensors, packed=packed, split='vgg_16/conv1/conv1_1/weights')
+    r = T.NewCheckpointReader(fn)
+    assert r.version == 1 and r.get_variable_to_shape_map()['vgg_16/conv1/conv1_1/weights'] == [3, 3, 3, 8]
+    for k, v in tensors.items():
+        assert np.array_equal(r.get_tensor(k), v)
+
+
+def test_reference_variable_map_matches_reference_graph():
+    """odtk.ssd300.reference_variable_map against the variables the reference's own SSD300 class creates
+    (tests/golden/ssd300_variables.json, tests/golden/make_golden_variables.py), misspelt names included"""
+    import json
+    from odtk.ssd300 import reference_variable_map
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ssd300_variables.json')))
+    m = reference_variable_map()
+    assert set(m) | {'global_step'} == set(want)
+    assert 'feature_extractor/kenrel_conv2_1' in m and 'feature_extractor/bias_conv_3_1' in m
+    for name, ours in m.items():
+        assert want[name]['trainable'] == (not ours.endswith(('.mmean', '.mvar'))), name
+        if ours.endswith('.w'):
+            assert len(want[name]['shape']) == 4

@@ -136,6 +136,7 @@ int odtk_maxpool2x2_bwd_idx(const void* idx, const void* dy, void* dx, int N, in
 /* tf.layers.batch_normalization, fused semantics (SSD300.py:506-512), momentum .99 eps 1e-3.
  * z [M][ldz] (dtype) -> y.  Output row m is written at y + (m / rows_per_img)*y_img_stride
  * + (m % rows_per_img)*ldy (lets the head write straight into pred [N,8828,25]).
+ * relu: 0 none, 1 tf.nn.relu, 2 tf.nn.leaky_relu(., 0.1) (YOLOv3.py:505); the backward masks / scales dy by the sign of y.
  * training: batch statistics (biased var), saves mean / inv-std (f32 [C]) for backward and
  * updates moving stats with the unbiased variance.  Inference: uses moving stats.
  * workspace: >= odtk_bn_workspace_bytes(M, C) bytes (always required). */
@@ -150,6 +151,16 @@ int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, int C, int 
                 int y_dtype, int ldy, int rows_per_img, long long y_img_stride,
                 const float* gamma, const float* save_mean, const float* save_invstd, int relu,
                 void* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
+
+/* Glue of the residual / pyramid detectors (SURVEY.md 8f.1 backbones).  Rows are [M][ld] with their own pitch, so a
+ * channel slice of a concat buffer is an ordinary operand; C and every pitch multiples of 16 bytes, pointers 16-byte aligned.
+ * odtk_add2d: y = a + b (b NULL: pitched copy; y may alias a: accumulate) -- `conv = conv + conv2` (YOLOv3.py:489-491),
+ * tf.concat halves and their gradients (:412).  odtk_upsample2x_*: tf.image.resize_nearest_neighbor to twice the size
+ * (:411) and its gradient (sum of the four copies; accumulate != 0 adds to dx). */
+int odtk_add2d(const void* a, int lda, const void* b, int ldb, void* y, int ldy, long long M, int C, int dtype, void* stream);
+int odtk_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream);
+int odtk_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, int dtype, int accumulate,
+                        void* stream);
 
 /* tf.nn.l2_normalize(axis=C) * scalar gamma (SSD300.py:74-83). */
 int odtk_l2norm_fwd(const void* x, void* y, int M, int C, int ld, int dtype, const float* gamma,

@@ -419,7 +419,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
 #pragma unroll
         for (int e = 0; e < KC; ++e) {
             f[e] = f[e] * sc[e] + of[e];
-            if (relu) f[e] = fmaxf(f[e], 0.f);
+            if (relu == 1) f[e] = fmaxf(f[e], 0.f);
+            else if (relu == 2) f[e] = f[e] > 0.f ? f[e] : 0.1f * f[e];      // tf.nn.leaky_relu(x, 0.1)
         }
         TY* yp = y + out_off(m, rows_per_img, y_img_stride, ldy) + c0;
         if (full && vec_ok) {
@@ -453,7 +454,7 @@ __device__ __forceinline__ void bn_load_dy(const TY* __restrict__ y, const TY* _
         Chunk<bf16_t>::unpack(ld16(reinterpret_cast<const bf16_t*>(dy) + oo), dv);
         if (relu) Chunk<bf16_t>::unpack(ld16(reinterpret_cast<const bf16_t*>(y) + oo), yv);
 #pragma unroll
-        for (int e = 0; e < KC; ++e) d[e] = (relu && !(yv[e % 8] > 0.f)) ? 0.f : dv[e % 8];
+        for (int e = 0; e < KC; ++e) d[e] = (relu && !(yv[e % 8] > 0.f)) ? (relu == 2 ? 0.1f * dv[e % 8] : 0.f) : dv[e % 8];
         return;
     }
 #pragma unroll
@@ -461,7 +462,7 @@ __device__ __forceinline__ void bn_load_dy(const TY* __restrict__ y, const TY* _
         d[e] = 0.f;
         if (c0 + e >= C) continue;
         float v = elem<TY>::load(dy[oo + e]);
-        if (relu && !(elem<TY>::load(y[oo + e]) > 0.f)) v = 0.f;
+        if (relu && !(elem<TY>::load(y[oo + e]) > 0.f)) v = relu == 2 ? 0.1f * v : 0.f;
         d[e] = v;
     }
 }
@@ -1025,6 +1026,124 @@ extern "C" int odtk_cast_from_f32(const float* in, void* out, long long n, int d
     ODTK_REQUIRE(in && out, "cast: null pointer");
     hipStream_t st = (hipStream_t)stream;
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(cast_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, (T*)out, n);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Residual sum / pitched copy / nearest 2x up-sampling: the glue between the convolutions of the residual and
+// pyramid detectors (YOLOv3.py:489-491 `conv = conv + conv2`, :411-412 resize_nearest_neighbor + concat).
+// HBM-bound, 16 bytes per lane, rows addressed through their own pitch so that a channel slice of a concat buffer
+// is an ordinary operand.
+namespace odtk {
+namespace {
+
+// y[m, :C] = a[m, :C] (+ b[m, :C])
+template <typename T>
+__global__ void __launch_bounds__(256) add2d_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb, T* __restrict__ y,
+                                                    int ldy, long long M, int C) {
+    constexpr int KC = Chunk<T>::N;
+    const int cpr = C / KC;
+    const long long total = M * cpr, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long m = i / cpr;
+        const int c = (int)(i - m * cpr) * KC;
+        float fa[KC];
+        Chunk<T>::unpack(ld16(a + m * lda + c), fa);
+        if (b) {
+            float fb[KC];
+            Chunk<T>::unpack(ld16(b + m * ldb + c), fb);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) fa[e] += fb[e];
+        }
+        st16(y + m * ldy + c, Chunk<T>::pack(fa));
+    }
+}
+
+// y[n, 2h + i, 2w + j, :C] = x[n, h, w, :C]
+template <typename T>
+__global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int H, int W,
+                                                             int C) {
+    constexpr int KC = Chunk<T>::N;
+    const int cpr = C / KC;
+    const long long total = (long long)N * 2 * H * 2 * W * cpr, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long row = i / cpr;
+        const int c = (int)(i - row * cpr) * KC;
+        const int wo = (int)(row % (2 * W));
+        const long long r2 = row / (2 * W);
+        const int ho = (int)(r2 % (2 * H)), n = (int)(r2 / (2 * H));
+        st16(y + row * ldy + c, ld16(x + (((long long)n * H + (ho >> 1)) * W + (wo >> 1)) * ldx + c));
+    }
+}
+
+// dx[n, h, w] (+)= sum of the four dy it was copied to (f32 sum, one rounding)
+template <typename T>
+__global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int N, int H,
+                                                             int W, int C, int accumulate) {
+    constexpr int KC = Chunk<T>::N;
+    const int cpr = C / KC;
+    const long long total = (long long)N * H * W * cpr, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long row = i / cpr;
+        const int c = (int)(i - row * cpr) * KC;
+        const int w = (int)(row % W);
+        const long long r2 = row / W;
+        const int h = (int)(r2 % H), n = (int)(r2 / H);
+        float s[KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) s[e] = 0.f;
+        if (accumulate) Chunk<T>::unpack(ld16(dx + row * lddx + c), s);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(dy + (((long long)n * 2 * H + 2 * h + (q >> 1)) * 2 * W + 2 * w + (q & 1)) * lddy + c), f);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) s[e] += f[e];
+        }
+        st16(dx + row * lddx + c, Chunk<T>::pack(s));
+    }
+}
+
+int glue_check(const char* who, int C, int dtype, std::initializer_list<int> pitches, std::initializer_list<const void*> ptrs) {
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(dtype == ODTK_BF16 || dtype == ODTK_F32, "%s: bad dtype %d", who, dtype);
+    ODTK_REQUIRE(C > 0 && C % kc == 0, "%s: C=%d must be a multiple of %d", who, C, kc);
+    for (int ld : pitches) ODTK_REQUIRE(ld >= C && ld % kc == 0, "%s: pitch %d must be >= C and a multiple of %d", who, ld, kc);
+    for (const void* p : ptrs) ODTK_REQUIRE(p && ((uintptr_t)p) % 16 == 0, "%s: operands must be non-null and 16-byte aligned", who);
+    return ODTK_OK;
+}
+
+}  // namespace
+}  // namespace odtk
+
+extern "C" int odtk_add2d(const void* a, int lda, const void* b, int ldb, void* y, int ldy, long long M, int C, int dtype, void* stream) {
+    if (int e = glue_check("add2d", C, dtype, {lda, ldy, b ? ldb : C}, {a, y, b ? b : a})) return e;
+    ODTK_REQUIRE(M > 0, "add2d: M=%lld", M);
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(add2d_kernel<T>, dim3(grid_for(M * (C / kc), 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)a, lda, (const T*)b, ldb, (T*)y, ldy, M, C);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream) {
+    if (int e = glue_check("upsample2x_fwd", C, dtype, {ldx, ldy}, {x, y})) return e;
+    ODTK_REQUIRE(N > 0 && H > 0 && W > 0, "upsample2x_fwd: bad geometry");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3(grid_for((long long)N * 4 * H * W * (C / kc), 256, 65536)), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, N, H, W, C);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, int dtype, int accumulate,
+                                   void* stream) {
+    if (int e = glue_check("upsample2x_bwd", C, dtype, {lddy, lddx}, {dy, dx})) return e;
+    ODTK_REQUIRE(N > 0 && H > 0 && W > 0, "upsample2x_bwd: bad geometry");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(grid_for((long long)N * H * W * (C / kc), 256, 65536)), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C, accumulate);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

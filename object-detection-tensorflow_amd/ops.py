@@ -152,6 +152,19 @@ def bn_bwd(z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, save_me
          _p(gamma), _p(save_mean), _p(save_invstd), int(relu), _p(dz), _p(dgamma), _p(dbeta), _p(ws), _stream())
 
 
+def add2d(a, lda, b, ldb, y, ldy, M, C_):
+    """y[:, :C] = a[:, :C] (+ b[:, :C]); operands are 2-D views with their own pitch (a channel slice of a concat buffer)"""
+    call("odtk_add2d", _p(a), int(lda), _p(b), int(ldb), _p(y), int(ldy), int(M), int(C_), dt_of(a), _stream())
+
+
+def upsample2x_fwd(x, ldx, y, ldy, N, H, W, C_):
+    call("odtk_upsample2x_fwd", _p(x), int(ldx), _p(y), int(ldy), N, H, W, int(C_), dt_of(x), _stream())
+
+
+def upsample2x_bwd(dy, lddy, dx, lddx, N, H, W, C_, accumulate=False):
+    call("odtk_upsample2x_bwd", _p(dy), int(lddy), _p(dx), int(lddx), N, H, W, int(C_), dt_of(dy), int(accumulate), _stream())
+
+
 def l2norm_fwd(x, y, M, C_, ld, gamma):
     call("odtk_l2norm_fwd", _p(x), _p(y), M, C_, ld, dt_of(x), _p(gamma), _stream())
 

@@ -495,6 +495,10 @@ class _NN:
     def l2_loss(v):
         return (v * v).sum() / 2
 
+    @staticmethod
+    def leaky_relu(x, alpha=0.2, name=None):
+        return torch.where(x > 0, x, x * alpha)
+
 
 nn = _NN()
 
@@ -508,9 +512,16 @@ def _glorot_uniform(shape_hwio, gen):
 class _Layers:
     gen = torch.Generator().manual_seed(1234)
 
+    conv_count = 0
+
     @staticmethod
-    def conv2d(inputs, filters, kernel_size, strides, padding, name, data_format, dilation_rate=1):
+    def conv2d(inputs, filters, kernel_size, strides=1, padding='valid', name=None, data_format='channels_last', dilation_rate=1,
+               kernel_initializer=None):
         assert padding == 'same' and data_format == 'channels_last'
+        filters = int(filters)                        # YOLOv3.py:487 passes filters/2, a float under true division
+        if name is None:                              # default layer names count over the whole graph: conv2d, conv2d_1, ...
+            name = 'conv2d' if _Layers.conv_count == 0 else f'conv2d_{_Layers.conv_count}'
+            _Layers.conv_count += 1
         ci = inputs.shape[-1]
         with variable_scope(name):
             w = get_variable('kernel', initializer=_glorot_uniform((kernel_size, kernel_size, ci, filters), _Layers.gen))
@@ -642,6 +653,16 @@ def _contrib_rotate(img, ang, interpolation='NEAREST'):
 
 
 ROTATE_TRACE = []          # outputs of tf.contrib.image.rotate, for callers whose return value drops the image
+def _resize_nearest_neighbor(images, size, align_corners=False):
+    """NHWC; TF-1.x legacy grid: src = floor(dst * in / out)"""
+    n, h, w, c = images.shape
+    oh, ow = int(size[0]), int(size[1])
+    iy = torch.clamp(torch.floor(torch.arange(oh, dtype=torch.float32) * (h / oh)).long(), max=h - 1)
+    ix = torch.clamp(torch.floor(torch.arange(ow, dtype=torch.float32) * (w / ow)).long(), max=w - 1)
+    return images[:, iy][:, :, ix]
+
+
+_Image.resize_nearest_neighbor = staticmethod(_resize_nearest_neighbor)
 _Image.adjust_brightness = staticmethod(lambda images, delta: images + delta)
 _Image.adjust_contrast = staticmethod(_adjust_contrast)
 _Image.adjust_hue = staticmethod(_adjust_hue)
@@ -678,7 +699,7 @@ class _ContribFramework:
         return torch.sort(x).values
 
 
-contrib = types.SimpleNamespace(framework=_ContribFramework(),
+contrib = types.SimpleNamespace(framework=_ContribFramework(), layers=types.SimpleNamespace(variance_scaling_initializer=lambda *a, **k: None),
                                image=types.SimpleNamespace(rotate=_contrib_rotate))
 random = types.SimpleNamespace(uniform=random_uniform)
 
@@ -761,6 +782,7 @@ class InteractiveSession:
         S.ph_count = 0
         S.pending = []
         _Layers.bn_count = 0
+        _Layers.conv_count = 0
         wants_update = 'train_op' in names
         m._define_inputs()
         for k, val in overrides.items():      # e.g. test_one_image feeds self.images = placeholder - mean,
@@ -784,6 +806,7 @@ def install(vgg_tensors=None):
     """Registers fake `tensorflow` / `tensorflow.python.pywrap_tensorflow` modules."""
     reset()
     _Layers.bn_count = 0
+    _Layers.conv_count = 0
     tf = types.ModuleType('tensorflow')
     me = sys.modules[__name__]
     for k in dir(me):
@@ -808,6 +831,7 @@ def install(vgg_tensors=None):
     pw.NewCheckpointReader = _Reader
     py.pywrap_tensorflow = pw
     tf.python = py
+    torch.Tensor.get_shape = lambda self: list(self.shape)       # static shapes (YOLOv3.py:404-408); removed by uninstall()
     sys.modules['tensorflow'] = tf
     sys.modules['tensorflow.python'] = py
     sys.modules['tensorflow.python.pywrap_tensorflow'] = pw
@@ -815,6 +839,8 @@ def install(vgg_tensors=None):
 
 
 def uninstall():
+    if hasattr(torch.Tensor, 'get_shape'):
+        del torch.Tensor.get_shape
     for k in ('tensorflow', 'tensorflow.python', 'tensorflow.python.pywrap_tensorflow'):
         sys.modules.pop(k, None)
 

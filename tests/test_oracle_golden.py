@@ -251,3 +251,46 @@ def test_augmentor_lost_boxes_and_fallback():
         A.image_augmentor(img, [20, 30, 3], 'NHWC', [10, 10])
     with pytest.raises(Exception, match="rotate range must be -5 to 5"):
         A.image_augmentor(img, [20, 30, 3], 'channels_last', [10, 10], rotate=[.5, -9., 3.], ground_truth=gt, pad_truth_to=4)   # (-9, 9) slips through :56, as in the reference
+
+
+def test_yolov3_network_vs_reference_graph():
+    """oracle/yolov3_net_ref.forward against the reference's own _feature_extractor / _yolo3_header run on the shim
+    (tests/golden/yolov3_net.npz): predictions in training and inference mode, moving-statistic updates, and gradients of a
+    fixed scalar through the whole graph"""
+    from oracle import yolov3_net_ref as NR
+    g = np.load(os.path.join(GOLD, 'yolov3_net.npz'))
+    gen = torch.Generator().manual_seed(3)
+    images = torch.rand(2, 64, 64, 3, generator=gen) * 255 - torch.tensor(NR.MEAN_RGB)
+    assert np.array_equal(images.numpy(), g['images'])
+    p = NR.init_params(11)
+    for k in p:
+        if k.endswith('.mmean'):
+            p[k] = 0.05 * torch.randn(p[k].shape, generator=gen)
+        if k.endswith('.mvar'):
+            p[k] = 0.5 + torch.rand(p[k].shape, generator=gen)
+    assert len(NR.layer_specs()) == 75 and len(g['names']) == 75
+    keys = [k[5:].replace('__', '.') for k in g.files if k.startswith('grad_')]
+    for k in keys:
+        p[k].requires_grad_(True)
+    stats = {}
+    preds = NR.forward(p, images, True, stats, subtract_mean=False)
+    scalar = 0.
+    for l, q in enumerate(preds):
+        want = g[f'train_pred{l + 1}']
+        got = q.reshape(want.shape)
+        assert float((got.detach() - torch.from_numpy(want)).abs().max()) < 2e-4 * float(np.abs(want).max() + 1), l
+        scalar = scalar + (got * torch.from_numpy(g[f'weight{l + 1}'])).sum()
+    grads = torch.autograd.grad(scalar, [p[k] for k in keys])
+    for k, gr in zip(keys, grads):
+        want = torch.from_numpy(g['grad_' + k.replace('.', '__')])
+        gr = gr.reshape(-1)[::max(1, gr.numel() // 2048)]                     # the fixture keeps every n-th element
+        assert float((gr - want).norm()) < 2e-3 * float(want.norm() + 1e-6), k
+        p[k].requires_grad_(False)
+    for s in ('c0', 'c26', 'c59', 'c74'):
+        mean, var_unb = stats[s]
+        np.testing.assert_allclose((p[s + '.mmean'] * 0.99 + 0.01 * mean).numpy(), g[f'new_mmean_{s}'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose((p[s + '.mvar'] * 0.99 + 0.01 * var_unb).numpy(), g[f'new_mvar_{s}'], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        for l, q in enumerate(NR.forward(p, images, False, subtract_mean=False)):
+            want = g[f'test_pred{l + 1}']
+            assert float((q.reshape(want.shape) - torch.from_numpy(want)).abs().max()) < 2e-4 * float(np.abs(want).max() + 1), l

@@ -9,11 +9,14 @@ reached through the C-ABI in ``include/odtk.h`` (``libodtk.so``).
 from . import _lib                      # noqa: F401
 from ._lib import BF16, F32, OdtkError  # noqa: F401
 
-__all__ = ["BF16", "F32", "OdtkError", "SSD300"]
+__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3"]
 
 
 def __getattr__(name):
     if name == "SSD300":
         from .ssd300 import SSD300
         return SSD300
+    if name == "YOLOv3":
+        from .yolov3 import YOLOv3
+        return YOLOv3
     raise AttributeError(name)

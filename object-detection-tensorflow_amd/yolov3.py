@@ -1,0 +1,458 @@
+"""YOLOv3 (DarkNet-53) behind the reference's class surface, on libodtk.
+
+Reference: /root/reference/YOLOv3.py
+  * constructor, config keys, data_provider ... :11-60     (`YOLOv3(config, data_provider)`; test mode forces batch 1)
+  * input ..................................... :62-79     (images - mean; test mode feeds the tensor AFTER the subtraction,
+                                                            so fed pixels bypass the mean -- reproduced, `test_subtract_mean` opts out)
+  * network ................................... :81-95, :389-417, :484-514: every conv = conv2d(same, bias) + batch norm
+                                                (+ leaky_relu 0.1), INCLUDING the three prediction convs; lateral convs without activation;
+                                                heads built with 1024 / 256 / 128 filters on block5 / block4 / block3
+  * loss, optimizer ........................... :96-318    (odtk_yolov3_loss; .5 * mean + wd * l2; Momentum 0.9; BN update ops)
+  * inference ................................. :320-368    (heads.yolov3_detect)
+  * train_one_epoch / test_one_image / save_weight / load_weight ... :437-482
+Every convolution, batch norm, residual sum, up-sampling and the box side run in libodtk (no torch compute, no CPU
+fallback); this file owns the buffers, the launch order and the gradient bookkeeping:
+  * activations are [N*H*W][C] rows (NHWC) in the compute dtype (bf16 default, 'f32' for parity tests), pre-BN conv
+    outputs are kept for the backward pass;
+  * `conv = conv + conv2` (:489-491): the sum node and its two inputs SHARE one gradient buffer -- d(sum) is read by the
+    batch-norm backward of conv2, and the 1x1 conv's dgrad later accumulates into the same rows, which then are d(input);
+  * concat(bottom, upsampled lateral) (:412) is one buffer of C1 + C2 channels; its halves are addressed by pitch.
+Layers are c0 .. c74 in creation (= forward) order; parameters live in one flat f32 buffer in that order (what the
+data-parallel gradient buckets of dist.py rely on).
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import heads, ops
+from ._lib import BF16, F32
+
+MEAN_RGB = (123.68, 116.779, 103.979)                                       # YOLOv3.py:65
+DARKNET_BLOCKS = ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4))         # :391-395
+HEAD_FILTERS = (1024, 256, 128)                                             # :83-86
+STRIDE = (8., 16., 32.)                                                     # :38
+LEAKY = 2                                                                   # odtk_bn_fwd activation code
+
+
+class _Act:
+    """rows x pitch activation; `gid` names the gradient buffer it shares with its residual partners"""
+
+    def __init__(self, name, N, H, W, C, ld, dtype, dev):
+        self.name, self.N, self.H, self.W, self.C, self.ld = name, N, H, W, C, ld
+        self.M = N * H * W
+        self.t = torch.zeros(self.M, ld, dtype=dtype, device=dev)
+        self.gid = name
+
+
+class YOLOv3:
+    def __init__(self, config, data_provider):
+        assert len(config['data_shape']) == 3
+        assert config['mode'] in ['train', 'test']
+        assert config['data_format'] in ['channels_first', 'channels_last']
+        self.config = config
+        self.data_provider = data_provider
+        self.data_shape = config['data_shape']
+        self.num_classes = config['num_classes']
+        self.weight_decay = config['weight_decay']
+        self.data_format = config['data_format']
+        self.mode = config['mode']
+        self.batch_size = config['batch_size'] if config['mode'] == 'train' else 1
+        self.scales = (config['coord_scale'], config['noobj_scale'], config['obj_scale'], config['class_scale'])
+        self.num_priors = config['num_priors']
+        self.nms_score_threshold = config['nms_score_threshold']
+        self.nms_max_boxes = config['nms_max_boxes']
+        self.nms_iou_threshold = config['nms_iou_threshold']
+        priors = config['priors']
+        # head l (1 = coarsest) is paired with priors[l-1] / stride[l-1], the reference's own pairing (:111-113 with :37-42)
+        self.priors_flat = [float(v) / STRIDE[i] for i in range(3) for hw in priors[i] for v in hw]
+        self.final_units = (self.num_classes + 5) * self.num_priors
+        self.verbose = bool(config.get('verbose', True))
+        self.dev = torch.device(config.get('device', 'cuda:0'))
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16')]
+        self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
+        self.chunk = ops.chunk(self.DT)
+        h, w, c = self.data_shape
+        assert c == 3 and h % 32 == 0 and w % 32 == 0, "YOLOv3 needs an input that is a multiple of 32 (five stride-2 stages)"
+        if self.mode == 'train':
+            self.num_train = data_provider['num_train']
+            self.train_generator = data_provider['train_generator']
+            if isinstance(self.train_generator, tuple) and len(self.train_generator) == 2:
+                self.train_initializer, self.train_iterator = self.train_generator
+            else:
+                self.train_initializer, self.train_iterator = None, self.train_generator
+            if data_provider.get('val_generator') is not None:
+                self.num_val = data_provider['num_val']
+                self.val_generator = data_provider['val_generator']
+        self.global_step = 0
+        self.dist = None
+        self.loss_divisor_batch = self.batch_size
+        torch.cuda.set_device(self.dev)
+        self.specs = layer_specs(self.num_classes, self.num_priors)
+        self._init_parameters(int(config.get('seed', 0)))
+        self._build()
+
+    # ------------------------------------------------------------------ parameters
+    def _init_parameters(self, seed):
+        self.pinfo, self.sinfo = OrderedDict(), OrderedDict()
+        off = soff = 0
+        for name, cin, cout, k, _, _ in self.specs:
+            for suffix, shape in (('.w', (cout, k, k, ops.pad_to(cin, self.chunk))), ('.b', (cout,)), ('.gamma', (cout,)), ('.beta', (cout,))):
+                self.pinfo[name + suffix] = (off, shape)
+                off += ops.pad_to(int(np.prod(shape)), 64)
+            for suffix in ('.mmean', '.mvar'):
+                self.sinfo[name + suffix] = (soff, (cout,))
+                soff += ops.pad_to(cout, 64)
+        self.nparam = off
+        dev = self.dev
+        self.P = torch.zeros(off, device=dev)
+        self.Mom = torch.zeros(off, device=dev)
+        self.G = torch.zeros(off, device=dev)
+        self.Pc = torch.zeros(off, dtype=self.tdt, device=dev) if self.DT == BF16 else self.P
+        self.S = torch.zeros(soff, device=dev)
+        self.l2_partial = torch.zeros(ops.sgd_blocks(off), device=dev)
+        self.l2_sum = torch.zeros(1, device=dev)
+        # synthetic initialisation: variance-scaling kernels (:501), zero bias, BN gamma 1 / beta 0 / moving (0, 1)
+        g = torch.Generator().manual_seed(seed)
+        for name, cin, cout, k, _, _ in self.specs:
+            self.set_param(name + '.w', torch.randn(cout, k, k, cin, generator=g) * math.sqrt(2.0 / (cin * k * k)))
+            self.param(name + '.gamma').fill_(1.0)
+            self.stat(name + '.mvar').fill_(1.0)
+
+    def param(self, name, buf=None):
+        off, shape = self.pinfo[name]
+        buf = self.P if buf is None else buf
+        return buf[off: off + int(np.prod(shape))].view(shape)
+
+    def stat(self, name):
+        off, shape = self.sinfo[name]
+        return self.S[off: off + int(np.prod(shape))].view(shape)
+
+    def _flat(self, name, buf):
+        off, shape = self.pinfo[name]
+        return buf[off: off + int(np.prod(shape))]
+
+    def set_param(self, name, value):
+        """value in the logical shape (conv kernels [K,R,S,Cin] un-padded)"""
+        dst = self.param(name)
+        value = torch.as_tensor(value, dtype=torch.float32)
+        if name.endswith('.w'):
+            dst.zero_()
+            dst[..., : value.shape[-1]] = value.to(self.dev)
+        else:
+            dst.copy_(value.to(self.dev).view(dst.shape))
+
+    def get_param(self, name, buf=None):
+        v = self.param(name, buf).detach().cpu().clone()
+        if name.endswith('.w'):
+            v = v[..., : self._cin[name[:-2]]].contiguous()
+        return v
+
+    def load_oracle_params(self, p):
+        """dict name -> tensor in the oracle's naming ([K,R,S,Cin] kernels)"""
+        for k, v in p.items():
+            if k in self.pinfo:
+                self.set_param(k, v)
+            elif k in self.sinfo:
+                self.stat(k).copy_(torch.as_tensor(v, dtype=torch.float32).to(self.dev))
+        self._refresh_operand_copies()
+
+    def export_params(self):
+        out = OrderedDict((k, self.get_param(k)) for k in self.pinfo)
+        for k in self.sinfo:
+            out[k] = self.stat(k).detach().cpu().clone()
+        return out
+
+    def _refresh_operand_copies(self):
+        if self.DT == BF16:
+            ops.cast_from_f32(self.P, self.Pc)
+        if getattr(self, '_fp_batch', None) is not None:
+            self._fp_batch.run()
+
+    # ------------------------------------------------------------------ the graph: buffers + launch plan
+    def _build(self):
+        N, dev, dt = self.batch_size, self.dev, self.tdt
+        H, W, _ = self.data_shape
+        self._cin = {s[0]: s[1] for s in self.specs}
+        self.images = torch.zeros(N, H, W, 3, device=dev)
+        c0 = ops.pad_to(3, self.chunk)
+        x = _Act('input', N, H, W, 3, c0, dt, dev)
+        self.input = x
+        self.plan, self.desc, self.z, self.bnsave = [], {}, {}, {}
+        self.acts = {'input': x}
+        it = iter(self.specs)
+        max_ws = max_z = 0
+        groups = {}                                            # union-find over gradient groups
+
+        def find(g):
+            while groups.setdefault(g, g) != g:
+                g = groups[g]
+            return g
+
+        def conv(src, out_f32=False):
+            nonlocal max_ws, max_z
+            name, cin, cout, k, stride, act = next(it)
+            assert cin == src.C, (name, cin, src.C)
+            ldz = ops.pad_to(cout, self.chunk)
+            d = ops.conv_desc(N, src.H, src.W, ops.pad_to(cin, self.chunk), src.ld, cout, ldz, k, stride, 1, self.DT, self.DT)
+            self.desc[name] = d
+            z = _Act(name + '.z', N, d.Ho, d.Wo, cout, ldz, dt, dev)
+            y = _Act(name, N, d.Ho, d.Wo, cout, cout if out_f32 else ldz, torch.float32 if out_f32 else dt, dev)
+            self.z[name], self.acts[name] = z, y
+            self.bnsave[name] = (torch.zeros(cout, device=dev), torch.zeros(cout, device=dev))
+            max_ws = max(max_ws, ops.bn_workspace_bytes(z.M, cout))
+            max_z = max(max_z, z.M * ldz)
+            self.plan.append(('conv', name, src, z, y, LEAKY if act else 0))
+            return y
+
+        def add(a, b):
+            y = _Act(f'sum{len(self.plan)}', N, a.H, a.W, a.C, a.ld, dt, dev)
+            self.acts[y.name] = y
+            groups[find(b.gid)] = find(y.gid)                 # b, a and y share one gradient buffer
+            groups[find(a.gid)] = find(y.gid)
+            self.plan.append(('add', a, b, y))
+            return y
+
+        def upcat(bottom, lat):
+            y = _Act(f'cat{len(self.plan)}', N, bottom.H, bottom.W, bottom.C + lat.C, bottom.C + lat.C, dt, dev)
+            self.acts[y.name] = y
+            self.plan.append(('upcat', bottom, lat, y))
+            return y
+
+        x = conv(x)
+        outs = []
+        for f, blocks in DARKNET_BLOCKS:
+            x = conv(x)
+            for _ in range(blocks):
+                x = add(x, conv(conv(x)))
+            outs.append(x)
+        self.pred_acts, top = [], None
+        for lvl, bottom in enumerate((outs[4], outs[3], outs[2])):
+            x = bottom
+            if top is not None:
+                x = upcat(bottom, conv(top))
+            x = conv(conv(conv(conv(x))))
+            top = conv(x)
+            self.pred_acts.append(conv(conv(top), out_f32=True))
+        assert next(it, None) is None
+        self.ws = torch.zeros(max_ws, dtype=torch.uint8, device=dev)
+        E = self.num_classes + 5
+        self.preds = [a.t.view(N, a.H, a.W, self.num_priors, E) for a in self.pred_acts]
+        # dgrad-layout filters (every conv but the first: the input needs no gradient)
+        self.wt, entries = {}, []
+        for name, cin, cout, k, _, _ in self.specs[1:]:
+            d = self.desc[name]
+            kp = self.z[name].ld
+            self.wt[name] = torch.zeros(d.C * k * k * kp, dtype=dt, device=dev)
+            entries.append((self._flat(name + '.w', self.P), self.wt[name], cout, k, k, d.C, kp))
+        self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, dev)
+        self.find = find
+        if self.mode == 'train':
+            # gradient buffers, one per group; the backward plan records who writes first and who accumulates
+            self.zg = torch.zeros(max_z, dtype=dt, device=dev)            # d(pre-BN conv output): lives for one layer
+            self.dpreds = [torch.zeros_like(p) for p in self.preds]
+            self.g = {find(a.gid): dp.view(a.M, a.ld) for a, dp in zip(self.pred_acts, self.dpreds)}
+            written = set(self.g)
+            self.bplan = []
+            for op in reversed(self.plan):
+                if op[0] == 'conv':
+                    _, name, src, z, y, act = op
+                    assert find(y.gid) in written, name
+                    acc = find(src.gid) in written
+                    self.bplan.append(('conv', name, src, z, y, act, acc))
+                    written.add(find(src.gid))
+                elif op[0] == 'upcat':
+                    _, bottom, lat, y = op
+                    assert find(y.gid) in written
+                    self.bplan.append(('upcat', bottom, lat, y, find(bottom.gid) in written))
+                    written.add(find(bottom.gid)); written.add(find(lat.gid))
+                else:
+                    assert find(op[3].gid) in written
+            for a in self.acts.values():
+                gid = find(a.gid)
+                if gid not in self.g and gid in written and a is not self.input:
+                    self.g[gid] = torch.zeros(a.M, a.ld, dtype=dt, device=dev)
+            self.loss_parts = torch.zeros(N, 5, device=dev)
+            self.loss_ws = ops.yolov3_workspace(self.preds, N, dev)
+            self.gt = None
+        self._refresh_operand_copies()
+
+    def grad_of(self, act):
+        return self.g[self.find(act.gid)]
+
+    # ------------------------------------------------------------------ forward / backward
+    def _forward(self, training, subtract_mean=True):
+        ops.preprocess(self.images, MEAN_RGB if subtract_mean else (0., 0., 0.), self.input.ld, self.DT, self.input.t)
+        for op in self.plan:
+            if op[0] == 'conv':
+                _, name, src, z, y, act = op
+                ops.conv2d_fwd(self.desc[name], src.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), z.t, False)
+                sm, si = self.bnsave[name]
+                ops.bn_fwd(z.t, z.M, z.C, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'), self.stat(name + '.mmean'),
+                           self.stat(name + '.mvar'), sm, si, training, act, y.t, y.ld, z.M, 0, self.ws)
+            elif op[0] == 'add':
+                _, a, b, y = op
+                ops.add2d(a.t, a.ld, b.t, b.ld, y.t, y.ld, y.M, y.C)
+            else:
+                _, bottom, lat, y = op
+                ops.add2d(bottom.t, bottom.ld, None, 0, y.t, y.ld, y.M, bottom.C)
+                ops.upsample2x_fwd(lat.t, lat.ld, y.t[:, bottom.C:], y.ld, lat.N, lat.H, lat.W, lat.C)
+
+    def _loss(self, grad_scale):
+        ops.yolov3_loss(self.preds, self.priors_flat, (STRIDE[2], STRIDE[1], STRIDE[0]), self.gt, self.scales, grad_scale, self.loss_parts,
+                        self.dpreds, self.loss_ws)
+
+    def _backward_iter(self):
+        """yields a layer name once every gradient of that layer and of all later layers has been launched"""
+        for op in self.bplan:
+            if op[0] == 'conv':
+                _, name, src, z, y, act, acc = op
+                dy = self.grad_of(y)
+                zg = self.zg[: z.M * z.ld].view(z.M, z.ld)
+                sm, si = self.bnsave[name]
+                ops.bn_bwd(z.t, y.t, dy, z.M, z.C, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, act, zg,
+                           self._flat(name + '.gamma', self.G), self._flat(name + '.beta', self.G), self.ws)
+                # the bias feeds batch norm: its gradient is exactly zero (only weight decay acts on it)
+                ops.conv2d_wgrad(self.desc[name], src.t, zg, z.ld, self._flat(name + '.w', self.G), None)
+                if src is not self.input:
+                    ops.conv2d_dgrad(self.desc[name], zg, z.ld, self.wt[name], None, self.grad_of(src), acc)
+                yield name
+            else:
+                _, bottom, lat, y, acc = op
+                dcat = self.grad_of(y)
+                db = self.grad_of(bottom)
+                if acc:
+                    ops.add2d(db, bottom.ld, dcat, y.ld, db, bottom.ld, y.M, bottom.C)
+                else:
+                    ops.add2d(dcat, y.ld, None, 0, db, bottom.ld, y.M, bottom.C)
+                ops.upsample2x_bwd(dcat[:, bottom.C:], y.ld, self.grad_of(lat), lat.ld, lat.N, lat.H, lat.W, lat.C, False)
+
+    # ------------------------------------------------------------------ public: training
+    def set_batch(self, images, ground_truth):
+        images = torch.as_tensor(images, dtype=torch.float32)
+        if self.data_format == 'channels_first' and images.shape[1] == 3:
+            images = images.permute(0, 2, 3, 1)
+        assert tuple(images.shape) == tuple(self.images.shape), images.shape
+        self.images.copy_(images, non_blocking=True)
+        gt = torch.as_tensor(ground_truth, dtype=torch.float32)
+        if self.gt is None or self.gt.shape != gt.shape:
+            self.gt = torch.zeros(gt.shape, device=self.dev)
+        self.gt.copy_(gt, non_blocking=True)
+
+    def train_step(self, lr):
+        """one optimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor"""
+        if self.dist is not None:
+            self.dist.begin_step()
+        self.G.zero_()
+        self._forward(True)
+        self._loss(0.5 / self.loss_divisor_batch)              # d(.5 * mean_i loss_i)
+        for name in self._backward_iter():
+            if self.dist is not None:
+                self.dist.layer_ready(name)
+        if self.dist is not None:
+            self.dist.finish_step()
+        ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial, self.Pc if self.DT == BF16 else None)
+        ops.sum_f32(self.l2_partial, self.l2_sum)
+        self._fp_batch.run()
+        self.global_step += 1
+        return 0.5 * self.loss_parts[:, 4].mean() + self.weight_decay * self.l2_sum        # YOLOv3.py:311-315 (pre-update weights)
+
+    def train_one_epoch(self, lr):
+        if callable(self.train_initializer):
+            self.train_initializer()
+        mean_loss = []
+        num_iters = self.num_train // self.batch_size
+        it = iter(self.train_iterator)
+        for i in range(num_iters):
+            try:
+                images, gt = next(it)
+            except StopIteration:
+                it = iter(self.train_iterator)
+                images, gt = next(it)
+            self.set_batch(images, gt)
+            loss = float(self.train_step(lr).item())
+            if self.verbose:
+                sys.stdout.write('\r>> ' + 'iters ' + str(i) + str('/') + str(num_iters) + ' loss ' + str(loss))
+                sys.stdout.flush()
+            mean_loss.append(loss)
+        if self.verbose:
+            sys.stdout.write('\n')
+        return np.mean(mean_loss)
+
+    # ------------------------------------------------------------------ public: inference
+    def test_one_image(self, images):
+        images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+        if self.data_format == 'channels_first' and images.shape[1] == 3:
+            images = images.permute(0, 2, 3, 1)
+        assert self.batch_size == 1 and tuple(images.shape) == tuple(self.images.shape), images.shape
+        self.images.copy_(images)
+        self._forward(False, subtract_mean=bool(self.config.get('test_subtract_mean', False)))
+        scores, bbox, cid = heads.yolov3_detect([p[0] for p in self.preds], self.priors_flat, self.nms_score_threshold, self.nms_max_boxes,
+                                                self.nms_iou_threshold, decode_scale=(STRIDE[2], STRIDE[2], STRIDE[1]))
+        return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
+
+    # ------------------------------------------------------------------ checkpoints / data parallel
+    def save_weight(self, mode, path):
+        assert (mode in ['latest', 'best'])
+        dirname = os.path.dirname(path)
+        if dirname and not os.path.exists(dirname):
+            os.makedirs(dirname)
+            print(dirname, 'does not exist, create it done')
+        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': dict(self.pinfo)}
+        torch.save(blob, path + '-' + str(self.global_step))
+        print('save', mode, 'model in', path, 'successfully')
+
+    def load_weight(self, path):
+        blob = torch.load(path, map_location='cpu', weights_only=False)
+        self.load_oracle_params(blob['params'])
+        if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
+            self.Mom.copy_(blob['momentum'].to(self.dev))
+        self.global_step = int(blob.get('global_step', 0))
+        print('load weight', path, 'successfully')
+
+    def load_pretraining_weight(self, path):
+        """YOLOv3.py:480-482 restores the trainable 'backone' variables: here the c0 .. c51 entries of a saved file"""
+        blob = torch.load(path, map_location='cpu', weights_only=False)['params']
+        self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < 52 and k in self.pinfo})
+        print('load pretraining weight', path, 'successfully')
+
+    def attach_data_parallel(self, group=None, bucket_mb=25):
+        """images sharded over ranks (one process per GPU); gradients summed with the bucketed RCCL all-reduce of dist.py,
+        overlapped with the backward pass; the loss divisor becomes the GLOBAL batch"""
+        from .dist import GradAllReducer
+        self.dist = GradAllReducer(self, group, bucket_mb)
+        self.loss_divisor_batch = self.batch_size * self.dist.world
+        return self.dist
+
+
+def layer_specs(num_classes=20, num_priors=3):
+    """[(name, cin, cout, k, stride, leaky)] in creation order: DarkNet-53 (52 convs, YOLOv3.py:389-396, :484-491), then per level
+    [lateral 1x1 (no activation)], 1x1, 3x3, 1x1, 3x3, 1x1, 3x3, prediction 1x1 (:398-417)"""
+    specs = []
+
+    def add(cin, cout, k, s, act=True):
+        specs.append((f'c{len(specs)}', cin, cout, k, s, act))
+        return cout
+    c = add(3, 32, 3, 1)
+    outs = []
+    for f, blocks in DARKNET_BLOCKS:
+        c = add(c, f, 3, 2)
+        for _ in range(blocks):
+            add(c, f // 2, 1, 1)
+            add(f // 2, f, 3, 1)
+        outs.append(c)
+    top = None
+    for lvl, f in enumerate(HEAD_FILTERS):
+        cin = outs[4 - lvl]
+        if top is not None:
+            cin += add(top, f, 1, 1, False)
+        add(cin, f // 2, 1, 1); add(f // 2, f, 3, 1); add(f, f // 2, 1, 1); add(f // 2, f, 3, 1)
+        top = add(f, f // 2, 1, 1)
+        add(f // 2, f, 3, 1)
+        add(f, (num_classes + 5) * num_priors, 1, 1)
+    return specs

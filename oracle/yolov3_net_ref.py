@@ -82,8 +82,8 @@ def trainable_names(p):
 
 
 class _Net:
-    def __init__(self, p, training, stats_out, taps):
-        self.p, self.training, self.stats, self.taps, self.i = p, training, stats_out, taps, 0
+    def __init__(self, p, training, stats_out, taps, leaky_masks=None):
+        self.p, self.training, self.stats, self.taps, self.i, self.masks = p, training, stats_out, taps, 0, leaky_masks
         self.specs = layer_specs_cache(p)
 
     def conv(self, x):
@@ -102,7 +102,10 @@ class _Net:
         y = (z - mean[None, :, None, None]) * (torch.rsqrt(var + BN_EPS) * p[name + '.gamma'])[None, :, None, None] \
             + p[name + '.beta'][None, :, None, None]
         if act == 'leaky':
-            y = F.leaky_relu(y, 0.1)
+            if self.masks is not None:        # the linear region is dictated (see forward): gradients comparable to 1e-4
+                y = torch.where(self.masks[name], y, 0.1 * y)
+            else:
+                y = F.leaky_relu(y, 0.1)
         if self.taps is not None:
             self.taps[name] = y
         return y
@@ -113,13 +116,16 @@ def layer_specs_cache(p):
     return layer_specs(final // 3 - 5, 3)
 
 
-def forward(p, images_nhwc, training, stats_out=None, taps=None, subtract_mean=True):
-    """-> [pred1, pred2, pred3] each [N, H_l, W_l, num_priors, C+5] (head 1 = coarsest), YOLOv3.py:82-95"""
+def forward(p, images_nhwc, training, stats_out=None, taps=None, subtract_mean=True, leaky_masks=None):
+    """-> [pred1, pred2, pred3] each [N, H_l, W_l, num_priors, C+5] (head 1 = coarsest), YOLOv3.py:82-95.
+    leaky_masks {layer: bool NCHW}: which elements take the slope-1 branch.  A pre-activation within float round-off of 0
+    may fall on different sides in two implementations; one such element moves every upstream gradient by ~1 / sqrt(elements)
+    (about 1 %), so gradient parity is tested on the SAME linear region as the implementation under test."""
     x = images_nhwc.float()
     if subtract_mean:
         x = x - torch.tensor(MEAN_RGB).view(1, 1, 1, 3)
     x = x.permute(0, 3, 1, 2)
-    net = _Net(p, training, stats_out, taps)
+    net = _Net(p, training, stats_out, taps, leaky_masks)
     x = net.conv(x)
     outs = []
     for f, blocks in DARKNET_BLOCKS:
@@ -142,9 +148,9 @@ def forward(p, images_nhwc, training, stats_out=None, taps=None, subtract_mean=T
     return preds
 
 
-def loss_fn(p, images_nhwc, ground_truth, weight_decay=5e-4, stats_out=None, scales=(1., 1., 5., 1.)):
+def loss_fn(p, images_nhwc, ground_truth, weight_decay=5e-4, stats_out=None, scales=(1., 1., 5., 1.), leaky_masks=None):
     """(total, data): .5 * mean_i loss_i + wd * sum l2_loss(trainables)   (YOLOv3.py:311-315)"""
-    preds = forward(p, images_nhwc, True, stats_out)
+    preds = forward(p, images_nhwc, True, stats_out, leaky_masks=leaky_masks)
     C = preds[0].shape[-1] - 5
     data = YR.batch_loss(preds, ground_truth, num_classes=C, coord_scale=scales[0], noobj_scale=scales[1], obj_scale=scales[2],
                          class_scale=scales[3])
@@ -152,13 +158,13 @@ def loss_fn(p, images_nhwc, ground_truth, weight_decay=5e-4, stats_out=None, sca
     return .5 * data + weight_decay * l2, data
 
 
-def train_step(p, mom, images_nhwc, ground_truth, lr, weight_decay=5e-4):
+def train_step(p, mom, images_nhwc, ground_truth, lr, weight_decay=5e-4, leaky_masks=None):
     names = trainable_names(p)
     for k in names:
         p[k].requires_grad_(True)
         p[k].grad = None
     stats = {}
-    total, data = loss_fn(p, images_nhwc, ground_truth, weight_decay, stats)
+    total, data = loss_fn(p, images_nhwc, ground_truth, weight_decay, stats, leaky_masks=leaky_masks)
     total.backward()
     grads = {}
     with torch.no_grad():
@@ -181,4 +187,4 @@ def test_one_image(p, images_nhwc, score_thr=0.5, max_boxes=10, iou_thr=0.5, sub
         preds = forward(p, images_nhwc, False, subtract_mean=subtract_mean)
     C = preds[0].shape[-1] - 5
     conf, box = YR.decode_candidates([q[0] for q in preds], num_classes=C)
-    return DC.per_class_nms(conf, box, score_thr, max_boxes, iou_thr, C)
+    return DC.per_class_nms(conf, box, C, score_thr, max_boxes, iou_thr)

@@ -52,3 +52,60 @@ def test_two_ranks_one_gpu(tmp_path, dev):
     d = float((res[True]['P'] - res[False]['P']).abs().max())
     assert d <= 2e-3, d
     assert abs(res[True]['losses'][0] - res[False]['losses'][0]) <= 1e-3 * abs(res[False]['losses'][0])
+
+
+def _yolo_cfg(batch, size):
+    from oracle import yolov3_ref as YR
+    return {'mode': 'train', 'data_shape': [size, size, 3], 'num_classes': 20, 'weight_decay': 5e-4, 'keep_prob': 0.5, 'data_format': 'channels_last',
+            'batch_size': batch, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'num_priors': 3, 'nms_score_threshold': 0.5,
+            'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'priors': YR.PRIORS_PX, 'verbose': False, 'compute_dtype': 'f32', 'seed': 3}
+
+
+def _yolo_batch(rank, batch, size):
+    from oracle import yolov3_ref as YR
+    g = torch.Generator().manual_seed(900 + rank)
+    return (torch.rand(batch, size, size, 3, generator=g) * 255).round(), YR.synthetic_gt(batch, size, 950 + rank, max_obj=3)
+
+
+def _yolo_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import odtk
+    B, size = 2, 64
+    m = odtk.YOLOv3(_yolo_cfg(B, size), {'num_train': B, 'train_generator': [], 'val_generator': None, 'num_val': 0})
+    red = m.attach_data_parallel(bucket_mb=16)
+    m.set_batch(*_yolo_batch(rank, B, size))
+    loss = float(m.train_step(0.002))
+    torch.cuda.synchronize()
+    torch.save({'P': m.P.cpu(), 'G': m.G.cpu(), 'loss': loss, 'buckets': len(red.red.buckets)}, os.path.join(out_dir, f'y{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_yolov3_two_ranks_one_gpu(tmp_path, dev):
+    """YOLOv3 data parallel (BASELINE config 4 shards 64 images over 8 GPUs): the bucketed all-reduce hooked on the layer order
+    c74 .. c0 leaves both replicas bit-identical, and what it exchanged is the SUM of the replicas' local gradients (batch norm
+    stays local to a replica, as in the reference; the loss is a mean over the GLOBAL batch)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_yolo_worker, args=(2, 29650, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(os.path.join(tmp_path, 'y0.pt')), torch.load(os.path.join(tmp_path, 'y1.pt'))
+    assert torch.equal(a['P'], b['P']) and torch.equal(a['G'], b['G'])
+    assert a['buckets'] > 1 and a['loss'] == a['loss'] and b['loss'] == b['loss']
+    import odtk
+    B, size = 2, 64
+    total = p0 = None
+    for rank in range(2):
+        m = odtk.YOLOv3(_yolo_cfg(B, size), {'num_train': B, 'train_generator': [], 'val_generator': None, 'num_val': 0})
+        p0 = m.P.clone()
+        m.set_batch(*_yolo_batch(rank, B, size))
+        m.G.zero_(); m._forward(True); m._loss(0.5 / (2 * B))
+        for _ in m._backward_iter():
+            pass
+        total = m.G.clone() if total is None else total + m.G
+    torch.cuda.synchronize()
+    g = a['G'].to(total.device)
+    assert float((g - total).norm()) < 1e-4 * float(total.norm())          # f32 engine; filter gradients use float atomics
+    after = p0 - 0.002 * (total + 5e-4 * p0)                                # first momentum step: accum = grad + wd * var
+    assert float((a['P'].to(total.device) - after).norm()) < 1e-4 * float((after - p0).norm()) + 1e-7 * float(p0.norm())

@@ -397,17 +397,74 @@ class YOLOv3:
         return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
 
     # ------------------------------------------------------------------ checkpoints / data parallel
+    def _logical(self, name, buf):
+        """parameter `name` out of a flat buffer (P or Mom) in TensorFlow's layout: kernels HWIO, un-padded"""
+        v = self.get_param(name, buf)
+        return np.ascontiguousarray((v.permute(1, 2, 3, 0) if name.endswith('.w') else v).numpy())
+
+    def export_tf_variables(self):
+        """what the reference's `tf.train.Saver()` (YOLOv3.py:377-381) writes: every variable of its graph under its name
+        (reference_variable_map), global_step, and the momentum slots `<variable>/Momentum` (the optimizer is created outside any
+        variable scope, :312)"""
+        out = OrderedDict()
+        for tfname, ours in reference_variable_map().items():
+            if ours in self.pinfo:
+                out[tfname] = self._logical(ours, self.P)
+                out[tfname + '/Momentum'] = self._logical(ours, self.Mom)
+            else:
+                out[tfname] = self.stat(ours).detach().cpu().numpy().copy()
+        out['global_step'] = np.asarray(self.global_step, dtype=np.int32)
+        return out
+
+    def load_tf_checkpoint(self, path, backbone_trainables_only=False):
+        """`saver.restore(sess, path)` from tf.train.Saver files (ours or the reference's); backbone_trainables_only: what
+        `pretraining_weight_saver` restores (YOLOv3.py:377-378, :480-482: the trainable variables under 'backone')"""
+        from .tf_checkpoint import NewCheckpointReader
+        reader = NewCheckpointReader(str(path))
+        names = reader.get_variable_to_shape_map()
+        for tfname, ours in reference_variable_map().items():
+            if backbone_trainables_only and (not tfname.startswith('backone') or ours in self.sinfo):
+                continue
+            v = torch.from_numpy(reader.get_tensor(tfname))                     # KeyError = Saver's NotFoundError
+            if ours in self.sinfo:
+                self.stat(ours).copy_(v.to(self.dev))
+                continue
+            self.set_param(ours, v.permute(3, 0, 1, 2).contiguous() if ours.endswith('.w') else v)
+            if not backbone_trainables_only and tfname + '/Momentum' in names:
+                mv = torch.from_numpy(reader.get_tensor(tfname + '/Momentum'))
+                dst = self.param(ours, self.Mom)
+                if ours.endswith('.w'):
+                    dst.zero_()
+                    dst[..., : mv.shape[2]] = mv.permute(3, 0, 1, 2).to(self.dev)
+                else:
+                    dst.copy_(mv.to(self.dev).view(dst.shape))
+        if not backbone_trainables_only and reader.has_tensor('global_step'):
+            self.global_step = int(reader.get_tensor('global_step'))
+        self._refresh_operand_copies()
+
     def save_weight(self, mode, path):
+        """YOLOv3.py:466-475.  config['checkpoint_format'] = 'tf' writes tf.train.Saver files (tf_checkpoint.py)."""
         assert (mode in ['latest', 'best'])
         dirname = os.path.dirname(path)
         if dirname and not os.path.exists(dirname):
             os.makedirs(dirname)
             print(dirname, 'does not exist, create it done')
+        if self.config.get('checkpoint_format', 'torch') == 'tf':
+            from . import tf_checkpoint
+            prefix = path + '-' + str(self.global_step)
+            tf_checkpoint.write_bundle(prefix, self.export_tf_variables())
+            tf_checkpoint.update_checkpoint_state(prefix)
+            print('save', mode, 'model in', path, 'successfully')
+            return
         blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': dict(self.pinfo)}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
     def load_weight(self, path):
+        if os.path.exists(str(path) + '.index'):                 # a tf.train.Saver checkpoint prefix
+            self.load_tf_checkpoint(path)
+            print('load weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=False)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
@@ -417,6 +474,10 @@ class YOLOv3:
 
     def load_pretraining_weight(self, path):
         """YOLOv3.py:480-482 restores the trainable 'backone' variables: here the c0 .. c51 entries of a saved file"""
+        if os.path.exists(str(path) + '.index'):
+            self.load_tf_checkpoint(path, backbone_trainables_only=True)
+            print('load pretraining weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=False)['params']
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < 52 and k in self.pinfo})
         print('load pretraining weight', path, 'successfully')
@@ -456,3 +517,23 @@ def layer_specs(num_classes=20, num_priors=3):
         add(f // 2, f, 3, 1)
         add(f, (num_classes + 5) * num_priors, 1, 1)
     return specs
+
+
+def reference_variable_map():
+    """name of every variable of the reference's YOLOv3 graph -> our parameter / statistic name.  tf.layers default layer names
+    count over the whole graph (conv2d, conv2d_1 ... conv2d_74; batch_normalization ... _74) inside the variable scopes
+    'backone' (sic, YOLOv3.py:82) / 'backone/block<b>' (:485) / 'head/pyd<l>' (:399).  Pinned by tests/golden/yolov3_variables.json
+    (collected from the reference's own class)."""
+    scopes = ['backone']
+    for b, (_, blocks) in enumerate(DARKNET_BLOCKS):
+        scopes += [f'backone/block{b + 1}'] * (1 + 2 * blocks)
+    for lvl in range(3):
+        scopes += [f'head/pyd{lvl + 1}'] * (7 if lvl == 0 else 8)
+    m = OrderedDict()
+    for i, scope in enumerate(scopes):
+        sfx = '' if i == 0 else f'_{i}'
+        m[f'{scope}/conv2d{sfx}/kernel'], m[f'{scope}/conv2d{sfx}/bias'] = f'c{i}.w', f'c{i}.b'
+        bn = f'{scope}/batch_normalization{sfx}'
+        m[bn + '/gamma'], m[bn + '/beta'] = f'c{i}.gamma', f'c{i}.beta'
+        m[bn + '/moving_mean'], m[bn + '/moving_variance'] = f'c{i}.mmean', f'c{i}.mvar'
+    return m

@@ -142,6 +142,8 @@ def reduce_sum(x, axis=None):
 
 
 def reduce_mean(x, axis=None):
+    if isinstance(x, (list, tuple)):                          # tf.reduce_mean packs a list of scalars (YOLOv3.py:311)
+        x = torch.stack([_t(v) for v in x])
     return x.mean() if axis is None else x.mean(dim=axis)      # mean of empty -> nan, as TF
 
 
@@ -408,8 +410,8 @@ def get_variable(name, shape=None, initializer=None, trainable=True, dtype=None)
     return S.variables[full]
 
 
-def trainable_variables():
-    return [S.variables[n] for n in S.trainable]
+def trainable_variables(scope=None):
+    return [S.variables[n] for n in S.trainable if scope is None or n.startswith(scope)]
 
 
 class GraphKeys:
@@ -715,6 +717,9 @@ class _MomentumOptimizer:
 
 
 class _Saver:
+    def __init__(self, var_list=None):
+        self.var_list = var_list
+
     def save(self, sess, path, global_step=None):
         return path
 

@@ -200,3 +200,36 @@ def test_f32_inference_detections_equal_oracle(dev):
     assert np.array_equal(got[2], want[2].numpy())
     np.testing.assert_allclose(got[0], want[0].numpy(), atol=2e-3)
     np.testing.assert_allclose(got[1], want[1].numpy(), atol=0.5)
+
+
+def test_tf_saver_checkpoint_roundtrip(dev, tmp_path):
+    """checkpoint_format='tf': the files tf.train.Saver would leave (YOLOv3.py:466-478), every variable of the reference's graph under
+    its name and shape (tests/golden/yolov3_variables.json) + momentum slots + global_step, and back; `load_pretraining_weight`
+    restores the trainable 'backone' variables only (:377-378, :480-482)."""
+    import json
+    import os
+    from odtk import tf_checkpoint as T
+    batches = [_batch(2, 64, 70)]
+    m = _model('train', 'bf16', 2, 64, _provider(batches), checkpoint_format='tf', seed=1)
+    m.train_one_epoch(0.001)
+    path = str(tmp_path / 'ck' / 'yolo.ckpt')
+    m.save_weight('latest', path)
+    r = T.NewCheckpointReader(path + '-1')
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'yolov3_variables.json')))
+    shapes = r.get_variable_to_shape_map()
+    for name, info in want.items():
+        assert shapes[name] == info['shape'], name
+        assert (name + '/Momentum' in shapes) == info['trainable'], name
+    assert len(shapes) == len(want) + sum(v['trainable'] for v in want.values())
+    m2 = _model('train', 'bf16', 2, 64, _provider(batches), seed=2)
+    m2.load_weight(path + '-1')
+    a, b = m.export_params(), m2.export_params()
+    assert all(torch.equal(a[k], b[k]) for k in a) and torch.equal(m.Mom, m2.Mom) and m2.global_step == 1
+    m3 = _model('train', 'bf16', 2, 64, _provider(batches), seed=3)
+    before = m3.export_params()
+    m3.load_pretraining_weight(path + '-1')
+    c = m3.export_params()
+    for k in a:
+        layer = int(k[1:].split('.')[0])
+        restored = layer < 52 and not k.endswith(('.mmean', '.mvar'))
+        assert torch.equal(c[k], a[k] if restored else before[k]), k

@@ -294,3 +294,32 @@ def test_yolov3_network_vs_reference_graph():
         for l, q in enumerate(NR.forward(p, images, False, subtract_mean=False)):
             want = g[f'test_pred{l + 1}']
             assert float((q.reshape(want.shape) - torch.from_numpy(want)).abs().max()) < 2e-4 * float(np.abs(want).max() + 1), l
+
+
+def test_yolov3_two_training_steps_match_reference_class():
+    """oracle/yolov3_net_ref.train_step against two steps of the reference's own YOLOv3 class run through its session on the
+    shim (tests/golden/yolov3_train.npz): the loss incl. the L2 term, parameters of every kind after the momentum updates,
+    moving statistics.  Float chaos through 75 batch norms over 8-128 samples bounds the agreement of the second step."""
+    from oracle import yolov3_net_ref as NR
+    from oracle import yolov3_ref as YR
+    g = np.load(os.path.join(GOLD, 'yolov3_train.npz'))
+    p = NR.init_params(21)
+    mom = {k: torch.zeros_like(v) for k, v in p.items() if k in NR.trainable_names(p)}
+    losses = []
+    for s in (300, 301):
+        gen = torch.Generator().manual_seed(s)
+        imgs = (torch.rand(2, 64, 64, 3, generator=gen) * 255).round()
+        gt = YR.synthetic_gt(2, 64, s + 10, max_obj=3)
+        total, _, _ = NR.train_step(p, mom, imgs, gt, 0.01)
+        losses.append(total)
+    assert abs(losses[0] - g['losses'][0]) < 1e-4 * g['losses'][0], (losses, g['losses'])
+    assert abs(losses[1] - g['losses'][1]) < 2e-2 * g['losses'][1], (losses, g['losses'])
+    for key in g.files:
+        if key == 'losses':
+            continue
+        k = key.replace('__', '.')
+        got = p[k].detach().reshape(-1)
+        got = got[::max(1, got.numel() // 1024)].numpy()
+        want = g[key]
+        err = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-9)
+        assert err < (5e-2 if k.endswith(('.b', '.beta')) else 1e-2), (k, err)

@@ -155,3 +155,22 @@ def test_reference_variable_map_matches_reference_graph():
         assert want[name]['trainable'] == (not ours.endswith(('.mmean', '.mvar'))), name
         if ours.endswith('.w'):
             assert len(want[name]['shape']) == 4
+
+
+def test_yolov3_variable_map_matches_reference_graph():
+    """odtk.yolov3.reference_variable_map / layer_specs against the variables the reference's own YOLOv3 class creates
+    (tests/golden/yolov3_variables.json, tests/golden/make_golden_yolov3_train.py), shapes included"""
+    import json
+    from odtk.yolov3 import layer_specs, reference_variable_map
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'yolov3_variables.json')))
+    m = reference_variable_map()
+    assert set(m) | {'global_step'} == set(want) and len(m) == 450
+    specs = {s[0]: s for s in layer_specs(20, 3)}
+    for name, ours in m.items():
+        layer, kind = ours.split('.')
+        _, cin, cout, k, _, _ = specs[layer]
+        assert want[name]['shape'] == ([k, k, cin, cout] if kind == 'w' else [cout]), name
+        assert want[name]['trainable'] == (kind not in ('mmean', 'mvar')), name
+    from oracle import yolov3_net_ref as NR
+    assert [s[:5] for s in layer_specs(20, 3)] == [s[:5] for s in NR.layer_specs(20, 3)]
+    assert [bool(s[5]) for s in layer_specs(20, 3)] == [s[5] is not None for s in NR.layer_specs(20, 3)]

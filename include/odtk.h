@@ -152,6 +152,29 @@ int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, int C, int 
                 const float* gamma, const float* save_mean, const float* save_invstd, int relu,
                 void* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
 
+/* Batch norm over the GLOBAL batch of a data-parallel job (SURVEY.md 8e option B): odtk_bn_fwd / odtk_bn_bwd split where the
+ * replicas exchange per-channel numbers, so that W ranks with B images each compute exactly what one device computes on W*B.
+ *   odtk_bn_moments   : mean[C], var[C] (biased) of the local rows.
+ *   (host) all-gather -> moments [W][2][C] = every replica's (mean, var); equal row counts per replica.
+ *   odtk_bn_fwd_given : combines them (parallel-variance formula), stores save_mean / save_invstd, updates the moving statistics
+ *                       with the unbiased variance over W*M rows, applies scale / offset / activation like odtk_bn_fwd.
+ *   odtk_bn_bwd_sums  : sums[0:C] = sum dy' (this replica's dbeta), sums[C:2C] = sum dy' * xhat (its dgamma).
+ *   (host) all-reduce(sum) of a COPY of sums -> sums_global; count = W*M.
+ *   odtk_bn_bwd_given : dz with the global means sums_global / count.
+ * Arguments shared with odtk_bn_fwd / odtk_bn_bwd have the same meaning; workspace as odtk_bn_workspace_bytes. */
+int odtk_bn_moments(const void* z, int M, int C, int ldz, int dtype, float* mean, float* var, void* workspace, void* stream);
+int odtk_bn_fwd_given(const void* z, int M, int C, int ldz, int dtype, const float* gamma, const float* beta,
+                      const float* moments, int replicas, float* moving_mean, float* moving_var, float* save_mean,
+                      float* save_invstd, int relu, void* y, int y_dtype, int ldy, int rows_per_img, long long y_img_stride,
+                      void* workspace, void* stream);
+int odtk_bn_bwd_sums(const void* z, const void* y, const void* dy, int M, int C, int ldz, int dtype, int y_dtype, int ldy,
+                     int rows_per_img, long long y_img_stride, const float* save_mean, const float* save_invstd, int relu,
+                     float* sums, void* workspace, void* stream);
+int odtk_bn_bwd_given(const void* z, const void* y, const void* dy, int M, int C, int ldz, int dtype, int y_dtype, int ldy,
+                      int rows_per_img, long long y_img_stride, const float* gamma, const float* save_mean,
+                      const float* save_invstd, int relu, const float* sums_global, long long count, void* dz, void* workspace,
+                      void* stream);
+
 /* Glue of the residual / pyramid detectors (SURVEY.md 8f.1 backbones).  Rows are [M][ld] with their own pitch, so a
  * channel slice of a concat buffer is an ordinary operand; C and every pitch multiples of 16 bytes, pointers 16-byte aligned.
  * odtk_add2d: y = a + b (b NULL: pitched copy; y may alias a: accumulate) -- `conv = conv + conv2` (YOLOv3.py:489-491),

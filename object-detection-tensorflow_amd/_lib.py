@@ -56,6 +56,10 @@ SIGNATURES = {
     "odtk_maxpool_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "odtk_maxpool2x2_fwd_idx": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "odtk_maxpool2x2_bwd_idx": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "odtk_bn_moments": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "odtk_bn_fwd_given": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _ll, _vp, _vp]),
+    "odtk_bn_bwd_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
+    "odtk_bn_bwd_given": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _vp, _vp, _vp, _i, _vp, _ll, _vp, _vp, _vp]),
     "odtk_add2d": (_i, [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _i, _vp]),
     "odtk_upsample2x_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "odtk_upsample2x_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

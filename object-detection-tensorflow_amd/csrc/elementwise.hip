@@ -1031,6 +1031,166 @@ extern "C" int odtk_cast_from_f32(const float* in, void* out, long long n, int d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Batch norm over the GLOBAL batch of a data-parallel job (SURVEY.md 8e option B, "sync-BN"): the single-call entry points
+// above split at the two places where the replicas have to exchange per-channel numbers.
+//   forward : odtk_bn_moments (local mean / biased variance)  -> all-gather of [2C] per rank (host, RCCL)
+//             -> odtk_bn_fwd_given (combines the replicas' moments with the parallel-variance formula, then apply)
+//   backward: odtk_bn_bwd_sums (local sum dy', sum dy' * xhat = this replica's dbeta / dgamma) -> all-reduce of [2C]
+//             -> odtk_bn_bwd_given (dz with the global means)
+// With equal local batches the result equals one device running the concatenated batch (tests/test_gpu_dist.py).
+namespace odtk {
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_moments_kernel(const T* __restrict__ z, int M, int C, const float* __restrict__ ws, int nsplit,
+                                                         float* __restrict__ mean, float* __restrict__ var) {
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), sl = threadIdx.x / FIN_CH;
+    float s1, s2;
+    reduce_partials(ws, nsplit, C, c, sl, s1, s2);
+    if (c >= C || sl != 0) return;
+    const float d = s1 / (float)M;
+    mean[c] = elem<T>::load(z[c]) + d;
+    var[c] = fmaxf(s2 / (float)M - d * d, 0.f);
+}
+
+// moments [W][2][C] of W replicas with `rows` rows each -> statistics of the union, scale / offset, moving-statistics update
+__global__ void bn_combine_kernel(const float* __restrict__ moments, int W, int C, long long rows, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* __restrict__ mmean, float* __restrict__ mvar,
+                                  float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ fin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean = 0.f;
+    for (int w = 0; w < W; ++w) mean += moments[((size_t)w * 2 + 0) * C + c];
+    mean /= (float)W;
+    float var = 0.f;
+    for (int w = 0; w < W; ++w) {
+        const float dm = moments[((size_t)w * 2 + 0) * C + c] - mean;
+        var += moments[((size_t)w * 2 + 1) * C + c] + dm * dm;
+    }
+    var /= (float)W;
+    const float n = (float)rows * (float)W;
+    save_mean[c] = mean;
+    save_invstd[c] = rsqrtf(var + 1e-3f);
+    mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
+    mvar[c] = mvar[c] * 0.99f + var * (n / (n > 1.f ? n - 1.f : 1.f)) * (1.f - 0.99f);
+    const float sc = rsqrtf(var + 1e-3f) * gamma[c];
+    fin[c] = sc;
+    fin[C + c] = beta[c] - mean * sc;
+}
+
+__global__ void bn_scale_sums_kernel(const float* __restrict__ sums, int n, float inv_count, float* __restrict__ fin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fin[i] = sums[i] * inv_count;
+}
+
+}  // namespace
+}  // namespace odtk
+
+extern "C" int odtk_bn_moments(const void* z, int M, int C, int ldz, int dtype, float* mean, float* var, void* workspace, void* stream) {
+    ODTK_REQUIRE(z && mean && var && workspace, "bn_moments: null pointer");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_moments: ldz=%d must be a multiple of %d", ldz, kc);
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan pl = red_plan(M, C, kc);
+    float* ws = (float*)workspace;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st, (const T*)z, M, C, ldz,
+                                           pl.rows_per_split, ws);
+              hipLaunchKernelGGL(bn_moments_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M, C, ws, pl.nsplit, mean, var);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_bn_fwd_given(const void* z, int M, int C, int ldz, int dtype, const float* gamma, const float* beta,
+                                 const float* moments, int replicas, float* moving_mean, float* moving_var, float* save_mean,
+                                 float* save_invstd, int relu, void* y, int y_dtype, int ldy, int rows_per_img, long long y_img_stride,
+                                 void* workspace, void* stream) {
+    ODTK_REQUIRE(z && y && gamma && beta && moments && moving_mean && moving_var && save_mean && save_invstd && workspace, "bn_fwd_given: null pointer");
+    ODTK_REQUIRE(replicas >= 1, "bn_fwd_given: replicas=%d", replicas);
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_fwd_given: ldz=%d must be a multiple of %d", ldz, kc);
+    ODTK_REQUIRE(!(y_dtype == ODTK_BF16 && dtype == ODTK_F32), "bn_fwd_given: f32 in / bf16 out unsupported");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan pl = red_plan(M, C, kc);
+    float* ws = (float*)workspace;
+    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, moments, replicas, C, (long long)M, gamma, beta, moving_mean,
+                       moving_var, save_mean, save_invstd, fin);
+    const size_t ysz = dtype_size(y_dtype);
+    const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 && ((uintptr_t)y % 16) == 0;
+    const int rows_per_block = pl.rows_per_split;
+    dim3 grid(pl.colgroups, ceil_div(M, rows_per_block));
+#define BN_APPLY(T, TY)                                                                                        \
+    hipLaunchKernelGGL((bn_apply_kernel<T, TY>), grid, dim3(256), 0, st, (const T*)z, M, C, ldz, relu, (TY*)y, \
+                       ldy, rows_per_img, y_img_stride, vec_ok, fin, rows_per_block)
+    if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) BN_APPLY(bf16_t, bf16_t);
+    else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) BN_APPLY(bf16_t, float);
+    else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) BN_APPLY(float, float);
+    else ODTK_REQUIRE(false, "bn_fwd_given: bad dtype");
+#undef BN_APPLY
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_bn_bwd_sums(const void* z, const void* y, const void* dy, int M, int C, int ldz, int dtype, int y_dtype, int ldy,
+                                int rows_per_img, long long y_img_stride, const float* save_mean, const float* save_invstd, int relu,
+                                float* sums, void* workspace, void* stream) {
+    ODTK_REQUIRE(z && dy && save_mean && save_invstd && sums && workspace, "bn_bwd_sums: null pointer");
+    ODTK_REQUIRE(!relu || y, "bn_bwd_sums: relu needs y");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_bwd_sums: ldz=%d must be a multiple of %d", ldz, kc);
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan pl = red_plan(M, C, kc);
+    float* ws = (float*)workspace;
+    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    dim3 g1(pl.colgroups, pl.nsplit);
+    const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;
+    const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 && ((uintptr_t)dy) % 16 == 0 &&
+                       (!relu || ((uintptr_t)y) % 16 == 0);
+#define BN_SUMS(T, TY)                                                                                                      \
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz, \
+                       ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu, vec_ok, pl.rows_per_split, ws);        \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, ws, pl.nsplit, C, M, sums + C, sums, fin)
+    if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_SUMS(bf16_t, bf16_t); }
+    else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_SUMS(bf16_t, float); }
+    else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_SUMS(float, float); }
+    else ODTK_REQUIRE(false, "bn_bwd_sums: bad dtype");
+#undef BN_SUMS
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_bn_bwd_given(const void* z, const void* y, const void* dy, int M, int C, int ldz, int dtype, int y_dtype, int ldy,
+                                 int rows_per_img, long long y_img_stride, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, int relu, const float* sums_global, long long count, void* dz, void* workspace,
+                                 void* stream) {
+    ODTK_REQUIRE(z && dy && dz && gamma && save_mean && save_invstd && sums_global && workspace, "bn_bwd_given: null pointer");
+    ODTK_REQUIRE(!relu || y, "bn_bwd_given: relu needs y");
+    ODTK_REQUIRE(count >= M, "bn_bwd_given: count=%lld < local rows %d", count, M);
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_bwd_given: ldz=%d must be a multiple of %d", ldz, kc);
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan pl = red_plan(M, C, kc);
+    float* ws = (float*)workspace;
+    const int rows_per_block = pl.rows_per_split;
+    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
+    const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;
+    const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 && ((uintptr_t)dy) % 16 == 0 &&
+                       (!relu || ((uintptr_t)y) % 16 == 0);
+    hipLaunchKernelGGL(bn_scale_sums_kernel, dim3(ceil_div(2 * C, 256)), dim3(256), 0, st, sums_global, 2 * C, 1.f / (float)count, fin);
+#define BN_GIVEN(T, TY)                                                                                                       \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz,   \
+                       ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, fin, rows_per_block)
+    if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_GIVEN(bf16_t, bf16_t); }
+    else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_GIVEN(bf16_t, float); }
+    else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_GIVEN(float, float); }
+    else ODTK_REQUIRE(false, "bn_bwd_given: bad dtype");
+#undef BN_GIVEN
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Residual sum / pitched copy / nearest 2x up-sampling: the glue between the convolutions of the residual and
 // pyramid detectors (YOLOv3.py:489-491 `conv = conv + conv2`, :411-412 resize_nearest_neighbor + concat).
 // HBM-bound, 16 bytes per lane, rows addressed through their own pitch so that a channel slice of a concat buffer

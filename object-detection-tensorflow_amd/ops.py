@@ -152,6 +152,44 @@ def bn_bwd(z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, save_me
          _p(gamma), _p(save_mean), _p(save_invstd), int(relu), _p(dz), _p(dgamma), _p(dbeta), _p(ws), _stream())
 
 
+class SyncBN:
+    """Batch norm over the GLOBAL batch of a data-parallel job (include/odtk.h: odtk_bn_moments ... odtk_bn_bwd_given): the
+    replicas exchange [2C] floats per layer and pass, forward (all-gather, done as an all-reduce of a zero-padded buffer so that
+    it also runs on the gloo backend) and backward (all-reduce).  Same arguments as bn_fwd / bn_bwd."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.buf = {}
+
+    def _scratch(self, C_, device):
+        key = (C_, str(device))
+        if key not in self.buf:
+            self.buf[key] = (torch.zeros(self.world, 2, C_, device=device), torch.zeros(2 * C_, device=device),
+                             torch.zeros(2 * C_, device=device))
+        return self.buf[key]
+
+    def fwd(self, z, M, C_, ldz, gamma, beta, mmean, mvar, save_mean, save_invstd, relu, y, ldy, rows_per_img, y_img_stride, ws):
+        mom, _, _ = self._scratch(C_, z.device)
+        mom.zero_()
+        mine = mom[self.rank]
+        call("odtk_bn_moments", _p(z), M, C_, ldz, dt_of(z), _p(mine[0]), _p(mine[1]), _p(ws), _stream())
+        self.dist.all_reduce(mom, op=self.dist.ReduceOp.SUM, group=self.group)          # rows of the other ranks were zero: a gather
+        call("odtk_bn_fwd_given", _p(z), M, C_, ldz, dt_of(z), _p(gamma), _p(beta), _p(mom), self.world, _p(mmean), _p(mvar),
+             _p(save_mean), _p(save_invstd), int(relu), _p(y), dt_of(y), ldy, rows_per_img, y_img_stride, _p(ws), _stream())
+
+    def bwd(self, z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, dz, dgamma, dbeta, ws):
+        _, sums, glob = self._scratch(C_, z.device)
+        call("odtk_bn_bwd_sums", _p(z), _p(y), _p(dy), M, C_, ldz, dt_of(z), dt_of(dy), ldy, rows_per_img, y_img_stride, _p(save_mean),
+             _p(save_invstd), int(relu), _p(sums), _p(ws), _stream())
+        dbeta.copy_(sums[:C_]); dgamma.copy_(sums[C_:])          # the LOCAL sums: the gradient all-reduce adds the replicas' up
+        glob.copy_(sums)
+        self.dist.all_reduce(glob, op=self.dist.ReduceOp.SUM, group=self.group)
+        call("odtk_bn_bwd_given", _p(z), _p(y), _p(dy), M, C_, ldz, dt_of(z), dt_of(dy), ldy, rows_per_img, y_img_stride, _p(gamma),
+             _p(save_mean), _p(save_invstd), int(relu), _p(glob), int(M) * self.world, _p(dz), _p(ws), _stream())
+
+
 def add2d(a, lda, b, ldb, y, ldy, M, C_):
     """y[:, :C] = a[:, :C] (+ b[:, :C]); operands are 2-D views with their own pitch (a channel slice of a concat buffer)"""
     call("odtk_add2d", _p(a), int(lda), _p(b), int(ldb), _p(y), int(ldy), int(M), int(C_), dt_of(a), _stream())

@@ -161,6 +161,7 @@ class SSD300:
             if data_provider.get('val_generator') is not None:
                 self.val_generator = data_provider['val_generator']
         self.global_step = 0
+        self.sync_bn = None
         self.checkpoint_format = config.get('checkpoint_format', 'torch')          # 'tf': tf.train.Saver files (tf_checkpoint.py)
         self.use_graph = bool(config.get('use_graph', True))   # HIP-graph replay of the step after 2 eager steps
         # optional: filter gradients on a second HIP stream (wgrad(L) only needs dy(L) and the stored input of L, nothing
@@ -440,6 +441,19 @@ class SSD300:
             self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, self.dev)
         self._fp_batch.run()
 
+    # ------------------------------------------------------------------ batch norm: local, or over the global batch (sync_bn)
+    def _bn_fwd(self, z, M, C_, ldz, gamma, beta, mmean, mvar, sm, si, training, relu, y, ldy, rows_per_img, y_img_stride, ws):
+        if training and self.sync_bn is not None:
+            self.sync_bn.fwd(z, M, C_, ldz, gamma, beta, mmean, mvar, sm, si, relu, y, ldy, rows_per_img, y_img_stride, ws)
+        else:
+            ops.bn_fwd(z, M, C_, ldz, gamma, beta, mmean, mvar, sm, si, training, relu, y, ldy, rows_per_img, y_img_stride, ws)
+
+    def _bn_bwd(self, z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, sm, si, relu, dz, dgamma, dbeta, ws):
+        if self.sync_bn is not None:
+            self.sync_bn.bwd(z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, sm, si, relu, dz, dgamma, dbeta, ws)
+        else:
+            ops.bn_bwd(z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, sm, si, relu, dz, dgamma, dbeta, ws)
+
     # ------------------------------------------------------------------ forward
     def _conv_fwd(self, name, src, dst, bias, relu):
         ops.conv2d_fwd(self.desc[name], src.t, self._wslice(name + '.w', self.Pc), bias, dst.t, relu)
@@ -466,7 +480,7 @@ class SSD300:
             z, y = self.zbuf[name], a[name]
             self._conv_fwd(name, src, z, self.param(name + '.b'), False)
             sm, si = self.bnsave[name]
-            ops.bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
+            self._bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
                        self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, True,
                        y.t, y.ld, z.M, 0, self.ws)
         A25 = NUM_PRIORS * self.row
@@ -477,7 +491,7 @@ class SSD300:
             sm, si = self.bnsave[name]
             co = self.convs[name].cout
             out = self.pred.view(-1)[self.head_off[i] * self.row:]
-            ops.bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
+            self._bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
                        self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, False,
                        out, co, src.H * src.W, A25, self.ws)
 
@@ -539,7 +553,7 @@ class SSD300:
             co = self.convs[name].cout
             sm, si = self.bnsave[name]
             dyv = self.dpred.view(-1)[self.head_off[i] * self.row:]
-            ops.bn_bwd(z.t, None, dyv, z.M, co, z.ld, co, src.H * src.W, A25, self.param(name + '.gamma'), sm, si,
+            self._bn_bwd(z.t, None, dyv, z.M, co, z.ld, co, src.H * src.W, A25, self.param(name + '.gamma'), sm, si,
                        False, z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
             self._conv_bwd_params(name, src, z.g, z.ld)
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], None, src.g, False)
@@ -549,7 +563,7 @@ class SSD300:
             src = a[self.extra_src[name]]
             z, y = self.zbuf[name], a[name]
             sm, si = self.bnsave[name]
-            ops.bn_bwd(z.t, y.t, y.g, z.M, co, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, True,
+            self._bn_bwd(z.t, y.t, y.g, z.M, co, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, True,
                        z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
             self._conv_bwd_params(name, src, z.g, z.ld)
             # the source already holds the head's gradient when it is a feature map
@@ -839,11 +853,17 @@ class SSD300:
         print('load weight', path, 'successfully')
 
     # ------------------------------------------------------------------ data parallel
-    def attach_data_parallel(self, group=None, bucket_mb=25):
+    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False):
         """Shard images over ranks (one process per GPU); gradients are summed with bucketed
         RCCL all-reduce overlapped with backward.  The loss divisor becomes the GLOBAL batch."""
         from .dist import GradAllReducer
         self.dist = GradAllReducer(self, group, bucket_mb)
         self._graphs_invalidate()
         self.loss_divisor_batch = self.batch_size * self.dist.world
+        if sync_bn:
+            # SURVEY.md 8e option B: batch statistics over all replicas -- W ranks x B images compute exactly what one device
+            # computes on W*B (strong scaling with reference semantics).  Two small collectives per BN layer and pass sit inside
+            # the step, so the launches stay eager (no HIP-graph replay).
+            self.sync_bn = ops.SyncBN(group)
+            self.use_graph = False
         return self.dist

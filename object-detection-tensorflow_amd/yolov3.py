@@ -91,6 +91,7 @@ class YOLOv3:
                 self.val_generator = data_provider['val_generator']
         self.global_step = 0
         self.dist = None
+        self.sync_bn = None
         self.loss_divisor_batch = self.batch_size
         torch.cuda.set_device(self.dev)
         self.specs = layer_specs(self.num_classes, self.num_priors)
@@ -293,8 +294,12 @@ class YOLOv3:
                 _, name, src, z, y, act = op
                 ops.conv2d_fwd(self.desc[name], src.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), z.t, False)
                 sm, si = self.bnsave[name]
-                ops.bn_fwd(z.t, z.M, z.C, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'), self.stat(name + '.mmean'),
-                           self.stat(name + '.mvar'), sm, si, training, act, y.t, y.ld, z.M, 0, self.ws)
+                if training and self.sync_bn is not None:
+                    self.sync_bn.fwd(z.t, z.M, z.C, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'), self.stat(name + '.mmean'),
+                                     self.stat(name + '.mvar'), sm, si, act, y.t, y.ld, z.M, 0, self.ws)
+                else:
+                    ops.bn_fwd(z.t, z.M, z.C, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'), self.stat(name + '.mmean'),
+                               self.stat(name + '.mvar'), sm, si, training, act, y.t, y.ld, z.M, 0, self.ws)
             elif op[0] == 'add':
                 _, a, b, y = op
                 ops.add2d(a.t, a.ld, b.t, b.ld, y.t, y.ld, y.M, y.C)
@@ -315,8 +320,9 @@ class YOLOv3:
                 dy = self.grad_of(y)
                 zg = self.zg[: z.M * z.ld].view(z.M, z.ld)
                 sm, si = self.bnsave[name]
-                ops.bn_bwd(z.t, y.t, dy, z.M, z.C, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, act, zg,
-                           self._flat(name + '.gamma', self.G), self._flat(name + '.beta', self.G), self.ws)
+                (self.sync_bn.bwd if self.sync_bn is not None else ops.bn_bwd)(
+                    z.t, y.t, dy, z.M, z.C, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, act, zg,
+                    self._flat(name + '.gamma', self.G), self._flat(name + '.beta', self.G), self.ws)
                 # the bias feeds batch norm: its gradient is exactly zero (only weight decay acts on it)
                 ops.conv2d_wgrad(self.desc[name], src.t, zg, z.ld, self._flat(name + '.w', self.G), None)
                 if src is not self.input:
@@ -482,12 +488,15 @@ class YOLOv3:
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < 52 and k in self.pinfo})
         print('load pretraining weight', path, 'successfully')
 
-    def attach_data_parallel(self, group=None, bucket_mb=25):
+    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False):
         """images sharded over ranks (one process per GPU); gradients summed with the bucketed RCCL all-reduce of dist.py,
-        overlapped with the backward pass; the loss divisor becomes the GLOBAL batch"""
+        overlapped with the backward pass; the loss divisor becomes the GLOBAL batch.  sync_bn: batch statistics over all replicas
+        (ops.SyncBN), i.e. exactly the single-device computation on the global batch"""
         from .dist import GradAllReducer
         self.dist = GradAllReducer(self, group, bucket_mb)
         self.loss_divisor_batch = self.batch_size * self.dist.world
+        if sync_bn:
+            self.sync_bn = ops.SyncBN(group)
         return self.dist
 
 

@@ -109,3 +109,56 @@ def test_yolov3_two_ranks_one_gpu(tmp_path, dev):
     assert float((g - total).norm()) < 1e-4 * float(total.norm())          # f32 engine; filter gradients use float atomics
     after = p0 - 0.002 * (total + 5e-4 * p0)                                # first momentum step: accum = grad + wd * var
     assert float((a['P'].to(total.device) - after).norm()) < 1e-4 * float((after - p0).norm()) + 1e-7 * float(p0.norm())
+
+
+def _syncbn_worker(rank, world, port, out_dir, model):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    m, batches = _syncbn_model(model, 2)
+    m.attach_data_parallel(bucket_mb=16, sync_bn=True)
+    m.set_batch(*batches[rank])
+    loss = float(m.train_step(0.002))
+    torch.cuda.synchronize()
+    torch.save({'P': m.P.cpu(), 'S': m.S.cpu(), 'loss': loss}, os.path.join(out_dir, f's{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def _syncbn_model(model, batch):
+    """f32 engine, same seed everywhere; returns the model for `batch` images per process and the two per-rank batches"""
+    import odtk
+    if model == 'ssd300':
+        from oracle import ssd300_ref as R
+        cfg = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': batch,
+               'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '', 'verbose': False,
+               'compute_dtype': 'f32', 'seed': 0, 'use_graph': False}
+        m = odtk.SSD300(cfg, {'data_shape': [300, 300, 3], 'num_train': batch, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+        return m, [R.synthetic_batch(2, 400 + r) for r in range(2)]
+    m = odtk.YOLOv3(_yolo_cfg(batch, 64), {'num_train': batch, 'train_generator': [], 'val_generator': None, 'num_val': 0})
+    return m, [_yolo_batch(r, 2, 64) for r in range(2)]
+
+
+@pytest.mark.parametrize('model', ['ssd300', 'yolov3'])
+def test_sync_bn_two_ranks_equal_one_device_on_the_global_batch(tmp_path, dev, model):
+    """SURVEY.md 8e option B: 2 ranks x 2 images with batch statistics exchanged between the replicas (ops.SyncBN) leave the same
+    parameters and moving statistics as ONE process training on the 4 images -- strong scaling with the reference's semantics."""
+    import torch.multiprocessing as mp
+    mp.spawn(_syncbn_worker, args=(2, 29670 + (model == 'yolov3'), str(tmp_path), model), nprocs=2, join=True)
+    a, b = torch.load(os.path.join(tmp_path, 's0.pt')), torch.load(os.path.join(tmp_path, 's1.pt'))
+    assert torch.equal(a['P'], b['P']) and torch.equal(a['S'], b['S'])
+    m, batches = _syncbn_model(model, 4)
+    p0 = m.P.clone().cpu()
+    m.set_batch(torch.cat([batches[0][0], batches[1][0]]), torch.cat([batches[0][1], batches[1][1]]))
+    loss = float(m.train_step(0.002))
+    torch.cuda.synchronize()
+    step = m.P.cpu() - p0
+    # the two runs reduce in different orders: a (leaky-)ReLU input within round-off of 0 may land on the other side, and one such
+    # element moves the upstream gradients by ~1 % (tests/test_gpu_yolov3.py); without a flip the runs agree to ~1e-3 of the update
+    err = float((a['P'] - m.P.cpu()).norm()) / float(step.norm())
+    print('sync-BN update error relative to the update:', err)
+    assert err < 2e-2, 'parameter update'
+    assert float((a['S'] - m.S.cpu()).norm()) < 1e-5 * float(m.S.cpu().norm()), 'moving statistics'
+    # the loss a rank reports is the mean over ITS images / world ... both use the global divisor: the two ranks' data terms add up
+    assert loss == loss and a['loss'] == a['loss']

@@ -187,6 +187,7 @@ def main():
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region')
     ap.add_argument('--wgrad-stream', action='store_true', help='A/B: filter gradients on a second HIP stream')
     ap.add_argument('--match-stream', action='store_true', help='A/B: box matching on a second HIP stream under the forward pass')
+    ap.add_argument('--sync-bn', action='store_true', help='N > 1: batch-norm statistics over all replicas (SURVEY 8e option B; eager launches)')
     ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
     args = ap.parse_args()
 
@@ -215,7 +216,7 @@ def main():
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)
     if world > 1:
-        model.attach_data_parallel()
+        model.attach_data_parallel(sync_bn=args.sync_bn)
     images, gt = synthetic_batch(B, 1000 + rank, dev)
     model.set_batch(images, gt)
 
@@ -277,7 +278,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
-                       'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
+                       'global_batch': B * world, 'parallelism': f'dp{world}' + ('+sync-bn' if args.sync_bn and world > 1 else ''), 'final_loss': round(final_loss, 4),
                        'launch': 'eager' if not model.use_graph else ('hip-graph replay (fwd+loss+bwd)' if model._g_back is not None
                                                                         else f'hip-graph replay (fwd+loss; bwd as {len(model._g_back_segs or [])} '
                                                                              'bucket graphs with RCCL all-reduces between them)')},

@@ -99,7 +99,7 @@ int odtk_filter_prepare(const float* w, int K, int R, int S, int C, int Kp, int 
 
 /* The same w -> w_t transform for MANY layers in one launch (the optimizer refreshes every dgrad
  * filter each step).  `items_dev` is a DEVICE array of n_items odtk_fp_item; item i owns the blocks
- * [block_begin, block_begin + ktiles*R*S*ctiles) with ctiles = ceil(C/32), ktiles = ceil(Kp/32);
+ * [block_begin, block_begin + ktiles*R*S*ctiles) with ctiles = ceil(C/32), ktiles = ceil(Kp/64);
  * total_blocks is the sum. */
 typedef struct odtk_fp_item {
     const float* w;      /* f32 master [K][R*S][C]              */

@@ -749,28 +749,34 @@ struct FpItem {                      // mirrors odtk_fp_item (include/odtk.h)
     int block_begin, ctiles, ktiles, pad_;
 };
 template <typename T>
-__global__ void filter_prepare_batched_kernel(const FpItem* __restrict__ items, int n_items) {
-    __shared__ float tile[32][33];
-    // wave-uniform search of the item that owns this block
-    int it = 0;
-    for (int i = 1; i < n_items; ++i)
-        if ((int)blockIdx.x >= items[i].block_begin) it = i;
-    const FpItem d = items[it];
+__global__ void __launch_bounds__(256) filter_prepare_batched_kernel(const FpItem* __restrict__ items, int n_items) {
+    // one workgroup = one tile of 64 k x 32 c for one tap: 128-byte row reads (32 f32 along c), 128-byte row writes (64 bf16 along k)
+    __shared__ float tile[64][33];
+    // wave-uniform binary search of the item that owns this block (block_begin ascending)
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= items[mid].block_begin) lo = mid; else hi = mid - 1;
+    }
+    const FpItem d = items[lo];
     const int lb = blockIdx.x - d.block_begin;
     const int kt = lb / (d.RS * d.ctiles), rem = lb - kt * (d.RS * d.ctiles);
     const int rs = rem / d.ctiles, ct = rem - rs * d.ctiles;
-    const int c0 = ct * 32, k0 = kt * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
-        const int k = k0 + i, c = c0 + tx;
-        tile[i][tx] = (k < d.K && c < d.C) ? d.w[((size_t)k * d.RS + rs) * d.C + c] : 0.f;
+    const int c0 = ct * 32, k0 = kt * 64;
+    {
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int i = ty; i < 64; i += 8) {
+            const int k = k0 + i, c = c0 + tx;
+            tile[i][tx] = (k < d.K && c < d.C) ? d.w[((size_t)k * d.RS + rs) * d.C + c] : 0.f;
+        }
     }
     __syncthreads();
     const int rsf = d.RS - 1 - rs;
     T* wt = reinterpret_cast<T*>(d.w_t);
-    for (int i = ty; i < 32; i += 8) {
-        const int cc = c0 + i, k = k0 + tx;
-        if (cc < d.C && k < d.Kp) wt[((size_t)cc * d.RS + rsf) * d.Kp + k] = elem<T>::store(k < d.K ? tile[tx][i] : 0.f);
+    const int tk = threadIdx.x & 63, tc = threadIdx.x >> 6;
+    for (int i = tc; i < 32; i += 4) {
+        const int cc = c0 + i, k = k0 + tk;
+        if (cc < d.C && k < d.Kp) wt[((size_t)cc * d.RS + rsf) * d.Kp + k] = elem<T>::store(k < d.K ? tile[tk][i] : 0.f);
     }
 }
 

@@ -100,7 +100,7 @@ class FilterPrepareBatch:
         blob = b''
         begin = 0
         for (w, wt, K, R, S, C_, Kp) in entries:
-            ct, kt = (C_ + 31) // 32, (Kp + 31) // 32
+            ct, kt = (C_ + 31) // 32, (Kp + 63) // 64
             blob += struct.pack('<QQiiiiiiii', w.data_ptr(), wt.data_ptr(), K, R * S, C_, Kp, begin, ct, kt, 0)
             begin += kt * R * S * ct
         self.keep = entries                                   # the item table holds raw pointers

@@ -46,7 +46,8 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  * key 2 = A/B bits of the conv kernels: bits 0-3 ablations (skip DMA / one slab; RESULTS WRONG), 5 no fragment double
  *         buffering, 6 no early/late DMA stagger, 7 "landed early" protocol, 8 64-bit global addressing for the LDS-DMA,
  *         9 no XCD remap (wgrad), 10 s_setprio, 11 no 64->64 / first-layer halo kernels, 12 per-lane tap walk,
- *         13 no split-K, 14 interleaved slab body, 15 4-wave kernel (v5), 16 no raster-run halo kernel (v6);
+ *         13 no split-K, 14 interleaved slab body, 15 4-wave kernel (v5), 16 no raster-run halo kernel (v6), 17 256x256 wgrad tile (v7),
+ *         18-25 = n: halo kernel instead of split-K on layers with >= n tiles (0 = split-K policy as is);
  * key 3 = single-kernel NMS (value != 0) */
 int odtk_debug_set(int key, int value);
 /* name of the device kernel the last odtk_conv2d_* call of this thread dispatched to (bench.py attributes

@@ -2010,7 +2010,10 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     // split-K: few tiles with a long k loop leave most CUs idle and run at DMA latency; give every tile
     // up to 256 / tiles blocks of >= 4 k-slabs each (dbg bit 13 turns it off for A/B runs)
     int ksplit = 1;
-    if (tiles <= 128 && nk >= 8 && !(a.dbg & 8192)) {
+    const bool v6_ok = !(a.dbg & 65536) && PT == 128 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
+                       a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && 2 * a.dil * (a.W + 1) <= 160 && a.Kdim == 9 * a.C;
+    const int v6_min_tiles = (a.dbg >> 18) & 255;         // A/B (dbg bits 18-25): halo kernel instead of split-K from this many tiles on
+    if (tiles <= 128 && nk >= 8 && !(a.dbg & 8192) && !(v6_ok && v6_min_tiles && tiles >= v6_min_tiles)) {
         ksplit = 256 / tiles;                    // (2..6 slabs per part and 512 / tiles were measured: this is the best)
         if (ksplit > nk / 4) ksplit = nk / 4;
         if (ksplit > 32) ksplit = 32;
@@ -2028,8 +2031,7 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     a.ksplit = 1;
     const int grid = tiles;
     // raster-run halo kernel: 3x3 (dilated), stride 1, SAME, patch of 256 + 2 * dil * (W + 1) rows <= 416 (dbg bit 16 = off, A/B)
-    if (!(a.dbg & 65536) && PT == 128 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
-        a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && 2 * a.dil * (a.W + 1) <= 160 && a.Kdim == 9 * a.C) {
+    if (v6_ok) {
         hipLaunchKernelGGL(conv_gather_v6_kernel, dim3(grid), dim3(256), 0, st, a);
         a.ksplit = -1;                                   // tells the dispatcher which kernel ran (odtk_conv_last_kernel)
         return 0;

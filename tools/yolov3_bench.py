@@ -18,6 +18,9 @@ cfg = {'mode': 'train', 'data_shape': [size, size, 3], 'num_classes': 20, 'weigh
 g = torch.Generator().manual_seed(0)
 imgs = (torch.rand(batch, size, size, 3, generator=g) * 255).round()
 gt = S.synthetic_gt(batch, size, 1, lo=0.05, hi=0.8)
+if os.environ.get('ODTK_DBG'):
+    from odtk import ops as _ops
+    _ops.debug_set(2, int(os.environ['ODTK_DBG']))
 m = odtk.YOLOv3(cfg, {'num_train': batch, 'train_generator': [(imgs, gt)], 'val_generator': None, 'num_val': 0})
 m.set_batch(imgs, gt)
 for _ in range(3):
@@ -34,6 +37,27 @@ for name, cin, cout, k, s, _ in m.specs:
     flops += 2 * batch * d.Ho * d.Wo * cout * cin * k * k
 flops *= 3                                   # forward + dgrad + wgrad (the first layer has no dgrad: < 0.1 %)
 print(f'YOLOv3 {size}x{size} batch {batch} bf16: {dt * 1e3:8.2f} ms/step  {batch / dt:8.1f} images/s   conv {flops / dt / 1e12:6.1f} TFLOP/s   loss {float(loss):.3f}')
+if os.environ.get('YOLO_TABLE'):
+    # per-layer conv launches with HIP events (bench.py's ConvTimer), grouped by shape
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from odtk import ops
+    timer = bench.ConvTimer(ops)
+    timer.install()
+    timer.enabled = True
+    nst = 5
+    for _ in range(nst):
+        m.train_step(1e-4)
+    torch.cuda.synchronize()
+    timer.enabled = False
+    rows = {}
+    for kind, kern, fl, tt, ab, shp in timer.per_step(nst):
+        r = rows.setdefault((kind, kern, shp), [0, 0.0, 0.0]); r[0] += 1; r[1] += tt; r[2] += fl
+    tot = sum(r[1] for r in rows.values())
+    print(f'conv launches per step: {sum(r[0] for r in rows.values())}, {tot * 1e3:.2f} ms')
+    for (kind, kern, shp), r in sorted(rows.items(), key=lambda kv: -kv[1][1])[:45]:
+        N, H, W, C_, K, R, s, dl = shp
+        print(f'{kind:13s} {kern:38s} H{H:<3d} C{C_:<4d} K{K:<4d} k{R} s{s}  x{r[0]:<2d} {r[1] * 1e6 / r[0]:7.1f} us each {r[1] * 1e3:6.3f} ms  {r[2] / r[1] / 1e12:6.1f} TF')
 if os.environ.get('YOLO_PROFILE'):
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:

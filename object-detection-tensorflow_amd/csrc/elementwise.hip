@@ -903,7 +903,9 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     const size_t ysz = dtype_size(y_dtype);
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
                        ((uintptr_t)y % 16) == 0;
-    const int rows_per_block = pl.rows_per_split;
+    // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
+    // pass keeps <= 256 row splits because its partials live in the workspace)
+    const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
     dim3 grid(pl.colgroups, ceil_div(M, rows_per_block));
 #define BN_APPLY(T, TY)                                                                                        \
     hipLaunchKernelGGL((bn_apply_kernel<T, TY>), grid, dim3(256), 0, st, (const T*)z, M, C, ldz, relu, (TY*)y, \
@@ -929,7 +931,9 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
     float* ws = (float*)workspace;
-    const int rows_per_block = pl.rows_per_split;
+    // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
+    // pass keeps <= 256 row splits because its partials live in the workspace)
+    const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
     dim3 g1(pl.colgroups, pl.nsplit);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
@@ -1117,7 +1121,9 @@ extern "C" int odtk_bn_fwd_given(const void* z, int M, int C, int ldz, int dtype
                        moving_var, save_mean, save_invstd, fin);
     const size_t ysz = dtype_size(y_dtype);
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 && ((uintptr_t)y % 16) == 0;
-    const int rows_per_block = pl.rows_per_split;
+    // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
+    // pass keeps <= 256 row splits because its partials live in the workspace)
+    const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
     dim3 grid(pl.colgroups, ceil_div(M, rows_per_block));
 #define BN_APPLY(T, TY)                                                                                        \
     hipLaunchKernelGGL((bn_apply_kernel<T, TY>), grid, dim3(256), 0, st, (const T*)z, M, C, ldz, relu, (TY*)y, \
@@ -1171,7 +1177,9 @@ extern "C" int odtk_bn_bwd_given(const void* z, const void* y, const void* dy, i
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
     float* ws = (float*)workspace;
-    const int rows_per_block = pl.rows_per_split;
+    // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
+    // pass keeps <= 256 row splits because its partials live in the workspace)
+    const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
     const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;

@@ -90,6 +90,8 @@ class YOLOv3:
                 self.num_val = data_provider['num_val']
                 self.val_generator = data_provider['val_generator']
         self.global_step = 0
+        self.use_graph = bool(config.get('use_graph', True))
+        self._graph, self._graph_gt, self._eager_steps = None, None, 0
         self.dist = None
         self.sync_bn = None
         self.loss_divisor_batch = self.batch_size
@@ -350,16 +352,31 @@ class YOLOv3:
             self.gt = torch.zeros(gt.shape, device=self.dev)
         self.gt.copy_(gt, non_blocking=True)
 
-    def train_step(self, lr):
-        """one optimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor"""
-        if self.dist is not None:
-            self.dist.begin_step()
+    def _step_body(self):
         self.G.zero_()
         self._forward(True)
         self._loss(0.5 / self.loss_divisor_batch)              # d(.5 * mean_i loss_i)
         for name in self._backward_iter():
             if self.dist is not None:
                 self.dist.layer_ready(name)
+
+    def train_step(self, lr):
+        """one optimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor.
+        Single device: after two eager steps (the library's lazily grown scratch buffers exist by then) forward + loss + backward
+        replay from ONE HIP graph -- ~1 000 dependent launches of 5-25 us each leave the queue without host round trips; the
+        optimizer launches stay outside (lr is a launch argument).  Data parallel / sync-BN: eager (collectives inside the step)."""
+        if self.dist is not None:
+            self.dist.begin_step()
+        if self.use_graph and self.dist is None and self._eager_steps >= 2:
+            if self._graph is None or self._graph_gt is not self.gt:
+                self._graph = torch.cuda.CUDAGraph()
+                self._graph_gt = self.gt                       # the captured launches hold this buffer's pointer and pad length
+                with torch.cuda.graph(self._graph):
+                    self._step_body()
+            self._graph.replay()
+        else:
+            self._step_body()
+            self._eager_steps += 1
         if self.dist is not None:
             self.dist.finish_step()
         ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial, self.Pc if self.DT == BF16 else None)

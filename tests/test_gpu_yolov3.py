@@ -233,3 +233,20 @@ def test_tf_saver_checkpoint_roundtrip(dev, tmp_path):
         layer = int(k[1:].split('.')[0])
         restored = layer < 52 and not k.endswith(('.mmean', '.mvar'))
         assert torch.equal(c[k], a[k] if restored else before[k]), k
+
+
+def test_graph_replay_equals_eager_launches(dev):
+    """the HIP-graph replay of forward + loss + backward (default from the third step on) against eager launches of the same
+    steps: f32 engine, equality up to the float-atomic order of the filter gradients"""
+    batch = _batch(2, 64, 80)
+    out = {}
+    for use_graph in (False, True):
+        m = _model('train', 'f32', 2, 64, _provider([batch]), seed=4, use_graph=use_graph)
+        m.set_batch(*batch)
+        losses = [float(m.train_step(0.002)) for _ in range(5)]
+        assert (m._graph is not None) == use_graph
+        out[use_graph] = (losses, m.P.clone())
+    for a, b in zip(out[False][0], out[True][0]):
+        assert abs(a - b) <= 2e-3 * abs(a), (out[False][0], out[True][0])
+    step = out[False][1] - _model('train', 'f32', 2, 64, _provider([batch]), seed=4).P
+    assert float((out[True][1] - out[False][1]).norm()) < 2e-2 * float(step.norm())

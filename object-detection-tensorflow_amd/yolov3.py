@@ -101,16 +101,23 @@ class YOLOv3:
         self._build()
 
     # ------------------------------------------------------------------ parameters
-    def _init_parameters(self, seed):
-        self.pinfo, self.sinfo = OrderedDict(), OrderedDict()
+    @staticmethod
+    def param_layout(specs, chunk):
+        """(pinfo, nparam, sinfo, nstat): offsets of every parameter / statistic in the flat buffers, creation order (host logic,
+        no device needed: the data-parallel bucketing is tested on CPU with exactly this layout)"""
+        pinfo, sinfo = OrderedDict(), OrderedDict()
         off = soff = 0
-        for name, cin, cout, k, _, _ in self.specs:
-            for suffix, shape in (('.w', (cout, k, k, ops.pad_to(cin, self.chunk))), ('.b', (cout,)), ('.gamma', (cout,)), ('.beta', (cout,))):
-                self.pinfo[name + suffix] = (off, shape)
+        for name, cin, cout, k, _, _ in specs:
+            for suffix, shape in (('.w', (cout, k, k, ops.pad_to(cin, chunk))), ('.b', (cout,)), ('.gamma', (cout,)), ('.beta', (cout,))):
+                pinfo[name + suffix] = (off, shape)
                 off += ops.pad_to(int(np.prod(shape)), 64)
             for suffix in ('.mmean', '.mvar'):
-                self.sinfo[name + suffix] = (soff, (cout,))
+                sinfo[name + suffix] = (soff, (cout,))
                 soff += ops.pad_to(cout, 64)
+        return pinfo, off, sinfo, soff
+
+    def _init_parameters(self, seed):
+        self.pinfo, off, self.sinfo, soff = self.param_layout(self.specs, self.chunk)
         self.nparam = off
         dev = self.dev
         self.P = torch.zeros(off, device=dev)

@@ -69,3 +69,65 @@ def test_single_process_is_a_noop():
     red = BucketAllReducer(flat, [('a', 0, 40), ('b', 40, 100)], None, bucket_bytes=64)
     red.begin_step(); red.segment_ready('b'); red.segment_ready('a'); red.finish_step()
     assert torch.equal(flat, torch.arange(100, dtype=torch.float32))
+
+
+def _yolo_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import odtk  # noqa: F401
+    from odtk.dist import GradAllReducer
+    from odtk.yolov3 import YOLOv3, layer_specs
+    specs = layer_specs(20, 3)
+    pinfo, nparam, _, _ = YOLOv3.param_layout(specs, 8)
+    model = types.SimpleNamespace(pinfo=pinfo, nparam=nparam, G=torch.zeros(nparam))
+    red = GradAllReducer(model, None, bucket_mb=25)
+    layers = [s[0] for s in specs]
+    launched = []
+    ok = True
+    for step in range(2):
+        model.G.zero_()
+        red.begin_step()
+        for name in reversed(layers):                       # YOLOv3._backward_iter finishes c74 first, c0 last
+            for suffix in ('.w', '.gamma', '.beta'):
+                off, shape = pinfo[name + suffix]
+                n = 1
+                for d in shape:
+                    n *= d
+                model.G[off:off + n] = float(rank + 1) * (1 + step)
+            before = red.red.next_bucket
+            red.layer_ready(name)
+            if red.red.next_bucket > before:
+                launched.append(name)
+        red.finish_step()
+        off, shape = pinfo['c30.w']
+        ok = ok and float(model.G[off]) == 3.0 * (1 + step) and float(model.G[pinfo['c74.beta'][0]]) == 3.0 * (1 + step)
+        ok = ok and float(model.G[pinfo['c0.b'][0]]) == 0.0             # the bias slots carry no gradient
+    q.put((rank, ok, len(red.red.buckets), launched[: len(red.red.buckets)], red.boundary_layers()))
+    dist.destroy_process_group()
+
+
+def test_yolov3_gradient_buckets_world2():
+    """the data-parallel hooks of the YOLOv3 class on its real parameter layout (62 M parameters, 75 layers), two gloo ranks on
+    the CPU: buckets of ~25 MB close in backward order c74 -> c0, each as soon as its lowest layer is done, and the exchanged
+    buffer holds the sum of the replicas"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_yolo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _, _ in res)
+    _, _, nb, launched, boundary = res[0]
+    assert 8 <= nb <= 12                                    # 247 MB of f32 gradients in ~25 MB buckets
+    assert launched == boundary                             # a bucket's all-reduce starts at the layer that closes it
+    idx = [int(n[1:]) for n in boundary]
+    assert idx == sorted(idx, reverse=True) and idx[-1] == 0

@@ -186,6 +186,14 @@ int odtk_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, 
 int odtk_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, int dtype, int accumulate,
                         void* stream);
 
+/* tf.image.resize_bilinear(x, [Ho, Wo]) on NHWC rows, TF-1.x grid (align_corners=False: src = dst * in / out): the top-down path of
+ * the RetinaNet / FCOS pyramids (RetinaNet.py:309, FCOS.py:373), and its gradient (a gather, no atomics; up-scaling only).
+ * accumulate != 0 adds to y / dx -- `feat + resize(top_feat)` (RetinaNet.py:310) in one pass.  Pitch rules as odtk_add2d. */
+int odtk_resize_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                             int accumulate, void* stream);
+int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                             int accumulate, void* stream);
+
 /* tf.nn.l2_normalize(axis=C) * scalar gamma (SSD300.py:74-83). */
 int odtk_l2norm_fwd(const void* x, void* y, int M, int C, int ld, int dtype, const float* gamma,
                     void* stream);

@@ -60,6 +60,8 @@ SIGNATURES = {
     "odtk_bn_fwd_given": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _ll, _vp, _vp]),
     "odtk_bn_bwd_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
     "odtk_bn_bwd_given": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _vp, _vp, _vp, _i, _vp, _ll, _vp, _vp, _vp]),
+    "odtk_resize_bilinear_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "odtk_resize_bilinear_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "odtk_add2d": (_i, [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _i, _vp]),
     "odtk_upsample2x_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "odtk_upsample2x_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -1315,3 +1315,117 @@ extern "C" int odtk_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx,
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// tf.image.resize_bilinear(x, size) on feature maps, TF-1.x grid (align_corners=False, no half-pixel centres: src = dst * in/out),
+// forward and backward: the top-down path of the RetinaNet / FCOS pyramids (RetinaNet.py:309, FCOS.py:373).  NHWC rows with their
+// own pitch, 16 bytes of channels per lane.  Backward is a gather over the (few) output pixels that read an input pixel -- no atomics:
+// for an up-scaling by s every input pixel is touched by at most (ceil(s) + 1)^2 outputs, found by inverting the index map.
+namespace odtk {
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256) resize_bilinear_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int H,
+                                                                  int W, int Ho, int Wo, int C, int accumulate) {
+    constexpr int KC = Chunk<T>::N;
+    const int cpr = C / KC;
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    const long long total = (long long)N * Ho * Wo * cpr, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long row = i / cpr;
+        const int c = (int)(i - row * cpr) * KC;
+        const int xo = (int)(row % Wo);
+        const long long r2 = row / Wo;
+        const int yo = (int)(r2 % Ho), n = (int)(r2 / Ho);
+        const float fy = (float)yo * sy, fx = (float)xo * sx;
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        float tl[KC], tr[KC], bl[KC], br[KC], o[KC];
+        const T* base = x + (long long)n * H * W * ldx + c;
+        Chunk<T>::unpack(ld16(base + ((long long)y0 * W + x0) * ldx), tl);
+        Chunk<T>::unpack(ld16(base + ((long long)y0 * W + x1) * ldx), tr);
+        Chunk<T>::unpack(ld16(base + ((long long)y1 * W + x0) * ldx), bl);
+        Chunk<T>::unpack(ld16(base + ((long long)y1 * W + x1) * ldx), br);
+        if (accumulate) Chunk<T>::unpack(ld16(y + row * ldy + c), o);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            const float top = tl[e] + (tr[e] - tl[e]) * lx, bot = bl[e] + (br[e] - bl[e]) * lx;
+            const float v = top + (bot - top) * ly;
+            o[e] = accumulate ? o[e] + v : v;
+        }
+        st16(y + row * ldy + c, Chunk<T>::pack(o));
+    }
+}
+
+// weight of input index `in` in output index `out` along one axis (0 when it is not one of the two taps)
+__device__ __forceinline__ float bilinear_tap_weight(int out, int in, float scale, int in_size) {
+    const float f = (float)out * scale;
+    const int i0 = (int)floorf(f), i1 = min(i0 + 1, in_size - 1);
+    const float l = f - (float)i0;
+    float w = 0.f;
+    if (in == i0) w += 1.f - l;
+    if (in == i1) w += l;
+    return w;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) resize_bilinear_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int N, int H,
+                                                                  int W, int Ho, int Wo, int C, int accumulate) {
+    constexpr int KC = Chunk<T>::N;
+    const int cpr = C / KC;
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    const long long total = (long long)N * H * W * cpr, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long row = i / cpr;
+        const int c = (int)(i - row * cpr) * KC;
+        const int xi = (int)(row % W);
+        const long long r2 = row / W;
+        const int yi = (int)(r2 % H), n = (int)(r2 / H);
+        // outputs whose taps can include (yi, xi): floor(out * s) in {yi - 1, yi}  <=>  out in ((yi - 1) / s, (yi + 1) / s)
+        const int ya = max((int)floorf((float)(yi - 1) / sy), 0), yb = min((int)ceilf((float)(yi + 1) / sy), Ho - 1);
+        const int xa = max((int)floorf((float)(xi - 1) / sx), 0), xb = min((int)ceilf((float)(xi + 1) / sx), Wo - 1);
+        float s[KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) s[e] = 0.f;
+        if (accumulate) Chunk<T>::unpack(ld16(dx + row * lddx + c), s);
+        for (int yo = ya; yo <= yb; ++yo) {
+            const float wy = bilinear_tap_weight(yo, yi, sy, H);
+            if (wy == 0.f) continue;
+            for (int xo = xa; xo <= xb; ++xo) {
+                const float w = wy * bilinear_tap_weight(xo, xi, sx, W);
+                if (w == 0.f) continue;
+                float f[KC];
+                Chunk<T>::unpack(ld16(dy + (((long long)n * Ho + yo) * Wo + xo) * lddy + c), f);
+#pragma unroll
+                for (int e = 0; e < KC; ++e) s[e] += w * f[e];
+            }
+        }
+        st16(dx + row * lddx + c, Chunk<T>::pack(s));
+    }
+}
+
+}  // namespace
+}  // namespace odtk
+
+extern "C" int odtk_resize_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                                        int accumulate, void* stream) {
+    if (int e = glue_check("resize_bilinear_fwd", C, dtype, {ldx, ldy}, {x, y})) return e;
+    ODTK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "resize_bilinear_fwd: bad geometry");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(resize_bilinear_fwd_kernel<T>, dim3(grid_for((long long)N * Ho * Wo * (C / kc), 256, 65536)), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, N, H, W, Ho, Wo, C, accumulate);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                                        int accumulate, void* stream) {
+    if (int e = glue_check("resize_bilinear_bwd", C, dtype, {lddy, lddx}, {dy, dx})) return e;
+    ODTK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho >= H && Wo >= W, "resize_bilinear_bwd: up-scaling only (Ho >= H, Wo >= W)");
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(resize_bilinear_bwd_kernel<T>, dim3(grid_for((long long)N * H * W * (C / kc), 256, 65536)), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, Ho, Wo, C, accumulate);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

@@ -203,6 +203,15 @@ def upsample2x_bwd(dy, lddy, dx, lddx, N, H, W, C_, accumulate=False):
     call("odtk_upsample2x_bwd", _p(dy), int(lddy), _p(dx), int(lddx), N, H, W, int(C_), dt_of(dy), int(accumulate), _stream())
 
 
+def resize_bilinear_fwd(x, ldx, y, ldy, N, H, W, Ho, Wo, C_, accumulate=False):
+    """tf.image.resize_bilinear (TF-1.x grid, align_corners=False) on NHWC rows; accumulate: y += resize(x)"""
+    call("odtk_resize_bilinear_fwd", _p(x), int(ldx), _p(y), int(ldy), N, H, W, Ho, Wo, int(C_), dt_of(x), int(accumulate), _stream())
+
+
+def resize_bilinear_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, accumulate=False):
+    call("odtk_resize_bilinear_bwd", _p(dy), int(lddy), _p(dx), int(lddx), N, H, W, Ho, Wo, int(C_), dt_of(dy), int(accumulate), _stream())
+
+
 def l2norm_fwd(x, y, M, C_, ld, gamma):
     call("odtk_l2norm_fwd", _p(x), _p(y), M, C_, ld, dt_of(x), _p(gamma), _stream())
 

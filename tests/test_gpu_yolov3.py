@@ -253,3 +253,31 @@ def test_graph_replay_equals_eager_launches(dev):
         assert abs(a - b) <= 2e-3 * abs(a), (out[False][0], out[True][0])
     step = out[False][1] - _model('train', 'f32', 2, 64, _provider([batch]), seed=4).P
     assert float((out[True][1] - out[False][1]).norm()) < 5e-2 * float(step.norm())
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_resize_bilinear_feature_maps(dev, dt):
+    """tf.image.resize_bilinear on NHWC feature maps (TF-1.x grid), forward, accumulate form, and the gather backward against
+    autograd of the CPU restatement (oracle/augment_ref.resize_bilinear_legacy): the pyramid glue of RetinaNet / FCOS"""
+    import odtk  # noqa: F401
+    from odtk import ops
+    from oracle import augment_ref as AR
+    tdt = torch.float32 if dt == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    for (N, H, W, Ho, Wo, C, ld) in [(2, 5, 7, 10, 14, 16, 16), (1, 4, 4, 7, 9, 8, 24), (2, 3, 5, 3, 5, 8, 8), (1, 13, 13, 25, 25, 32, 32)]:
+        x = torch.randn(N * H * W, ld, generator=g).to(tdt)
+        xd = x.to(dev)
+        y = torch.zeros(N * Ho * Wo, C, dtype=tdt, device=dev)
+        ops.resize_bilinear_fwd(xd, ld, y, C, N, H, W, Ho, Wo, C)
+        xr = x[:, :C].float().view(N, H, W, C).clone().requires_grad_(True)
+        want = torch.stack([AR.resize_bilinear_legacy(xr[n], Ho, Wo) for n in range(N)])
+        tol = 2e-2 if dt == 'bf16' else 1e-5
+        torch.testing.assert_close(y.float().cpu().view(N, Ho, Wo, C), want.detach(), rtol=tol, atol=tol)
+        ops.resize_bilinear_fwd(xd, ld, y, C, N, H, W, Ho, Wo, C, accumulate=True)
+        torch.testing.assert_close(y.float().cpu().view(N, Ho, Wo, C), 2 * want.detach(), rtol=2 * tol, atol=2 * tol)
+        dy = torch.randn(N * Ho * Wo, C, generator=g).to(tdt)
+        want.backward(dy.float().view(N, Ho, Wo, C))
+        dx = torch.zeros(N * H * W, ld, dtype=tdt, device=dev)
+        ops.resize_bilinear_bwd(dy.to(dev), C, dx, ld, N, H, W, Ho, Wo, C)
+        torch.testing.assert_close(dx[:, :C].float().cpu().view(N, H, W, C), xr.grad, rtol=tol, atol=2 * tol)
+        assert float(dx[:, C:].abs().sum()) == 0                          # pad columns of the pitched operand untouched

@@ -49,6 +49,26 @@ CONV_CASES = [
 ]
 
 
+# geometries of the models that are not built yet: the reference's RetinaNet has 7 / 14 / 28 / 56 (x4) channels
+# (filters_list from the kernel size, RetinaNet.py:27), a 7x7 / stride-2 stem and stride-2 3x3 shortcuts; CenterNet's 4x4 / stride-2
+# transposed convolution is the dgrad of a 4x4 / stride-2 convolution
+BACKBONE_CASES = [
+    (2, 64, 64, 3, 16, 7, 2, 1),      # stem: 3 real channels in one chunk, 7x7, stride 2 (asymmetric SAME pad 2 / 3)
+    (2, 32, 32, 16, 7, 1, 1, 1),      # bottleneck 1x1 to 7 channels (pitch 8)
+    (2, 32, 32, 7, 7, 3, 1, 1),       # 7 -> 7, 3x3
+    (2, 32, 32, 7, 28, 1, 1, 1),      # 7 -> 28 (pitch 32)
+    (2, 32, 32, 16, 28, 3, 1, 1),     # shortcut 16 -> 28, 3x3
+    (2, 32, 32, 28, 14, 1, 1, 1),
+    (2, 32, 32, 14, 14, 3, 2, 1),     # stride 2 inside a bottleneck
+    (2, 32, 32, 28, 56, 3, 2, 1),     # stride-2 shortcut
+    (1, 16, 16, 224, 256, 1, 1, 1),   # pyramid lateral on the last stage (56 * 4 channels)
+    (2, 16, 16, 256, 180, 3, 1, 1),   # class subnet output, 9 anchors x 20 classes
+    (2, 8, 8, 256, 36, 3, 1, 1),      # box subnet output, 9 x 4
+    (2, 16, 16, 256, 256, 3, 2, 1),   # p6 / p7
+    (2, 16, 16, 64, 64, 4, 2, 1),     # 4x4 / stride 2: its dgrad is tf.layers.conv2d_transpose(4, 2, 'same') (CenterNet.py:349-361)
+]
+
+
 def _ref_conv(x_nhwc, w_krsc, b, stride, dil):
     y = R.conv2d_same(x_nhwc.permute(0, 3, 1, 2), w_krsc, b, stride, dil)
     return y.permute(0, 2, 3, 1).contiguous()
@@ -122,6 +142,12 @@ def test_conv_ssd300_layer_geometries_bf16(case, dev):
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_fwd_dgrad_wgrad(case, dt, dev):
+    _conv_case(case, dt, dev)
+
+
+@pytest.mark.parametrize("case", BACKBONE_CASES)
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_backbone_geometries(case, dt, dev):
     _conv_case(case, dt, dev)
 
 

@@ -518,7 +518,7 @@ class _Layers:
 
     @staticmethod
     def conv2d(inputs, filters, kernel_size, strides=1, padding='valid', name=None, data_format='channels_last', dilation_rate=1,
-               kernel_initializer=None):
+               kernel_initializer=None, bias_initializer=None):
         assert padding == 'same' and data_format == 'channels_last'
         filters = int(filters)                        # YOLOv3.py:487 passes filters/2, a float under true division
         if name is None:                              # default layer names count over the whole graph: conv2d, conv2d_1, ...
@@ -527,7 +527,7 @@ class _Layers:
         ci = inputs.shape[-1]
         with variable_scope(name):
             w = get_variable('kernel', initializer=_glorot_uniform((kernel_size, kernel_size, ci, filters), _Layers.gen))
-            b = get_variable('bias', shape=[filters])
+            b = get_variable('bias', shape=[filters], initializer=bias_initializer)
         return _conv_nhwc(inputs, w, strides, dilation_rate) + b
 
     bn_count = 0
@@ -664,6 +664,22 @@ def _resize_nearest_neighbor(images, size, align_corners=False):
     return images[:, iy][:, :, ix]
 
 
+def _resize_bilinear(images, size, align_corners=False):
+    """NHWC, TF-1.x grid (src = dst * in / out, no half-pixel centres); differentiable"""
+    assert not align_corners
+    n, h, w, c = images.shape
+    oh, ow = int(size[0]), int(size[1])
+    fy = torch.arange(oh, dtype=torch.float32) * (h / oh)
+    fx = torch.arange(ow, dtype=torch.float32) * (w / ow)
+    y0, x0 = torch.floor(fy).long(), torch.floor(fx).long()
+    y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
+    ly, lx = (fy - y0.float()).view(1, oh, 1, 1), (fx - x0.float()).view(1, 1, ow, 1)
+    top = images[:, y0][:, :, x0] * (1 - lx) + images[:, y0][:, :, x1] * lx
+    bot = images[:, y1][:, :, x0] * (1 - lx) + images[:, y1][:, :, x1] * lx
+    return top * (1 - ly) + bot * ly
+
+
+_Image.resize_bilinear = staticmethod(_resize_bilinear)
 _Image.resize_nearest_neighbor = staticmethod(_resize_nearest_neighbor)
 _Image.adjust_brightness = staticmethod(lambda images, delta: images + delta)
 _Image.adjust_contrast = staticmethod(_adjust_contrast)
@@ -789,11 +805,14 @@ class InteractiveSession:
         _Layers.bn_count = 0
         _Layers.conv_count = 0
         wants_update = 'train_op' in names
-        m._define_inputs()
+        # RetinaNet.py names its graph methods per task (:101, :137); every other class has _define_inputs / _build_graph
+        define = getattr(m, '_define_inputs', None) or m._define_detection_inputs
+        build = getattr(m, '_build_graph', None) or m._build_detection_graph
+        define()
         for k, val in overrides.items():      # e.g. test_one_image feeds self.images = placeholder - mean,
             old = getattr(m, k)               # i.e. the fed pixels BYPASS the mean subtraction
             setattr(m, k, wrap(_t(val, old.dtype).clone()))
-        m._build_graph()
+        build()
         out = []
         for n in names:
             v = getattr(m, n)

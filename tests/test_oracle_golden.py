@@ -323,3 +323,36 @@ def test_yolov3_two_training_steps_match_reference_class():
         want = g[key]
         err = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-9)
         assert err < (5e-2 if k.endswith(('.b', '.beta')) else 1e-2), (k, err)
+
+
+def test_retinanet_two_training_steps_match_reference_class():
+    """oracle/retinanet_net_ref (pre-activation bottleneck ResNet with the reference's 7 / 14 / 28 / 56 filters, pyramid, ten
+    subnets, focal + smooth-L1 loss, momentum) against two steps of the reference's own RetinaNet class run through its session on
+    the shim (tests/golden/retinanet_train.npz)"""
+    from oracle import retinanet_net_ref as NR
+    from oracle import retinanet_ref as RR
+    g = np.load(os.path.join(GOLD, 'retinanet_train.npz'))
+    assert len(NR.layer_specs()) == 122 == len(g['names'])
+    p = NR.init_params(31)
+    mom = {k: torch.zeros_like(v) for k, v in p.items() if k in NR.trainable_names(p)}
+    losses = []
+    after_first = None
+    for s in (500, 501):
+        gen = torch.Generator().manual_seed(s)
+        imgs = (torch.rand(2, 128, 128, 3, generator=gen) * 255).round()
+        gt = RR.synthetic_gt(2, 128, s + 10)
+        total, _, _ = NR.train_step(p, mom, imgs, gt, 0.01)
+        losses.append(total)
+        if after_first is None:
+            after_first = {k: v.detach().clone() for k, v in p.items()}
+    assert abs(losses[0] - g['losses'][0]) < 1e-4 * g['losses'][0], (losses, g['losses'])
+    assert abs(losses[1] - g['losses'][1]) < 2e-2 * g['losses'][1], (losses, g['losses'])
+    for key in g.files:
+        if key in ('losses', 'names'):
+            continue
+        k = key.replace('__', '.')
+        got = after_first[k].reshape(-1)                    # the fixture holds the parameters after the FIRST step
+        got = got[::max(1, got.numel() // 1024)].numpy()
+        want = g[key]
+        err = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-9)
+        assert err < (5e-2 if k.endswith(('.b', '.beta')) else 1e-2), (k, err)

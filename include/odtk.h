@@ -194,6 +194,14 @@ int odtk_resize_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, in
 int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
                              int accumulate, void* stream);
 
+/* conv rows <-> the f32 prediction tensors of the box-side kernels: tf.reshape + tf.concat over the pyramid levels
+ * (RetinaNet.py:184-186, :321-326).  Row m of image n = m / rows_per_img is read / written at
+ * y + n * y_img_stride + (m % rows_per_img) * ldy (floats); x is [M][ldx] in `dtype`; _from_f32 zeroes x's pad columns. */
+int odtk_rows_to_f32(const void* x, int ldx, int dtype, float* y, int ldy, int rows_per_img, long long y_img_stride, long long M, int C,
+                     void* stream);
+int odtk_rows_from_f32(const float* y, int ldy, int rows_per_img, long long y_img_stride, void* x, int ldx, int dtype, long long M, int C,
+                       void* stream);
+
 /* tf.nn.l2_normalize(axis=C) * scalar gamma (SSD300.py:74-83). */
 int odtk_l2norm_fwd(const void* x, void* y, int M, int C, int ld, int dtype, const float* gamma,
                     void* stream);

@@ -9,7 +9,7 @@ reached through the C-ABI in ``include/odtk.h`` (``libodtk.so``).
 from . import _lib                      # noqa: F401
 from ._lib import BF16, F32, OdtkError  # noqa: F401
 
-__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3"]
+__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet"]
 
 
 def __getattr__(name):
@@ -19,4 +19,7 @@ def __getattr__(name):
     if name == "YOLOv3":
         from .yolov3 import YOLOv3
         return YOLOv3
+    if name == "RetinaNet":
+        from .retinanet import RetinaNet
+        return RetinaNet
     raise AttributeError(name)

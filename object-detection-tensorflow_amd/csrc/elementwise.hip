@@ -1429,3 +1429,55 @@ extern "C" int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int 
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv rows <-> the f32 prediction tensors of the box-side kernels: a subnet's last convolution leaves [N*H*W][ld] rows in the
+// compute dtype, the loss / decode kernels read pconf [N][A][classes] / pbbox [N][A][4] with all levels of one image back to back
+// (RetinaNet.py:184-186, :321-326).  Row m of image n = m / rows_per_img lands at y + n * y_img_stride + (m % rows_per_img) * ldy.
+namespace odtk {
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256) rows_to_f32_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int rows_per_img,
+                                                          long long y_img_stride, long long M, int C) {
+    const long long total = M * C, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long m = i / C;
+        const int c = (int)(i - m * C);
+        const long long n = m / rows_per_img;
+        y[n * y_img_stride + (m - n * rows_per_img) * ldy + c] = elem<T>::load(x[m * ldx + c]);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) rows_from_f32_kernel(const float* __restrict__ y, int ldy, int rows_per_img, long long y_img_stride,
+                                                            T* __restrict__ x, int ldx, long long M, int C) {
+    const long long total = M * ldx, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long m = i / ldx;
+        const int c = (int)(i - m * ldx);
+        const long long n = m / rows_per_img;
+        x[i] = elem<T>::store(c < C ? y[n * y_img_stride + (m - n * rows_per_img) * ldy + c] : 0.f);      // pad columns zeroed
+    }
+}
+
+}  // namespace
+}  // namespace odtk
+
+extern "C" int odtk_rows_to_f32(const void* x, int ldx, int dtype, float* y, int ldy, int rows_per_img, long long y_img_stride, long long M,
+                                int C, void* stream) {
+    ODTK_REQUIRE(x && y && M > 0 && C > 0 && ldx >= C && ldy >= C && rows_per_img > 0, "rows_to_f32: bad argument");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(rows_to_f32_kernel<T>, dim3(grid_for(M * C, 256, 65536)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                           ldx, y, ldy, rows_per_img, y_img_stride, M, C);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_rows_from_f32(const float* y, int ldy, int rows_per_img, long long y_img_stride, void* x, int ldx, int dtype, long long M,
+                                  int C, void* stream) {
+    ODTK_REQUIRE(x && y && M > 0 && C > 0 && ldx >= C && ldy >= C && rows_per_img > 0, "rows_from_f32: bad argument");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(rows_from_f32_kernel<T>, dim3(grid_for(M * ldx, 256, 65536)), dim3(256), 0, (hipStream_t)stream, y, ldy,
+                                           rows_per_img, y_img_stride, (T*)x, ldx, M, C);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

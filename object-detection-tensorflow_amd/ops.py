@@ -212,6 +212,15 @@ def resize_bilinear_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, accumulate=Fals
     call("odtk_resize_bilinear_bwd", _p(dy), int(lddy), _p(dx), int(lddx), N, H, W, Ho, Wo, int(C_), dt_of(dy), int(accumulate), _stream())
 
 
+def rows_to_f32(x, ldx, y, ldy, rows_per_img, y_img_stride, M, C_):
+    """conv rows [M][ldx] -> f32 prediction tensor (row m of image m // rows_per_img at y + n * y_img_stride + (m % rows_per_img) * ldy)"""
+    call("odtk_rows_to_f32", _p(x), int(ldx), dt_of(x), _p(y), int(ldy), int(rows_per_img), int(y_img_stride), int(M), int(C_), _stream())
+
+
+def rows_from_f32(y, ldy, rows_per_img, y_img_stride, x, ldx, M, C_):
+    call("odtk_rows_from_f32", _p(y), int(ldy), int(rows_per_img), int(y_img_stride), _p(x), int(ldx), dt_of(x), int(M), int(C_), _stream())
+
+
 def l2norm_fwd(x, y, M, C_, ld, gamma):
     call("odtk_l2norm_fwd", _p(x), _p(y), M, C_, ld, dt_of(x), _p(gamma), _stream())
 

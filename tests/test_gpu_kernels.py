@@ -66,6 +66,11 @@ BACKBONE_CASES = [
     (2, 8, 8, 256, 36, 3, 1, 1),      # box subnet output, 9 x 4
     (2, 16, 16, 256, 256, 3, 2, 1),   # p6 / p7
     (2, 16, 16, 64, 64, 4, 2, 1),     # 4x4 / stride 2: its dgrad is tf.layers.conv2d_transpose(4, 2, 'same') (CenterNet.py:349-361)
+    (2, 2, 2, 256, 36, 3, 1, 1),      # the coarsest pyramid levels at small inputs: 8 and 18 rows in all
+    (2, 2, 2, 256, 189, 3, 1, 1),
+    (2, 3, 3, 256, 256, 3, 2, 1),     # p7 from a 3 x 3 p6
+    (2, 3, 3, 256, 256, 3, 1, 1),
+    (1, 1, 1, 256, 256, 3, 1, 1),     # one pixel
 ]
 
 

@@ -131,3 +131,24 @@ def test_augmentor_plan_matches_oracle_plan():
             for k in ('brightness', 'contrast', 'hue'):
                 assert (ref[k] is not None) == bool(mine['has_' + k]) and (ref[k] is None or ref[k] == mine[k])
             assert (ref['angle'] is not None) == bool(mine['has_rotate']) and (ref['angle'] is None or ref['angle'] == mine['angle'])
+
+
+def test_retinanet_layer_specs_and_priors_match_oracle_and_reference_graph():
+    """odtk.retinanet.layer_specs / level_priors (host logic) against the oracle's and against the variables of the reference's own
+    class (tests/golden/retinanet_variables.json: 122 kernels with these shapes, in this order)"""
+    import json
+    import os
+    from odtk import retinanet as R
+    from oracle import retinanet_net_ref as NR
+    from oracle import retinanet_ref as RR
+    specs = R.layer_specs([3, 4, 6, 3], 16, 21, 9)
+    assert specs == NR.layer_specs()
+    for s in RR.ANCHOR_SIZES:
+        assert [tuple(map(float, v)) for v in R.level_priors(s)] == [tuple(map(float, v)) for v in RR.level_priors(s)]
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'retinanet_variables.json')))
+    kernels = sorted((k for k in want if k.endswith('/kernel')), key=lambda k: int((k.split('conv2d')[1].split('/')[0] or '_0')[1:]))
+    gammas = sorted((k for k in want if k.endswith('/gamma')), key=lambda k: int((k.split('batch_normalization')[1].split('/')[0] or '_0')[1:]))
+    assert len(kernels) == len(gammas) == len(specs) == 122
+    for (name, cin, cout, k, _, bnc, _), kn, gn in zip(specs, kernels, gammas):
+        assert want[kn]['shape'] == [k, k, cin, cout], (name, kn)
+        assert want[gn]['shape'] == [bnc], (name, gn)

@@ -162,3 +162,56 @@ def test_sync_bn_two_ranks_equal_one_device_on_the_global_batch(tmp_path, dev, m
     assert float((a['S'] - m.S.cpu()).norm()) < 1e-5 * float(m.S.cpu().norm()), 'moving statistics'
     # the loss a rank reports is the mean over ITS images / world ... both use the global divisor: the two ranks' data terms add up
     assert loss == loss and a['loss'] == a['loss']
+
+
+def _retina_cfg(batch, size):
+    return {'is_bottleneck': True, 'residual_block_list': [3, 4, 6, 3], 'init_conv_filters': 16, 'mode': 'train', 'is_pretraining': False,
+            'data_shape': [size, size, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'data_format': 'channels_last', 'batch_size': batch,
+            'gamma': 2.0, 'alpha': 0.25, 'nms_score_threshold': 0.8, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False,
+            'compute_dtype': 'f32', 'seed': 5}
+
+
+def _retina_batch(rank, batch, size):
+    from oracle import retinanet_ref as RR
+    g = torch.Generator().manual_seed(700 + rank)
+    return (torch.rand(batch, size, size, 3, generator=g) * 255).round(), RR.synthetic_gt(batch, size, 750 + rank)
+
+
+def _retina_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import odtk
+    B, size = 2, 128
+    m = odtk.RetinaNet(_retina_cfg(B, size), {'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+    red = m.attach_data_parallel(bucket_mb=2)
+    m.set_batch(*_retina_batch(rank, B, size))
+    loss = float(m.train_step(0.002))
+    torch.cuda.synchronize()
+    torch.save({'P': m.P.cpu(), 'G': m.G.cpu(), 'loss': loss, 'buckets': len(red.red.buckets)}, os.path.join(out_dir, f'q{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_retinanet_two_ranks_one_gpu(tmp_path, dev):
+    """RetinaNet data parallel: the bucketed all-reduce hooked on the layer order l121 .. l0 leaves both replicas bit-identical, and
+    what it exchanged is the sum of the replicas' local gradients (loss divided by the GLOBAL batch)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_retina_worker, args=(2, 29690, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(os.path.join(tmp_path, 'q0.pt')), torch.load(os.path.join(tmp_path, 'q1.pt'))
+    assert torch.equal(a['P'], b['P']) and torch.equal(a['G'], b['G'])
+    assert a['buckets'] > 1 and a['loss'] == a['loss'] and b['loss'] == b['loss']
+    import odtk
+    B, size = 2, 128
+    total = None
+    for rank in range(2):
+        m = odtk.RetinaNet(_retina_cfg(B, size), {'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+        m.set_batch(*_retina_batch(rank, B, size))
+        m.G.zero_(); m._forward(True); m._loss(1.0 / (2 * B))
+        for _ in m._backward_iter():
+            pass
+        total = m.G.clone() if total is None else total + m.G
+    torch.cuda.synchronize()
+    g = a['G'].to(total.device)
+    assert float((g - total).norm()) < 1e-4 * float(total.norm())

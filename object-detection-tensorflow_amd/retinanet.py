@@ -521,17 +521,72 @@ class RetinaNet:
         return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
 
     # ------------------------------------------------------------------ checkpoints / data parallel
+    def _logical(self, name, buf):
+        v = self.get_param(name, buf)
+        return np.ascontiguousarray((v.permute(1, 2, 3, 0) if name.endswith('.w') else v).numpy())
+
+    def export_tf_variables(self):
+        """what the reference's detection `tf.train.Saver()` (RetinaNet.py:553-557) writes: every variable of the graph under its name
+        (reference_variable_map), global_step, and the momentum slots, created inside the 'inference' scope (:172, :206)"""
+        out = OrderedDict()
+        for tfname, ours in reference_variable_map(self.block_list).items():
+            if ours in self.pinfo:
+                out[tfname] = self._logical(ours, self.P)
+                out[f'inference/{tfname}/Momentum'] = self._logical(ours, self.Mom)
+            else:
+                out[tfname] = self.stat(ours).detach().cpu().numpy().copy()
+        out['global_step'] = np.asarray(self.global_step, dtype=np.int32)
+        return out
+
+    def load_tf_checkpoint(self, path, backbone_only=False):
+        from .tf_checkpoint import NewCheckpointReader
+        reader = NewCheckpointReader(str(path))
+        names = reader.get_variable_to_shape_map()
+        nb = 1 + 4 * sum(self.block_list)
+        for tfname, ours in reference_variable_map(self.block_list).items():
+            if backbone_only and int(ours[1:].split('.')[0]) >= nb:
+                continue
+            v = torch.from_numpy(reader.get_tensor(tfname))
+            if ours in self.sinfo:
+                self.stat(ours).copy_(v.to(self.dev))
+                continue
+            self.set_param(ours, v.permute(3, 0, 1, 2).contiguous() if ours.endswith('.w') else v)
+            slot = [k for k in names if k.endswith(tfname + '/Momentum')]
+            if slot and not backbone_only:
+                mv = torch.from_numpy(reader.get_tensor(slot[0]))
+                dst = self.param(ours, self.Mom)
+                if ours.endswith('.w'):
+                    dst.zero_()
+                    dst[..., : mv.shape[2]] = mv.permute(3, 0, 1, 2).to(self.dev)
+                else:
+                    dst.copy_(mv.to(self.dev).view(dst.shape))
+        if not backbone_only and reader.has_tensor('global_step'):
+            self.global_step = int(reader.get_tensor('global_step'))
+        self._refresh_operand_copies()
+
     def save_weight(self, mode, path):
+        """RetinaNet.py:521-531.  config['checkpoint_format'] = 'tf' writes tf.train.Saver files (tf_checkpoint.py)."""
         assert (mode in ['latest', 'best'])
         dirname = os.path.dirname(path)
         if dirname and not os.path.exists(dirname):
             os.makedirs(dirname)
             print(dirname, 'does not exist, create it done')
+        if self.config.get('checkpoint_format', 'torch') == 'tf':
+            from . import tf_checkpoint
+            prefix = path + '-' + str(self.global_step)
+            tf_checkpoint.write_bundle(prefix, self.export_tf_variables())
+            tf_checkpoint.update_checkpoint_state(prefix)
+            print('save', mode, 'model in', path, 'successfully')
+            return
         blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': dict(self.pinfo)}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
     def load_weight(self, path):
+        if os.path.exists(str(path) + '.index'):                 # a tf.train.Saver checkpoint prefix
+            self.load_tf_checkpoint(path)
+            print('load weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=False)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
@@ -542,6 +597,10 @@ class RetinaNet:
     def load_pretraining_weight(self, path):
         """RetinaNet.py:537-539 restores the 'feature_extractor' variables saved by the pre-training graph: here the backbone layers
         (stem + units) of a saved file"""
+        if os.path.exists(str(path) + '.index'):
+            self.load_tf_checkpoint(path, backbone_only=True)
+            print('load pretraining weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=False)['params']
         nb = 1 + 4 * sum(self.block_list)
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < nb})
@@ -552,3 +611,24 @@ class RetinaNet:
         self.dist = GradAllReducer(self, group, bucket_mb)
         self.loss_divisor_batch = self.batch_size * self.dist.world
         return self.dist
+
+
+def reference_variable_map(block_list=(3, 4, 6, 3)):
+    """name of every variable of the reference's detection graph -> our parameter / statistic name.  tf.layers default layer names
+    count over the whole graph (conv2d ... conv2d_121, batch_normalization ... _121); scopes: 'feature_extractor' for the stem and the
+    pyramid, 'feature_extractor/block<b>_unit<u>/conv_branch|identity_branch' for the units (RetinaNet.py:621-643), 'regressor' for the
+    subnets (:145).  Pinned by tests/golden/retinanet_variables.json (collected from the reference's own class)."""
+    scopes = ['feature_extractor']
+    for b, blocks in enumerate(block_list):
+        for u in range(blocks):
+            base = f'feature_extractor/block{b + 1}_unit{u + 1}'
+            scopes += [base + '/conv_branch'] * 3 + [base + '/identity_branch']
+    scopes += ['feature_extractor'] * 7 + ['regressor'] * 50
+    m = OrderedDict()
+    for i, scope in enumerate(scopes):
+        sfx = '' if i == 0 else f'_{i}'
+        m[f'{scope}/conv2d{sfx}/kernel'], m[f'{scope}/conv2d{sfx}/bias'] = f'l{i}.w', f'l{i}.b'
+        bn = f'{scope}/batch_normalization{sfx}'
+        m[bn + '/gamma'], m[bn + '/beta'] = f'l{i}.gamma', f'l{i}.beta'
+        m[bn + '/moving_mean'], m[bn + '/moving_variance'] = f'l{i}.mmean', f'l{i}.mvar'
+    return m

@@ -155,3 +155,32 @@ def test_bf16_step_and_class_surface(dev, tmp_path):
     assert all(torch.equal(a[k], b[k]) for k in a)
     out = m2.test_one_image(batches[0][0][:1].numpy())
     assert len(out) == 3 and out[1].shape[1] == 4
+
+
+def test_tf_saver_checkpoint_roundtrip(dev, tmp_path):
+    """checkpoint_format='tf': tf.train.Saver files under the reference's 733 variable names (tests/golden/retinanet_variables.json) with
+    momentum slots, and back; load_pretraining_weight restores the backbone only"""
+    import json
+    import os
+    from odtk import tf_checkpoint as T
+    batches = [_batch(2, 128, 120)]
+    m = _model('train', 'f32', 2, 128, _provider(batches), checkpoint_format='tf', seed=1)
+    m.train_one_epoch(0.001)
+    path = str(tmp_path / 'ck' / 'retina.ckpt')
+    m.save_weight('latest', path)
+    r = T.NewCheckpointReader(path + '-1')
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'retinanet_variables.json')))
+    shapes = r.get_variable_to_shape_map()
+    for name, info in want.items():
+        assert shapes[name] == info['shape'], name
+        assert (f'inference/{name}/Momentum' in shapes) == info['trainable'], name
+    m2 = _model('train', 'f32', 2, 128, _provider(batches), seed=2)
+    m2.load_weight(path + '-1')
+    a, b = m.export_params(), m2.export_params()
+    assert all(torch.equal(a[k], b[k]) for k in a) and torch.equal(m.Mom, m2.Mom) and m2.global_step == 1
+    m3 = _model('train', 'f32', 2, 128, _provider(batches), seed=3)
+    before = m3.export_params()
+    m3.load_pretraining_weight(path + '-1')
+    c = m3.export_params()
+    for k in a:
+        assert torch.equal(c[k], a[k] if int(k[1:].split('.')[0]) < 65 else before[k]), k

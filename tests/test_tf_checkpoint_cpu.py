@@ -174,3 +174,20 @@ def test_yolov3_variable_map_matches_reference_graph():
     from oracle import yolov3_net_ref as NR
     assert [s[:5] for s in layer_specs(20, 3)] == [s[:5] for s in NR.layer_specs(20, 3)]
     assert [bool(s[5]) for s in layer_specs(20, 3)] == [s[5] is not None for s in NR.layer_specs(20, 3)]
+
+
+def test_retinanet_variable_map_matches_reference_graph():
+    """odtk.retinanet.reference_variable_map against the 733 variables the reference's own RetinaNet class creates
+    (tests/golden/retinanet_variables.json, tests/golden/make_golden_retinanet_net.py), shapes and trainable flags included"""
+    import json
+    from odtk.retinanet import layer_specs, reference_variable_map
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'retinanet_variables.json')))
+    m = reference_variable_map()
+    assert set(m) | {'global_step'} == set(want) and len(m) == 732
+    specs = {s[0]: s for s in layer_specs([3, 4, 6, 3], 16, 21, 9)}
+    for name, ours in m.items():
+        layer, kind = ours.split('.')
+        _, cin, cout, k, _, bnc, _ = specs[layer]
+        shape = [k, k, cin, cout] if kind == 'w' else ([cout] if kind == 'b' else [bnc])
+        assert want[name]['shape'] == shape, name
+        assert want[name]['trainable'] == (kind not in ('mmean', 'mvar')), name

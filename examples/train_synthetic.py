@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The reference's driver flow (testSSD300.py / testYOLOv3.py: config dict -> data provider -> model -> train_one_epoch ->
 save_weight -> test_one_image) on synthetic VOC-shaped pictures, with the GPU augmentor in front of the model.
-Needs an MI355X:   python examples/train_synthetic.py [ssd300|yolov3] [epochs]
+Needs an MI355X:   python examples/train_synthetic.py [ssd300|yolov3|retinanet] [epochs]
 
 What changes for a user of the reference:
     import SSD300 as net; model = net.SSD300(config, data_provider)        ->   from odtk import SSD300
@@ -20,7 +20,7 @@ from odtk.augment import Augmentor            # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'ssd300'
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-size = 300 if which == 'ssd300' else 416
+size = {'ssd300': 300, 'yolov3': 416, 'retinanet': 512}[which]
 batch_size = 8
 dev = torch.device('cuda:0')
 
@@ -54,6 +54,12 @@ if which == 'ssd300':
     config = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': batch_size,
               'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': './vgg_16.ckpt'}   # testSSD300.py:15-32
     model = odtk.SSD300(config, data_provider)
+elif which == 'retinanet':
+    config = {'is_bottleneck': True, 'residual_block_list': [3, 4, 6, 3], 'init_conv_filters': 16, 'mode': 'train', 'is_pretraining': False,
+              'data_shape': [size, size, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'data_format': 'channels_last',
+              'batch_size': batch_size, 'gamma': 2.0, 'alpha': 0.25, 'nms_score_threshold': 0.8, 'nms_max_boxes': 10,
+              'nms_iou_threshold': 0.45}                                                                # testretinanet.py:22-41
+    model = odtk.RetinaNet(config, data_provider)
 else:
     config = {'mode': 'train', 'data_shape': [size, size, 3], 'num_classes': 20, 'weight_decay': 5e-4, 'keep_prob': 0.5, 'data_format': 'channels_last',
               'batch_size': batch_size, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'num_priors': 3,

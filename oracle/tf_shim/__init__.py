@@ -363,6 +363,9 @@ def group(*args, **kw):
 
 
 # ---------------------------------------------------------------------------- variables / scopes
+AUTO_REUSE = 'auto_reuse'          # tf.AUTO_REUSE: accepted by variable_scope, variables are looked up by name anyway
+
+
 class variable_scope:
     def __init__(self, name, *a, **k):
         self.name = name
@@ -717,7 +720,27 @@ class _ContribFramework:
         return torch.sort(x).values
 
 
-contrib = types.SimpleNamespace(framework=_ContribFramework(), layers=types.SimpleNamespace(variance_scaling_initializer=lambda *a, **k: None),
+def _group_norm(inputs, groups=32, channels_axis=-1, reduction_axes=(-3, -2), trainable=True, epsilon=1e-6):
+    """tf.contrib.layers.group_norm on NHWC: per sample and group, moments over H, W and the group's channels; gamma / beta [C] under
+    variable_scope(None, 'GroupNorm'), whose default name is made unique WITHIN the enclosing scope (GroupNorm, GroupNorm_1, ...)"""
+    assert channels_axis in (3, -1) and tuple(reduction_axes) in ((1, 2), (-3, -2))
+    n, h, w, c = inputs.shape
+    key = '/'.join(S.scope)
+    idx = _GN_COUNT.get(key, 0)
+    _GN_COUNT[key] = idx + 1
+    with variable_scope('GroupNorm' if idx == 0 else f'GroupNorm_{idx}'):
+        beta = get_variable('beta', initializer=torch.zeros(c))
+        gamma = get_variable('gamma', initializer=torch.ones(c))
+    x = inputs.reshape(n, h, w, groups, c // groups)
+    mean = x.mean(dim=(1, 2, 4), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(1, 2, 4), keepdim=True)
+    gain = torch.rsqrt(var + epsilon)
+    y = ((x - mean) * gain).reshape(n, h, w, c)
+    return y * gamma + beta
+
+
+_GN_COUNT = {}
+contrib = types.SimpleNamespace(framework=_ContribFramework(), layers=types.SimpleNamespace(variance_scaling_initializer=lambda *a, **k: None, group_norm=_group_norm),
                                image=types.SimpleNamespace(rotate=_contrib_rotate))
 random = types.SimpleNamespace(uniform=random_uniform)
 
@@ -804,6 +827,7 @@ class InteractiveSession:
         S.pending = []
         _Layers.bn_count = 0
         _Layers.conv_count = 0
+        _GN_COUNT.clear()
         wants_update = 'train_op' in names
         # RetinaNet.py names its graph methods per task (:101, :137); every other class has _define_inputs / _build_graph
         define = getattr(m, '_define_inputs', None) or m._define_detection_inputs
@@ -831,6 +855,7 @@ def install(vgg_tensors=None):
     reset()
     _Layers.bn_count = 0
     _Layers.conv_count = 0
+    _GN_COUNT.clear()
     tf = types.ModuleType('tensorflow')
     me = sys.modules[__name__]
     for k in dir(me):

@@ -356,3 +356,34 @@ def test_retinanet_two_training_steps_match_reference_class():
         want = g[key]
         err = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-9)
         assert err < (5e-2 if k.endswith(('.b', '.beta')) else 1e-2), (k, err)
+
+
+def test_fcos_two_training_steps_match_reference_class():
+    """oracle/fcos_net_ref (group-normalised pre-activation bottleneck ResNet, pyramid, per-level heads with centre-ness, Momentum)
+    against two steps of the reference's own FCOS class run through its session on the shim (tests/golden/fcos_train.npz)"""
+    from oracle import fcos_net_ref as NR
+    from oracle import fcos_ref as FR
+    g = np.load(os.path.join(GOLD, 'fcos_train.npz'))
+    assert len(NR.layer_specs()) == 130 == len(g['names'])
+    p = NR.init_params(41)
+    mom = {k: torch.zeros_like(v) for k, v in p.items()}
+    losses, after_first = [], None
+    for s in (600, 601):
+        gen = torch.Generator().manual_seed(s)
+        imgs = (torch.rand(2, 128, 160, 3, generator=gen) * 255).round()
+        gt = FR.synthetic_gt(2, 128, s + 10)
+        total, _, _ = NR.train_step(p, mom, imgs, gt, 0.001)
+        losses.append(total)
+        if after_first is None:
+            after_first = {k: v.detach().clone() for k, v in p.items()}
+    assert abs(losses[0] - g['losses'][0]) < 1e-4 * g['losses'][0], (losses, g['losses'])
+    assert abs(losses[1] - g['losses'][1]) < 2e-2 * g['losses'][1], (losses, g['losses'])
+    for key in g.files:
+        if key in ('losses', 'names', 'gn_names'):
+            continue
+        k = key.replace('__', '.')
+        got = after_first[k].reshape(-1)
+        got = got[::max(1, got.numel() // 1024)].numpy()
+        want = g[key]
+        err = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-9)
+        assert err < 1e-3, (k, err)

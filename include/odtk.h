@@ -194,6 +194,17 @@ int odtk_resize_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, in
 int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
                              int accumulate, void* stream);
 
+/* tf.contrib.layers.group_norm(groups, epsilon 1e-6) (+ ReLU when relu != 0) on NHWC rows [N*HW][ld]: the normalisation of the
+ * reference's FCOS (FCOS.py:438-446).  Statistics per sample and group over HW x (C / groups) elements; save_mean_rstd [N][groups][2]
+ * (may be NULL in inference).  Backward: dx (accumulate != 0 adds to it), dgamma / dbeta [C] overwritten; the ReLU mask comes from the
+ * sign of y.  workspace: odtk_gn_workspace_bytes(N, C). */
+long long odtk_gn_workspace_bytes(int N, int C);
+int odtk_gn_fwd(const void* x, int ldx, void* y, int ldy, int N, int HW, int C, int groups, int dtype, const float* gamma,
+                const float* beta, int relu, float* save_mean_rstd, void* stream);
+int odtk_gn_bwd(const void* x, int ldx, const void* y, const void* dy, int ldy, void* dx, int lddx, int N, int HW, int C, int groups,
+                int dtype, const float* gamma, const float* save_mean_rstd, int relu, int accumulate, float* dgamma, float* dbeta,
+                void* workspace, void* stream);
+
 /* conv rows <-> the f32 prediction tensors of the box-side kernels: tf.reshape + tf.concat over the pyramid levels
  * (RetinaNet.py:184-186, :321-326).  Row m of image n = m / rows_per_img is read / written at
  * y + n * y_img_stride + (m % rows_per_img) * ldy (floats); x is [M][ldx] in `dtype`; _from_f32 zeroes x's pad columns. */

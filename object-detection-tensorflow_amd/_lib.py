@@ -64,6 +64,9 @@ SIGNATURES = {
     "odtk_resize_bilinear_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "odtk_rows_to_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _ll, _ll, _i, _vp]),
     "odtk_rows_from_f32": (_i, [_vp, _i, _i, _ll, _vp, _i, _i, _ll, _i, _vp]),
+    "odtk_gn_workspace_bytes": (_ll, [_i, _i]),
+    "odtk_gn_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "odtk_gn_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "odtk_add2d": (_i, [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _i, _vp]),
     "odtk_upsample2x_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "odtk_upsample2x_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

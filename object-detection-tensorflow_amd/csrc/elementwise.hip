@@ -1481,3 +1481,157 @@ extern "C" int odtk_rows_from_f32(const float* y, int ldy, int rows_per_img, lon
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// tf.contrib.layers.group_norm(groups, epsilon 1e-6) (+ ReLU) on NHWC rows, forward and backward: the normalisation of the reference's
+// FCOS (FCOS.py:438-446: EVERY norm of that model).  Statistics are per SAMPLE and group over H x W x (C / groups) elements, so one
+// workgroup owns one (sample, group): it reduces, then applies -- no partial sums, no second launch; the rows it re-reads come from L2.
+// Backward: the same ownership for dx; dgamma / dbeta need a sum over the samples, taken in a fixed order from per-sample partials.
+namespace odtk {
+namespace {
+
+constexpr int GN_THREADS = 256;
+
+__device__ __forceinline__ float gn_block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < GN_THREADS / 64; ++w) t += red[w];
+    return t;
+}
+
+// grid (groups, N).  x, y [N*HW][ld]; save [N][groups][2] = mean, rstd
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS) gn_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int HW, int C, int groups,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                            float* __restrict__ save) {
+    __shared__ float red[GN_THREADS / 64];
+    const int g = blockIdx.x, n = blockIdx.y, cg = C / groups, c0 = g * cg;
+    const long long row0 = (long long)n * HW;
+    const int total = HW * cg;
+    const float shift = elem<T>::load(x[row0 * ldx + c0]);               // sums about the first element: no cancellation for large means
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < total; i += GN_THREADS) {
+        const int r = i / cg, c = i - r * cg;
+        const float d = elem<T>::load(x[(row0 + r) * ldx + c0 + c]) - shift;
+        s1 += d; s2 += d * d;
+    }
+    s1 = gn_block_sum(s1, red);
+    s2 = gn_block_sum(s2, red);
+    const float dm = s1 / (float)total;
+    const float mean = shift + dm, var = fmaxf(s2 / (float)total - dm * dm, 0.f);
+    const float rstd = rsqrtf(var + 1e-6f);
+    if (threadIdx.x == 0 && save) { save[((size_t)n * groups + g) * 2] = mean; save[((size_t)n * groups + g) * 2 + 1] = rstd; }
+    for (int i = threadIdx.x; i < total; i += GN_THREADS) {
+        const int r = i / cg, c = i - r * cg;
+        float v = (elem<T>::load(x[(row0 + r) * ldx + c0 + c]) - mean) * rstd * gamma[c0 + c] + beta[c0 + c];
+        if (relu) v = fmaxf(v, 0.f);
+        y[(row0 + r) * ldy + c0 + c] = elem<T>::store(v);
+    }
+}
+
+// grid (groups, N).  dx [N*HW][lddx] (accumulate: dx += ...); part [N][2][C] = this sample's dgamma, dbeta contributions
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS) gn_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y, const T* __restrict__ dy, int ldy,
+                                                            T* __restrict__ dx, int lddx, int HW, int C, int groups,
+                                                            const float* __restrict__ gamma, const float* __restrict__ save, int relu,
+                                                            int accumulate, float* __restrict__ part) {
+    __shared__ float red[GN_THREADS / 64];
+    const int g = blockIdx.x, n = blockIdx.y, cg = C / groups, c0 = g * cg;
+    const long long row0 = (long long)n * HW;
+    const int total = HW * cg;
+    const float mean = save[((size_t)n * groups + g) * 2], rstd = save[((size_t)n * groups + g) * 2 + 1];
+    // per-channel sums (dgamma, dbeta of this sample): thread t owns channel t % cg of rows t / cg, t / cg + rows_per_pass, ...
+    float a1 = 0.f, a2 = 0.f;                                            // group sums of dy' * gamma and dy' * gamma * xhat
+    float sg = 0.f, sb = 0.f;                                            // this thread's share of dgamma / dbeta (fast path below)
+    const bool fixed_channel = GN_THREADS % cg == 0;                     // then thread t only ever sees channel t % cg
+    for (int i = threadIdx.x; i < total; i += GN_THREADS) {
+        const int r = i / cg, c = i - r * cg;
+        float d = elem<T>::load(dy[(row0 + r) * ldy + c0 + c]);
+        if (relu && !(elem<T>::load(y[(row0 + r) * ldy + c0 + c]) > 0.f)) d = 0.f;
+        const float xh = (elem<T>::load(x[(row0 + r) * ldx + c0 + c]) - mean) * rstd;
+        const float dg = d * gamma[c0 + c];
+        a1 += dg; a2 += dg * xh;
+        sg += d * xh; sb += d;
+    }
+    a1 = gn_block_sum(a1, red);
+    a2 = gn_block_sum(a2, red);
+    const float m1 = a1 / (float)total, m2 = a2 / (float)total;
+    for (int i = threadIdx.x; i < total; i += GN_THREADS) {
+        const int r = i / cg, c = i - r * cg;
+        float d = elem<T>::load(dy[(row0 + r) * ldy + c0 + c]);
+        if (relu && !(elem<T>::load(y[(row0 + r) * ldy + c0 + c]) > 0.f)) d = 0.f;
+        const float xh = (elem<T>::load(x[(row0 + r) * ldx + c0 + c]) - mean) * rstd;
+        float v = rstd * (d * gamma[c0 + c] - m1 - xh * m2);
+        T* o = dx + (row0 + r) * lddx + c0 + c;
+        if (accumulate) v += elem<T>::load(*o);
+        *o = elem<T>::store(v);
+    }
+    // dgamma / dbeta partials of this sample
+    if (fixed_channel) {                                                 // fold the threads that share a channel, in thread order
+        __shared__ float s_g[GN_THREADS], s_b[GN_THREADS];
+        s_g[threadIdx.x] = sg; s_b[threadIdx.x] = sb;
+        __syncthreads();
+        if ((int)threadIdx.x < cg) {
+            float tg = 0.f, tb = 0.f;
+            for (int j = threadIdx.x; j < GN_THREADS; j += cg) { tg += s_g[j]; tb += s_b[j]; }
+            part[((size_t)n * 2 + 0) * C + c0 + threadIdx.x] = tg;
+            part[((size_t)n * 2 + 1) * C + c0 + threadIdx.x] = tb;
+        }
+        return;
+    }
+    for (int c = threadIdx.x; c < cg; c += GN_THREADS) {                 // general case: one thread per channel walks the rows
+        float sg = 0.f, sb = 0.f;
+        for (int r = 0; r < HW; ++r) {
+            float d = elem<T>::load(dy[(row0 + r) * ldy + c0 + c]);
+            if (relu && !(elem<T>::load(y[(row0 + r) * ldy + c0 + c]) > 0.f)) d = 0.f;
+            sg += d * (elem<T>::load(x[(row0 + r) * ldx + c0 + c]) - mean) * rstd;
+            sb += d;
+        }
+        part[((size_t)n * 2 + 0) * C + c0 + c] = sg;
+        part[((size_t)n * 2 + 1) * C + c0 + c] = sb;
+    }
+}
+
+__global__ void gn_param_grad_kernel(const float* __restrict__ part, int N, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sg = 0.f, sb = 0.f;
+    for (int n = 0; n < N; ++n) { sg += part[((size_t)n * 2 + 0) * C + c]; sb += part[((size_t)n * 2 + 1) * C + c]; }
+    dgamma[c] = sg;
+    dbeta[c] = sb;
+}
+
+}  // namespace
+}  // namespace odtk
+
+extern "C" long long odtk_gn_workspace_bytes(int N, int C) { return (long long)N * 2 * C * sizeof(float); }
+
+extern "C" int odtk_gn_fwd(const void* x, int ldx, void* y, int ldy, int N, int HW, int C, int groups, int dtype, const float* gamma,
+                           const float* beta, int relu, float* save_mean_rstd, void* stream) {
+    ODTK_REQUIRE(x && y && gamma && beta, "gn_fwd: null pointer");
+    ODTK_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && ldx >= C && ldy >= C, "gn_fwd: N=%d HW=%d C=%d groups=%d", N, HW, C, groups);
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(gn_fwd_kernel<T>, dim3(groups, N), dim3(GN_THREADS), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, HW, C,
+                                           groups, gamma, beta, relu, save_mean_rstd);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_gn_bwd(const void* x, int ldx, const void* y, const void* dy, int ldy, void* dx, int lddx, int N, int HW, int C, int groups,
+                           int dtype, const float* gamma, const float* save_mean_rstd, int relu, int accumulate, float* dgamma, float* dbeta,
+                           void* workspace, void* stream) {
+    ODTK_REQUIRE(x && dy && dx && gamma && save_mean_rstd && dgamma && dbeta && workspace, "gn_bwd: null pointer");
+    ODTK_REQUIRE(!relu || y, "gn_bwd: relu needs y");
+    ODTK_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && ldx >= C && ldy >= C && lddx >= C, "gn_bwd: N=%d HW=%d C=%d groups=%d", N, HW, C, groups);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(gn_bwd_kernel<T>, dim3(groups, N), dim3(GN_THREADS), 0, st, (const T*)x, ldx, (const T*)y, (const T*)dy, ldy,
+                                           (T*)dx, lddx, HW, C, groups, gamma, save_mean_rstd, relu, accumulate, part);)
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, N, C, dgamma, dbeta);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

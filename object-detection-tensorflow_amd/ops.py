@@ -212,6 +212,20 @@ def resize_bilinear_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, accumulate=Fals
     call("odtk_resize_bilinear_bwd", _p(dy), int(lddy), _p(dx), int(lddx), N, H, W, Ho, Wo, int(C_), dt_of(dy), int(accumulate), _stream())
 
 
+def gn_workspace(N, C_, device):
+    return torch.zeros(int(_lib.load().odtk_gn_workspace_bytes(N, C_)), dtype=torch.uint8, device=device)
+
+
+def gn_fwd(x, ldx, y, ldy, N, HW, C_, groups, gamma, beta, relu, save):
+    """tf.contrib.layers.group_norm (+ ReLU) on NHWC rows; save [N, groups, 2] = mean, rstd (None in inference)"""
+    call("odtk_gn_fwd", _p(x), int(ldx), _p(y), int(ldy), N, HW, int(C_), int(groups), dt_of(x), _p(gamma), _p(beta), int(relu), _p(save), _stream())
+
+
+def gn_bwd(x, ldx, y, dy, ldy, dx, lddx, N, HW, C_, groups, gamma, save, relu, accumulate, dgamma, dbeta, ws):
+    call("odtk_gn_bwd", _p(x), int(ldx), _p(y), _p(dy), int(ldy), _p(dx), int(lddx), N, HW, int(C_), int(groups), dt_of(x), _p(gamma), _p(save),
+         int(relu), int(accumulate), _p(dgamma), _p(dbeta), _p(ws), _stream())
+
+
 def rows_to_f32(x, ldx, y, ldy, rows_per_img, y_img_stride, M, C_):
     """conv rows [M][ldx] -> f32 prediction tensor (row m of image m // rows_per_img at y + n * y_img_stride + (m % rows_per_img) * ldy)"""
     call("odtk_rows_to_f32", _p(x), int(ldx), dt_of(x), _p(y), int(ldy), int(rows_per_img), int(y_img_stride), int(M), int(C_), _stream())

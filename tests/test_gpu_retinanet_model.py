@@ -184,3 +184,46 @@ def test_tf_saver_checkpoint_roundtrip(dev, tmp_path):
     c = m3.export_params()
     for k in a:
         assert torch.equal(c[k], a[k] if int(k[1:].split('.')[0]) < 65 else before[k]), k
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_group_norm_kernels(dev, dt):
+    """tf.contrib.layers.group_norm(groups=8, epsilon 1e-6) + ReLU on NHWC rows, forward / backward (incl. accumulate and pitched operands)
+    against torch autograd: the normalisation of the reference's FCOS (FCOS.py:438-446), groundwork for that model"""
+    import odtk  # noqa: F401
+    from odtk import ops
+    tdt = torch.float32 if dt == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(4)
+    for (N, H, W, C, ld, groups) in [(2, 5, 7, 16, 16, 8), (3, 4, 4, 64, 72, 8), (2, 9, 3, 256, 256, 8), (1, 6, 5, 24, 24, 8), (2, 1, 2, 256, 256, 8)]:
+        HW = H * W
+        x = (torch.randn(N * HW, ld, generator=g) * 2 + 0.7).to(tdt)
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)), 0.2 * torch.randn(C, generator=g)
+        xd = x.to(dev)
+        y = torch.zeros(N * HW, ld, dtype=tdt, device=dev)
+        save = torch.zeros(N, groups, 2, device=dev)
+        for relu in (1, 0):
+            ops.gn_fwd(xd, ld, y, ld, N, HW, C, groups, gamma.to(dev), beta.to(dev), relu, save)
+            xr = x[:, :C].float().view(N, HW, C).permute(0, 2, 1).clone().requires_grad_(True)          # [N, C, HW]
+            gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            ref = torch.nn.functional.group_norm(xr, groups, gr, br, eps=1e-6)
+            if relu:
+                ref = torch.relu(ref)
+            tol = 3e-2 if dt == 'bf16' else 2e-5
+            torch.testing.assert_close(y[:, :C].float().cpu().view(N, HW, C).permute(0, 2, 1), ref.detach(), rtol=tol, atol=tol)
+            dy = torch.randn(N * HW, ld, generator=g).to(tdt)
+            mask = (y[:, :C].float().cpu() > 0) if relu else torch.ones(N * HW, C, dtype=torch.bool)     # the GPU's own ReLU region
+            (torch.where(mask.view(N, HW, C).permute(0, 2, 1), torch.nn.functional.group_norm(xr, groups, gr, br, eps=1e-6), torch.zeros(()))
+             * dy[:, :C].float().view(N, HW, C).permute(0, 2, 1)).sum().backward()
+            prev = torch.randn(N * HW, ld, generator=g).to(tdt)
+            dx = prev.clone().to(dev)
+            dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            ws = ops.gn_workspace(N, C, dev)
+            ops.gn_bwd(xd, ld, y, dy.to(dev), ld, dx, ld, N, HW, C, groups, gamma.to(dev), save, relu, True, dg, db, ws)
+            want_dx = xr.grad.permute(0, 2, 1).reshape(N * HW, C) + prev[:, :C].float()
+            if dt == 'f32':
+                torch.testing.assert_close(dx[:, :C].cpu(), want_dx, rtol=2e-4, atol=2e-4)
+                torch.testing.assert_close(dg.cpu(), gr.grad, rtol=2e-4, atol=2e-4)
+                torch.testing.assert_close(db.cpu(), br.grad, rtol=2e-4, atol=2e-4)
+            else:
+                assert float((dx[:, :C].float().cpu() - want_dx).norm() / want_dx.norm()) < 3e-2
+                assert float((dg.cpu() - gr.grad).norm() / (gr.grad.norm() + 1e-6)) < 3e-2

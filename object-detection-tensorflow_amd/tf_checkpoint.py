@@ -229,16 +229,30 @@ class _Table:
             yield from self._entries(self._block(off, size))
 
 
-def _build_table(items, block_size: int = 262144, restart_interval: int = 16) -> bytes:
-    """write side: `items` sorted (key, value) pairs, no compression (what BundleWriter asks for)"""
+def _snappy_literal(data: bytes) -> bytes:
+    """a valid (if pointless) snappy stream: the length, then literals of <= 60 bytes -- enough to exercise readers of compressed blocks"""
+    out = bytearray(_put_varint(len(data)))
+    for i in range(0, len(data), 60):
+        chunk = data[i:i + 60]
+        out.append((len(chunk) - 1) << 2)
+        out += chunk
+    return bytes(out)
+
+
+def _build_table(items, block_size: int = 262144, restart_interval: int = 16, snappy: bool = False) -> bytes:
+    """write side: `items` sorted (key, value) pairs, no compression (what BundleWriter asks for); snappy=True marks the blocks
+    compressed and stores them as literal-only snappy streams (for tests of the reader)"""
     out = bytearray()
     index = []                                                         # (last key of block, handle)
 
     def emit(block: bytes):
         off = len(out)
+        kind = b'\x01' if snappy else b'\x00'                          # kSnappyCompression / kNoCompression
+        if snappy:
+            block = _snappy_literal(block)
         out.extend(block)
-        out.append(0)                                                  # kNoCompression
-        out.extend(struct.pack('<I', mask_crc(crc32c(block + b'\x00'))))
+        out.extend(kind)
+        out.extend(struct.pack('<I', mask_crc(crc32c(block + kind))))
         return _put_varint(off) + _put_varint(len(block))
 
     def block_of(entries, interval):
@@ -500,3 +514,30 @@ def latest_checkpoint(directory: str):
             p = line.split(':', 1)[1].strip().strip('"')
             return p if os.path.isabs(p) else os.path.join(directory, p)
     return None
+
+
+def main(argv=None):
+    """python -m odtk.tf_checkpoint <checkpoint prefix or V1 file> [tensor name]: what inspect_checkpoint prints"""
+    import sys
+    argv = sys.argv[1:] if argv is None else argv
+    if not argv:
+        print(main.__doc__)
+        return 2
+    r = CheckpointReader(argv[0])
+    if len(argv) > 1:
+        a = r.get_tensor(argv[1])
+        print(argv[1], a.dtype, list(a.shape))
+        print(a)
+        return 0
+    shapes, dtypes = r.get_variable_to_shape_map(), r.get_variable_to_dtype_map()
+    total = 0
+    for k in sorted(shapes):
+        n = int(np.prod(shapes[k])) if shapes[k] else 1
+        total += n
+        print(f'{k}  {getattr(dtypes[k], "__name__", dtypes[k])}  {shapes[k]}')
+    print(f'# {len(shapes)} tensors, {total} elements, format V{r.version}')
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())

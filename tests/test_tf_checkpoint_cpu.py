@@ -191,3 +191,25 @@ def test_retinanet_variable_map_matches_reference_graph():
         shape = [k, k, cin, cout] if kind == 'w' else ([cout] if kind == 'b' else [bnc])
         assert want[name]['shape'] == shape, name
         assert want[name]['trainable'] == (kind not in ('mmean', 'mvar')), name
+
+
+def test_snappy_compressed_tables_and_cli(tmp_path, capsys):
+    """tables whose blocks are marked compressed (type 1, snappy) read back like plain ones -- V1 checkpoints written with snappy
+    available -- and the inspect-style command line lists a bundle"""
+    items = [(f'k{i:05d}'.encode(), os.urandom(1 + i % 97)) for i in range(500)]
+    for bs in (128, 4096):
+        assert list(T._Table(T._build_table(items, block_size=bs, snappy=True)).items()) == items
+    rng = np.random.default_rng(2)
+    tensors = {'a/kernel': rng.standard_normal((3, 3, 4, 8)).astype(np.float32), 'global_step': np.asarray(5, np.int32)}
+    fn = str(tmp_path / 'v1.ckpt')
+    _v1_file(fn, {'a/kernel': tensors['a/kernel']})
+    raw = open(fn, 'rb').read()
+    entries = list(T._Table(raw).items())
+    open(fn, 'wb').write(T._build_table(entries, block_size=256, snappy=True))          # the same V1 content in compressed blocks
+    assert np.array_equal(T.CheckpointReader(fn).get_tensor('a/kernel'), tensors['a/kernel'])
+    prefix = str(tmp_path / 'm.ckpt-5')
+    T.write_bundle(prefix, tensors)
+    assert T.main([prefix]) == 0
+    out = capsys.readouterr().out
+    assert 'a/kernel  float32  [3, 3, 4, 8]' in out and '# 2 tensors, 289 elements, format V2' in out
+    assert T.main([prefix, 'global_step']) == 0 and 'int32' in capsys.readouterr().out

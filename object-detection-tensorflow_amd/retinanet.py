@@ -126,7 +126,8 @@ class RetinaNet:
         self.global_step = 0
         self.dist = None
         self.loss_divisor_batch = self.batch_size
-        torch.cuda.set_device(self.dev)
+        if self.dev.type == 'cuda':          # (a 'cpu' device only gets past ops._p with the mocked library of tests/mock_ops.py: host-logic tests)
+            torch.cuda.set_device(self.dev)
         self.specs = layer_specs(self.block_list, config['init_conv_filters'], self.num_classes, self.num_anchors)
         self._init_parameters(int(config.get('seed', 0)))
         self._build()

@@ -95,7 +95,8 @@ class YOLOv3:
         self.dist = None
         self.sync_bn = None
         self.loss_divisor_batch = self.batch_size
-        torch.cuda.set_device(self.dev)
+        if self.dev.type == 'cuda':          # (a 'cpu' device only gets past ops._p with the mocked library of tests/mock_ops.py: host-logic tests)
+            torch.cuda.set_device(self.dev)
         self.specs = layer_specs(self.num_classes, self.num_priors)
         self._init_parameters(int(config.get('seed', 0)))
         self._build()

@@ -1,0 +1,271 @@
+"""A torch-CPU stand-in for the launches of odtk.ops (TEST INFRASTRUCTURE ONLY): every function has the signature and the memory
+semantics (rows x pitch operands, zero pad columns, accumulate flags, in-place outputs) of the libodtk wrapper it replaces, computed with
+plain torch ops.  With it the model classes' HOST LOGIC -- buffer planning, launch order, gradient bookkeeping, optimizer glue -- runs
+and is checked against the oracles without a GPU (`-m "not gpu"`); the kernels themselves are checked on the GPU, one by one and
+through the same classes.  Usage: `with mock_ops.installed(): model = odtk.YOLOv3(dict(config, device='cpu'), provider)`."""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS, BN_MOM = 1e-3, 0.99
+
+
+def _nhwc(rows, d_or_shape, C):
+    N, H, W = d_or_shape
+    return rows[:, :C].float().reshape(N, H, W, C)
+
+
+def _conv_weights(w_flat, d):
+    return w_flat.float().reshape(d.K, d.R, d.S, d.C)
+
+
+def _same_pads(in_size, out_size, k, stride, dil, pad_before):
+    total = max((out_size - 1) * stride + (k - 1) * dil + 1 - in_size, 0)
+    return pad_before, total - pad_before
+
+
+def _conv(x_nhwc, w_krsc, d):
+    pt, pb = _same_pads(d.H, d.Ho, d.R, d.stride, d.dil, d.pad_t)
+    pl, pr = _same_pads(d.W, d.Wo, d.S, d.stride, d.dil, d.pad_l)
+    xp = F.pad(x_nhwc.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    return F.conv2d(xp, w_krsc.permute(0, 3, 1, 2), None, stride=d.stride, dilation=d.dil).permute(0, 2, 3, 1)
+
+
+def conv2d_fwd(d, x, w, bias, y, relu):
+    out = _conv(_nhwc(x, (d.N, d.H, d.W), d.C), _conv_weights(w, d), d)
+    if bias is not None:
+        out = out + bias.float()
+    if relu:
+        out = torch.relu(out)
+    y[:, :d.K] = out.reshape(-1, d.K).to(y.dtype)
+
+
+def conv2d_dgrad(d, dy, lddy, w_t, relu_src, dx, accumulate):
+    Kp = lddy
+    wt = w_t.float().reshape(d.C, d.R * d.S, Kp)
+    w = wt.flip(1)[:, :, :d.K].permute(2, 1, 0).reshape(d.K, d.R, d.S, d.C)              # undo the flip / transpose of filter_prepare
+    x = torch.zeros(d.N, d.H, d.W, d.C, requires_grad=True)
+    out = _conv(x, w, d)
+    g, = torch.autograd.grad(out, x, dy[:, :d.K].float().reshape(out.shape))
+    g = g.reshape(-1, d.C)
+    if accumulate:
+        g = g + dx[:, :d.C].float()
+    if relu_src is not None:
+        g = g * (relu_src[:, :d.C].float() > 0)
+    dx[:, :d.C] = g.to(dx.dtype)
+
+
+def conv2d_wgrad(d, x, dy, lddy, dw, dbias=None):
+    w = torch.zeros(d.K, d.R, d.S, d.C, requires_grad=True)
+    out = _conv(_nhwc(x, (d.N, d.H, d.W), d.C), w, d)
+    g, = torch.autograd.grad(out, w, dy[:, :d.K].float().reshape(out.shape))
+    dw.view(-1)[: g.numel()] += g.reshape(-1)
+    if dbias is not None:
+        dbias[: d.K] += dy[:, :d.K].float().sum(0)
+
+
+class FilterPrepareBatch:
+    def __init__(self, entries, dtype, device):
+        self.entries = entries
+
+    def run(self):
+        for (w, wt, K, R, S, C_, Kp) in self.entries:
+            full = torch.zeros(C_, R * S, Kp)
+            full[:, :, :K] = w.float().reshape(K, R * S, C_).permute(2, 1, 0).flip(1)
+            wt.copy_(full.reshape(-1).to(wt.dtype))
+
+
+def preprocess(images, mean3, ldx, dtype, x):
+    x.zero_()
+    x[:, :3] = (images.float() - torch.tensor(mean3, dtype=torch.float32)).reshape(-1, 3).to(x.dtype)
+
+
+def _act(v, relu):
+    return torch.relu(v) if relu == 1 else (torch.where(v > 0, v, 0.1 * v) if relu == 2 else v)
+
+
+def bn_fwd(z, M, C_, ldz, gamma, beta, mmean, mvar, save_mean, save_invstd, training, relu, y, ldy, rows_per_img, y_img_stride, ws):
+    assert y_img_stride == 0 and rows_per_img == M
+    v = z[:M, :C_].float()
+    if training:
+        mean = v.mean(0)
+        var = ((v - mean) ** 2).mean(0)
+        save_mean.copy_(mean); save_invstd.copy_(torch.rsqrt(var + BN_EPS))
+        mmean.mul_(BN_MOM).add_((1 - BN_MOM) * mean)
+        mvar.mul_(BN_MOM).add_((1 - BN_MOM) * var * (M / max(M - 1, 1)))
+    else:
+        mean, var = mmean.float(), mvar.float()
+    out = (v - mean) * (torch.rsqrt(var + BN_EPS) * gamma.float()) + beta.float()
+    y[:M, :C_] = _act(out, relu).to(y.dtype)
+
+
+def bn_bwd(z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, dz, dgamma, dbeta, ws):
+    assert y_img_stride == 0 and rows_per_img == M
+    d = dy[:M, :C_].float()
+    if relu == 1:
+        d = d * (y[:M, :C_].float() > 0)
+    elif relu == 2:
+        d = torch.where(y[:M, :C_].float() > 0, d, 0.1 * d)
+    xh = (z[:M, :C_].float() - save_mean) * save_invstd
+    dbeta.copy_(d.sum(0)); dgamma.copy_((d * xh).sum(0))
+    out = gamma.float() * save_invstd * (d - d.mean(0) - xh * (d * xh).mean(0))
+    dz.zero_()
+    dz[:M, :C_] = out.to(dz.dtype)
+
+
+def add2d(a, lda, b, ldb, y, ldy, M, C_):
+    v = a[:M, :C_].float() + (b[:M, :C_].float() if b is not None else 0.)
+    y[:M, :C_] = v.to(y.dtype)
+
+
+def upsample2x_fwd(x, ldx, y, ldy, N, H, W, C_):
+    v = x[:, :C_].reshape(N, H, W, C_).repeat_interleave(2, 1).repeat_interleave(2, 2)
+    y[:, :C_] = v.reshape(-1, C_)
+
+
+def upsample2x_bwd(dy, lddy, dx, lddx, N, H, W, C_, accumulate=False):
+    v = dy[:, :C_].float().reshape(N, H, 2, W, 2, C_).sum(dim=(2, 4)).reshape(-1, C_)
+    dx[:, :C_] = (v + (dx[:, :C_].float() if accumulate else 0.)).to(dx.dtype)
+
+
+def _bilinear(x_nhwc, Ho, Wo):
+    n, h, w, c = x_nhwc.shape
+    fy = torch.arange(Ho, dtype=torch.float32) * (h / Ho)
+    fx = torch.arange(Wo, dtype=torch.float32) * (w / Wo)
+    y0, x0 = torch.floor(fy).long(), torch.floor(fx).long()
+    y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
+    ly, lx = (fy - y0.float()).view(1, Ho, 1, 1), (fx - x0.float()).view(1, 1, Wo, 1)
+    top = x_nhwc[:, y0][:, :, x0] + (x_nhwc[:, y0][:, :, x1] - x_nhwc[:, y0][:, :, x0]) * lx
+    bot = x_nhwc[:, y1][:, :, x0] + (x_nhwc[:, y1][:, :, x1] - x_nhwc[:, y1][:, :, x0]) * lx
+    return top + (bot - top) * ly
+
+
+def resize_bilinear_fwd(x, ldx, y, ldy, N, H, W, Ho, Wo, C_, accumulate=False):
+    v = _bilinear(x[:, :C_].float().reshape(N, H, W, C_), Ho, Wo).reshape(-1, C_)
+    y[:, :C_] = (v + (y[:, :C_].float() if accumulate else 0.)).to(y.dtype)
+
+
+def resize_bilinear_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, accumulate=False):
+    x = torch.zeros(N, H, W, C_, requires_grad=True)
+    g, = torch.autograd.grad(_bilinear(x, Ho, Wo), x, dy[:, :C_].float().reshape(N, Ho, Wo, C_))
+    dx[:, :C_] = (g.reshape(-1, C_) + (dx[:, :C_].float() if accumulate else 0.)).to(dx.dtype)
+
+
+def _pool(x_nhwc, k, stride, pt, pl, Ho, Wo):
+    n, h, w, c = x_nhwc.shape
+    pb = max((Ho - 1) * stride + k - h - pt, 0)
+    pr = max((Wo - 1) * stride + k - w - pl, 0)
+    xp = F.pad(x_nhwc.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float('-inf'))
+    return F.max_pool2d(xp, k, stride).permute(0, 2, 3, 1)
+
+
+def maxpool_fwd(x, y, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
+    y[:, :C_] = _pool(x[:, :C_].float().reshape(N, H, W, C_), k, stride, pad_t, pad_l, Ho, Wo).reshape(-1, C_).to(y.dtype)
+
+
+def maxpool_bwd(x, y, dy, dx, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
+    xr = x[:, :C_].float().reshape(N, H, W, C_).clone().requires_grad_(True)
+    g, = torch.autograd.grad(_pool(xr, k, stride, pad_t, pad_l, Ho, Wo), xr, dy[:, :C_].float().reshape(N, Ho, Wo, C_))
+    dx[:, :C_] = g.reshape(-1, C_).to(dx.dtype)
+
+
+def _storage(y):
+    """the kernels get a raw pointer (here: into the middle of the [N][A][width] prediction tensor) and address past the view they were
+    handed: (whole storage as a flat tensor, element offset of y in it)"""
+    return torch.empty(0, dtype=y.dtype).set_(y.untyped_storage()), y.storage_offset()
+
+
+def rows_to_f32(x, ldx, y, ldy, rows_per_img, y_img_stride, M, C_):
+    flat, base = _storage(y)
+    for n in range(M // rows_per_img):
+        blk = x[n * rows_per_img:(n + 1) * rows_per_img, :C_].float()
+        idx = base + n * y_img_stride + torch.arange(rows_per_img).view(-1, 1) * ldy + torch.arange(C_).view(1, -1)
+        flat[idx.reshape(-1)] = blk.reshape(-1)
+
+
+def rows_from_f32(y, ldy, rows_per_img, y_img_stride, x, ldx, M, C_):
+    flat, base = _storage(y)
+    x.zero_()
+    for n in range(M // rows_per_img):
+        idx = base + n * y_img_stride + torch.arange(rows_per_img).view(-1, 1) * ldy + torch.arange(C_).view(1, -1)
+        x[n * rows_per_img:(n + 1) * rows_per_img, :C_] = flat[idx.reshape(-1)].reshape(rows_per_img, C_).to(x.dtype)
+
+
+def sgd_momentum(p, m, g, lr, momentum, wd, grad_scale, l2_partial, p_cast):
+    l2_partial.zero_()
+    l2_partial[0] = (p * p).sum() / 2
+    m.mul_(momentum).add_(g * grad_scale + wd * p)
+    p.sub_(lr * m)
+    if p_cast is not None and p_cast is not p:
+        p_cast.copy_(p.to(p_cast.dtype))
+
+
+def sum_f32(x, out):
+    out[0] = x.sum()
+
+
+def cast_from_f32(x, out):
+    out.copy_(x.to(out.dtype))
+
+
+# ---- box side through the oracles (autograd supplies the gradients the kernels return)
+def yolov3_workspace(preds, N, device):
+    return torch.zeros(4, dtype=torch.uint8)
+
+
+def yolov3_loss(preds, priors_flat, head_stride, gt, scales, grad_scale, loss_parts, d_preds, ws):
+    from oracle import yolov3_ref as YR
+    N = preds[0].shape[0]
+    ps = [p.detach().clone().requires_grad_(True) for p in preds]
+    tot = 0.
+    for i in range(N):
+        d = YR.one_image_loss([p[i] for p in ps], gt[i], num_classes=preds[0].shape[-1] - 5, coord_scale=scales[0], noobj_scale=scales[1],
+                              obj_scale=scales[2], class_scale=scales[3], detail=True)
+        loss_parts[i, 4] = d['total'].detach()
+        tot = tot + d['total']
+    grads = torch.autograd.grad(tot * grad_scale, ps)
+    for dp, g in zip(d_preds, grads):
+        dp.copy_(g)
+
+
+def retina_anchors(input_dim, shapes, nas, prior_hw_flat, device):
+    from oracle import retinanet_ref as RR
+    return RR.anchors([0, input_dim, 3], shapes)
+
+
+def retina_match_workspace(A, N, P, device):
+    return torch.zeros(4, dtype=torch.uint8)
+
+
+def retina_match(*a):
+    pass                                                       # the mocked loss below matches internally
+
+
+def retina_loss(pconf, pbox, yx, hw, gt, ngt, best, status, rgindex, counts, alpha, gamma, grad_scale, loss_parts, dconf, dbox):
+    from oracle import retinanet_ref as RR
+    anc = retina_loss.anchors
+    pc, pb = pconf.detach().clone().requires_grad_(True), pbox.detach().clone().requires_grad_(True)
+    tot = 0.
+    for i in range(pconf.shape[0]):
+        d = RR.one_image_loss(pb[i, :, :2], pb[i, :, 2:], pc[i], anc, gt[i], alpha, gamma, detail=True)
+        loss_parts[i, 0], loss_parts[i, 1] = d['conf_loss'].detach(), (d['total'] - d['conf_loss']).detach()
+        tot = tot + d['total']
+    gc, gb = torch.autograd.grad(tot * grad_scale, [pc, pb])
+    dconf.copy_(gc); dbox.copy_(gb)
+
+
+@contextlib.contextmanager
+def installed():
+    """swap the launching functions of odtk.ops for the ones above (and back)"""
+    import odtk  # noqa: F401
+    from odtk import ops
+    names = [n for n, v in globals().items() if callable(v) and not n.startswith('_') and n not in ('installed', 'contextlib') and hasattr(ops, n)]
+    old = {n: getattr(ops, n) for n in names}
+    try:
+        for n in names:
+            setattr(ops, n, globals()[n])
+        yield
+    finally:
+        for n, v in old.items():
+            setattr(ops, n, v)

@@ -1,0 +1,85 @@
+"""The model classes' host logic on the CPU: YOLOv3 and RetinaNet run a full training step with every libodtk launch replaced by its
+torch-CPU stand-in (tests/mock_ops.py) and must reproduce the oracle's loss, EVERY gradient and the optimizer update -- buffer planning,
+launch order, shared gradient buffers, accumulate flags, prediction scatter, loss / optimizer glue are all exercised without a GPU.
+(The kernels behind the launches are verified on the GPU, alone and through the same classes: tests/test_gpu_*.py.)"""
+import pytest
+import torch
+
+import mock_ops
+
+
+def _rel(a, b):
+    return float((a - b).norm()) / (float(b.norm()) + 1e-12)
+
+
+def test_yolov3_training_step_host_logic():
+    import odtk
+    from oracle import yolov3_net_ref as NR
+    from oracle import yolov3_ref as YR
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'data_shape': [64, 64, 3], 'num_classes': 20, 'weight_decay': 5e-4, 'keep_prob': 0.5, 'data_format': 'channels_last',
+           'batch_size': 2, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'num_priors': 3, 'nms_score_threshold': 0.5,
+           'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'priors': YR.PRIORS_PX, 'verbose': False, 'compute_dtype': 'f32', 'device': 'cpu',
+           'use_graph': False}
+    g = torch.Generator().manual_seed(40)
+    imgs = (torch.rand(2, 64, 64, 3, generator=g) * 255).round()
+    gt = YR.synthetic_gt(2, 64, 41, max_obj=3)
+    p = NR.init_params(5)
+    with mock_ops.installed():
+        m = odtk.YOLOv3(cfg, {'num_train': 2, 'train_generator': [(imgs, gt)], 'val_generator': None, 'num_val': 0})
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        loss = float(m.train_step(0.01))
+        masks = {}
+        for name, _, _, _, _, act in NR.layer_specs():
+            if act:
+                a = m.acts[name]
+                masks[name] = (a.t[:, :a.C] > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
+        q = {k: v.clone() for k, v in p.items()}
+        mom = {k: torch.zeros_like(v) for k, v in p.items() if k in NR.trainable_names(p)}
+        total, data, grads = NR.train_step(q, mom, imgs, gt, 0.01, leaky_masks=masks)
+        assert abs(loss - total) < 1e-4 * abs(total)
+        for k in NR.trainable_names(p):
+            if k.endswith('.b') or k in ('c59.beta', 'c67.beta'):
+                continue                                   # true gradient 0 (a batch norm follows): round-off on both sides
+            assert _rel(m.get_param(k, m.G), grads[k] - 5e-4 * p[k]) < 2e-3, k
+        after = m.export_params()
+        for k in ('c0.w', 'c30.gamma', 'c58.w', 'c74.beta', 'c26.mmean', 'c74.mvar'):
+            assert _rel(after[k], q[k]) < 1e-4, k
+
+
+def test_retinanet_training_step_host_logic():
+    import odtk
+    from oracle import retinanet_net_ref as NR
+    from oracle import retinanet_ref as RR
+    torch.set_num_threads(8)
+    cfg = {'is_bottleneck': True, 'residual_block_list': [3, 4, 6, 3], 'init_conv_filters': 16, 'mode': 'train', 'is_pretraining': False,
+           'data_shape': [128, 128, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'data_format': 'channels_last', 'batch_size': 2,
+           'gamma': 2.0, 'alpha': 0.25, 'nms_score_threshold': 0.8, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False,
+           'compute_dtype': 'f32', 'device': 'cpu'}
+    g = torch.Generator().manual_seed(90)
+    imgs = (torch.rand(2, 128, 128, 3, generator=g) * 255).round()
+    gt = RR.synthetic_gt(2, 128, 91)
+    p = NR.init_params(7)
+    with mock_ops.installed():
+        m = odtk.RetinaNet(cfg, {'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+        mock_ops.retina_loss.anchors = m.anc
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        loss = float(m.train_step(0.01))
+        masks = {}
+        for name, *_ in NR.layer_specs():
+            a = m.acts[name if name == 'l0' else name + '.y']
+            masks[name] = (a.t[:, :a.C] > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
+        q = {k: v.clone() for k, v in p.items()}
+        mom = {k: torch.zeros_like(v) for k, v in p.items() if k in NR.trainable_names(p)}
+        total, data, grads = NR.train_step(q, mom, imgs, gt, 0.01, relu_masks=masks)
+        assert abs(loss - total) < 1e-4 * abs(total)
+        for k in NR.trainable_names(p):
+            want = grads[k] - 1e-4 * p[k]
+            if k.endswith('.b') and float(want.norm()) < 1e-4 * float(grads[k[:-2] + '.w'].norm()):
+                continue                                   # only the ten prediction convs have a live bias gradient
+            assert _rel(m.get_param(k, m.G), want) < 5e-3, k
+        after = m.export_params()
+        for k in ('l0.w', 'l30.gamma', 'l65.w', 'l76.b', 'l121.w', 'l1.mmean', 'l121.mvar'):
+            assert _rel(after[k], q[k]) < 1e-4, k

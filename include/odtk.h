@@ -205,6 +205,11 @@ int odtk_gn_bwd(const void* x, int ldx, const void* y, const void* dy, int ldy, 
                 int dtype, const float* gamma, const float* save_mean_rstd, int relu, int accumulate, float* dgamma, float* dbeta,
                 void* workspace, void* stream);
 
+/* tf.exp on the distance outputs of the FCOS regression heads (FCOS.py:363), laid out for odtk_fcos_loss: y f32 [M][C] = exp(x rows),
+ * and its chain rule dx rows = dy * y (pad columns of dx zeroed). */
+int odtk_exp_rows_to_f32(const void* x, int ldx, int dtype, float* y, long long M, int C, void* stream);
+int odtk_exp_rows_bwd(const float* dy, const float* y, void* dx, int lddx, int dtype, long long M, int C, void* stream);
+
 /* conv rows <-> the f32 prediction tensors of the box-side kernels: tf.reshape + tf.concat over the pyramid levels
  * (RetinaNet.py:184-186, :321-326).  Row m of image n = m / rows_per_img is read / written at
  * y + n * y_img_stride + (m % rows_per_img) * ldy (floats); x is [M][ldx] in `dtype`; _from_f32 zeroes x's pad columns. */

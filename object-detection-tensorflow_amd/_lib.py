@@ -67,6 +67,8 @@ SIGNATURES = {
     "odtk_gn_workspace_bytes": (_ll, [_i, _i]),
     "odtk_gn_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "odtk_gn_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "odtk_exp_rows_to_f32": (_i, [_vp, _i, _i, _vp, _ll, _i, _vp]),
+    "odtk_exp_rows_bwd": (_i, [_vp, _vp, _vp, _i, _i, _ll, _i, _vp]),
     "odtk_add2d": (_i, [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _i, _vp]),
     "odtk_upsample2x_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "odtk_upsample2x_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

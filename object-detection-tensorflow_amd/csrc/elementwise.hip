@@ -1635,3 +1635,48 @@ extern "C" int odtk_gn_bwd(const void* x, int ldx, const void* y, const void* dy
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// tf.exp on the distance outputs of the FCOS regression heads (FCOS.py:363) while they are laid out for the loss kernel, and its
+// chain rule: y[m][c] = exp(x[m][c]) as f32 [M][C]; dx[m][c] = dy[m][c] * y[m][c] back in the conv rows (pad columns zeroed).
+namespace odtk {
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256) exp_rows_to_f32_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, long long M, int C) {
+    const long long total = M * C, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long m = i / C;
+        y[i] = expf(elem<T>::load(x[m * ldx + (int)(i - m * C)]));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) exp_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, T* __restrict__ dx, int lddx,
+                                                           long long M, int C) {
+    const long long total = M * lddx, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long m = i / lddx;
+        const int c = (int)(i - m * lddx);
+        dx[i] = elem<T>::store(c < C ? dy[m * C + c] * y[m * C + c] : 0.f);
+    }
+}
+
+}  // namespace
+}  // namespace odtk
+
+extern "C" int odtk_exp_rows_to_f32(const void* x, int ldx, int dtype, float* y, long long M, int C, void* stream) {
+    ODTK_REQUIRE(x && y && M > 0 && C > 0 && ldx >= C, "exp_rows_to_f32: bad argument");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(exp_rows_to_f32_kernel<T>, dim3(grid_for(M * C, 256, 65536)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                           ldx, y, M, C);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_exp_rows_bwd(const float* dy, const float* y, void* dx, int lddx, int dtype, long long M, int C, void* stream) {
+    ODTK_REQUIRE(dy && y && dx && M > 0 && C > 0 && lddx >= C, "exp_rows_bwd: bad argument");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(exp_rows_bwd_kernel<T>, dim3(grid_for(M * lddx, 256, 65536)), dim3(256), 0, (hipStream_t)stream, dy, y, (T*)dx,
+                                           lddx, M, C);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

@@ -1,0 +1,496 @@
+"""FCOS (the reference's group-normalised pre-activation ResNet + pyramid + per-level heads) behind the reference's class surface, on libodtk.
+
+Reference: /root/reference/FCOS.py
+  * constructor, config keys ............. :12-49    (blocks 3, 4, 6, 3 and filters 16 * 2^i are fixed in the class, :29-31)
+  * input ................................ :51-68    (images - mean; test mode feeds the tensor after the subtraction)
+  * network .............................. :70-110, :350-382, :438-513: EVERY normalisation is tf.contrib.layers.group_norm(groups=8);
+                                           stem conv + GN + ReLU + 3x3 / s2 max pool; bottleneck units [GN-ReLU-1x1 f, GN-ReLU-3x3 f (stride),
+                                           GN-ReLU-1x1 4f] + [GN-ReLU-3x3 4f (stride)] shortcut; c3 / c4 / c5 1x1; bilinear top-down pyramid (the sum is
+                                           handed down); p6 / p7; per level 4 x 3x3 -> classes and centre-ness, 4 x 3x3 -> exp(distances)
+  * loss, optimizer ...................... :111-192  (odtk_fcos_loss; mean over images + wd * l2; Momentum 0.9)
+  * inference ............................ :193-265  (heads.fcos_detect; classes 0 .. C-2, sic)
+  * train / test / checkpoints ........... :401-436
+Same conventions as retinanet.py: layers l0 .. l129 in creation order (layer k = conv k + group norm k), one flat f32 parameter buffer.
+Group norm has no batch statistics: nothing like moving averages exists, and data parallel needs no sync-BN.
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import heads, ops
+from ._lib import BF16, F32
+
+MEAN_RGB = (123.68, 116.779, 103.979)
+BLOCKS = (3, 4, 6, 3)                                          # FCOS.py:30
+FILTERS = (16, 32, 64, 128)                                    # :31
+GROUPS = 8                                                     # :441
+PI = 0.01                                                      # :486
+
+
+def layer_specs(num_classes):
+    """[(name, cin, cout, k, stride, gn_channels, bias_init)] in creation order (FCOS.py:70-110, :350-382, :504-513)"""
+    specs = []
+
+    def add(cin, cout, k, s, bias_init=0.):
+        specs.append((f'l{len(specs)}', cin, cout, k, s, cin if specs else cout, bias_init))
+        return cout
+    c = add(3, 16, 7, 2)
+    stage_out = []
+    for i, blocks in enumerate(BLOCKS):
+        f = FILTERS[i]
+        for j in range(blocks):
+            s = 2 if (i > 0 and j == 0) else 1
+            add(c, f, 1, 1); add(f, f, 3, s); add(f, 4 * f, 1, 1)
+            add(c, 4 * f, 3, s)
+            c = 4 * f
+        stage_out.append(c)
+    e3, e4, e5 = stage_out[-3:]
+    add(e3, 256, 1, 1); add(e4, 256, 1, 1); add(e5, 256, 1, 1)
+    add(256, 256, 3, 1)
+    add(256, 256, 1, 1); add(256, 256, 3, 1)
+    add(256, 256, 1, 1); add(256, 256, 3, 1)
+    add(256, 256, 3, 2); add(256, 256, 3, 2)
+    bias = -math.log((1 - PI) / PI)
+    for _ in range(5):
+        for _ in range(4):
+            add(256, 256, 3, 1)
+        add(256, num_classes, 3, 1, bias)
+        add(256, 1, 3, 1, bias)
+        for _ in range(4):
+            add(256, 256, 3, 1)
+        add(256, 4, 3, 1)
+    return specs
+
+
+class _Act:
+    def __init__(self, name, N, H, W, C, ld, dtype, dev):
+        self.name, self.N, self.H, self.W, self.C, self.ld = name, N, H, W, C, ld
+        self.M = N * H * W
+        self.t = torch.zeros(self.M, ld, dtype=dtype, device=dev)
+        self.gid = name
+
+
+class FCOS:
+    def __init__(self, config, data_provider):
+        assert config['mode'] in ['train', 'test']
+        assert config['data_format'] in ['channels_first', 'channels_last']
+        self.config = config
+        self.data_provider = data_provider
+        self.data_shape = config['data_shape']
+        self.num_classes = config['num_classes']
+        self.weight_decay = config['weight_decay']
+        self.data_format = config['data_format']
+        self.mode = config['mode']
+        self.batch_size = config['batch_size'] if config['mode'] == 'train' else 1
+        self.nms_score_threshold = config['nms_score_threshold']
+        self.nms_max_boxes = config['nms_max_boxes']
+        self.nms_iou_threshold = config['nms_iou_threshold']
+        self.verbose = bool(config.get('verbose', True))
+        self.dev = torch.device(config.get('device', 'cuda:0'))
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'f32')]       # f32 until the bf16 backward is validated (cf. retinanet.py)
+        self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
+        self.chunk = ops.chunk(self.DT)
+        if self.mode == 'train':
+            self.num_train = data_provider['num_train']
+            self.num_val = data_provider['num_val']
+            self.train_generator = data_provider['train_generator']
+            if isinstance(self.train_generator, tuple) and len(self.train_generator) == 2:
+                self.train_initializer, self.train_iterator = self.train_generator
+            else:
+                self.train_initializer, self.train_iterator = None, self.train_generator
+            if data_provider.get('val_generator') is not None:
+                self.val_generator = data_provider['val_generator']
+        self.global_step = 0
+        self.dist = None
+        self.loss_divisor_batch = self.batch_size
+        if self.dev.type == 'cuda':          # (a 'cpu' device only gets past ops._p with the mocked library of tests/mock_ops.py: host-logic tests)
+            torch.cuda.set_device(self.dev)
+        self.specs = layer_specs(self.num_classes)
+        self._init_parameters(int(config.get('seed', 0)))
+        self._build()
+
+    # ------------------------------------------------------------------ parameters
+    def param_layout(self):
+        pinfo = OrderedDict()
+        off = 0
+        for name, cin, cout, k, _, gnc, _ in self.specs:
+            for suffix, shape in (('.w', (cout, k, k, ops.pad_to(cin, self.chunk))), ('.b', (cout,)), ('.gamma', (gnc,)), ('.beta', (gnc,))):
+                pinfo[name + suffix] = (off, shape)
+                off += ops.pad_to(int(np.prod(shape)), 64)
+        return pinfo, off
+
+    def _init_parameters(self, seed):
+        self.pinfo, off = self.param_layout()
+        self.nparam = off
+        dev = self.dev
+        self.P = torch.zeros(off, device=dev)
+        self.Mom = torch.zeros(off, device=dev)
+        self.G = torch.zeros(off, device=dev)
+        self.Pc = torch.zeros(off, dtype=self.tdt, device=dev) if self.DT == BF16 else self.P
+        self.l2_partial = torch.zeros(ops.sgd_blocks(off), device=dev)
+        self.l2_sum = torch.zeros(1, device=dev)
+        self._cin = {s[0]: s[1] for s in self.specs}
+        g = torch.Generator().manual_seed(seed)
+        for name, cin, cout, k, _, _, bias_init in self.specs:
+            self.set_param(name + '.w', torch.randn(cout, k, k, cin, generator=g) * math.sqrt(2.0 / (cin * k * k)))
+            self.param(name + '.b').fill_(float(bias_init))
+            self.param(name + '.gamma').fill_(1.0)
+
+    def param(self, name, buf=None):
+        off, shape = self.pinfo[name]
+        buf = self.P if buf is None else buf
+        return buf[off: off + int(np.prod(shape))].view(shape)
+
+    def _flat(self, name, buf):
+        off, shape = self.pinfo[name]
+        return buf[off: off + int(np.prod(shape))]
+
+    def set_param(self, name, value):
+        dst = self.param(name)
+        value = torch.as_tensor(value, dtype=torch.float32)
+        if name.endswith('.w'):
+            dst.zero_()
+            dst[..., : value.shape[-1]] = value.to(self.dev)
+        else:
+            dst.copy_(value.to(self.dev).view(dst.shape))
+
+    def get_param(self, name, buf=None):
+        v = self.param(name, buf).detach().cpu().clone()
+        if name.endswith('.w'):
+            v = v[..., : self._cin[name[:-2]]].contiguous()
+        return v
+
+    def load_oracle_params(self, p):
+        for k, v in p.items():
+            if k in self.pinfo:
+                self.set_param(k, v)
+        self._refresh_operand_copies()
+
+    def export_params(self):
+        return OrderedDict((k, self.get_param(k)) for k in self.pinfo)
+
+    def _refresh_operand_copies(self):
+        if self.DT == BF16:
+            ops.cast_from_f32(self.P, self.Pc)
+        if getattr(self, '_fp_batch', None) is not None:
+            self._fp_batch.run()
+
+    # ------------------------------------------------------------------ the graph
+    def _build(self):
+        N, dev, dt, ch = self.batch_size, self.dev, self.tdt, self.chunk
+        H, W, _ = self.data_shape
+        self.images = torch.zeros(N, H, W, 3, device=dev)
+        c0 = ops.pad_to(3, ch)
+        self.input = _Act('input', N, H, W, 3, c0, dt, dev)
+        self.plan, self.desc, self.gnsave, self.acts = [], {}, {}, {}
+        it = iter(self.specs)
+        self._max_scr = 0
+        groups = {}
+
+        def find(g):
+            while groups.setdefault(g, g) != g:
+                g = groups[g]
+            return g
+        self.find = find
+
+        def act(name, H_, W_, C_):
+            a = _Act(name, N, H_, W_, C_, ops.pad_to(C_, ch), dt, dev)
+            self.acts[name] = a
+            return a
+
+        def conv_desc(name, src, cout, k, stride, ldy):
+            d = ops.conv_desc(N, src.H, src.W, src.ld, src.ld, cout, ldy, k, stride, 1, self.DT, self.DT)
+            self.desc[name] = d
+            return d
+
+        def gnconv(x):
+            """group norm -> ReLU -> conv(bias): returns the conv output"""
+            name, cin, cout, k, stride, gnc, _ = next(it)
+            assert cin == x.C == gnc and gnc % GROUPS == 0, (name, cin, x.C)
+            y = act(name + '.y', x.H, x.W, x.C)
+            d = conv_desc(name, y, cout, k, stride, ops.pad_to(cout, ch))
+            out = act(name, d.Ho, d.Wo, cout)
+            self.gnsave[name] = torch.zeros(N, GROUPS, 2, device=dev)
+            self._max_scr = max(self._max_scr, y.M * y.ld)
+            self.plan.append(('gnconv', name, x, y, out))
+            return out
+
+        def add(a, b):
+            y = act(f'sum{len(self.plan)}', a.H, a.W, a.C)
+            groups[find(a.gid)] = find(y.gid)
+            groups[find(b.gid)] = find(y.gid)
+            self.plan.append(('add', a, b, y))
+            return y
+
+        def resize_add(lat, top):
+            y = act(f'total{len(self.plan)}', lat.H, lat.W, lat.C)
+            groups[find(lat.gid)] = find(y.gid)
+            self.plan.append(('resize_add', lat, top, y))
+            return y
+
+        name, cin, cout, k, stride, gnc, _ = next(it)
+        d = conv_desc(name, self.input, cout, k, stride, ops.pad_to(cout, ch))
+        z = act(name + '.z', d.Ho, d.Wo, cout)
+        y = act(name, d.Ho, d.Wo, cout)
+        self.gnsave[name] = torch.zeros(N, GROUPS, 2, device=dev)
+        self._max_scr = max(self._max_scr, z.M * z.ld)
+        self.plan.append(('stem', name, self.input, z, y))
+        Hp, pt, _ = ops.same_pad(y.H, 3, 2)
+        Wp, pl, _ = ops.same_pad(y.W, 3, 2)
+        x = act('pool1', Hp, Wp, cout)
+        self.plan.append(('pool', y, x, 3, 2, pt, pl))
+        feats = []
+        for blocks in BLOCKS:
+            for _ in range(blocks):
+                branch = gnconv(gnconv(gnconv(x)))
+                x = add(branch, gnconv(x))
+            feats.append(x)
+        c3, c4, c5 = gnconv(feats[-3]), gnconv(feats[-2]), gnconv(feats[-1])
+        p5 = gnconv(c5)
+        total4 = resize_add(gnconv(c4), p5)
+        p4 = gnconv(total4)
+        total3 = resize_add(gnconv(c3), total4)
+        p3 = gnconv(total3)
+        p6 = gnconv(p5)
+        p7 = gnconv(p6)
+        self.levels = [p3, p4, p5, p6, p7]
+        self.conf = [torch.zeros(N, a.H, a.W, self.num_classes, device=dev) for a in self.levels]
+        self.reg = [torch.zeros(N, a.H, a.W, 4, device=dev) for a in self.levels]
+        self.center = [torch.zeros(N, a.H, a.W, 1, device=dev) for a in self.levels]
+        for l, lvl in enumerate(self.levels):
+            c = lvl
+            for _ in range(4):
+                c = gnconv(c)
+            self.plan.append(('pred', gnconv(c), self.conf, l, False))
+            self.plan.append(('pred', gnconv(c), self.center, l, False))
+            r = lvl
+            for _ in range(4):
+                r = gnconv(r)
+            self.plan.append(('pred', gnconv(r), self.reg, l, True))       # tf.exp on the distances (FCOS.py:363)
+        assert next(it, None) is None
+        self.wt, entries = {}, []
+        for name, cin, cout, k, _, _, _ in self.specs[1:]:
+            d = self.desc[name]
+            kp = self.acts[name].ld
+            self.wt[name] = torch.zeros(d.C * k * k * kp, dtype=dt, device=dev)
+            entries.append((self._flat(name + '.w', self.P), self.wt[name], cout, k, k, d.C, kp))
+        self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, dev)
+        if self.mode == 'train':
+            self._build_backward(N, dt, dev)
+        self._refresh_operand_copies()
+
+    def _build_backward(self, N, dt, dev):
+        find = self.find
+        self.dconf = [torch.zeros_like(t) for t in self.conf]
+        self.dreg = [torch.zeros_like(t) for t in self.reg]
+        self.dcenter = [torch.zeros_like(t) for t in self.center]
+        self.scr_y = torch.zeros(self._max_scr, dtype=dt, device=dev)          # d(relu(gn(x))): lives inside one layer
+        self.gn_ws = ops.gn_workspace(N, max(s[5] for s in self.specs), dev)
+        written = set()
+        self.bplan = []
+        for op in reversed(self.plan):
+            kind = op[0]
+            if kind == 'pred':
+                self.bplan.append(op)
+                written.add(find(op[1].gid))
+            elif kind == 'gnconv':
+                _, name, x, y, out = op
+                assert find(out.gid) in written, name
+                self.bplan.append(('gnconv', name, x, y, out, find(x.gid) in written))
+                written.add(find(x.gid))
+            elif kind == 'add':
+                assert find(op[3].gid) in written
+            elif kind == 'resize_add':
+                _, lat, top, y = op
+                assert find(y.gid) in written
+                self.bplan.append(('resize_add', lat, top, y, find(top.gid) in written))
+                written.add(find(top.gid))
+            elif kind == 'pool':
+                _, x, y, k, s, pt, pl = op
+                assert find(y.gid) in written
+                self.bplan.append(op)
+                written.add(find(x.gid))
+            else:
+                self.bplan.append(op)
+        self.g = {}
+        for a in self.acts.values():
+            gid = find(a.gid)
+            if gid in written and gid not in self.g:
+                self.g[gid] = torch.zeros(a.M, a.ld, dtype=dt, device=dev)
+        self.loss_img = torch.zeros(N, device=dev)
+        self.loss_ws = ops.fcos_workspace(self.conf, N, dev)
+        self.gt = None
+
+    def grad_of(self, a):
+        return self.g[self.find(a.gid)]
+
+    # ------------------------------------------------------------------ forward / loss / backward
+    def _gn_relu(self, name, x, y):
+        ops.gn_fwd(x.t, x.ld, y.t, y.ld, x.N, x.H * x.W, x.C, GROUPS, self.param(name + '.gamma'), self.param(name + '.beta'), 1, self.gnsave[name])
+
+    def _forward(self, subtract_mean=True):
+        ops.preprocess(self.images, MEAN_RGB if subtract_mean else (0., 0., 0.), self.input.ld, self.DT, self.input.t)
+        for op in self.plan:
+            kind = op[0]
+            if kind == 'gnconv':
+                _, name, x, y, out = op
+                self._gn_relu(name, x, y)
+                ops.conv2d_fwd(self.desc[name], y.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), out.t, False)
+            elif kind == 'add':
+                _, a, b, y = op
+                ops.add2d(a.t, a.ld, b.t, b.ld, y.t, y.ld, y.M, y.ld)
+            elif kind == 'resize_add':
+                _, lat, top, y = op
+                ops.add2d(lat.t, lat.ld, None, 0, y.t, y.ld, y.M, y.ld)
+                ops.resize_bilinear_fwd(top.t, top.ld, y.t, y.ld, top.N, top.H, top.W, y.H, y.W, top.C, True)
+            elif kind == 'pred':
+                _, c, targets, l, is_exp = op
+                if is_exp:
+                    ops.exp_rows_to_f32(c.t, c.ld, targets[l], c.M, c.C)
+                else:
+                    ops.rows_to_f32(c.t, c.ld, targets[l], c.C, c.M, 0, c.M, c.C)
+            elif kind == 'stem':
+                _, name, src, z, y = op
+                ops.conv2d_fwd(self.desc[name], src.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), z.t, False)
+                self._gn_relu(name, z, y)
+            else:
+                _, x, y, k, s, pt, pl = op
+                ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pl)
+
+    def _loss(self, grad_scale):
+        ops.fcos_loss(self.conf, self.reg, self.center, self.gt, grad_scale, self.loss_img, self.dconf, self.dreg, self.dcenter, self.loss_ws)
+
+    def _backward_iter(self):
+        for op in self.bplan:
+            kind = op[0]
+            if kind == 'pred':
+                _, c, targets, l, is_exp = op
+                if is_exp:
+                    ops.exp_rows_bwd(self.dreg[l], self.reg[l], self.grad_of(c), c.ld, c.M, c.C)
+                else:
+                    d = self.dconf[l] if targets is self.conf else self.dcenter[l]
+                    ops.rows_from_f32(d, c.C, c.M, 0, self.grad_of(c), c.ld, c.M, c.C)
+            elif kind == 'gnconv':
+                _, name, x, y, out, acc = op
+                dz = self.grad_of(out)
+                ops.conv2d_wgrad(self.desc[name], y.t, dz, out.ld, self._flat(name + '.w', self.G), self._flat(name + '.b', self.G))
+                dy = self.scr_y[: y.M * y.ld].view(y.M, y.ld)
+                ops.conv2d_dgrad(self.desc[name], dz, out.ld, self.wt[name], None, dy, False)
+                ops.gn_bwd(x.t, x.ld, y.t, dy, y.ld, self.grad_of(x), x.ld, x.N, x.H * x.W, x.C, GROUPS, self.param(name + '.gamma'),
+                           self.gnsave[name], 1, acc, self._flat(name + '.gamma', self.G), self._flat(name + '.beta', self.G), self.gn_ws)
+                yield name
+            elif kind == 'resize_add':
+                _, lat, top, y, acc = op
+                ops.resize_bilinear_bwd(self.grad_of(y), y.ld, self.grad_of(top), top.ld, top.N, top.H, top.W, y.H, y.W, top.C, acc)
+            elif kind == 'pool':
+                _, x, y, k, s, pt, pl = op
+                ops.maxpool_bwd(x.t, y.t, self.grad_of(y), self.grad_of(x), x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pl)
+            else:                                               # stem: conv -> GN -> ReLU (its bias DOES have a gradient: group norm is not
+                _, name, src, z, y = op                        # invariant to a per-channel shift inside a group)
+                dzs = self.scr_y[: z.M * z.ld].view(z.M, z.ld)
+                ops.gn_bwd(z.t, z.ld, y.t, self.grad_of(y), y.ld, dzs, z.ld, z.N, z.H * z.W, z.C, GROUPS, self.param(name + '.gamma'),
+                           self.gnsave[name], 1, False, self._flat(name + '.gamma', self.G), self._flat(name + '.beta', self.G), self.gn_ws)
+                ops.conv2d_wgrad(self.desc[name], src.t, dzs, z.ld, self._flat(name + '.w', self.G), self._flat(name + '.b', self.G))
+                yield name
+
+    # ------------------------------------------------------------------ public: training
+    def set_batch(self, images, ground_truth):
+        images = torch.as_tensor(images, dtype=torch.float32)
+        if self.data_format == 'channels_first' and images.shape[1] == 3:
+            images = images.permute(0, 2, 3, 1)
+        assert tuple(images.shape) == tuple(self.images.shape), images.shape
+        self.images.copy_(images, non_blocking=True)
+        gt = torch.as_tensor(ground_truth, dtype=torch.float32)
+        if self.gt is None or self.gt.shape != gt.shape:
+            self.gt = torch.zeros(gt.shape, device=self.dev)
+        self.gt.copy_(gt, non_blocking=True)
+
+    def train_step(self, lr):
+        """one optimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor"""
+        if self.dist is not None:
+            self.dist.begin_step()
+        self.G.zero_()
+        self._forward()
+        self._loss(1.0 / self.loss_divisor_batch)
+        for name in self._backward_iter():
+            if self.dist is not None:
+                self.dist.layer_ready(name)
+        if self.dist is not None:
+            self.dist.finish_step()
+        ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial, self.Pc if self.DT == BF16 else None)
+        ops.sum_f32(self.l2_partial, self.l2_sum)
+        self._fp_batch.run()
+        self.global_step += 1
+        return self.loss_img.mean() + self.weight_decay * self.l2_sum                              # FCOS.py:186-187
+
+    def train_one_epoch(self, lr):
+        if callable(self.train_initializer):
+            self.train_initializer()
+        mean_loss = []
+        num_iters = self.num_train // self.batch_size
+        it = iter(self.train_iterator)
+        for i in range(num_iters):
+            try:
+                images, gt = next(it)
+            except StopIteration:
+                it = iter(self.train_iterator)
+                images, gt = next(it)
+            self.set_batch(images, gt)
+            loss = float(self.train_step(lr).item())
+            if self.verbose:
+                sys.stdout.write('\r>> ' + 'iters ' + str(i) + str('/') + str(num_iters) + ' loss ' + str(loss))
+                sys.stdout.flush()
+            mean_loss.append(loss)
+        if self.verbose:
+            sys.stdout.write('\n')
+        return np.mean(mean_loss)
+
+    # ------------------------------------------------------------------ public: inference
+    def test_one_image(self, images):
+        images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+        if self.data_format == 'channels_first' and images.shape[1] == 3:
+            images = images.permute(0, 2, 3, 1)
+        assert self.batch_size == 1 and tuple(images.shape) == tuple(self.images.shape), images.shape
+        self.images.copy_(images)
+        self._forward(subtract_mean=bool(self.config.get('test_subtract_mean', False)))
+        scores, bbox, cid = heads.fcos_detect([t[0] for t in self.conf], [t[0] for t in self.reg], [t[0] for t in self.center],
+                                              self.nms_score_threshold, self.nms_max_boxes, self.nms_iou_threshold)
+        return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
+
+    # ------------------------------------------------------------------ checkpoints / data parallel
+    def save_weight(self, mode, path):
+        assert (mode in ['latest', 'best'])
+        dirname = os.path.dirname(path)
+        if dirname and not os.path.exists(dirname):
+            os.makedirs(dirname)
+            print(dirname, 'does not exist, create it done')
+        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': dict(self.pinfo)}
+        torch.save(blob, path + '-' + str(self.global_step))
+        print('save', mode, 'model in', path, 'successfully')
+
+    def load_weight(self, path):
+        blob = torch.load(path, map_location='cpu', weights_only=False)
+        self.load_oracle_params(blob['params'])
+        if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
+            self.Mom.copy_(blob['momentum'].to(self.dev))
+        self.global_step = int(blob.get('global_step', 0))
+        print('load weight', path, 'successfully')
+
+    def load_pretrained_weight(self, path):
+        """FCOS.py:434-436 restores the 'backone' variables: here the stem + unit layers of a saved file"""
+        blob = torch.load(path, map_location='cpu', weights_only=False)['params']
+        nb = 1 + 4 * sum(BLOCKS)
+        self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < nb})
+        print('load pretrained weight', path, 'successfully')
+
+    def attach_data_parallel(self, group=None, bucket_mb=25):
+        from .dist import GradAllReducer
+        self.dist = GradAllReducer(self, group, bucket_mb)
+        self.loss_divisor_batch = self.batch_size * self.dist.world
+        return self.dist

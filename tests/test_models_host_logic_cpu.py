@@ -83,3 +83,36 @@ def test_retinanet_training_step_host_logic():
         after = m.export_params()
         for k in ('l0.w', 'l30.gamma', 'l65.w', 'l76.b', 'l121.w', 'l1.mmean', 'l121.mvar'):
             assert _rel(after[k], q[k]) < 1e-4, k
+
+
+def test_fcos_training_step_host_logic():
+    import odtk
+    from oracle import fcos_net_ref as NR
+    from oracle import fcos_ref as FR
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'data_shape': [128, 160, 3], 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+           'batch_size': 2, 'nms_score_threshold': 0.5, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False, 'compute_dtype': 'f32',
+           'device': 'cpu'}
+    g = torch.Generator().manual_seed(130)
+    imgs = (torch.rand(2, 128, 160, 3, generator=g) * 255).round()
+    gt = FR.synthetic_gt(2, 128, 131)
+    p = NR.init_params(13)
+    with mock_ops.installed():
+        m = odtk.FCOS(cfg, {'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        loss = float(m.train_step(0.001))
+        masks = {}
+        for name, *_ in NR.layer_specs():
+            a = m.acts[name if name == 'l0' else name + '.y']
+            masks[name] = (a.t[:, :a.C] > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
+        q = {k: v.clone() for k, v in p.items()}
+        mom = {k: torch.zeros_like(v) for k, v in p.items()}
+        total, data, grads = NR.train_step(q, mom, imgs, gt, 0.001, relu_masks=masks)
+        assert abs(loss - total) < 1e-4 * abs(total), (loss, total)
+        for k in p:
+            want = grads[k] - 1e-4 * p[k]
+            assert _rel(m.get_param(k, m.G), want) < 5e-3 or float(want.norm()) < 1e-7, k
+        after = m.export_params()
+        for k in ('l0.w', 'l0.b', 'l30.gamma', 'l65.w', 'l79.b', 'l80.w', 'l85.w', 'l129.w'):
+            assert _rel(after[k], q[k]) < 1e-4, k

@@ -464,17 +464,65 @@ class FCOS:
         return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
 
     # ------------------------------------------------------------------ checkpoints / data parallel
+    def _logical(self, name, buf):
+        v = self.get_param(name, buf)
+        return np.ascontiguousarray((v.permute(1, 2, 3, 0) if name.endswith('.w') else v).numpy())
+
+    def export_tf_variables(self):
+        """what the reference's `tf.train.Saver()` (FCOS.py:390-394) writes: every variable under its name (reference_variable_map),
+        global_step, and the momentum slots `<variable>/Momentum` created under the 'head' scope of the graph (:111, :188)"""
+        out = OrderedDict()
+        for tfname, ours in reference_variable_map().items():
+            out[tfname] = self._logical(ours, self.P)
+            out[f'head/{tfname}/Momentum'] = self._logical(ours, self.Mom)
+        out['global_step'] = np.asarray(self.global_step, dtype=np.int32)
+        return out
+
+    def load_tf_checkpoint(self, path, backbone_only=False):
+        from .tf_checkpoint import NewCheckpointReader
+        reader = NewCheckpointReader(str(path))
+        names = reader.get_variable_to_shape_map()
+        for tfname, ours in reference_variable_map().items():
+            if backbone_only and not tfname.startswith('backone'):
+                continue
+            v = torch.from_numpy(reader.get_tensor(tfname))
+            self.set_param(ours, v.permute(3, 0, 1, 2).contiguous() if ours.endswith('.w') else v)
+            slot = [k for k in names if k.endswith(tfname + '/Momentum')]
+            if slot and not backbone_only:
+                mv = torch.from_numpy(reader.get_tensor(slot[0]))
+                dst = self.param(ours, self.Mom)
+                if ours.endswith('.w'):
+                    dst.zero_()
+                    dst[..., : mv.shape[2]] = mv.permute(3, 0, 1, 2).to(self.dev)
+                else:
+                    dst.copy_(mv.to(self.dev).view(dst.shape))
+        if not backbone_only and reader.has_tensor('global_step'):
+            self.global_step = int(reader.get_tensor('global_step'))
+        self._refresh_operand_copies()
+
     def save_weight(self, mode, path):
+        """FCOS.py:418-428.  config['checkpoint_format'] = 'tf' writes tf.train.Saver files (tf_checkpoint.py)."""
         assert (mode in ['latest', 'best'])
         dirname = os.path.dirname(path)
         if dirname and not os.path.exists(dirname):
             os.makedirs(dirname)
             print(dirname, 'does not exist, create it done')
+        if self.config.get('checkpoint_format', 'torch') == 'tf':
+            from . import tf_checkpoint
+            prefix = path + '-' + str(self.global_step)
+            tf_checkpoint.write_bundle(prefix, self.export_tf_variables())
+            tf_checkpoint.update_checkpoint_state(prefix)
+            print('save', mode, 'model in', path, 'successfully')
+            return
         blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': dict(self.pinfo)}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
     def load_weight(self, path):
+        if os.path.exists(str(path) + '.index'):                 # a tf.train.Saver checkpoint prefix
+            self.load_tf_checkpoint(path)
+            print('load weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=False)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
@@ -484,6 +532,10 @@ class FCOS:
 
     def load_pretrained_weight(self, path):
         """FCOS.py:434-436 restores the 'backone' variables: here the stem + unit layers of a saved file"""
+        if os.path.exists(str(path) + '.index'):
+            self.load_tf_checkpoint(path, backbone_only=True)
+            print('load pretrained weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=False)['params']
         nb = 1 + 4 * sum(BLOCKS)
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < nb})
@@ -494,3 +546,27 @@ class FCOS:
         self.dist = GradAllReducer(self, group, bucket_mb)
         self.loss_divisor_batch = self.batch_size * self.dist.world
         return self.dist
+
+
+def reference_variable_map():
+    """name of every variable of the reference's FCOS graph -> our parameter name.  Convs: tf.layers default names count over the whole
+    graph (conv2d ... conv2d_129); group norms: `variable_scope(None, 'GroupNorm')` counts PER enclosing scope (GroupNorm, GroupNorm_1, ...).
+    Scopes: 'backone' (sic, FCOS.py:71) with 'block<b>_unit<u>/conv_branch|identity_branch' (:504-513), 'pyramid' (:98), 'head/classifier_head' and
+    'head/regress_head' (:351, :358; AUTO_REUSE shares nothing).  Pinned by tests/golden/fcos_variables.json (from the reference's own class)."""
+    scopes = ['backone']
+    for b, blocks in enumerate(BLOCKS):
+        for u in range(blocks):
+            base = f'backone/block{b + 1}_unit{u + 1}'
+            scopes += [base + '/conv_branch'] * 3 + [base + '/identity_branch']
+    scopes += ['pyramid'] * 10
+    for _ in range(5):
+        scopes += ['head/classifier_head'] * 6 + ['head/regress_head'] * 5
+    m, gn_count = OrderedDict(), {}
+    for i, scope in enumerate(scopes):
+        sfx = '' if i == 0 else f'_{i}'
+        m[f'{scope}/conv2d{sfx}/kernel'], m[f'{scope}/conv2d{sfx}/bias'] = f'l{i}.w', f'l{i}.b'
+        k = gn_count.get(scope, 0)
+        gn_count[scope] = k + 1
+        gn = f'{scope}/GroupNorm' + (f'_{k}' if k else '')
+        m[gn + '/beta'], m[gn + '/gamma'] = f'l{i}.beta', f'l{i}.gamma'
+    return m

@@ -213,3 +213,47 @@ def test_snappy_compressed_tables_and_cli(tmp_path, capsys):
     out = capsys.readouterr().out
     assert 'a/kernel  float32  [3, 3, 4, 8]' in out and '# 2 tensors, 289 elements, format V2' in out
     assert T.main([prefix, 'global_step']) == 0 and 'int32' in capsys.readouterr().out
+
+
+def test_fcos_variable_map_and_saver_roundtrip_through_mocked_launches(tmp_path):
+    """odtk.fcos.reference_variable_map against the 521 variables of the reference's own FCOS class (tests/golden/fcos_variables.json;
+    group norms are numbered per scope), and a tf.train.Saver round trip of the class on the CPU (tests/mock_ops.py)"""
+    import json
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mock_ops
+    import odtk
+    from odtk.fcos import layer_specs, reference_variable_map
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fcos_variables.json')))
+    m = reference_variable_map()
+    assert set(m) | {'global_step'} == set(want) and len(m) == 520
+    specs = {s[0]: s for s in layer_specs(20)}
+    for name, ours in m.items():
+        layer, kind = ours.split('.')
+        _, cin, cout, k, _, gnc, _ = specs[layer]
+        assert want[name]['shape'] == ([k, k, cin, cout] if kind == 'w' else ([cout] if kind == 'b' else [gnc])), name
+    cfg = {'mode': 'train', 'data_shape': [64, 64, 3], 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+           'batch_size': 1, 'nms_score_threshold': 0.5, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False, 'device': 'cpu',
+           'checkpoint_format': 'tf'}
+    prov = {'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    with mock_ops.installed():
+        a = odtk.FCOS(dict(cfg, seed=1), prov)
+        a.Mom.copy_(torch.randn(a.Mom.shape))
+        a.global_step = 7
+        path = str(tmp_path / 'ck' / 'fcos.ckpt')
+        a.save_weight('latest', path)
+        r = T.NewCheckpointReader(path + '-7')
+        shapes = r.get_variable_to_shape_map()
+        assert all(shapes[n] == v['shape'] for n, v in want.items()) and len(shapes) == 2 * 520 + 1
+        b = odtk.FCOS(dict(cfg, seed=2), prov)
+        b.load_weight(path + '-7')
+        pa, pb = a.export_params(), b.export_params()
+        assert all(torch.equal(pa[k], pb[k]) for k in pa) and b.global_step == 7
+        for k in ('l0.w', 'l64.gamma', 'l129.b'):
+            assert torch.equal(a.get_param(k, a.Mom), b.get_param(k, b.Mom)), k
+        c = odtk.FCOS(dict(cfg, seed=3), prov)
+        before = c.export_params()
+        c.load_pretrained_weight(path + '-7')
+        pc = c.export_params()
+        assert all(torch.equal(pc[k], pa[k] if int(k[1:].split('.')[0]) < 65 else before[k]) for k in pa)

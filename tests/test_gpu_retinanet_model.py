@@ -139,11 +139,11 @@ def test_bf16_step_and_class_surface(dev, tmp_path):
         a, b = m.get_param(k, m.G).reshape(-1), (grads[k] - 1e-4 * p[k]).reshape(-1)
         cos.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-12)))
     print('bf16 gradient cosines', cos)
-    # bf16 engine: forward and loss track the f32 oracle, and so do the gradients of the layers next to the loss (l76: the class
-    # output of p3).  One batch-norm backward further down the direction is already mostly lost (cos 0.6, then 0.3, 0.1 ...):
-    # at the pi-initialisation every anchor pushes "background", d(logits) has a per-channel common mode that the batch-norm
-    # backward subtracts, and the bf16 storage of dy between dgrad and that subtraction keeps 8 bits of a residual that is
-    # ~1 % of the stored value.  The f32 engine is the validated one for this model; nothing is asserted below l76.
+    # bf16 engine: the loss tracks the f32 oracle and so do the gradients of the layers next to it (l76: the class output of p3); one
+    # layer further down the direction is mostly lost (cos 0.5, 0.3, 0.1 ...).  Not a kernel bug -- tests/mock_ops.py in bf16 storage
+    # mode gives the same cosines on the CPU: the reference's units have a conv on EVERY shortcut, at random initialisation the stack is
+    # chaotic (the error of relu(bn(x)) doubles every ~8 layers: 0.3 % after the stem, 90 % at the end of the backbone) and bf16's
+    # rounding is amplified to O(1).  f32 is the validated engine for this model; nothing is asserted below l76.
     assert cos[1] > 0.99 and cos[2] > 0.99
     l0 = m.train_one_epoch(0.001)
     assert np.isfinite(l0) and m.global_step == 3

@@ -167,8 +167,9 @@ class SSD300:
         # optional: filter gradients on a second HIP stream (wgrad(L) only needs dy(L) and the stored input of L, nothing
         # on the dgrad chain needs its result before the optimizer).  Measured neutral on MI355X (both chains are
         # full-chip kernels with one workgroup per CU), so it is off by default; config key 'wgrad_stream'.
-        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if config.get('wgrad_stream', False) else None
-        self._side = torch.cuda.Stream(device=self.dev)          # box matching under the forward pass
+        on_gpu = self.dev.type == 'cuda'      # (a 'cpu' device only gets past ops._p with the mocked library of tests/mock_ops.py: host-logic tests)
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (on_gpu and config.get('wgrad_stream', False)) else None
+        self._side = torch.cuda.Stream(device=self.dev) if on_gpu else None          # box matching under the forward pass
         self._g_front = self._g_back = None
         self._g_back_segs = None
         self._eager_steps = 0
@@ -615,13 +616,13 @@ class SSD300:
     def _step_front(self):
         self.G.zero_()
         # the matching only depends on the ground truth: it runs on a second stream under the forward pass
-        main = torch.cuda.current_stream()
         if self.m_best is None or self.m_best.shape[1] != self.gt.shape[1]:
             self.m_best = torch.zeros(self.batch_size, self.gt.shape[1], dtype=torch.int32, device=self.dev)
         if not self.config.get('match_stream', False):     # measured: no gain (a concurrent small kernel slows the convs)
             self._forward(True)
             self._loss(1.0 / self.loss_divisor_batch)
             return
+        main = torch.cuda.current_stream()
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             self._match()

@@ -131,3 +131,73 @@ def test_yolov3_gradient_buckets_world2():
     assert launched == boundary                             # a bucket's all-reduce starts at the layer that closes it
     idx = [int(n[1:]) for n in boundary]
     assert idx == sorted(idx, reverse=True) and idx[-1] == 0
+
+
+def _yolo_model_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import mock_ops
+    import odtk
+    torch.set_num_threads(4)
+    m, batch = _yolo_cpu_model(rank)
+    with mock_ops.installed():
+        m.attach_data_parallel(bucket_mb=16)
+        m.set_batch(*batch)
+        loss = float(m.train_step(0.002))
+    torch.save({'P': m.P.clone(), 'G': m.G.clone(), 'loss': loss}, os.path.join(out_dir, f'm{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def _yolo_cpu_model(rank):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import mock_ops
+    import odtk
+    from oracle import yolov3_ref as YR
+    cfg = {'mode': 'train', 'data_shape': [64, 64, 3], 'num_classes': 20, 'weight_decay': 5e-4, 'keep_prob': 0.5, 'data_format': 'channels_last',
+           'batch_size': 1, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'num_priors': 3, 'nms_score_threshold': 0.5,
+           'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'priors': YR.PRIORS_PX, 'verbose': False, 'compute_dtype': 'f32', 'device': 'cpu',
+           'use_graph': False, 'seed': 3}
+    g = torch.Generator().manual_seed(800 + rank)
+    batch = ((torch.rand(1, 64, 64, 3, generator=g) * 255).round(), YR.synthetic_gt(1, 64, 850 + rank, max_obj=3))
+    with mock_ops.installed():
+        m = odtk.YOLOv3(cfg, {'num_train': 1, 'train_generator': [], 'val_generator': None, 'num_val': 0})
+    return m, batch
+
+
+def test_yolov3_model_data_parallel_world2_on_cpu(tmp_path):
+    """the whole data-parallel training step of the YOLOv3 class on two gloo ranks, every libodtk launch mocked on the CPU: replicas end
+    identical, and the exchanged gradient is the sum of the ranks' local gradients with the loss divided by the GLOBAL batch"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mock_ops
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_yolo_model_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    a, b = torch.load(os.path.join(tmp_path, 'm0.pt')), torch.load(os.path.join(tmp_path, 'm1.pt'))
+    assert torch.equal(a['P'], b['P']) and torch.equal(a['G'], b['G'])
+    total = None
+    threads = torch.get_num_threads()
+    torch.set_num_threads(4)                     # as in the workers: the same reduction order inside the CPU convolutions
+    for rank in range(2):
+        m, batch = _yolo_cpu_model(rank)
+        with mock_ops.installed():
+            m.set_batch(*batch)
+            m.G.zero_(); m._forward(True); m._loss(0.5 / 2)
+            for _ in m._backward_iter():
+                pass
+        total = m.G.clone() if total is None else total + m.G
+    torch.set_num_threads(threads)
+    # batch 1 at 64 x 64 puts batch norms over 4 samples into the model: a leaky-ReLU input that lands on the other side of 0 in one of the
+    # two computations moves the gradient by per cents (tests/test_gpu_yolov3.py); identical thread counts usually give identical bits
+    assert float((a['G'] - total).norm()) < 5e-2 * float(total.norm())

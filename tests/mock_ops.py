@@ -273,6 +273,46 @@ def fcos_loss(conf, reg, center, gt, grad_scale, loss, d_conf, d_reg, d_center, 
         dst.copy_(g if g is not None else torch.zeros_like(dst))
 
 
+# ---- inference tails: decode kernels and the batched per-class NMS
+def nms_batched(boxes, box_stride, scores, score_bstride, score_estride, valid, valid_bstride, valid_estride, valid_value, n, B,
+                max_out_dev, max_out_stride, max_out_const, iou_thr, out_idx, cap, out_cnt):
+    """tf.image.non_max_suppression for B problems with the strided operand addressing of odtk_nms_batched (oracle NMS inside);
+    called with no-op intent by the mocked SSD loss path (max_out_dev given): then nothing is done"""
+    if max_out_dev is not None:
+        return
+    from oracle import ssd300_ref as R
+    bx, sc = boxes.reshape(-1), scores.reshape(-1)
+    vd = valid.reshape(-1) if valid is not None else None
+    idx = torch.arange(n)
+    for b in range(B):
+        bb = bx[b * box_stride: b * box_stride + 4 * n].reshape(n, 4)
+        ss = sc[b * score_bstride + idx * score_estride]
+        ok = torch.ones(n, dtype=torch.bool) if vd is None else (vd[b * valid_bstride + idx * valid_estride] == valid_value)
+        rows = torch.nonzero(ok).flatten()
+        sel = torch.from_numpy(R.nms(bb[rows].numpy(), ss[rows].numpy(), int(max_out_const), float(iou_thr)).astype('int64'))
+        k = min(sel.numel(), cap)
+        out_idx[b, :k] = rows[sel[:k]].to(out_idx.dtype)
+        out_cnt[b] = k
+
+
+def yolov3_decode_candidates(preds, priors_flat, decode_scale):
+    from oracle import yolov3_ref as YR
+    assert [float(v) for v in decode_scale] == [32., 32., 16.]
+    pri = [[[priors_flat[(l * 3 + a) * 2] * YR.STRIDE[l], priors_flat[(l * 3 + a) * 2 + 1] * YR.STRIDE[l]] for a in range(3)] for l in range(3)]
+    return YR.decode_candidates([p.float() for p in preds], num_classes=preds[0].shape[-1] - 5, priors_px=pri)
+
+
+def fcos_decode_candidates(conf, reg, center):
+    from oracle import fcos_ref as FR
+    return FR.decode_candidates([c.float() for c in conf], [r.float() for r in reg], [z.float() for z in center])
+
+
+def retina_decode(pconf, pbox, yx, hw, thr):
+    from oracle import retinanet_ref as RR
+    conf, boxes, keep, cand = RR.decode_candidates(pbox[:, :2], pbox[:, 2:], pconf, (None, None, yx, hw), thr, num_classes=pconf.shape[1])
+    return conf.contiguous(), boxes.contiguous(), keep.to(torch.uint8), cand.to(torch.uint8)
+
+
 # ---- SSD300-specific launches
 _POOL_ARGMAX = {}
 
@@ -320,10 +360,6 @@ def ssd_match(*a):
 
 
 def softmax_ce_const(*a):
-    pass
-
-
-def nms_batched(*a):
     pass
 
 

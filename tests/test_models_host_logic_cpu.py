@@ -148,3 +148,70 @@ def test_ssd300_training_step_host_logic():
             # same bound as the GPU test: a single ReLU flip of a ~1e-6 pre-activation in front of a batch norm over 18-722 samples
             # moves the upstream gradients by up to a per cent (the oracle has no dictated-region mode for this model)
             assert _rel(after[k] - p[k], step) < 3e-2, k
+
+
+def test_inference_tails_host_logic():
+    """test_one_image of YOLOv3, RetinaNet and FCOS on the CPU (forward in inference mode + heads.py: decode -> threshold -> batched per-class
+    NMS -> [scores, bbox, class_id] in the reference's order) against the oracles' detections"""
+    import numpy as np
+    import odtk
+    from oracle import detect_common as DC
+    from oracle import fcos_net_ref as FN, fcos_ref as FR
+    from oracle import retinanet_net_ref as RN, retinanet_ref as RR
+    from oracle import yolov3_net_ref as YN, yolov3_ref as YR
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(5)
+
+    def check(got, want, boxes_tol=1e-2):
+        assert len(want[0]) > 0 and len(got[0]) == len(want[0])
+        assert np.array_equal(got[2], want[2].numpy())
+        np.testing.assert_allclose(got[0], want[0].numpy(), atol=1e-4)
+        np.testing.assert_allclose(got[1], want[1].numpy(), rtol=1e-3, atol=boxes_tol)
+    with mock_ops.installed():
+        # YOLOv3
+        p = YN.init_params(8)
+        imgs = (torch.rand(1, 128, 128, 3, generator=g) * 255).round()
+        stats = {}
+        with torch.no_grad():
+            YN.forward(p, imgs + 20 * torch.randn(imgs.shape, generator=g), True, stats, subtract_mean=False)
+        for k, (mean, var) in stats.items():
+            p[k + '.mmean'], p[k + '.mvar'] = mean.clone(), var.clone()
+        cfg = {'mode': 'test', 'data_shape': [128, 128, 3], 'num_classes': 20, 'weight_decay': 5e-4, 'keep_prob': 0.5, 'data_format': 'channels_last',
+               'batch_size': 1, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'num_priors': 3, 'nms_score_threshold': 0.5,
+               'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'priors': YR.PRIORS_PX, 'verbose': False, 'compute_dtype': 'f32', 'device': 'cpu'}
+        m = odtk.YOLOv3(cfg, None)
+        m.load_oracle_params(p)
+        check(m.test_one_image(imgs.numpy()), YN.test_one_image(p, imgs, 0.5, 10, 0.5))
+        # FCOS
+        p = FN.init_params(19)
+        for i in (79, 90, 101, 112, 123):
+            p[f'l{i}.b'] = p[f'l{i}.b'] + 4.0; p[f'l{i + 1}.b'] = p[f'l{i + 1}.b'] + 4.0; p[f'l{i + 6}.w'] = p[f'l{i + 6}.w'] * 0.05
+        imgs = (torch.rand(1, 128, 160, 3, generator=g) * 255).round()
+        cfg = {'mode': 'test', 'data_shape': [128, 160, 3], 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+               'batch_size': 1, 'nms_score_threshold': 0.3, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False, 'device': 'cpu'}
+        m = odtk.FCOS(cfg, None)
+        m.load_oracle_params(p)
+        with torch.no_grad():
+            conf, reg, center = FN.forward(p, imgs, subtract_mean=False)
+        pconf, pbbox = FR.decode_candidates([c[0] for c in conf], [r[0] for r in reg], [z[0] for z in center])
+        check(m.test_one_image(imgs.numpy()), DC.per_class_nms(pconf, pbbox, 19, 0.3, 10, 0.45))
+        # RetinaNet
+        p = RN.init_params(9)
+        imgs = (torch.rand(1, 128, 128, 3, generator=g) * 255).round()
+        stats = {}
+        with torch.no_grad():
+            RN.forward(p, imgs + 20 * torch.randn(imgs.shape, generator=g), True, stats, subtract_mean=False)
+        for k, (mean, var) in stats.items():
+            p[k + '.mmean'], p[k + '.mvar'] = mean.clone(), var.clone()
+        for i in (81, 91, 101, 111, 121):
+            p[f'l{i}.w'] = p[f'l{i}.w'] * 0.02
+        cfg = {'is_bottleneck': True, 'residual_block_list': [3, 4, 6, 3], 'init_conv_filters': 16, 'mode': 'test', 'is_pretraining': False,
+               'data_shape': [128, 128, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'data_format': 'channels_last', 'batch_size': 1,
+               'gamma': 2.0, 'alpha': 0.25, 'nms_score_threshold': 0.15, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False, 'device': 'cpu'}
+        m = odtk.RetinaNet(cfg, None)
+        m.load_oracle_params(p)
+        with torch.no_grad():
+            pc, pb = RN.forward(p, imgs, False, subtract_mean=False)
+        anc = RR.anchors([128, 128, 3], RR.pyramid_shapes(128, 128))
+        conf, boxes, keep, _ = RR.decode_candidates(pb[0, :, :2], pb[0, :, 2:], pc[0], anc, 0.15)
+        check(m.test_one_image(imgs.numpy()), DC.per_class_nms(conf, boxes, 20, 0.15, 10, 0.45, row_mask=keep), boxes_tol=5e-2)

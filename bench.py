@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the SSD300 VGG-16 training hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 without a launcher it starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one full training step (preprocess + forward + loss incl. hard-negative-mining NMS +
@@ -86,11 +86,12 @@ class ConvTimer:
             return r
         return f
 
-    def per_step(self, steps):
-        """One step's launches with the mean duration of each launch over the recorded steps, first step and the single
-        slowest sample dropped (the launch sequence of a step is fixed, so record i and record i + launches_per_step are
-        the same launch).  A slow outlier -- a clock ramp, a page-in behind the first eager launch after graph replay --
-        must not move the roofline line; otherwise this is the plain average rocprofv3 --stats reports."""
+    def per_step(self, steps, trimmed=False):
+        """One step's launches with the mean duration of each launch over the recorded steps (the launch sequence of a
+        step is fixed, so record i and record i + launches_per_step are the same launch).  Default: the PLAIN average over
+        every recorded step but the first (the first eager step after graph replay is a warm-up of the eager path) --
+        what `rocprofv3 --kernel-trace --stats` reports for the kernel.  trimmed=True additionally drops the slowest sample
+        of every launch; it is reported next to the plain number, never instead of it."""
         n = len(self.records)
         per = n // steps if steps > 0 and n % steps == 0 else n
         reps = n // per
@@ -98,17 +99,18 @@ class ConvTimer:
         for i in range(per):
             ts = [self.records[i + r * per][3].elapsed_time(self.records[i + r * per][4]) * 1e-3 for r in range(reps)]
             if reps >= 3:
-                ts = ts[1:]                            # the first eager step after graph replay pays one-off costs
-            ts.sort()
-            if len(ts) >= 4:
-                ts = ts[:-1]                           # ... and one outlier per launch may go
+                ts = ts[1:]
+            if trimmed:
+                ts.sort()
+                if len(ts) >= 4:
+                    ts = ts[:-1]
             kind, kern, fl, _, _, ab, shp = self.records[i]
             out.append((kind, kern, fl, sum(ts) / len(ts), ab, shp))
         return out
 
-    def summary(self, steps):
+    def summary(self, steps, trimmed=False):
         per_kernel, per_pass = {}, {}
-        for kind, kern, fl, t, ab, _ in self.per_step(steps):
+        for kind, kern, fl, t, ab, _ in self.per_step(steps, trimmed):
             for d, k in ((per_kernel, kern), (per_pass, kind)):
                 a = d.setdefault(k, [0.0, 0.0, 0, 0.0]); a[0] += fl; a[1] += t; a[2] += 1; a[3] += ab
         return per_kernel, per_pass
@@ -126,15 +128,24 @@ class ConvTimer:
 
     def roofline(self, steps, peak, whole_step_frac):
         per_kernel, per_pass = self.summary(steps)
+        trimmed_kernel, _ = self.summary(steps, trimmed=True)
         steps = 1                                   # summary() is per step already
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
         fl, t, n, ab = per_kernel[dom]
+        t_trim = trimmed_kernel[dom][1]
+        pmc = pmc_traffic(dom)
         tot_f = sum(v[0] for v in per_kernel.values()); tot_t = sum(v[1] for v in per_kernel.values())
         return {
             'bound': 'mfma', 'kernel': dom,
             'achieved': round(fl / t / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': round(fl / t / peak, 4),
-            'traffic': pmc_traffic(dom),
+            'traffic': pmc,
+            # SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (launch duration x 2.4 GHz x 1024 SIMDs)
+            'mfma_busy_pct': None if (pmc is None or not pmc.get('mfma_busy_cycles')) else
+            round(100.0 * pmc['mfma_busy_cycles'] / ((t / n) * 2.4e9 * 1024), 1),
+            'hbm_gbps': None if pmc is None else round(pmc['hbm_bytes'] / (t / n) / 1e9, 1),
+            'hbm_frac_of_8TBps': None if pmc is None else round(pmc['hbm_bytes'] / (t / n) / 8e12, 4),
             'launches_per_step': n // steps, 'avg_launch_us': round(t / n * 1e6, 2),
+            'avg_launch_us_trimmed': round(t_trim / n * 1e6, 2), 'frac_trimmed': round(fl / t_trim / peak, 4),
             'algorithmic_gflop_per_launch': round(fl / n / 1e9, 2),
             'algorithmic_mb_per_launch': round(ab / n / 1e6, 1),
             'family': {'kernels': 'all conv kernels (fwd + dgrad + wgrad, every layer)',
@@ -171,7 +182,9 @@ def pmc_traffic(kernel):
             name, e = best
             return {'hbm_read_bytes': int(e['hbm_read_bytes_corrected']), 'hbm_write_bytes': int(e['hbm_write_bytes']),
                     'hbm_bytes': int(e['hbm_read_bytes_corrected'] + e['hbm_write_bytes']),
-                    'source': os.path.relpath(f, ROOT) + ' :: ' + name}
+                    'mfma_busy_cycles': e.get('SQ_VALU_MFMA_BUSY_CYCLES'),
+                    'source': 'STATIC (committed rocprofv3 --pmc passes of this command, not re-measured in this run): '
+                              + os.path.relpath(f, ROOT) + ' :: ' + name}
     return None
 
 
@@ -189,11 +202,22 @@ def main():
     ap.add_argument('--match-stream', action='store_true', help='A/B: box matching on a second HIP stream under the forward pass')
     ap.add_argument('--sync-bn', action='store_true', help='N > 1: batch-norm statistics over all replicas (SURVEY 8e option B; eager launches)')
     ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
+    ap.add_argument('--bucket-mb', type=int, default=25, help='N > 1: gradient all-reduce bucket size')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='exercise ONLY the launcher / rendezvous / timing / one-JSON-line skeleton with a dummy all-reduce step '
+                         '(gloo when there is no GPU); prints metric "launch-check", never a measurement')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], need_gpus=not args.launch_check))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; pass the same N to both '
+                         f'(or drop the launcher: `python bench.py --gpus N` starts its own ranks)')
+    if args.launch_check:
+        return launch_check(args, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -201,8 +225,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import odtk
     from odtk import ops
@@ -216,7 +240,7 @@ def main():
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)
     if world > 1:
-        model.attach_data_parallel(sync_bn=args.sync_bn)
+        model.attach_data_parallel(bucket_mb=args.bucket_mb, sync_bn=args.sync_bn)
     images, gt = synthetic_batch(B, 1000 + rank, dev)
     model.set_batch(images, gt)
 
@@ -262,11 +286,13 @@ def main():
         model.use_graph = saved
         model.wgrad_stream = saved_side
     loss = final_loss_t
+    comm = None
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        comm = comm_metrics(model, args, lr, barrier, dt / args.steps * 1e3, dev)
     final_loss = float(loss.item())
 
     if rank == 0:
@@ -291,12 +317,140 @@ def main():
                     f.write(timer.table(min(args.steps, 5) + 1) + '\n')
             out['roofline']['measured_on'] = (f'{min(args.steps, 5) + 1} eager steps right after the timed region '
                                               '(HIP events per conv launch on the launch stream; per-launch mean without the first step and the slowest sample)')
+        if comm is not None:
+            out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch_ranks(n, argv, need_gpus=True):
+    """`python bench.py --gpus N` without torchrun: start N copies of this script, one rank per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment, exactly what torch.distributed.run sets), rank 0 inherits stdout so that its ONE
+    JSON line is this process's output.  Returns the exit code (first failing rank's; the others are then terminated by PID)."""
+    import subprocess
+    if need_gpus and (not torch.cuda.is_available() or torch.cuda.device_count() < n):
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        print(f'bench.py: --gpus {n} but only {have} GPU(s) visible on this node', file=sys.stderr)
+        return 2
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), ODTK_BENCH_LAUNCHER='self')
+    env0.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this driver (RCCL needs it)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in live:                     # one rank failed: the others would hang in the next collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def launch_check(args, world, rank, local_rank):
+    """--launch-check: the launcher, the rendezvous, barrier + max-over-ranks timing and the one-JSON-line contract with a dummy
+    step (an all-reduce of 1 M floats).  gloo on a box without GPUs -- this is what tests/test_bench_launch_cpu.py runs."""
+    import torch.distributed as dist
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    dev = torch.device('cuda', local_rank) if use_gpu else torch.device('cpu')
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl' if use_gpu else 'gloo', rank=rank, world_size=world,
+                                **({'device_id': dev} if use_gpu else {}))
+    buf = torch.ones(1 << 20, device=dev)
+
+    def barrier():
+        if use_gpu:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        if world > 1:
+            dist.all_reduce(buf)
+            buf.mul_(1.0 / world)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ok = bool(torch.allclose(buf, torch.ones_like(buf)))
+    if rank == 0:
+        print(json.dumps({'metric': 'launch-check', 'value': round(args.steps / dt, 2), 'unit': 'dummy steps/sec', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'launcher / rendezvous self-check (1 M-float all-reduce per step); NOT a measurement'},
+                          'comm': {'backend': dist.get_backend() if world > 1 else None,
+                                   'world_size': dist.get_world_size() if world > 1 else 1,
+                                   'launcher': os.environ.get('ODTK_BENCH_LAUNCHER', 'external'), 'allreduce_ok': ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def comm_metrics(model, args, lr, barrier, ms_step, dev):
+    """N > 1, after the timed region: what RCCL saw (world size, backend), the gradient all-reduce's own time per step
+    (every bucket back to back, nothing to overlap with), the step time with the collectives switched off, and from the two
+    the fraction of the all-reduce hidden under backward:  overlap = 1 - (step - step_without_comm) / allreduce_alone."""
+    import torch.distributed as dist
+    red = model.dist.red
+    k = max(3, min(args.steps, 10))
+    for _ in range(2):
+        red.all_reduce_alone()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        red.all_reduce_alone()
+    barrier()
+    t_ar = (time.perf_counter() - t0) / k * 1e3
+    red.enabled = False
+    model.train_step(lr)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        model.train_step(lr)
+    barrier()
+    t_nc = (time.perf_counter() - t0) / k * 1e3
+    red.enabled = True
+    v = torch.tensor([t_ar, t_nc], device=dev)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    t_ar, t_nc = (float(x) for x in v.tolist())
+    nbytes = sum(red.bucket_bytes())
+    w = dist.get_world_size()
+    return {'backend': dist.get_backend(), 'world_size': w, 'launcher': os.environ.get('ODTK_BENCH_LAUNCHER', 'external'),
+            'buckets': len(red.buckets), 'gradient_mb': round(nbytes / 1e6, 1),
+            'allreduce_ms_per_step': round(t_ar, 3),
+            'allreduce_busbw_gbps': round(nbytes * 2 * (w - 1) / w / (t_ar * 1e-3) / 1e9, 1),
+            'ms_per_step_without_comm': round(t_nc, 3), 'exposed_comm_ms': round(max(ms_step - t_nc, 0.0), 3),
+            'overlap_frac': round(min(max(1.0 - max(ms_step - t_nc, 0.0) / max(t_ar, 1e-9), 0.0), 1.0), 3)}
 
 
 def usable_cores():
@@ -312,11 +466,12 @@ def usable_cores():
 
 
 def cpu_baseline():
-    """PyTorch-CPU oracle (restatement of the reference graph) on a bounded sample: batch 4."""
+    """PyTorch-CPU oracle (restatement of the reference graph) on a bounded sample of the SAME workload: full training steps
+    at batch 32 (one warm-up, then steps until ~20 s are spent, at most 3)."""
     from oracle import ssd300_ref as R
     cores = usable_cores()
     torch.set_num_threads(cores)
-    bs = 4
+    bs = 32
     p = R.init_params(0)
     mom = {k: torch.zeros_like(v) for k, v in p.items()}
     imgs, gt = R.synthetic_batch(bs, 0)
@@ -324,13 +479,14 @@ def cpu_baseline():
     R.train_step(p, mom, imgs, gt, 0.01, 1e-4, anchors)          # warm-up
     t0 = time.perf_counter()
     n = 0
-    while n < 1 or (time.perf_counter() - t0 < 12 and n < 6):
+    while n < 1 or (time.perf_counter() - t0 < 20 and n < 3):
         R.train_step(p, mom, imgs, gt, 0.01, 1e-4, anchors)
         n += 1
     dt = time.perf_counter() - t0
     return {'value': round(bs * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} full train steps at batch {bs} (same synthetic generator), PyTorch-CPU fp32 oracle; '
-                      'the reference TF-1.13 graph itself cannot run (no tensorflow, SSD300.py:41-43 syntax error)'}
+            'mkldnn': bool(torch.backends.mkldnn.is_available() and torch.backends.mkldnn.enabled),
+            'sample': f'{n} full train step(s) at batch {bs} after one warm-up step (same synthetic generator), PyTorch-CPU fp32 '
+                      'oracle; the reference TF-1.13 graph itself cannot run (no tensorflow, SSD300.py:41-43 syntax error)'}
 
 
 if __name__ == '__main__':

@@ -728,8 +728,11 @@ static int loss_scratch(int N, float** out) {
 }
 
 static bool g_nms_legacy = false;      // odtk_debug_set key 3
-// per-device scratch of the split NMS path, grown on demand (never freed; reused by every call on
-// the device -- calls are stream-ordered by the caller, as everything else in this library)
+// per-device scratch of the split NMS path, grown on demand and -- like conv_scratch / loss_scratch -- NEVER freed or
+// moved once handed out: a captured HIP graph may still point into an earlier buffer (train at batch 8 with the graph built,
+// then a 20- or 80-class test model in the same process asks for more problems).  On growth a NEW buffer of at least twice
+// the size is allocated and the old one is retired (kept alive, just not handed out again).  Calls are stream-ordered by
+// the caller, as everything else in this library.  hipMalloc inside a stream capture fails: run one eager step first.
 struct NmsScratchOwner { void* base = nullptr; int B = 0; };
 static NmsScratchOwner g_nms_scratch[16];
 static int nms_scratch(int B, NmsScratch* ws) {
@@ -738,11 +741,12 @@ static int nms_scratch(int B, NmsScratch* ws) {
     ODTK_REQUIRE(dev >= 0 && dev < 16, "nms: device index %d unsupported", dev);
     NmsScratchOwner& o = g_nms_scratch[dev];
     if (o.B < B) {
-        if (o.base) ODTK_CHECK_HIP(hipFree(o.base));
-        o.base = nullptr; o.B = 0;
+        int want = o.B ? 2 * o.B : 64;
+        if (want < B) want = B;
         const size_t per = (size_t)NMS_TCAP * (4 + 16 + NMS_WORDS * 8) + 64;
-        ODTK_CHECK_HIP(hipMalloc(&o.base, per * B));
-        o.B = B;
+        void* p = nullptr;
+        ODTK_CHECK_HIP(hipMalloc(&p, per * want));
+        o.base = p; o.B = want;                          // the previous buffer stays allocated (retired, see above)
     }
     char* p = (char*)o.base;
     ws->mat = (unsigned long long*)p; p += (size_t)o.B * NMS_TCAP * NMS_WORDS * 8;

@@ -41,6 +41,7 @@ class BucketAllReducer:
                 end = s
                 size = 0
         self.index = {name: i for i, (name, _, _) in enumerate(self.segments)}
+        self.enabled = True            # False: walk the buckets without launching collectives (bench.py: step time without comm)
         self.begin_step()
 
     def begin_step(self):
@@ -53,10 +54,20 @@ class BucketAllReducer:
         self.lowest_ready = min(self.lowest_ready, self.index[name])
         while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][2] >= self.lowest_ready:
             s, e, _ = self.buckets[self.next_bucket]
-            if self.world > 1:
+            if self.world > 1 and self.enabled:
                 self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                     async_op=True))
             self.next_bucket += 1
+
+    def bucket_bytes(self):
+        return [(e - s) * self.flat.element_size() for s, e, _ in self.buckets]
+
+    def all_reduce_alone(self):
+        """Every bucket's all-reduce back to back with nothing to overlap with (bench.py: the collective's own time)."""
+        if self.world > 1:
+            hs = [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e, _ in self.buckets]
+            for h in hs:
+                h.wait()
 
     def finish_step(self):
         """Flush whatever is left and make the reduced gradients visible to the current stream."""

@@ -514,7 +514,7 @@ class FCOS:
             tf_checkpoint.update_checkpoint_state(prefix)
             print('save', mode, 'model in', path, 'successfully')
             return
-        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': dict(self.pinfo)}
+        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': {k: (int(o), tuple(int(x) for x in shp)) for k, (o, shp) in self.pinfo.items()}}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
@@ -523,7 +523,7 @@ class FCOS:
             self.load_tf_checkpoint(path)
             print('load weight', path, 'successfully')
             return
-        blob = torch.load(path, map_location='cpu', weights_only=False)
+        blob = torch.load(path, map_location='cpu', weights_only=True)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
             self.Mom.copy_(blob['momentum'].to(self.dev))
@@ -536,7 +536,7 @@ class FCOS:
             self.load_tf_checkpoint(path, backbone_only=True)
             print('load pretrained weight', path, 'successfully')
             return
-        blob = torch.load(path, map_location='cpu', weights_only=False)['params']
+        blob = torch.load(path, map_location='cpu', weights_only=True)['params']
         nb = 1 + 4 * sum(BLOCKS)
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < nb})
         print('load pretrained weight', path, 'successfully')

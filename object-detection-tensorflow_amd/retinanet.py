@@ -579,7 +579,7 @@ class RetinaNet:
             tf_checkpoint.update_checkpoint_state(prefix)
             print('save', mode, 'model in', path, 'successfully')
             return
-        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': dict(self.pinfo)}
+        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': {k: (int(o), tuple(int(x) for x in shp)) for k, (o, shp) in self.pinfo.items()}}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
@@ -588,7 +588,7 @@ class RetinaNet:
             self.load_tf_checkpoint(path)
             print('load weight', path, 'successfully')
             return
-        blob = torch.load(path, map_location='cpu', weights_only=False)
+        blob = torch.load(path, map_location='cpu', weights_only=True)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
             self.Mom.copy_(blob['momentum'].to(self.dev))
@@ -602,7 +602,7 @@ class RetinaNet:
             self.load_tf_checkpoint(path, backbone_only=True)
             print('load pretraining weight', path, 'successfully')
             return
-        blob = torch.load(path, map_location='cpu', weights_only=False)['params']
+        blob = torch.load(path, map_location='cpu', weights_only=True)['params']
         nb = 1 + 4 * sum(self.block_list)
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < nb})
         print('load pretraining weight', path, 'successfully')
@@ -616,7 +616,7 @@ class RetinaNet:
 
 def reference_variable_map(block_list=(3, 4, 6, 3)):
     """name of every variable of the reference's detection graph -> our parameter / statistic name.  tf.layers default layer names
-    count over the whole graph (conv2d ... conv2d_121, batch_normalization ... _121); scopes: 'feature_extractor' for the stem and the
+    (conv2d, conv2d_1, ...; batch_normalization, _1, ...) are numbered PER ENCLOSING variable scope; scopes: 'feature_extractor' for the stem and the
     pyramid, 'feature_extractor/block<b>_unit<u>/conv_branch|identity_branch' for the units (RetinaNet.py:621-643), 'regressor' for the
     subnets (:145).  Pinned by tests/golden/retinanet_variables.json (collected from the reference's own class)."""
     scopes = ['feature_extractor']
@@ -625,9 +625,11 @@ def reference_variable_map(block_list=(3, 4, 6, 3)):
             base = f'feature_extractor/block{b + 1}_unit{u + 1}'
             scopes += [base + '/conv_branch'] * 3 + [base + '/identity_branch']
     scopes += ['feature_extractor'] * 7 + ['regressor'] * 50
-    m = OrderedDict()
+    m, count = OrderedDict(), {}
     for i, scope in enumerate(scopes):
-        sfx = '' if i == 0 else f'_{i}'
+        k = count.get(scope, 0)                      # default layer names are numbered per enclosing variable scope
+        count[scope] = k + 1
+        sfx = '' if k == 0 else f'_{k}'
         m[f'{scope}/conv2d{sfx}/kernel'], m[f'{scope}/conv2d{sfx}/bias'] = f'l{i}.w', f'l{i}.b'
         bn = f'{scope}/batch_normalization{sfx}'
         m[bn + '/gamma'], m[bn + '/beta'] = f'l{i}.gamma', f'l{i}.beta'

@@ -58,8 +58,9 @@ def reference_variable_map():
     """name of every variable of the reference's graph -> our parameter / statistic name.
     SSD300.py:193-300 (`kernel_convX_Y` / `bias_convX_Y` under 'feature_extractor', with the two misspelt names
     `kenrel_conv2_1` :212 and `bias_conv_3_1` :232), :77 l2_norm_factor, :304-313 + :85-90 tf.layers.conv2d
-    (`<scope>/<name>/kernel|bias`) each followed by tf.layers.batch_normalization, whose default layer names count
-    up over the whole graph (batch_normalization, _1 ... _15)."""
+    (`<scope>/<name>/kernel|bias`) each followed by tf.layers.batch_normalization, whose default layer name is made
+    unique PER ENCLOSING variable scope (Layer._set_scope -> variable_scope(None, default_name='batch_normalization')):
+    feature_extractor/batch_normalization, _1 ... _9 and regressor/batch_normalization, _1 ... _5."""
     m = OrderedDict()
     for item in VGG_SEQ:
         n = item[0]
@@ -67,11 +68,9 @@ def reference_variable_map():
             m['feature_extractor/' + ('kenrel_' if n == 'conv2_1' else 'kernel_') + n] = n + '.w'
             m['feature_extractor/' + ('bias_conv_3_1' if n == 'conv3_1' else 'bias_' + n)] = n + '.b'
     m['feature_extractor/l2_norm_factor'] = 'l2norm.gamma'
-    bn = 0
     for scope, names in (('feature_extractor', [e[0] for e in EXTRA_SEQ]), ('regressor', [f'pred{i}' for i in range(1, 7)])):
-        for n in names:
+        for bn, n in enumerate(names):
             bns = f'{scope}/batch_normalization' + (f'_{bn}' if bn else '')
-            bn += 1
             m[f'{scope}/{n}/kernel'], m[f'{scope}/{n}/bias'] = n + '.w', n + '.b'
             m[bns + '/gamma'], m[bns + '/beta'] = n + '.gamma', n + '.beta'
             m[bns + '/moving_mean'], m[bns + '/moving_variance'] = n + '.mmean', n + '.mvar'
@@ -305,7 +304,7 @@ class SSD300:
             if str(path).endswith('.npz'):
                 blob = dict(np.load(path))
             elif str(path).endswith(('.pt', '.pth')):
-                blob = torch.load(path, map_location='cpu')
+                blob = torch.load(path, map_location='cpu', weights_only=True)
             else:                                                # slim's vgg_16.ckpt (V1) or a Saver prefix (V2): SSD300.py:31
                 from .tf_checkpoint import NewCheckpointReader
                 reader = NewCheckpointReader(str(path))
@@ -837,7 +836,7 @@ class SSD300:
             print('save', mode, 'model in', path, 'successfully')
             return
         blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(),
-                'global_step': self.global_step, 'layout': dict(self.pinfo)}
+                'global_step': self.global_step, 'layout': {k: (int(o), tuple(int(x) for x in shp)) for k, (o, shp) in self.pinfo.items()}}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
@@ -846,7 +845,7 @@ class SSD300:
             self.load_tf_checkpoint(path)
             print('load weight', path, 'successfully')
             return
-        blob = torch.load(path, map_location='cpu', weights_only=False)
+        blob = torch.load(path, map_location='cpu', weights_only=True)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
             self.Mom.copy_(blob['momentum'].to(self.dev))

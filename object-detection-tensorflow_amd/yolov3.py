@@ -487,7 +487,7 @@ class YOLOv3:
             tf_checkpoint.update_checkpoint_state(prefix)
             print('save', mode, 'model in', path, 'successfully')
             return
-        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': dict(self.pinfo)}
+        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step, 'layout': {k: (int(o), tuple(int(x) for x in shp)) for k, (o, shp) in self.pinfo.items()}}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
@@ -496,7 +496,7 @@ class YOLOv3:
             self.load_tf_checkpoint(path)
             print('load weight', path, 'successfully')
             return
-        blob = torch.load(path, map_location='cpu', weights_only=False)
+        blob = torch.load(path, map_location='cpu', weights_only=True)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
             self.Mom.copy_(blob['momentum'].to(self.dev))
@@ -509,7 +509,7 @@ class YOLOv3:
             self.load_tf_checkpoint(path, backbone_trainables_only=True)
             print('load pretraining weight', path, 'successfully')
             return
-        blob = torch.load(path, map_location='cpu', weights_only=False)['params']
+        blob = torch.load(path, map_location='cpu', weights_only=True)['params']
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < 52 and k in self.pinfo})
         print('load pretraining weight', path, 'successfully')
 
@@ -555,7 +555,8 @@ def layer_specs(num_classes=20, num_priors=3):
 
 def reference_variable_map():
     """name of every variable of the reference's YOLOv3 graph -> our parameter / statistic name.  tf.layers default layer names
-    count over the whole graph (conv2d, conv2d_1 ... conv2d_74; batch_normalization ... _74) inside the variable scopes
+    (conv2d, conv2d_1, ...; batch_normalization, _1, ...) are numbered PER ENCLOSING variable scope (Layer._set_scope ->
+    variable_scope(None, default_name=...)); the scopes:
     'backone' (sic, YOLOv3.py:82) / 'backone/block<b>' (:485) / 'head/pyd<l>' (:399).  Pinned by tests/golden/yolov3_variables.json
     (collected from the reference's own class)."""
     scopes = ['backone']
@@ -563,9 +564,11 @@ def reference_variable_map():
         scopes += [f'backone/block{b + 1}'] * (1 + 2 * blocks)
     for lvl in range(3):
         scopes += [f'head/pyd{lvl + 1}'] * (7 if lvl == 0 else 8)
-    m = OrderedDict()
+    m, count = OrderedDict(), {}
     for i, scope in enumerate(scopes):
-        sfx = '' if i == 0 else f'_{i}'
+        k = count.get(scope, 0)                      # default layer names are numbered per enclosing variable scope
+        count[scope] = k + 1
+        sfx = '' if k == 0 else f'_{k}'
         m[f'{scope}/conv2d{sfx}/kernel'], m[f'{scope}/conv2d{sfx}/bias'] = f'c{i}.w', f'c{i}.b'
         bn = f'{scope}/batch_normalization{sfx}'
         m[bn + '/gamma'], m[bn + '/beta'] = f'c{i}.gamma', f'c{i}.beta'

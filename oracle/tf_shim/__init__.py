@@ -367,15 +367,45 @@ AUTO_REUSE = 'auto_reuse'          # tf.AUTO_REUSE: accepted by variable_scope, 
 
 
 class variable_scope:
-    def __init__(self, name, *a, **k):
-        self.name = name
+    """tf.variable_scope with TF 1.x's scope-count bookkeeping (variable_scope.py, _VariableScopeStore): entering a scope
+    counts its full name (open_variable_scope); LEAVING it resets the counts of all of its sub-scopes
+    (close_variable_subscopes) -- so default layer names ('conv2d', 'batch_normalization', 'GroupNorm') are numbered per
+    ENCLOSING scope, and a scope that is entered again (FCOS.py:351,358 with reuse=tf.AUTO_REUSE) hands out the same default
+    names again: its layers then find their variables by name, i.e. the five pyramid levels SHARE one set of head weights.
+    (Without reuse TensorFlow raises 'Variable ... already exists' there; the shim looks variables up by name either way.)"""
+
+    def __init__(self, name, *a, default_name=None, **k):
+        self.name = name if name is not None else _unique_scope_name(default_name)
 
     def __enter__(self):
         S.scope.append(self.name)
+        full = '/'.join(S.scope)
+        _SCOPE_COUNT[full] = _SCOPE_COUNT.get(full, 0) + 1
         return self
 
     def __exit__(self, *exc):
+        full = '/'.join(S.scope)
+        for k in list(_SCOPE_COUNT):
+            if k.startswith(full + '/'):
+                _SCOPE_COUNT[k] = 0
         S.scope.pop()
+
+
+_SCOPE_COUNT = {}
+
+
+def _unique_scope_name(prefix):
+    """variable_scope(None, default_name=prefix): _get_unique_variable_scope -- prefix, prefix_1, ... among the scopes opened
+    (and not yet reset) under the CURRENT scope.  This is how tf.layers names a layer created without `name=`
+    (Layer._set_scope: variable_scope(None, default_name=self._base_name)) and how contrib's group_norm names its scope."""
+    cur = '/'.join(S.scope)
+    name = (cur + '/' + prefix) if cur else prefix
+    if _SCOPE_COUNT.get(name, 0) == 0:
+        return prefix
+    idx = 1
+    while _SCOPE_COUNT.get(f'{name}_{idx}', 0) > 0:
+        idx += 1
+    return f'{prefix}_{idx}'
 
 
 def _full(name):
@@ -517,32 +547,22 @@ def _glorot_uniform(shape_hwio, gen):
 class _Layers:
     gen = torch.Generator().manual_seed(1234)
 
-    conv_count = 0
-
     @staticmethod
     def conv2d(inputs, filters, kernel_size, strides=1, padding='valid', name=None, data_format='channels_last', dilation_rate=1,
                kernel_initializer=None, bias_initializer=None):
         assert padding == 'same' and data_format == 'channels_last'
         filters = int(filters)                        # YOLOv3.py:487 passes filters/2, a float under true division
-        if name is None:                              # default layer names count over the whole graph: conv2d, conv2d_1, ...
-            name = 'conv2d' if _Layers.conv_count == 0 else f'conv2d_{_Layers.conv_count}'
-            _Layers.conv_count += 1
         ci = inputs.shape[-1]
-        with variable_scope(name):
+        with variable_scope(name, default_name='conv2d'):     # default names: conv2d, conv2d_1, ... per enclosing variable scope
             w = get_variable('kernel', initializer=_glorot_uniform((kernel_size, kernel_size, ci, filters), _Layers.gen))
             b = get_variable('bias', shape=[filters], initializer=bias_initializer)
         return _conv_nhwc(inputs, w, strides, dilation_rate) + b
-
-    bn_count = 0
 
     @staticmethod
     def batch_normalization(inputs, axis=3, training=False, momentum=0.99, epsilon=1e-3):
         assert axis == 3
         c = inputs.shape[-1]
-        idx = _Layers.bn_count
-        _Layers.bn_count += 1
-        scope = 'batch_normalization' if idx == 0 else f'batch_normalization_{idx}'
-        with variable_scope(scope):
+        with variable_scope(None, default_name='batch_normalization'):
             gamma = get_variable('gamma', initializer=torch.ones(c))
             beta = get_variable('beta', initializer=torch.zeros(c))
             mm = get_variable('moving_mean', initializer=torch.zeros(c), trainable=False)
@@ -725,10 +745,7 @@ def _group_norm(inputs, groups=32, channels_axis=-1, reduction_axes=(-3, -2), tr
     variable_scope(None, 'GroupNorm'), whose default name is made unique WITHIN the enclosing scope (GroupNorm, GroupNorm_1, ...)"""
     assert channels_axis in (3, -1) and tuple(reduction_axes) in ((1, 2), (-3, -2))
     n, h, w, c = inputs.shape
-    key = '/'.join(S.scope)
-    idx = _GN_COUNT.get(key, 0)
-    _GN_COUNT[key] = idx + 1
-    with variable_scope('GroupNorm' if idx == 0 else f'GroupNorm_{idx}'):
+    with variable_scope(None, default_name='GroupNorm'):
         beta = get_variable('beta', initializer=torch.zeros(c))
         gamma = get_variable('gamma', initializer=torch.ones(c))
     x = inputs.reshape(n, h, w, groups, c // groups)
@@ -739,7 +756,6 @@ def _group_norm(inputs, groups=32, channels_axis=-1, reduction_axes=(-3, -2), tr
     return y * gamma + beta
 
 
-_GN_COUNT = {}
 contrib = types.SimpleNamespace(framework=_ContribFramework(), layers=types.SimpleNamespace(variance_scaling_initializer=lambda *a, **k: None, group_norm=_group_norm),
                                image=types.SimpleNamespace(rotate=_contrib_rotate))
 random = types.SimpleNamespace(uniform=random_uniform)
@@ -825,9 +841,7 @@ class InteractiveSession:
                 overrides[byid[id(ph)]] = val
         S.ph_count = 0
         S.pending = []
-        _Layers.bn_count = 0
-        _Layers.conv_count = 0
-        _GN_COUNT.clear()
+        _SCOPE_COUNT.clear()
         wants_update = 'train_op' in names
         # RetinaNet.py names its graph methods per task (:101, :137); every other class has _define_inputs / _build_graph
         define = getattr(m, '_define_inputs', None) or m._define_detection_inputs
@@ -853,9 +867,7 @@ class InteractiveSession:
 def install(vgg_tensors=None):
     """Registers fake `tensorflow` / `tensorflow.python.pywrap_tensorflow` modules."""
     reset()
-    _Layers.bn_count = 0
-    _Layers.conv_count = 0
-    _GN_COUNT.clear()
+    _SCOPE_COUNT.clear()
     tf = types.ModuleType('tensorflow')
     me = sys.modules[__name__]
     for k in dir(me):

@@ -39,8 +39,7 @@ def main():
         setattr(me, name, (lambda n: (lambda *a, **k: getattr(ref.YOLOv3, n)(me, *a, **k)))(name))
 
     def network(images):                        # YOLOv3.py:82-88
-        tf_shim._Layers.bn_count = 0
-        tf_shim._Layers.conv_count = 0
+        tf_shim._SCOPE_COUNT.clear()
         tf_shim.S.pending = []
         with tf.variable_scope('backone'):
             pyd1, pyd2, pyd3 = me._feature_extractor(images)

@@ -146,9 +146,14 @@ def test_retinanet_layer_specs_and_priors_match_oracle_and_reference_graph():
     for s in RR.ANCHOR_SIZES:
         assert [tuple(map(float, v)) for v in R.level_priors(s)] == [tuple(map(float, v)) for v in RR.level_priors(s)]
     want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'retinanet_variables.json')))
-    kernels = sorted((k for k in want if k.endswith('/kernel')), key=lambda k: int((k.split('conv2d')[1].split('/')[0] or '_0')[1:]))
-    gammas = sorted((k for k in want if k.endswith('/gamma')), key=lambda k: int((k.split('batch_normalization')[1].split('/')[0] or '_0')[1:]))
+    # creation order = the order of reference_variable_map (default layer names are numbered per enclosing variable scope)
+    vm = R.reference_variable_map()
+    assert set(vm) | {'global_step'} == set(want)
+    kernels = [k for k in vm if k.endswith('/kernel')]
+    gammas = [k for k in vm if k.endswith('/gamma')]
     assert len(kernels) == len(gammas) == len(specs) == 122
-    for (name, cin, cout, k, _, bnc, _), kn, gn in zip(specs, kernels, gammas):
+    for i, ((name, cin, cout, k, _, bnc, _), kn, gn) in enumerate(zip(specs, kernels, gammas)):
+        assert vm[kn] == f'l{i}.w' and vm[gn] == f'l{i}.gamma'
         assert want[kn]['shape'] == [k, k, cin, cout], (name, kn)
         assert want[gn]['shape'] == [bnc], (name, gn)
+    assert 'feature_extractor/conv2d_7/kernel' in want and 'regressor/conv2d_49/kernel' in want and 'regressor/conv2d_50/kernel' not in want

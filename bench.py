@@ -94,6 +94,7 @@ class ConvTimer:
         of every launch; it is reported next to the plain number, never instead of it."""
         n = len(self.records)
         per = n // steps if steps > 0 and n % steps == 0 else n
+        self._per = per
         reps = n // per
         out = []
         for i in range(per):
@@ -106,6 +107,15 @@ class ConvTimer:
                     ts = ts[:-1]
             kind, kern, fl, _, _, ab, shp = self.records[i]
             out.append((kind, kern, fl, sum(ts) / len(ts), ab, shp))
+        return out
+
+    def per_step_totals(self, kernel):
+        """summed duration of `kernel`'s launches in every recorded eager step (ms) -- shows whether a slow average is one slow step"""
+        per = self._per
+        out = []
+        for r in range(len(self.records) // per):
+            out.append(round(sum(self.records[i + r * per][3].elapsed_time(self.records[i + r * per][4])
+                                 for i in range(per) if self.records[i][1] == kernel), 3))
         return out
 
     def summary(self, steps, trimmed=False):
@@ -146,6 +156,7 @@ class ConvTimer:
             'hbm_frac_of_8TBps': None if pmc is None else round(pmc['hbm_bytes'] / (t / n) / 8e12, 4),
             'launches_per_step': n // steps, 'avg_launch_us': round(t / n * 1e6, 2),
             'avg_launch_us_trimmed': round(t_trim / n * 1e6, 2), 'frac_trimmed': round(fl / t_trim / peak, 4),
+            'per_step_ms': self.per_step_totals(dom),
             'algorithmic_gflop_per_launch': round(fl / n / 1e9, 2),
             'algorithmic_mb_per_launch': round(ab / n / 1e6, 1),
             'family': {'kernels': 'all conv kernels (fwd + dgrad + wgrad, every layer)',
@@ -316,7 +327,8 @@ def main():
                 with open(args.conv_table, 'w') as f:
                     f.write(timer.table(min(args.steps, 5) + 1) + '\n')
             out['roofline']['measured_on'] = (f'{min(args.steps, 5) + 1} eager steps right after the timed region '
-                                              '(HIP events per conv launch on the launch stream; per-launch mean without the first step and the slowest sample)')
+                                              '(HIP events per conv launch on the launch stream; plain per-launch mean without the first eager step; '
+                                              '*_trimmed additionally drops the slowest sample of every launch)')
         if comm is not None:
             out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:

@@ -11,7 +11,7 @@ is a re-iterable (or a `(initializer, iterable)` pair, mirroring the reference t
 `(images f32 [B,300,300,3] RGB 0..255, ground_truth f32 [B,pad,5] = [yc,xc,h,w,cls] px, pad rows -1)`
 as torch tensors or numpy arrays -- exactly what utils/image_augmentor.py:24-27 documents.
 
-Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' default | 'f32'),
+Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' | 'f32'; default bf16 in train mode, f32 in test mode),
 'device', 'seed', 'verbose', 'test_subtract_mean' (False = reproduce the reference's test-mode feed quirk),
 'use_graph' (True: replay the step's kernel launches from HIP graphs after two eager steps).
 """
@@ -135,7 +135,9 @@ class SSD300:
         assert self.num_classes + 4 == 25 or True
         self.row = self.num_classes + 4
 
-        cd = config.get('compute_dtype', 'bf16')
+        # training defaults to the bf16 engine (the benchmarked configuration); inference to f32: north_star's 1e-3 bound on
+        # boxes / scores holds for the f32 engine only (tests/test_gpu_ssd300_b32.py::test_bf16_test_one_image_vs_oracle)
+        cd = config.get('compute_dtype', 'bf16' if config['mode'] == 'train' else 'f32')
         assert cd in ('bf16', 'f32')
         self.DT = BF16 if cd == 'bf16' else F32
         self.tdt = ops.torch_dtype(self.DT)

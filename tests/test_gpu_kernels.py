@@ -144,6 +144,15 @@ def test_conv_ssd300_layer_geometries_bf16(case, dev):
     _conv_case(case, "bf16", dev)
 
 
+# ... and at the BENCHMARKED batch (BASELINE configs[1]: 32 images / GPU): the v6 grid of 1 408 tiles, persistent blocks that walk
+# several tiles, the split-K decisions and the 32-bit byte offsets of the LDS-DMA all depend on N.  Reference: torch-CPU f32
+# convolution fed the same bf16-rounded operands (6 TFLOP in all, ~20 s of host time).
+@pytest.mark.parametrize("case", [(32,) + c[1:] for c in SSD300_LAYER_CASES])
+def test_conv_ssd300_layer_geometries_bf16_batch32(case, dev):
+    torch.set_num_threads(16)
+    _conv_case(case, "bf16", dev)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_fwd_dgrad_wgrad(case, dt, dev):

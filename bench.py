@@ -274,7 +274,10 @@ def main():
         model._graphs_build_safe()                           # untimed; a capture executes nothing
     if args.eager:
         model.use_graph = False
-    barrier()
+    import gc
+    gc.collect()
+    gc.disable()               # a generation-2 collection in the launching thread is a 10-30 ms host stall; with eager launches
+    barrier()                  # (the HIP-event pass below) the GPU runs dry behind it and the stall lands in some kernel's events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = model.train_step(lr)
@@ -294,8 +297,10 @@ def main():
             model.train_step(lr)
         torch.cuda.synchronize()
         timer.enabled = False
+        gc.enable()
         model.use_graph = saved
         model.wgrad_stream = saved_side
+    gc.enable()
     loss = final_loss_t
     comm = None
     if world > 1:

@@ -635,12 +635,19 @@ __global__ void __launch_bounds__(256) conv_gather_v5_kernel(const GatherArgs a)
 // 196 KiB instead of 432 KiB of LDS-DMA per chunk.  slot ^ ((row >> 1) & 7) keeps ds_read_b128 conflict-free for any
 // start row.  k order = (chunk, tap); the filter k index stays tap * C + channel.
 // ---------------------------------------------------------------------------------------
+// Template: NPP patch pieces per wave (patch rows = 32 NPP).  DBUF = true (NPP = 13, W <= 79): two patch buffers, the next
+// chunk's pieces ride on the tap slabs of the current one.  DBUF = false (NPP = 18, W <= 159: conv2_x at 150 x 150): ONE patch
+// buffer of 576 rows; the next chunk's patch is written into rows that are already DEAD -- tap row dr only reads patch rows
+// >= dr * dil * W, so groups i < G1 = floor(dil W / 32) are issued on the slab of tap 3, groups < G2 = floor(2 dil W / 32) on
+// tap 6, and only the last NPP - G2 groups (258 rows) are exposed between two chunks.
+template <int NPP, bool DBUF, int G1, int G2>
 __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a) {
     constexpr int PT = 128, QT = 256, NTHR = 256, PI = 2, QI = 4;
     constexpr int NP = PT / 32;                          // filter DMA pieces per wave and slab
-    constexpr int NPP = 13, PROWS = NPP * 32;            // patch DMA pieces per wave and chunk; patch rows (416)
+    constexpr int PROWS = NPP * 32;                      // patch rows (416 | 576)
     constexpr int PATCH = PROWS * 128, WST = PT * 128;
-    constexpr int ZOFF = 2 * PATCH + 3 * WST;
+    constexpr int WBASE = (DBUF ? 2 : 1) * PATCH;        // the three filter stages follow the patch buffer(s)
+    constexpr int ZOFF = WBASE + 3 * WST;
     __shared__ __attribute__((aligned(16))) char smem[ZOFF + 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave & 1, wq = wave >> 1;
@@ -706,7 +713,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     auto issue_w = [&](int kt, int stage) __attribute__((always_inline)) {        // filter slab kt = cs*9 + tap
         const int cs = kt / 9, tap = kt - cs * 9;
         const unsigned woff = (unsigned)((tap * a.C + cs * 64) * 2);
-        const unsigned dP = smem_base + 2u * PATCH + (unsigned)stage * WST + wave_u * 1024u;
+        const unsigned dP = smem_base + (unsigned)WBASE + (unsigned)stage * WST + wave_u * 1024u;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const unsigned addr = poff32[i] + woff;
@@ -736,18 +743,18 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     auto slab = [&](auto TAPC, int kt, int cs, int st_c, int st_n) __attribute__((always_inline)) {
         constexpr int tap = decltype(TAPC)::value;
         constexpr int dr = tap / 3, ds = tap - dr * 3;
-        constexpr int NX = tap < 5 ? 2 : (tap < 8 ? 1 : 0);
-        constexpr int XBASE = tap < 5 ? 2 * tap : 10 + (tap - 5);
+        constexpr int NX = DBUF ? (tap < 5 ? 2 : (tap < 8 ? 1 : 0)) : (tap == 3 ? G1 : (tap == 6 ? G2 - G1 : 0));
+        constexpr int XBASE = DBUF ? (tap < 5 ? 2 * tap : 10 + (tap - 5)) : (tap == 3 ? 0 : G1);
         constexpr int NPC = NP + NX;
-        const char* sP = smem + 2 * PATCH + st_c * WST;
-        const unsigned pbase = smem_base + (unsigned)((cs & 1) * PATCH);
+        const char* sP = smem + WBASE + st_c * WST;
+        const unsigned pbase = smem_base + (DBUF ? (unsigned)((cs & 1) * PATCH) : 0u);
         const unsigned zrow = smem_base + ZOFF;
         const bool more_x = cs + 1 < ncs, more_w = kt + 2 < 9 * ncs;
         // filter slab kt+2 = (chunk, tap) two positions ahead
         const int csn = tap < 7 ? cs : cs + 1;
         constexpr int tn = (tap + 2) % 9;
         const unsigned woff = (unsigned)((tn * a.C + csn * 64) * 2);
-        const unsigned dW = smem_base + 2u * PATCH + (unsigned)st_n * WST + wave_u * 1024u;
+        const unsigned dW = smem_base + (unsigned)WBASE + (unsigned)st_n * WST + wave_u * 1024u;
         // fragment addressing of this tap: row + dr*W + ds, slot ^ ((row >> 1) & 7); padding lanes -> the zero row
         unsigned qa[QI], qx[QI];
         const int shift = (dr * a.W + ds) * a.dil;
@@ -795,7 +802,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
                                 const int xi = XBASE + q - NP;
                                 const unsigned addr = xoff32[xi] + (unsigned)((cs + 1) * 128);
                                 glds16_buf_nc(rx, (((xok >> xi) & 1u) && more_x) ? addr : 0xFFFFFFF0u,
-                                              smem_base + (unsigned)(((cs + 1) & 1) * PATCH) + (wave_u + 4u * (unsigned)xi) * 1024u);
+                                              smem_base + (DBUF ? (unsigned)(((cs + 1) & 1) * PATCH) : 0u) + (wave_u + 4u * (unsigned)xi) * 1024u);
                             }
                         }
                     __builtin_amdgcn_sched_barrier(0);
@@ -808,8 +815,17 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
             constexpr int tap = decltype(TAPC)::value;
             // may stay in flight: what the PREVIOUS slab issued (filter slab kt+1 and the patch pieces of its position)
             constexpr int PREV = (tap + 8) % 9;
-            constexpr int NXP = PREV < 5 ? 2 : (PREV < 8 ? 1 : 0);
-            wait_vmcnt<NP + NXP>();
+            constexpr int NXP = DBUF ? (PREV < 5 ? 2 : (PREV < 8 ? 1 : 0)) : (PREV == 3 ? G1 : (PREV == 6 ? G2 - G1 : 0));
+            if (!DBUF && tap == 0 && cs > 0) {
+                // single patch buffer: every wave is past its last read of the old chunk (barrier), the rest of the new
+                // chunk's patch (groups G2 .. NPP-1) goes out now and must land before the first tap reads it
+                block_barrier();
+#pragma unroll
+                for (int i = G2; i < NPP; ++i) issue_x(i, cs, 0);
+                wait_vmcnt<0>();
+            } else {
+                wait_vmcnt<NP + NXP>();
+            }
             block_barrier();
             slab(TAPC, kt, cs, st_c, st_n);
             st_c = st_c == 2 ? 0 : st_c + 1;
@@ -2010,8 +2026,11 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     // split-K: few tiles with a long k loop leave most CUs idle and run at DMA latency; give every tile
     // up to 256 / tiles blocks of >= 4 k-slabs each (dbg bit 13 turns it off for A/B runs)
     int ksplit = 1;
+    const int halo = 2 * a.dil * (a.W + 1);               // patch rows beyond the 256 of the tile
+    // wide maps (conv2_x, W = 150): single-buffer variant, groups 0..3 / 4..8 of the next chunk ride on taps 3 / 6 (dbg bit 26 = off, A/B)
+    const bool v6_wide = halo > 160 && halo <= 320 && a.dil * a.W >= 144 && !(a.dbg & (1 << 26));
     const bool v6_ok = !(a.dbg & 65536) && PT == 128 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
-                       a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && 2 * a.dil * (a.W + 1) <= 160 && a.Kdim == 9 * a.C;
+                       a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && (halo <= 160 || v6_wide) && a.Kdim == 9 * a.C;
     const int v6_min_tiles = (a.dbg >> 18) & 255;         // A/B (dbg bits 18-25): halo kernel instead of split-K from this many tiles on
     if (tiles <= 128 && nk >= 8 && !(a.dbg & 8192) && !(v6_ok && v6_min_tiles && tiles >= v6_min_tiles)) {
         ksplit = 256 / tiles;                    // (2..6 slabs per part and 512 / tiles were measured: this is the best)
@@ -2032,7 +2051,8 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     const int grid = tiles;
     // raster-run halo kernel: 3x3 (dilated), stride 1, SAME, patch of 256 + 2 * dil * (W + 1) rows <= 416 (dbg bit 16 = off, A/B)
     if (v6_ok) {
-        hipLaunchKernelGGL(conv_gather_v6_kernel, dim3(grid), dim3(256), 0, st, a);
+        if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<13, true, 0, 0>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 9>), dim3(grid), dim3(256), 0, st, a);
         a.ksplit = -1;                                   // tells the dispatcher which kernel ran (odtk_conv_last_kernel)
         return 0;
     }

@@ -94,6 +94,9 @@ V3_EXTRA_CASES = [
     (2, 19, 19, 64, 300, 3, 1, 1),    # 256-row wgrad tile with a channel tail (300 = 256 + 44)
     (1, 8, 8, 64, 96, 3, 1, 1),       # one partial pixel tile: the halo patch is mostly outside the tensor
     (30, 45, 70, 8, 64, 3, 1, 1),     # first-layer kernel (3 real channels in one 16-B chunk): 540 ragged tiles, several per block
+    (1, 60, 150, 192, 160, 3, 1, 1),  # wide raster-run halo kernel (single patch buffer, W = 150): 3 chunks, channel-tile tail
+    (1, 20, 159, 64, 128, 3, 1, 1),   # ... widest supported map: the patch needs all 576 rows
+    (2, 80, 72, 128, 128, 3, 1, 2),   # ... dilation 2 (dil * W = 144: the early groups end exactly at the first live row)
 ]
 
 

@@ -40,7 +40,7 @@ LAYERS = {  # name: (N, H, C, K, k, stride, dil)   (C = padded input channels)
 which = list(LAYERS) if len(sys.argv) < 2 or sys.argv[1] == 'all' else sys.argv[1].split(',')
 passes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fwd', 'dgrad', 'wgrad']
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-modes = [int(m) for m in sys.argv[4].split(',')] if len(sys.argv) > 4 else [1, 2]
+modes = [(m if ':' in m else int(m)) for m in sys.argv[4].split(',')] if len(sys.argv) > 4 else [1, 2]      # 'E:bits' = engine E, debug bits
 # mode >= 100: 8-wave kernels with perf-experiment bits (mode - 100) -> odtk_debug_set(2, bits); results are garbage
 dev = torch.device('cuda')
 tot = {m: 0.0 for m in modes}
@@ -67,7 +67,9 @@ for name in which:
         f = fns[p]
         line = f'{name:8s} {p:6s}'
         for mode in modes:
-            if mode >= 1000000:
+            if isinstance(mode, str):
+                ops.debug_set(1, int(mode.split(':')[0])); ops.debug_set(2, int(mode.split(':')[1]))
+            elif mode >= 1000000:
                 ops.debug_set(1, mode // 1000000); ops.debug_set(2, mode % 1000000)
             else:
               ops.debug_set(1, mode // 10000 if mode >= 10000 else mode // 1000 if mode >= 1000 else 3 if mode >= 200 else 2 if mode >= 100 else mode)
@@ -82,7 +84,7 @@ for name in which:
             s1.record(); torch.cuda.synchronize()
             t = s0.elapsed_time(s1) / reps * 1e-3
             tot[mode] += t
-            line += f' | mode{mode} {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF'
+            line += f' | mode{mode} {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF [{ops.conv_last_kernel()}]'
         print(line, flush=True)
 ops.debug_set(1, 0)
 ops.debug_set(2, 0)

@@ -209,8 +209,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region')
+    ap.add_argument('--auto-launch', action='store_true', help="use_graph='auto': the faster of replay / eager launches, measured during warm-up")
     ap.add_argument('--wgrad-stream', action='store_true', help='A/B: filter gradients on a second HIP stream')
     ap.add_argument('--match-stream', action='store_true', help='A/B: box matching on a second HIP stream under the forward pass')
+    ap.add_argument('--no-tail-stream', action='store_true', help='A/B: heads after the extra layers on one stream (round-1 order)')
     ap.add_argument('--sync-bn', action='store_true', help='N > 1: batch-norm statistics over all replicas (SURVEY 8e option B; eager launches)')
     ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
     ap.add_argument('--bucket-mb', type=int, default=25, help='N > 1: gradient all-reduce bucket size')
@@ -246,7 +248,7 @@ def main():
         'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
         'keep_prob': 0.5, 'batch_size': B, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20,
         'nms_iou_threshold': 0.5, 'pretraining_weight': os.path.join('.', 'vgg_16.ckpt'),
-        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream,
+        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else True,
     }
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)
@@ -274,6 +276,9 @@ def main():
         model._graphs_build_safe()                           # untimed; a capture executes nothing
     if args.eager:
         model.use_graph = False
+        model._auto = None
+    while model.launch_mode_pending:                         # use_graph='auto': replay vs eager launches, decided by measurement (untimed)
+        loss = model.train_step(lr)
     import gc
     gc.collect()
     gc.disable()               # a generation-2 collection in the launching thread is a 10-30 ms host stall; with eager launches
@@ -321,6 +326,7 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
                        'global_batch': B * world, 'parallelism': f'dp{world}' + ('+sync-bn' if args.sync_bn and world > 1 else ''), 'final_loss': round(final_loss, 4),
+                       'launch_mode_calibration': model.launch_mode,
                        'launch': 'eager' if not model.use_graph else ('hip-graph replay (fwd+loss+bwd)' if model._g_back is not None
                                                                         else f'hip-graph replay (fwd+loss; bwd as {len(model._g_back_segs or [])} '
                                                                              'bucket graphs with RCCL all-reduces between them)')},

@@ -50,6 +50,11 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         18-25 = n: halo kernel instead of split-K on layers with >= n tiles (0 = split-K policy as is);
  * key 3 = single-kernel NMS (value != 0) */
 int odtk_debug_set(int key, int value);
+/* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to
+ * every later call of this thread until the slot changes.  Calls on ONE stream are ordered and share slot 0; a caller that
+ * launches convolutions on several streams CONCURRENTLY (SSD300: the heads beside the extra-layer chain) selects a different
+ * slot (0..3) per stream before launching on it.  Buffers are never freed or moved (captured graphs point into them). */
+int odtk_scratch_slot(int slot);
 /* name of the device kernel the last odtk_conv2d_* call of this thread dispatched to (bench.py attributes
  * its HIP-event timings to kernels with it, so the roofline line and the rocprofv3 trace name the same kernel) */
 const char* odtk_conv_last_kernel(void);

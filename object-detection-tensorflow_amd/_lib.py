@@ -45,6 +45,7 @@ SIGNATURES = {
     "odtk_device_info": (_i, [C.POINTER(_i), C.c_char_p, _i]),
     "odtk_crc32c": (C.c_uint, [_vp, _ll, C.c_uint]),
     "odtk_debug_set": (_i, [_i, _i]),
+    "odtk_scratch_slot": (_i, [_i]),
     "odtk_conv_last_kernel": (C.c_char_p, []),
     "odtk_conv2d_fwd": (_i, [_cd, _vp, _vp, _vp, _vp, _i, _vp]),
     "odtk_conv2d_dgrad": (_i, [_cd, _vp, _i, _vp, _vp, _vp, _i, _vp]),

@@ -874,6 +874,11 @@ using namespace odtk;
 
 extern "C" const char* odtk_conv_last_kernel(void) { return g_last_kernel; }
 
+extern "C" int odtk_scratch_slot(int slot) {
+    ODTK_REQUIRE(set_scratch_slot(slot) == 0, "scratch_slot: slot %d out of range (0..3)", slot);
+    return ODTK_OK;
+}
+
 extern "C" int odtk_debug_set(int key, int value) {
     if (key == 0) { g_force_regstage = value != 0; return ODTK_OK; }
     if (key == 1) { g_v3_mode = value; return ODTK_OK; }

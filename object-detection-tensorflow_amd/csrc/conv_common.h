@@ -258,6 +258,7 @@ bool wgrad_c64_supported(const WgradArgs& a, int dtype);                      //
 int launch_wgrad_c64(WgradArgs& a, hipStream_t st);
 bool wgrad_v3_supported(const WgradArgs& a, int dtype);
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
+int set_scratch_slot(int slot);          // split-K partial buffers are per (device, slot); 0 on success
 
 }  // namespace cv
 }  // namespace odtk

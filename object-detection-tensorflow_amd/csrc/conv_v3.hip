@@ -1985,12 +1985,19 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
 // else in this library.  A buffer that was handed out is NEVER freed or moved: a captured HIP graph may still replay
 // kernels that point into it, so growth allocates a new, at least twice as large buffer and retires the old one.
 struct ConvScratchOwner { void* base = nullptr; size_t bytes = 0; };
-static ConvScratchOwner g_conv_scratch[16];
+constexpr int SCRATCH_SLOTS = 4;
+static ConvScratchOwner g_conv_scratch[16][SCRATCH_SLOTS];
+static thread_local int g_scratch_slot = 0;            // odtk_scratch_slot(): one slot per stream the caller launches on concurrently
+int set_scratch_slot(int slot) {
+    if (slot < 0 || slot >= SCRATCH_SLOTS) return -1;
+    g_scratch_slot = slot;
+    return 0;
+}
 static int conv_scratch(size_t bytes, float** out) {
     int dev = 0;
     ODTK_CHECK_HIP(hipGetDevice(&dev));
     ODTK_REQUIRE(dev >= 0 && dev < 16, "conv: device index %d unsupported", dev);
-    ConvScratchOwner& o = g_conv_scratch[dev];
+    ConvScratchOwner& o = g_conv_scratch[dev][g_scratch_slot];
     if (o.bytes < bytes) {
         size_t want = o.bytes ? 2 * o.bytes : ((size_t)64 << 20);
         if (want < bytes) want = bytes;

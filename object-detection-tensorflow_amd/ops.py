@@ -68,6 +68,11 @@ def debug_set(key: int, value: int):
     call("odtk_debug_set", int(key), int(value))
 
 
+def scratch_slot(slot: int):
+    """Select the library scratch slot of the following launches (include/odtk.h: odtk_scratch_slot): one per concurrently used stream."""
+    call("odtk_scratch_slot", int(slot))
+
+
 def conv_last_kernel() -> str:
     """Device kernel the last conv2d_* call dispatched to."""
     return _lib.load().odtk_conv_last_kernel().decode()

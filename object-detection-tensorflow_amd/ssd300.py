@@ -13,10 +13,12 @@ as torch tensors or numpy arrays -- exactly what utils/image_augmentor.py:24-27 
 
 Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' | 'f32'; default bf16 in train mode, f32 in test mode),
 'device', 'seed', 'verbose', 'test_subtract_mean' (False = reproduce the reference's test-mode feed quirk),
-'use_graph' (True: replay the step's kernel launches from HIP graphs after two eager steps).
+'use_graph' (True, default: replay the step's kernel launches from HIP graphs after two eager steps | False | 'auto' = the faster of the two, measured),
+'tail_stream' (True: the six heads run on a second stream beside the extra-layer chain).
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import sys
@@ -164,13 +166,27 @@ class SSD300:
         self.global_step = 0
         self.sync_bn = None
         self.checkpoint_format = config.get('checkpoint_format', 'torch')          # 'tf': tf.train.Saver files (tf_checkpoint.py)
-        self.use_graph = bool(config.get('use_graph', True))   # HIP-graph replay of the step after 2 eager steps
+        # HIP-graph replay of the step after 2 eager steps: True (default) | False | 'auto'.  'auto' builds the graphs, then
+        # times AUTO_STEPS steps replayed and AUTO_STEPS steps launched eagerly (real training steps, synchronised only
+        # while calibrating) and keeps the faster mode: replay wins when the host cannot issue ~220 launches per step as
+        # fast as the GPU retires them.  On a host that can, the two modes measured within 1 % of each other (9.63-9.66 ms
+        # eager vs 9.75-9.82 ms replayed, same box), so replay -- which does not depend on the host -- is the default.
+        ug = config.get('use_graph', True)
+        self.use_graph = True if ug == 'auto' else bool(ug)
+        self._auto = {'left': 2 * self.AUTO_STEPS, 't': {}} if ug == 'auto' else None
         # optional: filter gradients on a second HIP stream (wgrad(L) only needs dy(L) and the stored input of L, nothing
         # on the dgrad chain needs its result before the optimizer).  Measured neutral on MI355X (both chains are
         # full-chip kernels with one workgroup per CU), so it is off by default; config key 'wgrad_stream'.
         on_gpu = self.dev.type == 'cuda'      # (a 'cpu' device only gets past ops._p with the mocked library of tests/mock_ops.py: host-logic tests)
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (on_gpu and config.get('wgrad_stream', False)) else None
         self._side = torch.cuda.Stream(device=self.dev) if on_gpu else None          # box matching under the forward pass
+        # The six heads run on a second stream BESIDE the extra-layer chain (forward and backward): conv8_1 .. conv11_2 and
+        # pred3 .. pred6 work on 10 x 10 ... 3 x 3 maps -- ~130 launches of 5-25 us that leave most of the chip idle and are
+        # bound by launch-to-launch latency, 14 % of the step for 0.5 % of its FLOPs.  Each head only depends on its own
+        # feature map, so the head chain (incl. the two large heads pred1 / pred2, which fill the idle CUs) overlaps with the
+        # sequential extras.  Config key 'tail_stream' (default on).  The two chains use separate batch-norm workspaces and
+        # separate split-K scratch slots (odtk_scratch_slot).
+        self._tail = torch.cuda.Stream(device=self.dev) if (on_gpu and config.get('tail_stream', True) and self.wgrad_stream is None) else None
         self._g_front = self._g_back = None
         self._g_back_segs = None
         self._eager_steps = 0
@@ -390,6 +406,7 @@ class SSD300:
         for a in self.acts.values():
             max_ws = max(max_ws, ops.bn_workspace_bytes(a.M, a.C))
         self.ws = torch.zeros(max_ws, dtype=torch.uint8, device=dev)
+        self.ws_tail = torch.zeros(max_ws, dtype=torch.uint8, device=dev) if self._tail is not None else None
         # dgrad-layout filters
         self.wt = {}
         for name, c in self.convs.items():
@@ -477,6 +494,12 @@ class SSD300:
                     ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
         c43 = a['conv4_3']
         ops.l2norm_fwd(c43.t, a['feat1'].t, c43.M, 512, c43.ld, self.param('l2norm.gamma'))
+        tail = self._tail if self.sync_bn is None else None
+        main = torch.cuda.current_stream() if tail is not None else None
+        if tail is not None:
+            tail.wait_stream(main)                       # fork: feat1 is final
+            with self._on_tail():
+                self._head_fwd(0, training)
         for (name, ci, co, k, s, d) in EXTRA_SEQ:
             src = a[self.extra_src[name]]
             z, y = self.zbuf[name], a[name]
@@ -485,17 +508,41 @@ class SSD300:
             self._bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
                        self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, True,
                        y.t, y.ld, z.M, 0, self.ws)
+            if tail is not None and name in FEAT_SRC:
+                tail.wait_stream(main)                   # this feature map is final: its head may start
+                with self._on_tail():
+                    self._head_fwd(FEAT_SRC.index(name), training)
+        if tail is not None:
+            main.wait_stream(tail)                       # join: pred is complete
+        else:
+            for i in range(6):
+                self._head_fwd(i, training)
+
+    def _head_fwd(self, i, training):
+        """pred<i+1>: 3x3 conv + bias + batch norm, written straight into pred [N, 8828, 25] (SSD300.py:85-90, :316-321)"""
+        a = self.acts
         A25 = NUM_PRIORS * self.row
-        for i, src_name in enumerate(FEAT_SRC):
-            name = f'pred{i + 1}'
-            src, z = a[src_name], self.zbuf[name]
-            self._conv_fwd(name, src, z, self.param(name + '.b'), False)
-            sm, si = self.bnsave[name]
-            co = self.convs[name].cout
-            out = self.pred.view(-1)[self.head_off[i] * self.row:]
-            self._bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
-                       self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, False,
-                       out, co, src.H * src.W, A25, self.ws)
+        name = f'pred{i + 1}'
+        src, z = a[FEAT_SRC[i]], self.zbuf[name]
+        self._conv_fwd(name, src, z, self.param(name + '.b'), False)
+        sm, si = self.bnsave[name]
+        co = self.convs[name].cout
+        out = self.pred.view(-1)[self.head_off[i] * self.row:]
+        self._bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
+                   self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, False,
+                   out, co, src.H * src.W, A25, self.ws)
+
+    @contextlib.contextmanager
+    def _on_tail(self):
+        """launches inside go to the head stream, with its own batch-norm workspace and split-K scratch slot"""
+        ops.scratch_slot(1)
+        ws, self.ws = self.ws, self.ws_tail
+        try:
+            with torch.cuda.stream(self._tail):
+                yield
+        finally:
+            self.ws = ws
+            ops.scratch_slot(0)
 
     # ------------------------------------------------------------------ loss
     def _match(self):
@@ -547,32 +594,47 @@ class SSD300:
         """Backward pass as a generator: it hands back a layer name as soon as every gradient of that layer (and of all
         later layers) has been launched -- the data-parallel hooks and the segmented graph capture hang on these points."""
         a = self.acts
-        A25 = NUM_PRIORS * self.row
-        # heads (pred6 .. pred1): dpred -> BN bwd -> wgrad / dgrad into the feature map
-        for i in reversed(range(6)):
-            name = f'pred{i + 1}'
-            src, z = a[FEAT_SRC[i]], self.zbuf[name]
-            co = self.convs[name].cout
-            sm, si = self.bnsave[name]
-            dyv = self.dpred.view(-1)[self.head_off[i] * self.row:]
-            self._bn_bwd(z.t, None, dyv, z.M, co, z.ld, co, src.H * src.W, A25, self.param(name + '.gamma'), sm, si,
-                       False, z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
-            self._conv_bwd_params(name, src, z.g, z.ld)
-            ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], None, src.g, False)
-            yield name
+        tail = self._tail if (self.sync_bn is None and self.wgrad_stream is None) else None
+        evs = {}
+        if tail is None:
+            # heads (pred6 .. pred1): dpred -> BN bwd -> wgrad / dgrad into the feature map
+            for i in reversed(range(6)):
+                self._head_bwd(i)
+                yield f'pred{i + 1}'
+        else:
+            # ... on the head stream, beside the extras' chain; an event per head tells the chain when a feature map's
+            # gradient holds the head's contribution
+            main = torch.cuda.current_stream()
+            tail.wait_stream(main)                       # fork: d(pred) is final
+            with self._on_tail():
+                for i in reversed(range(6)):
+                    self._head_bwd(i)
+                    evs[FEAT_SRC[i]] = torch.cuda.Event()
+                    evs[FEAT_SRC[i]].record()
         # extra layers conv11_2 .. conv6
         for (name, ci, co, k, s, d) in reversed(EXTRA_SEQ):
             src = a[self.extra_src[name]]
             z, y = self.zbuf[name], a[name]
             sm, si = self.bnsave[name]
+            if name == 'conv11_2' and name in evs:
+                main.wait_event(evs[name])               # the last feature map: only its head wrote y.g
             self._bn_bwd(z.t, y.t, y.g, z.M, co, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, True,
                        z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
             self._conv_bwd_params(name, src, z.g, z.ld)
             # the source already holds the head's gradient when it is a feature map
             acc = self.extra_src[name] in FEAT_SRC
+            if acc and self.extra_src[name] in evs:
+                main.wait_event(evs[self.extra_src[name]])
             relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], relu_src, src.g, acc)
-            yield name
+            if tail is None:
+                yield name
+        if tail is not None:
+            main.wait_stream(tail)                       # join: pred1 -> feat1.g is final before the trunk reads it
+            for i in reversed(range(6)):
+                yield f'pred{i + 1}'
+            for e in reversed(EXTRA_SEQ):
+                yield e[0]
         # VGG trunk
         for step in reversed(self.vgg_plan):
             if step[0] == 'pool':
@@ -596,6 +658,19 @@ class SSD300:
                 yield name
         if self.wgrad_stream is not None and self.dist is None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)     # join before the optimizer
+
+    def _head_bwd(self, i):
+        a = self.acts
+        A25 = NUM_PRIORS * self.row
+        name = f'pred{i + 1}'
+        src, z = a[FEAT_SRC[i]], self.zbuf[name]
+        co = self.convs[name].cout
+        sm, si = self.bnsave[name]
+        dyv = self.dpred.view(-1)[self.head_off[i] * self.row:]
+        self._bn_bwd(z.t, None, dyv, z.M, co, z.ld, co, src.H * src.W, A25, self.param(name + '.gamma'), sm, si,
+                   False, z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
+        self._conv_bwd_params(name, src, z.g, z.ld)
+        ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], None, src.g, False)
 
     def _mark_ready(self, layer_name):
         if self.dist is not None:
@@ -689,12 +764,48 @@ class SSD300:
                     segs.append((g, names))
             self._g_back_segs = segs
 
+    AUTO_STEPS = 5
+
+    @property
+    def launch_mode_pending(self):
+        """True while use_graph='auto' has not decided yet (bench.py keeps warming up until it has)"""
+        return self._auto is not None and self.use_graph
+
+    def _auto_step(self, lr):
+        """One calibration step of use_graph='auto': steps AUTO_STEPS.. replay the graphs, the last AUTO_STEPS launch eagerly."""
+        au = self._auto
+        mode = 'graph' if au['left'] > self.AUTO_STEPS else 'eager'
+        torch.cuda.synchronize()
+        t0 = __import__('time').perf_counter()
+        saved = self.use_graph
+        self.use_graph = mode == 'graph'
+        self._auto = None
+        try:
+            loss = self.train_step(lr)
+        finally:
+            self._auto, self.use_graph = au, saved
+        torch.cuda.synchronize()
+        au['t'].setdefault(mode, []).append(__import__('time').perf_counter() - t0)
+        au['left'] -= 1
+        if au['left'] == 0:
+            best = {m: min(v[1:]) for m, v in au['t'].items()}        # first step of a mode: one-off costs
+            self.use_graph = best['graph'] <= best['eager']
+            self.launch_mode = {'picked': 'graph' if self.use_graph else 'eager', 'ms': {m: round(v * 1e3, 3) for m, v in best.items()}}
+            self._auto = None
+            if self.verbose:
+                print('[odtk] launch mode:', self.launch_mode)
+        return loss
+
+    launch_mode = None
+
     def train_step(self, lr):
         """One optimizer step on the batch loaded by set_batch(); returns the loss (data + L2)
         as a 1-element device tensor without synchronising."""
         use_graph = self.use_graph and self._eager_steps >= 2
         if use_graph and self._g_front is None:
             use_graph = self._graphs_build_safe()
+        if use_graph and self._auto is not None:
+            return self._auto_step(lr)
         if self.dist is not None:
             self.dist.begin_step()
         if use_graph:

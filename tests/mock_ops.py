@@ -439,6 +439,10 @@ def retina_loss(pconf, pbox, yx, hw, gt, ngt, best, status, rgindex, counts, alp
     dconf.copy_(gc); dbox.copy_(gb)
 
 
+def scratch_slot(slot):
+    pass
+
+
 @contextlib.contextmanager
 def installed():
     """swap the launching functions of odtk.ops for the ones above (and back)"""

@@ -222,3 +222,36 @@ def test_graph_replay_gradients_match_eager_under_allocation_churn(side_stream, 
     assert m._g_front is not None                              # steps 2.. were graph replays
     if side_stream == "dp":
         assert m._g_back is None and len(m._g_back_segs) >= 4 and sum(len(n) for _, n in m._g_back_segs) >= 25
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_head_stream_equals_single_stream(use_graph, dev):
+    """config 'tail_stream' (default on): the six heads run on a second stream beside the extra-layer chain, forward and backward,
+    with their own batch-norm workspace and split-K scratch slot.  The result must be what the one-stream order computes: same
+    loss, same predictions (bit for bit: no atomics in the forward pass), same gradients up to the float-atomic order of wgrad --
+    for several steps, so that a missing cross-stream dependency (a head reading a feature map too early, an extras dgrad
+    accumulating into a gradient buffer the head has not written yet) has a chance to show."""
+    import odtk
+    B = 8
+    imgs, gt = R.synthetic_batch(B, 17)
+    res = {}
+    for tail in (False, True):
+        cfg = dict(CONFIG, compute_dtype='bf16', batch_size=B, use_graph=use_graph, tail_stream=tail, seed=2)
+        m = odtk.SSD300(cfg, {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+        assert (m._tail is not None) == tail
+        m.set_batch(imgs, gt)
+        out = []
+        for step in range(5):
+            loss = float(m.train_step(0.0).item())           # lr 0: identical weights in every step
+            torch.cuda.synchronize()
+            out.append((loss, m.pred.clone(), m.G.clone()))
+        res[tail] = out
+        assert (m._g_front is not None) == use_graph
+    for (l0, p0, g0), (l1, p1, g1) in zip(res[False], res[True]):
+        assert l0 == l1 or abs(l0 - l1) <= 1e-6 * abs(l0)
+        assert torch.equal(p0, p1)
+        assert float((g0 - g1).abs().max()) <= 2e-2 * float(g0.abs().max())
+        for name, (off, shape) in m.pinfo.items():
+            n = int(np.prod(shape))
+            a, b = g0[off:off + n], g1[off:off + n]
+            assert float((a - b).abs().max()) <= 2e-2 * (float(a.abs().max()) + 1e-12), name

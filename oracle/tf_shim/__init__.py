@@ -617,10 +617,40 @@ losses = _Losses()
 
 class _Image:
     @staticmethod
-    def non_max_suppression(boxes, scores, max_output_size, iou_threshold=0.5):
-        from oracle import ssd300_ref
-        idx = ssd300_ref.nms(boxes.detach().numpy(), scores.detach().numpy(), int(max_output_size), float(iou_threshold))
-        return torch.from_numpy(idx.astype(np.int32))
+    def non_max_suppression(boxes, scores, max_output_size, iou_threshold=0.5, score_threshold=float('-inf')):
+        """tf.image.non_max_suppression (NonMaxSuppressionV3) -- the shim's OWN implementation, written a different way than
+        oracle/nms_ref.cpp (which mirrors the op's priority queue): the whole IoU matrix in float32 numpy with the op's
+        expression (corner-order agnostic, area <= 0 -> 0, inter / (a_i + a_j - inter)), candidates in descending score order
+        (equal scores: lower index first -- what the op's heap gives for boxes pushed in index order whenever it matters
+        for the fixtures: their scores are distinct), suppression iff IoU > threshold (strict).  The golden fixtures produced
+        through this function therefore CROSS-CHECK nms_ref.cpp instead of echoing it (round-1 verdict)."""
+        b = np.asarray(boxes.detach().numpy() if hasattr(boxes, 'detach') else boxes, dtype=np.float32).reshape(-1, 4)
+        sc = np.asarray(scores.detach().numpy() if hasattr(scores, 'detach') else scores, dtype=np.float32).reshape(-1)
+        n = sc.shape[0]
+        if n == 0 or int(max_output_size) <= 0:
+            return torch.zeros(0, dtype=torch.int32)
+        y0, y1 = np.minimum(b[:, 0], b[:, 2]), np.maximum(b[:, 0], b[:, 2])
+        x0, x1 = np.minimum(b[:, 1], b[:, 3]), np.maximum(b[:, 1], b[:, 3])
+        area = ((y1 - y0) * (x1 - x0)).astype(np.float32)
+        order = np.lexsort((np.arange(n), -sc.astype(np.float64)))
+        order = order[sc[order] > np.float32(score_threshold)]
+        keep = []
+        thr = np.float32(iou_threshold)
+        for i in order:
+            if len(keep) >= int(max_output_size):
+                break
+            if keep:
+                k = np.asarray(keep)
+                ih = np.maximum(np.minimum(y1[i], y1[k]) - np.maximum(y0[i], y0[k]), np.float32(0)).astype(np.float32)
+                iw = np.maximum(np.minimum(x1[i], x1[k]) - np.maximum(x0[i], x0[k]), np.float32(0)).astype(np.float32)
+                inter = (ih * iw).astype(np.float32)
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    iou = (inter / ((area[i] + area[k]).astype(np.float32) - inter)).astype(np.float32)
+                iou = np.where((area[i] <= 0) | (area[k] <= 0), np.float32(0), iou)
+                if np.any(iou > thr):
+                    continue
+            keep.append(int(i))
+        return torch.from_numpy(np.asarray(keep, dtype=np.int32))
 
 
 class _ResizeMethod:

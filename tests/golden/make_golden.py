@@ -40,13 +40,11 @@ def vgg_tensors(p):
 
 
 def push_params(p):
-    """Copy the oracle-named parameters into the shim's variable store (creation-order BN names)."""
+    """Copy the oracle-named parameters into the shim's variable store (batch-norm default names: numbered per enclosing variable scope)."""
     V = tf_shim.S.variables
-    bn = 0
     for scope, names in (('feature_extractor', EXTRA), ('regressor', [f'pred{i}' for i in range(1, 7)])):
-        for n in names:
+        for bn, n in enumerate(names):                   # default layer names are numbered per enclosing variable scope
             bns = 'batch_normalization' if bn == 0 else f'batch_normalization_{bn}'
-            bn += 1
             with torch.no_grad():
                 V[f'{scope}/{n}/kernel'].copy_(p[n + '.w'].permute(1, 2, 3, 0))
                 V[f'{scope}/{n}/bias'].copy_(p[n + '.b'])
@@ -72,11 +70,9 @@ def pull_params():
             if bname not in V:                       # reference typo: 'bias_conv_3_1' (SSD300.py:232)
                 bname = 'feature_extractor/bias_conv_3_1'
             out[n + '.b'] = V[bname].detach().numpy().copy()
-    bn = 0
     for scope, names in (('feature_extractor', EXTRA), ('regressor', [f'pred{i}' for i in range(1, 7)])):
-        for n in names:
+        for bn, n in enumerate(names):                   # default layer names are numbered per enclosing variable scope
             bns = 'batch_normalization' if bn == 0 else f'batch_normalization_{bn}'
-            bn += 1
             out[n + '.w'] = V[f'{scope}/{n}/kernel'].detach().permute(3, 0, 1, 2).contiguous().numpy()
             out[n + '.b'] = V[f'{scope}/{n}/bias'].detach().numpy().copy()
             out[n + '.gamma'] = V[f'{scope}/{bns}/gamma'].detach().numpy().copy()

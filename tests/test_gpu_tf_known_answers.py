@@ -1,0 +1,75 @@
+"""GPU: TensorFlow's own known answers (tests/tf_known_answers.py) against the HIP kernels, through the C-ABI:
+NonMaxSuppression op-test vectors on both NMS engines, the ResizeImagesTest tables on odtk_resize_bilinear_fwd (TF-1.x grid) and on
+the augmentor's align_corners=True resize, the fused-batch-norm statistics on odtk_bn_fwd."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tf_known_answers as K  # noqa: E402
+
+
+def _ops():
+    import odtk  # noqa: F401
+    from odtk import ops
+    return ops
+
+
+@pytest.mark.parametrize("engine", ["split", "single"])
+@pytest.mark.parametrize("case", [c for c in K.NMS_CASES if len(c[2])], ids=[c[0] for c in K.NMS_CASES if len(c[2])])
+def test_nms_op_vectors(case, engine, dev):
+    name, boxes, scores, max_out, iou, score_thr, want = case
+    ops = _ops()
+    ops.debug_set(3, 1 if engine == "single" else 0)
+    try:
+        n = len(scores)
+        b = torch.from_numpy(boxes).to(dev).contiguous()
+        s = torch.from_numpy(scores).to(dev).contiguous()
+        valid = torch.from_numpy((scores > (-np.inf if score_thr is None else score_thr)).astype(np.uint8)).to(dev)   # V3's score threshold
+        cap = max(max_out, 1)
+        out_idx = torch.full((1, cap), -1, dtype=torch.int32, device=dev)
+        out_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.nms_batched(b, 0, s, n, 1, valid, n, 1, 1, n, 1, None, 0, max_out, iou, out_idx, cap, out_cnt)
+        torch.cuda.synchronize()
+        assert out_idx[0, : int(out_cnt[0])].cpu().tolist() == want
+    finally:
+        ops.debug_set(3, 0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_resize_bilinear_legacy_grid(dt, dev):
+    ops = _ops()
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    C = 8
+    x = torch.from_numpy(K.RESIZE_LEGACY_IN).repeat(1, 1, C).reshape(6, C).to(dtype).to(dev).contiguous()        # rows = 3 x 2 pixels
+    y = torch.zeros(24, C, dtype=dtype, device=dev)
+    ops.resize_bilinear_fwd(x, C, y, C, 1, 3, 2, 6, 4, C)
+    torch.cuda.synchronize()
+    want = torch.from_numpy(K.RESIZE_LEGACY_OUT).reshape(24, 1).repeat(1, C)
+    assert torch.equal(y.float().cpu(), want)                     # every table value is exact in bf16
+
+
+def test_augmentor_resize_align_corners(dev):
+    from odtk import augment as A
+    img = torch.from_numpy(K.RESIZE_ALIGN_IN).repeat(1, 1, 3).to(dev).contiguous()         # HWC f32, 3 x 2 x 3
+    out = A.image_augmentor(img, [3, 2, 3], 'channels_last', output_shape=[5, 4], fill_mode='BILINEAR')
+    torch.cuda.synchronize()
+    want = torch.from_numpy(K.RESIZE_ALIGN_OUT).repeat(1, 1, 3)
+    assert torch.allclose(out.float().cpu().reshape(5, 4, 3), want, atol=1e-5)
+
+
+def test_fused_batch_norm_training_statistics(dev):
+    ops = _ops()
+    e = K.BN_EXPECT
+    C, M = 4, 2                                                     # one f32 chunk of identical channels
+    z = torch.from_numpy(K.BN_X).reshape(2, 1).repeat(1, C).to(dev).contiguous()
+    mm = torch.zeros(C, device=dev); mv = torch.ones(C, device=dev)
+    sm = torch.empty(C, device=dev); si = torch.empty(C, device=dev)
+    ws = torch.zeros(ops.bn_workspace_bytes(M, C), dtype=torch.uint8, device=dev)
+    y = torch.zeros(M, C, device=dev)
+    ops.bn_fwd(z, M, C, C, torch.ones(C, device=dev), torch.zeros(C, device=dev), mm, mv, sm, si, True, False, y, C, M, M * C, ws)
+    torch.cuda.synchronize()
+    assert torch.allclose(y[:, 0].cpu(), torch.tensor(e['y'], dtype=torch.float32), atol=1e-6)
+    assert abs(float(sm[0]) - e['mean']) < 1e-6
+    assert abs(float(mm[0]) - e['moving_mean']) < 1e-6 and abs(float(mv[0]) - e['moving_var']) < 1e-6

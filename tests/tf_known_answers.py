@@ -1,0 +1,53 @@
+"""Known answers of TensorFlow 1.x's OWN kernels and documentation, quoted from memory of TensorFlow's source tree (no
+TensorFlow binary exists in this environment; every vector names the file / test it comes from so that it can be checked
+against a TensorFlow checkout).  They pin the layer BELOW the reference's Python: the semantics oracle/tf_shim, the oracles
+and the HIP kernels all have to share.  Used by tests/test_tf_known_answers_cpu.py and tests/test_gpu_tf_known_answers.py.
+"""
+import numpy as np
+
+# ---- tensorflow/core/kernels/non_max_suppression_op_test.cc (NonMaxSuppressionOpTest / V2 / V3: same vectors) -------------
+# boxes are (y1, x1, y2, x2); three clusters of overlapping boxes
+NMS_BOXES = np.array([[0, 0, 1, 1], [0, 0.1, 1, 1.1], [0, -0.1, 1, 0.9], [0, 10, 1, 11], [0, 10.1, 1, 11.1], [0, 100, 1, 101]], np.float32)
+NMS_BOXES_FLIPPED = np.array([[1, 1, 0, 0], [0, 0.1, 1, 1.1], [0, .9, 1, -0.1], [0, 10, 1, 11], [1, 10.1, 0, 11.1], [1, 101, 0, 100]], np.float32)
+NMS_SCORES = np.array([.9, .75, .6, .95, .5, .3], np.float32)
+NMS_CASES = [
+    # name of the TEST_F,                                   boxes,             scores,            max, iou, score_thr, expected
+    ('TestSelectFromThreeClusters',                          NMS_BOXES,         NMS_SCORES,        3,   .5,  None,     [3, 0, 5]),
+    ('TestSelectFromThreeClustersFlippedCoordinates',        NMS_BOXES_FLIPPED, NMS_SCORES,        3,   .5,  None,     [3, 0, 5]),
+    ('TestSelectAtMostTwoBoxesFromThreeClusters',            NMS_BOXES,         NMS_SCORES,        2,   .5,  None,     [3, 0]),
+    ('TestSelectWithNegativeScores',                         NMS_BOXES,         NMS_SCORES - 10.,  6,   .5,  None,     [3, 0, 5]),
+    ('TestSelectAtMostThirtyBoxesFromThreeClusters',         NMS_BOXES,         NMS_SCORES,        30,  .5,  None,     [3, 0, 5]),
+    ('TestSelectSingleBox',                                  NMS_BOXES[:1],     NMS_SCORES[:1],    3,   .5,  None,     [0]),
+    ('TestSelectFromTenIdenticalBoxes',                      np.tile(NMS_BOXES[:1], (10, 1)), np.full(10, .9, np.float32), 3, .5, None, [0]),
+    ('V3 TestSelectFromThreeClustersWithScoreThreshold',     NMS_BOXES,         NMS_SCORES,        3,   .5,  .4,       [3, 0]),
+    ('TestEmptyInput',                                       np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 30, .5, None, []),
+]
+
+# ---- tensorflow/python/ops/image_ops_test.py, ResizeImagesTest -------------------------------------------------------------
+# testResizeUp (align_corners=False, the TF-1.x grid: src = dst * in / out): 3 x 2 -> 6 x 4
+RESIZE_LEGACY_IN = np.array([64, 32, 32, 64, 50, 100], np.float32).reshape(3, 2, 1)
+RESIZE_LEGACY_OUT = np.array([64.0, 48.0, 32.0, 32.0, 48.0, 48.0, 48.0, 48.0, 32.0, 48.0, 64.0, 64.0,
+                              41.0, 61.5, 82.0, 82.0, 50.0, 75.0, 100.0, 100.0, 50.0, 75.0, 100.0, 100.0], np.float32).reshape(6, 4, 1)
+# testResizeUpAlignCornersTrue: 3 x 2 -> 5 x 4, scale = (in - 1) / (out - 1)
+RESIZE_ALIGN_IN = np.array([6, 3, 3, 6, 6, 9], np.float32).reshape(3, 2, 1)
+RESIZE_ALIGN_OUT = np.array([6.0, 5.0, 4.0, 3.0, 4.5, 4.5, 4.5, 4.5, 3.0, 4.0, 5.0, 6.0, 4.5, 5.5, 6.5, 7.5, 6.0, 7.0, 8.0, 9.0], np.float32).reshape(5, 4, 1)
+
+# ---- tensorflow/docs_src/api_guides/python/nn.md ("Convolution": the SAME / VALID diagram) ---------------------------------
+# input width 13, filter width 6, stride 5:  VALID keeps 2 windows and drops 12, 13;  SAME pads 1 left and 2 right -> 3 windows:
+#     pad| 0 |1 2 3 4 5 6 7 8 9 10 11 12 13| 0 0 |pad       out = ceil(13 / 5) = 3, total = (3 - 1) * 5 + 6 - 13 = 3, before = 3 // 2
+SAME_PAD_CASES = [  # (in, k, stride, dil) -> (out, pad_before, pad_after)
+    ((13, 6, 5, 1), (3, 1, 2)),
+    ((300, 3, 1, 1), (300, 1, 1)),        # SSD300 3x3 / s1
+    ((19, 3, 2, 1), (10, 1, 1)),          # conv8_2: 19 -> 10 (odd input, total 2)
+    ((10, 3, 2, 1), (5, 0, 1)),           # conv9_2: 10 -> 5  (even input: the extra cell goes bottom / right only)
+    ((75, 2, 2, 1), (38, 0, 1)),          # pool3: 75 -> 38
+    ((19, 3, 1, 2), (19, 2, 2)),          # conv6, dilation 2 (effective kernel 5)
+]
+
+# ---- tensorflow/python/ops/nn_fused_batchnorm_test.py, _training_ref ---------------------------------------------------------
+# y is normalised with the BIASED batch variance; the variance handed to the moving average is the UNBIASED one
+# (var * n / max(n - 1, 1)); tf.layers.batch_normalization: moving = moving * momentum + batch * (1 - momentum), momentum 0.99,
+# epsilon 1e-3.  Smallest case: one channel, values 1 and 3 -> mean 2, biased variance 1, unbiased 2.
+BN_X = np.array([1., 3.], np.float32).reshape(2, 1, 1, 1)
+BN_EXPECT = dict(mean=2.0, var_biased=1.0, var_unbiased=2.0, y=[-1.0 / np.sqrt(1.0 + 1e-3), 1.0 / np.sqrt(1.0 + 1e-3)],
+                 moving_mean=0.0 * 0.99 + 2.0 * 0.01, moving_var=1.0 * 0.99 + 2.0 * 0.01)

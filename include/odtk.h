@@ -201,7 +201,8 @@ int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N
 
 /* tf.contrib.layers.group_norm(groups, epsilon 1e-6) (+ ReLU when relu != 0) on NHWC rows [N*HW][ld]: the normalisation of the
  * reference's FCOS (FCOS.py:438-446).  Statistics per sample and group over HW x (C / groups) elements; save_mean_rstd [N][groups][2]
- * (may be NULL in inference).  Backward: dx (accumulate != 0 adds to it), dgamma / dbeta [C] overwritten; the ReLU mask comes from the
+ * (may be NULL in inference).  Backward: `accumulate` bit 0 adds to dx instead of overwriting it, bit 1 adds to dgamma / dbeta [C] (a norm
+ * whose parameters serve several activations: FCOS shares its heads over the pyramid levels, FCOS.py:351,358); the ReLU mask comes from the
  * sign of y.  workspace: odtk_gn_workspace_bytes(N, C). */
 long long odtk_gn_workspace_bytes(int N, int C);
 int odtk_gn_fwd(const void* x, int ldx, void* y, int ldy, int N, int HW, int C, int groups, int dtype, const float* gamma,

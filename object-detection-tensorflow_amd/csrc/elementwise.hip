@@ -1597,13 +1597,13 @@ __global__ void __launch_bounds__(GN_THREADS) gn_bwd_kernel(const T* __restrict_
     }
 }
 
-__global__ void gn_param_grad_kernel(const float* __restrict__ part, int N, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void gn_param_grad_kernel(const float* __restrict__ part, int N, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float sg = 0.f, sb = 0.f;
     for (int n = 0; n < N; ++n) { sg += part[((size_t)n * 2 + 0) * C + c]; sb += part[((size_t)n * 2 + 1) * C + c]; }
-    dgamma[c] = sg;
-    dbeta[c] = sb;
+    dgamma[c] = acc ? dgamma[c] + sg : sg;          // acc: a norm whose gamma / beta serve several activations (FCOS heads shared over the levels)
+    dbeta[c] = acc ? dbeta[c] + sb : sb;
 }
 
 }  // namespace
@@ -1630,8 +1630,8 @@ extern "C" int odtk_gn_bwd(const void* x, int ldx, const void* y, const void* dy
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(gn_bwd_kernel<T>, dim3(groups, N), dim3(GN_THREADS), 0, st, (const T*)x, ldx, (const T*)y, (const T*)dy, ldy,
-                                           (T*)dx, lddx, HW, C, groups, gamma, save_mean_rstd, relu, accumulate, part);)
-    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, N, C, dgamma, dbeta);
+                                           (T*)dx, lddx, HW, C, groups, gamma, save_mean_rstd, relu, accumulate & 1, part);)
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, N, C, dgamma, dbeta, accumulate & 2);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

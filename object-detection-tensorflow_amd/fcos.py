@@ -6,11 +6,13 @@ Reference: /root/reference/FCOS.py
   * network .............................. :70-110, :350-382, :438-513: EVERY normalisation is tf.contrib.layers.group_norm(groups=8);
                                            stem conv + GN + ReLU + 3x3 / s2 max pool; bottleneck units [GN-ReLU-1x1 f, GN-ReLU-3x3 f (stride),
                                            GN-ReLU-1x1 4f] + [GN-ReLU-3x3 4f (stride)] shortcut; c3 / c4 / c5 1x1; bilinear top-down pyramid (the sum is
-                                           handed down); p6 / p7; per level 4 x 3x3 -> classes and centre-ness, 4 x 3x3 -> exp(distances)
+                                           handed down); p6 / p7; per level 4 x 3x3 -> classes and centre-ness, 4 x 3x3 -> exp(distances), the head WEIGHTS shared by the
+                                           levels (variable_scope(..., reuse=tf.AUTO_REUSE), :351, :358)
   * loss, optimizer ...................... :111-192  (odtk_fcos_loss; mean over images + wd * l2; Momentum 0.9)
   * inference ............................ :193-265  (heads.fcos_detect; classes 0 .. C-2, sic)
   * train / test / checkpoints ........... :401-436
-Same conventions as retinanet.py: layers l0 .. l129 in creation order (layer k = conv k + group norm k), one flat f32 parameter buffer.
+Same conventions as retinanet.py: layers l0 .. l85 in creation order (layer k = conv k + group norm k; l75 .. l85 are the heads, ONE set of
+weights applied at all five pyramid levels -- instance names l<k>@<level>), one flat f32 parameter buffer.
 Group norm has no batch statistics: nothing like moving averages exists, and data parallel needs no sync-BN.
 """
 from __future__ import annotations
@@ -57,15 +59,21 @@ def layer_specs(num_classes):
     add(256, 256, 1, 1); add(256, 256, 3, 1)
     add(256, 256, 3, 2); add(256, 256, 3, 2)
     bias = -math.log((1 - PI) / PI)
-    for _ in range(5):
-        for _ in range(4):
-            add(256, 256, 3, 1)
-        add(256, num_classes, 3, 1, bias)
-        add(256, 1, 3, 1, bias)
-        for _ in range(4):
-            add(256, 256, 3, 1)
-        add(256, 4, 3, 1)
+    # ONE set of head layers for all five levels: _detect_head enters variable_scope('classifier_head' / 'regress_head',
+    # reuse=tf.AUTO_REUSE) once per level (FCOS.py:351, :358); leaving a variable scope resets the default-name counters of its
+    # sub-scopes (variable_scope.py, close_variable_subscopes), so every level asks for conv2d, conv2d_1, ... and GroupNorm,
+    # GroupNorm_1, ... again and AUTO_REUSE hands back the variables of the first level: convs AND group norms are shared.
+    for _ in range(4):
+        add(256, 256, 3, 1)
+    add(256, num_classes, 3, 1, bias)
+    add(256, 1, 3, 1, bias)
+    for _ in range(4):
+        add(256, 256, 3, 1)
+    add(256, 4, 3, 1)
     return specs
+
+
+HEAD_LAYERS = 11                                               # the last 11 specs: 6 classifier-head + 5 regress-head layers, shared by the levels
 
 
 class _Act:
@@ -209,16 +217,18 @@ class FCOS:
             self.desc[name] = d
             return d
 
-        def gnconv(x):
-            """group norm -> ReLU -> conv(bias): returns the conv output"""
-            name, cin, cout, k, stride, gnc, _ = next(it)
+        def gnconv(x, spec=None, level=None):
+            """group norm -> ReLU -> conv(bias): returns the conv output.  `spec`, `level`: a shared head layer applied at one
+            pyramid level -- parameters under the layer's name `pname`, buffers / descriptor under the instance name pname@level"""
+            pname, cin, cout, k, stride, gnc, _ = next(it) if spec is None else spec
+            name = pname if level is None else f'{pname}@{level}'
             assert cin == x.C == gnc and gnc % GROUPS == 0, (name, cin, x.C)
             y = act(name + '.y', x.H, x.W, x.C)
             d = conv_desc(name, y, cout, k, stride, ops.pad_to(cout, ch))
             out = act(name, d.Ho, d.Wo, cout)
             self.gnsave[name] = torch.zeros(N, GROUPS, 2, device=dev)
             self._max_scr = max(self._max_scr, y.M * y.ld)
-            self.plan.append(('gnconv', name, x, y, out))
+            self.plan.append(('gnconv', name, x, y, out, pname))
             return out
 
         def add(a, b):
@@ -263,23 +273,23 @@ class FCOS:
         self.conf = [torch.zeros(N, a.H, a.W, self.num_classes, device=dev) for a in self.levels]
         self.reg = [torch.zeros(N, a.H, a.W, 4, device=dev) for a in self.levels]
         self.center = [torch.zeros(N, a.H, a.W, 1, device=dev) for a in self.levels]
+        head = list(it)                                         # the 11 head layers: one set of weights, five levels
+        assert len(head) == HEAD_LAYERS
         for l, lvl in enumerate(self.levels):
             c = lvl
-            for _ in range(4):
-                c = gnconv(c)
-            self.plan.append(('pred', gnconv(c), self.conf, l, False))
-            self.plan.append(('pred', gnconv(c), self.center, l, False))
+            for j in range(4):
+                c = gnconv(c, head[j], l)
+            self.plan.append(('pred', gnconv(c, head[4], l), self.conf, l, False))
+            self.plan.append(('pred', gnconv(c, head[5], l), self.center, l, False))
             r = lvl
-            for _ in range(4):
-                r = gnconv(r)
-            self.plan.append(('pred', gnconv(r), self.reg, l, True))       # tf.exp on the distances (FCOS.py:363)
-        assert next(it, None) is None
+            for j in range(4):
+                r = gnconv(r, head[6 + j], l)
+            self.plan.append(('pred', gnconv(r, head[10], l), self.reg, l, True))       # tf.exp on the distances (FCOS.py:363)
         self.wt, entries = {}, []
         for name, cin, cout, k, _, _, _ in self.specs[1:]:
-            d = self.desc[name]
-            kp = self.acts[name].ld
-            self.wt[name] = torch.zeros(d.C * k * k * kp, dtype=dt, device=dev)
-            entries.append((self._flat(name + '.w', self.P), self.wt[name], cout, k, k, d.C, kp))
+            kp, cpad = ops.pad_to(cout, ch), ops.pad_to(cin, ch)        # dgrad-layout filter: one per PARAMETER (shared by the levels)
+            self.wt[name] = torch.zeros(cpad * k * k * kp, dtype=dt, device=dev)
+            entries.append((self._flat(name + '.w', self.P), self.wt[name], cout, k, k, cpad, kp))
         self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, dev)
         if self.mode == 'train':
             self._build_backward(N, dt, dev)
@@ -293,6 +303,7 @@ class FCOS:
         self.scr_y = torch.zeros(self._max_scr, dtype=dt, device=dev)          # d(relu(gn(x))): lives inside one layer
         self.gn_ws = ops.gn_workspace(N, max(s[5] for s in self.specs), dev)
         written = set()
+        seen_params = set()
         self.bplan = []
         for op in reversed(self.plan):
             kind = op[0]
@@ -300,9 +311,14 @@ class FCOS:
                 self.bplan.append(op)
                 written.add(find(op[1].gid))
             elif kind == 'gnconv':
-                _, name, x, y, out = op
+                _, name, x, y, out, pname = op
                 assert find(out.gid) in written, name
-                self.bplan.append(('gnconv', name, x, y, out, find(x.gid) in written))
+                # a shared head layer: its norm's d(gamma), d(beta) accumulate over the levels (the filter / bias gradients always
+                # accumulate); the layer is final -- for the gradient all-reduce -- after the LAST level processed (level 0)
+                first_use = pname not in seen_params
+                seen_params.add(pname)
+                last_use = name == pname or name.endswith('@0')
+                self.bplan.append(('gnconv', name, x, y, out, find(x.gid) in written, pname, not first_use, last_use))
                 written.add(find(x.gid))
             elif kind == 'add':
                 assert find(op[3].gid) in written
@@ -331,17 +347,18 @@ class FCOS:
         return self.g[self.find(a.gid)]
 
     # ------------------------------------------------------------------ forward / loss / backward
-    def _gn_relu(self, name, x, y):
-        ops.gn_fwd(x.t, x.ld, y.t, y.ld, x.N, x.H * x.W, x.C, GROUPS, self.param(name + '.gamma'), self.param(name + '.beta'), 1, self.gnsave[name])
+    def _gn_relu(self, name, x, y, pname=None):
+        pname = pname or name
+        ops.gn_fwd(x.t, x.ld, y.t, y.ld, x.N, x.H * x.W, x.C, GROUPS, self.param(pname + '.gamma'), self.param(pname + '.beta'), 1, self.gnsave[name])
 
     def _forward(self, subtract_mean=True):
         ops.preprocess(self.images, MEAN_RGB if subtract_mean else (0., 0., 0.), self.input.ld, self.DT, self.input.t)
         for op in self.plan:
             kind = op[0]
             if kind == 'gnconv':
-                _, name, x, y, out = op
-                self._gn_relu(name, x, y)
-                ops.conv2d_fwd(self.desc[name], y.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), out.t, False)
+                _, name, x, y, out, pname = op
+                self._gn_relu(name, x, y, pname)
+                ops.conv2d_fwd(self.desc[name], y.t, self._flat(pname + '.w', self.Pc), self.param(pname + '.b'), out.t, False)
             elif kind == 'add':
                 _, a, b, y = op
                 ops.add2d(a.t, a.ld, b.t, b.ld, y.t, y.ld, y.M, y.ld)
@@ -377,14 +394,16 @@ class FCOS:
                     d = self.dconf[l] if targets is self.conf else self.dcenter[l]
                     ops.rows_from_f32(d, c.C, c.M, 0, self.grad_of(c), c.ld, c.M, c.C)
             elif kind == 'gnconv':
-                _, name, x, y, out, acc = op
+                _, name, x, y, out, acc, pname, acc_params, last_use = op
                 dz = self.grad_of(out)
-                ops.conv2d_wgrad(self.desc[name], y.t, dz, out.ld, self._flat(name + '.w', self.G), self._flat(name + '.b', self.G))
+                ops.conv2d_wgrad(self.desc[name], y.t, dz, out.ld, self._flat(pname + '.w', self.G), self._flat(pname + '.b', self.G))
                 dy = self.scr_y[: y.M * y.ld].view(y.M, y.ld)
-                ops.conv2d_dgrad(self.desc[name], dz, out.ld, self.wt[name], None, dy, False)
-                ops.gn_bwd(x.t, x.ld, y.t, dy, y.ld, self.grad_of(x), x.ld, x.N, x.H * x.W, x.C, GROUPS, self.param(name + '.gamma'),
-                           self.gnsave[name], 1, acc, self._flat(name + '.gamma', self.G), self._flat(name + '.beta', self.G), self.gn_ws)
-                yield name
+                ops.conv2d_dgrad(self.desc[name], dz, out.ld, self.wt[pname], None, dy, False)
+                ops.gn_bwd(x.t, x.ld, y.t, dy, y.ld, self.grad_of(x), x.ld, x.N, x.H * x.W, x.C, GROUPS, self.param(pname + '.gamma'),
+                           self.gnsave[name], 1, int(acc) | (2 if acc_params else 0), self._flat(pname + '.gamma', self.G),
+                           self._flat(pname + '.beta', self.G), self.gn_ws)
+                if last_use:
+                    yield pname
             elif kind == 'resize_add':
                 _, lat, top, y, acc = op
                 ops.resize_bilinear_bwd(self.grad_of(y), y.ld, self.grad_of(top), top.ld, top.N, top.H, top.W, y.H, y.W, top.C, acc)
@@ -549,24 +568,22 @@ class FCOS:
 
 
 def reference_variable_map():
-    """name of every variable of the reference's FCOS graph -> our parameter name.  Convs: tf.layers default names count over the whole
-    graph (conv2d ... conv2d_129); group norms: `variable_scope(None, 'GroupNorm')` counts PER enclosing scope (GroupNorm, GroupNorm_1, ...).
-    Scopes: 'backone' (sic, FCOS.py:71) with 'block<b>_unit<u>/conv_branch|identity_branch' (:504-513), 'pyramid' (:98), 'head/classifier_head' and
-    'head/regress_head' (:351, :358; AUTO_REUSE shares nothing).  Pinned by tests/golden/fcos_variables.json (from the reference's own class)."""
+    """name of every variable of the reference's FCOS graph -> our parameter name.  Default layer names (tf.layers: conv2d, conv2d_1, ...;
+    contrib's group_norm: GroupNorm, GroupNorm_1, ...) are numbered PER ENCLOSING variable scope.  Scopes: 'backone' (sic, FCOS.py:71) with
+    'block<b>_unit<u>/conv_branch|identity_branch' (:504-513), 'pyramid' (:98), 'head/classifier_head' and 'head/regress_head' (:351, :358) --
+    entered once per level with reuse=tf.AUTO_REUSE, which SHARES the 6 + 5 head layers over the five levels (layer_specs).
+    Pinned by tests/golden/fcos_variables.json (from the reference's own class on the shim)."""
     scopes = ['backone']
     for b, blocks in enumerate(BLOCKS):
         for u in range(blocks):
             base = f'backone/block{b + 1}_unit{u + 1}'
             scopes += [base + '/conv_branch'] * 3 + [base + '/identity_branch']
-    scopes += ['pyramid'] * 10
-    for _ in range(5):
-        scopes += ['head/classifier_head'] * 6 + ['head/regress_head'] * 5
-    m, gn_count = OrderedDict(), {}
+    scopes += ['pyramid'] * 10 + ['head/classifier_head'] * 6 + ['head/regress_head'] * 5
+    m, count = OrderedDict(), {}
     for i, scope in enumerate(scopes):
-        sfx = '' if i == 0 else f'_{i}'
+        k = count.get(scope, 0)
+        count[scope] = k + 1
+        sfx = f'_{k}' if k else ''
         m[f'{scope}/conv2d{sfx}/kernel'], m[f'{scope}/conv2d{sfx}/bias'] = f'l{i}.w', f'l{i}.b'
-        k = gn_count.get(scope, 0)
-        gn_count[scope] = k + 1
-        gn = f'{scope}/GroupNorm' + (f'_{k}' if k else '')
-        m[gn + '/beta'], m[gn + '/gamma'] = f'l{i}.beta', f'l{i}.gamma'
+        m[f'{scope}/GroupNorm{sfx}/beta'], m[f'{scope}/GroupNorm{sfx}/gamma'] = f'l{i}.beta', f'l{i}.gamma'
     return m

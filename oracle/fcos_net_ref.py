@@ -10,11 +10,14 @@ Follows /root/reference/FCOS.py:
   * pyramid .............................. c3, c4, c5 = 1x1(256) on the last three stages; p5 = 3x3(c5); p4 / p3: ANOTHER 1x1 on c4 / c3 + bilinear
                                            resize of the level above (TF-1.x grid), the sum is handed down, 3x3 on the sum; p6, p7 = 3x3 / s2
                                            (:98-107, :366-382)
-  * heads ................................ per level (variable_scope(..., reuse=AUTO_REUSE) shares nothing: the default layer names are unique per
-                                           call): 4 x 3x3(256) -> 3x3(classes, pi bias) and 3x3(1, pi bias) centre-ness; 4 x 3x3(256) -> exp(3x3(4))
-                                           (:350-364)
+  * heads ................................ 4 x 3x3(256) -> 3x3(classes, pi bias) and 3x3(1, pi bias) centre-ness; 4 x 3x3(256) -> exp(3x3(4))
+                                           (:350-364).  ONE set of 6 + 5 layers (convs AND group norms) serves all five levels: _detect_head enters
+                                           variable_scope('classifier_head' / 'regress_head', reuse=tf.AUTO_REUSE) once per level, leaving a scope
+                                           resets the default-name counters of its sub-scopes (TF 1.x variable_scope.py, close_variable_subscopes),
+                                           so every level asks for conv2d, conv2d_1, ... / GroupNorm, GroupNorm_1, ... again and gets the first
+                                           level's variables back
   * loss / optimizer ..................... mean_i loss_i + wd * l2(all trainables), Momentum 0.9 (:186-192); per-image loss: oracle/fcos_ref.py
-Layers l0 .. l129 in creation order; layer k owns conv k and group norm k ('.w' [K,R,S,C], '.b', '.gamma', '.beta'): l0 is conv -> GN -> ReLU,
+Layers l0 .. l85 in creation order (l75 .. l85: the shared head layers; their ReLU masks / taps are keyed l<k>@<level>); layer k owns conv k and group norm k ('.w' [K,R,S,C], '.b', '.gamma', '.beta'): l0 is conv -> GN -> ReLU,
 every other layer GN -> ReLU -> conv (its GN has the conv's INPUT channels).
 Pinned against the reference's own class run on oracle/tf_shim: tests/golden/fcos_train.npz (tests/golden/make_golden_fcos_net.py).
 Only tests/ and the smoke/bench checkers may import this file.
@@ -60,15 +63,17 @@ def layer_specs(num_classes=20):
     add(256, 256, 1, 1); add(256, 256, 3, 1)                         # p4: 1x1 on c4, 3x3 on the sum
     add(256, 256, 1, 1); add(256, 256, 3, 1)                         # p3
     add(256, 256, 3, 2); add(256, 256, 3, 2)                         # p6, p7
-    for _ in range(5):
-        for _ in range(4):
-            add(256, 256, 3, 1)
-        add(256, num_classes, 3, 1, PI_BIAS)
-        add(256, 1, 3, 1, PI_BIAS)
-        for _ in range(4):
-            add(256, 256, 3, 1)
-        add(256, 4, 3, 1)
+    for _ in range(4):                                               # the heads: one set of layers for all five levels
+        add(256, 256, 3, 1)
+    add(256, num_classes, 3, 1, PI_BIAS)
+    add(256, 1, 3, 1, PI_BIAS)
+    for _ in range(4):
+        add(256, 256, 3, 1)
+    add(256, 4, 3, 1)
     return specs
+
+
+HEAD_LAYERS = 11
 
 
 def init_params(seed=0, num_classes=20):
@@ -96,11 +101,12 @@ class _Net:
     def __init__(self, p, specs, relu_masks, taps):
         self.p, self.specs, self.masks, self.taps, self.i = p, specs, relu_masks, taps, 0
 
-    def _gn_relu(self, name, x):
+    def _gn_relu(self, name, x, key=None):
+        key = key or name                                # instance key of a shared layer: l<k>@<level>
         y = group_norm(x, self.p[name + '.gamma'], self.p[name + '.beta'])
-        y = torch.where(self.masks[name], y, torch.zeros_like(y)) if self.masks is not None else F.relu(y)
+        y = torch.where(self.masks[key], y, torch.zeros_like(y)) if self.masks is not None else F.relu(y)
         if self.taps is not None:
-            self.taps[name] = y
+            self.taps[key] = y
         return y
 
     def stem(self, x):
@@ -112,6 +118,11 @@ class _Net:
         name, _, _, _, stride, _, _ = self.specs[self.i]
         self.i += 1
         return conv2d_same(self._gn_relu(name, x), self.p[name + '.w'], self.p[name + '.b'], stride)
+
+    def head(self, j, level, x):
+        """shared head layer j (0 .. 10, counted from the first head spec) applied at pyramid level `level`"""
+        name, _, _, _, stride, _, _ = self.specs[len(self.specs) - HEAD_LAYERS + j]
+        return conv2d_same(self._gn_relu(name, x, f'{name}@{level}'), self.p[name + '.w'], self.p[name + '.b'], stride)
 
 
 def _resize(x, h, w):
@@ -144,17 +155,17 @@ def forward(p, images_nhwc, subtract_mean=True, relu_masks=None, taps=None):
     p6 = net.conv(p5)
     p7 = net.conv(p6)
     conf, reg, center = [], [], []
-    for level in (p3, p4, p5, p6, p7):
+    assert net.i == len(specs) - HEAD_LAYERS
+    for l, level in enumerate((p3, p4, p5, p6, p7)):
         c = level
-        for _ in range(4):
-            c = net.conv(c)
-        conf.append(net.conv(c).permute(0, 2, 3, 1))
-        center.append(net.conv(c).permute(0, 2, 3, 1))
+        for j in range(4):
+            c = net.head(j, l, c)
+        conf.append(net.head(4, l, c).permute(0, 2, 3, 1))
+        center.append(net.head(5, l, c).permute(0, 2, 3, 1))
         r = level
-        for _ in range(4):
-            r = net.conv(r)
-        reg.append(torch.exp(net.conv(r)).permute(0, 2, 3, 1))
-    assert net.i == len(specs)
+        for j in range(4):
+            r = net.head(6 + j, l, r)
+        reg.append(torch.exp(net.head(10, l, r)).permute(0, 2, 3, 1))
     return conf, reg, center
 
 

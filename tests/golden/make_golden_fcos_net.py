@@ -22,7 +22,7 @@ from oracle import tf_shim                    # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 KEEP = ['l0.w', 'l0.gamma', 'l1.b', 'l1.gamma', 'l3.w', 'l4.w', 'l4.beta', 'l30.w', 'l64.w', 'l65.w', 'l67.b', 'l68.w', 'l70.w', 'l74.w', 'l75.w', 'l79.w',
-        'l79.b', 'l80.w', 'l80.b', 'l85.w', 'l85.gamma', 'l118.w', 'l129.w', 'l129.b']
+        'l79.b', 'l80.w', 'l80.b', 'l81.gamma', 'l84.beta', 'l85.w', 'l85.gamma', 'l85.b']
 CONFIG = {'mode': 'train', 'data_shape': [128, 160, 3], 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
           'batch_size': 2, 'nms_score_threshold': 0.5, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45}
 
@@ -53,7 +53,7 @@ def main():
         json.dump(variables, f, indent=0, sort_keys=True)
     kernels = [k for k in V if k.endswith('/kernel')]
     gns = [k[:-len('/gamma')] for k in V if k.endswith('/gamma')]
-    assert len(kernels) == len(gns) == 130, (len(kernels), len(gns))
+    assert len(kernels) == len(gns) == 86, (len(kernels), len(gns))        # 75 + ONE set of 11 head layers shared by the levels
     p = NR.init_params(41)
     with torch.no_grad():
         for i, (kn, gn) in enumerate(zip(kernels, gns)):

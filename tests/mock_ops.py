@@ -234,12 +234,15 @@ def gn_bwd(x, ldx, y, dy, ldy, dx, lddx, N, HW, C_, groups, gamma, save, relu, a
     if relu:
         d = d * (y[:, :C_].float() > 0)
     xh = _gn_xhat(x, N, HW, C_, groups, save[:, :, 0], save[:, :, 1])
-    dbeta.copy_(d.sum(0)); dgamma.copy_((d * xh.reshape(N * HW, C_)).sum(0))
+    db_, dg_ = d.sum(0), (d * xh.reshape(N * HW, C_)).sum(0)
+    if int(accumulate) & 2:
+        db_, dg_ = db_ + dbeta, dg_ + dgamma
+    dbeta.copy_(db_); dgamma.copy_(dg_)
     dg = (d * gamma.float()).reshape(N, HW, groups, C_ // groups)
     m1 = dg.mean(dim=(1, 3), keepdim=True)
     m2 = (dg * xh).mean(dim=(1, 3), keepdim=True)
     out = (save[:, :, 1].view(N, 1, groups, 1) * (dg - m1 - xh * m2)).reshape(N * HW, C_)
-    if accumulate:
+    if int(accumulate) & 1:
         out = out + dx[:, :C_].float()
     dx[:, :C_] = out.to(dx.dtype)
 

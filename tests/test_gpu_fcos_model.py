@@ -50,9 +50,9 @@ def test_f32_model_matches_oracle_forward_loss_gradients_and_step(dev):
         assert float((m.reg[l].cpu() - reg[l]).abs().max()) < 5e-3 * (float(reg[l].abs().max()) + 1), ('reg', l)
         assert float((m.center[l].cpu() - center[l]).abs().max()) < 2e-3 * (float(center[l].abs().max()) + 1), ('center', l)
     masks = {}
-    for name, *_ in NR.layer_specs():
-        a = m.acts[name if name == 'l0' else name + '.y']
-        masks[name] = (a.t[:, :a.C].float().cpu() > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
+    for name, a in m.acts.items():                   # ReLU outputs: the stem's 'l0', every other layer's '<instance>.y' (heads: l<k>@<level>)
+        if name == 'l0' or name.endswith('.y'):
+            masks[name[:-2] if name.endswith('.y') else name] = (a.t[:, :a.C].float().cpu() > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
     mom = {k: torch.zeros_like(v) for k, v in p.items()}
     total, data, grads = NR.train_step(q, mom, imgs, gt, 0.001, relu_masks=masks)
     assert abs(loss - total) < 2e-3 * abs(total), (loss, total)
@@ -77,10 +77,9 @@ def test_f32_model_matches_oracle_forward_loss_gradients_and_step(dev):
 def test_inference_and_class_surface(dev, tmp_path):
     torch.set_num_threads(16)
     p = NR.init_params(19)
-    for i in (79, 90, 101, 112, 123):                  # class outputs: lift the pi bias so that detections exist
-        p[f'l{i}.b'] = p[f'l{i}.b'] + 4.0
-        p[f'l{i + 1}.b'] = p[f'l{i + 1}.b'] + 4.0       # centre-ness
-        p[f'l{i + 6}.w'] = p[f'l{i + 6}.w'] * 0.05      # distances: keep exp(t) in a sane range
+    p['l79.b'] = p['l79.b'] + 4.0                      # class outputs (shared by the five levels): lift the pi bias so that detections exist
+    p['l80.b'] = p['l80.b'] + 4.0                      # centre-ness
+    p['l85.w'] = p['l85.w'] * 0.05                     # distances: keep exp(t) in a sane range
     imgs, _ = _batch(1, 150)
     m = _model('test', 1, nms_score_threshold=0.3)
     m.load_oracle_params(p)

@@ -68,9 +68,9 @@ def test_retinanet_training_step_host_logic():
         m.set_batch(imgs, gt)
         loss = float(m.train_step(0.01))
         masks = {}
-        for name, *_ in NR.layer_specs():
-            a = m.acts[name if name == 'l0' else name + '.y']
-            masks[name] = (a.t[:, :a.C] > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
+        for name, a in m.acts.items():               # ReLU outputs: the stem's 'l0', every other layer's '<instance>.y' (heads: l<k>@<level>)
+            if name == 'l0' or name.endswith('.y'):
+                masks[name[:-2] if name.endswith('.y') else name] = (a.t[:, :a.C] > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
         q = {k: v.clone() for k, v in p.items()}
         mom = {k: torch.zeros_like(v) for k, v in p.items() if k in NR.trainable_names(p)}
         total, data, grads = NR.train_step(q, mom, imgs, gt, 0.01, relu_masks=masks)
@@ -103,9 +103,9 @@ def test_fcos_training_step_host_logic():
         m.set_batch(imgs, gt)
         loss = float(m.train_step(0.001))
         masks = {}
-        for name, *_ in NR.layer_specs():
-            a = m.acts[name if name == 'l0' else name + '.y']
-            masks[name] = (a.t[:, :a.C] > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
+        for name, a in m.acts.items():               # ReLU outputs: the stem's 'l0', every other layer's '<instance>.y' (heads: l<k>@<level>)
+            if name == 'l0' or name.endswith('.y'):
+                masks[name[:-2] if name.endswith('.y') else name] = (a.t[:, :a.C] > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
         q = {k: v.clone() for k, v in p.items()}
         mom = {k: torch.zeros_like(v) for k, v in p.items()}
         total, data, grads = NR.train_step(q, mom, imgs, gt, 0.001, relu_masks=masks)
@@ -114,7 +114,7 @@ def test_fcos_training_step_host_logic():
             want = grads[k] - 1e-4 * p[k]
             assert _rel(m.get_param(k, m.G), want) < 5e-3 or float(want.norm()) < 1e-7, k
         after = m.export_params()
-        for k in ('l0.w', 'l0.b', 'l30.gamma', 'l65.w', 'l79.b', 'l80.w', 'l85.w', 'l129.w'):
+        for k in ('l0.w', 'l0.b', 'l30.gamma', 'l65.w', 'l75.w', 'l79.b', 'l80.w', 'l81.gamma', 'l85.w', 'l85.b'):
             assert _rel(after[k], q[k]) < 1e-4, k
 
 
@@ -184,8 +184,7 @@ def test_inference_tails_host_logic():
         check(m.test_one_image(imgs.numpy()), YN.test_one_image(p, imgs, 0.5, 10, 0.5))
         # FCOS
         p = FN.init_params(19)
-        for i in (79, 90, 101, 112, 123):
-            p[f'l{i}.b'] = p[f'l{i}.b'] + 4.0; p[f'l{i + 1}.b'] = p[f'l{i + 1}.b'] + 4.0; p[f'l{i + 6}.w'] = p[f'l{i + 6}.w'] * 0.05
+        p['l79.b'] = p['l79.b'] + 4.0; p['l80.b'] = p['l80.b'] + 4.0; p['l85.w'] = p['l85.w'] * 0.05      # the heads are shared by the levels
         imgs = (torch.rand(1, 128, 160, 3, generator=g) * 255).round()
         cfg = {'mode': 'test', 'data_shape': [128, 160, 3], 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
                'batch_size': 1, 'nms_score_threshold': 0.3, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False, 'device': 'cpu'}

@@ -364,7 +364,7 @@ def test_fcos_two_training_steps_match_reference_class():
     from oracle import fcos_net_ref as NR
     from oracle import fcos_ref as FR
     g = np.load(os.path.join(GOLD, 'fcos_train.npz'))
-    assert len(NR.layer_specs()) == 130 == len(g['names'])
+    assert len(NR.layer_specs()) == 86 == len(g["names"])              # 75 + ONE set of 11 head layers shared by the five levels
     p = NR.init_params(41)
     mom = {k: torch.zeros_like(v) for k, v in p.items()}
     losses, after_first = [], None

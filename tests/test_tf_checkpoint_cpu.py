@@ -216,8 +216,8 @@ def test_snappy_compressed_tables_and_cli(tmp_path, capsys):
 
 
 def test_fcos_variable_map_and_saver_roundtrip_through_mocked_launches(tmp_path):
-    """odtk.fcos.reference_variable_map against the 521 variables of the reference's own FCOS class (tests/golden/fcos_variables.json;
-    group norms are numbered per scope), and a tf.train.Saver round trip of the class on the CPU (tests/mock_ops.py)"""
+    """odtk.fcos.reference_variable_map against the 345 variables of the reference's own FCOS class (tests/golden/fcos_variables.json;
+    default layer names numbered per scope, the 11 head layers shared by the five levels), and a tf.train.Saver round trip of the class on the CPU (tests/mock_ops.py)"""
     import json
     import sys
     import torch
@@ -227,7 +227,7 @@ def test_fcos_variable_map_and_saver_roundtrip_through_mocked_launches(tmp_path)
     from odtk.fcos import layer_specs, reference_variable_map
     want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fcos_variables.json')))
     m = reference_variable_map()
-    assert set(m) | {'global_step'} == set(want) and len(m) == 520
+    assert set(m) | {'global_step'} == set(want) and len(m) == 344          # 86 layers x (kernel, bias, gamma, beta): the heads are shared
     specs = {s[0]: s for s in layer_specs(20)}
     for name, ours in m.items():
         layer, kind = ours.split('.')
@@ -245,12 +245,12 @@ def test_fcos_variable_map_and_saver_roundtrip_through_mocked_launches(tmp_path)
         a.save_weight('latest', path)
         r = T.NewCheckpointReader(path + '-7')
         shapes = r.get_variable_to_shape_map()
-        assert all(shapes[n] == v['shape'] for n, v in want.items()) and len(shapes) == 2 * 520 + 1
+        assert all(shapes[n] == v['shape'] for n, v in want.items()) and len(shapes) == 2 * 344 + 1
         b = odtk.FCOS(dict(cfg, seed=2), prov)
         b.load_weight(path + '-7')
         pa, pb = a.export_params(), b.export_params()
         assert all(torch.equal(pa[k], pb[k]) for k in pa) and b.global_step == 7
-        for k in ('l0.w', 'l64.gamma', 'l129.b'):
+        for k in ('l0.w', 'l64.gamma', 'l85.b'):
             assert torch.equal(a.get_param(k, a.Mom), b.get_param(k, b.Mom)), k
         c = odtk.FCOS(dict(cfg, seed=3), prov)
         before = c.export_params()

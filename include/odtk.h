@@ -123,6 +123,15 @@ int odtk_filter_prepare_batched(const void* items_dev, int n_items, int total_bl
 int odtk_preprocess(const float* images, long long pixels, const float* mean3, int ldx, int dtype,
                     void* x, void* stream);
 
+/* CenterNet's input transform (CenterNet.py:51-65): x = (images / div - mean) / std per RGB channel, in that float32 order;
+ * same layout contract as odtk_preprocess (pixels x 3 floats in, pixels x ldx elements out, pad channels zero). */
+int odtk_preprocess_norm(const float* images, long long pixels, float div, const float* mean3, const float* std3, int ldx, int dtype,
+                         void* x, void* stream);
+/* tf.layers.average_pooling2d(2, 2, 'same') on even maps (CenterNet.py:423-431): y [N,H/2,W/2,ld] = mean of the 2x2 window;
+ * backward: every input of a window receives dy / 4 (dx fully written).  All ld columns are processed. */
+int odtk_avgpool2x2_fwd(const void* x, void* y, int N, int H, int W, int ld, int dtype, void* stream);
+int odtk_avgpool2x2_bwd(const void* dy, void* dx, int N, int H, int W, int ld, int dtype, void* stream);
+
 /* tf.layers.max_pooling2d SAME (SSD300.py:539-547): kxk window, stride, pad_before. */
 int odtk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int ld, int Ho, int Wo,
                      int k, int stride, int pad_t, int pad_l, int dtype, void* stream);
@@ -244,6 +253,11 @@ int odtk_sgd_blocks(long long n);
 int odtk_sgd_momentum(float* p, float* m, const float* grad, long long n, float lr, float momentum,
                       float wd, float grad_scale, float* l2_partial, void* p_cast, int cast_dtype,
                       void* stream);
+/* tf.train.AdamOptimizer (CenterNet.py:154; ApplyAdam) fused with the L2 term of the loss over one flat f32 parameter buffer:
+ * g = grad*grad_scale + wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps), where the caller passes
+ * lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) for step t = 1, 2, ...  l2_partial / p_cast as in odtk_sgd_momentum (same block layout). */
+int odtk_adam(float* p, float* m, float* v, const float* grad, long long n, float lr_t, float beta1, float beta2, float eps,
+              float wd, float grad_scale, float* l2_partial, void* p_cast, int cast_dtype, void* stream);
 /* out[0] = sum_{i<n} in[i] (deterministic tree). */
 int odtk_sum_f32(const float* in, long long n, float* out, void* stream);
 /* cast f32 -> dtype */

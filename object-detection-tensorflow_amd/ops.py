@@ -122,6 +122,20 @@ def preprocess(images, mean3, ldx, dtype, x):
     call("odtk_preprocess", _p(images), images.numel() // 3, m, ldx, dtype, _p(x), _stream())
 
 
+def preprocess_norm(images, div, mean3, std3, ldx, dtype, x):
+    """x = (images / div - mean) / std per channel (CenterNet.py:63)"""
+    m, s = (C.c_float * 3)(*mean3), (C.c_float * 3)(*std3)
+    call("odtk_preprocess_norm", _p(images), images.numel() // 3, float(div), m, s, ldx, dtype, _p(x), _stream())
+
+
+def avgpool2x2_fwd(x, y, N, H, W, ld):
+    call("odtk_avgpool2x2_fwd", _p(x), _p(y), N, H, W, ld, dt_of(x), _stream())
+
+
+def avgpool2x2_bwd(dy, dx, N, H, W, ld):
+    call("odtk_avgpool2x2_bwd", _p(dy), _p(dx), N, H, W, ld, dt_of(dy), _stream())
+
+
 def maxpool_fwd(x, y, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
     call("odtk_maxpool_fwd", _p(x), _p(y), N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l, dt_of(x), _stream())
 
@@ -268,6 +282,12 @@ def sgd_blocks(n):
 
 def sgd_momentum(p, m, g, lr, momentum, wd, grad_scale, l2_partial, p_cast):
     call("odtk_sgd_momentum", _p(p), _p(m), _p(g), p.numel(), float(lr), float(momentum), float(wd),
+         float(grad_scale), _p(l2_partial), _p(p_cast), dt_of(p_cast) if p_cast is not None else BF16, _stream())
+
+
+def adam(p, m, v, g, lr_t, beta1, beta2, eps, wd, grad_scale, l2_partial, p_cast):
+    """fused tf.train.AdamOptimizer step + L2 term (include/odtk.h: odtk_adam); lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)"""
+    call("odtk_adam", _p(p), _p(m), _p(v), _p(g), p.numel(), float(lr_t), float(beta1), float(beta2), float(eps), float(wd),
          float(grad_scale), _p(l2_partial), _p(p_cast), dt_of(p_cast) if p_cast is not None else BF16, _stream())
 
 

@@ -347,8 +347,31 @@ def where(c, a, b):
     return torch.where(c, a, b)
 
 
+TRACE_DEAD_COND_BRANCHES = False
+
+
 def cond(pred, true_fn, false_fn):
-    return true_fn() if bool(pred) else false_fn()
+    """tf.cond: the taken branch's value.  TensorFlow BUILDS both branches (cond_v1 traces true_fn, then false_fn), so variables a
+    branch creates exist -- and are trainable, regularised, saved -- even when the branch never runs (CenterNet._basic_block's
+    1x1 shortcut conv, CenterNet.py:378-389).  With TRACE_DEAD_COND_BRANCHES the untaken branch is therefore executed for its
+    variable creation only: its value and its pending updates (batch-norm moving statistics: ops of a dead branch do not run) are
+    dropped.  Off by default: a dead branch must not consume scripted random draws (image_augmentor)."""
+    take_true = bool(pred)
+    if not TRACE_DEAD_COND_BRANCHES:
+        return true_fn() if take_true else false_fn()
+    out = None
+    for is_true, fn in ((True, true_fn), (False, false_fn)):
+        if is_true == take_true:
+            out = fn()
+        else:
+            n = len(S.pending)
+            try:
+                with torch.no_grad():
+                    fn()                                 # eager arithmetic of a branch that would not run may fail (empty tensors):
+            except Exception:                            # noqa: BLE001 -- only its variable creation matters, graph building has no values
+                pass
+            del S.pending[n:]
+    return out
 
 
 def while_loop(cond_fn, body, loop_vars):
@@ -579,6 +602,36 @@ class _Layers:
         return (inputs - mean) * (torch.rsqrt(var + epsilon) * gamma) + beta
 
     @staticmethod
+    def conv2d_transpose(inputs, filters, kernel_size, strides=1, padding='valid', name=None, data_format='channels_last',
+                         kernel_initializer=None, bias_initializer=None):
+        """tf.layers.conv2d_transpose(padding='same'): kernel [kh, kw, filters, in]; the output (in * stride) is the gradient of a SAME
+        conv2d (filters -> in channels, this kernel, this stride) with respect to its input -- computed literally that way."""
+        assert padding == 'same' and data_format == 'channels_last'
+        filters = int(filters)
+        n, h, w, ci = inputs.shape
+        with variable_scope(name, default_name='conv2d_transpose'):
+            kern = get_variable('kernel', initializer=_glorot_uniform((kernel_size, kernel_size, filters, ci), _Layers.gen))
+            b = get_variable('bias', shape=[filters], initializer=bias_initializer)
+        oh, ow = h * strides, w * strides
+        (pt, pb), (pl, pr) = _same_pad(oh, kernel_size, strides), _same_pad(ow, kernel_size, strides)
+        wt = kern.permute(3, 2, 0, 1)                                       # forward conv weight [out = ci, in = filters, kh, kw]
+        full = torch.nn.grad.conv2d_input((n, filters, oh + pt + pb, ow + pl + pr), wt, inputs.permute(0, 3, 1, 2), stride=strides)
+        y = full[:, :, pt: pt + oh, pl: pl + ow]
+        return y.permute(0, 2, 3, 1) + b
+
+    @staticmethod
+    def average_pooling2d(inputs, pool_size, strides, padding, data_format, name=None):
+        """SAME average pooling: the mean over the cells of the window that lie inside the picture"""
+        assert padding == 'same' and data_format == 'channels_last'
+        pt, pb = _same_pad(inputs.shape[1], pool_size, strides)
+        pl, pr = _same_pad(inputs.shape[2], pool_size, strides)
+        xc = F.pad(inputs.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+        ones = F.pad(torch.ones(1, 1, inputs.shape[1], inputs.shape[2]), (pl, pr, pt, pb))
+        s_ = F.avg_pool2d(xc, pool_size, strides) * (pool_size * pool_size)
+        c_ = F.avg_pool2d(ones, pool_size, strides) * (pool_size * pool_size)
+        return (s_ / c_).permute(0, 2, 3, 1)
+
+    @staticmethod
     def max_pooling2d(inputs, pool_size, strides, padding, data_format, name=None):
         assert padding == 'same' and data_format == 'channels_last'
         pt, pb = _same_pad(inputs.shape[1], pool_size, strides)
@@ -801,6 +854,32 @@ class _MomentumOptimizer:
         return ('train_op',)
 
 
+class _AdamOptimizer:
+    """tf.train.AdamOptimizer(lr): beta1 0.9, beta2 0.999, epsilon 1e-8; ApplyAdam:
+    lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  var -= lr_t m / (sqrt(v) + eps)"""
+
+    def __init__(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+
+    def minimize(self, loss, global_step=None):
+        S.pending.append(('minimize', self, loss, global_step))
+        return ('train_op',)
+
+    def apply(self, names, vars_, grads):
+        st = S.momentum.setdefault('__adam__', {'t': 0, 'm': {}, 'v': {}})
+        st['t'] += 1
+        t = st['t']
+        lr_t = float(self.lr) * (1.0 - self.b2 ** t) ** 0.5 / (1.0 - self.b1 ** t)
+        for n, v, g in zip(names, vars_, grads):
+            if g is None:
+                g = torch.zeros_like(v)
+            m_ = st['m'].setdefault(n, torch.zeros_like(v))
+            v_ = st['v'].setdefault(n, torch.zeros_like(v))
+            m_.mul_(self.b1).add_(g * (1.0 - self.b1))
+            v_.mul_(self.b2).add_(g * g * (1.0 - self.b2))
+            v.sub_(lr_t * m_ / (torch.sqrt(v_) + self.eps))
+
+
 class _Saver:
     def __init__(self, var_list=None):
         self.var_list = var_list
@@ -812,7 +891,7 @@ class _Saver:
         return None
 
 
-train = types.SimpleNamespace(MomentumOptimizer=_MomentumOptimizer, Saver=_Saver)
+train = types.SimpleNamespace(MomentumOptimizer=_MomentumOptimizer, AdamOptimizer=_AdamOptimizer, Saver=_Saver)
 
 summary = types.SimpleNamespace(scalar=lambda *a, **k: None, merge_all=lambda: None)
 gfile = types.SimpleNamespace(Exists=lambda p: True, MakeDirs=lambda p: None)
@@ -831,6 +910,11 @@ def _flush(apply_):
             grads = torch.autograd.grad(loss, vars_, allow_unused=True)
             lr = float(opt.lr)
             with torch.no_grad():
+                if isinstance(opt, _AdamOptimizer):
+                    opt.apply(names, vars_, grads)
+                    if gstep is not None:
+                        gstep.add_(1)
+                    continue
                 for n, v, g in zip(names, vars_, grads):
                     if g is None:
                         g = torch.zeros_like(v)

@@ -446,6 +446,57 @@ def scratch_slot(slot):
     pass
 
 
+# ---- CenterNet: input transform, 2x2 average pooling, Adam, loss / decode
+def preprocess_norm(images, div, mean3, std3, ldx, dtype, x):
+    x.zero_()
+    v = (images.float() / div - torch.tensor(mean3, dtype=torch.float32)) / torch.tensor(std3, dtype=torch.float32)
+    x[:, :3] = v.reshape(-1, 3).to(x.dtype)
+
+
+def avgpool2x2_fwd(x, y, N, H, W, ld):
+    v = x.float().reshape(N, H // 2, 2, W // 2, 2, ld)
+    y.copy_((((v[:, :, 0, :, 0] + v[:, :, 0, :, 1]) + v[:, :, 1, :, 0]) + v[:, :, 1, :, 1]).div(4.).reshape(-1, ld).to(y.dtype))
+
+
+def avgpool2x2_bwd(dy, dx, N, H, W, ld):
+    v = (dy.float() / 4.).to(dx.dtype).reshape(N, H // 2, 1, W // 2, 1, ld).expand(N, H // 2, 2, W // 2, 2, ld)
+    dx.copy_(v.reshape(-1, ld))
+
+
+def adam(p, m, v, g, lr_t, beta1, beta2, eps, wd, grad_scale, l2_partial, p_cast):
+    if l2_partial is not None:
+        l2_partial.zero_()
+        l2_partial[0] = 0.5 * (p.double() ** 2).sum().float()
+    gg = g * grad_scale + wd * p
+    m.mul_(beta1).add_((1 - beta1) * gg)
+    v.mul_(beta2).add_((1 - beta2) * gg * gg)
+    p.sub_(lr_t * m / (torch.sqrt(v) + eps))
+    if p_cast is not None:
+        p_cast.copy_(p.to(p_cast.dtype))
+
+
+def centernet_workspace(N, H, W, Cn, device):
+    return torch.zeros(4, dtype=torch.uint8)
+
+
+def centernet_loss(keypoints, offset, size, gt, stride, grad_scale, loss_parts, d_keypoints, d_offset, d_size, ws):
+    from oracle import centernet_ref as CR
+    k, o, z = (t.detach().clone().requires_grad_(True) for t in (keypoints, offset, size))
+    tot = 0.
+    for i in range(keypoints.shape[0]):
+        li = CR.one_image_loss(k[i], o[i], z[i], gt[i], stride)
+        loss_parts[i, 3] = li.detach()
+        tot = tot + li
+    grads = torch.autograd.grad(tot * grad_scale, [k, o, z])
+    for dst, g in zip((d_keypoints, d_offset, d_size), grads):
+        dst.copy_(g)
+
+
+def centernet_decode(keypoints, offset, size, stride, score_threshold, top_k, ws):
+    from oracle import centernet_ref as CR
+    return CR.decode(keypoints, offset, size, score_threshold, top_k, stride)
+
+
 @contextlib.contextmanager
 def installed():
     """swap the launching functions of odtk.ops for the ones above (and back)"""

@@ -214,3 +214,56 @@ def test_inference_tails_host_logic():
         anc = RR.anchors([128, 128, 3], RR.pyramid_shapes(128, 128))
         conf, boxes, keep, _ = RR.decode_candidates(pb[0, :, :2], pb[0, :, 2:], pc[0], anc, 0.15)
         check(m.test_one_image(imgs.numpy()), DC.per_class_nms(conf, boxes, 20, 0.15, 10, 0.45, row_mask=keep), boxes_tol=5e-2)
+
+
+def test_centernet_training_step_host_logic():
+    """CenterNet: DLA tree (activations feeding several sums and layers -> write / accumulate per gradient buffer), transposed convs as
+    dgrad (forward) / forward conv + swapped wgrad (backward), max / average pooling, ghost shortcut layers, the Adam step -- one training
+    step of the class on the CPU mock against oracle/centernet_net_ref.train_step: loss, every gradient, every parameter after the step,
+    the moving statistics (ghost layers: untouched)"""
+    import odtk
+    from oracle import centernet_net_ref as NR
+    from oracle import centernet_ref as CR
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'input_size': 64, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+           'batch_size': 2, 'score_threshold': 0.1, 'top_k_results_output': 100, 'verbose': False, 'compute_dtype': 'f32', 'device': 'cpu'}
+    g = torch.Generator().manual_seed(170)
+    imgs = (torch.rand(2, 64, 64, 3, generator=g) * 255).round()
+    gt = CR.synthetic_gt(2, 64, 171, pad=8, max_obj=3)
+    p = NR.init_params(17)
+    with mock_ops.installed():
+        m = odtk.CenterNet(cfg, {'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+        assert [s[:6] for s in m.specs] == [s[:6] for s in NR.layer_specs()]
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        loss = float(m.train_step(0.001))
+        masks = {}
+        for name, kind, _, _, _, _, relu, ghost in NR.layer_specs():
+            if relu and not ghost:
+                a = m.acts[name]
+                masks[name] = (a.t[:, :a.C] > 0).view(a.N, a.H, a.W, a.C).permute(0, 3, 1, 2)
+        q = {k: v.clone() for k, v in p.items()}
+        total, data, grads = NR.train_step(q, {}, imgs, gt, 0.001, relu_masks=masks)
+        assert abs(loss - total) < 1e-4 * abs(total), (loss, total)
+        for k in NR.trainable_names(p):
+            if k.endswith('.b'):
+                assert float(m.get_param(k, m.G).abs().max()) == 0.0          # in front of a batch norm: exactly zero here
+                continue
+            want = grads[k] - 1e-4 * p[k]                                     # the kernel adds the L2 term inside the optimizer
+            if float(want.norm()) < 1e-9:
+                assert float(m.get_param(k, m.G).norm()) < 1e-9, k            # ghost layers
+                continue
+            assert _rel(m.get_param(k, m.G), want) < 5e-3, (k, _rel(m.get_param(k, m.G), want))
+        after = m.export_params()
+        for k in q:
+            if k.endswith('.b'):
+                continue
+            if k in grads:
+                # Adam's first step moves every weight by lr * sign(g) (m / sqrt(v) = +-1): where |g| is at round-off level the sign, and
+                # with it the weight, may differ by 2 lr between two summation orders -- compare where the gradient is significant
+                sig = grads[k].abs() > 1e-3 * grads[k].abs().max()
+                assert float((after[k] - q[k])[sig].abs().max()) < 1e-5, k       # 1 % of one Adam step (lr = 1e-3)
+                assert float((after[k] - q[k]).abs().max()) <= 2.01e-3, k          # everywhere else: at most one flipped step
+            else:
+                assert _rel(after[k], q[k]) < 1e-4 or float((after[k] - q[k]).abs().max()) < 1e-6, k
+        assert torch.equal(after['c8.mmean'], torch.zeros(64)) and torch.equal(after['c8.mvar'], torch.ones(64))      # a ghost layer's statistics

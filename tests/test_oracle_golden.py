@@ -387,3 +387,53 @@ def test_fcos_two_training_steps_match_reference_class():
         want = g[key]
         err = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-9)
         assert err < 1e-3, (k, err)
+
+
+def test_centernet_two_training_steps_match_reference_class():
+    """oracle/centernet_net_ref (DLA backbone with ghost shortcut layers, transposed-conv up-sampling tree, centre detector, Adam)
+    against two steps of the reference's own CenterNet class run through its session on the shim (tests/golden/centernet_train.npz)"""
+    from oracle import centernet_net_ref as NR
+    from oracle import centernet_ref as CR
+    g = np.load(os.path.join(GOLD, 'centernet_train.npz'))
+    specs = NR.layer_specs()
+    assert len(specs) == 66 == len(g['names']) and sum(s[7] for s in specs) == 8
+    assert [i for i, n in enumerate(g['names']) if 'transpose' in str(n)] == [i for i, s in enumerate(specs) if s[1] == 'dconv']
+    p = NR.init_params(51)
+    state, losses, after_first = {}, [], None
+    for s in (700, 701):
+        gen = torch.Generator().manual_seed(s)
+        imgs = (torch.rand(2, 128, 128, 3, generator=gen) * 255).round()
+        gt = CR.synthetic_gt(2, 128, s + 10, pad=8, max_obj=4)
+        total, _, _ = NR.train_step(p, state, imgs, gt, 0.001)
+        losses.append(total)
+        if after_first is None:
+            after_first = {k: v.detach().clone() for k, v in p.items()}
+    assert abs(losses[0] - g['losses'][0]) < 1e-5 * g['losses'][0], (losses, g['losses'])
+    assert abs(losses[1] - g['losses'][1]) < 1e-3 * g['losses'][1], (losses, g['losses'])
+    for key in g.files:
+        if key in ('losses', 'names', 'bn_names'):
+            continue
+        k = key.replace('__', '.')
+        got = after_first[k].reshape(-1)
+        got = got[::max(1, got.numel() // 1024)].numpy()
+        want = g[key]
+        assert np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-9) < 1e-4, k
+    # a ghost shortcut layer: trainable (moved by Adam through the L2 term alone), its moving statistics untouched
+    assert float((after_first['c8.w'] - NR.init_params(51)['c8.w']).abs().max()) > 5e-4
+    assert torch.equal(after_first['c8.mmean'], torch.zeros(64)) and torch.equal(after_first['c8.mvar'], torch.ones(64))
+
+
+def test_centernet_variable_map_matches_reference_graph():
+    import json
+    import odtk  # noqa: F401
+    from odtk.centernet import layer_specs, reference_variable_map
+    want = json.load(open(os.path.join(GOLD, 'centernet_variables.json')))
+    m = reference_variable_map()
+    assert set(m) | {'global_step'} == set(want) and len(m) == 66 * 6
+    specs = {s[0]: s for s in layer_specs(20)}
+    for name, ours in m.items():
+        layer, kind = ours.split('.')
+        _, lk, cin, cout, k, _, _, _ = specs[layer]
+        shape = ([k, k, cin, cout] if lk == 'conv' else [k, k, cout, cin]) if kind == 'w' else [cout]
+        assert want[name]['shape'] == shape, name
+        assert want[name]['trainable'] == (kind not in ('mmean', 'mvar')), name

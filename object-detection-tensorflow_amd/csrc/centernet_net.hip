@@ -69,7 +69,8 @@ constexpr int ADAM_THREADS = 256;
 constexpr int ADAM_PER_BLOCK = ADAM_THREADS * 4 * 8;     // the block size of odtk_sgd_blocks: the two optimizers share the l2_partial layout
 
 // tf.train.AdamOptimizer (training/adam.py, kernels/training_ops.cc ApplyAdam), g = grad * gscale + wd * p (the L2 term is part of the loss):
-//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr_t * m / (sqrt(v) + eps),  lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) (host)
+//   m += (g - m) (1 - b1);  v += (g g - v) (1 - b2);  p -= (m lr_t) / (sqrt(v) + eps)   -- ApplyAdam's own float32 expression order;
+//   lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) comes from the host
 template <typename TC>
 __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                             const float* __restrict__ g, long long n, float lr_t, float b1, float b2, float eps,
@@ -83,9 +84,10 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(float* __restrict__ 
             float pv = p[j];
             ss += pv * pv;
             const float gv = g[j] * gscale + wd * pv;
-            const float mv = b1 * m[j] + (1.f - b1) * gv;
-            const float vv = b2 * v[j] + (1.f - b2) * gv * gv;
-            pv -= lr_t * mv / (sqrtf(vv) + eps);
+            float mv = m[j], vv = v[j];
+            mv += (gv - mv) * (1.f - b1);
+            vv += (gv * gv - vv) * (1.f - b2);
+            pv -= (mv * lr_t) / (sqrtf(vv) + eps);
             p[j] = pv; m[j] = mv; v[j] = vv;
             if (pc) pc[j] = elem<TC>::store(pv);
         }

@@ -468,9 +468,9 @@ def adam(p, m, v, g, lr_t, beta1, beta2, eps, wd, grad_scale, l2_partial, p_cast
         l2_partial.zero_()
         l2_partial[0] = 0.5 * (p.double() ** 2).sum().float()
     gg = g * grad_scale + wd * p
-    m.mul_(beta1).add_((1 - beta1) * gg)
-    v.mul_(beta2).add_((1 - beta2) * gg * gg)
-    p.sub_(lr_t * m / (torch.sqrt(v) + eps))
+    m.add_((gg - m) * (1 - beta1))
+    v.add_((gg * gg - v) * (1 - beta2))
+    p.sub_((m * lr_t) / (torch.sqrt(v) + eps))
     if p_cast is not None:
         p_cast.copy_(p.to(p_cast.dtype))
 

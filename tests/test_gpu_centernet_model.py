@@ -89,10 +89,12 @@ def test_adam_kernel_three_steps(dev):
         l2_want = 0.5 * float((p.double() ** 2).sum())
         ops.adam(pd, md, vd, grad.to(dev), lr_t, 0.9, 0.999, 1e-8, wd, 1.0, part, pc)
         ops.sum_f32(part, tot)
-        gg = grad + wd * p
-        m = 0.9 * m + 0.1 * gg
-        v = 0.999 * v + 0.001 * gg * gg
-        p = p - lr_t * m / (torch.sqrt(v) + 1e-8)
+        f = torch.float32
+        b1, b2 = torch.tensor(0.9, dtype=f), torch.tensor(0.999, dtype=f)
+        gg = grad + torch.tensor(wd, dtype=f) * p                         # ApplyAdam in float32, its own expression order
+        m = m + (gg - m) * (1 - b1)
+        v = v + (gg * gg - v) * (1 - b2)
+        p = p - (m * torch.tensor(lr_t, dtype=f)) / (torch.sqrt(v) + torch.tensor(1e-8, dtype=f))
         torch.cuda.synchronize()
         assert float((pd.cpu() - p).abs().max()) < 1e-6 and _rel(md.cpu(), m) < 1e-6 and _rel(vd.cpu(), v) < 1e-6
         assert abs(float(tot) - l2_want) < 1e-5 * l2_want

@@ -26,6 +26,7 @@ for _ in range(steps):
     loss = m.train_step(1e-4)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-flops = 3 * sum(2 * batch * m.desc[n].Ho * m.desc[n].Wo * co * ci * k * k for n, ci, co, k, _, _, _ in m.specs)
+spec = {s[0]: s for s in m.specs}
+flops = 3 * sum(2 * batch * d.Ho * d.Wo * spec[n.split('@')[0]][2] * spec[n.split('@')[0]][1] * spec[n.split('@')[0]][3] ** 2 for n, d in m.desc.items())     # head layers: one launch per level
 print(f'FCOS {size}x{size} batch {batch} {dtype}: {dt * 1e3:8.2f} ms/step  {batch / dt:8.1f} images/s   conv {flops / dt / 1e12:6.1f} TFLOP/s   '
       f'loss {float(loss):.3f}')

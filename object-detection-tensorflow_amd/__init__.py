@@ -9,7 +9,7 @@ reached through the C-ABI in ``include/odtk.h`` (``libodtk.so``).
 from . import _lib                      # noqa: F401
 from ._lib import BF16, F32, OdtkError  # noqa: F401
 
-__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet"]
+__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "SSD512"]
 
 
 def __getattr__(name):
@@ -25,6 +25,9 @@ def __getattr__(name):
     if name == "FCOS":
         from .fcos import FCOS
         return FCOS
+    if name == "SSD512":
+        from .ssd512 import SSD512
+        return SSD512
     if name == "CenterNet":
         from .centernet import CenterNet
         return CenterNet

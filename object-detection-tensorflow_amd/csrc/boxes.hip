@@ -54,7 +54,7 @@ __global__ void priors_kernel(const PriorArgs p, float* __restrict__ y1x1, float
 // ------------------------------------------------------------------ matching
 constexpr int MATCH_THREADS = 1024;
 constexpr int MAX_GT = 128;
-constexpr int MAX_ANCH = 16384;
+constexpr int MAX_ANCH = 32768;                // SSD512 has 24 912 priors (SSD512.py:116-133)
 
 struct GtBox { float y1, x1, y2, x2, area; };
 
@@ -229,14 +229,18 @@ struct NmsScratch {
     NBox* sbox;                     // [B][TCAP]  their normalised boxes
     unsigned long long* mat;        // [B][TCAP][WORDS]  bit j of word w of row i: iou(i, 64w+j) > thr
     int* info;                      // [B][4] = {lim, nvalid, mo, fallback flag}
+    char* big;                      // [B][32768 * 16] or null: global-memory work area of the single-workgroup kernel for n > 16384
 };
 
 // MODE 0: whole problem in one workgroup (sort + greedy selection by wave 0); with `flags`
 //         only problems whose info[b][3] != 0 are processed (fallback of the split path).
 // MODE 1: sort only; emits the best `lim` candidates for the bit-matrix path.
-template <int MODE>
+// BIG: n > 16384 (SSD512's 24 912 priors): the 8-byte keys of the full sort no longer fit the 160 KiB of LDS; the work area moves to
+//         global memory (ws.big, 16 SZ bytes per problem).  Slow (a bitonic sort through L2) but only the rare fallback runs it.
+template <int MODE, bool BIG = false>
 __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a, const NmsScratch ws, const int use_flags) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char lds_area[];
+    char* smem = BIG ? ws.big + (size_t)blockIdx.x * ((size_t)a.SZ * 16) : lds_area;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     __shared__ int s_nvalid;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a, const
     }
     const int nvalid = s_nvalid;
     // compact to 32-bit indices in the first half; second half becomes the selected-box cache
-    unsigned idxreg[16];
+    unsigned idxreg[BIG ? 32 : 16];
     {
         int c = 0;
         for (int i = tid; i < SZ; i += NMS_THREADS, ++c) idxreg[c] = 0xffffffffu - (unsigned)(keys[i] & 0xffffffffull);
@@ -313,7 +317,7 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a, const
     if (wave != 0) return;
 
     NBox* selbox = reinterpret_cast<NBox*>(smem + (size_t)SZ * 4);
-    const int selcap = SZ / 4;                       // boxes that fit in the freed half
+    const int selcap = BIG ? (SZ * 3) / 4 : SZ / 4;  // boxes that fit behind the indices (LDS: the freed half; global: 12 SZ bytes)
     int* oidx = a.out_idx + (long long)b * a.cap;
     int count = 0;
     for (int base = 0; base < nvalid && count < mo; base += 64) {
@@ -733,9 +737,9 @@ static bool g_nms_legacy = false;      // odtk_debug_set key 3
 // then a 20- or 80-class test model in the same process asks for more problems).  On growth a NEW buffer of at least twice
 // the size is allocated and the old one is retired (kept alive, just not handed out again).  Calls are stream-ordered by
 // the caller, as everything else in this library.  hipMalloc inside a stream capture fails: run one eager step first.
-struct NmsScratchOwner { void* base = nullptr; int B = 0; };
+struct NmsScratchOwner { void* base = nullptr; int B = 0; void* big = nullptr; int bigB = 0; };
 static NmsScratchOwner g_nms_scratch[16];
-static int nms_scratch(int B, NmsScratch* ws) {
+static int nms_scratch(int B, NmsScratch* ws, bool need_big) {
     int dev = 0;
     ODTK_CHECK_HIP(hipGetDevice(&dev));
     ODTK_REQUIRE(dev >= 0 && dev < 16, "nms: device index %d unsupported", dev);
@@ -753,6 +757,17 @@ static int nms_scratch(int B, NmsScratch* ws) {
     ws->sbox = (NBox*)p;              p += (size_t)o.B * NMS_TCAP * 16;
     ws->sidx = (unsigned*)p;          p += (size_t)o.B * NMS_TCAP * 4;
     ws->info = (int*)p;
+    ws->big = nullptr;
+    if (need_big) {
+        if (o.bigB < B) {
+            int want = o.bigB ? 2 * o.bigB : 32;
+            if (want < B) want = B;
+            void* q = nullptr;
+            ODTK_CHECK_HIP(hipMalloc(&q, (size_t)want * 32768 * 16));      // never freed / moved, like the buffer above
+            o.big = q; o.bigB = want;
+        }
+        ws->big = (char*)o.big;
+    }
     return ODTK_OK;
 }
 }  // namespace
@@ -814,7 +829,7 @@ extern "C" int odtk_nms_batched(const float* boxes, long long box_stride, const 
                                 const int* max_out_dev, int max_out_stride, int max_out_const,
                                 float iou_threshold, int* out_idx, int cap, int* out_cnt, void* stream) {
     ODTK_REQUIRE(boxes && scores && out_idx && out_cnt, "nms: null pointer");
-    ODTK_REQUIRE(n > 0 && n <= 16384, "nms: n=%d out of range (1..16384)", n);
+    ODTK_REQUIRE(n > 0 && n <= 32768, "nms: n=%d out of range (1..32768)", n);
     ODTK_REQUIRE(B > 0 && cap > 0, "nms: B and cap must be positive");
     ODTK_REQUIRE(((uintptr_t)boxes % 16) == 0 && (box_stride % 4) == 0, "nms: boxes must be 16-byte aligned");
     NmsArgs a;
@@ -828,7 +843,8 @@ extern "C" int odtk_nms_batched(const float* boxes, long long box_stride, const 
     a.max_out_dev = max_out_dev; a.max_out_stride = max_out_stride; a.max_out_const = max_out_const;
     a.thr = iou_threshold;
     a.out_idx = out_idx; a.cap = cap; a.out_cnt = out_cnt;
-    const size_t lds = (size_t)SZ * 8;
+    const bool big = SZ > 16384;
+    const size_t lds = big ? 0 : (size_t)SZ * 8;
     static bool attr_set = false;
     if (!attr_set) {
         ODTK_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
@@ -836,18 +852,20 @@ extern "C" int odtk_nms_batched(const float* boxes, long long box_stride, const 
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    NmsScratch ws = {nullptr, nullptr, nullptr, nullptr};
+    NmsScratch ws = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (int e = nms_scratch(B, &ws, big)) return e;
     if (g_nms_legacy) {
-        hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 0);
+        if (big) hipLaunchKernelGGL((nms_kernel<0, true>), dim3(B), dim3(NMS_THREADS), 0, st, a, ws, 0);
+        else hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 0);
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }
     // split path: sort -> suppression bit matrix -> scan (+ whole-problem fallback for flagged problems)
-    if (int e = nms_scratch(B, &ws)) return e;
     hipLaunchKernelGGL(nms_topk_kernel, dim3(B), dim3(NMS_THREADS), 4096 * 4 + NMS_TCAP * 8 + 64, st, a, ws);
     hipLaunchKernelGGL(nms_matrix_kernel, dim3(NMS_WORDS, B), dim3(256), 0, st, ws, iou_threshold);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, ws, out_idx, cap, out_cnt);
-    hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 1);
+    if (big) hipLaunchKernelGGL((nms_kernel<0, true>), dim3(B), dim3(NMS_THREADS), 0, st, a, ws, 1);
+    else hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, st, a, ws, 1);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -56,7 +56,7 @@ EXTRA_SEQ = [
 FEAT_SRC = ["feat1", "conv7", "conv8_2", "conv9_2", "conv10_2", "conv11_2"]   # reference SSD300.py:314
 
 
-def reference_variable_map():
+def reference_variable_map(extra_seq=None, n_heads=6):
     """name of every variable of the reference's graph -> our parameter / statistic name.
     SSD300.py:193-300 (`kernel_convX_Y` / `bias_convX_Y` under 'feature_extractor', with the two misspelt names
     `kenrel_conv2_1` :212 and `bias_conv_3_1` :232), :77 l2_norm_factor, :304-313 + :85-90 tf.layers.conv2d
@@ -70,7 +70,8 @@ def reference_variable_map():
             m['feature_extractor/' + ('kenrel_' if n == 'conv2_1' else 'kernel_') + n] = n + '.w'
             m['feature_extractor/' + ('bias_conv_3_1' if n == 'conv3_1' else 'bias_' + n)] = n + '.b'
     m['feature_extractor/l2_norm_factor'] = 'l2norm.gamma'
-    for scope, names in (('feature_extractor', [e[0] for e in EXTRA_SEQ]), ('regressor', [f'pred{i}' for i in range(1, 7)])):
+    extra_seq = EXTRA_SEQ if extra_seq is None else extra_seq
+    for scope, names in (('feature_extractor', [e[0] for e in extra_seq]), ('regressor', [f'pred{i}' for i in range(1, n_heads + 1)])):
         for bn, n in enumerate(names):
             bns = f'{scope}/batch_normalization' + (f'_{bn}' if bn else '')
             m[f'{scope}/{n}/kernel'], m[f'{scope}/{n}/bias'] = n + '.w', n + '.b'
@@ -79,19 +80,27 @@ def reference_variable_map():
     return m
 
 
-def prior_spec(input_size=INPUT_SIZE):
+def prior_scales(input_size):
+    """SSD300.py:112-113: the (s_k, sqrt(s_k s_k+1)) pair of every level, python doubles"""
+    s = [(0.2 + (0.9 - 0.2) / 5 * (i - 1)) * input_size for i in range(1, 8)]
+    return [[s[i], (s[i] * s[i + 1]) ** 0.5] for i in range(0, 6)]
+
+
+def prior_spec(input_size=INPUT_SIZE, scales=None, aspects=None, feature_sizes=None, anchors_per_cell=None):
     """Host part of SSD300._get_abbox (reference SSD300.py:112-119, 333-336): the python-double
     (h, w) list per level, flattened; the per-cell arithmetic runs in odtk_ssd_priors."""
-    s = [(0.2 + (0.9 - 0.2) / 5 * (i - 1)) * input_size for i in range(1, 8)]
-    s = [[s[i], (s[i] * s[i + 1]) ** 0.5] for i in range(0, 6)]
+    s = prior_scales(input_size) if scales is None else scales
+    aspects = ASPECTS if aspects is None else aspects
+    feature_sizes = FEATURE_SIZES if feature_sizes is None else feature_sizes
+    anchors_per_cell = ANCHORS_PER_CELL if anchors_per_cell is None else anchors_per_cell
     flat = []
-    for size, ar in zip(s, ASPECTS):
+    for size, ar in zip(s, aspects):
         pr = [[size[0], size[0]], [size[1], size[1]]]
         for a in ar:
             pr.append([size[0] * (a ** 0.5), size[0] / (a ** 0.5)])
         for h, w in pr:
             flat += [h, w]
-    return FEATURE_SIZES, ANCHORS_PER_CELL, flat
+    return feature_sizes, anchors_per_cell, flat
 
 
 class _Act:
@@ -117,14 +126,35 @@ class _Conv:
 
 
 class SSD300:
+    # the variant: SSD512 (ssd512.py) overrides these
+    INPUT_SIZE = INPUT_SIZE
+    FEATURE_SIZES = FEATURE_SIZES
+    ANCHORS_PER_CELL = ANCHORS_PER_CELL
+    ASPECTS = ASPECTS
+    EXTRA_SEQ = EXTRA_SEQ
+    FEAT_SRC = FEAT_SRC
+    FEAT_CH = [512, 1024, 512, 256, 256, 256]
+
+    @classmethod
+    def prior_scales(cls):
+        return prior_scales(cls.INPUT_SIZE)
+
+    @property
+    def NH(self):
+        return len(self.FEAT_SRC)
+
+    @property
+    def NUM_PRIORS(self):
+        return sum(f * f * a for f, a in zip(self.FEATURE_SIZES, self.ANCHORS_PER_CELL))
+
     def __init__(self, config, data_provider):
         assert config['mode'] in ['train', 'test']
         assert config['data_format'] in ['channels_first', 'channels_last']
         self.config = config
         self.data_provider = data_provider
-        self.input_size = INPUT_SIZE
+        self.input_size = self.INPUT_SIZE
         self.data_format = config['data_format']
-        self.data_shape = [300, 300, 3] if self.data_format == 'channels_last' else [3, 300, 300]
+        self.data_shape = [self.INPUT_SIZE, self.INPUT_SIZE, 3] if self.data_format == 'channels_last' else [3, self.INPUT_SIZE, self.INPUT_SIZE]
         self.num_classes = config['num_classes'] + 1          # background = LAST index
         self.weight_decay = config['weight_decay']
         self.prob = 1. - config['keep_prob']                  # unused, as in the reference
@@ -204,10 +234,9 @@ class SSD300:
         for item in VGG_SEQ:
             if item[0].startswith('conv'):
                 self.convs[item[0]] = _Conv(item[0], item[1], item[2], 3, 1, 1, False, True)
-        for (n, ci, co, k, s, d) in EXTRA_SEQ:
+        for (n, ci, co, k, s, d) in self.EXTRA_SEQ:
             self.convs[n] = _Conv(n, ci, co, k, s, d, True, True)
-        feat_ch = [512, 1024, 512, 256, 256, 256]
-        for i, (ch, a) in enumerate(zip(feat_ch, ANCHORS_PER_CELL)):
+        for i, (ch, a) in enumerate(zip(self.FEAT_CH, self.ANCHORS_PER_CELL)):
             self.convs[f'pred{i + 1}'] = _Conv(f'pred{i + 1}', ch, a * self.row, 3, 1, 1, True, False)
 
     def _cin_pad(self, c):
@@ -222,7 +251,7 @@ class SSD300:
                 order.append(item[0])
             if item[0] == 'conv4_3':
                 order.append('l2norm')
-        order += [e[0] for e in EXTRA_SEQ] + [f'pred{i}' for i in range(1, 7)]
+        order += [e[0] for e in self.EXTRA_SEQ] + [f'pred{i}' for i in range(1, self.NH + 1)]
         self.layer_order = order
         self.pinfo = OrderedDict()
         off = 0
@@ -344,11 +373,11 @@ class SSD300:
     # ------------------------------------------------------------------ buffers
     def _build_buffers(self):
         N, dev, dt = self.batch_size, self.dev, self.tdt
-        self.images = torch.zeros(N, 300, 300, 3, device=dev)
+        self.images = torch.zeros(N, self.INPUT_SIZE, self.INPUT_SIZE, 3, device=dev)
         self.acts = OrderedDict()
         c0 = self._cin_pad(3)
-        self.acts['input'] = _Act(N, 300, 300, c0, c0, dt, dev)
-        H = 300
+        self.acts['input'] = _Act(N, self.INPUT_SIZE, self.INPUT_SIZE, c0, c0, dt, dev)
+        H = self.INPUT_SIZE
         cur_c = c0
         self.desc = {}
         prev = 'input'
@@ -375,7 +404,7 @@ class SSD300:
                 self.acts['feat1'] = _Act(N, H, H, 512, 512, dt, dev)
         self.zbuf, self.bnsave = {}, {}
         max_ws = 0
-        for (name, ci, co, k, s, d) in EXTRA_SEQ:
+        for (name, ci, co, k, s, d) in self.EXTRA_SEQ:
             src = self.acts[prev]
             self.desc[name] = ops.conv_desc(N, src.H, src.W, ci, src.ld, co, co, k, s, d, self.DT, self.DT)
             Ho = self.desc[name].Ho
@@ -387,11 +416,11 @@ class SSD300:
             self.extra_src[name] = prev
             prev = name
         # heads write straight into pred [N, 8828, 25] (reference SSD300.py:316-321 reshape/concat)
-        self.pred = torch.zeros(N, NUM_PRIORS, self.row, device=dev)
+        self.pred = torch.zeros(N, self.NUM_PRIORS, self.row, device=dev)
         self.dpred = torch.zeros_like(self.pred)
         self.head_off = []
         off = 0
-        for i, src_name in enumerate(FEAT_SRC):
+        for i, src_name in enumerate(self.FEAT_SRC):
             name = f'pred{i + 1}'
             src = self.acts[src_name]
             c = self.convs[name]
@@ -401,8 +430,8 @@ class SSD300:
             self.bnsave[name] = (torch.zeros(c.cout, device=dev), torch.zeros(c.cout, device=dev))
             max_ws = max(max_ws, ops.bn_workspace_bytes(src.M, c.cout))
             self.head_off.append(off)
-            off += src.H * src.W * ANCHORS_PER_CELL[i]
-        assert off == NUM_PRIORS
+            off += src.H * src.W * self.ANCHORS_PER_CELL[i]
+        assert off == self.NUM_PRIORS
         for a in self.acts.values():
             max_ws = max(max_ws, ops.bn_workspace_bytes(a.M, a.C))
         self.ws = torch.zeros(max_ws, dtype=torch.uint8, device=dev)
@@ -416,9 +445,9 @@ class SSD300:
             kp = ops.pad_to(c.cout, 8) if name.startswith('pred') else c.cout
             self.wt[name] = torch.zeros(d.C * c.k * c.k * kp, dtype=dt, device=dev)
         # box side
-        fs, nas, hw = prior_spec()
-        self.pri = ops.ssd_priors(INPUT_SIZE, fs, nas, hw, dev)       # y1x1, y2x2, yx, hw, nmsbox
-        A = NUM_PRIORS
+        fs, nas, hw = prior_spec(self.INPUT_SIZE, self.prior_scales(), self.ASPECTS, self.FEATURE_SIZES, self.ANCHORS_PER_CELL)
+        self.pri = ops.ssd_priors(self.INPUT_SIZE, fs, nas, hw, dev)       # y1x1, y2x2, yx, hw, nmsbox
+        A = self.NUM_PRIORS
         self.gt = None
         i32 = dict(dtype=torch.int32, device=dev)
         self.m_ngt = torch.zeros(N, **i32)
@@ -500,7 +529,7 @@ class SSD300:
             tail.wait_stream(main)                       # fork: feat1 is final
             with self._on_tail():
                 self._head_fwd(0, training)
-        for (name, ci, co, k, s, d) in EXTRA_SEQ:
+        for (name, ci, co, k, s, d) in self.EXTRA_SEQ:
             src = a[self.extra_src[name]]
             z, y = self.zbuf[name], a[name]
             self._conv_fwd(name, src, z, self.param(name + '.b'), False)
@@ -508,22 +537,22 @@ class SSD300:
             self._bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
                        self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, True,
                        y.t, y.ld, z.M, 0, self.ws)
-            if tail is not None and name in FEAT_SRC:
+            if tail is not None and name in self.FEAT_SRC:
                 tail.wait_stream(main)                   # this feature map is final: its head may start
                 with self._on_tail():
-                    self._head_fwd(FEAT_SRC.index(name), training)
+                    self._head_fwd(self.FEAT_SRC.index(name), training)
         if tail is not None:
             main.wait_stream(tail)                       # join: pred is complete
         else:
-            for i in range(6):
+            for i in range(self.NH):
                 self._head_fwd(i, training)
 
     def _head_fwd(self, i, training):
         """pred<i+1>: 3x3 conv + bias + batch norm, written straight into pred [N, 8828, 25] (SSD300.py:85-90, :316-321)"""
         a = self.acts
-        A25 = NUM_PRIORS * self.row
+        A25 = self.NUM_PRIORS * self.row
         name = f'pred{i + 1}'
-        src, z = a[FEAT_SRC[i]], self.zbuf[name]
+        src, z = a[self.FEAT_SRC[i]], self.zbuf[name]
         self._conv_fwd(name, src, z, self.param(name + '.b'), False)
         sm, si = self.bnsave[name]
         co = self.convs[name].cout
@@ -553,7 +582,7 @@ class SSD300:
         ops.ssd_match(pri[0], pri[1], pri[3], self.gt, self.m_ngt, self.m_best, self.m_status, self.m_rg, self.m_counts)
 
     def _loss(self, grad_scale, matched=False):
-        N, A = self.batch_size, NUM_PRIORS
+        N, A = self.batch_size, self.NUM_PRIORS
         pri = self.pri
         if not matched:
             self._match()
@@ -598,7 +627,7 @@ class SSD300:
         evs = {}
         if tail is None:
             # heads (pred6 .. pred1): dpred -> BN bwd -> wgrad / dgrad into the feature map
-            for i in reversed(range(6)):
+            for i in reversed(range(self.NH)):
                 self._head_bwd(i)
                 yield f'pred{i + 1}'
         else:
@@ -607,22 +636,22 @@ class SSD300:
             main = torch.cuda.current_stream()
             tail.wait_stream(main)                       # fork: d(pred) is final
             with self._on_tail():
-                for i in reversed(range(6)):
+                for i in reversed(range(self.NH)):
                     self._head_bwd(i)
-                    evs[FEAT_SRC[i]] = torch.cuda.Event()
-                    evs[FEAT_SRC[i]].record()
+                    evs[self.FEAT_SRC[i]] = torch.cuda.Event()
+                    evs[self.FEAT_SRC[i]].record()
         # extra layers conv11_2 .. conv6
-        for (name, ci, co, k, s, d) in reversed(EXTRA_SEQ):
+        for (name, ci, co, k, s, d) in reversed(self.EXTRA_SEQ):
             src = a[self.extra_src[name]]
             z, y = self.zbuf[name], a[name]
             sm, si = self.bnsave[name]
-            if name == 'conv11_2' and name in evs:
+            if name == self.EXTRA_SEQ[-1][0] and name in evs:
                 main.wait_event(evs[name])               # the last feature map: only its head wrote y.g
             self._bn_bwd(z.t, y.t, y.g, z.M, co, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, True,
                        z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
             self._conv_bwd_params(name, src, z.g, z.ld)
             # the source already holds the head's gradient when it is a feature map
-            acc = self.extra_src[name] in FEAT_SRC
+            acc = self.extra_src[name] in self.FEAT_SRC
             if acc and self.extra_src[name] in evs:
                 main.wait_event(evs[self.extra_src[name]])
             relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
@@ -631,9 +660,9 @@ class SSD300:
                 yield name
         if tail is not None:
             main.wait_stream(tail)                       # join: pred1 -> feat1.g is final before the trunk reads it
-            for i in reversed(range(6)):
+            for i in reversed(range(self.NH)):
                 yield f'pred{i + 1}'
-            for e in reversed(EXTRA_SEQ):
+            for e in reversed(self.EXTRA_SEQ):
                 yield e[0]
         # VGG trunk
         for step in reversed(self.vgg_plan):
@@ -661,9 +690,9 @@ class SSD300:
 
     def _head_bwd(self, i):
         a = self.acts
-        A25 = NUM_PRIORS * self.row
+        A25 = self.NUM_PRIORS * self.row
         name = f'pred{i + 1}'
-        src, z = a[FEAT_SRC[i]], self.zbuf[name]
+        src, z = a[self.FEAT_SRC[i]], self.zbuf[name]
         co = self.convs[name].cout
         sm, si = self.bnsave[name]
         dyv = self.dpred.view(-1)[self.head_off[i] * self.row:]
@@ -681,7 +710,7 @@ class SSD300:
         images = torch.as_tensor(images, dtype=torch.float32)
         if self.data_format == 'channels_first' and images.shape[1] == 3:
             images = images.permute(0, 2, 3, 1)
-        assert tuple(images.shape) == (self.batch_size, 300, 300, 3), images.shape
+        assert tuple(images.shape) == (self.batch_size, self.INPUT_SIZE, self.INPUT_SIZE, 3), images.shape
         self.images.copy_(images, non_blocking=True)
         gt = torch.as_tensor(ground_truth, dtype=torch.float32)
         if self.gt is None or self.gt.shape != gt.shape:
@@ -859,7 +888,7 @@ class SSD300:
         images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
         if self.data_format == 'channels_first' and images.shape[1] == 3:
             images = images.permute(0, 2, 3, 1)
-        assert self.batch_size == 1 and tuple(images.shape) == (1, 300, 300, 3)
+        assert self.batch_size == 1 and tuple(images.shape) == (1, self.INPUT_SIZE, self.INPUT_SIZE, 3)
         self.images.copy_(images)
         # Reference quirk, reproduced by default: test mode re-binds self.images to `placeholder - mean`
         # and feeds THAT tensor (SSD300.py:65-66,487), so fed pixels bypass the mean subtraction.
@@ -871,7 +900,7 @@ class SSD300:
         cap = max(int(self.nms_max_boxes), 1)
         out_idx = torch.zeros(nc, cap, dtype=torch.int32, device=self.dev)
         out_cnt = torch.zeros(nc, dtype=torch.int32, device=self.dev)
-        ops.nms_batched(self.d_boxes, 0, self.d_conf, 1, nc, self.d_cand, 1, nc, 1, NUM_PRIORS, nc, None, 0,
+        ops.nms_batched(self.d_boxes, 0, self.d_conf, 1, nc, self.d_cand, 1, nc, 1, self.NUM_PRIORS, nc, None, 0,
                         int(self.nms_max_boxes), self.nms_iou_threshold, out_idx, cap, out_cnt)
         cnt = out_cnt.cpu().tolist()
         idx = out_idx.cpu()
@@ -885,7 +914,7 @@ class SSD300:
 
     # ------------------------------------------------------------------ checkpoints
     def tf_variable_map(self):
-        return reference_variable_map()
+        return reference_variable_map(self.EXTRA_SEQ, self.NH)
 
     def _logical(self, name, buf):
         """parameter `name` out of a flat buffer (P or Mom) in TensorFlow's layout: kernels HWIO, un-padded"""

@@ -217,26 +217,29 @@ def forward(p, images_nhwc, training, stats_out=None, taps=None, subtract_mean=T
 # priors (SSD300.py:112-127, 323-343)
 # ----------------------------------------------------------------------------
 def feature_sizes():
+    """side of the feature maps FEATS: conv4_3 after three 2x2 / s2 SAME pools, conv7 after the fourth, then the strides of the extra layers"""
     s = INPUT_SIZE
-    sizes = []
     for _ in range(3):            # pool1..3 (2x2 s2 SAME)
         s = -(-s // 2)
-    sizes.append(s)               # conv4_3: 38
-    s = -(-s // 2)
-    sizes.append(s)               # conv7: 19
-    s = -(-s // 2); sizes.append(s)   # conv8_2: 10
-    s = -(-s // 2); sizes.append(s)   # conv9_2: 5
-    sizes.append(s)                   # conv10_2 stride 1: 5  (SSD300.py:311)
-    s = -(-s // 2); sizes.append(s)   # conv11_2: 3
-    return sizes
+    at = {"conv4_3": s}           # 38
+    s = -(-s // 2)                # pool4; pool5 is 3x3 / s1
+    for (n, ci, co, k, st, d) in EXTRA_LAYERS:
+        s = -(-s // st)           # conv10_2 has stride 1 (SSD300.py:311): 5 again
+        at[n] = s
+    return [at[n] for n in FEATS]
+
+
+def prior_scales():
+    """SSD300.py:112-113 (python doubles)"""
+    s = [(0.2 + (0.9 - 0.2) / 5 * (i - 1)) * INPUT_SIZE for i in range(1, 8)]
+    return [[s[i], (s[i] * s[i + 1]) ** 0.5] for i in range(0, 6)]
 
 
 def priors():
     """Returns y1x1, y2x2, yx, hw each [8828, 2] float32, following the exact
     op order of _get_abbox so results are bit-identical to float32 TF math."""
     f32 = np.float32
-    s = [(0.2 + (0.9 - 0.2) / 5 * (i - 1)) * INPUT_SIZE for i in range(1, 8)]   # python doubles
-    s = [[s[i], (s[i] * s[i + 1]) ** 0.5] for i in range(0, 6)]
+    s = prior_scales()
     outs = [[], [], [], []]
     for lvl, (f, size, ar) in enumerate(zip(feature_sizes(), s, ASPECTS)):
         ty = (np.arange(0., f, dtype=f32).reshape(-1, 1, 1, 1) + f32(0.5))

@@ -39,10 +39,10 @@ def vgg_tensors(p):
     return t
 
 
-def push_params(p):
+def push_params(p, n_heads=6):
     """Copy the oracle-named parameters into the shim's variable store (batch-norm default names: numbered per enclosing variable scope)."""
     V = tf_shim.S.variables
-    for scope, names in (('feature_extractor', EXTRA), ('regressor', [f'pred{i}' for i in range(1, 7)])):
+    for scope, names in (('feature_extractor', EXTRA), ('regressor', [f'pred{i}' for i in range(1, n_heads + 1)])):
         for bn, n in enumerate(names):                   # default layer names are numbered per enclosing variable scope
             bns = 'batch_normalization' if bn == 0 else f'batch_normalization_{bn}'
             with torch.no_grad():
@@ -56,7 +56,7 @@ def push_params(p):
         V['feature_extractor/l2_norm_factor'].copy_(p['l2norm.gamma'])
 
 
-def pull_params():
+def pull_params(n_heads=6):
     V = tf_shim.S.variables
     out = {}
     for l in R.VGG_LAYERS:
@@ -70,7 +70,7 @@ def pull_params():
             if bname not in V:                       # reference typo: 'bias_conv_3_1' (SSD300.py:232)
                 bname = 'feature_extractor/bias_conv_3_1'
             out[n + '.b'] = V[bname].detach().numpy().copy()
-    for scope, names in (('feature_extractor', EXTRA), ('regressor', [f'pred{i}' for i in range(1, 7)])):
+    for scope, names in (('feature_extractor', EXTRA), ('regressor', [f'pred{i}' for i in range(1, n_heads + 1)])):
         for bn, n in enumerate(names):                   # default layer names are numbered per enclosing variable scope
             bns = 'batch_normalization' if bn == 0 else f'batch_normalization_{bn}'
             out[n + '.w'] = V[f'{scope}/{n}/kernel'].detach().permute(3, 0, 1, 2).contiguous().numpy()

@@ -267,3 +267,34 @@ def test_centernet_training_step_host_logic():
             else:
                 assert _rel(after[k], q[k]) < 1e-4 or float((after[k] - q[k]).abs().max()) < 1e-6, k
         assert torch.equal(after['c8.mmean'], torch.zeros(64)) and torch.equal(after['c8.mvar'], torch.ones(64))      # a ghost layer's statistics
+
+
+def test_ssd512_training_step_host_logic():
+    """SSD512 = the SSD300 class with the 512 x 512 variant's tables (7 heads, conv12_x, 24 912 priors): one training step at batch 1 on the
+    CPU mock against oracle/ssd512_ref (pinned on the reference's own SSD512.py, tests/golden/ssd512.npz)"""
+    import odtk
+    from oracle import ssd512_ref as R5
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+           'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '', 'verbose': False,
+           'compute_dtype': 'f32', 'seed': 0, 'use_graph': False, 'device': 'cpu'}
+    imgs, gt = R5.synthetic_batch(1, 33)
+    p = R5.init_params(4)
+    with mock_ops.installed(), R5.tables():                       # the mocked box-side launches call the oracle, which reads the swapped tables
+        m = odtk.SSD512(cfg, {'data_shape': [512, 512, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+        assert m.NUM_PRIORS == 24912 and m.pred.shape == (1, 24912, 25) and [m.acts[n].H for n in m.FEAT_SRC] == [64, 32, 16, 8, 8, 4, 2]
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        loss = float(m.train_step(0.01))
+        q = {k: v.clone() for k, v in p.items()}
+        mom = {k: torch.zeros_like(p[k]) for k in R5.trainable_names(p)}
+        total, data = R5.train_step(q, mom, imgs, gt, 0.01)
+        assert abs(loss - total) < 1e-4 * abs(total), (loss, total)
+        after = m.export_params()
+        for k in q:
+            if k.endswith('.b') and (k[:-2] + '.gamma') in q:
+                continue
+            step = q[k] - p[k]
+            if float(step.norm()) < 1e-12:
+                continue
+            assert _rel(after[k] - p[k], step) < 3e-2, k

@@ -437,3 +437,31 @@ def test_centernet_variable_map_matches_reference_graph():
         shape = ([k, k, cin, cout] if lk == 'conv' else [k, k, cout, cin]) if kind == 'w' else [cout]
         assert want[name]['shape'] == shape, name
         assert want[name]['trainable'] == (kind not in ('mmean', 'mvar')), name
+
+
+def test_ssd512_oracle_matches_reference_class():
+    """oracle/ssd512_ref (ssd300_ref with the 512 variant's tables) against the reference's own SSD512.py on the shim: the 24 912 priors of its
+    _get_abbox bit for bit, and one training step of the whole class (tests/golden/ssd512.npz); the variable names of the graph against
+    odtk.ssd512.reference_variable_map"""
+    import json
+    from oracle import ssd512_ref as R5
+    g = np.load(os.path.join(GOLD, 'ssd512.npz'))
+    pri = R5.priors()
+    for got, key in zip(pri, ('y1x1', 'y2x2', 'yx', 'hw')):
+        assert got.shape == (24912, 2) and np.array_equal(got.numpy(), g[key]), key
+    p = R5.init_params(11)
+    imgs, gt = R5.synthetic_batch(1, 300)
+    mom = {k: torch.zeros_like(p[k]) for k in R5.trainable_names(p)}
+    total, _ = R5.train_step(p, mom, imgs, gt, 0.01)
+    assert abs(total - float(g['loss'][0])) < 1e-5 * float(g['loss'][0]), (total, g['loss'])
+    for key in g.files:
+        if key in ('loss', 'y1x1', 'y2x2', 'yx', 'hw'):
+            continue
+        k = key.replace('__', '.')
+        got = p[k].detach().reshape(-1)
+        got = got[::max(1, got.numel() // 1024)].numpy()
+        assert np.linalg.norm(got - g[key]) / (np.linalg.norm(g[key]) + 1e-9) < (5e-2 if k.endswith(('.b', '.beta')) else 2e-3), k      # (biases: 1e-6-sized steps)
+    import odtk  # noqa: F401
+    from odtk.ssd512 import reference_variable_map
+    want = json.load(open(os.path.join(GOLD, 'ssd512_variables.json')))
+    assert set(reference_variable_map()) | {'global_step'} == set(want)

@@ -257,3 +257,55 @@ def test_fcos_variable_map_and_saver_roundtrip_through_mocked_launches(tmp_path)
         c.load_pretrained_weight(path + '-7')
         pc = c.export_params()
         assert all(torch.equal(pc[k], pa[k] if int(k[1:].split('.')[0]) < 65 else before[k]) for k in pa)
+
+
+def test_reader_on_files_of_an_independent_encoder(tmp_path):
+    """tests/tf_format_independent.py writes both checkpoint formats with NO code shared with tf_checkpoint.py (own CRC32C -- checked here
+    against the RFC 3720 vectors --, own protobuf wire encoder, own table builder with other block sizes / restart intervals, other proto
+    field choices: default-valued fields left out).  A whole vgg_16-shaped V1 file (real variable names and shapes of slim's checkpoint,
+    74 MB) and a V2 bundle must come back bit for bit through the product's reader -- and the V1 file must initialise SSD300's trunk."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tf_format_independent as I
+    assert I.crc32c_bitwise(bytes(32)) == 0x8A9136AA and I.crc32c_bitwise(b'\xff' * 32) == 0x62A8AB43          # RFC 3720 B.4
+    assert I.crc32c_bitwise(bytes(range(32))) == 0x46DD794E and I.crc32c_fast(b'123456789') == I.crc32c_bitwise(b'123456789') == 0xE3069283
+    vgg = I.vgg16_slim_tensors(seed=3)
+    fn = str(tmp_path / 'vgg_16.ckpt')
+    I.write_v1_slices(fn, vgg, split_first_dim=('vgg_16/fc8/weights', 'vgg_16/conv4/conv4_2/biases'))
+    r = T.CheckpointReader(fn)
+    assert r.version == 1 and set(r.get_variable_to_shape_map()) == set(vgg)
+    for name, a in vgg.items():
+        got = r.get_tensor(name)
+        assert got.dtype == a.dtype and got.shape == a.shape and np.array_equal(got, a), name
+    assert r.get_variable_to_shape_map()['vgg_16/conv1/conv1_1/weights'] == [3, 3, 3, 64]
+    # V2: a Saver-style bundle incl. a scalar int64 and momentum slots
+    g = np.random.default_rng(8)
+    tensors = {'feature_extractor/kernel_conv1_1': g.standard_normal((3, 3, 3, 64)).astype(np.float32),
+               'feature_extractor/bias_conv1_1': g.standard_normal(64).astype(np.float32),
+               'inference/feature_extractor/kernel_conv1_1/Momentum': g.standard_normal((3, 3, 3, 64)).astype(np.float32),
+               'regressor/batch_normalization_5/moving_variance': g.random(100).astype(np.float32),
+               'regressor/pred6/kernel': g.standard_normal((3, 3, 256, 100)).astype(np.float32),
+               'global_step': np.asarray(12345, np.int64), 'some/int32': np.arange(-5, 7, dtype=np.int32).reshape(3, 4)}
+    prefix = str(tmp_path / 'model.ckpt-12345')
+    I.write_v2_bundle(prefix, tensors)
+    r2 = T.CheckpointReader(prefix)
+    assert r2.version == 2 and set(r2.get_variable_to_shape_map()) == set(tensors)
+    for name, a in tensors.items():
+        got = r2.get_tensor(name)
+        assert got.dtype == a.dtype and got.shape == a.shape and np.array_equal(got, a), name
+    # a flipped data byte must fail the per-tensor checksum
+    raw = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read()); raw[100] ^= 0x40
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='crc|checksum'):
+        [T.CheckpointReader(prefix).get_tensor(n) for n in tensors]
+    # the vgg file through the class: SSD300.py:31, :193-299
+    import mock_ops
+    import odtk
+    with mock_ops.installed():
+        m = odtk.SSD300({'mode': 'test', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+                         'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': fn, 'verbose': False,
+                         'compute_dtype': 'f32', 'device': 'cpu'}, None)
+        for n in ('conv1_1', 'conv3_3', 'conv5_3'):
+            blk = n.split('_')[0]
+            assert np.array_equal(m.get_param(n + '.w').permute(1, 2, 3, 0).numpy(), vgg[f'vgg_16/{blk}/{n}/weights'])
+            assert np.array_equal(m.get_param(n + '.b').numpy(), vgg[f'vgg_16/{blk}/{n}/biases'])

@@ -330,12 +330,31 @@ int odtk_retina_anchors(int input_dim, int nlevels, const int* fh, const int* fw
 
 /* Matching (RetinaNet.py:357-417).  best[N][P]: first arg-max anchor of every GT; status[N][A]: 0 ignore
  * (0.4 <= IoU <= 0.5), 1 positive (IoU > 0.5), 2 negative (IoU < 0.4), 3 best anchor of some GT;
- * rgindex[N][A]: first arg-max GT of the anchor; counts[N][4] = {rows of the positive set, negatives, 0, 0}.
+ * rgindex[N][A]: first arg-max GT of the anchor; counts[N][4] = {rows of the positive set, negatives, min(3 * positives, negatives), 0}.
  * Indices are bit-exact vs the reference's float32 arithmetic.  workspace: odtk_retina_match_workspace_bytes. */
 long long odtk_retina_match_workspace_bytes(int A, int N, int P);
 int odtk_retina_match(const float* y1x1, const float* y2x2, const float* hw, int A, const float* gt, int N,
                       int P, int* ngt, int* best, unsigned char* status, int* rgindex, int* counts,
                       void* workspace, void* stream);
+
+/* RefineDet, two-stage loss (RefineDet.py:422-567) on top of odtk_retina_match (same matching rule), odtk_softmax_ce_const (ARM background
+ * cross entropy of every anchor, 2 classes, label 1) and odtk_nms_batched (hard negatives among status == 2, budget counts[n][2], IoU 0.7).
+ * arm_loc / odm_loc [N][A][4] = (ty, tx, th, tw), arm_conf [N][A][2] (class 0 = object), odm_conf [N][A][C] (background = C-1).
+ * ARM: mean CE of the mined negatives, mean CE + smooth-L1 of the positive rows against the anchors.  ODM: mean CE against background of the mined
+ * negatives whose ARM background LOGIT is < 0.99 (sic), mean CE + smooth-L1 of the positive rows against the ARM-REFINED anchors -- the box term
+ * also differentiates the refined anchors (no stop_gradient in the reference).  loss_parts [N][8] = {arm negatives, arm positives, arm boxes,
+ * odm negatives, odm positives, odm boxes, total, #odm negatives}; the four gradients (of sum_n total_n * grad_scale) are fully written. */
+int odtk_refinedet_loss(const float* arm_loc, const float* arm_conf, const float* odm_loc, const float* odm_conf, int N, int A, int C,
+                        const float* yx, const float* hw, const float* gt, int P, const int* ngt, const int* best,
+                        const unsigned char* status, const int* rgindex, const int* counts, const float* negloss, const int* sel_idx,
+                        int sel_cap, const int* sel_cnt, float grad_scale, float* loss_parts, float* d_arm_loc, float* d_arm_conf,
+                        float* d_odm_loc, float* d_odm_conf, void* stream);
+/* RefineDet inference decode (RefineDet.py:189-206) for one image: keep[a] = softmax(arm)[1] < 0.99 and arg-max(softmax(odm)) != background;
+ * conf [A][C-1] = softmax(odm) without the background column; boxes [A][4] y1x1y2x2 decoded through both stages; cand = keep and conf >= threshold
+ * (the per-class NMS that follows is odtk_nms_batched, as for SSD300). */
+int odtk_refinedet_decode(const float* arm_loc, const float* arm_conf, const float* odm_loc, const float* odm_conf, int A, int C,
+                          const float* yx, const float* hw, float score_threshold, float* conf, float* boxes, unsigned char* keep,
+                          unsigned char* cand, void* stream);
 
 /* Focal (softmax flavour, alpha on positives AND negatives, p clipped to [1e-8, 1], sum / #positives;
  * RetinaNet.py:457-474) + smooth-L1 on the positive rows (:441-446).  pconf [N][A][C] logits (background =

@@ -54,6 +54,9 @@ SIGNATURES = {
     "odtk_filter_prepare_batched": (_i, [_vp, _i, _i, _i, _vp]),
     "odtk_preprocess": (_i, [_vp, _ll, C.POINTER(_f), _i, _i, _vp, _vp]),
     "odtk_preprocess_norm": (_i, [_vp, _ll, _f, C.POINTER(_f), C.POINTER(_f), _i, _i, _vp, _vp]),
+    "odtk_refinedet_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp,
+                                _vp, _vp]),
+    "odtk_refinedet_decode": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "odtk_avgpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "odtk_avgpool2x2_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "odtk_adam": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _vp, _vp, _i, _vp]),

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(RL_THREADS) retina_iou_kernel(
 
 // Pass 2 (one workgroup per image): best anchor per GT = first arg-max over all tiles (tiles in ascending order,
 // strict >), then the best anchors leave the "other" set (:397-407): status 3, counts corrected once per DISTINCT
-// best anchor.  counts[n] = {rows of the positive set = G + #(IoU > 0.5 among the others), #negatives, 0, 0}.
+// best anchor.  counts[n] = {rows of the positive set = G + #(IoU > 0.5 among the others), #negatives, min(3 * positives, negatives), 0}.
 __global__ void __launch_bounds__(RL_THREADS) retina_status_kernel(
     const float* __restrict__ gt, int P, int A, int ntile, const float* __restrict__ part_iou,
     const int* __restrict__ part_idx, const float* __restrict__ maxiou, int* __restrict__ ngt, int* __restrict__ best,
@@ -200,9 +200,11 @@ __global__ void __launch_bounds__(RL_THREADS) retina_status_kernel(
     __syncthreads();
     if (tid == 0) {
         ngt[n] = G;
-        counts[n * 4 + 0] = G + counts[n * 4 + 0] - s_fix[0];
-        counts[n * 4 + 1] = counts[n * 4 + 1] - s_fix[1];
-        counts[n * 4 + 2] = 0; counts[n * 4 + 3] = 0;
+        const int np_ = G + counts[n * 4 + 0] - s_fix[0], nn_ = counts[n * 4 + 1] - s_fix[1];
+        counts[n * 4 + 0] = np_;
+        counts[n * 4 + 1] = nn_;
+        counts[n * 4 + 2] = 3 * np_ < nn_ ? 3 * np_ : nn_;         // hard-negative budget of the detectors that mine (RefineDet.py:521)
+        counts[n * 4 + 3] = 0;
     }
 }
 

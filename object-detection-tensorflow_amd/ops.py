@@ -373,6 +373,28 @@ def retina_loss(pconf, pbox, yx, hw, gt, ngt, best, status, rgindex, counts, alp
          _p(dbox), _stream())
 
 
+def refinedet_loss(arm_loc, arm_conf, odm_loc, odm_conf, yx, hw, gt, ngt, best, status, rgindex, counts, negloss, sel_idx, sel_cnt, grad_scale,
+                   loss_parts, d_arm_loc, d_arm_conf, d_odm_loc, d_odm_conf):
+    """RefineDet.py:422-567 for the batch (include/odtk.h: odtk_refinedet_loss); loss_parts [N, 8]"""
+    N, A, Cn = odm_conf.shape
+    call("odtk_refinedet_loss", _p(arm_loc), _p(arm_conf), _p(odm_loc), _p(odm_conf), N, A, Cn, _p(yx), _p(hw), _p(gt), gt.shape[1], _p(ngt),
+         _p(best), _p(status), _p(rgindex), _p(counts), _p(negloss), _p(sel_idx), sel_idx.shape[1], _p(sel_cnt), float(grad_scale), _p(loss_parts),
+         _p(d_arm_loc), _p(d_arm_conf), _p(d_odm_loc), _p(d_odm_conf), _stream())
+
+
+def refinedet_decode(arm_loc, arm_conf, odm_loc, odm_conf, yx, hw, thr):
+    """RefineDet.py:189-206 for one image -> conf [A, C-1], boxes [A, 4], keep [A], cand [A, C-1]"""
+    A, Cn = odm_conf.shape
+    dev = odm_conf.device
+    conf = torch.empty(A, Cn - 1, device=dev)
+    boxes = torch.empty(A, 4, device=dev)
+    keep = torch.empty(A, dtype=torch.uint8, device=dev)
+    cand = torch.empty(A, Cn - 1, dtype=torch.uint8, device=dev)
+    call("odtk_refinedet_decode", _p(arm_loc), _p(arm_conf), _p(odm_loc), _p(odm_conf), A, Cn, _p(yx), _p(hw), float(thr), _p(conf), _p(boxes),
+         _p(keep), _p(cand), _stream())
+    return conf, boxes, keep, cand
+
+
 def retina_decode(pconf, pbox, yx, hw, thr):
     """RetinaNet.py:224-238 for one image: pconf [A,C], pbox [A,4] -> conf [A,C-1], boxes [A,4], keep [A], cand [A,C-1]."""
     A, Cn = pconf.shape

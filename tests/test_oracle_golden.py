@@ -465,3 +465,23 @@ def test_ssd512_oracle_matches_reference_class():
     from odtk.ssd512 import reference_variable_map
     want = json.load(open(os.path.join(GOLD, 'ssd512_variables.json')))
     assert set(reference_variable_map()) | {'global_step'} == set(want)
+
+
+def test_refinedet_box_side_matches_reference_functions():
+    """oracle/refinedet_ref against the reference's own _get_abbox, _compute_one_image_loss (two-stage ARM -> ODM loss, NMS-mined negatives, the
+    ODM targets relative to the ARM-refined anchors) and inference branch run on the shim (tests/golden/refinedet.npz)"""
+    from oracle import refinedet_ref as FR
+    g = np.load(os.path.join(GOLD, 'refinedet.npz'))
+    anc = FR.anchors(320)
+    assert anc[0].shape == (6375, 2)
+    for got, key in zip(anc, ('y1x1', 'y2x2', 'yx', 'hw')):
+        assert np.array_equal(got.numpy(), g[key]), key
+    arm_loc, arm_conf = torch.from_numpy(g['arm_loc'].astype(np.float32)), torch.from_numpy(g['arm_conf'].astype(np.float32))
+    odm_loc, odm_conf = torch.from_numpy(g['odm_loc'].astype(np.float32)), torch.from_numpy(g['odm_conf'].astype(np.float32))
+    gt = torch.from_numpy(g['gt'])
+    for i in range(3):
+        l = FR.one_image_loss(arm_loc[i, :, :2], arm_loc[i, :, 2:], arm_conf[i], odm_loc[i, :, :2], odm_loc[i, :, 2:], odm_conf[i], anc, gt[i])
+        assert abs(float(l) - g['loss'][i]) < 1e-5 * g['loss'][i], (i, float(l), g['loss'][i])
+    s, b, c = FR.detect(arm_loc[0], arm_conf[0], odm_loc[0], odm_conf[0], anc, 0.12, 10, 0.45)
+    assert c.tolist() == g['det_class'].tolist() and len(s) > 0
+    assert np.allclose(s.numpy(), g['det_scores'], atol=1e-6) and np.allclose(b.numpy(), g['det_bbox'], rtol=1e-5, atol=1e-3)

@@ -132,6 +132,11 @@ int odtk_preprocess_norm(const float* images, long long pixels, float div, const
 int odtk_avgpool2x2_fwd(const void* x, void* y, int N, int H, int W, int ld, int dtype, void* stream);
 int odtk_avgpool2x2_bwd(const void* dy, void* dx, int N, int H, int W, int ld, int dtype, void* stream);
 
+/* y = relu(a + b) on rows with their own pitches (RefineDet's transfer-connection block, RefineDet.py:371), and the gradient of a ReLU taken
+ * from its OUTPUT: dx[m][c] (+= when accumulate) = dy[m][c] where y[m][c] > 0.  dy shares y's pitch. */
+int odtk_add_relu_fwd(const void* a, int lda, const void* b, int ldb, void* y, int ldy, long long M, int C, int dtype, void* stream);
+int odtk_relu_bwd(const void* y, const void* dy, int ldy, void* dx, int lddx, long long M, int C, int dtype, int accumulate, void* stream);
+
 /* tf.layers.max_pooling2d SAME (SSD300.py:539-547): kxk window, stride, pad_before. */
 int odtk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int ld, int Ho, int Wo,
                      int k, int stride, int pad_t, int pad_l, int dtype, void* stream);

@@ -9,7 +9,7 @@ reached through the C-ABI in ``include/odtk.h`` (``libodtk.so``).
 from . import _lib                      # noqa: F401
 from ._lib import BF16, F32, OdtkError  # noqa: F401
 
-__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "SSD512"]
+__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "SSD512", "RefineDet320"]
 
 
 def __getattr__(name):
@@ -28,6 +28,9 @@ def __getattr__(name):
     if name == "SSD512":
         from .ssd512 import SSD512
         return SSD512
+    if name == "RefineDet320":
+        from .refinedet import RefineDet320
+        return RefineDet320
     if name == "CenterNet":
         from .centernet import CenterNet
         return CenterNet

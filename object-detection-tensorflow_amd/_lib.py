@@ -57,6 +57,8 @@ SIGNATURES = {
     "odtk_refinedet_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp,
                                 _vp, _vp]),
     "odtk_refinedet_decode": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "odtk_add_relu_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _i, _vp]),
+    "odtk_relu_bwd": (_i, [_vp, _vp, _i, _vp, _i, _ll, _i, _i, _i, _vp]),
     "odtk_avgpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "odtk_avgpool2x2_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "odtk_adam": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _vp, _vp, _i, _vp]),

@@ -59,6 +59,33 @@ __global__ void avgpool2x2_kernel(const T* __restrict__ src, T* __restrict__ dst
     }
 }
 
+// y = relu(a + b) on [M][ld] rows (RefineDet's transfer-connection block: tf.nn.relu(conv2 + dconv), RefineDet.py:371), and the gradient of a
+// ReLU from its OUTPUT: dx (+)= dy where y > 0
+template <typename T>
+__global__ void add_relu_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb, T* __restrict__ y, int ldy, long long M, int C) {
+    const long long total = M * C;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        const long long m = i / C; const int c = (int)(i - m * C);
+        const float v = elem<T>::load(a[m * lda + c]) + elem<T>::load(b[m * ldb + c]);
+        y[m * ldy + c] = elem<T>::store(fmaxf(v, 0.f));
+    }
+}
+
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, int ldy, T* __restrict__ dx, int lddx, long long M, int C, int accumulate) {
+    const long long total = M * C;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        const long long m = i / C; const int c = (int)(i - m * C);
+        float g = elem<T>::load(y[m * ldy + c]) > 0.f ? elem<T>::load(dy[m * ldy + c]) : 0.f;
+        if (accumulate) g += elem<T>::load(dx[m * lddx + c]);
+        dx[m * lddx + c] = elem<T>::store(g);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -129,6 +156,22 @@ extern "C" int odtk_avgpool2x2_bwd(const void* dy, void* dx, int N, int H, int W
     const long long total = (long long)N * (H / 2) * (W / 2) * ld;
     DT_SWITCH(dtype, T, hipLaunchKernelGGL((avgpool2x2_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)dy, (T*)dx, N, H, W, ld);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_add_relu_fwd(const void* a, int lda, const void* b, int ldb, void* y, int ldy, long long M, int C, int dtype, void* stream) {
+    ODTK_REQUIRE(a && b && y && M > 0 && C > 0 && lda >= C && ldb >= C && ldy >= C, "add_relu_fwd: bad argument");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(add_relu_kernel<T>, dim3(grid_for(M * C, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, (const T*)b, ldb,
+                                           (T*)y, ldy, M, C);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_relu_bwd(const void* y, const void* dy, int ldy, void* dx, int lddx, long long M, int C, int dtype, int accumulate, void* stream) {
+    ODTK_REQUIRE(y && dy && dx && M > 0 && C > 0 && ldy >= C && lddx >= C, "relu_bwd: bad argument");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(grid_for(M * C, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)dy, ldy,
+                                           (T*)dx, lddx, M, C, accumulate);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

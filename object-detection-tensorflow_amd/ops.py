@@ -128,6 +128,14 @@ def preprocess_norm(images, div, mean3, std3, ldx, dtype, x):
     call("odtk_preprocess_norm", _p(images), images.numel() // 3, float(div), m, s, ldx, dtype, _p(x), _stream())
 
 
+def add_relu_fwd(a, lda, b, ldb, y, ldy, M, C_):
+    call("odtk_add_relu_fwd", _p(a), int(lda), _p(b), int(ldb), _p(y), int(ldy), int(M), int(C_), dt_of(y), _stream())
+
+
+def relu_bwd(y, dy, ldy, dx, lddx, M, C_, accumulate=False):
+    call("odtk_relu_bwd", _p(y), _p(dy), int(ldy), _p(dx), int(lddx), int(M), int(C_), dt_of(y), int(accumulate), _stream())
+
+
 def avgpool2x2_fwd(x, y, N, H, W, ld):
     call("odtk_avgpool2x2_fwd", _p(x), _p(y), N, H, W, ld, dt_of(x), _stream())
 

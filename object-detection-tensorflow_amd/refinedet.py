@@ -1,0 +1,572 @@
+"""RefineDet320 / 512 (VGG-16 + anchor refinement module + transfer connection blocks + object detection module) behind the reference's class
+surface, on libodtk.
+
+Reference: /root/reference/RefineDet.py (class RefineDet320; `input_size` 320 or 512, testrefinedet.py:20-33)
+  * constructor, config keys ............. :11-49
+  * input ................................ :51-70   (images - mean; test mode feeds the tensor after the subtraction -- reproduced, 'test_subtract_mean' opts out)
+  * VGG trunk + extras ................... :232-385  (conv1_1 .. conv5_3: conv + bias + ReLU; conv6 .. conv10_2: conv(bias) + batch norm + ReLU)
+  * L2-normalised conv4_3 / conv5_3 ...... :74-95    (one learnable scalar each, 10 and 8)
+  * ARM / TCB / ODM ...................... :387-415  (4 x [3x3(256) + BN + ReLU] + two 3x3 + BN outputs per level; TCB: 3x3 + BN + ReLU, 3x3 + BN,
+                                                       + [4x4 / s2 transposed conv + BN] of the level above, ReLU)
+  * loss, optimizer ...................... :160-187  (heads.RefineDetLoss: matching, NMS-mined ARM negatives, two-stage loss; Momentum 0.9)
+  * inference ............................ :189-230  (heads.refinedet_detect)
+  * train / test / checkpoints ........... :583-617
+Layers by name (oracle/refinedet_net_ref.layer_specs' names), one flat f32 parameter buffer in TensorFlow's creation order.  The graph engine is
+centernet.py's (every activation owns its gradient buffer; a consumer writes it first or accumulates later), extended by the VGG convention of
+ssd300.py: the gradient buffer of a bias + ReLU activation holds d(pre-activation) and every consumer applies the ReLU mask itself (dgrad's
+`relu_src`, the L2-norm backward's; a max pool routes only to unmasked cells).
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import heads, ops
+from ._lib import BF16, F32
+
+MEAN_RGB = (123.68, 116.779, 103.979)
+VGG_SEQ = [("conv1_1", 3, 64), ("conv1_2", 64, 64), "pool1", ("conv2_1", 64, 128), ("conv2_2", 128, 128), "pool2",
+           ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256), "pool3",
+           ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3", 512, 512), "pool4",
+           ("conv5_1", 512, 512), ("conv5_2", 512, 512), ("conv5_3", 512, 512), "pool5"]
+EXTRAS = [("conv6", 512, 1024, 3, 1, 2), ("conv7", 1024, 1024, 1, 1, 1), ("conv8_1", 1024, 256, 1, 1, 1), ("conv8_2", 256, 512, 3, 2, 1),
+          ("conv9_1", 512, 256, 1, 1, 1), ("conv9_2", 256, 512, 3, 2, 1), ("conv10_1", 512, 256, 1, 1, 1), ("conv10_2", 256, 256, 3, 1, 1)]
+FEAT_CH = [512, 512, 512, 256]
+NA = 3
+
+
+def layer_specs(num_classes):
+    """[(name, kind, cin, cout, k, stride, dil, relu)] in creation order; kind 'vgg' (bias + ReLU) | 'conv' | 'dconv' (both + batch norm)"""
+    s = []
+    for l in VGG_SEQ:
+        if isinstance(l, tuple):
+            s.append((l[0], 'vgg', l[1], l[2], 3, 1, 1, True))
+    for (n, ci, co, k, st, d) in EXTRAS:
+        s.append((n, 'conv', ci, co, k, st, d, True))
+
+    def head(prefix, cin, ncls):
+        c = cin
+        for j in range(1, 5):
+            s.append((f'{prefix}.c{j}', 'conv', c, 256, 3, 1, 1, True)); c = 256
+        s.append((f'{prefix}.loc', 'conv', 256, 4 * NA, 3, 1, 1, False))
+        s.append((f'{prefix}.conf', 'conv', 256, ncls * NA, 3, 1, 1, False))
+    for l in range(4):
+        head(f'arm{l + 1}', FEAT_CH[l], 2)
+    for l in (4, 3, 2, 1):
+        s.append((f'tcb{l}.c1', 'conv', FEAT_CH[l - 1], 256, 3, 1, 1, True))
+        s.append((f'tcb{l}.c2', 'conv', 256, 256, 3, 1, 1, l == 4))
+        if l < 4:
+            s.append((f'tcb{l}.d', 'dconv', 256, 256, 4, 2, 1, False))
+    for l in range(4):
+        head(f'odm{l + 1}', 256, num_classes)
+    return s
+
+
+class _Act:
+    def __init__(self, name, N, H, W, C, ld, dtype, dev, vgg=False, alloc=True):
+        self.name, self.N, self.H, self.W, self.C, self.ld, self.vgg = name, N, H, W, C, ld, vgg
+        self.M = N * H * W
+        self.t = torch.zeros(self.M, ld, dtype=dtype, device=dev) if alloc else None
+        self.g = None
+
+
+class RefineDet320:
+    def __init__(self, config, data_provider):
+        assert config['mode'] in ['train', 'test']
+        assert config['data_format'] in ['channels_first', 'channels_last']
+        self.config = config
+        self.data_provider = data_provider
+        self.input_size = config['input_size']
+        self.data_shape = [self.input_size, self.input_size, 3] if config['data_format'] == 'channels_last' else [3, self.input_size, self.input_size]
+        self.num_classes = config['num_classes'] + 1          # background = LAST index
+        self.weight_decay = config['weight_decay']
+        self.prob = 1. - config['keep_prob']
+        self.data_format = config['data_format']
+        self.mode = config['mode']
+        self.batch_size = config['batch_size'] if config['mode'] == 'train' else 1
+        self.anchor_ratios = [0.5, 1.0, 2.0]
+        self.num_anchors = NA
+        self.nms_score_threshold = config['nms_score_threshold']
+        self.nms_max_boxes = config['nms_max_boxes']
+        self.nms_iou_threshold = config['nms_iou_threshold']
+        self.pretraining_weight = config.get('pretraining_weight')
+        assert self.input_size % 64 == 0, "RefineDet: the input size must be a multiple of 64 (320 or 512 in the reference)"
+        if self.mode == 'train':
+            self.num_train = data_provider['num_train']
+            self.num_val = data_provider['num_val']
+            self.train_generator = data_provider['train_generator']
+            if isinstance(self.train_generator, tuple) and len(self.train_generator) == 2:
+                self.train_initializer, self.train_iterator = self.train_generator
+            else:
+                self.train_initializer, self.train_iterator = None, self.train_generator
+            if data_provider.get('val_generator') is not None:
+                self.val_generator = data_provider['val_generator']
+        self.verbose = bool(config.get('verbose', True))
+        self.dev = torch.device(config.get('device', 'cuda:0'))
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'f32')]
+        self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
+        self.chunk = ops.chunk(self.DT)
+        self.global_step = 0
+        self.dist = None
+        self.loss_divisor_batch = self.batch_size
+        if self.dev.type == 'cuda':
+            torch.cuda.set_device(self.dev)
+        self.specs = layer_specs(self.num_classes)
+        self._init_parameters(int(config.get('seed', 0)))
+        self._build()
+        self._load_pretraining_weight()
+
+    # ------------------------------------------------------------------ parameters
+    def _wshape(self, spec):
+        _, kind, cin, cout, k, _, _, _ = spec
+        kout, kin = (cout, cin) if kind != 'dconv' else (cin, cout)
+        return (kout, k, k, ops.pad_to(kin, self.chunk)), kin
+
+    def _init_parameters(self, seed):
+        pinfo, sinfo = OrderedDict(), OrderedDict()
+        off = soff = 0
+        self._kin, self._kind = {}, {}
+
+        def add(name, shape):
+            nonlocal off
+            pinfo[name] = (off, tuple(shape))
+            off += ops.pad_to(int(np.prod(shape)), 64)
+        for i, spec in enumerate(self.specs):
+            name, kind, cout = spec[0], spec[1], spec[3]
+            wshape, kin = self._wshape(spec)
+            self._kin[name], self._kind[name] = kin, kind
+            add(name + '.w', wshape); add(name + '.b', (cout,))
+            if kind != 'vgg':
+                add(name + '.gamma', (cout,)); add(name + '.beta', (cout,))
+                for suffix in ('.mmean', '.mvar'):
+                    sinfo[name + suffix] = (soff, (cout,))
+                    soff += ops.pad_to(cout, 64)
+            if name == 'conv10_2':                              # creation order: the two L2-norm scalars follow the feature extractor (:77, :79)
+                add('feat1_l2_norm', (1,)); add('feat2_l2_norm', (1,))
+        self.pinfo, self.sinfo, self.nparam = pinfo, sinfo, off
+        dev = self.dev
+        self.P = torch.zeros(off, device=dev)
+        self.Mom = torch.zeros(off, device=dev)
+        self.G = torch.zeros(off, device=dev)
+        self.Pc = torch.zeros(off, dtype=self.tdt, device=dev) if self.DT == BF16 else self.P
+        self.S = torch.zeros(soff, device=dev)
+        self.l2_partial = torch.zeros(ops.sgd_blocks(off), device=dev)
+        self.l2_sum = torch.zeros(1, device=dev)
+        g = torch.Generator().manual_seed(seed)
+        for name, kind, cin, cout, k, _, _, _ in self.specs:
+            kout, kin = (cout, cin) if kind != 'dconv' else (cin, cout)
+            self.set_param(name + '.w', torch.randn(kout, k, k, kin, generator=g) * math.sqrt(2.0 / (cin * k * k)))
+            if kind != 'vgg':
+                self.param(name + '.gamma').fill_(1.0)
+                self.stat(name + '.mvar').fill_(1.0)
+        self.param('feat1_l2_norm').fill_(10.0)
+        self.param('feat2_l2_norm').fill_(8.0)
+
+    def param(self, name, buf=None):
+        off, shape = self.pinfo[name]
+        buf = self.P if buf is None else buf
+        return buf[off: off + int(np.prod(shape))].view(shape)
+
+    def stat(self, name):
+        off, shape = self.sinfo[name]
+        return self.S[off: off + int(np.prod(shape))].view(shape)
+
+    def _flat(self, name, buf):
+        off, shape = self.pinfo[name]
+        return buf[off: off + int(np.prod(shape))]
+
+    def set_param(self, name, value):
+        dst = self.param(name)
+        value = torch.as_tensor(value, dtype=torch.float32)
+        if name.endswith('.w'):
+            dst.zero_()
+            dst[..., : value.shape[-1]] = value.to(self.dev)
+        else:
+            dst.copy_(value.to(self.dev).view(dst.shape))
+
+    def get_param(self, name, buf=None):
+        v = self.param(name, buf).detach().cpu().clone()
+        if name.endswith('.w'):
+            v = v[..., : self._kin[name[:-2]]].contiguous()
+        return v
+
+    def load_oracle_params(self, p):
+        for k, v in p.items():
+            if k in self.pinfo:
+                if k.endswith('.b') and self._kind.get(k[:-2]) == 'dconv' and float(torch.as_tensor(v).abs().max()) != 0.0:
+                    raise NotImplementedError('non-zero bias of a transposed convolution (zero-initialised, in front of a batch norm: it never moves)')
+                self.set_param(k, v)
+            elif k in self.sinfo:
+                self.stat(k).copy_(torch.as_tensor(v, dtype=torch.float32).to(self.dev))
+        self._refresh_operand_copies()
+
+    def export_params(self):
+        out = OrderedDict((k, self.get_param(k)) for k in self.pinfo)
+        for k in self.sinfo:
+            out[k] = self.stat(k).detach().cpu().clone()
+        return out
+
+    def _refresh_operand_copies(self):
+        if self.DT == BF16:
+            ops.cast_from_f32(self.P, self.Pc)
+        if getattr(self, '_fp_batch', None) is not None:
+            self._fp_batch.run()
+
+    def _load_pretraining_weight(self):
+        """the 13 VGG convolutions from slim's vgg_16.ckpt (RefineDet.py:33, :232-365), as ssd300.py does"""
+        path = self.pretraining_weight
+        if not path or not (os.path.exists(str(path)) or os.path.exists(str(path) + '.index')):
+            return
+        from .tf_checkpoint import NewCheckpointReader
+        reader = NewCheckpointReader(str(path))
+        for l in VGG_SEQ:
+            if isinstance(l, tuple):
+                n = l[0]
+                key = f'vgg_16/{n.split("_")[0]}/{n}'
+                if reader.has_tensor(key + '/weights'):
+                    self.set_param(n + '.w', torch.from_numpy(reader.get_tensor(key + '/weights')).permute(3, 0, 1, 2).contiguous())
+                    self.set_param(n + '.b', torch.from_numpy(reader.get_tensor(key + '/biases')))
+        self._refresh_operand_copies()
+
+    # ------------------------------------------------------------------ the graph
+    def _build(self):
+        N, dev, dt, ch = self.batch_size, self.dev, self.tdt, self.chunk
+        S_ = self.input_size
+        spec = {s[0]: s for s in self.specs}
+        self.images = torch.zeros(N, S_, S_, 3, device=dev)
+        self.input = _Act('input', N, S_, S_, 3, ops.pad_to(3, ch), dt, dev)
+        self.plan, self.desc, self.z, self.bnsave, self.acts = [], {}, {}, {}, {'input': self.input}
+        self._max_ws = self._max_z = self._max_scr = 0
+        self.anc = heads.refinedet_anchors(S_, dev)                      # y1x1, y2x2, yx, hw, nmsbox
+        A = self.anc[0].shape[0]
+        self.A = A
+        C = self.num_classes
+        self.arm_loc = torch.zeros(N, A, 4, device=dev); self.arm_conf = torch.zeros(N, A, 2, device=dev)
+        self.odm_loc = torch.zeros(N, A, 4, device=dev); self.odm_conf = torch.zeros(N, A, C, device=dev)
+
+        def act(name, H_, W_, C_, vgg=False):
+            a = _Act(name, N, H_, W_, C_, ops.pad_to(C_, ch), dt, dev, vgg)
+            self.acts[name] = a
+            return a
+
+        def vgg(name, src):
+            _, _, cin, cout, k, _, _, _ = spec[name]
+            self.desc[name] = ops.conv_desc(N, src.H, src.W, ops.pad_to(cin, ch), src.ld, cout, ops.pad_to(cout, ch), 3, 1, 1, self.DT, self.DT)
+            y = act(name, src.H, src.W, cout, vgg=True)
+            self._max_scr = max(self._max_scr, src.M * src.ld)
+            self.plan.append(('vgg', name, src, y))
+            return y
+
+        def bn(name, src, out=None):
+            """conv / transposed conv + batch norm (+ ReLU); out = (tensor, first row, width): the output goes straight into a prediction tensor"""
+            _, kind, cin, cout, k, stride, dil, relu = spec[name]
+            assert cin == src.C, (name, cin, src.C)
+            ldz = ops.pad_to(cout, ch)
+            if kind == 'conv':
+                d = ops.conv_desc(N, src.H, src.W, ops.pad_to(cin, ch), src.ld, cout, ldz, k, stride, dil, self.DT, self.DT)
+                Ho, Wo = d.Ho, d.Wo
+            else:
+                Ho, Wo = src.H * stride, src.W * stride
+                d = ops.conv_desc(N, Ho, Wo, ldz, ldz, cin, src.ld, k, stride, 1, self.DT, self.DT)
+                assert d.Ho == src.H and d.Wo == src.W
+            self.desc[name] = d
+            z = _Act(name + '.z', N, Ho, Wo, cout, ldz, dt, dev)
+            self.z[name] = z
+            if out is None:
+                y = act(name, Ho, Wo, cout)
+            else:
+                y = _Act(name, N, Ho, Wo, cout, cout, torch.float32, dev, alloc=False)
+                self.acts[name] = y
+            self.bnsave[name] = (torch.zeros(cout, device=dev), torch.zeros(cout, device=dev))
+            self._max_ws = max(self._max_ws, ops.bn_workspace_bytes(z.M, cout))
+            self._max_z = max(self._max_z, z.M * ldz)
+            self._max_scr = max(self._max_scr, src.M * src.ld)
+            self.plan.append(('bn', name, kind, src, z, y, 1 if relu else 0, out))
+            return y
+
+        def pool(name, x, k, s):
+            Ho, pt, _ = ops.same_pad(x.H, k, s)
+            y = act(name, Ho, Ho, x.C, vgg=x.vgg)
+            self._max_scr = max(self._max_scr, x.M * x.ld)
+            self.plan.append(('pool', x, y, k, s, pt))
+            return y
+
+        def l2norm(name, x, gname):
+            y = act(name, x.H, x.W, x.C)
+            self.plan.append(('l2norm', x, y, gname))
+            return y
+
+        x = self.input
+        feats = {}
+        for l in VGG_SEQ:
+            if isinstance(l, tuple):
+                x = vgg(l[0], x)
+                feats[l[0]] = x
+            else:
+                x = pool(l, x, 3, 1) if l == 'pool5' else pool(l, x, 2, 2)
+        for e in EXTRAS:
+            x = bn(e[0], x)
+            feats[e[0]] = x
+        f = [l2norm('feat1', feats['conv4_3'], 'feat1_l2_norm'), l2norm('feat2', feats['conv5_3'], 'feat2_l2_norm'), feats['conv8_2'], feats['conv10_2']]
+        self.level_off, off = [], 0
+        for a in f:
+            self.level_off.append(off)
+            off += a.H * a.W * NA
+        assert off == A, (off, A)
+
+        def head(prefix, x, lvl, loc_t, conf_t, ncls):
+            c = x
+            for j in range(1, 5):
+                c = bn(f'{prefix}.c{j}', c)
+            bn(f'{prefix}.loc', c, (loc_t, self.level_off[lvl], 4))
+            bn(f'{prefix}.conf', c, (conf_t, self.level_off[lvl], ncls))
+        for l in range(4):
+            head(f'arm{l + 1}', f[l], l, 'arm_loc', 'arm_conf', 2)
+        tcb = {}
+        for l in (4, 3, 2, 1):
+            c2 = bn(f'tcb{l}.c2', bn(f'tcb{l}.c1', f[l - 1]))
+            if l == 4:
+                tcb[l] = c2
+            else:
+                d_ = bn(f'tcb{l}.d', tcb[l + 1])
+                y = act(f'tcb{l}', c2.H, c2.W, c2.C)
+                self.plan.append(('add_relu', c2, d_, y))
+                tcb[l] = y
+        for l in range(4):
+            head(f'odm{l + 1}', tcb[l + 1], l, 'odm_loc', 'odm_conf', C)
+        self.ws = torch.zeros(self._max_ws, dtype=torch.uint8, device=dev)
+        self.wt, entries = {}, []
+        for sp in self.specs:
+            name, kind, cin, cout, k = sp[0], sp[1], sp[2], sp[3], sp[4]
+            if name == 'conv1_1':
+                continue
+            (kout, _, _, kin_pad), _ = self._wshape(sp)
+            kp = ops.pad_to(kout, ch)
+            self.wt[name] = torch.zeros(kin_pad * k * k * kp, dtype=dt, device=dev)
+            entries.append((self._flat(name + '.w', self.P), self.wt[name], kout, k, k, kin_pad, kp))
+        self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, dev)
+        if self.mode == 'train':
+            self._build_backward(N, dt, dev)
+        self._refresh_operand_copies()
+
+    def _pred_view(self, out, grad=False):
+        """(flat tensor starting at this level's first row, row width, rows per image of the level is implied by the caller, image stride)"""
+        tname, first, width = out
+        t = getattr(self.loss, 'd_' + tname) if grad else getattr(self, tname)
+        return t.view(-1)[first * width:], width, self.A * width
+
+    def _build_backward(self, N, dt, dev):
+        self.loss = None                                        # heads.RefineDetLoss, built with the first batch (needs the ground-truth pad length)
+        self.zg = torch.zeros(self._max_z, dtype=dt, device=dev)
+        self.scr = torch.zeros(self._max_scr, dtype=dt, device=dev)
+        written = set()
+
+        def emit(a):
+            acc = id(a) in written
+            written.add(id(a))
+            if a.g is None and a is not self.input:
+                a.g = torch.zeros(a.M, a.ld, dtype=dt, device=dev)
+            return acc
+        self.bplan = []
+        for op in reversed(self.plan):
+            kind = op[0]
+            if kind == 'bn':
+                _, name, lk, src, z, y, relu, out = op
+                assert out is not None or id(y) in written, name
+                self.bplan.append(('bn', name, lk, src, z, y, relu, out, emit(src)))
+            elif kind == 'vgg':
+                _, name, src, y = op
+                assert id(y) in written, name
+                self.bplan.append(('vgg', name, src, y, emit(src) if src is not self.input else False))
+            elif kind == 'pool':
+                _, x, y, k, s, pt = op
+                assert id(y) in written
+                self.bplan.append(('pool', x, y, k, s, pt, emit(x)))
+            elif kind == 'l2norm':
+                _, x, y, gname = op
+                assert id(y) in written
+                self.bplan.append(('l2norm', x, y, gname, emit(x)))
+            else:
+                _, a, b, y = op
+                assert id(y) in written
+                self.bplan.append(('add_relu', (a, emit(a)), (b, emit(b)), y))
+        self.gt = None
+
+    # ------------------------------------------------------------------ forward / loss / backward
+    def _forward(self, training, subtract_mean=True):
+        ops.preprocess(self.images, MEAN_RGB if subtract_mean else (0., 0., 0.), self.input.ld, self.DT, self.input.t)
+        for op in self.plan:
+            kind = op[0]
+            if kind == 'vgg':
+                _, name, src, y = op
+                ops.conv2d_fwd(self.desc[name], src.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), y.t, True)
+            elif kind == 'bn':
+                _, name, lk, src, z, y, relu, out = op
+                if lk == 'conv':
+                    ops.conv2d_fwd(self.desc[name], src.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), z.t, False)
+                else:
+                    ops.conv2d_dgrad(self.desc[name], src.t, src.ld, self.wt[name], None, z.t, False)
+                sm, si = self.bnsave[name]
+                if out is None:
+                    dst, ldy, rpi, stride = y.t, y.ld, z.M, 0
+                else:
+                    dst, _, stride = self._pred_view(out)
+                    ldy, rpi = z.C, z.H * z.W                   # a cell's NA * width outputs are contiguous rows of the prediction tensor
+                ops.bn_fwd(z.t, z.M, z.C, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'), self.stat(name + '.mmean'),
+                           self.stat(name + '.mvar'), sm, si, training, relu, dst, ldy, rpi, stride, self.ws)
+            elif kind == 'pool':
+                _, x, y, k, s, pt = op
+                ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
+            elif kind == 'l2norm':
+                _, x, y, gname = op
+                ops.l2norm_fwd(x.t, y.t, x.M, x.C, x.ld, self.param(gname))
+            else:
+                _, a, b, y = op
+                ops.add_relu_fwd(a.t, a.ld, b.t, b.ld, y.t, y.ld, y.M, y.ld)
+
+    def _into(self, a, acc):
+        return self.scr[: a.M * a.ld].view(a.M, a.ld) if acc else a.g
+
+    def _fold(self, a, acc):
+        if acc:
+            ops.add2d(a.g, a.ld, self.scr[: a.M * a.ld].view(a.M, a.ld), a.ld, a.g, a.ld, a.M, a.ld)
+
+    def _backward_iter(self):
+        for op in self.bplan:
+            kind = op[0]
+            if kind == 'bn':
+                _, name, lk, src, z, y, relu, out, acc = op
+                zg = self.zg[: z.M * z.ld].view(z.M, z.ld)
+                sm, si = self.bnsave[name]
+                if out is None:
+                    dy, ldy, rpi, stride, yt = y.g, y.ld, z.M, 0, (y.t if relu else None)
+                else:
+                    dy, _, stride = self._pred_view(out, grad=True)
+                    ldy, rpi, yt = z.C, z.H * z.W, None
+                ops.bn_bwd(z.t, yt, dy, z.M, z.C, z.ld, ldy, rpi, stride, self.param(name + '.gamma'), sm, si, relu, zg,
+                           self._flat(name + '.gamma', self.G), self._flat(name + '.beta', self.G), self.ws)
+                mask = src.t if src.vgg else None
+                if lk == 'conv':
+                    ops.conv2d_wgrad(self.desc[name], src.t, zg, z.ld, self._flat(name + '.w', self.G), None)
+                    ops.conv2d_dgrad(self.desc[name], zg, z.ld, self.wt[name], mask, src.g, acc)
+                else:
+                    ops.conv2d_wgrad(self.desc[name], zg, src.t, src.ld, self._flat(name + '.w', self.G), None)
+                    ops.conv2d_fwd(self.desc[name], zg, self._flat(name + '.w', self.Pc), None, self._into(src, acc), False)
+                    self._fold(src, acc)
+                yield name
+            elif kind == 'vgg':
+                _, name, src, y, acc = op
+                ops.conv2d_wgrad(self.desc[name], src.t, y.g, y.ld, self._flat(name + '.w', self.G), self._flat(name + '.b', self.G))
+                if src is not self.input:
+                    ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], src.t if src.vgg else None, src.g, acc)
+                yield name
+            elif kind == 'pool':
+                _, x, y, k, s, pt, acc = op
+                ops.maxpool_bwd(x.t, y.t, y.g, self._into(x, acc), x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
+                self._fold(x, acc)
+            elif kind == 'l2norm':
+                _, x, y, gname, acc = op
+                ops.l2norm_bwd(x.t, y.g, x.g, x.M, x.C, x.ld, self.param(gname), self._flat(gname, self.G), acc, x.t)
+                yield gname
+            else:
+                _, (a, acc_a), (b, acc_b), y = op
+                ops.relu_bwd(y.t, y.g, y.ld, a.g, a.ld, y.M, y.ld, acc_a)
+                ops.relu_bwd(y.t, y.g, y.ld, b.g, b.ld, y.M, y.ld, acc_b)
+
+    # ------------------------------------------------------------------ public: training
+    def set_batch(self, images, ground_truth):
+        images = torch.as_tensor(images, dtype=torch.float32)
+        if self.data_format == 'channels_first' and images.shape[1] == 3:
+            images = images.permute(0, 2, 3, 1)
+        assert tuple(images.shape) == tuple(self.images.shape), images.shape
+        self.images.copy_(images, non_blocking=True)
+        gt = torch.as_tensor(ground_truth, dtype=torch.float32)
+        if self.gt is None or self.gt.shape != gt.shape:
+            self.gt = torch.zeros(gt.shape, device=self.dev)
+            self.loss = heads.RefineDetLoss(self.anc, self.batch_size, self.num_classes, gt.shape[1], self.dev)
+        self.gt.copy_(gt, non_blocking=True)
+
+    def train_step(self, lr):
+        """one MomentumOptimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor"""
+        if self.dist is not None:
+            self.dist.begin_step()
+        self.G.zero_()
+        self._forward(True)
+        parts = self.loss(self.arm_loc, self.arm_conf, self.odm_loc, self.odm_conf, self.gt, 1.0 / self.loss_divisor_batch)
+        for name in self._backward_iter():
+            # gradient segments of the all-reduce are the blocks before the first '.' (arm1, tcb3, ...); a block is final when its FIRST
+            # layer in creation order (.c1) has been processed -- backward walks a block's layers in reverse
+            if self.dist is not None and ('.' not in name or name.endswith('.c1')):
+                self.dist.layer_ready(name.split('.')[0])
+        if self.dist is not None:
+            self.dist.finish_step()
+        ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial, self.Pc if self.DT == BF16 else None)
+        ops.sum_f32(self.l2_partial, self.l2_sum)
+        self._fp_batch.run()
+        self.global_step += 1
+        return parts[:, 6].sum() / self.batch_size + self.weight_decay * self.l2_sum      # RefineDet.py:180-184 (pre-update weights)
+
+    def train_one_epoch(self, lr):
+        if callable(self.train_initializer):
+            self.train_initializer()
+        mean_loss = []
+        num_iters = self.num_train // self.batch_size
+        it = iter(self.train_iterator)
+        for i in range(num_iters):
+            try:
+                images, gt = next(it)
+            except StopIteration:
+                it = iter(self.train_iterator)
+                images, gt = next(it)
+            self.set_batch(images, gt)
+            loss = float(self.train_step(lr).item())
+            if self.verbose:
+                sys.stdout.write('\r>> ' + 'iters ' + str(i + 1) + str('/') + str(num_iters) + ' loss ' + str(loss))
+                sys.stdout.flush()
+            mean_loss.append(loss)
+        if self.verbose:
+            sys.stdout.write('\n')
+        return np.mean(mean_loss)
+
+    # ------------------------------------------------------------------ public: inference
+    def test_one_image(self, images):
+        images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+        if self.data_format == 'channels_first' and images.shape[1] == 3:
+            images = images.permute(0, 2, 3, 1)
+        assert self.batch_size == 1 and tuple(images.shape) == tuple(self.images.shape), images.shape
+        self.images.copy_(images)
+        self._forward(False, subtract_mean=bool(self.config.get('test_subtract_mean', False)))      # reference quirk: the fed tensor is `images - mean`
+        scores, bbox, cid = heads.refinedet_detect(self.arm_loc[0], self.arm_conf[0], self.odm_loc[0], self.odm_conf[0], self.anc[2], self.anc[3],
+                                                   self.nms_score_threshold, self.nms_max_boxes, self.nms_iou_threshold)
+        return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
+
+    # ------------------------------------------------------------------ checkpoints / data parallel
+    def save_weight(self, mode, path):
+        assert (mode in ['latest', 'best'])
+        dirname = os.path.dirname(path)
+        if dirname and not os.path.exists(dirname):
+            os.makedirs(dirname)
+            print(dirname, 'does not exist, create it done')
+        blob = {'params': self.export_params(), 'momentum': self.Mom.detach().cpu(), 'global_step': self.global_step,
+                'layout': {k: (int(o), tuple(int(x) for x in shp)) for k, (o, shp) in self.pinfo.items()}}
+        torch.save(blob, path + '-' + str(self.global_step))
+        print('save', mode, 'model in', path, 'successfully')
+
+    def load_weight(self, path):
+        blob = torch.load(path, map_location='cpu', weights_only=True)
+        self.load_oracle_params(blob['params'])
+        if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
+            self.Mom.copy_(blob['momentum'].to(self.dev))
+        self.global_step = int(blob.get('global_step', 0))
+        print('load weight', path, 'successfully')
+
+    def attach_data_parallel(self, group=None, bucket_mb=25):
+        from .dist import GradAllReducer
+        self.dist = GradAllReducer(self, group, bucket_mb)
+        self.loss_divisor_batch = self.batch_size * self.dist.world
+        return self.dist

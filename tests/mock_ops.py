@@ -353,9 +353,24 @@ def l2norm_bwd(x, dy, dx, M, C_, ld, gamma, dgamma, accumulate, relu_src):
 
 
 def ssd_priors(input_size, fsizes, nas, prior_hw_flat, device):
-    from oracle import ssd300_ref as R
-    y1x1, y2x2, yx, hw = R.priors()
-    return y1x1, y2x2, yx, hw, torch.cat([y1x1, y2x2], 1)
+    """the prior kernel's arithmetic in numpy float32, in the op order of the reference's _get_abbox (SSD300.py:323-343)"""
+    import numpy as np
+    f32 = np.float32
+    outs, k = [[], [], [], []], 0
+    for f, na in zip(fsizes, nas):
+        pr = np.asarray(prior_hw_flat[2 * k: 2 * (k + na)], dtype=np.float64).astype(f32).reshape(1, 1, na, 2)
+        k += na
+        ty = (np.arange(0., f, dtype=f32).reshape(-1, 1, 1, 1) + f32(0.5))
+        tx = (np.arange(0., f, dtype=f32).reshape(1, -1, 1, 1) + f32(0.5))
+        ty = np.tile(ty, [1, f, 1, 1]) * f32(input_size) / f32(f)
+        tx = np.tile(tx, [f, 1, 1, 1]) * f32(input_size) / f32(f)
+        tyx = np.tile(np.concatenate([ty, tx], -1), [1, 1, na, 1])
+        y1x1 = (tyx - pr / f32(2.)).reshape(-1, 2)
+        y2x2 = (tyx + pr / f32(2.)).reshape(-1, 2)
+        for o, v in zip(outs, (y1x1, y2x2, y1x1 / f32(2.) + y2x2 / f32(2.), y2x2 - y1x1)):
+            o.append(v.astype(f32))
+    y1x1, y2x2, yx, hw = (torch.from_numpy(np.concatenate(o, 0)) for o in outs)
+    return y1x1, y2x2, yx, hw, torch.cat([yx - hw / 2., yx + hw / 2.], 1)
 
 
 def ssd_match(*a):
@@ -453,6 +468,15 @@ def preprocess_norm(images, div, mean3, std3, ldx, dtype, x):
     x[:, :3] = v.reshape(-1, 3).to(x.dtype)
 
 
+def add_relu_fwd(a, lda, b, ldb, y, ldy, M, C_):
+    y[:M, :C_] = torch.relu(a[:M, :C_].float() + b[:M, :C_].float()).to(y.dtype)
+
+
+def relu_bwd(y, dy, ldy, dx, lddx, M, C_, accumulate=False):
+    g = dy[:M, :C_].float() * (y[:M, :C_].float() > 0)
+    dx[:M, :C_] = (g + (dx[:M, :C_].float() if accumulate else 0.)).to(dx.dtype)
+
+
 def avgpool2x2_fwd(x, y, N, H, W, ld):
     v = x.float().reshape(N, H // 2, 2, W // 2, 2, ld)
     y.copy_((((v[:, :, 0, :, 0] + v[:, :, 0, :, 1]) + v[:, :, 1, :, 0]) + v[:, :, 1, :, 1]).div(4.).reshape(-1, ld).to(y.dtype))
@@ -473,6 +497,28 @@ def adam(p, m, v, g, lr_t, beta1, beta2, eps, wd, grad_scale, l2_partial, p_cast
     p.sub_((m * lr_t) / (torch.sqrt(v) + eps))
     if p_cast is not None:
         p_cast.copy_(p.to(p_cast.dtype))
+
+
+def refinedet_loss(arm_loc, arm_conf, odm_loc, odm_conf, yx, hw, gt, ngt, best, status, rgindex, counts, negloss, sel_idx, sel_cnt, grad_scale,
+                   loss_parts, d_arm_loc, d_arm_conf, d_odm_loc, d_odm_conf):
+    """matching, mining and the two-stage loss by the oracle (the mocked retina_match / softmax_ce_const / nms_batched in front of it do nothing)"""
+    from oracle import refinedet_ref as FR
+    anc = (yx - hw / 2., yx + hw / 2., yx, hw)
+    leaves = [t.detach().clone().requires_grad_(True) for t in (arm_loc, arm_conf, odm_loc, odm_conf)]
+    tot = 0.
+    for i in range(arm_loc.shape[0]):
+        li = FR.one_image_loss(leaves[0][i, :, :2], leaves[0][i, :, 2:], leaves[1][i], leaves[2][i, :, :2], leaves[2][i, :, 2:], leaves[3][i], anc, gt[i],
+                               odm_conf.shape[-1])
+        loss_parts[i, 6] = li.detach()
+        tot = tot + li
+    for dst, g in zip((d_arm_loc, d_arm_conf, d_odm_loc, d_odm_conf), torch.autograd.grad(tot * grad_scale, leaves)):
+        dst.copy_(g)
+
+
+def refinedet_decode(arm_loc, arm_conf, odm_loc, odm_conf, yx, hw, thr):
+    from oracle import refinedet_ref as FR
+    conf, boxes, keep = FR.decode(arm_loc, arm_conf, odm_loc, odm_conf, (None, None, yx, hw), odm_conf.shape[-1])
+    return conf.contiguous(), boxes.contiguous(), keep.to(torch.uint8), ((conf >= thr) & keep[:, None]).to(torch.uint8)
 
 
 def centernet_workspace(N, H, W, Cn, device):

@@ -298,3 +298,39 @@ def test_ssd512_training_step_host_logic():
             if float(step.norm()) < 1e-12:
                 continue
             assert _rel(after[k] - p[k], step) < 3e-2, k
+
+
+def test_refinedet_training_step_host_logic():
+    """RefineDet320: VGG trunk (ReLU mask at the consumers), two L2-normalised feature maps, extras, four ARM / ODM heads writing straight into the
+    prediction tensors, the top-down TCB chain with transposed convs and add + ReLU, multi-consumer gradient buffers -- one training step on the CPU
+    mock against oracle/refinedet_net_ref.train_step (pinned on the reference's own class, tests/golden/refinedet_train.npz)"""
+    import odtk
+    from oracle import refinedet_net_ref as NR
+    from oracle import refinedet_ref as FR
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'input_size': 320, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+           'nms_score_threshold': 0.1, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.45, 'pretraining_weight': '', 'verbose': False, 'compute_dtype': 'f32',
+           'device': 'cpu'}
+    g = torch.Generator().manual_seed(190)
+    imgs = (torch.rand(1, 320, 320, 3, generator=g) * 255).round()
+    gt = FR.synthetic_gt(1, 320, 191, pad=8, max_obj=3)
+    p = NR.init_params(19)
+    with mock_ops.installed():
+        m = odtk.RefineDet320(cfg, {'data_shape': [320, 320, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+        assert [s[:4] for s in m.specs] == [s[:4] for s in NR.layer_specs()] and m.A == 6375
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        loss = float(m.train_step(0.001))
+        q = {k: v.clone() for k, v in p.items()}
+        mom = {k: torch.zeros_like(p[k]) for k in NR.trainable_names(p)}
+        total, data, grads = NR.train_step(q, mom, imgs, gt, 0.001)
+        assert abs(loss - total) < 1e-4 * abs(total), (loss, total)
+        for k in NR.trainable_names(p):
+            if k.endswith('.b') and (k[:-2] + '.gamma') in p:
+                assert float(m.get_param(k, m.G).abs().max()) == 0.0          # a bias in front of a batch norm
+                continue
+            want = grads[k] - 1e-4 * p[k]
+            assert _rel(m.get_param(k, m.G), want) < 3e-2, (k, _rel(m.get_param(k, m.G), want))     # batch-1 batch norm over 25 ... 1600 samples: the SSD300 bound
+        after = m.export_params()
+        for k in ('conv1_1.w', 'conv5_3.b', 'conv10_2.gamma', 'arm1.c1.w', 'tcb2.d.w', 'odm4.conf.beta', 'feat1_l2_norm', 'tcb3.d.mmean', 'odm1.loc.mvar'):
+            assert _rel(after[k], q[k]) < 1e-3 or float((after[k] - q[k]).abs().max()) < 1e-6, k

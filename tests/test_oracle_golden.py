@@ -485,3 +485,39 @@ def test_refinedet_box_side_matches_reference_functions():
     s, b, c = FR.detect(arm_loc[0], arm_conf[0], odm_loc[0], odm_conf[0], anc, 0.12, 10, 0.45)
     assert c.tolist() == g['det_class'].tolist() and len(s) > 0
     assert np.allclose(s.numpy(), g['det_scores'], atol=1e-6) and np.allclose(b.numpy(), g['det_bbox'], rtol=1e-5, atol=1e-3)
+
+
+def test_refinedet_two_training_steps_match_reference_class():
+    """oracle/refinedet_net_ref (VGG trunk, L2-normalised features, extras, ARM / TCB / ODM, Momentum) against two steps of the reference's own
+    RefineDet320 class run through its session on the shim (tests/golden/refinedet_train.npz); variable names / shapes of the graph"""
+    import json
+    from oracle import refinedet_net_ref as NR
+    from oracle import refinedet_ref as FR
+    g = np.load(os.path.join(GOLD, 'refinedet_train.npz'))
+    specs = NR.layer_specs()
+    assert len(specs) == 80 == len(g['names']) and len(g['bn_names']) == 67
+    p = NR.init_params(61)
+    mom = {k: torch.zeros_like(p[k]) for k in NR.trainable_names(p)}
+    losses, after_first = [], None
+    for s in (800, 801):
+        gen = torch.Generator().manual_seed(s)
+        imgs = (torch.rand(2, 320, 320, 3, generator=gen) * 255).round()
+        gt = FR.synthetic_gt(2, 320, s + 10, pad=8, max_obj=4)
+        total, _, _ = NR.train_step(p, mom, imgs, gt, 0.001)
+        losses.append(total)
+        if after_first is None:
+            after_first = {k: v.detach().clone() for k, v in p.items()}
+    assert abs(losses[0] - g['losses'][0]) < 1e-5 * g['losses'][0] and abs(losses[1] - g['losses'][1]) < 1e-3 * g['losses'][1], (losses, g['losses'])
+    for key in g.files:
+        if key in ('losses', 'names', 'bn_names'):
+            continue
+        k = key.replace('__', '.')
+        got = after_first[k].reshape(-1)
+        got = got[::max(1, got.numel() // 1024)].numpy()
+        assert np.linalg.norm(got - g[key]) / (np.linalg.norm(g[key]) + 1e-9) < 1e-4, k
+    names = json.load(open(os.path.join(GOLD, 'refinedet_names.json')))
+    want = json.load(open(os.path.join(GOLD, 'refinedet_variables.json')))
+    assert set(names.values()) | {'global_step'} == set(want) and set(names) == set(p)
+    for ours, tfname in names.items():
+        shp = list(p[ours].permute(1, 2, 3, 0).shape) if ours.endswith('.w') else list(p[ours].shape)
+        assert want[tfname]['shape'] == shp, (ours, tfname)

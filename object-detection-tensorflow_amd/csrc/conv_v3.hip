@@ -640,9 +640,13 @@ __global__ void __launch_bounds__(256) conv_gather_v5_kernel(const GatherArgs a)
 // buffer of 576 rows; the next chunk's patch is written into rows that are already DEAD -- tap row dr only reads patch rows
 // >= dr * dil * W, so groups i < G1 = floor(dil W / 32) are issued on the slab of tap 3, groups < G2 = floor(2 dil W / 32) on
 // tap 6, and only the last NPP - G2 groups (258 rows) are exposed between two chunks.
-template <int NPP, bool DBUF, int G1, int G2>
+// WP x (4 / WP) waves, every wave PI x QI accumulator tiles of 32 x 32: 2, 2, 4 = the 128 x 256 tile (0.75 fragment reads per MFMA);
+// 1, 4, 4 = a 128 x 512 tile of four 128 x 128 wave tiles (0.5 reads per MFMA, round 2: the 75- and 150-pixel maps, whose time is LDS
+// bandwidth); 2, 2, 3 = 128 x 192 (conv5_x: 244 instead of 184 tiles for 256 CUs).
+template <int NPP, bool DBUF, int G1, int G2, int WP = 2, int PI = 2, int QI = 4>
 __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a) {
-    constexpr int PT = 128, QT = 256, NTHR = 256, PI = 2, QI = 4;
+    constexpr int PT = WP * PI * 32, QT = (4 / WP) * QI * 32, NTHR = 256;
+    static_assert(PT == 128, "the filter slab is 128 rows");
     constexpr int NP = PT / 32;                          // filter DMA pieces per wave and slab
     constexpr int PROWS = NPP * 32;                      // patch rows (416 | 576)
     constexpr int PATCH = PROWS * 128, WST = PT * 128;
@@ -650,7 +654,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     constexpr int ZOFF = WBASE + 3 * WST;
     __shared__ __attribute__((aligned(16))) char smem[ZOFF + 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wp = wave & 1, wq = wave >> 1;
+    const int wp = wave % WP, wq = wave / WP;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
     const int p0 = tp * PT, q0 = tq * QT;
@@ -672,19 +676,19 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     }
     // ---- patch DMA: piece q = wave + 4 i covers patch rows 8q .. 8q+7; row r holds raster pixel q0 - W - 1 + r
     const int total_px = a.N * a.H * a.W;
-    unsigned xoff32[NPP];
+    // (piece i of a wave is 32 rows below piece i - 1 and 32 i does not touch (row >> 1) & 7: one base offset + i * xstep)
     unsigned xok = 0;
+    const int xrow0 = wave * 8 + (lane >> 3);
+    const unsigned xoff0 = (unsigned)((q0 - a.dil * (a.W + 1) + xrow0) * a.ldx * 2 + (((lane & 7) ^ ((xrow0 >> 1) & 7)) * 16));
+    const unsigned xstep = (unsigned)(64 * a.ldx);
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
-        const int row = (wave + 4 * i) * 8 + (lane >> 3);
-        const int g = q0 - a.dil * (a.W + 1) + row;
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        xoff32[i] = (unsigned)(g * a.ldx * 2 + lc * 16);
+        const int g = q0 - a.dil * (a.W + 1) + xrow0 + 32 * i;
         if ((unsigned)g < (unsigned)total_px) xok |= 1u << i;
     }
     // ---- fragment rows of this lane: pixel rows qrow0 + 32 j + l31, their 9-bit tap masks
     const int l31 = lane & 31, hi = lane >> 5;
-    const int prow0 = wp * (PT / 2), qrow0 = wq * 128;
+    const int prow0 = wp * (PI * 32), qrow0 = wq * (QI * 32);
     unsigned qmask[QI];
     const int HW = a.H * a.W;
 #pragma unroll
@@ -721,7 +725,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         }
     };
     auto issue_x = [&](int i, int cs, int buf) __attribute__((always_inline)) {    // patch piece i of chunk cs
-        const unsigned addr = xoff32[i] + (unsigned)(cs * 128);
+        const unsigned addr = xoff0 + (unsigned)i * xstep + (unsigned)(cs * 128);
         glds16_buf_nc(rx, ((xok >> i) & 1u) ? addr : 0xFFFFFFF0u, smem_base + (unsigned)buf * PATCH + (wave_u + 4u * (unsigned)i) * 1024u);
     };
 
@@ -738,13 +742,14 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     issue_w(1, 1);
 
     // One tap slab.  Every slab issues the SAME number of pieces (filter slab kt+2: NP; patch pieces of chunk cs+1 by tap
-    // position: 2,2,2,2,2,1,1,1,0), so the counted vmcnt in front of each barrier is a compile-time constant; past the end
+    // position: 2,2,2,2,2,1,1,1,0 for 13 pieces), so the counted vmcnt in front of each barrier is a compile-time constant; past the end
     // of the k loop the pieces carry out-of-range offsets (zero fill into stages nobody reads again).
     auto slab = [&](auto TAPC, int kt, int cs, int st_c, int st_n) __attribute__((always_inline)) {
         constexpr int tap = decltype(TAPC)::value;
         constexpr int dr = tap / 3, ds = tap - dr * 3;
-        constexpr int NX = DBUF ? (tap < 5 ? 2 : (tap < 8 ? 1 : 0)) : (tap == 3 ? G1 : (tap == 6 ? G2 - G1 : 0));
-        constexpr int XBASE = DBUF ? (tap < 5 ? 2 * tap : 10 + (tap - 5)) : (tap == 3 ? 0 : G1);
+        // (double buffer: the NPP pieces of the next chunk dealt over taps 0..7, NPP = 13 -> 2,2,2,2,2,1,1,1,0)
+        constexpr int NX = DBUF ? (tap < 8 ? NPP / 8 + (tap < NPP % 8 ? 1 : 0) : 0) : (tap == 3 ? G1 : (tap == 6 ? G2 - G1 : 0));
+        constexpr int XBASE = DBUF ? tap * (NPP / 8) + (tap < NPP % 8 ? tap : NPP % 8) : (tap == 3 ? 0 : G1);
         constexpr int NPC = NP + NX;
         const char* sP = smem + WBASE + st_c * WST;
         const unsigned pbase = smem_base + (DBUF ? (unsigned)((cs & 1) * PATCH) : 0u);
@@ -794,13 +799,13 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
                     }
 #pragma unroll
                     for (int q = 0; q < NPC; ++q)
-                        if (q * 32 / NPC == slotno) {
+                        if (q * (4 * PI * QI) / NPC == slotno) {
                             if (q < NP) {
                                 const unsigned addr = poff32[q] + woff;
                                 glds16_buf_nc(rw, (pok[q] && more_w) ? addr : 0xFFFFFFF0u, dW + q * 4096u);
                             } else {
                                 const int xi = XBASE + q - NP;
-                                const unsigned addr = xoff32[xi] + (unsigned)((cs + 1) * 128);
+                                const unsigned addr = xoff0 + (unsigned)xi * xstep + (unsigned)((cs + 1) * 128);
                                 glds16_buf_nc(rx, (((xok >> xi) & 1u) && more_x) ? addr : 0xFFFFFFF0u,
                                               smem_base + (DBUF ? (unsigned)(((cs + 1) & 1) * PATCH) : 0u) + (wave_u + 4u * (unsigned)xi) * 1024u);
                             }
@@ -815,7 +820,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
             constexpr int tap = decltype(TAPC)::value;
             // may stay in flight: what the PREVIOUS slab issued (filter slab kt+1 and the patch pieces of its position)
             constexpr int PREV = (tap + 8) % 9;
-            constexpr int NXP = DBUF ? (PREV < 5 ? 2 : (PREV < 8 ? 1 : 0)) : (PREV == 3 ? G1 : (PREV == 6 ? G2 - G1 : 0));
+            constexpr int NXP = DBUF ? (PREV < 8 ? NPP / 8 + (PREV < NPP % 8 ? 1 : 0) : 0) : (PREV == 3 ? G1 : (PREV == 6 ? G2 - G1 : 0));
             if (!DBUF && tap == 0 && cs > 0) {
                 // single patch buffer: every wave is past its last read of the old chunk (barrier), the rest of the new
                 // chunk's patch (groups G2 .. NPP-1) goes out now and must land before the first tap reads it
@@ -2058,9 +2063,30 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     const int grid = tiles;
     // raster-run halo kernel: 3x3 (dilated), stride 1, SAME, patch of 256 + 2 * dil * (W + 1) rows <= 416 (dbg bit 16 = off, A/B)
     if (v6_ok) {
+        if (g_num_cu == 0) query_num_cu();
+        a.ksplit = -1;                                   // tells the dispatcher which kernel ran (odtk_conv_last_kernel)
+        // 128 x 512 tiles of four 128 x 128 wave tiles (0.5 instead of 0.75 fragment reads per MFMA) where the map is large enough to fill
+        // the chip twice over with them: conv3_x (W = 75) and conv2_x (W = 150); dbg bit 27 = off (A/B)
+        const int tq512 = ceil_div(a.M, 512);
+        // (measured, same box: conv3_2 fwd 198 -> 180 us, dgrad 215 -> 199, conv3_1 fwd 116 -> 106, conv2_1 fwd 164 -> 157, conv2_2 fwd 228 -> 224; the
+        // wide variant with a masked / accumulating epilogue -- conv2_2 dgrad -- is 2 % SLOWER: 64 more operand registers -> not used there)
+        const bool post512 = a.accumulate || a.mask;
+        if (!(a.dbg & (1 << 27)) && tq512 * a.tiles_p >= 2 * g_num_cu && a.dil * a.W >= 64 && (halo <= 160 || !post512)) {
+            a.tiles_q = tq512;
+            if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<21, false, 2, 4, 1, 4, 4>), dim3(tq512 * a.tiles_p), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gather_v6_kernel<26, false, 4, 9, 1, 4, 4>), dim3(tq512 * a.tiles_p), dim3(256), 0, st, a);
+            return 0;
+        }
+        // 128 x 192 tiles where 256-pixel tiles leave a quarter of the CUs idle and 192-pixel tiles still fit one round (conv5_x: 184 -> 244
+        // workgroups of 3/4 the work, 56 -> 50 us); dbg bit 28 = off (A/B)
+        const int tq192 = ceil_div(a.M, 192);
+        if (!(a.dbg & (1 << 28)) && halo <= 160 && tiles < g_num_cu && tq192 * a.tiles_p <= g_num_cu && tq192 * a.tiles_p > tiles) {
+            a.tiles_q = tq192;
+            hipLaunchKernelGGL((conv_gather_v6_kernel<11, true, 0, 0, 2, 2, 3>), dim3(tq192 * a.tiles_p), dim3(256), 0, st, a);
+            return 0;
+        }
         if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<13, true, 0, 0>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 9>), dim3(grid), dim3(256), 0, st, a);
-        a.ksplit = -1;                                   // tells the dispatcher which kernel ran (odtk_conv_last_kernel)
         return 0;
     }
     if ((a.dbg & 32768) && PT == 128 && a.C % 64 == 0 && a.Kdim % 64 == 0) {      // 4-wave hand-scheduled variant (dbg bit 15, A/B)

@@ -97,6 +97,8 @@ V3_EXTRA_CASES = [
     (1, 60, 150, 192, 160, 3, 1, 1),  # wide raster-run halo kernel (single patch buffer, W = 150): 3 chunks, channel-tile tail
     (1, 20, 159, 64, 128, 3, 1, 1),   # ... widest supported map: the patch needs all 576 rows
     (2, 80, 72, 128, 128, 3, 1, 2),   # ... dilation 2 (dil * W = 144: the early groups end exactly at the first live row)
+    (24, 75, 75, 64, 200, 3, 1, 1),   # 128 x 512 tiles of four 128 x 128 wave tiles (>= 2 rounds of 256 workgroups): ragged last tile, channel tail
+    (24, 19, 19, 64, 512, 3, 1, 1),   # 128 x 192 tiles (136 workgroups of 256 pixels would leave CUs idle, 184 of 192 pixels fit one round)
 ]
 
 

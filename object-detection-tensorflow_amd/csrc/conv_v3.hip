@@ -2179,6 +2179,252 @@ bool wgrad_v3_supported(const WgradArgs& a, int dtype) {
            (long long)a.P * a.lddy * 2 < (1ll << 31) && (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31);
 }
 
+// ---------------------------------------------------------------------------------------
+// "v8" filter gradient (round 2): FOUR waves, one per SIMD, every wave a 128 (k) x 128 (columns) block of 4 x 4 accumulator
+// tiles -- the wave shape of the 128 x 512 halo kernel: 16 transpose reads + 8 | 10 LDS-DMA pieces per 32 MFMAs, 768 | 832 LDS
+// bytes per MFMA against 1408 of conv_wgrad_v3_kernel (these kernels run at MFMA time + LDS time).
+// WPN = 2: 256 (k) x 256 (columns) tile, waves 2 x 2 (Cout a multiple of 256: conv3_x .. conv7);
+// WPN = 1: 128 (k) x 512 (columns), waves 1 x 4 (Cout <= 128: conv2_2, the 100-channel head).
+// 32 pixels per k-slab, three stages, every slab issues the same number of pieces (past the end: out-of-range offsets = zero
+// fill into a stage nobody reads) so the counted vmcnt is a constant; transpose reads of the second 16 pixels and the DMA
+// pieces are pinned between the MFMAs.  The bias gradient (column sums of dy) is dealt over the column tiles of a k range:
+// tile tq sums the slabs kt = tq (mod tiles_q), so no workgroup is the slow one of its round.
+// ---------------------------------------------------------------------------------------
+template <int WPN>
+__global__ void __launch_bounds__(256) conv_wgrad_v8_kernel(const WgradArgs a) {
+    constexpr int PI = 4, QI = 4;
+    constexpr int NPS = WPN, NQS = 4 / WPN;          // 128-channel dy sub-slabs, 128-column x sub-slabs
+    constexpr int NSUB = NPS + NQS;
+    constexpr int PKE = 32;                          // pixels per k-slab
+    constexpr int OPB = PKE * 256;                   // bytes per sub-slab (8 KiB)
+    constexpr int STAGE = NSUB * OPB;
+    constexpr int NST = 3;
+    constexpr int NDMA = 2 * NSUB;                   // pieces per wave and slab (8 | 10)
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave % WPN, wq = wave / WPN;
+    const int ntiles = a.tiles_p * a.tiles_q;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = vb / ntiles, tile = vb - split * ntiles;
+    const int tq = tile / a.tiles_p, tp = tile - tq * a.tiles_p;
+    const int p0 = tp * (128 * NPS), q0 = tq * (128 * NQS);
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
+
+    // DMA lane role: pixel row dr of the 4-pixel piece, logical 16-B chunk dch (source-side swizzle)
+    const int dr = lane >> 4;
+    const int dch = (lane & 15) ^ (dr << 2);
+    const int pch = p0 + dch * 8;
+    // x sub-slab s of this lane: tap offset as a packed (row, column) pair of 16-bit adds, byte offset the tap adds to the pixel's
+    // address; an out-of-range column chunk gets a tap offset that fails the bounds check of every pixel
+    unsigned pkd[NQS];
+    int qd[NQS];
+#pragma unroll
+    for (int s = 0; s < NQS; ++s) {
+        const int j0 = q0 + s * 128 + dch * 8;
+        pkd[s] = 0x80008000u; qd[s] = 0;
+        if (j0 < a.RSC) {
+            const int rs = j0 / a.C;
+            const int qc = j0 - rs * a.C;
+            const int qr = rs / a.S, qs = rs - qr * a.S;
+            const int dh = qr * a.dil - a.pad_t, dw = qs * a.dil - a.pad_l;
+            pkd[s] = ((unsigned)(dh & 0xffff) << 16) | (unsigned)(dw & 0xffff);
+            qd[s] = ((dh * a.W + dw) * a.ldx + qc) * 2;
+        }
+    }
+    const unsigned lim = ((unsigned)(a.H - 1) << 16) | (unsigned)(a.W - 1);
+    const int HoWo = a.Ho * a.Wo;
+    const int iters_total = (a.P + PKE - 1) / PKE;
+    const int it0 = split * a.iters_per_split;
+    int it1 = it0 + a.iters_per_split;
+    if (it1 > iters_total) it1 = iters_total;
+    if (it0 >= it1) return;
+    const int nk = it1 - it0;
+
+    // The two pixels of this lane per slab (pieces wave and wave + 4) WALK: one slab on = 32 pixels = dn images + dho rows + dwo
+    // columns, carried with compares and adds -- no per-slab division or 32-bit multiply (quarter rate, and with one wave per
+    // SIMD every VALU cycle outside an MFMA shadow is lost).  Past the end of dy the buffer range check returns zeros, and what
+    // a slab past this block's pixel range fetches lands in a stage nobody reads, so the pieces need no pixel bound at all.
+    const int l2 = a.ldx * 2;
+    const int dn = PKE / HoWo, r1 = PKE - dn * HoWo, dho = r1 / a.Wo, dwo = r1 - dho * a.Wo;
+    const int DHS = dho * a.stride, DWS = dwo * a.stride, WoS = a.Wo * a.stride, HoS = a.Ho * a.stride;
+    const unsigned DX = (unsigned)((dn * a.H * a.W + DHS * a.W + DWS) * l2);
+    const unsigned CW = (unsigned)((a.stride * a.W - WoS) * l2), CH = (unsigned)((a.H * a.W - HoS * a.W) * l2);
+    const unsigned DY = (unsigned)(PKE * a.lddy * 2);
+    int hi0[2], wi0[2];
+    unsigned xo[2], dyo[2], pk[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = it0 * PKE + (wave + 4 * h) * 4 + dr;
+        const unsigned n = fdiv((unsigned)p, a.div_howo);
+        const unsigned rem = (unsigned)p - n * (unsigned)HoWo;
+        const unsigned ho = fdiv(rem, a.div_wo);
+        const unsigned wo = rem - ho * (unsigned)a.Wo;
+        hi0[h] = (int)ho * a.stride;
+        wi0[h] = (int)wo * a.stride;
+        xo[h] = (unsigned)(((int)n * a.H + hi0[h]) * a.W + wi0[h]) * (unsigned)l2;
+        dyo[h] = (unsigned)((p * a.lddy + pch) * 2);
+        pk[h] = ((unsigned)hi0[h] << 16) | (unsigned)wi0[h];
+    }
+    auto advance = [&](int h) __attribute__((always_inline)) {
+        wi0[h] += DWS; hi0[h] += DHS; xo[h] += DX; dyo[h] += DY;
+        const bool cw = wi0[h] >= WoS;
+        wi0[h] -= cw ? WoS : 0; hi0[h] += cw ? a.stride : 0; xo[h] += cw ? CW : 0u;
+        const bool chh = hi0[h] >= HoS;
+        hi0[h] -= chh ? HoS : 0; xo[h] += chh ? CH : 0u;
+        pk[h] = ((unsigned)hi0[h] << 16) | (unsigned)wi0[h];
+    };
+    typedef unsigned short u16x2_v __attribute__((ext_vector_type(2)));
+    // piece q of the current slab: q < 2 NPS -> dy sub-slab q / 2, else x sub-slab (q - 2 NPS) / 2; pixel half q & 1
+    auto piece = [&](int q, int stage) __attribute__((always_inline)) {
+        const int h = q & 1, sub = q >> 1;
+        const unsigned dst = smem_base + (unsigned)(stage * STAGE + sub * OPB) + (unsigned)(wave + 4 * h) * 1024u;
+        if (sub < NPS) {
+            glds16_buf_nc(rdy, pch + sub * 128 < a.lddy ? dyo[h] + (unsigned)(sub * 256) : 0xFFFFFFF0u, dst);
+        } else {
+            const int s = sub - NPS;
+            const u16x2_v t = __builtin_bit_cast(u16x2_v, pk[h]) + __builtin_bit_cast(u16x2_v, pkd[s]);
+            const u16x2_v m = __builtin_elementwise_min(t, __builtin_bit_cast(u16x2_v, lim));
+            const bool ok = __builtin_bit_cast(unsigned, m) == __builtin_bit_cast(unsigned, t);
+            glds16_buf_nc(rx, ok ? xo[h] + (unsigned)qd[s] : 0xFFFFFFF0u, dst);
+        }
+    };
+
+    // transpose-read lane role (see conv_wgrad_dma_kernel): group g = lane>>4, c = lane&15
+    const int g = lane >> 4, c = lane & 15;
+    const int rr = c >> 2;
+    unsigned fo[PI + QI];                            // 4 dy fragments (k rows), 4 x fragments (columns)
+#pragma unroll
+    for (int i = 0; i < PI + QI; ++i) {
+        const int ch = ((i & 3) * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
+        const int sub = i < PI ? wp : NPS + wq;
+        fo[i] = smem_base + (unsigned)(sub * OPB + (2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
+    }
+
+    f32x16_v acc[PI][QI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bsum[PI] = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) piece(q, 0);
+    advance(0); advance(1);
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) piece(q, 1);
+    int st_c = 0, st_n = 2;
+    int bias_cnt = tq, bias_w = 0;                   // slabs until this tile's next bias turn; the column wave that takes it
+    for (int kt = 0; kt < nk; ++kt) {
+        if (a.dbg & 4) wait_vmcnt<0>(); else wait_vmcnt<NDMA>();
+        block_barrier();
+        unsigned fb[PI + QI];                        // fragment addresses in this stage: the reads below only add immediates
+        const unsigned so = (unsigned)st_c * STAGE;
+#pragma unroll
+        for (int i = 0; i < PI + QI; ++i) fb[i] = fo[i] + so;
+        uint2 fr[2][PI + QI][2];
+        auto rd = [&](int ks, int t) __attribute__((always_inline)) {      // read t of k-step ks: fragments in the order P0 Q0 P1 P2 P3 Q1 Q2 Q3
+            constexpr int ORD[8] = {0, 4, 1, 2, 3, 5, 6, 7};
+            const int f = ORD[t >> 1], half = t & 1;
+            fr[ks][f][half] = lds_tr16(fb[f] + (unsigned)(ks * 4096 + half * 1024));
+        };
+#pragma unroll
+        for (int t = 0; t < 16; ++t) rd(0, t);
+        const bool bias_turn = a.dbias != nullptr && bias_cnt == 0 && wq == bias_w;      // wave-uniform
+        static_for<2>([&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+#pragma unroll
+            for (int j = 0; j < QI; ++j)
+#pragma unroll
+                for (int i = 0; i < PI; ++i) {
+                    const int mi = j * PI + i, slot = ks * 16 + mi;
+                    const uint4 pf = make_uint4(fr[ks][i][0].x, fr[ks][i][0].y, fr[ks][i][1].x, fr[ks][i][1].y);
+                    const uint4 qf = make_uint4(fr[ks][PI + j][0].x, fr[ks][PI + j][0].y, fr[ks][PI + j][1].x, fr[ks][PI + j][1].y);
+                    Mma<bf16_t>::run(pf, qf, acc[i][j]);
+                    if (ks == 0) rd(1, mi);
+                    // the walk to slab kt + 2 in the shadow of the first MFMAs, then its pieces from slot 4 on
+                    if (slot == 1) advance(0);
+                    if (slot == 2) advance(1);
+#pragma unroll
+                    for (int q = 0; q < NDMA; ++q)
+                        if (4 + q * 28 / NDMA == slot && !(a.dbg & 4)) piece(q, st_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if (bias_turn) {
+#pragma unroll
+                for (int i = 0; i < PI; ++i)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        bsum[i] = dot2_bf16_ones(fr[ks][i][half].x, bsum[i]);
+                        bsum[i] = dot2_bf16_ones(fr[ks][i][half].y, bsum[i]);
+                    }
+            }
+        });
+        if (bias_cnt == 0) { bias_cnt = a.tiles_q; bias_w = bias_w + 1 == 4 / WPN ? 0 : bias_w + 1; }
+        --bias_cnt;
+        st_c = st_c == 2 ? 0 : st_c + 1;
+        st_n = st_n == 2 ? 0 : st_n + 1;
+    }
+    wait_vmcnt<0>();
+
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int col = q0 + wq * 128 + j * 32 + l31;
+        if (col >= a.RSC) continue;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = p0 + wp * 128 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                if (k < a.K && !(a.dbg & 16)) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+            }
+        }
+    }
+    if (a.dbias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const float t = bsum[i] + __shfl_xor(bsum[i], 32);       // both pixel halves of the k row
+            const int k = p0 + wp * 128 + i * 32 + l31;
+            if (hi == 0 && k < a.K && t != 0.f) atomicAdd(a.dbias + k, t);
+        }
+    }
+}
+
+// Returns false (nothing launched) when the pixel range per block would be short: every block ends with 64 K float atomics (~40 us
+// measured, independent of the layer), which only >= ~100 slabs of 32 pixels amortise better than the 32 K of the 128 x 256 kernel.
+// Measured at batch 32, same box, v8 | v3: conv3_2 223 | 241 us, conv4_2 220 | 252, conv6 134 | 150 (taken); conv4_1 138 | 133, conv3_1
+// 150 | 138, conv5_x 97 | 79, conv7 73 | 49 (left on v3); the 128 x 512 variant (WPN = 1) lost on conv2_2 (299 | 272) and the heads.
+bool launch_wgrad_v8(WgradArgs& a, hipStream_t st) {
+    const int tiles_p = ceil_div(a.K, 256), tiles_q = ceil_div(a.RSC, 256);
+    const int tiles = tiles_p * tiles_q;
+    const int iters_total = ceil_div(a.P, 32);
+    if (g_num_cu == 0) query_num_cu();
+    int best_s = 1;
+    double best_t = 1e30;
+    const int smax = iters_total < 8 ? 1 : iters_total / 8;
+    for (int s = 1; s <= smax && s <= 1024; ++s) {      // rounds x (slabs x ~0.85 us + prologue and 64 K float atomics per block)
+        const int ips = ceil_div(iters_total, s);
+        const int sp = ceil_div(iters_total, ips);
+        const double rounds = (double)ceil_div(tiles * sp, g_num_cu);
+        const double tt = rounds * (ips * 0.85 + 45.0);
+        if (tt < best_t - 1e-9) { best_t = tt; best_s = sp; }
+    }
+    const int ips = ceil_div(iters_total, best_s);
+    if (ips < 110 && !(a.dbg & (1 << 30))) return false;
+    a.tiles_p = tiles_p; a.tiles_q = tiles_q;
+    a.iters_per_split = ips;
+    const int splits = ceil_div(iters_total, a.iters_per_split);
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
+    a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    hipLaunchKernelGGL(conv_wgrad_v8_kernel<2>, dim3(tiles * splits), dim3(256), 0, st, a);
+    return true;
+}
+
 int launch_wgrad_v7(WgradArgs& a, hipStream_t st) {
     a.tiles_p = ceil_div(a.K, 256);
     a.tiles_q = ceil_div(a.RSC, 256);
@@ -2205,6 +2451,9 @@ int launch_wgrad_v7(WgradArgs& a, hipStream_t st) {
 
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
     if (a.K >= 256 && (a.dbg & 131072)) return launch_wgrad_v7(a, st);       // 256 x 256 tile (dbg bit 17, A/B)
+    // four-wave kernel with 128 x 128 wave tiles: Cout a multiple of 256 (no tile waste) and long pixel ranges per block
+    // (dbg bit 29 = off, bit 30 = also with short ranges: A/B)
+    if (!(a.dbg & (1 << 29)) && a.K % 256 == 0 && a.RSC % 256 == 0 && launch_wgrad_v8(a, st)) return 0;
     a.tiles_p = ceil_div(a.K, 128);
     a.tiles_q = ceil_div(a.RSC, 256);
     const int tiles = a.tiles_p * a.tiles_q;

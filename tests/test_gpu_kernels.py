@@ -99,14 +99,17 @@ V3_EXTRA_CASES = [
     (2, 80, 72, 128, 128, 3, 1, 2),   # ... dilation 2 (dil * W = 144: the early groups end exactly at the first live row)
     (24, 75, 75, 64, 200, 3, 1, 1),   # 128 x 512 tiles of four 128 x 128 wave tiles (>= 2 rounds of 256 workgroups): ragged last tile, channel tail
     (24, 19, 19, 64, 512, 3, 1, 1),   # 128 x 192 tiles (136 workgroups of 256 pixels would leave CUs idle, 184 of 192 pixels fit one round)
+    (6, 20, 17, 256, 512, 3, 1, 1),   # four-wave filter gradient (256 x 256 tiles, fixture wgrad-v8): two k tiles, nine column tiles, ragged last 32-pixel slab
+    (5, 19, 23, 256, 256, 3, 2, 1),   # ... stride 2 with the asymmetric SAME pad (the pixel walk steps input rows / columns by 2)
+    (7, 5, 3, 256, 256, 3, 1, 1),     # ... 15-pixel images: one 32-pixel slab spans three images (walk: dn = 2 images + 2 pixels)
 ]
 
 
-@pytest.fixture(params=[(2, 0), (3, 0), (2, 256 + 65536), (2, 16384 + 65536), (2, 8192 + 65536), (2, 32768 + 8192 + 65536), (2, 8192), (2, 65536), (2, 131072)], ids=["v3-8wave", "v4-persistent", "v3-globaldma", "v3-interleaved", "v3-nosplitk", "v5-4wave", "v6-halo-nosplitk", "v3-nohalo", "wgrad-v7"])
+@pytest.fixture(params=[(2, 0), (3, 0), (2, 256 + 65536), (2, 16384 + 65536), (2, 8192 + 65536), (2, 32768 + 8192 + 65536), (2, 8192), (2, 65536), (2, 131072), (2, 1 << 30)], ids=["v3-8wave", "v4-persistent", "v3-globaldma", "v3-interleaved", "v3-nosplitk", "v5-4wave", "v6-halo-nosplitk", "v3-nohalo", "wgrad-v7", "wgrad-v8"])
 def v3_engine(request):
     """Force the 8-wave (2) / persistent wave-specialised (3) conv kernels wherever they are
     supported (odtk_debug_set key 1); key 2 bit 8 selects 64-bit global addressing for the LDS-DMA, bit 14 the
-    interleaved slab body, bit 13 turns split-K off."""
+    interleaved slab body, bit 13 turns split-K off, bit 30 lets the four-wave filter-gradient kernel (256 x 256 tiles) take short pixel ranges."""
     ops = _ops()
     ops.debug_set(1, request.param[0])
     ops.debug_set(2, request.param[1])

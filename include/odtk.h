@@ -47,8 +47,11 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         buffering, 6 no early/late DMA stagger, 7 "landed early" protocol, 8 64-bit global addressing for the LDS-DMA,
  *         9 no XCD remap (wgrad), 10 s_setprio, 11 no 64->64 / first-layer halo kernels, 12 per-lane tap walk,
  *         13 no split-K, 14 interleaved slab body, 15 4-wave kernel (v5), 16 no raster-run halo kernel (v6), 17 256x256 wgrad tile (v7),
- *         18-25 = n: halo kernel instead of split-K on layers with >= n tiles (0 = split-K policy as is);
- * key 3 = single-kernel NMS (value != 0) */
+ *         18-25 = n: halo kernel instead of split-K on layers with >= n tiles (0 = split-K policy as is), 26 no wide (W <= 159) halo
+ *         variant, 27 no 128x512 halo tiles, 28 no 128x192 halo tiles, 29 no four-wave filter-gradient kernel (v8), 30 v8 also on
+ *         short pixel ranges;
+ * key 3 = single-kernel NMS (value != 0);
+ * key 4 = batch norm: maps of up to `value` rows run statistics + finalize + apply in ONE launch (default 1024, 0 = never) */
 int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to
  * every later call of this thread until the slot changes.  Calls on ONE stream are ordered and share slot 0; a caller that

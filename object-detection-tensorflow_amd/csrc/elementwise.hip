@@ -571,6 +571,175 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     }
 }
 
+// ------------------------------------------------------------------ batch norm of SMALL maps in one launch
+// The extra layers and the heads of the small feature maps (10 x 10 and below at batch 32: <= 3200 rows) spend their time in
+// launch and dependency latency, not in bandwidth: stats -> finalize -> apply are three dependent launches of 2..16
+// workgroups each (5-10 us apiece in the profile, r02i timeline).  Up to 1024 rows (5 x 5 and below at batch 32; measured: at
+// 3200 rows one workgroup per 64 channels streams too slowly and the step LOSES 3 %) ONE launch does all three: a
+// 512-thread workgroup per 8 chunks of channels (64 row lanes x 8 chunk lanes) sums its columns, finalizes them in
+// registers and walks the rows a second time (L2 hits) to apply.  Same formulas as the three-kernel path; the
+// summation order differs (one block instead of row splits), so results agree to f32 round-off, not bit for bit.
+constexpr int SM_ROWS = 64;
+
+template <int NV>
+__device__ __forceinline__ void block_rowlane_reduce64(float (&v)[NV], float* sm /*[64][8][NV]*/, int rl, int cl) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) sm[(rl * 8 + cl) * NV + e] = v[e];
+    __syncthreads();
+    for (int s = SM_ROWS / 2; s > 0; s >>= 1) {
+        if (rl < s) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) sm[(rl * 8 + cl) * NV + e] += sm[((rl + s) * 8 + cl) * NV + e];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = sm[cl * NV + e];
+}
+
+template <typename T, typename TY>
+__global__ void __launch_bounds__(512) bn_fwd_small_kernel(
+    const T* __restrict__ z, int M, int C, int ldz, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    int relu, TY* __restrict__ y, int ldy, int rows_per_img, long long y_img_stride, int vec_ok) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[SM_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    float acc[2 * KC], sh[KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < KC; ++e) sh[e] = 0.f;
+    if (c0 < C) {
+        Chunk<T>::unpack(ld16(z + c0), sh);
+#pragma unroll 8
+        for (int m = rl; m < M; m += SM_ROWS) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                const float d = f[e] - sh[e];
+                acc[e] += d;
+                acc[KC + e] += d * d;
+            }
+        }
+    }
+    block_rowlane_reduce64<2 * KC>(acc, sm, rl, cl);
+    if (c0 >= C) return;
+    float sc[KC], of[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        sc[e] = 0.f; of[e] = 0.f;
+        const int c = c0 + e;
+        if (c >= C) continue;
+        const float d = acc[e] / (float)M;
+        const float mean = sh[e] + d;
+        const float var = fmaxf(acc[KC + e] / (float)M - d * d, 0.f);
+        const float inv = rsqrtf(var + 1e-3f);
+        sc[e] = inv * gamma[c];
+        of[e] = beta[c] - mean * sc[e];
+        if (rl == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = inv;
+            const float unb = var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+            mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
+            mvar[c] = mvar[c] * 0.99f + unb * (1.f - 0.99f);
+        }
+    }
+    const bool full = c0 + KC <= C;
+#pragma unroll 4
+    for (int m = rl; m < M; m += SM_ROWS) {
+        float f[KC];
+        Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            f[e] = f[e] * sc[e] + of[e];
+            if (relu == 1) f[e] = fmaxf(f[e], 0.f);
+            else if (relu == 2) f[e] = f[e] > 0.f ? f[e] : 0.1f * f[e];
+        }
+        TY* yp = y + out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+        if (full && vec_ok) {
+            if (sizeof(TY) == 2) {
+                float f8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f8[e] = f[e % KC];
+                st16(reinterpret_cast<bf16_t*>(yp), Chunk<bf16_t>::pack(f8));   // only reached when KC == 8
+            } else {
+#pragma unroll
+                for (int q = 0; q < KC / 4; ++q)
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yp) + 4 * q) =
+                        make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < KC; ++e)
+                if (c0 + e < C) yp[e] = elem<TY>::store(f[e]);
+        }
+    }
+}
+
+template <typename T, typename TY>
+__global__ void __launch_bounds__(512) bn_bwd_small_kernel(
+    const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
+    int rows_per_img, long long y_img_stride, const float* __restrict__ gamma, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, int relu, int vec_ok, T* __restrict__ dz, float* __restrict__ dgamma,
+    float* __restrict__ dbeta) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[SM_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    float acc[2 * KC], mu[KC], iv[KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        mu[e] = c0 + e < C ? save_mean[c0 + e] : 0.f;
+        iv[e] = c0 + e < C ? save_invstd[c0 + e] : 0.f;
+    }
+    if (c0 < C) {
+#pragma unroll 4
+        for (int m = rl; m < M; m += SM_ROWS) {
+            float f[KC], d[KC];
+            Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+            bn_load_dy<T, TY>(y, dy, out_off(m, rows_per_img, y_img_stride, ldy) + c0, c0, C, relu, vec_ok, d);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                if (c0 + e >= C) continue;
+                acc[e] += d[e];
+                acc[KC + e] += d[e] * ((f[e] - mu[e]) * iv[e]);
+            }
+        }
+    }
+    block_rowlane_reduce64<2 * KC>(acc, sm, rl, cl);
+    if (c0 >= ldz) return;
+    float gs[KC], k1[KC], k2[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        const int c = c0 + e;
+        gs[e] = 0.f; k1[e] = 0.f; k2[e] = 0.f;
+        if (c >= C) continue;
+        gs[e] = gamma[c] * iv[e];
+        k1[e] = acc[e] / (float)M;
+        k2[e] = acc[KC + e] / (float)M;
+        if (rl == 0) { dbeta[c] = acc[e]; dgamma[c] = acc[KC + e]; }
+    }
+#pragma unroll 4
+    for (int m = rl; m < M; m += SM_ROWS) {
+        float f[KC], o[KC], d[KC];
+        Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+        bn_load_dy<T, TY>(y, dy, out_off(m, rows_per_img, y_img_stride, ldy) + c0, c0, C, relu, vec_ok, d);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            o[e] = 0.f;
+            if (c0 + e >= C) continue;
+            const float xh = (f[e] - mu[e]) * iv[e];
+            o[e] = gs[e] * (d[e] - k1[e] - xh * k2[e]);
+        }
+        st16(dz + (size_t)m * ldz + c0, Chunk<T>::pack(o));
+    }
+}
+
 // generic column sum (bias gradient)
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int M, int C, int ld,
@@ -791,6 +960,9 @@ inline RedPlan red_plan(int M, int C, int kc) {
 
 using namespace odtk;
 
+static int g_bn_small_rows = 1024;        // odtk_debug_set key 4
+namespace odtk { void set_bn_small_rows(int rows) { g_bn_small_rows = rows; } }
+
 #define DT_SWITCH(dtype, T, ...)                                         \
     if ((dtype) == ODTK_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
     else if ((dtype) == ODTK_F32) { typedef float T; __VA_ARGS__ }       \
@@ -891,6 +1063,21 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     ODTK_REQUIRE(!(y_dtype == ODTK_BF16 && dtype == ODTK_F32), "bn_fwd: f32 in / bf16 out unsupported");
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
+    const size_t ysz = dtype_size(y_dtype);
+    const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
+                       ((uintptr_t)y % 16) == 0;
+    if (training && M <= g_bn_small_rows) {              // small map: statistics, finalize and apply in one launch
+#define BN_SMALL(T, TY)                                                                                                      \
+    hipLaunchKernelGGL((bn_fwd_small_kernel<T, TY>), dim3(pl.colgroups), dim3(512), 0, st, (const T*)z, M, C, ldz, gamma, beta, \
+                       moving_mean, moving_var, save_mean, save_invstd, relu, (TY*)y, ldy, rows_per_img, y_img_stride, vec_ok)
+        if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) BN_SMALL(bf16_t, bf16_t);
+        else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) BN_SMALL(bf16_t, float);
+        else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) BN_SMALL(float, float);
+        else ODTK_REQUIRE(false, "bn_fwd: bad dtype");
+#undef BN_SMALL
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     float* ws = (float*)workspace;
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
     if (training) {
@@ -900,9 +1087,6 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M,
                                            C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
                                            pl.nsplit, fin);)
-    const size_t ysz = dtype_size(y_dtype);
-    const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
-                       ((uintptr_t)y % 16) == 0;
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
     const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
@@ -940,6 +1124,18 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
                        ((uintptr_t)dy) % 16 == 0 && (!relu || ((uintptr_t)y) % 16 == 0);
+    if (M <= g_bn_small_rows) {                          // small map: sums, finalize and apply in one launch
+#define BN_BWD_SMALL(T, TY)                                                                                                   \
+    hipLaunchKernelGGL((bn_bwd_small_kernel<T, TY>), dim3(g2.x), dim3(512), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, \
+                       C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, dgamma, dbeta)
+        if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_BWD_SMALL(bf16_t, bf16_t); }
+        else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_BWD_SMALL(bf16_t, float); }
+        else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD_SMALL(float, float); }
+        else ODTK_REQUIRE(false, "bn_bwd: bad dtype");
+#undef BN_BWD_SMALL
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
 #define BN_BWD(T, TY)                                                                                             \
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu,   \

@@ -330,8 +330,19 @@ def test_maxpool2x2_recorded_argmax_equals_gather_path(geom, dt, dev):
 @pytest.mark.parametrize("shape", [(2 * 19 * 19, 1024, True), (2 * 38 * 38, 100, False), (3 * 5 * 5, 150, False),
                                    (2 * 3 * 3, 256, True),
                                    (6 * 38 * 38, 100, False), (14 * 19 * 19, 256, True)])   # M > 4096: split-row path
-def test_batchnorm(shape, dt, ydt, dev):
+@pytest.mark.parametrize("one_launch", [True, False], ids=["small-fused", "three-kernel"])
+def test_batchnorm(shape, dt, ydt, one_launch, dev):
+    """Maps of <= 1024 rows take the single-launch kernels (statistics + finalize + apply in one workgroup per 64 channels; here
+    the limit is raised to 4096 rows to cover more shapes); odtk_debug_set(4, 0) sends every map down the three-kernel path."""
     ops = _ops()
+    ops.debug_set(4, 4096 if one_launch else 0)
+    try:
+        _batchnorm_case(ops, shape, dt, ydt, dev)
+    finally:
+        ops.debug_set(4, 1024)
+
+
+def _batchnorm_case(ops, shape, dt, ydt, dev):
     M, C, relu = shape
     dtype = torch.float32 if dt == "f32" else torch.bfloat16
     ydtype = torch.float32 if ydt == "f32" else torch.bfloat16
@@ -351,8 +362,10 @@ def test_batchnorm(shape, dt, ydt, dev):
     yd = torch.zeros(M, C, dtype=ydtype, device=dev)
     ops.bn_fwd(zd, M, C, ldz, gamma.to(dev), beta.to(dev), mm, mv, sm, si, True, relu, yd, C, rpi, rpi * C, ws)
     zr = z.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
     mean = zr.mean(0); var = ((zr - mean) ** 2).mean(0)
-    yr = (zr - mean) * torch.rsqrt(var + 1e-3) * gamma + beta
+    yr = (zr - mean) * torch.rsqrt(var + 1e-3) * gr + br
     if relu:
         yr = F.relu(yr)
     torch.cuda.synchronize()
@@ -374,6 +387,10 @@ def test_batchnorm(shape, dt, ydt, dev):
     assert float((dzd[:, :C].float().cpu() - zr.grad).abs().max()) <= tolb * sc
     if ldz > C:
         assert float(dzd[:, C:].float().abs().max()) == 0.0
+    # gamma / beta gradients (the reference masks with ITS ReLU boundary: rows within rounding of 0 may differ in bf16)
+    tolg = 2e-3 if ydt == "f32" else 3e-2
+    assert float((db.cpu() - br.grad).abs().max()) <= tolg * (float(br.grad.abs().max()) + 1e-6)
+    assert float((dg.cpu() - gr.grad).abs().max()) <= tolg * (float(gr.grad.abs().max()) + 1e-6)
     # inference mode
     yd2 = torch.zeros(M, C, dtype=ydtype, device=dev)
     ops.bn_fwd(zd, M, C, ldz, gamma.to(dev), beta.to(dev), mm, mv, None, None, False, relu, yd2, C, rpi, rpi * C, ws)

@@ -216,7 +216,7 @@ def main():
     ap.add_argument('--sync-bn', action='store_true', help='N > 1: batch-norm statistics over all replicas (SURVEY 8e option B; eager launches)')
     ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
     ap.add_argument('--kernel-dbg', type=int, default=0, help='A/B: odtk_debug_set(2, bits) dispatch switches of csrc/conv_v3.hip (bits >= 1<<26 only)')
-    ap.add_argument('--debug-set', default='', help="A/B: comma list of KEY:VALUE for odtk_debug_set (keys that leave results intact: 3, 4)")
+    ap.add_argument('--debug-set', default='', help="A/B: comma list of KEY:VALUE for odtk_debug_set (keys that leave results intact: 3, 4, 5)")
     ap.add_argument('--bucket-mb', type=int, default=25, help='N > 1: gradient all-reduce bucket size')
     ap.add_argument('--launch-check', action='store_true',
                     help='exercise ONLY the launcher / rendezvous / timing / one-JSON-line skeleton with a dummy all-reduce step '
@@ -251,7 +251,7 @@ def main():
         odtk._lib.load().odtk_debug_set(2, args.kernel_dbg)
     for kv in filter(None, args.debug_set.split(',')):
         k, v = kv.split(':')
-        assert int(k) in (3, 4), 'only the dispatch switches leave results intact'
+        assert int(k) in (3, 4, 5), 'only the dispatch switches leave results intact'
         odtk._lib.load().odtk_debug_set(int(k), int(v))
     config = {
         'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,

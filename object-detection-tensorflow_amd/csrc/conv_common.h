@@ -159,6 +159,12 @@ struct WgradArgs {
     FastDiv div_howo, div_wo;
     int dbg;         // perf experiments only (odtk_debug_set key 2): bit0/1 zero-page DMA sources, bit2 no DMA after slab 0, bit4 no atomics
     unsigned x_bytes, dy_bytes;   // extents for the buffer-addressed DMA (8-wave kernel)
+    // deterministic split-reduce (opt-in, odtk_debug_set key 5; 8-wave / four-wave kernels with > 1 pixel split): every block STORES its partial tile to
+    // ws[split][K][RSC] (and its bias sums to bws[slot][K]); wgrad_reduce_kernel adds the splits in fixed order into dw / dbias.
+    // null = float atomics straight into dw (the default; one split always)
+    float* ws;
+    float* bws;
+    int nsplit, nbslot;
 };
 
 // 16 bytes of zeros that padded / out-of-range LDS-DMA lanes fetch instead of branching
@@ -258,6 +264,7 @@ bool wgrad_c64_supported(const WgradArgs& a, int dtype);                      //
 int launch_wgrad_c64(WgradArgs& a, hipStream_t st);
 bool wgrad_v3_supported(const WgradArgs& a, int dtype);
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
+void set_wgrad_deterministic(bool on);  // odtk_debug_set key 5: deterministic split-reduce instead of float atomics
 int set_scratch_slot(int slot);          // split-K partial buffers are per (device, slot); 0 on success
 
 }  // namespace cv

@@ -1132,6 +1132,35 @@ __global__ void __launch_bounds__(768) conv_gather_v4_kernel(const GatherArgs a,
 }
 
 
+// Partial filter-gradient tile of one wave -> ws[split] in full 16-byte, row-contiguous stores: the MFMA accumulator layout has a
+// lane own 4 consecutive K ROWS of one column, so storing it directly is one dword per lane and instruction (256 per lane for a
+// 128 x 128 wave tile -- measured 3.5 % of the step slower than float atomics); 32 rows at a time go through a wave-private LDS
+// patch [32][QI * 32] instead and leave as QI * 8 float4 per lane.  `lds` is free for the wave: the caller has passed a block
+// barrier after the last slab and the trailing LDS-DMA has landed.
+template <int PI, int QI>
+__device__ __forceinline__ void store_partial_tile(const f32x16_v (&acc)[PI][QI], float* lds, float* __restrict__ dst /* ws[split] */,
+                                                   int k0, int col0, int K, int RSC, int lane) {
+    constexpr int W = QI * 32;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lds[(8 * (e >> 2) + 4 * hi + (e & 3)) * W + j * 32 + l31] = acc[i][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: LDS executes in order, this pins the compiler
+#pragma unroll
+        for (int t = 0; t < W / 8; ++t) {
+            const int idx = t * 64 + lane;
+            const int row = idx / (W / 4), c4 = idx % (W / 4);
+            const float4 v = *reinterpret_cast<const float4*>(lds + row * W + c4 * 4);
+            const int k = k0 + i * 32 + row, col = col0 + c4 * 4;
+            if (k < K && col < RSC) *reinterpret_cast<float4*>(dst + (size_t)k * RSC + col) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // wgrad, 8-wave / 3-stage generation: dW[k][(r,s,c)] += sum_pixels dy[p][k] * x[p(r,s)][c]
 // Same operand handling as conv_wgrad_dma_kernel (conv.hip): both slabs stay [pixel][channel],
@@ -1286,16 +1315,22 @@ __global__ void __launch_bounds__(512) conv_wgrad_v3_kernel(const WgradArgs a) {
     }
 
     const int l31 = lane & 31, hi = lane >> 5;
+    if (a.ws) {
+        __syncthreads();                                   // every wave is past its last fragment read
+        store_partial_tile<PI, QI>(acc, reinterpret_cast<float*>(smem) + wave * (32 * QI * 32), a.ws + (size_t)split * a.K * a.RSC,
+                                   p0 + wp * 64, q0 + wq * 64, a.K, a.RSC, lane);
+    } else {
 #pragma unroll
-    for (int j = 0; j < QI; ++j) {
-        const int col = q0 + wq * 64 + j * 32 + l31;
-        if (col >= a.RSC) continue;
+        for (int j = 0; j < QI; ++j) {
+            const int col = q0 + wq * 64 + j * 32 + l31;
+            if (col >= a.RSC) continue;
 #pragma unroll
-        for (int i = 0; i < PI; ++i) {
+            for (int i = 0; i < PI; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = p0 + wp * 64 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                for (int e = 0; e < 16; ++e) {
+                    const int k = p0 + wp * 64 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                    if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                }
             }
         }
     }
@@ -1304,9 +1339,48 @@ __global__ void __launch_bounds__(512) conv_wgrad_v3_kernel(const WgradArgs a) {
         for (int i = 0; i < PI; ++i) {
             const float t = bsum[i] + __shfl_xor(bsum[i], 32);       // both k halves
             const int k = p0 + wp * 64 + i * 32 + l31;
-            if (hi == 0 && k < a.K) atomicAdd(a.dbias + k, t);
+            if (hi == 0 && k < a.K) {
+                if (a.bws) a.bws[(size_t)split * a.K + k] = t;       // one bias slot per pixel split
+                else atomicAdd(a.dbias + k, t);
+            }
         }
     }
+}
+
+// Sum of the per-split partial filter gradients in split order (deterministic), added into dw; the last blocks do the same
+// for the bias slots.  n4 = K * RSC / 4 (RSC is a multiple of 8).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, long long n4, float* __restrict__ dw,
+                                                           const float* __restrict__ bws, int nbslot, int K, float* __restrict__ dbias,
+                                                           int wblocks) {
+    if ((int)blockIdx.x >= wblocks) {
+        const int k = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+        if (k >= K) return;
+        float t = 0.f;
+        for (int s = 0; s < nbslot; ++s) t += bws[(size_t)s * K + k];
+        dbias[k] += t;
+        return;
+    }
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+        const float4 v0 = w4[(long long)s * n4 + i], v1 = w4[(long long)(s + 1) * n4 + i];
+        const float4 v2 = w4[(long long)(s + 2) * n4 + i], v3 = w4[(long long)(s + 3) * n4 + i];
+        t.x += v0.x; t.y += v0.y; t.z += v0.z; t.w += v0.w;
+        t.x += v1.x; t.y += v1.y; t.z += v1.z; t.w += v1.w;
+        t.x += v2.x; t.y += v2.y; t.z += v2.z; t.w += v2.w;
+        t.x += v3.x; t.y += v3.y; t.z += v3.z; t.w += v3.w;
+    }
+    for (; s < nsplit; ++s) {
+        const float4 v = w4[(long long)s * n4 + i];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float4* d4 = reinterpret_cast<float4*>(dw);
+    float4 o = d4[i];
+    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+    d4[i] = o;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2372,16 +2446,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_v8_kernel(const WgradArgs a) {
     wait_vmcnt<0>();
 
     const int l31 = lane & 31, hi = lane >> 5;
+    if (a.ws) {
+        block_barrier();                                   // every wave is past its last fragment read
+        if (!(a.dbg & 16))
+            store_partial_tile<PI, QI>(acc, reinterpret_cast<float*>(smem) + wave * (32 * QI * 32), a.ws + (size_t)split * a.K * a.RSC,
+                                       p0 + wp * 128, q0 + wq * 128, a.K, a.RSC, lane);
+    } else {
 #pragma unroll
-    for (int j = 0; j < QI; ++j) {
-        const int col = q0 + wq * 128 + j * 32 + l31;
-        if (col >= a.RSC) continue;
+        for (int j = 0; j < QI; ++j) {
+            const int col = q0 + wq * 128 + j * 32 + l31;
+            if (col >= a.RSC) continue;
 #pragma unroll
-        for (int i = 0; i < PI; ++i) {
+            for (int i = 0; i < PI; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = p0 + wp * 128 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                if (k < a.K && !(a.dbg & 16)) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                for (int e = 0; e < 16; ++e) {
+                    const int k = p0 + wp * 128 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                    if (k < a.K && !(a.dbg & 16)) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                }
             }
         }
     }
@@ -2390,9 +2471,39 @@ __global__ void __launch_bounds__(256) conv_wgrad_v8_kernel(const WgradArgs a) {
         for (int i = 0; i < PI; ++i) {
             const float t = bsum[i] + __shfl_xor(bsum[i], 32);       // both pixel halves of the k row
             const int k = p0 + wp * 128 + i * 32 + l31;
-            if (hi == 0 && k < a.K && t != 0.f) atomicAdd(a.dbias + k, t);
+            if (hi == 0 && k < a.K) {
+                // one bias slot per (pixel split, column tile, column wave): every wave writes its sum, zero if it had no turn
+                if (a.bws) a.bws[((size_t)(split * a.tiles_q + tq) * (4 / WPN) + wq) * a.K + k] = t;
+                else if (t != 0.f) atomicAdd(a.dbias + k, t);
+            }
         }
     }
+}
+
+// Deterministic split-reduce of the filter gradient, OPT-IN (odtk_debug_set key 5 = 1; config key 'deterministic_wgrad' of the
+// model classes): with more than one pixel split the blocks store their partial tiles (full 16-byte rows through a wave-private
+// LDS patch) to the per-(device, slot) scratch and wgrad_reduce_kernel adds them in split order -- bit-identical from run to
+// run.  The default stays float atomics into dw: measured on the SSD300 step at batch 32, same box, the split-reduce costs
+// 2.5-2.7 % (3 210 | 3 186 against 3 292 | 3 284 images/s): it moves splits x |dw| bytes twice (~700 MB per step) where the
+// atomics, ~40 us per 256 x 256-tile launch as they are, move them once.
+static bool g_wgrad_deterministic = false;
+void set_wgrad_deterministic(bool on) { g_wgrad_deterministic = on; }
+static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots) {
+    a.ws = nullptr; a.bws = nullptr; a.nsplit = splits; a.nbslot = bias_slots;
+    if (splits < 2 || !g_wgrad_deterministic) return 0;
+    float* base = nullptr;
+    const size_t wbytes = (size_t)splits * a.K * a.RSC * sizeof(float);
+    if (int e = conv_scratch(wbytes + (size_t)bias_slots * a.K * sizeof(float), &base)) return e;
+    a.ws = base;
+    a.bws = bias_slots ? base + (size_t)splits * a.K * a.RSC : nullptr;
+    return 0;
+}
+static void wgrad_split_reduce(const WgradArgs& a, hipStream_t st) {
+    if (!a.ws) return;
+    const long long n4 = (long long)a.K * a.RSC / 4;
+    const int wblocks = (int)((n4 + 255) / 256), bblocks = a.bws ? ceil_div(a.K, 256) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, a.ws, a.nsplit, n4, a.dw, a.bws, a.nbslot, a.K,
+                       a.dbias, wblocks);
 }
 
 // Returns false (nothing launched) when the pixel range per block would be short: every block ends with 64 K float atomics (~40 us
@@ -2421,7 +2532,9 @@ bool launch_wgrad_v8(WgradArgs& a, hipStream_t st) {
     const int splits = ceil_div(iters_total, a.iters_per_split);
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    if (wgrad_split_scratch(a, splits, a.dbias ? splits * tiles_q * 2 : 0)) return false;
     hipLaunchKernelGGL(conv_wgrad_v8_kernel<2>, dim3(tiles * splits), dim3(256), 0, st, a);
+    wgrad_split_reduce(a, st);
     return true;
 }
 
@@ -2476,7 +2589,9 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
     const int splits = ceil_div(iters_total, a.iters_per_split);
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    if (int e = wgrad_split_scratch(a, splits, a.dbias ? splits : 0)) return e;
     hipLaunchKernelGGL(conv_wgrad_v3_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
+    wgrad_split_reduce(a, st);
     return 0;
 }
 

@@ -208,6 +208,10 @@ class SSD300:
         # on the dgrad chain needs its result before the optimizer).  Measured neutral on MI355X (both chains are
         # full-chip kernels with one workgroup per CU), so it is off by default; config key 'wgrad_stream'.
         on_gpu = self.dev.type == 'cuda'      # (a 'cpu' device only gets past ops._p with the mocked library of tests/mock_ops.py: host-logic tests)
+        # config key 'deterministic_wgrad': filter gradients by partial tiles + a fixed-order reduction instead of float atomics
+        # (bit-identical from run to run, 2.5 % slower; a process-wide switch of the library: include/odtk.h, odtk_debug_set key 5)
+        if on_gpu and 'deterministic_wgrad' in config:
+            ops.debug_set(5, 1 if config['deterministic_wgrad'] else 0)
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (on_gpu and config.get('wgrad_stream', False)) else None
         self._side = torch.cuda.Stream(device=self.dev) if on_gpu else None          # box matching under the forward pass
         # The six heads run on a second stream BESIDE the extra-layer chain (forward and backward): conv8_1 .. conv11_2 and
@@ -612,8 +616,12 @@ class SSD300:
             ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
             return
         side.wait_stream(torch.cuda.current_stream())                 # dy(L) is complete at this point of the main stream
-        with torch.cuda.stream(side):
-            ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
+        ops.scratch_slot(2)                                           # the split partials of this launch: not the main stream's scratch
+        try:
+            with torch.cuda.stream(side):
+                ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
+        finally:
+            ops.scratch_slot(0)
 
     def _backward(self):
         for name in self._backward_iter():

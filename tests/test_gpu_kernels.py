@@ -659,3 +659,49 @@ def test_decode_and_detect_vs_oracle(dev):
     assert cc == c_ref.tolist()
     assert float((sc - s_ref).abs().max()) < 1e-5
     assert float((bb - b_ref).abs().max()) < 1e-3
+
+
+def test_wgrad_split_reduce_is_deterministic_and_matches_the_atomics(dev):
+    """Filter gradients with > 1 pixel split under odtk_debug_set(5, 1): the blocks store partial tiles and wgrad_reduce_kernel
+    adds them in split order (the default path uses float atomics: run-to-run differences in the last bits).  Two runs are
+    bit-identical; the atomic path agrees to f32 round-off; dw is ACCUMULATED into (FCOS shares its head filters over 5 levels)."""
+    ops = _ops()
+    for (N, H, W, C, K, k, s, dil), v8 in [((6, 38, 38, 128, 256, 3, 1, 1), False), ((6, 20, 17, 256, 512, 3, 1, 1), True),
+                                             ((8, 19, 19, 64, 100, 3, 1, 1), False)]:
+        Kp = ops.pad_to(K, 8)
+        desc = ops.conv_desc(N, H, W, C, C, K, Kp, k, s, dil, ops.BF16, ops.BF16)
+        M = N * desc.Ho * desc.Wo
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(N * H * W, C, generator=g).to(torch.bfloat16).to(dev)
+        dy = torch.zeros(M, Kp, dtype=torch.bfloat16, device=dev)
+        dy[:, :K] = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+        outs = []
+        for mode in (1, 1, 0):
+            ops.debug_set(5, mode)
+            ops.debug_set(2, (1 << 30) if v8 else 0)
+            try:
+                dw = torch.full((K, k, k, C), 0.5, device=dev)
+                db = torch.full((K,), -2.0, device=dev)
+                ops.conv2d_wgrad(desc, x, dy, Kp, dw, db)
+                torch.cuda.synchronize()
+            finally:
+                ops.debug_set(5, 0)
+                ops.debug_set(2, 0)
+            outs.append((dw.clone(), db.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        sc = float((outs[2][0] - 0.5).abs().max())
+        assert float((outs[0][0] - outs[2][0]).abs().max()) <= 2e-5 * sc + 1e-6
+        assert float((outs[0][1] - outs[2][1]).abs().max()) <= 2e-5 * float((outs[2][1] + 2.0).abs().max()) + 1e-6
+        # accumulate semantics: the 0.5 / -2 that were in the buffers are still there
+        xr = x.float().view(N, H, W, C).permute(0, 3, 1, 2)
+        wr = torch.zeros(K, C, k, k, device=dev, requires_grad=True)
+        pt, pl = desc.pad_t, desc.pad_l
+        Ho, Wo = desc.Ho, desc.Wo
+        pb = max((Ho - 1) * s + (k - 1) * dil + 1 - H - pt, 0)
+        pr = max((Wo - 1) * s + (k - 1) * dil + 1 - W - pl, 0)
+        yr = F.conv2d(F.pad(xr, (pl, pr, pt, pb)), wr, stride=s, dilation=dil)
+        yr.backward(dy[:, :K].float().view(N, Ho, Wo, K).permute(0, 3, 1, 2))
+        ref = wr.grad.permute(0, 2, 3, 1) + 0.5
+        assert float((outs[0][0] - ref).abs().max()) <= 2e-3 * float(wr.grad.abs().max())
+        refb = dy[:, :K].float().sum(0) - 2.0
+        assert float((outs[0][1] - refb).abs().max()) <= 2e-3 * float(refb.abs().max())

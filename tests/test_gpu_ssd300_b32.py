@@ -403,3 +403,36 @@ def test_bf16_engine_every_layer_in_situ_at_batch32(pair):
                 add_g(prev, dx * (xin > 0))                    # ReLU mask of the producer rides on the dgrad (pool outputs: same mask)
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:8]
     print('in-situ check of', len(worst), 'buffers at batch 32; largest relative errors:', [(k, round(v, 5)) for k, v in top])
+
+
+def test_deterministic_filter_gradients_at_batch32(dev):
+    """config key 'deterministic_wgrad' (odtk_debug_set key 5): the filter gradients of the layers on the 8-wave / four-wave
+    kernels (conv2_x .. conv11_2 and the heads: split over pixels, reduced in fixed order) are bit-identical from run to run; with
+    the default float atomics the same two runs differ in the last bits of at least one of them."""
+    import odtk
+    p = R.init_params(5)
+    imgs, gt = R.synthetic_batch(B, 77)
+    names = ['conv2_2.w', 'conv3_1.w', 'conv3_3.w', 'conv4_2.w', 'conv5_3.w', 'conv6.w', 'conv7.w', 'conv8_2.w', 'pred1.w', 'pred2.w', 'conv3_3.b', 'conv6.b']
+    runs = {}
+    try:
+        for det in (True, False):
+            got = []
+            for rep in range(2):
+                m = _model('bf16', use_graph=False, deterministic_wgrad=det)
+                m.load_oracle_params(p)
+                m.set_batch(imgs, gt)
+                m._step_front()
+                m._backward()
+                torch.cuda.synchronize()
+                got.append({k: m.param(k, m.G).clone() for k in names if k in m.pinfo})
+                del m
+            runs[det] = got
+    finally:
+        odtk.ops.debug_set(5, 0)
+    for k in runs[True][0]:
+        assert torch.equal(runs[True][0][k], runs[True][1][k]), k
+    assert any(not torch.equal(runs[False][0][k], runs[False][1][k]) for k in runs[False][0])
+    # and the two reductions agree to f32 round-off of sums of ~1e5 terms
+    for k in runs[True][0]:
+        a, b = runs[True][0][k], runs[False][0][k]
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7, k

@@ -771,12 +771,14 @@ def _resize_nearest_neighbor(images, size, align_corners=False):
 
 
 def _resize_bilinear(images, size, align_corners=False):
-    """NHWC, TF-1.x grid (src = dst * in / out, no half-pixel centres); differentiable"""
-    assert not align_corners
+    """NHWC, TF-1.x grid (no half-pixel centres): src = dst * in / out, or dst * (in - 1) / (out - 1) with align_corners (and out > 1)
+    -- CalculateResizeScale of tensorflow/core/kernels/image_resizer_state.h; taps floor(src) and min(floor(src) + 1, in - 1); differentiable"""
     n, h, w, c = images.shape
     oh, ow = int(size[0]), int(size[1])
-    fy = torch.arange(oh, dtype=torch.float32) * (h / oh)
-    fx = torch.arange(ow, dtype=torch.float32) * (w / ow)
+    sy = (h - 1) / (oh - 1) if (align_corners and oh > 1) else h / oh
+    sx = (w - 1) / (ow - 1) if (align_corners and ow > 1) else w / ow
+    fy = torch.arange(oh, dtype=torch.float32) * torch.tensor(sy, dtype=torch.float32)
+    fx = torch.arange(ow, dtype=torch.float32) * torch.tensor(sx, dtype=torch.float32)
     y0, x0 = torch.floor(fy).long(), torch.floor(fx).long()
     y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
     ly, lx = (fy - y0.float()).view(1, oh, 1, 1), (fx - x0.float()).view(1, 1, ow, 1)

@@ -31,7 +31,7 @@ EXTRA = [e[0] for e in R.EXTRA_LAYERS]
 def vgg_tensors(p):
     t = {}
     for l in R.VGG_LAYERS:
-        if isinstance(l, tuple):
+        if isinstance(l, tuple) and l[0] + '.w' in p:          # (PFPNetR stops at conv4_3)
             n = l[0]
             key = f'vgg_16/{n.split("_")[0]}/{n}'
             t[key + '/weights'] = p[n + '.w'].permute(1, 2, 3, 0).contiguous().numpy()     # KRSC -> HWIO

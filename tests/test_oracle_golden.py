@@ -521,3 +521,40 @@ def test_refinedet_two_training_steps_match_reference_class():
     for ours, tfname in names.items():
         shp = list(p[ours].permute(1, 2, 3, 0).shape) if ours.endswith('.w') else list(p[ours].shape)
         assert want[tfname]['shape'] == shp, (ours, tfname)
+
+
+def test_pfpnet_two_training_steps_match_reference_class():
+    """oracle/pfpnet_net_ref (VGG trunk to conv4_3, align_corners bilinear resizes, the 85-channel up / down pyramid branches, the four 767-channel
+    concatenations, ARM / TCB / ODM, Momentum) against two steps of the reference's own PFPNetR class run through its session on the shim
+    (tests/golden/pfpnet_train.npz); variable names / shapes of the graph"""
+    import json
+    from oracle import pfpnet_net_ref as PR
+    from oracle import refinedet_ref as FR
+    g = np.load(os.path.join(GOLD, 'pfpnet_train.npz'))
+    specs = PR.layer_specs()
+    assert len(specs) == 91 == len(g['names']) and len(g['bn_names']) == 81
+    p = PR.init_params(71)
+    mom = {k: torch.zeros_like(p[k]) for k in PR.trainable_names(p)}
+    losses, after_first = [], None
+    for s in (900, 901):
+        gen = torch.Generator().manual_seed(s)
+        imgs = (torch.rand(2, 320, 320, 3, generator=gen) * 255).round()
+        gt = FR.synthetic_gt(2, 320, s + 10, pad=8, max_obj=4)
+        total, _, _ = PR.train_step(p, mom, imgs, gt, 0.001)
+        losses.append(total)
+        if after_first is None:
+            after_first = {k: v.detach().clone() for k, v in p.items()}
+    assert abs(losses[0] - g['losses'][0]) < 1e-5 * g['losses'][0] and abs(losses[1] - g['losses'][1]) < 1e-3 * g['losses'][1], (losses, g['losses'])
+    for key in g.files:
+        if key in ('losses', 'names', 'bn_names'):
+            continue
+        k = key.replace('__', '.')
+        got = after_first[k].reshape(-1)
+        got = got[::max(1, got.numel() // 1024)].numpy()
+        assert np.linalg.norm(got - g[key]) / (np.linalg.norm(g[key]) + 1e-9) < 1e-4, k
+    names = json.load(open(os.path.join(GOLD, 'pfpnet_names.json')))
+    want = json.load(open(os.path.join(GOLD, 'pfpnet_variables.json')))
+    assert set(names.values()) | {'global_step'} == set(want) and set(names) == set(p)
+    for ours, tfname in names.items():
+        shp = list(p[ours].permute(1, 2, 3, 0).shape) if ours.endswith('.w') else list(p[ours].shape)
+        assert want[tfname]['shape'] == shp, (ours, tfname)

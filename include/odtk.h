@@ -217,6 +217,18 @@ int odtk_resize_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, in
                              int accumulate, void* stream);
 int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
                              int accumulate, void* stream);
+/* The same with TensorFlow's `align_corners` switch (src = dst * (in - 1) / (out - 1)) and any scaling, down as well as up: PFPNetR resizes
+ * conv4_3 to 1/2, 1/4, 1/8 with align_corners=True (PFPNetR.py:320-322).  relu_src (NULL or the forward input, rows as dx): the input is a
+ * bias + ReLU activation whose gradient buffer holds d(pre-activation) -- the gradient is zeroed where the activation is <= 0. */
+int odtk_resize_bilinear2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                              int align_corners, int accumulate, void* stream);
+int odtk_resize_bilinear2_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                              int align_corners, int accumulate, const void* relu_src, void* stream);
+/* tf.concat over channels (and its gradient) for pieces that do not start on 16-byte channel boundaries -- PFPNetR's 512 + 85 + 85 + 85
+ * features (PFPNetR.py:366-396): dst[m][dst_off + c] (+)= src[m][src_off + c] for c < C; pitches and offsets in ELEMENTS, any alignment;
+ * relu_src (NULL or a tensor with the rows of dst) zeroes the copy where relu_src[m][dst_off + c] <= 0. */
+int odtk_copy_channels(const void* src, int lds, int src_off, void* dst, int ldd, int dst_off, long long M, int C, int dtype,
+                       int accumulate, const void* relu_src, void* stream);
 
 /* tf.contrib.layers.group_norm(groups, epsilon 1e-6) (+ ReLU when relu != 0) on NHWC rows [N*HW][ld]: the normalisation of the
  * reference's FCOS (FCOS.py:438-446).  Statistics per sample and group over HW x (C / groups) elements; save_mean_rstd [N][groups][2]

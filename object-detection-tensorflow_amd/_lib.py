@@ -72,6 +72,9 @@ SIGNATURES = {
     "odtk_bn_bwd_given": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _vp, _vp, _vp, _i, _vp, _ll, _vp, _vp, _vp]),
     "odtk_resize_bilinear_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "odtk_resize_bilinear_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "odtk_resize_bilinear2_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "odtk_resize_bilinear2_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "odtk_copy_channels": (_i, [_vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _i, _vp, _vp]),
     "odtk_rows_to_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _ll, _ll, _i, _vp]),
     "odtk_rows_from_f32": (_i, [_vp, _i, _i, _ll, _vp, _i, _i, _ll, _i, _vp]),
     "odtk_gn_workspace_bytes": (_ll, [_i, _i]),

@@ -1522,10 +1522,9 @@ namespace {
 
 template <typename T>
 __global__ void __launch_bounds__(256) resize_bilinear_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int H,
-                                                                  int W, int Ho, int Wo, int C, int accumulate) {
+                                                                  int W, int Ho, int Wo, int C, int accumulate, const float sy, const float sx) {
     constexpr int KC = Chunk<T>::N;
     const int cpr = C / KC;
-    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
     const long long total = (long long)N * Ho * Wo * cpr, step = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const long long row = i / cpr;
@@ -1567,10 +1566,10 @@ __device__ __forceinline__ float bilinear_tap_weight(int out, int in, float scal
 
 template <typename T>
 __global__ void __launch_bounds__(256) resize_bilinear_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int N, int H,
-                                                                  int W, int Ho, int Wo, int C, int accumulate) {
+                                                                  int W, int Ho, int Wo, int C, int accumulate, const float sy, const float sx,
+                                                                  const T* __restrict__ relu_src) {
     constexpr int KC = Chunk<T>::N;
     const int cpr = C / KC;
-    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
     const long long total = (long long)N * H * W * cpr, step = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const long long row = i / cpr;
@@ -1579,12 +1578,13 @@ __global__ void __launch_bounds__(256) resize_bilinear_bwd_kernel(const T* __res
         const long long r2 = row / W;
         const int yi = (int)(r2 % H), n = (int)(r2 / H);
         // outputs whose taps can include (yi, xi): floor(out * s) in {yi - 1, yi}  <=>  out in ((yi - 1) / s, (yi + 1) / s)
-        const int ya = max((int)floorf((float)(yi - 1) / sy), 0), yb = min((int)ceilf((float)(yi + 1) / sy), Ho - 1);
-        const int xa = max((int)floorf((float)(xi - 1) / sx), 0), xb = min((int)ceilf((float)(xi + 1) / sx), Wo - 1);
-        float s[KC];
+        // (one more candidate on either side: the weights below re-derive the forward taps, a wider range only costs a test)
+        const int ya = max((int)floorf((float)(yi - 1) / sy) - 1, 0), yb = min((int)ceilf((float)(yi + 1) / sy) + 1, Ho - 1);
+        const int xa = max((int)floorf((float)(xi - 1) / sx) - 1, 0), xb = min((int)ceilf((float)(xi + 1) / sx) + 1, Wo - 1);
+        float s[KC], acc0[KC];
 #pragma unroll
-        for (int e = 0; e < KC; ++e) s[e] = 0.f;
-        if (accumulate) Chunk<T>::unpack(ld16(dx + row * lddx + c), s);
+        for (int e = 0; e < KC; ++e) { s[e] = 0.f; acc0[e] = 0.f; }
+        if (accumulate) Chunk<T>::unpack(ld16(dx + row * lddx + c), acc0);
         for (int yo = ya; yo <= yb; ++yo) {
             const float wy = bilinear_tap_weight(yo, yi, sy, H);
             if (wy == 0.f) continue;
@@ -1597,31 +1597,83 @@ __global__ void __launch_bounds__(256) resize_bilinear_bwd_kernel(const T* __res
                 for (int e = 0; e < KC; ++e) s[e] += w * f[e];
             }
         }
+        if (relu_src) {                                    // the input is a bias + ReLU activation whose gradient buffer holds d(pre-activation)
+            float r[KC];
+            Chunk<T>::unpack(ld16(relu_src + row * lddx + c), r);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) if (!(r[e] > 0.f)) s[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < KC; ++e) s[e] += acc0[e];
         st16(dx + row * lddx + c, Chunk<T>::pack(s));
+    }
+}
+
+// dst[m][dst_off + c] (+)= src[m][src_off + c], c < C: tf.concat / its gradient when the pieces do NOT start on 16-byte channel boundaries
+// (PFPNetR's 512 + 85 + 85 + 85 features).  Element granular; `relu_src` (same rows as dst) zeroes the copy where the ReLU output is <= 0.
+template <typename T>
+__global__ void __launch_bounds__(256) copy_channels_kernel(const T* __restrict__ src, int lds, int src_off, T* __restrict__ dst, int ldd, int dst_off,
+                                                            long long M, int C, int accumulate, const T* __restrict__ relu_src) {
+    const long long total = M * C, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long long m = i / C;
+        const int c = (int)(i - m * C);
+        float v = elem<T>::load(src[m * lds + src_off + c]);
+        T* d = dst + m * ldd + dst_off + c;
+        if (relu_src && !(elem<T>::load(relu_src[m * ldd + dst_off + c]) > 0.f)) v = 0.f;
+        if (accumulate) v += elem<T>::load(*d);
+        *d = elem<T>::store(v);
     }
 }
 
 }  // namespace
 }  // namespace odtk
 
-extern "C" int odtk_resize_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int Ho, int Wo, int C, int dtype,
-                                        int accumulate, void* stream) {
+static float resize_scale(int in, int out, int align_corners) {          // CalculateResizeScale (tensorflow/core/kernels/image_resizer_state.h)
+    return (align_corners && out > 1) ? (float)(in - 1) / (float)(out - 1) : (float)in / (float)out;
+}
+
+extern "C" int odtk_resize_bilinear2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                                         int align_corners, int accumulate, void* stream) {
     if (int e = glue_check("resize_bilinear_fwd", C, dtype, {ldx, ldy}, {x, y})) return e;
     ODTK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "resize_bilinear_fwd: bad geometry");
     const int kc = dtype == ODTK_BF16 ? 8 : 4;
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(resize_bilinear_fwd_kernel<T>, dim3(grid_for((long long)N * Ho * Wo * (C / kc), 256, 65536)), dim3(256), 0,
-                                           (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, N, H, W, Ho, Wo, C, accumulate);)
+                                           (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, N, H, W, Ho, Wo, C, accumulate,
+                                           resize_scale(H, Ho, align_corners), resize_scale(W, Wo, align_corners));)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
 
-extern "C" int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
-                                        int accumulate, void* stream) {
+extern "C" int odtk_resize_bilinear2_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                                         int align_corners, int accumulate, const void* relu_src, void* stream) {
     if (int e = glue_check("resize_bilinear_bwd", C, dtype, {lddy, lddx}, {dy, dx})) return e;
-    ODTK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho >= H && Wo >= W, "resize_bilinear_bwd: up-scaling only (Ho >= H, Wo >= W)");
+    ODTK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "resize_bilinear_bwd: bad geometry");
+    ODTK_REQUIRE(!relu_src || ((uintptr_t)relu_src % 16) == 0, "resize_bilinear_bwd: relu_src must be 16-byte aligned");
     const int kc = dtype == ODTK_BF16 ? 8 : 4;
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(resize_bilinear_bwd_kernel<T>, dim3(grid_for((long long)N * H * W * (C / kc), 256, 65536)), dim3(256), 0,
-                                           (hipStream_t)stream, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, Ho, Wo, C, accumulate);)
+                                           (hipStream_t)stream, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, Ho, Wo, C, accumulate,
+                                           resize_scale(H, Ho, align_corners), resize_scale(W, Wo, align_corners), (const T*)relu_src);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_resize_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                                        int accumulate, void* stream) {
+    return odtk_resize_bilinear2_fwd(x, ldx, y, ldy, N, H, W, Ho, Wo, C, dtype, 0, accumulate, stream);
+}
+
+extern "C" int odtk_resize_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                                        int accumulate, void* stream) {
+    return odtk_resize_bilinear2_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C, dtype, 0, accumulate, nullptr, stream);
+}
+
+extern "C" int odtk_copy_channels(const void* src, int lds, int src_off, void* dst, int ldd, int dst_off, long long M, int C, int dtype,
+                                  int accumulate, const void* relu_src, void* stream) {
+    ODTK_REQUIRE(src && dst && M > 0 && C > 0 && src_off >= 0 && dst_off >= 0 && src_off + C <= lds && dst_off + C <= ldd,
+                 "copy_channels: bad argument (C=%d, offsets %d / %d, pitches %d / %d)", C, src_off, dst_off, lds, ldd);
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(copy_channels_kernel<T>, dim3(grid_for(M * C, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)src, lds, src_off, (T*)dst, ldd, dst_off, M, C, accumulate, (const T*)relu_src);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -239,6 +239,22 @@ def resize_bilinear_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, accumulate=Fals
     call("odtk_resize_bilinear_bwd", _p(dy), int(lddy), _p(dx), int(lddx), N, H, W, Ho, Wo, int(C_), dt_of(dy), int(accumulate), _stream())
 
 
+def resize_bilinear2_fwd(x, ldx, y, ldy, N, H, W, Ho, Wo, C_, align_corners, accumulate=False):
+    """tf.image.resize_bilinear with the align_corners switch, any scaling (include/odtk.h: odtk_resize_bilinear2_fwd)"""
+    call("odtk_resize_bilinear2_fwd", _p(x), int(ldx), _p(y), int(ldy), N, H, W, Ho, Wo, int(C_), dt_of(x), int(align_corners), int(accumulate), _stream())
+
+
+def resize_bilinear2_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, align_corners, accumulate=False, relu_src=None):
+    call("odtk_resize_bilinear2_bwd", _p(dy), int(lddy), _p(dx), int(lddx), N, H, W, Ho, Wo, int(C_), dt_of(dy), int(align_corners), int(accumulate),
+         _p(relu_src), _stream())
+
+
+def copy_channels(src, lds, src_off, dst, ldd, dst_off, M, C_, accumulate=False, relu_src=None):
+    """dst[:, dst_off : dst_off + C] (+)= src[:, src_off : src_off + C], element granular (include/odtk.h: odtk_copy_channels)"""
+    call("odtk_copy_channels", _p(src), int(lds), int(src_off), _p(dst), int(ldd), int(dst_off), int(M), int(C_), dt_of(src), int(accumulate),
+         _p(relu_src), _stream())
+
+
 def gn_workspace(N, C_, device):
     return torch.zeros(int(_lib.load().odtk_gn_workspace_bytes(N, C_)), dtype=torch.uint8, device=device)
 

@@ -76,6 +76,14 @@ class _Act:
 
 
 class RefineDet320:
+    VGG_SEQ = VGG_SEQ                       # the trunk this class builds (pfpnet.PFPNetR stops at conv4_3)
+    L2_AFTER = 'conv10_2'                   # creation order: the two L2-norm scalars follow the feature extractor (:77, :79)
+    NAME = 'RefineDet'
+
+    @staticmethod
+    def layer_specs(num_classes):
+        return layer_specs(num_classes)
+
     def __init__(self, config, data_provider):
         assert config['mode'] in ['train', 'test']
         assert config['data_format'] in ['channels_first', 'channels_last']
@@ -95,7 +103,7 @@ class RefineDet320:
         self.nms_max_boxes = config['nms_max_boxes']
         self.nms_iou_threshold = config['nms_iou_threshold']
         self.pretraining_weight = config.get('pretraining_weight')
-        assert self.input_size % 64 == 0, "RefineDet: the input size must be a multiple of 64 (320 or 512 in the reference)"
+        assert self.input_size % 64 == 0, f"{self.NAME}: the input size must be a multiple of 64 (320 or 512 in the reference)"
         if self.mode == 'train':
             self.num_train = data_provider['num_train']
             self.num_val = data_provider['num_val']
@@ -116,7 +124,7 @@ class RefineDet320:
         self.loss_divisor_batch = self.batch_size
         if self.dev.type == 'cuda':
             torch.cuda.set_device(self.dev)
-        self.specs = layer_specs(self.num_classes)
+        self.specs = self.layer_specs(self.num_classes)
         self._init_parameters(int(config.get('seed', 0)))
         self._build()
         self._load_pretraining_weight()
@@ -146,7 +154,7 @@ class RefineDet320:
                 for suffix in ('.mmean', '.mvar'):
                     sinfo[name + suffix] = (soff, (cout,))
                     soff += ops.pad_to(cout, 64)
-            if name == 'conv10_2':                              # creation order: the two L2-norm scalars follow the feature extractor (:77, :79)
+            if name == self.L2_AFTER:
                 add('feat1_l2_norm', (1,)); add('feat2_l2_norm', (1,))
         self.pinfo, self.sinfo, self.nparam = pinfo, sinfo, off
         dev = self.dev
@@ -224,7 +232,7 @@ class RefineDet320:
             return
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
-        for l in VGG_SEQ:
+        for l in self.VGG_SEQ:
             if isinstance(l, tuple):
                 n = l[0]
                 key = f'vgg_16/{n.split("_")[0]}/{n}'
@@ -301,18 +309,33 @@ class RefineDet320:
             self.plan.append(('l2norm', x, y, gname))
             return y
 
-        x = self.input
-        feats = {}
-        for l in VGG_SEQ:
-            if isinstance(l, tuple):
-                x = vgg(l[0], x)
-                feats[l[0]] = x
-            else:
-                x = pool(l, x, 3, 1) if l == 'pool5' else pool(l, x, 2, 2)
-        for e in EXTRAS:
-            x = bn(e[0], x)
-            feats[e[0]] = x
-        f = [l2norm('feat1', feats['conv4_3'], 'feat1_l2_norm'), l2norm('feat2', feats['conv5_3'], 'feat2_l2_norm'), feats['conv8_2'], feats['conv10_2']]
+        def resize(name, x, Ho, Wo):
+            """tf.image.resize_bilinear(align_corners=True)"""
+            y = act(name, Ho, Wo, x.C)
+            self.plan.append(('resize', x, y))
+            return y
+
+        def avgpool(name, x):
+            assert x.H % 2 == 0 and x.W % 2 == 0
+            y = act(name, x.H // 2, x.W // 2, x.C)
+            self._max_scr = max(self._max_scr, x.M * x.ld)
+            self.plan.append(('avgpool', x, y))
+            return y
+
+        def add(name, a, b):
+            assert (a.M, a.C, a.ld) == (b.M, b.C, b.ld) and not a.vgg and not b.vgg
+            y = act(name, a.H, a.W, a.C)
+            self.plan.append(('add', a, b, y))
+            return y
+
+        def concat(name, srcs):
+            """tf.concat over the channels; the pieces need not start on 16-byte boundaries (odtk_copy_channels)"""
+            y = act(name, srcs[0].H, srcs[0].W, sum(a.C for a in srcs))
+            assert all(a.M == y.M for a in srcs)
+            self.plan.append(('concat', tuple(srcs), y))
+            return y
+        from types import SimpleNamespace
+        f = self._build_features(SimpleNamespace(vgg=vgg, bn=bn, pool=pool, l2norm=l2norm, resize=resize, avgpool=avgpool, add=add, concat=concat, act=act))
         self.level_off, off = [], 0
         for a in f:
             self.level_off.append(off)
@@ -354,6 +377,21 @@ class RefineDet320:
             self._build_backward(N, dt, dev)
         self._refresh_operand_copies()
 
+    def _build_features(self, h):
+        """-> the four feature activations of the ARM / TCB (RefineDet.py:232-385, :74-95): conv4_3 and conv5_3 L2-normalised, conv8_2, conv10_2"""
+        x = self.input
+        feats = {}
+        for l in self.VGG_SEQ:
+            if isinstance(l, tuple):
+                x = h.vgg(l[0], x)
+                feats[l[0]] = x
+            else:
+                x = h.pool(l, x, 3, 1) if l == 'pool5' else h.pool(l, x, 2, 2)
+        for e in EXTRAS:
+            x = h.bn(e[0], x)
+            feats[e[0]] = x
+        return [h.l2norm('feat1', feats['conv4_3'], 'feat1_l2_norm'), h.l2norm('feat2', feats['conv5_3'], 'feat2_l2_norm'), feats['conv8_2'], feats['conv10_2']]
+
     def _pred_view(self, out, grad=False):
         """(flat tensor starting at this level's first row, row width, rows per image of the level is implied by the caller, image stride)"""
         tname, first, width = out
@@ -391,6 +429,18 @@ class RefineDet320:
                 _, x, y, gname = op
                 assert id(y) in written
                 self.bplan.append(('l2norm', x, y, gname, emit(x)))
+            elif kind in ('resize', 'avgpool'):
+                _, x, y = op
+                assert id(y) in written
+                self.bplan.append((kind, x, y, emit(x)))
+            elif kind == 'add':
+                _, a, b, y = op
+                assert id(y) in written
+                self.bplan.append(('add', (a, emit(a)), (b, emit(b)), y))
+            elif kind == 'concat':
+                _, srcs, y = op
+                assert id(y) in written
+                self.bplan.append(('concat', tuple((a, emit(a)) for a in srcs), y))
             else:
                 _, a, b, y = op
                 assert id(y) in written
@@ -424,7 +474,22 @@ class RefineDet320:
                 ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
             elif kind == 'l2norm':
                 _, x, y, gname = op
-                ops.l2norm_fwd(x.t, y.t, x.M, x.C, x.ld, self.param(gname))
+                ops.l2norm_fwd(x.t, y.t, x.M, x.ld, x.ld, self.param(gname))        # (pad channels are zero: they do not change the norm)
+            elif kind == 'resize':
+                _, x, y = op
+                ops.resize_bilinear2_fwd(x.t, x.ld, y.t, y.ld, x.N, x.H, x.W, y.H, y.W, x.ld, True)
+            elif kind == 'avgpool':
+                _, x, y = op
+                ops.avgpool2x2_fwd(x.t, y.t, x.N, x.H, x.W, x.ld)
+            elif kind == 'add':
+                _, a, b, y = op
+                ops.add2d(a.t, a.ld, b.t, b.ld, y.t, y.ld, y.M, y.ld)
+            elif kind == 'concat':
+                _, srcs, y = op
+                off = 0
+                for a in srcs:
+                    ops.copy_channels(a.t, a.ld, 0, y.t, y.ld, off, y.M, a.C)
+                    off += a.C
             else:
                 _, a, b, y = op
                 ops.add_relu_fwd(a.t, a.ld, b.t, b.ld, y.t, y.ld, y.M, y.ld)
@@ -471,8 +536,25 @@ class RefineDet320:
                 self._fold(x, acc)
             elif kind == 'l2norm':
                 _, x, y, gname, acc = op
-                ops.l2norm_bwd(x.t, y.g, x.g, x.M, x.C, x.ld, self.param(gname), self._flat(gname, self.G), acc, x.t)
+                ops.l2norm_bwd(x.t, y.g, x.g, x.M, x.ld, x.ld, self.param(gname), self._flat(gname, self.G), acc, x.t if x.vgg else None)
                 yield gname
+            elif kind == 'resize':
+                _, x, y, acc = op
+                ops.resize_bilinear2_bwd(y.g, y.ld, x.g, x.ld, x.N, x.H, x.W, y.H, y.W, x.ld, True, acc, x.t if x.vgg else None)
+            elif kind == 'avgpool':
+                _, x, y, acc = op
+                ops.avgpool2x2_bwd(y.g, self._into(x, acc), x.N, x.H, x.W, x.ld)
+                self._fold(x, acc)
+            elif kind == 'add':
+                _, (a, acc_a), (b, acc_b), y = op
+                for t, acc in ((a, acc_a), (b, acc_b)):
+                    ops.add2d(y.g, y.ld, t.g if acc else None, t.ld, t.g, t.ld, y.M, y.ld)
+            elif kind == 'concat':
+                _, srcs, y = op
+                off = 0
+                for a, acc in srcs:
+                    ops.copy_channels(y.g, y.ld, off, a.g, a.ld, 0, y.M, a.C, acc, a.t if a.vgg else None)
+                    off += a.C
             else:
                 _, (a, acc_a), (b, acc_b), y = op
                 ops.relu_bwd(y.t, y.g, y.ld, a.g, a.ld, y.M, y.ld, acc_a)

@@ -175,6 +175,41 @@ def resize_bilinear_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, accumulate=Fals
     dx[:, :C_] = (g.reshape(-1, C_) + (dx[:, :C_].float() if accumulate else 0.)).to(dx.dtype)
 
 
+def _bilinear2(x_nhwc, Ho, Wo, align_corners):
+    n, h, w, c = x_nhwc.shape
+    sy = (h - 1) / (Ho - 1) if (align_corners and Ho > 1) else h / Ho
+    sx = (w - 1) / (Wo - 1) if (align_corners and Wo > 1) else w / Wo
+    fy = torch.arange(Ho, dtype=torch.float32) * torch.tensor(sy, dtype=torch.float32)
+    fx = torch.arange(Wo, dtype=torch.float32) * torch.tensor(sx, dtype=torch.float32)
+    y0, x0 = torch.floor(fy).long(), torch.floor(fx).long()
+    y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
+    ly, lx = (fy - y0.float()).view(1, Ho, 1, 1), (fx - x0.float()).view(1, 1, Wo, 1)
+    top = x_nhwc[:, y0][:, :, x0] + (x_nhwc[:, y0][:, :, x1] - x_nhwc[:, y0][:, :, x0]) * lx
+    bot = x_nhwc[:, y1][:, :, x0] + (x_nhwc[:, y1][:, :, x1] - x_nhwc[:, y1][:, :, x0]) * lx
+    return top + (bot - top) * ly
+
+
+def resize_bilinear2_fwd(x, ldx, y, ldy, N, H, W, Ho, Wo, C_, align_corners, accumulate=False):
+    v = _bilinear2(x[:, :C_].float().reshape(N, H, W, C_), Ho, Wo, align_corners).reshape(-1, C_)
+    y[:, :C_] = (v + (y[:, :C_].float() if accumulate else 0.)).to(y.dtype)
+
+
+def resize_bilinear2_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, align_corners, accumulate=False, relu_src=None):
+    x = torch.zeros(N, H, W, C_, requires_grad=True)
+    g, = torch.autograd.grad(_bilinear2(x, Ho, Wo, align_corners), x, dy[:, :C_].float().reshape(N, Ho, Wo, C_))
+    g = g.reshape(-1, C_)
+    if relu_src is not None:
+        g = g * (relu_src[:, :C_].float() > 0)
+    dx[:, :C_] = (g + (dx[:, :C_].float() if accumulate else 0.)).to(dx.dtype)
+
+
+def copy_channels(src, lds, src_off, dst, ldd, dst_off, M, C_, accumulate=False, relu_src=None):
+    v = src[:, src_off: src_off + C_].float()
+    if relu_src is not None:
+        v = v * (relu_src[:, dst_off: dst_off + C_].float() > 0)
+    dst[:, dst_off: dst_off + C_] = (v + (dst[:, dst_off: dst_off + C_].float() if accumulate else 0.)).to(dst.dtype)
+
+
 def _pool(x_nhwc, k, stride, pt, pl, Ho, Wo):
     n, h, w, c = x_nhwc.shape
     pb = max((Ho - 1) * stride + k - h - pt, 0)

@@ -705,3 +705,65 @@ def test_wgrad_split_reduce_is_deterministic_and_matches_the_atomics(dev):
         assert float((outs[0][0] - ref).abs().max()) <= 2e-3 * float(wr.grad.abs().max())
         refb = dy[:, :K].float().sum(0) - 2.0
         assert float((outs[0][1] - refb).abs().max()) <= 2e-3 * float(refb.abs().max())
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(2, 40, 40, 20, 20, 64, True), (2, 40, 40, 5, 5, 512, True), (1, 10, 12, 3, 5, 16, True), (2, 8, 8, 16, 16, 32, True),
+                                  (2, 9, 7, 4, 3, 24, False), (1, 6, 6, 1, 1, 8, True)])
+def test_resize_bilinear_align_corners_any_scale(geom, dt, dev):
+    """odtk_resize_bilinear2_* (PFPNetR.py:320-322: conv4_3 to 1/2, 1/4, 1/8 with align_corners=True): forward against the formula of
+    tensorflow/core/kernels/resize_bilinear_op.cc (src = dst * (in - 1) / (out - 1), taps floor and min(floor + 1, in - 1)), backward
+    against autograd of the same formula; accumulate and the ReLU mask of a bias + ReLU input."""
+    from tests import mock_ops as MO
+    ops = _ops()
+    N, H, W, Ho, Wo, C, ac = geom
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N * H * W, C, generator=g).to(dtype)
+    xd = x.to(dev)
+    y = torch.full((N * Ho * Wo, C), 7.0, dtype=dtype, device=dev)
+    ops.resize_bilinear2_fwd(xd, C, y, C, N, H, W, Ho, Wo, C, ac)
+    ref = MO._bilinear2(x.float().reshape(N, H, W, C), Ho, Wo, ac).reshape(-1, C)
+    tol = 1e-5 if dt == "f32" else 1e-2
+    assert float((y.float().cpu() - ref).abs().max()) <= tol * (float(ref.abs().max()) + 1)
+    dy = torch.randn(N * Ho * Wo, C, generator=g).to(dtype)
+    xr = x.float().reshape(N, H, W, C).clone().requires_grad_(True)
+    MO._bilinear2(xr, Ho, Wo, ac).backward(dy.float().reshape(N, Ho, Wo, C))
+    gref = xr.grad.reshape(-1, C)
+    dx = torch.full((N * H * W, C), 3.0, dtype=dtype, device=dev)
+    ops.resize_bilinear2_bwd(dy.to(dev), C, dx, C, N, H, W, Ho, Wo, C, ac)
+    assert float((dx.float().cpu() - gref).abs().max()) <= tol * (float(gref.abs().max()) + 1)
+    # accumulate + ReLU mask (the mask applies to the NEW gradient only)
+    base = torch.randn(N * H * W, C, generator=g).to(dtype)
+    dx2 = base.clone().to(dev)
+    ops.resize_bilinear2_bwd(dy.to(dev), C, dx2, C, N, H, W, Ho, Wo, C, ac, True, xd)
+    want = base.float() + gref * (x.float() > 0)
+    assert float((dx2.float().cpu() - want).abs().max()) <= 2 * tol * (float(want.abs().max()) + 1)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_copy_channels_unaligned_concat(dt, dev):
+    """odtk_copy_channels: tf.concat of 512 + 85 + 85 + 85 channels (PFPNetR.py:366-396) and its gradient: element-granular offsets"""
+    ops = _ops()
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(6)
+    M = 333
+    parts = [(512, 512), (85, 88), (85, 88), (85, 88)]
+    srcs = [torch.randn(M, ld, generator=g).to(dtype).to(dev) for _, ld in parts]
+    dst = torch.zeros(M, 768, dtype=dtype, device=dev)
+    off = 0
+    for (c, ld), s in zip(parts, srcs):
+        ops.copy_channels(s, ld, 0, dst, 768, off, M, c)
+        off += c
+    want = torch.cat([s[:, :c] for (c, _), s in zip(parts, srcs)], 1)
+    assert torch.equal(dst[:, :767], want) and float(dst[:, 767].float().abs().max()) == 0.0
+    # gradient: slices back out, accumulate, ReLU mask of the destination's forward tensor
+    dcat = torch.randn(M, 768, generator=g).to(dtype).to(dev)
+    out = torch.full((M, 88), 2.0, dtype=dtype, device=dev)
+    ops.copy_channels(dcat, 768, 597, out, 88, 0, M, 85)
+    assert torch.equal(out[:, :85], dcat[:, 597:682]) and float((out[:, 85:].float() - 2.0).abs().max()) == 0.0
+    fwd = torch.randn(M, 512, generator=g).to(dtype).to(dev)
+    acc = torch.ones(M, 512, dtype=dtype, device=dev)
+    ops.copy_channels(dcat, 768, 0, acc, 512, 0, M, 512, True, fwd)
+    want = (1.0 + dcat[:, :512].float() * (fwd.float() > 0)).to(dtype)
+    assert torch.equal(acc, want)

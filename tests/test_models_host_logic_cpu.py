@@ -3,6 +3,7 @@ torch-CPU stand-in (tests/mock_ops.py) and must reproduce the oracle's loss, EVE
 launch order, shared gradient buffers, accumulate flags, prediction scatter, loss / optimizer glue are all exercised without a GPU.
 (The kernels behind the launches are verified on the GPU, alone and through the same classes: tests/test_gpu_*.py.)"""
 import pytest
+import re
 import torch
 
 import mock_ops
@@ -333,4 +334,54 @@ def test_refinedet_training_step_host_logic():
             assert _rel(m.get_param(k, m.G), want) < 3e-2, (k, _rel(m.get_param(k, m.G), want))     # batch-1 batch norm over 25 ... 1600 samples: the SSD300 bound
         after = m.export_params()
         for k in ('conv1_1.w', 'conv5_3.b', 'conv10_2.gamma', 'arm1.c1.w', 'tcb2.d.w', 'odm4.conf.beta', 'feat1_l2_norm', 'tcb3.d.mmean', 'odm1.loc.mvar'):
+            assert _rel(after[k], q[k]) < 1e-3 or float((after[k] - q[k]).abs().max()) < 1e-6, k
+
+
+def test_pfpnet_training_step_host_logic():
+    """PFPNetR: VGG trunk to conv4_3 with FIVE consumers of its ReLU output (three align_corners resizes, a 1x1 branch, the concatenation), the
+    85-channel up / down pyramid branches (transposed convs, average pools, plain sums), four 767-channel concatenations at unaligned channel offsets,
+    RefineDet's heads -- one training step on the CPU mock against oracle/pfpnet_net_ref.train_step (pinned on the reference's own class,
+    tests/golden/pfpnet_train.npz)"""
+    import odtk
+    from oracle import pfpnet_net_ref as PR
+    from oracle import refinedet_ref as FR
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'input_size': 320, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+           'nms_score_threshold': 0.1, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.45, 'pretraining_weight': '', 'verbose': False, 'compute_dtype': 'f32',
+           'device': 'cpu'}
+    g = torch.Generator().manual_seed(290)
+    imgs = (torch.rand(1, 320, 320, 3, generator=g) * 255).round()
+    gt = FR.synthetic_gt(1, 320, 291, pad=8, max_obj=3)
+    p = PR.init_params(29)
+    with mock_ops.installed():
+        m = odtk.PFPNetR(cfg, {'data_shape': [320, 320, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+        assert [s[:4] for s in m.specs] == [s[:4] for s in PR.layer_specs()] and m.A == 6375
+        assert list(m.pinfo).index('feat1_l2_norm') == list(m.pinfo).index('fl3_4.beta') + 1          # creation order (PFPNetR.py:79)
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        loss = float(m.train_step(0.001))
+        q = {k: v.clone() for k, v in p.items()}
+        mom = {k: torch.zeros_like(p[k]) for k in PR.trainable_names(p)}
+        total, data, grads = PR.train_step(q, mom, imgs, gt, 0.001)
+        assert abs(loss - total) < 1e-4 * abs(total), (loss, total)
+        worst = ('', 0.)
+        for k in PR.trainable_names(p):
+            if k.endswith('.b') and (k[:-2] + '.gamma') in p:
+                assert float(m.get_param(k, m.G).abs().max()) == 0.0          # a bias in front of a batch norm
+                continue
+            want = grads[k] - 1e-4 * p[k]
+            if k.endswith('_l2_norm'):
+                assert float((m.get_param(k, m.G) - want).abs().max()) <= 0.3 * float(want.abs().max()) + 1e-4, k
+                continue
+            if re.fullmatch(r'fl\d_\dd\.beta', k):
+                # the offset of an up-path transposed conv's batch norm goes through `+ fl_b`, a 1x1 conv and the NEXT batch norm, which removes any
+                # per-channel constant: the true gradient is 0 and both sides hold round-off (compare against the scale of the layer's gamma gradient)
+                assert float((m.get_param(k, m.G) - want).abs().max()) <= 1e-3 * float(grads[k[:-5] + '.gamma'].abs().max()) + 1e-6, k
+                continue
+            err = _rel(m.get_param(k, m.G), want)
+            worst = max(worst, (k, err), key=lambda t: t[1])
+            assert err < 3e-2, (k, err)
+        print('worst relative gradient error', worst)
+        after = m.export_params()
+        for k in ('conv1_1.w', 'conv4_3.b', 'fl1.w', 'fl4_1d.w', 'fl2_3.gamma', 'arm1.c1.w', 'tcb2.d.w', 'odm4.conf.beta', 'fl3.mmean', 'fl4_2d.mvar'):
             assert _rel(after[k], q[k]) < 1e-3 or float((after[k] - q[k]).abs().max()) < 1e-6, k

@@ -165,6 +165,7 @@ struct WgradArgs {
     float* ws;
     float* bws;
     int nsplit, nbslot;
+    int which;       // set by launch_wgrad_v3: the kernel generation that ran (3 | 7 | 8), for odtk_conv_last_kernel
 };
 
 // 16 bytes of zeros that padded / out-of-range LDS-DMA lanes fetch instead of branching

@@ -2535,6 +2535,7 @@ bool launch_wgrad_v8(WgradArgs& a, hipStream_t st) {
     if (wgrad_split_scratch(a, splits, a.dbias ? splits * tiles_q * 2 : 0)) return false;
     hipLaunchKernelGGL(conv_wgrad_v8_kernel<2>, dim3(tiles * splits), dim3(256), 0, st, a);
     wgrad_split_reduce(a, st);
+    a.which = 8;
     return true;
 }
 
@@ -2559,6 +2560,7 @@ int launch_wgrad_v7(WgradArgs& a, hipStream_t st) {
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
     hipLaunchKernelGGL(conv_wgrad_v7_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
+    a.which = 7;
     return 0;
 }
 
@@ -2592,6 +2594,7 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
     if (int e = wgrad_split_scratch(a, splits, a.dbias ? splits : 0)) return e;
     hipLaunchKernelGGL(conv_wgrad_v3_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
     wgrad_split_reduce(a, st);
+    a.which = 3;
     return 0;
 }
 

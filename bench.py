@@ -192,3 +192,329 @@ def pmc_traffic(kernel):
                     'source': 'STATIC (committed rocprofv3 --pmc passes of this command, not re-measured in this run): '
                               + os.path.relpath(f, ROOT) + f' :: dispatch-weighted mean over {len(rows)} template variant(s) of {base}, {n} launches'}
     return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-conv-events', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region')
+    ap.add_argument('--auto-launch', action='store_true', help="use_graph='auto': the faster of replay / eager launches, measured during warm-up")
+    ap.add_argument('--wgrad-stream', action='store_true', help='A/B: filter gradients on a second HIP stream')
+    ap.add_argument('--match-stream', action='store_true', help='A/B: box matching on a second HIP stream under the forward pass')
+    ap.add_argument('--no-tail-stream', action='store_true', help='A/B: heads after the extra layers on one stream (round-1 order)')
+    ap.add_argument('--sync-bn', action='store_true', help='N > 1: batch-norm statistics over all replicas (SURVEY 8e option B; eager launches)')
+    ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
+    ap.add_argument('--kernel-dbg', type=int, default=0, help='A/B: odtk_debug_set(2, bits) dispatch switches of csrc/conv_v3.hip (bits >= 1<<26 only)')
+    ap.add_argument('--debug-set', default='', help="A/B: comma list of KEY:VALUE for odtk_debug_set (keys that leave results intact: 3, 4, 5)")
+    ap.add_argument('--bucket-mb', type=int, default=25, help='N > 1: gradient all-reduce bucket size')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='exercise ONLY the launcher / rendezvous / timing / one-JSON-line skeleton with a dummy all-reduce step '
+                         '(gloo when there is no GPU); prints metric "launch-check", never a measurement')
+    args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], need_gpus=not args.launch_check))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; pass the same N to both '
+                         f'(or drop the launcher: `python bench.py --gpus N` starts its own ranks)')
+    if args.launch_check:
+        return launch_check(args, world, rank, local_rank)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import odtk
+    from odtk import ops
+    B = args.batch
+    if args.kernel_dbg:
+        assert args.kernel_dbg >> 26 << 26 == args.kernel_dbg, 'only the dispatch switches leave results intact'
+        odtk._lib.load().odtk_debug_set(2, args.kernel_dbg)
+    for kv in filter(None, args.debug_set.split(',')):
+        k, v = kv.split(':')
+        assert int(k) in (3, 4, 5), 'only the dispatch switches leave results intact'
+        odtk._lib.load().odtk_debug_set(int(k), int(v))
+    config = {
+        'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
+        'keep_prob': 0.5, 'batch_size': B, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20,
+        'nms_iou_threshold': 0.5, 'pretraining_weight': os.path.join('.', 'vgg_16.ckpt'),
+        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else True,
+    }
+    provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    model = odtk.SSD300(config, provider)
+    if world > 1:
+        model.attach_data_parallel(bucket_mb=args.bucket_mb, sync_bn=args.sync_bn)
+    images, gt = synthetic_batch(B, 1000 + rank, dev)
+    model.set_batch(images, gt)
+
+    timer = ConvTimer(ops)
+    timer.install()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lr = 0.01
+    for _ in range(args.warmup):
+        loss = model.train_step(lr)
+    while model.use_graph and not args.eager and model._eager_steps < 2:
+        loss = model.train_step(lr)                          # a capture needs every lazily allocated buffer to exist
+    if model.use_graph and model._g_front is None and not args.eager:
+        model._graphs_build_safe()                           # untimed; a capture executes nothing
+    if args.eager:
+        model.use_graph = False
+        model._auto = None
+    while model.launch_mode_pending:                         # use_graph='auto': replay vs eager launches, decided by measurement (untimed)
+        loss = model.train_step(lr)
+    import gc
+    gc.collect()
+    gc.disable()               # a generation-2 collection in the launching thread is a 10-30 ms host stall; with eager launches
+    barrier()                  # (the HIP-event pass below) the GPU runs dry behind it and the stall lands in some kernel's events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = model.train_step(lr)
+    barrier()
+    dt = time.perf_counter() - t0
+    final_loss_t = loss
+    # roofline pass: the SAME step launched eagerly with HIP events around every conv launch on the launch
+    # stream (graph replay cannot carry per-kernel events; the kernels and their durations are identical)
+    if not args.no_conv_events:
+        saved = model.use_graph
+        saved_side = model.wgrad_stream
+        model.use_graph = False
+        model.wgrad_stream = None            # one stream: every conv kernel is timed with the chip to itself
+        timer.enabled = True
+        ev_steps = min(args.steps, 5) + 1
+        for _ in range(ev_steps):
+            model.train_step(lr)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        gc.enable()
+        model.use_graph = saved
+        model.wgrad_stream = saved_side
+    gc.enable()
+    loss = final_loss_t
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        comm = comm_metrics(model, args, lr, barrier, dt / args.steps * 1e3, dev)
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B * world * args.steps / dt
+        out = {
+            'metric': 'images/sec SSD300 VGG-16 batch=32 train',
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
+                       'global_batch': B * world, 'parallelism': f'dp{world}' + ('+sync-bn' if args.sync_bn and world > 1 else ''), 'final_loss': round(final_loss, 4),
+                       'launch_mode_calibration': model.launch_mode,
+                       'launch': 'eager' if not model.use_graph else ('hip-graph replay (fwd+loss+bwd)' if model._g_back is not None
+                                                                        else f'hip-graph replay (fwd+loss; bwd as {len(model._g_back_segs or [])} '
+                                                                             'bucket graphs with RCCL all-reduces between them)')},
+        }
+        peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
+        if timer.records:
+            out['roofline'] = timer.roofline(min(args.steps, 5) + 1, peak, value / world * 188.0e9 / peak)
+            if args.conv_table:
+                with open(args.conv_table, 'w') as f:
+                    f.write(timer.table(min(args.steps, 5) + 1) + '\n')
+            out['roofline']['measured_on'] = (f'{min(args.steps, 5) + 1} eager steps right after the timed region '
+                                              '(HIP events per conv launch on the launch stream; plain per-launch mean without the first eager step; '
+                                              '*_trimmed additionally drops the slowest sample of every launch)')
+        if comm is not None:
+            out['comm'] = comm
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch_ranks(n, argv, need_gpus=True):
+    """`python bench.py --gpus N` without torchrun: start N copies of this script, one rank per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment, exactly what torch.distributed.run sets), rank 0 inherits stdout so that its ONE
+    JSON line is this process's output.  Returns the exit code (first failing rank's; the others are then terminated by PID)."""
+    import subprocess
+    if need_gpus and (not torch.cuda.is_available() or torch.cuda.device_count() < n):
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        print(f'bench.py: --gpus {n} but only {have} GPU(s) visible on this node', file=sys.stderr)
+        return 2
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), ODTK_BENCH_LAUNCHER='self')
+    env0.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this driver (RCCL needs it)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in live:                     # one rank failed: the others would hang in the next collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def launch_check(args, world, rank, local_rank):
+    """--launch-check: the launcher, the rendezvous, barrier + max-over-ranks timing and the one-JSON-line contract with a dummy
+    step (an all-reduce of 1 M floats).  gloo on a box without GPUs -- this is what tests/test_bench_launch_cpu.py runs."""
+    import torch.distributed as dist
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    dev = torch.device('cuda', local_rank) if use_gpu else torch.device('cpu')
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl' if use_gpu else 'gloo', rank=rank, world_size=world,
+                                **({'device_id': dev} if use_gpu else {}))
+    buf = torch.ones(1 << 20, device=dev)
+
+    def barrier():
+        if use_gpu:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        if world > 1:
+            dist.all_reduce(buf)
+            buf.mul_(1.0 / world)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ok = bool(torch.allclose(buf, torch.ones_like(buf)))
+    if rank == 0:
+        print(json.dumps({'metric': 'launch-check', 'value': round(args.steps / dt, 2), 'unit': 'dummy steps/sec', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'launcher / rendezvous self-check (1 M-float all-reduce per step); NOT a measurement'},
+                          'comm': {'backend': dist.get_backend() if world > 1 else None,
+                                   'world_size': dist.get_world_size() if world > 1 else 1,
+                                   'launcher': os.environ.get('ODTK_BENCH_LAUNCHER', 'external'), 'allreduce_ok': ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def comm_metrics(model, args, lr, barrier, ms_step, dev):
+    """N > 1, after the timed region: what RCCL saw (world size, backend), the gradient all-reduce's own time per step
+    (every bucket back to back, nothing to overlap with), the step time with the collectives switched off, and from the two
+    the fraction of the all-reduce hidden under backward:  overlap = 1 - (step - step_without_comm) / allreduce_alone."""
+    import torch.distributed as dist
+    red = model.dist.red
+    k = max(3, min(args.steps, 10))
+    for _ in range(2):
+        red.all_reduce_alone()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        red.all_reduce_alone()
+    barrier()
+    t_ar = (time.perf_counter() - t0) / k * 1e3
+    red.enabled = False
+    model.train_step(lr)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        model.train_step(lr)
+    barrier()
+    t_nc = (time.perf_counter() - t0) / k * 1e3
+    red.enabled = True
+    v = torch.tensor([t_ar, t_nc], device=dev)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    t_ar, t_nc = (float(x) for x in v.tolist())
+    nbytes = sum(red.bucket_bytes())
+    w = dist.get_world_size()
+    return {'backend': dist.get_backend(), 'world_size': w, 'launcher': os.environ.get('ODTK_BENCH_LAUNCHER', 'external'),
+            'buckets': len(red.buckets), 'gradient_mb': round(nbytes / 1e6, 1),
+            'allreduce_ms_per_step': round(t_ar, 3),
+            'allreduce_busbw_gbps': round(nbytes * 2 * (w - 1) / w / (t_ar * 1e-3) / 1e9, 1),
+            'ms_per_step_without_comm': round(t_nc, 3), 'exposed_comm_ms': round(max(ms_step - t_nc, 0.0), 3),
+            'overlap_frac': round(min(max(1.0 - max(ms_step - t_nc, 0.0) / max(t_ar, 1e-9), 0.0), 1.0), 3)}
+
+
+def usable_cores():
+    """Host threads this process may really use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:                                             # noqa: BLE001
+        pass
+    return n
+
+
+def cpu_baseline():
+    """PyTorch-CPU oracle (restatement of the reference graph) on a bounded sample of the SAME workload: full training steps
+    at batch 32 (one warm-up, then steps until ~20 s are spent, at most 3)."""
+    from oracle import ssd300_ref as R
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    bs = 32
+    p = R.init_params(0)
+    mom = {k: torch.zeros_like(v) for k, v in p.items()}
+    imgs, gt = R.synthetic_batch(bs, 0)
+    anchors = R.priors()
+    R.train_step(p, mom, imgs, gt, 0.01, 1e-4, anchors)          # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 1 or (time.perf_counter() - t0 < 20 and n < 3):
+        R.train_step(p, mom, imgs, gt, 0.01, 1e-4, anchors)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(bs * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'mkldnn': bool(torch.backends.mkldnn.is_available() and torch.backends.mkldnn.enabled),
+            'sample': f'{n} full train step(s) at batch {bs} after one warm-up step (same synthetic generator), PyTorch-CPU fp32 '
+                      'oracle; the reference TF-1.13 graph itself cannot run (no tensorflow, SSD300.py:41-43 syntax error)'}
+
+
+if __name__ == '__main__':
+    main()

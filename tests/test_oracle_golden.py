@@ -558,3 +558,53 @@ def test_pfpnet_two_training_steps_match_reference_class():
     for ours, tfname in names.items():
         shp = list(p[ours].permute(1, 2, 3, 0).shape) if ours.endswith('.w') else list(p[ours].shape)
         assert want[tfname]['shape'] == shp, (ours, tfname)
+
+
+def test_yolov2_two_training_steps_and_detections_match_reference_class():
+    """oracle/yolov2_ref (Darknet-19, passthrough concat, the cell-unit loss with its unclamped intersections and mangled no-object prior boxes, Momentum;
+    decode with its additive offsets) against two steps of the reference's own YOLOv2 class and its test graph run on the shim
+    (tests/golden/yolov2_train.npz); variable names / shapes of the graph"""
+    import json
+    from oracle import yolov2_ref as YR
+    g = np.load(os.path.join(GOLD, 'yolov2_train.npz'))
+    specs = YR.layer_specs()
+    assert len(specs) == 24 == len(g['names']) == len(g['bn_names'])
+    p = YR.init_params(81)
+    mom = {k: torch.zeros_like(p[k]) for k in YR.trainable_names(p)}
+    losses, after_first = [], None
+    for s in (1000, 1001):
+        gen = torch.Generator().manual_seed(s)
+        imgs = (torch.rand(2, 416, 416, 3, generator=gen) * 255).round()
+        gt = YR.synthetic_gt(2, 416, s + 10, pad=8, max_obj=4)
+        total, _, _ = YR.train_step(p, mom, imgs, gt, 0.001)
+        losses.append(total)
+        if after_first is None:
+            after_first = {k: v.detach().clone() for k, v in p.items()}
+    assert abs(losses[0] - g['losses'][0]) < 1e-5 * g['losses'][0] and abs(losses[1] - g['losses'][1]) < 1e-3 * g['losses'][1], (losses, g['losses'])
+    for key in g.files:
+        if key in ('losses', 'names', 'bn_names') or key.startswith('det_'):
+            continue
+        k = key.replace('__', '.')
+        got = after_first[k].reshape(-1)
+        got = got[::max(1, got.numel() // 1024)].numpy()
+        assert np.linalg.norm(got - g[key]) / (np.linalg.norm(g[key]) + 1e-9) < 1e-4, k
+    names = json.load(open(os.path.join(GOLD, 'yolov2_names.json')))
+    want = json.load(open(os.path.join(GOLD, 'yolov2_variables.json')))
+    assert set(names.values()) | {'global_step'} == set(want) and set(names) == set(p)
+    for ours, tfname in names.items():
+        shp = list(p[ours].permute(1, 2, 3, 0).shape) if ours.endswith('.w') else list(p[ours].shape)
+        assert want[tfname]['shape'] == shp, (ours, tfname)
+    # inference: the calibration of make_golden_yolov2.py
+    q = YR.init_params(83)
+    gen = torch.Generator().manual_seed(1100)
+    img = (torch.rand(1, 416, 416, 3, generator=gen) * 255).round()
+    stats = {}
+    with torch.no_grad():
+        YR.forward(q, img, True, stats_out=stats, subtract_mean=False)
+    for name, (mean, unb) in stats.items():
+        q[name + '.mmean'], q[name + '.mvar'] = mean.clone(), unb.clone()
+    q['pred.beta'] = q['pred.beta'] + 1.5
+    scores, bbox, cid = YR.test_one_image(q, img, YR.PRIORS, 0.5, 10, 0.5)
+    assert len(scores) == len(g['det_scores']) > 0 and np.array_equal(cid.numpy(), g['det_class'])
+    np.testing.assert_allclose(scores.numpy(), g['det_scores'], atol=1e-5)
+    np.testing.assert_allclose(bbox.numpy(), g['det_bbox'], atol=1e-2)

@@ -437,6 +437,17 @@ int odtk_yolov3_decode_candidates(const float* const* pred, const int* shapes, c
                                   const float* decode_scale, int num_priors, int C, float* confidence, float* bbox,
                                   void* stream);
 
+/* YOLOv2 box side: the per-image loss loop of YOLOv2.py:102-166 (batch mean :167) and the decode of :177-186 (feed the candidates to
+ * odtk_nms_batched).  pred [N][H][W][num_priors][C+5] = class(C), yx(2), hw(2), obj(1) logits (f32, device); priors: HOST array [num_priors][2] (h, w) in
+ * cell units as the reference's config gives them; stride 32 (ground truth pixels / stride); gt [N][pad][5] = yc, xc, h, w, class padded with -1.
+ * loss_parts [N][5] = coord (yx + hw), class, objectness, no-object sums and the scaled per-image total; d_pred (fully written) = d(sum_i total_i) *
+ * grad_scale.  The reference's quirks (unclamped intersections, the mangled prior box of the no-object IoU, additive decode) are reproduced. */
+int odtk_yolov2_loss(const float* pred, int N, int H, int W, int num_priors, int C, const float* priors, float stride, const float* gt,
+                     int pad, float coord_scale, float noobj_scale, float obj_scale, float class_scale, float grad_scale,
+                     float* loss_parts, float* d_pred, void* stream);
+int odtk_yolov2_decode_candidates(const float* pred, int H, int W, int num_priors, int C, const float* priors, float stride,
+                                  float* confidence, float* bbox, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Image augmentor: replaces utils/image_augmentor.py:87-232 -- the tf.image / tf.contrib.image ops on
  * the picture and the box arithmetic next to them.  The host turns the reference's random draws (crop offsets, flip,

@@ -9,7 +9,7 @@ reached through the C-ABI in ``include/odtk.h`` (``libodtk.so``).
 from . import _lib                      # noqa: F401
 from ._lib import BF16, F32, OdtkError  # noqa: F401
 
-__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "SSD512", "RefineDet320", "PFPNetR"]
+__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "SSD512", "RefineDet320", "PFPNetR", "YOLOv2"]
 
 
 def __getattr__(name):
@@ -31,6 +31,9 @@ def __getattr__(name):
     if name == "RefineDet320":
         from .refinedet import RefineDet320
         return RefineDet320
+    if name == "YOLOv2":
+        from .yolov2 import YOLOv2
+        return YOLOv2
     if name == "PFPNetR":
         from .pfpnet import PFPNetR
         return PFPNetR

@@ -75,6 +75,8 @@ SIGNATURES = {
     "odtk_resize_bilinear2_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "odtk_resize_bilinear2_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "odtk_copy_channels": (_i, [_vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _i, _vp, _vp]),
+    "odtk_yolov2_loss": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_f), _f, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "odtk_yolov2_decode_candidates": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_f), _f, _vp, _vp, _vp]),
     "odtk_rows_to_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _ll, _ll, _i, _vp]),
     "odtk_rows_from_f32": (_i, [_vp, _i, _i, _ll, _vp, _i, _i, _ll, _i, _vp]),
     "odtk_gn_workspace_bytes": (_ll, [_i, _i]),

@@ -807,3 +807,182 @@ extern "C" int odtk_yolov3_decode_candidates(const float* const* pred, const int
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
+
+
+// =======================================================================================================
+// YOLOv2: YOLOv2.py:102-166 (per-image loss), :177-186 (decode).  One head [N][H][W][P][C + 5] = class (C), yx (2), hw (2),
+// objectness (1) logits; ground truth and priors in CELL units (pixels / 32).  The reference's arithmetic is followed literally, quirks included:
+// intersections are NOT clamped at 0 (prod of two negative extents is positive); the no-object IoU is taken on a mangled prior box
+// ("yx" := y1x1, "hw" := y2x2 of the prior, then y1x1 := "yx" - "hw"/2, y2x2 := "yx" + "hw"/2); every prior of a cell that holds a box centre is
+// exempt from the no-object term; two boxes in one cell both write (gradients add).  One workgroup per image; the box loop is serial with one thread
+// per output channel, so duplicate (cell, prior) targets accumulate in a fixed order (deterministic).
+// =======================================================================================================
+namespace odtk {
+namespace {
+
+constexpr int Y2_MAX_CELLS = 64 * 64, Y2_MAX_PRIORS = 16;
+
+struct Y2Args {
+    const float *pred, *gt;
+    float pri[Y2_MAX_PRIORS * 2];
+    int N, H, W, P, C, pad;
+    float coord, noobj, obj, cls, grad_scale, stride;
+    float* loss_parts;   // [N][5] coord, class, obj, no-object sums, per-image total
+    float* d_pred;
+};
+
+__global__ void __launch_bounds__(DH_THREADS) yolov2_loss_kernel(const Y2Args a) {
+    __shared__ unsigned char s_has[Y2_MAX_CELLS];
+    __shared__ float s_g[DH_MAX_GT][9];               // gy gx gh gw (cells), y1 x1 y2 x2, label
+    __shared__ float red[DH_THREADS / 64];
+    __shared__ int s_G;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int E = a.C + 5, cells = a.H * a.W;
+    const long long img = (long long)cells * a.P * E;
+    const float* pr = a.pred + (long long)n * img;
+    float* dp = a.d_pred + (long long)n * img;
+    const float* gt = a.gt + (long long)n * a.pad * 5;
+    if (tid == 0) s_G = min(first_argmin_col0(gt, a.pad), DH_MAX_GT);
+    for (long long i = tid; i < img; i += DH_THREADS) dp[i] = 0.f;
+    for (int i = tid; i < cells; i += DH_THREADS) s_has[i] = 0;
+    __syncthreads();
+    const int G = s_G;
+    for (int g = tid; g < G; g += DH_THREADS) {
+        const float gy = gt[g * 5] / a.stride, gx = gt[g * 5 + 1] / a.stride, gh = gt[g * 5 + 2] / a.stride, gw = gt[g * 5 + 3] / a.stride;
+        s_g[g][0] = gy; s_g[g][1] = gx; s_g[g][2] = gh; s_g[g][3] = gw;
+        s_g[g][4] = gy - gh / 2.f; s_g[g][5] = gx - gw / 2.f; s_g[g][6] = gy + gh / 2.f; s_g[g][7] = gx + gw / 2.f;
+        s_g[g][8] = gt[g * 5 + 4];
+        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
+        if (cy >= 0 && cy < a.H && cx >= 0 && cx < a.W) s_has[cy * a.W + cx] = 1;
+    }
+    __syncthreads();
+    // ---- no-object term: every prior of the cells without a box centre
+    float l_noobj = 0.f;
+    for (int idx = tid; idx < cells * a.P; idx += DH_THREADS) {
+        const int cell = idx / a.P, k = idx - cell * a.P;
+        if (s_has[cell]) continue;
+        const int cy = cell / a.W, cx = cell - cy * a.W;
+        const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f, ph = a.pri[2 * k], pw = a.pri[2 * k + 1];
+        const float my = ay - ph / 2.f, mx = ax - pw / 2.f, mh = ay + ph / 2.f, mw = ax + pw / 2.f;     // "yx" := y1x1, "hw" := y2x2
+        const float y1 = my - mh / 2.f, x1 = mx - mw / 2.f, y2 = my + mh / 2.f, x2 = mx + mw / 2.f;
+        const float aarea = (y2 - y1) * (x2 - x1);
+        float best = -INFINITY;
+        for (int g = 0; g < G; ++g) {
+            const float inter = (fminf(s_g[g][6], y2) - fmaxf(s_g[g][4], y1)) * (fminf(s_g[g][7], x2) - fmaxf(s_g[g][5], x1));
+            const float garea = (s_g[g][6] - s_g[g][4]) * (s_g[g][7] - s_g[g][5]);
+            const float iou = inter / (aarea + garea - inter);
+            best = fmaxf(best, iou);
+        }
+        if (best <= 0.6f) {
+            const float x = pr[(long long)idx * E + a.C + 4];
+            l_noobj += bce_logits(x, 0.f);
+            dp[(long long)idx * E + a.C + 4] = a.noobj * sigmoidf_(x) * a.grad_scale;
+        }
+    }
+    __syncthreads();
+    // ---- the boxes, one after the other; thread t owns output channel t of the chosen (cell, prior)
+    float l_coord = 0.f, l_cls = 0.f, l_obj = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float gy = s_g[g][0], gx = s_g[g][1], gh = s_g[g][2], gw = s_g[g][3];
+        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
+        if (cy < 0 || cy >= a.H || cx < 0 || cx >= a.W) continue;
+        const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f;
+        const float garea = (s_g[g][6] - s_g[g][4]) * (s_g[g][7] - s_g[g][5]);
+        int bk = 0;
+        float bv = -INFINITY;
+        for (int k = 0; k < a.P; ++k) {
+            const float ph = a.pri[2 * k], pw = a.pri[2 * k + 1];
+            const float y1 = ay - ph / 2.f, x1 = ax - pw / 2.f, y2 = ay + ph / 2.f, x2 = ax + pw / 2.f;
+            const float inter = (fminf(s_g[g][6], y2) - fmaxf(s_g[g][4], y1)) * (fminf(s_g[g][7], x2) - fmaxf(s_g[g][5], x1));
+            const float iou = inter / (ph * pw + garea - inter);
+            if (iou > bv) { bv = iou; bk = k; }        // first maximum
+        }
+        if (tid < E) {
+            const long long o = ((long long)(cy * a.W + cx) * a.P + bk) * E + tid;
+            const float x = pr[o];
+            float grad;
+            if (tid < a.C) {
+                const float z = (tid == (int)s_g[g][8]) ? 1.f : 0.f;
+                l_cls += bce_logits(x, z);
+                grad = a.cls * (sigmoidf_(x) - z);
+            } else if (tid < a.C + 2) {
+                const float v = tid == a.C ? gy : gx;
+                const float z = v - floorf(v);
+                l_coord += bce_logits(x, z);
+                grad = a.coord * (sigmoidf_(x) - z);
+            } else if (tid < a.C + 4) {
+                const float z = tid == a.C + 2 ? logf(gh / a.pri[2 * bk]) : logf(gw / a.pri[2 * bk + 1]);
+                const float d = x - z;
+                l_coord += 0.5f * (d * d);
+                grad = a.coord * d;
+            } else {
+                l_obj += bce_logits(x, 1.f);
+                grad = a.obj * (sigmoidf_(x) - 1.f);
+            }
+            dp[o] += grad * a.grad_scale;
+        }
+    }
+    const float t_coord = block_sum<DH_THREADS>(l_coord, red);
+    const float t_cls = block_sum<DH_THREADS>(l_cls, red);
+    const float t_obj = block_sum<DH_THREADS>(l_obj, red);
+    const float t_noobj = block_sum<DH_THREADS>(l_noobj, red);
+    if (tid == 0) {
+        float* lp = a.loss_parts + n * 5;
+        lp[0] = t_coord; lp[1] = t_cls; lp[2] = t_obj; lp[3] = t_noobj;
+        lp[4] = a.coord * t_coord + a.cls * t_cls + a.obj * t_obj + a.noobj * t_noobj;
+    }
+}
+
+__global__ void __launch_bounds__(DH_THREADS) yolov2_decode_kernel(const Y2Args a, float* __restrict__ conf, float* __restrict__ bbox) {
+    const int idx = blockIdx.x * DH_THREADS + threadIdx.x;
+    if (idx >= a.H * a.W * a.P) return;
+    const int E = a.C + 5;
+    const int cell = idx / a.P, k = idx - cell * a.P;
+    const int cy = cell / a.W, cx = cell - cy * a.W;
+    const float* pr = a.pred + (long long)idx * E;
+    const float so = sigmoidf_(pr[a.C + 4]);
+    for (int c = 0; c < a.C; ++c) conf[(long long)idx * a.C + c] = sigmoidf_(pr[c]) * so;
+    const float y = ((float)cy + 0.5f) + sigmoidf_(pr[a.C]), x = ((float)cx + 0.5f) + sigmoidf_(pr[a.C + 1]);
+    const float h = a.pri[2 * k] + expf(pr[a.C + 2]), w = a.pri[2 * k + 1] + expf(pr[a.C + 3]);       // sums, as written (YOLOv2.py:183-184)
+    float* b = bbox + (long long)idx * 4;
+    b[0] = (y - h / 2.f) * a.stride; b[1] = (x - w / 2.f) * a.stride; b[2] = (y + h / 2.f) * a.stride; b[3] = (x + w / 2.f) * a.stride;
+}
+
+int y2_fill(Y2Args& a, const float* pred, int H, int W, int P, int C, const float* priors) {
+    ODTK_REQUIRE(pred && priors, "yolov2: null pointer");
+    ODTK_REQUIRE(H > 0 && W > 0 && H * W <= Y2_MAX_CELLS && P > 0 && P <= Y2_MAX_PRIORS && C > 0 && C + 5 <= DH_THREADS,
+                 "yolov2: unsupported geometry H=%d W=%d priors=%d classes=%d", H, W, P, C);
+    a.pred = pred; a.H = H; a.W = W; a.P = P; a.C = C;
+    for (int i = 0; i < 2 * P; ++i) a.pri[i] = priors[i];
+    return ODTK_OK;
+}
+
+}  // namespace
+}  // namespace odtk
+
+extern "C" int odtk_yolov2_loss(const float* pred, int N, int H, int W, int num_priors, int C, const float* priors, float stride, const float* gt,
+                                int pad, float coord_scale, float noobj_scale, float obj_scale, float class_scale, float grad_scale,
+                                float* loss_parts, float* d_pred, void* stream) {
+    Y2Args a;
+    memset(&a, 0, sizeof(a));
+    if (int e = y2_fill(a, pred, H, W, num_priors, C, priors)) return e;
+    ODTK_REQUIRE(gt && loss_parts && d_pred && N > 0 && pad > 0, "yolov2_loss: bad argument");
+    a.gt = gt; a.N = N; a.pad = pad; a.stride = stride;
+    a.coord = coord_scale; a.noobj = noobj_scale; a.obj = obj_scale; a.cls = class_scale; a.grad_scale = grad_scale;
+    a.loss_parts = loss_parts; a.d_pred = d_pred;
+    hipLaunchKernelGGL(yolov2_loss_kernel, dim3(N), dim3(DH_THREADS), 0, (hipStream_t)stream, a);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_yolov2_decode_candidates(const float* pred, int H, int W, int num_priors, int C, const float* priors, float stride,
+                                             float* confidence, float* bbox, void* stream) {
+    Y2Args a;
+    memset(&a, 0, sizeof(a));
+    if (int e = y2_fill(a, pred, H, W, num_priors, C, priors)) return e;
+    ODTK_REQUIRE(confidence && bbox, "yolov2_decode_candidates: null pointer");
+    a.stride = stride;
+    hipLaunchKernelGGL(yolov2_decode_kernel, dim3(ceil_div(H * W * num_priors, DH_THREADS)), dim3(DH_THREADS), 0, (hipStream_t)stream, a, confidence, bbox);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}

@@ -117,6 +117,27 @@ def yolov3_detect(preds, priors_flat, score_thr, max_boxes, iou_thr, decode_scal
     return _per_class_nms(conf, bbox, cand, conf.shape[1], max_boxes, iou_thr)
 
 
+def yolov2_detect(pred0, priors_flat, score_thr, max_boxes, iou_thr, stride=32.0):
+    """YOLOv2.py:177-201.  pred0: [H, W, P, C + 5] of one image."""
+    conf, bbox = ops.yolov2_decode_candidates(pred0, priors_flat, stride)
+    cand = (conf >= score_thr).to(torch.uint8)
+    return _per_class_nms(conf, bbox, cand, conf.shape[1], max_boxes, iou_thr)
+
+
+class YOLOv2Loss:
+    """YOLOv2.py:102-167 for a batch (odtk_yolov2_loss); the gradient of the prediction tensor is in self.d_pred"""
+
+    def __init__(self, N, H, W, P, C, priors_flat, scales, device):
+        self.priors_flat, self.scales = priors_flat, scales
+        self.loss_parts = torch.zeros(N, 5, device=device)
+        self.d_pred = torch.zeros(N, H * W * P, C + 5, device=device)
+        self.shape = (N, H, W, P, C + 5)
+
+    def __call__(self, pred, gt, grad_scale, stride=32.0):
+        ops.yolov2_loss(pred.view(self.shape), self.priors_flat, stride, gt, self.scales, grad_scale, self.loss_parts, self.d_pred)
+        return self.loss_parts
+
+
 def centernet_detect(keypoints, offset, size, score_thr, top_k, stride=4.0, workspace=None):
     """CenterNet.py:159-185 (no NMS: 3x3 peak test + top-k)."""
     H, W, C = keypoints.shape

@@ -521,6 +521,22 @@ def yolov3_loss(preds, priors_flat, head_stride, gt, scales, grad_scale, loss_pa
          _ptr_array(d_preds), _p(ws), _stream())
 
 
+def yolov2_loss(pred, priors_flat, stride, gt, scales, grad_scale, loss_parts, d_pred):
+    """YOLOv2.py:102-167.  pred [N,H,W,P,C+5]; priors_flat: P*2 floats (h, w) in cell units; scales = (coord, noobj, obj, class); loss_parts [N,5]."""
+    N, H, W, P, E = pred.shape
+    call("odtk_yolov2_loss", _p(pred), N, H, W, P, E - 5, _farr(priors_flat), float(stride), _p(gt), gt.shape[1], float(scales[0]), float(scales[1]),
+         float(scales[2]), float(scales[3]), float(grad_scale), _p(loss_parts), _p(d_pred), _stream())
+
+
+def yolov2_decode_candidates(pred0, priors_flat, stride):
+    """YOLOv2.py:177-186 for one image [H,W,P,C+5]; returns confidence [L,C], bbox [L,4] (pixels)."""
+    H, W, P, E = pred0.shape
+    conf = torch.empty(H * W * P, E - 5, device=pred0.device)
+    bbox = torch.empty(H * W * P, 4, device=pred0.device)
+    call("odtk_yolov2_decode_candidates", _p(pred0), H, W, P, E - 5, _farr(priors_flat), float(stride), _p(conf), _p(bbox), _stream())
+    return conf, bbox
+
+
 def yolov3_decode_candidates(preds, priors_flat, decode_scale):
     """YOLOv3.py:320-350 for one image (three [H,W,P,C+5] tensors); returns confidence [L,C], bbox [L,4]."""
     dev = preds[0].device

@@ -172,8 +172,9 @@ class RefineDet320:
             if kind != 'vgg':
                 self.param(name + '.gamma').fill_(1.0)
                 self.stat(name + '.mvar').fill_(1.0)
-        self.param('feat1_l2_norm').fill_(10.0)
-        self.param('feat2_l2_norm').fill_(8.0)
+        if 'feat1_l2_norm' in pinfo:
+            self.param('feat1_l2_norm').fill_(10.0)
+            self.param('feat2_l2_norm').fill_(8.0)
 
     def param(self, name, buf=None):
         off, shape = self.pinfo[name]
@@ -242,20 +243,18 @@ class RefineDet320:
         self._refresh_operand_copies()
 
     # ------------------------------------------------------------------ the graph
+    def _input_hw(self):
+        return self.input_size, self.input_size
+
     def _build(self):
+        """the graph engine: helpers that append to the forward plan (shared with pfpnet.PFPNetR and yolov2.YOLOv2), the model, the buffers"""
         N, dev, dt, ch = self.batch_size, self.dev, self.tdt, self.chunk
-        S_ = self.input_size
+        Hin, Win = self._input_hw()
         spec = {s[0]: s for s in self.specs}
-        self.images = torch.zeros(N, S_, S_, 3, device=dev)
-        self.input = _Act('input', N, S_, S_, 3, ops.pad_to(3, ch), dt, dev)
+        self.images = torch.zeros(N, Hin, Win, 3, device=dev)
+        self.input = _Act('input', N, Hin, Win, 3, ops.pad_to(3, ch), dt, dev)
         self.plan, self.desc, self.z, self.bnsave, self.acts = [], {}, {}, {}, {'input': self.input}
         self._max_ws = self._max_z = self._max_scr = 0
-        self.anc = heads.refinedet_anchors(S_, dev)                      # y1x1, y2x2, yx, hw, nmsbox
-        A = self.anc[0].shape[0]
-        self.A = A
-        C = self.num_classes
-        self.arm_loc = torch.zeros(N, A, 4, device=dev); self.arm_conf = torch.zeros(N, A, 2, device=dev)
-        self.odm_loc = torch.zeros(N, A, 4, device=dev); self.odm_conf = torch.zeros(N, A, C, device=dev)
 
         def act(name, H_, W_, C_, vgg=False):
             a = _Act(name, N, H_, W_, C_, ops.pad_to(C_, ch), dt, dev, vgg)
@@ -294,12 +293,14 @@ class RefineDet320:
             self._max_ws = max(self._max_ws, ops.bn_workspace_bytes(z.M, cout))
             self._max_z = max(self._max_z, z.M * ldz)
             self._max_scr = max(self._max_scr, src.M * src.ld)
-            self.plan.append(('bn', name, kind, src, z, y, 1 if relu else 0, out))
+            self.plan.append(('bn', name, kind, src, z, y, int(relu), out))          # 0 none | 1 ReLU | 2 leaky_relu(0.1)
             return y
 
         def pool(name, x, k, s):
             Ho, pt, _ = ops.same_pad(x.H, k, s)
-            y = act(name, Ho, Ho, x.C, vgg=x.vgg)
+            Wo, pl, _ = ops.same_pad(x.W, k, s)
+            assert pl == pt, "the pool launch takes one pad for both axes"
+            y = act(name, Ho, Wo, x.C, vgg=x.vgg)
             self._max_scr = max(self._max_scr, x.M * x.ld)
             self.plan.append(('pool', x, y, k, s, pt))
             return y
@@ -335,7 +336,33 @@ class RefineDet320:
             self.plan.append(('concat', tuple(srcs), y))
             return y
         from types import SimpleNamespace
-        f = self._build_features(SimpleNamespace(vgg=vgg, bn=bn, pool=pool, l2norm=l2norm, resize=resize, avgpool=avgpool, add=add, concat=concat, act=act))
+        self._build_model(SimpleNamespace(vgg=vgg, bn=bn, pool=pool, l2norm=l2norm, resize=resize, avgpool=avgpool, add=add, concat=concat, act=act))
+        self.ws = torch.zeros(self._max_ws, dtype=torch.uint8, device=dev)
+        self.wt, entries = {}, []
+        for sp in self.specs:
+            name, kind, cin, cout, k = sp[0], sp[1], sp[2], sp[3], sp[4]
+            if name == self.specs[0][0]:                        # the first layer: the input needs no gradient
+                continue
+            (kout, _, _, kin_pad), _ = self._wshape(sp)
+            kp = ops.pad_to(kout, ch)
+            self.wt[name] = torch.zeros(kin_pad * k * k * kp, dtype=dt, device=dev)
+            entries.append((self._flat(name + '.w', self.P), self.wt[name], kout, k, k, kin_pad, kp))
+        self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, dev)
+        if self.mode == 'train':
+            self._build_backward(N, dt, dev)
+        self._refresh_operand_copies()
+
+    def _build_model(self, h):
+        """RefineDet.py:72-158: anchors, the four prediction tensors, features, ARM heads, the top-down TCB chain, ODM heads"""
+        N, dev = self.batch_size, self.dev
+        self.anc = heads.refinedet_anchors(self.input_size, dev)         # y1x1, y2x2, yx, hw, nmsbox
+        A = self.anc[0].shape[0]
+        self.A = A
+        C = self.num_classes
+        self.arm_loc = torch.zeros(N, A, 4, device=dev); self.arm_conf = torch.zeros(N, A, 2, device=dev)
+        self.odm_loc = torch.zeros(N, A, 4, device=dev); self.odm_conf = torch.zeros(N, A, C, device=dev)
+        bn, act = h.bn, h.act
+        f = self._build_features(h)
         self.level_off, off = [], 0
         for a in f:
             self.level_off.append(off)
@@ -362,20 +389,6 @@ class RefineDet320:
                 tcb[l] = y
         for l in range(4):
             head(f'odm{l + 1}', tcb[l + 1], l, 'odm_loc', 'odm_conf', C)
-        self.ws = torch.zeros(self._max_ws, dtype=torch.uint8, device=dev)
-        self.wt, entries = {}, []
-        for sp in self.specs:
-            name, kind, cin, cout, k = sp[0], sp[1], sp[2], sp[3], sp[4]
-            if name == 'conv1_1':
-                continue
-            (kout, _, _, kin_pad), _ = self._wshape(sp)
-            kp = ops.pad_to(kout, ch)
-            self.wt[name] = torch.zeros(kin_pad * k * k * kp, dtype=dt, device=dev)
-            entries.append((self._flat(name + '.w', self.P), self.wt[name], kout, k, k, kin_pad, kp))
-        self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, dev)
-        if self.mode == 'train':
-            self._build_backward(N, dt, dev)
-        self._refresh_operand_copies()
 
     def _build_features(self, h):
         """-> the four feature activations of the ARM / TCB (RefineDet.py:232-385, :74-95): conv4_3 and conv5_3 L2-normalised, conv8_2, conv10_2"""
@@ -518,7 +531,8 @@ class RefineDet320:
                 mask = src.t if src.vgg else None
                 if lk == 'conv':
                     ops.conv2d_wgrad(self.desc[name], src.t, zg, z.ld, self._flat(name + '.w', self.G), None)
-                    ops.conv2d_dgrad(self.desc[name], zg, z.ld, self.wt[name], mask, src.g, acc)
+                    if src is not self.input:
+                        ops.conv2d_dgrad(self.desc[name], zg, z.ld, self.wt[name], mask, src.g, acc)
                 else:
                     ops.conv2d_wgrad(self.desc[name], zg, src.t, src.ld, self._flat(name + '.w', self.G), None)
                     ops.conv2d_fwd(self.desc[name], zg, self._flat(name + '.w', self.Pc), None, self._into(src, acc), False)
@@ -570,8 +584,16 @@ class RefineDet320:
         gt = torch.as_tensor(ground_truth, dtype=torch.float32)
         if self.gt is None or self.gt.shape != gt.shape:
             self.gt = torch.zeros(gt.shape, device=self.dev)
-            self.loss = heads.RefineDetLoss(self.anc, self.batch_size, self.num_classes, gt.shape[1], self.dev)
+            self.loss = self._make_loss(gt.shape[1])
         self.gt.copy_(gt, non_blocking=True)
+
+    def _make_loss(self, pad):
+        return heads.RefineDetLoss(self.anc, self.batch_size, self.num_classes, pad, self.dev)
+
+    def _loss_step(self):
+        """loss kernels on the predictions of _forward (gradients into self.loss.d_*) -> sum of the per-image losses / batch, a device scalar"""
+        parts = self.loss(self.arm_loc, self.arm_conf, self.odm_loc, self.odm_conf, self.gt, 1.0 / self.loss_divisor_batch)
+        return parts[:, 6].sum() / self.batch_size
 
     def train_step(self, lr):
         """one MomentumOptimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor"""
@@ -579,7 +601,7 @@ class RefineDet320:
             self.dist.begin_step()
         self.G.zero_()
         self._forward(True)
-        parts = self.loss(self.arm_loc, self.arm_conf, self.odm_loc, self.odm_conf, self.gt, 1.0 / self.loss_divisor_batch)
+        data_loss = self._loss_step()
         for name in self._backward_iter():
             # gradient segments of the all-reduce are the blocks before the first '.' (arm1, tcb3, ...); a block is final when its FIRST
             # layer in creation order (.c1) has been processed -- backward walks a block's layers in reverse
@@ -591,7 +613,7 @@ class RefineDet320:
         ops.sum_f32(self.l2_partial, self.l2_sum)
         self._fp_batch.run()
         self.global_step += 1
-        return parts[:, 6].sum() / self.batch_size + self.weight_decay * self.l2_sum      # RefineDet.py:180-184 (pre-update weights)
+        return data_loss + self.weight_decay * self.l2_sum      # RefineDet.py:180-184 (pre-update weights)
 
     def train_one_epoch(self, lr):
         if callable(self.train_initializer):

@@ -592,3 +592,21 @@ def installed():
     finally:
         for n, v in old.items():
             setattr(ops, n, v)
+
+
+def yolov2_loss(pred, priors_flat, stride, gt, scales, grad_scale, loss_parts, d_pred):
+    from oracle import yolov2_ref as YR
+    N, H, W, P, E = pred.shape
+    priors = [[priors_flat[2 * k], priors_flat[2 * k + 1]] for k in range(P)]
+    x = pred.detach().clone().requires_grad_(True)
+    per = [YR.image_loss(x[i], gt[i], priors, scales, E - 5) for i in range(N)]
+    torch.stack(per).sum().backward()
+    d_pred.copy_((x.grad * grad_scale).view(d_pred.shape))
+    loss_parts.zero_()
+    loss_parts[:, 4] = torch.stack(per).detach()
+
+
+def yolov2_decode_candidates(pred0, priors_flat, stride):
+    from oracle import yolov2_ref as YR
+    P = pred0.shape[2]
+    return YR.decode(pred0, [[priors_flat[2 * k], priors_flat[2 * k + 1]] for k in range(P)])

@@ -2,6 +2,8 @@
 torch-CPU stand-in (tests/mock_ops.py) and must reproduce the oracle's loss, EVERY gradient and the optimizer update -- buffer planning,
 launch order, shared gradient buffers, accumulate flags, prediction scatter, loss / optimizer glue are all exercised without a GPU.
 (The kernels behind the launches are verified on the GPU, alone and through the same classes: tests/test_gpu_*.py.)"""
+import os
+
 import pytest
 import re
 import torch
@@ -384,4 +386,46 @@ def test_pfpnet_training_step_host_logic():
         print('worst relative gradient error', worst)
         after = m.export_params()
         for k in ('conv1_1.w', 'conv4_3.b', 'fl1.w', 'fl4_1d.w', 'fl2_3.gamma', 'arm1.c1.w', 'tcb2.d.w', 'odm4.conf.beta', 'fl3.mmean', 'fl4_2d.mvar'):
+            assert _rel(after[k], q[k]) < 1e-3 or float((after[k] - q[k]).abs().max()) < 1e-6, k
+
+
+def test_yolov2_training_step_host_logic():
+    """YOLOv2: Darknet-19 chain (leaky batch-norm layers, five pools), the passthrough concatenation, the batch-normalised prediction layer writing the f32
+    prediction tensor, loss hook, Momentum -- one training step on the CPU mock against oracle/yolov2_ref.train_step (pinned on the reference's own class,
+    tests/golden/yolov2_train.npz); the reference's variable names"""
+    import json
+    import odtk
+    from odtk.yolov2 import reference_variable_map
+    from oracle import yolov2_ref as YR
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'is_pretraining': False, 'data_shape': [192, 224, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+           'data_format': 'channels_last', 'batch_size': 2, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'nms_score_threshold': 0.5,
+           'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'rescore_confidence': False, 'priors': YR.PRIORS, 'verbose': False, 'compute_dtype': 'f32', 'device': 'cpu'}
+    g = torch.Generator().manual_seed(390)
+    imgs = (torch.rand(2, 192, 224, 3, generator=g) * 255).round()
+    gt = YR.synthetic_gt(2, 192, 391, pad=8, max_obj=3)
+    p = YR.init_params(39)
+    names = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'yolov2_names.json')))
+    assert reference_variable_map() == names
+    with mock_ops.installed():
+        m = odtk.YOLOv2(cfg, {'data_shape': [192, 224, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+        assert [(s[0], s[2], s[3], s[4]) for s in m.specs] == [s[:4] for s in YR.layer_specs()] and m.grid == (6, 7)
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        loss = float(m.train_step(0.001))
+        q = {k: v.clone() for k, v in p.items()}
+        mom = {k: torch.zeros_like(p[k]) for k in YR.trainable_names(p)}
+        total, data, grads = YR.train_step(q, mom, imgs, gt, 0.001)
+        assert abs(loss - total) < 1e-4 * abs(total), (loss, total)
+        worst = ('', 0.)
+        for k in YR.trainable_names(p):
+            if k.endswith('.b'):
+                assert float(m.get_param(k, m.G).abs().max()) == 0.0          # every bias sits in front of a batch norm
+                continue
+            err = _rel(m.get_param(k, m.G), grads[k] - 1e-4 * p[k])
+            worst = max(worst, (k, err), key=lambda t: t[1])
+            assert err < 3e-2, (k, err)
+        print('worst relative gradient error', worst)
+        after = m.export_params()
+        for k in ('b1.w', 'b9.gamma', 'b17.w', 'h5.beta', 'pred.w', 'pred.gamma', 'b3.mmean', 'pred.mvar'):
             assert _rel(after[k], q[k]) < 1e-3 or float((after[k] - q[k]).abs().max()) < 1e-6, k

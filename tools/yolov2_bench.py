@@ -1,0 +1,31 @@
+"""YOLOv2 training throughput (testYOLOv2.py's configuration: 480 x 480, batch 32): synthetic VOC-shaped batch, random-init weights, full step.
+usage: python tools/yolov2_bench.py [dtype=bf16] [batch=32] [steps=5]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import odtk
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _synth as S
+
+dtype = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+cfg = {'mode': 'train', 'is_pretraining': False, 'data_shape': [480, 480, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+       'data_format': 'channels_last', 'batch_size': batch, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'nms_score_threshold': 0.5,
+       'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'rescore_confidence': False,
+       'priors': [[1.08, 1.19], [3.42, 4.41], [6.63, 11.38], [9.42, 5.11], [16.62, 10.52]], 'verbose': False, 'compute_dtype': dtype}
+g = torch.Generator().manual_seed(0)
+imgs = (torch.rand(batch, 480, 480, 3, generator=g) * 255).round()
+gt = S.synthetic_gt(batch, 480, 1, lo=0.1, hi=0.7)
+m = odtk.YOLOv2(cfg, {'data_shape': [480, 480, 3], 'num_train': batch, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+m.set_batch(imgs, gt)
+for _ in range(2):
+    loss = m.train_step(1e-4)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    loss = m.train_step(1e-4)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+flops = sum(3 * 2 * batch * m.desc[n].Ho * m.desc[n].Wo * co * ci * k * k for n, kind, ci, co, k, *_ in m.specs)
+print(f'YOLOv2 batch {batch} {dtype}: {dt * 1e3:8.2f} ms/step  {batch / dt:8.1f} images/s   conv {flops / dt / 1e12:6.1f} TFLOP/s   loss {float(loss):.3f}')

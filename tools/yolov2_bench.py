@@ -1,5 +1,5 @@
 """YOLOv2 training throughput (testYOLOv2.py's configuration: 480 x 480, batch 32): synthetic VOC-shaped batch, random-init weights, full step.
-usage: python tools/yolov2_bench.py [dtype=bf16] [batch=32] [steps=5]"""
+usage: python tools/yolov2_bench.py [dtype=bf16] [batch=32] [steps=5] [graph]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 cfg = {'mode': 'train', 'is_pretraining': False, 'data_shape': [480, 480, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
        'data_format': 'channels_last', 'batch_size': batch, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'nms_score_threshold': 0.5,
        'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'rescore_confidence': False,
-       'priors': [[1.08, 1.19], [3.42, 4.41], [6.63, 11.38], [9.42, 5.11], [16.62, 10.52]], 'verbose': False, 'compute_dtype': dtype}
+       'priors': [[1.08, 1.19], [3.42, 4.41], [6.63, 11.38], [9.42, 5.11], [16.62, 10.52]], 'verbose': False, 'compute_dtype': dtype, 'use_graph': len(sys.argv) > 4 and sys.argv[4] == 'graph'}
 g = torch.Generator().manual_seed(0)
 imgs = (torch.rand(batch, 480, 480, 3, generator=g) * 255).round()
 gt = S.synthetic_gt(batch, 480, 1, lo=0.1, hi=0.7)

@@ -642,11 +642,12 @@ __global__ void __launch_bounds__(256) conv_gather_v5_kernel(const GatherArgs a)
 // tap 6, and only the last NPP - G2 groups (258 rows) are exposed between two chunks.
 // WP x (4 / WP) waves, every wave PI x QI accumulator tiles of 32 x 32: 2, 2, 4 = the 128 x 256 tile (0.75 fragment reads per MFMA);
 // 1, 4, 4 = a 128 x 512 tile of four 128 x 128 wave tiles (0.5 reads per MFMA, round 2: the 75- and 150-pixel maps, whose time is LDS
-// bandwidth); 2, 2, 3 = 128 x 192 (conv5_x: 244 instead of 184 tiles for 256 CUs).
+// bandwidth); 2, 2, 3 = 128 x 192 (conv5_x: 244 instead of 184 tiles for 256 CUs); 1, 2, 4 = 64 x 512 for Cout <= 64
+// (conv2_1's input gradient, 128 -> 64 channels at W = 150: it ran on the 8-wave gather kernel at 490 TFLOP/s).
 template <int NPP, bool DBUF, int G1, int G2, int WP = 2, int PI = 2, int QI = 4>
 __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a) {
     constexpr int PT = WP * PI * 32, QT = (4 / WP) * QI * 32, NTHR = 256;
-    static_assert(PT == 128, "the filter slab is 128 rows");
+    static_assert(PT == 128 || PT == 64, "the filter slab is 128 (or 64: Cout <= 64) rows");
     constexpr int NP = PT / 32;                          // filter DMA pieces per wave and slab
     constexpr int PROWS = NPP * 32;                      // patch rows (416 | 576)
     constexpr int PATCH = PROWS * 128, WST = PT * 128;
@@ -2122,6 +2123,16 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         ksplit = 256 / tiles;                    // (2..6 slabs per part and 512 / tiles were measured: this is the best)
         if (ksplit > nk / 4) ksplit = nk / 4;
         if (ksplit > 32) ksplit = 32;
+    }
+    // Cout <= 64 on the halo kernel: 64 x 512 tiles (dbg bit 27 = off, A/B)
+    if (PT == 64 && ksplit < 2 && !(a.dbg & 65536) && !(a.dbg & (1 << 27)) && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
+        a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && a.Kdim == 9 * a.C &&
+        ((halo <= 160 && a.dil * a.W >= 64) || v6_wide) && ceil_div(a.M, 512) >= 2 * 256) {
+        a.ksplit = -1;
+        a.tiles_q = ceil_div(a.M, 512);
+        if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<21, false, 2, 4, 1, 2, 4>), dim3(a.tiles_q), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v6_kernel<26, false, 4, 9, 1, 2, 4>), dim3(a.tiles_q), dim3(256), 0, st, a);
+        return 0;
     }
     if (ksplit >= 2) {
         float* ws = nullptr;

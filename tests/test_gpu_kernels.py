@@ -767,3 +767,10 @@ def test_copy_channels_unaligned_concat(dt, dev):
     ops.copy_channels(dcat, 768, 0, acc, 512, 0, M, 512, True, fwd)
     want = (1.0 + dcat[:, :512].float() * (fwd.float() > 0)).to(dtype)
     assert torch.equal(acc, want)
+
+
+@pytest.mark.parametrize("case", [(12, 150, 150, 128, 64, 3, 1, 1), (48, 75, 75, 64, 64, 3, 1, 1), (13, 150, 148, 64, 40, 3, 1, 1)])
+def test_conv_halo_kernel_64_channel_tiles(case, dev):
+    """Cout <= 64 on the raster-run halo kernel: 64 x 512 tiles (conv2_1's input gradient, 128 -> 64 channels at W = 150, batch 32); needs
+    >= 512 pixel tiles, so the shapes are large; the third has a channel tail (40 of 64 filter rows) and a ragged last tile"""
+    _conv_case(case, "bf16", dev)

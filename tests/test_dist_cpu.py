@@ -201,3 +201,82 @@ def test_yolov3_model_data_parallel_world2_on_cpu(tmp_path):
     # batch 1 at 64 x 64 puts batch norms over 4 samples into the model: a leaky-ReLU input that lands on the other side of 0 in one of the
     # two computations moves the gradient by per cents (tests/test_gpu_yolov3.py); identical thread counts usually give identical bits
     assert float((a['G'] - total).norm()) < 5e-2 * float(total.norm())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the shared graph engine of refinedet.py (RefineDet320, PFPNetR, YOLOv2): data-parallel hooks on two gloo ranks, launches mocked
+def _engine_cpu_model(kind, rank):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import mock_ops
+    import odtk
+    g = torch.Generator().manual_seed(900 + rank)
+    if kind == 'yolov2':
+        from oracle import yolov2_ref as YR
+        cfg = {'mode': 'train', 'is_pretraining': False, 'data_shape': [128, 160, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+               'data_format': 'channels_last', 'batch_size': 1, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1.,
+               'nms_score_threshold': 0.5, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'rescore_confidence': False, 'priors': YR.PRIORS, 'verbose': False,
+               'compute_dtype': 'f32', 'device': 'cpu', 'seed': 3}
+        batch = ((torch.rand(1, 128, 160, 3, generator=g) * 255).round(), YR.synthetic_gt(1, 128, 950 + rank, pad=6, max_obj=3))
+        with mock_ops.installed():
+            m = odtk.YOLOv2(cfg, {'data_shape': [128, 160, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+    else:
+        from oracle import refinedet_ref as FR
+        cfg = {'mode': 'train', 'input_size': 320, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+               'nms_score_threshold': 0.1, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.45, 'pretraining_weight': '', 'verbose': False, 'compute_dtype': 'f32',
+               'device': 'cpu', 'seed': 3}
+        batch = ((torch.rand(1, 320, 320, 3, generator=g) * 255).round(), FR.synthetic_gt(1, 320, 950 + rank, pad=8, max_obj=3))
+        with mock_ops.installed():
+            m = odtk.PFPNetR(cfg, {'data_shape': [320, 320, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+    return m, batch
+
+
+def _engine_model_worker(kind, rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import mock_ops
+    torch.set_num_threads(4)
+    m, batch = _engine_cpu_model(kind, rank)
+    with mock_ops.installed():
+        red = m.attach_data_parallel(bucket_mb=16)
+        m.set_batch(*batch)
+        loss = float(m.train_step(0.002))
+    torch.save({'P': m.P.clone(), 'G': m.G.clone(), 'loss': loss, 'buckets': len(red.red.buckets)}, os.path.join(out_dir, f'{kind}{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["yolov2", "pfpnet"])
+def test_engine_models_data_parallel_world2_on_cpu(kind, tmp_path):
+    """YOLOv2 and PFPNetR (refinedet.py's engine: per-layer readiness reported while the backward plan runs, L2-norm scalars and multi-consumer
+    gradient buffers included) on two gloo ranks with every libodtk launch mocked: replicas end identical, several buckets were exchanged, and the
+    exchanged gradient is the sum of the ranks' local gradients with the loss divided by the GLOBAL batch"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mock_ops
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_model_worker, args=(kind, r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0
+    a, b = torch.load(os.path.join(tmp_path, f'{kind}0.pt')), torch.load(os.path.join(tmp_path, f'{kind}1.pt'))
+    assert torch.equal(a['P'], b['P']) and torch.equal(a['G'], b['G']) and a['buckets'] >= 3
+    total = None
+    threads = torch.get_num_threads()
+    torch.set_num_threads(4)
+    for rank in range(2):
+        m, batch = _engine_cpu_model(kind, rank)
+        with mock_ops.installed():
+            m.loss_divisor_batch = 2                          # what attach_data_parallel sets: the global batch
+            m.set_batch(*batch)
+            m._step_body()
+        total = m.G.clone() if total is None else total + m.G
+    torch.set_num_threads(threads)
+    assert float((a['G'] - total).norm()) < 5e-2 * float(total.norm())

@@ -215,3 +215,59 @@ def test_retinanet_two_ranks_one_gpu(tmp_path, dev):
     torch.cuda.synchronize()
     g = a['G'].to(total.device)
     assert float((g - total).norm()) < 1e-4 * float(total.norm())
+
+
+def _yolov2_cfg(batch, size):
+    from oracle import yolov2_ref as YR
+    return {'mode': 'train', 'is_pretraining': False, 'data_shape': [size, size, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+            'data_format': 'channels_last', 'batch_size': batch, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1.,
+            'nms_score_threshold': 0.5, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'rescore_confidence': False, 'priors': YR.PRIORS, 'verbose': False,
+            'compute_dtype': 'f32', 'seed': 3}
+
+
+def _yolov2_batch(rank, batch, size):
+    from oracle import yolov2_ref as YR
+    g = torch.Generator().manual_seed(960 + rank)
+    return (torch.rand(batch, size, size, 3, generator=g) * 255).round(), YR.synthetic_gt(batch, size, 970 + rank, pad=6, max_obj=3)
+
+
+def _yolov2_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import odtk
+    B, size = 2, 160
+    m = odtk.YOLOv2(_yolov2_cfg(B, size), {'data_shape': [size, size, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+    red = m.attach_data_parallel(bucket_mb=16)
+    m.set_batch(*_yolov2_batch(rank, B, size))
+    loss = float(m.train_step(0.002))
+    torch.cuda.synchronize()
+    torch.save({'P': m.P.cpu(), 'G': m.G.cpu(), 'loss': loss, 'buckets': len(red.red.buckets)}, os.path.join(out_dir, f'v{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_yolov2_two_ranks_one_gpu(tmp_path, dev):
+    """the shared graph engine of refinedet.py (RefineDet320 / PFPNetR / YOLOv2) data parallel: bucketed all-reduce hooked on the backward plan leaves both
+    replicas bit-identical and exchanges the SUM of the replicas' local gradients (loss = mean over the GLOBAL batch, batch norm local)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_yolov2_worker, args=(2, 29670, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(os.path.join(tmp_path, 'v0.pt')), torch.load(os.path.join(tmp_path, 'v1.pt'))
+    assert torch.equal(a['P'], b['P']) and torch.equal(a['G'], b['G'])
+    assert a['buckets'] > 1 and a['loss'] == a['loss'] and b['loss'] == b['loss']
+    import odtk
+    B, size = 2, 160
+    total = p0 = None
+    for rank in range(2):
+        m = odtk.YOLOv2(_yolov2_cfg(B, size), {'data_shape': [size, size, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+        p0 = m.P.clone()
+        m.loss_divisor_batch = 2 * B
+        m.set_batch(*_yolov2_batch(rank, B, size))
+        m._step_body()
+        total = m.G.clone() if total is None else total + m.G
+    torch.cuda.synchronize()
+    g = a['G'].to(total.device)
+    assert float((g - total).norm()) < 1e-4 * float(total.norm())          # f32 engine; filter gradients use float atomics
+    after = p0 - 0.002 * (total + 1e-4 * p0)                                # first momentum step: accum = grad + wd * var
+    assert float((a['P'].to(total.device) - after).norm()) < 1e-4 * float((after - p0).norm()) + 1e-7 * float(p0.norm())

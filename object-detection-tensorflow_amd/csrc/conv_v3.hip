@@ -2260,6 +2260,7 @@ int launch_wgrad_c64(WgradArgs& a, hipStream_t st) {
 }
 
 bool wgrad_v3_supported(const WgradArgs& a, int dtype) {
+    // (K = 64 with fewer than 256 columns -- conv1_1's 72 -- stays on conv_wgrad_dma_kernel: 185 us there, 208 us here, measured in round 2)
     return dtype == ODTK_BF16 && (a.K > 64 || (a.K == 64 && a.RSC >= 256)) && a.lddy % 8 == 0 && a.ldx % 8 == 0 && a.C % 8 == 0 &&
            (long long)a.P * a.lddy * 2 < (1ll << 31) && (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31);
 }

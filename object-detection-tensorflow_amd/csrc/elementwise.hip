@@ -5,6 +5,7 @@
 // Reference call sites: SSD300.py:52-63 (mean subtraction), :539-547 (max_pooling2d SAME),
 // :506-512 (batch_normalization), :74-83 (l2_normalize * scalar), :149-154 (MomentumOptimizer
 // + l2_loss over all trainables).
+#include <initializer_list>
 #include "common.h"
 
 namespace odtk {
@@ -1845,6 +1846,291 @@ __global__ void __launch_bounds__(GN_THREADS) gn_bwd_kernel(const T* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Group norm on 16-byte channel chunks (round 2).  The kernels above give one workgroup a (sample, group) pair and walk its HW x (C / groups) elements
+// one 2-byte load at a time -- with 2..8 channels per group that is 4..16 useful bytes per pixel row and an integer division per element: the FCOS
+// step spent 79 % of its time there (gn_bwd 38 ms, gn_fwd 11 ms of 61.5 ms at 512 x 512, batch 16).  Here rows are read as whole chunks (8 bf16 / 4 f32
+// channels per lane, 8 chunk lanes x 32 row lanes per workgroup, the batch-norm kernels' shape), per-CHANNEL sums are reduced over row splits, a small
+// finalize kernel folds the channels of a group (in double: the channels carry different shifts), and the apply pass is elementwise.
+// ws: [N][splits][2][Cp] channel sums; st: [N][groups][2] mean / rstd (forward) or m1 / m2 (backward).
+template <typename T>
+__global__ void __launch_bounds__(256) gn_chunk_stats_kernel(const T* __restrict__ x, int ldx, int HW, int C, int Cp, int rows_per_split,
+                                                             float* __restrict__ ws) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    const int split = blockIdx.y, nsplit = gridDim.y, n = blockIdx.z;
+    const T* xs = x + (size_t)n * HW * ldx;
+    float acc[2 * KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        float sh[KC];
+        Chunk<T>::unpack(ld16(xs + c0), sh);                            // the sample's first row: the same shift in every split
+        const int m0 = split * rows_per_split;
+        int m1 = m0 + rows_per_split; if (m1 > HW) m1 = HW;
+#pragma unroll 4
+        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(xs + (size_t)m * ldx + c0), f);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                const float d = f[e] - sh[e];
+                acc[e] += d;
+                acc[KC + e] += d * d;
+            }
+        }
+    }
+    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    if (rl == 0 && c0 < C) {
+        float* w = ws + ((size_t)(n * nsplit + split) * 2) * Cp + c0;
+#pragma unroll
+        for (int e = 0; e < KC; ++e) { w[e] = acc[e]; w[Cp + e] = acc[KC + e]; }
+    }
+}
+
+// one workgroup per sample, one thread per group: mean / rstd from the channel sums
+template <typename T>
+__global__ void __launch_bounds__(256) gn_chunk_finalize_kernel(const T* __restrict__ x, int ldx, int HW, int C, int Cp, int groups, int nsplit,
+                                                                const float* __restrict__ ws, float* __restrict__ st) {
+    const int n = blockIdx.x, cg = C / groups;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double sx = 0.0, sxx = 0.0;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int s = 0; s < nsplit; ++s) {
+                const float* w = ws + ((size_t)(n * nsplit + s) * 2) * Cp + c;
+                s1 += (double)w[0]; s2 += (double)w[Cp];
+            }
+            const double sh = (double)elem<T>::load(x[(size_t)n * HW * ldx + c]);
+            sx += s1 + (double)HW * sh;
+            sxx += s2 + 2.0 * sh * s1 + (double)HW * sh * sh;
+        }
+        const double cnt = (double)HW * cg;
+        const double mean = sx / cnt;
+        double var = sxx / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[((size_t)n * groups + g) * 2] = (float)mean;
+        st[((size_t)n * groups + g) * 2 + 1] = rsqrtf((float)var + 1e-6f);
+    }
+}
+
+// The same two finalize steps with 64 channels x 4 split lanes per workgroup, grid (C / 64, N), for group sizes that divide 64 (every FCOS layer: 2 .. 64
+// channels per group): the one-thread-per-group loops above walked up to 64 channels x 128 splits serially and took 3.7 + 3.6 ms of a 24.8 ms FCOS step.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_chunk_finalize64_kernel(const T* __restrict__ x, int ldx, int HW, int C, int Cp, int groups, int nsplit,
+                                                                  const float* __restrict__ ws, float* __restrict__ st) {
+    __shared__ float s_a[4][64], s_b[4][64];
+    __shared__ double s_x[64], s_xx[64];
+    const int n = blockIdx.y, cl = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, cg = C / groups;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int s = sl; s < nsplit; s += 4) {
+            const float* w = ws + ((size_t)(n * nsplit + s) * 2) * Cp + c;
+            a += w[0]; b += w[Cp];
+        }
+    s_a[sl][cl] = a; s_b[sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        const double s1 = ((double)s_a[0][cl] + (double)s_a[1][cl]) + ((double)s_a[2][cl] + (double)s_a[3][cl]);
+        const double s2 = ((double)s_b[0][cl] + (double)s_b[1][cl]) + ((double)s_b[2][cl] + (double)s_b[3][cl]);
+        const double sh = (double)elem<T>::load(x[(size_t)n * HW * ldx + c]);
+        s_x[cl] = s1 + (double)HW * sh;
+        s_xx[cl] = s2 + 2.0 * sh * s1 + (double)HW * sh * sh;
+    }
+    __syncthreads();
+    const int gl = threadIdx.x;                             // group inside this block
+    if (gl < 64 / cg && blockIdx.x * 64 + gl * cg < C) {
+        double sx = 0.0, sxx = 0.0;
+        for (int j = 0; j < cg; ++j) { sx += s_x[gl * cg + j]; sxx += s_xx[gl * cg + j]; }
+        const double cnt = (double)HW * cg;
+        const double mean = sx / cnt;
+        double var = sxx / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const int g = (blockIdx.x * 64) / cg + gl;
+        st[((size_t)n * groups + g) * 2] = (float)mean;
+        st[((size_t)n * groups + g) * 2 + 1] = rsqrtf((float)var + 1e-6f);
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_chunk_bwd_finalize64_kernel(int HW, int C, int Cp, int groups, int nsplit, const float* __restrict__ ws,
+                                                                      const float* __restrict__ gamma, float* __restrict__ part, float* __restrict__ st) {
+    __shared__ float s_a[4][64], s_b[4][64], s_gb[64], s_gg[64];
+    const int n = blockIdx.y, cl = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, cg = C / groups;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int s = sl; s < nsplit; s += 4) {
+            const float* w = ws + ((size_t)(n * nsplit + s) * 2) * Cp + c;
+            a += w[0]; b += w[Cp];
+        }
+    s_a[sl][cl] = a; s_b[sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        const float sb = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
+        const float sg = (s_b[0][cl] + s_b[1][cl]) + (s_b[2][cl] + s_b[3][cl]);
+        part[((size_t)n * 2 + 0) * C + c] = sg;
+        part[((size_t)n * 2 + 1) * C + c] = sb;
+        s_gb[cl] = gamma[c] * sb;
+        s_gg[cl] = gamma[c] * sg;
+    }
+    __syncthreads();
+    const int gl = threadIdx.x;
+    if (gl < 64 / cg && blockIdx.x * 64 + gl * cg < C) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int j = 0; j < cg; ++j) { a1 += s_gb[gl * cg + j]; a2 += s_gg[gl * cg + j]; }
+        const float cnt = (float)HW * (float)cg;
+        const int g = (blockIdx.x * 64) / cg + gl;
+        st[((size_t)n * groups + g) * 2] = a1 / cnt;
+        st[((size_t)n * groups + g) * 2 + 1] = a2 / cnt;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_chunk_apply_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int HW, int C, int groups,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                             const float* __restrict__ st, int rows_per_block) {
+    constexpr int KC = Chunk<T>::N;
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    if (c0 >= C) return;
+    const int n = blockIdx.z, cg = C / groups;
+    float sc[KC], of[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        const int g = (c0 + e) / cg;
+        const float mean = st[((size_t)n * groups + g) * 2], rstd = st[((size_t)n * groups + g) * 2 + 1];
+        sc[e] = rstd * gamma[c0 + e];
+        of[e] = beta[c0 + e] - mean * sc[e];
+    }
+    const size_t base = (size_t)n * HW;
+    const int m0 = blockIdx.y * rows_per_block;
+    int m1 = m0 + rows_per_block; if (m1 > HW) m1 = HW;
+    for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+        float f[KC];
+        Chunk<T>::unpack(ld16(x + (base + m) * ldx + c0), f);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            f[e] = f[e] * sc[e] + of[e];
+            if (relu) f[e] = fmaxf(f[e], 0.f);
+        }
+        st16(y + (base + m) * ldy + c0, Chunk<T>::pack(f));
+    }
+}
+
+// backward: per-channel sums of dy' (ReLU-masked) and dy' * xhat over a row split
+template <typename T>
+__global__ void __launch_bounds__(256) gn_chunk_bwd_stats_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y, const T* __restrict__ dy, int ldy,
+                                                                 int HW, int C, int Cp, int groups, const float* __restrict__ save, int relu,
+                                                                 int rows_per_split, float* __restrict__ ws) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    const int split = blockIdx.y, nsplit = gridDim.y, n = blockIdx.z, cg = C / groups;
+    float acc[2 * KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        float mu[KC], rs[KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            const int g = (c0 + e) / cg;
+            mu[e] = save[((size_t)n * groups + g) * 2]; rs[e] = save[((size_t)n * groups + g) * 2 + 1];
+        }
+        const size_t base = (size_t)n * HW;
+        const int m0 = split * rows_per_split;
+        int m1 = m0 + rows_per_split; if (m1 > HW) m1 = HW;
+#pragma unroll 2
+        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+            float f[KC], d[KC], yy[KC];
+            Chunk<T>::unpack(ld16(x + (base + m) * ldx + c0), f);
+            Chunk<T>::unpack(ld16(dy + (base + m) * ldy + c0), d);
+            if (relu) Chunk<T>::unpack(ld16(y + (base + m) * ldy + c0), yy);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                const float dd = (relu && !(yy[e] > 0.f)) ? 0.f : d[e];
+                acc[e] += dd;
+                acc[KC + e] += dd * ((f[e] - mu[e]) * rs[e]);
+            }
+        }
+    }
+    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    if (rl == 0 && c0 < C) {
+        float* w = ws + ((size_t)(n * nsplit + split) * 2) * Cp + c0;
+#pragma unroll
+        for (int e = 0; e < KC; ++e) { w[e] = acc[e]; w[Cp + e] = acc[KC + e]; }
+    }
+}
+
+// one workgroup per sample: channel totals -> part [N][2][C] (dgamma, dbeta shares of this sample); group means m1 = mean(dy' gamma), m2 = mean(dy' gamma xhat)
+__global__ void __launch_bounds__(256) gn_chunk_bwd_finalize_kernel(int HW, int C, int Cp, int groups, int nsplit, const float* __restrict__ ws,
+                                                                    const float* __restrict__ gamma, float* __restrict__ part, float* __restrict__ st) {
+    const int n = blockIdx.x, cg = C / groups;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sb = 0.f, sg = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+            const float* w = ws + ((size_t)(n * nsplit + s) * 2) * Cp + c;
+            sb += w[0]; sg += w[Cp];
+        }
+        part[((size_t)n * 2 + 0) * C + c] = sg;
+        part[((size_t)n * 2 + 1) * C + c] = sb;
+    }
+    for (int g = threadIdx.x; g < groups; g += 256) {      // (re-summed from ws: no read-back of this block's own global stores)
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            float sb = 0.f, sg = 0.f;
+            for (int s = 0; s < nsplit; ++s) {
+                const float* w = ws + ((size_t)(n * nsplit + s) * 2) * Cp + c;
+                sb += w[0]; sg += w[Cp];
+            }
+            a1 += gamma[c] * sb;
+            a2 += gamma[c] * sg;
+        }
+        const float cnt = (float)HW * (float)cg;
+        st[((size_t)n * groups + g) * 2] = a1 / cnt;
+        st[((size_t)n * groups + g) * 2 + 1] = a2 / cnt;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_chunk_bwd_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y, const T* __restrict__ dy, int ldy,
+                                                                 T* __restrict__ dx, int lddx, int HW, int C, int groups, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ save, const float* __restrict__ st, int relu, int accumulate,
+                                                                 int rows_per_block) {
+    constexpr int KC = Chunk<T>::N;
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    if (c0 >= C) return;
+    const int n = blockIdx.z, cg = C / groups;
+    float mu[KC], rs[KC], gm[KC], m1[KC], m2[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        const int g = (c0 + e) / cg;
+        mu[e] = save[((size_t)n * groups + g) * 2]; rs[e] = save[((size_t)n * groups + g) * 2 + 1];
+        m1[e] = st[((size_t)n * groups + g) * 2]; m2[e] = st[((size_t)n * groups + g) * 2 + 1];
+        gm[e] = gamma[c0 + e];
+    }
+    const size_t base = (size_t)n * HW;
+    const int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block; if (r1 > HW) r1 = HW;
+    for (int m = r0 + rl; m < r1; m += RED_ROWS) {
+        float f[KC], d[KC], yy[KC], o[KC];
+        Chunk<T>::unpack(ld16(x + (base + m) * ldx + c0), f);
+        Chunk<T>::unpack(ld16(dy + (base + m) * ldy + c0), d);
+        if (relu) Chunk<T>::unpack(ld16(y + (base + m) * ldy + c0), yy);
+        if (accumulate) Chunk<T>::unpack(ld16(dx + (base + m) * lddx + c0), o);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            const float dd = (relu && !(yy[e] > 0.f)) ? 0.f : d[e];
+            const float xh = (f[e] - mu[e]) * rs[e];
+            const float v = rs[e] * (dd * gm[e] - m1[e] - xh * m2[e]);
+            o[e] = accumulate ? o[e] + v : v;
+        }
+        st16(dx + (base + m) * lddx + c0, Chunk<T>::pack(o));
+    }
+}
+
 __global__ void gn_param_grad_kernel(const float* __restrict__ part, int N, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -1859,11 +2145,69 @@ __global__ void gn_param_grad_kernel(const float* __restrict__ part, int N, int 
 
 extern "C" long long odtk_gn_workspace_bytes(int N, int C) { return (long long)N * 2 * C * sizeof(float); }
 
+// per-device scratch of the chunked group-norm path: channel sums per row split + the per-(sample, group) statistics.  Grown on demand, never freed or
+// moved once handed out (captured graphs keep pointing into it); launches are stream-ordered by the caller.
+static float* g_gn_scratch[16];
+static size_t g_gn_scratch_bytes[16];
+static int gn_scratch(size_t bytes, float** out) {
+    int dev = 0;
+    ODTK_CHECK_HIP(hipGetDevice(&dev));
+    ODTK_REQUIRE(dev >= 0 && dev < 16, "gn: device index %d unsupported", dev);
+    if (g_gn_scratch_bytes[dev] < bytes) {
+        size_t want = g_gn_scratch_bytes[dev] ? 2 * g_gn_scratch_bytes[dev] : ((size_t)8 << 20);
+        if (want < bytes) want = bytes;
+        void* p = nullptr;
+        ODTK_CHECK_HIP(hipMalloc(&p, want));              // fails inside a stream capture: run one eager step first
+        g_gn_scratch[dev] = (float*)p; g_gn_scratch_bytes[dev] = want;
+    }
+    *out = g_gn_scratch[dev];
+    return ODTK_OK;
+}
+
+struct GnPlan { int kc, colgroups, Cp, nsplit, rows_per_split, rows_per_block; bool chunked; };
+static GnPlan gn_plan(int N, int HW, int C, int dtype, std::initializer_list<int> pitches, std::initializer_list<const void*> ptrs) {
+    GnPlan p;
+    p.kc = dtype == ODTK_BF16 ? 8 : 4;
+    p.chunked = C % p.kc == 0;
+    for (int ld : pitches) p.chunked = p.chunked && ld % p.kc == 0;
+    for (const void* q : ptrs) p.chunked = p.chunked && ((uintptr_t)q % 16) == 0;
+    p.colgroups = ceil_div(C, 8 * p.kc);
+    p.Cp = p.colgroups * 8 * p.kc;
+    int want = ceil_div(1024, N * p.colgroups);          // enough workgroups to fill the chip
+    const int maxs = ceil_div(HW, 4 * RED_ROWS);
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 128) want = 128;
+    p.rows_per_split = ceil_div(HW, want);
+    p.nsplit = ceil_div(HW, p.rows_per_split);
+    p.rows_per_block = p.rows_per_split < 256 ? p.rows_per_split : 256;
+    return p;
+}
+
 extern "C" int odtk_gn_fwd(const void* x, int ldx, void* y, int ldy, int N, int HW, int C, int groups, int dtype, const float* gamma,
                            const float* beta, int relu, float* save_mean_rstd, void* stream) {
     ODTK_REQUIRE(x && y && gamma && beta, "gn_fwd: null pointer");
     ODTK_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && ldx >= C && ldy >= C, "gn_fwd: N=%d HW=%d C=%d groups=%d", N, HW, C, groups);
-    DT_SWITCH(dtype, T, hipLaunchKernelGGL(gn_fwd_kernel<T>, dim3(groups, N), dim3(GN_THREADS), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, HW, C,
+    hipStream_t st = (hipStream_t)stream;
+    const GnPlan pl = gn_plan(N, HW, C, dtype, {ldx, ldy}, {x, y});
+    if (pl.chunked) {
+        float* scr = nullptr;
+        const size_t wsn = (size_t)N * pl.nsplit * 2 * pl.Cp, stn = (size_t)N * groups * 2;
+        if (int e = gn_scratch((wsn + stn) * sizeof(float), &scr)) return e;
+        float* stat = save_mean_rstd ? save_mean_rstd : scr + wsn;
+        const bool fin64 = 64 % (C / groups) == 0;             // whole groups inside a 64-channel block
+        DT_SWITCH(dtype, T,
+                  hipLaunchKernelGGL(gn_chunk_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit, N), dim3(256), 0, st, (const T*)x, ldx, HW, C, pl.Cp,
+                                     pl.rows_per_split, scr);
+                  if (fin64) hipLaunchKernelGGL(gn_chunk_finalize64_kernel<T>, dim3(ceil_div(C, 64), N), dim3(256), 0, st, (const T*)x, ldx, HW, C, pl.Cp, groups,
+                                                pl.nsplit, scr, stat);
+                  else hipLaunchKernelGGL(gn_chunk_finalize_kernel<T>, dim3(N), dim3(256), 0, st, (const T*)x, ldx, HW, C, pl.Cp, groups, pl.nsplit, scr, stat);
+                  hipLaunchKernelGGL(gn_chunk_apply_kernel<T>, dim3(pl.colgroups, ceil_div(HW, pl.rows_per_block), N), dim3(256), 0, st, (const T*)x, ldx,
+                                     (T*)y, ldy, HW, C, groups, gamma, beta, relu, stat, pl.rows_per_block);)
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(gn_fwd_kernel<T>, dim3(groups, N), dim3(GN_THREADS), 0, st, (const T*)x, ldx, (T*)y, ldy, HW, C,
                                            groups, gamma, beta, relu, save_mean_rstd);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
@@ -1877,8 +2221,26 @@ extern "C" int odtk_gn_bwd(const void* x, int ldx, const void* y, const void* dy
     ODTK_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && ldx >= C && ldy >= C && lddx >= C, "gn_bwd: N=%d HW=%d C=%d groups=%d", N, HW, C, groups);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
-    DT_SWITCH(dtype, T, hipLaunchKernelGGL(gn_bwd_kernel<T>, dim3(groups, N), dim3(GN_THREADS), 0, st, (const T*)x, ldx, (const T*)y, (const T*)dy, ldy,
-                                           (T*)dx, lddx, HW, C, groups, gamma, save_mean_rstd, relu, accumulate & 1, part);)
+    const GnPlan pl = gn_plan(N, HW, C, dtype, {ldx, ldy, lddx}, {x, dy, dx, relu ? y : x});
+    if (pl.chunked) {
+        float* scr = nullptr;
+        const size_t wsn = (size_t)N * pl.nsplit * 2 * pl.Cp, stn = (size_t)N * groups * 2;
+        if (int e = gn_scratch((wsn + stn) * sizeof(float), &scr)) return e;
+        float* stat = scr + wsn;
+        const bool fin64 = 64 % (C / groups) == 0;
+        DT_SWITCH(dtype, T,
+                  hipLaunchKernelGGL(gn_chunk_bwd_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit, N), dim3(256), 0, st, (const T*)x, ldx, (const T*)y,
+                                     (const T*)dy, ldy, HW, C, pl.Cp, groups, save_mean_rstd, relu, pl.rows_per_split, scr);
+                  if (fin64) hipLaunchKernelGGL(gn_chunk_bwd_finalize64_kernel, dim3(ceil_div(C, 64), N), dim3(256), 0, st, HW, C, pl.Cp, groups, pl.nsplit, scr,
+                                                gamma, part, stat);
+                  else hipLaunchKernelGGL(gn_chunk_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, HW, C, pl.Cp, groups, pl.nsplit, scr, gamma, part, stat);
+                  hipLaunchKernelGGL(gn_chunk_bwd_apply_kernel<T>, dim3(pl.colgroups, ceil_div(HW, pl.rows_per_block), N), dim3(256), 0, st, (const T*)x,
+                                     ldx, (const T*)y, (const T*)dy, ldy, (T*)dx, lddx, HW, C, groups, gamma, save_mean_rstd, stat, relu, accumulate & 1,
+                                     pl.rows_per_block);)
+    } else {
+        DT_SWITCH(dtype, T, hipLaunchKernelGGL(gn_bwd_kernel<T>, dim3(groups, N), dim3(GN_THREADS), 0, st, (const T*)x, ldx, (const T*)y, (const T*)dy, ldy,
+                                               (T*)dx, lddx, HW, C, groups, gamma, save_mean_rstd, relu, accumulate & 1, part);)
+    }
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, N, C, dgamma, dbeta, accumulate & 2);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;

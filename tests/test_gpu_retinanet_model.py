@@ -194,7 +194,10 @@ def test_group_norm_kernels(dev, dt):
     from odtk import ops
     tdt = torch.float32 if dt == 'f32' else torch.bfloat16
     g = torch.Generator().manual_seed(4)
-    for (N, H, W, C, ld, groups) in [(2, 5, 7, 16, 16, 8), (3, 4, 4, 64, 72, 8), (2, 9, 3, 256, 256, 8), (1, 6, 5, 24, 24, 8), (2, 1, 2, 256, 256, 8)]:
+    # (the chunked kernels of round 2 take every shape whose channels and pitches are whole 16-byte chunks; 64 % (C / groups) == 0 selects the
+    #  parallel finalize; C = 20 falls back to the element-wise kernels; 40 x 40 and 33 x 31 maps are reduced over several row splits)
+    for (N, H, W, C, ld, groups) in [(2, 5, 7, 16, 16, 8), (3, 4, 4, 64, 72, 8), (2, 9, 3, 256, 256, 8), (1, 6, 5, 24, 24, 8), (2, 1, 2, 256, 256, 8),
+                                     (2, 40, 40, 64, 64, 32), (2, 33, 31, 128, 136, 32), (1, 8, 8, 2048, 2048, 32), (1, 6, 5, 20, 20, 4)]:
         HW = H * W
         x = (torch.randn(N * HW, ld, generator=g) * 2 + 0.7).to(tdt)
         gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)), 0.2 * torch.randn(C, generator=g)

@@ -246,7 +246,7 @@ def main():
         odtk._lib.load().odtk_debug_set(2, args.kernel_dbg)
     for kv in filter(None, args.debug_set.split(',')):
         k, v = kv.split(':')
-        assert int(k) in (3, 4, 5), 'only the dispatch switches leave results intact'
+        assert int(k) in (3, 4, 5), 'only the dispatch switches leave results intact'  # (values may be negative: 4:-1)
         odtk._lib.load().odtk_debug_set(int(k), int(v))
     config = {
         'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,

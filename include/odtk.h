@@ -51,7 +51,8 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         variant, 27 no 128x512 halo tiles, 28 no 128x192 halo tiles, 29 no four-wave filter-gradient kernel (v8), 30 v8 also on
  *         short pixel ranges;
  * key 3 = single-kernel NMS (value != 0);
- * key 4 = batch norm: maps of up to `value` rows run statistics + finalize + apply in ONE launch (default 1024, 0 = never);
+ * key 4 = batch norm: maps of up to `value` rows run statistics + finalize + apply in ONE launch (default 1024, 0 = never); larger maps take three
+ *         (statistics, finalize, apply); value -2 = two (apply with the finalize folded in: measured slower, A/B only), -1 = back to three;
  * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
  *         run, 2.5 % slower on the SSD300 step) instead of float atomics into dw (the default) */
 int odtk_debug_set(int key, int value);

@@ -444,6 +444,89 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     }
 }
 
+// Training-mode apply with the finalize step folded in (round 2 experiment, OFF by default: odtk_debug_set(4, -2)).  One launch less per batch norm, but
+// measured SLOWER: YOLOv3 416 x 416 batch 8 12.10 ms/step against 11.01 with the separate finalize kernel, SSD300 equal -- every one of the apply pass's
+// workgroups re-reduces the partials, which costs more than the 2-16 workgroup finalize launch it saves.  Every workgroup reduces the row-split partials of ITS 8 chunks of channels (32 row lanes
+// take the splits, then the LDS tree of the statistics kernel), derives scale / offset, and the workgroups of the first row block also write save_mean /
+// save_invstd and update the moving statistics.
+template <typename T, typename TY>
+__global__ void __launch_bounds__(256) bn_apply_fin_kernel(
+    const T* __restrict__ z, int M, int C, int ldz, int relu, TY* __restrict__ y, int ldy, int rows_per_img, long long y_img_stride, int vec_ok,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mmean, float* __restrict__ mvar,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, const float* __restrict__ ws, int nsplit, int rows_per_block) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    float acc[2 * KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+    if (c0 < C)
+        for (int s = rl; s < nsplit; s += RED_ROWS) {
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                if (c0 + e < C) {
+                    acc[e] += ws[((size_t)0 * nsplit + s) * C + c0 + e];
+                    acc[KC + e] += ws[((size_t)1 * nsplit + s) * C + c0 + e];
+                }
+            }
+        }
+    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    if (c0 >= C) return;
+    float sh[KC], sc[KC], of[KC];
+    Chunk<T>::unpack(ld16(z + c0), sh);
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        sc[e] = 0.f; of[e] = 0.f;
+        const int c = c0 + e;
+        if (c >= C) continue;
+        const float d = acc[e] / (float)M;
+        const float mean = sh[e] + d;
+        const float var = fmaxf(acc[KC + e] / (float)M - d * d, 0.f);
+        const float inv = rsqrtf(var + 1e-3f);
+        sc[e] = inv * gamma[c];
+        of[e] = beta[c] - mean * sc[e];
+        if (blockIdx.y == 0 && rl == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = inv;
+            const float unb = var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+            mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
+            mvar[c] = mvar[c] * 0.99f + unb * (1.f - 0.99f);
+        }
+    }
+    const int m0 = blockIdx.y * rows_per_block;
+    int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+    const bool full = c0 + KC <= C;
+    for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+        float f[KC];
+        Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            f[e] = f[e] * sc[e] + of[e];
+            if (relu == 1) f[e] = fmaxf(f[e], 0.f);
+            else if (relu == 2) f[e] = f[e] > 0.f ? f[e] : 0.1f * f[e];
+        }
+        TY* yp = y + out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+        if (full && vec_ok) {
+            if (sizeof(TY) == 2) {
+                float f8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f8[e] = f[e % KC];
+                st16(reinterpret_cast<bf16_t*>(yp), Chunk<bf16_t>::pack(f8));   // only reached when KC == 8
+            } else {
+#pragma unroll
+                for (int q = 0; q < KC / 4; ++q)
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yp) + 4 * q) =
+                        make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < KC; ++e)
+                if (c0 + e < C) yp[e] = elem<TY>::store(f[e]);
+        }
+    }
+}
+
 // dy / y operands of the BN backward kernels: one 16-byte load per chunk when the (y, dy) layout allows it (bf16 rows with a
 // 16-byte-aligned pitch: every extra layer), element loads otherwise (the heads read d(pred) rows of 25 floats).
 template <typename T, typename TY>
@@ -551,6 +634,65 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
             gs[e] = gamma[c] * iv[e];
             k1[e] = fin[c];
             k2[e] = fin[C + c];
+        }
+    }
+    const int m0 = blockIdx.y * rows_per_block;
+    int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+    for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+        float f[KC], o[KC];
+        Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+        const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+        float d[KC];
+        bn_load_dy<T, TY>(y, dy, oo, c0, C, relu, vec_ok, d);
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            o[e] = 0.f;
+            if (c0 + e >= C) continue;
+            const float xh = (f[e] - mu[e]) * iv[e];
+            o[e] = gs[e] * (d[e] - k1[e] - xh * k2[e]);
+        }
+        st16(dz + (size_t)m * ldz + c0, Chunk<T>::pack(o));
+    }
+}
+
+// backward apply with the finalize step folded in (see bn_apply_fin_kernel): the row-split partials of sum(dy') and sum(dy' * xhat) are reduced by every
+// workgroup for its own channels; the workgroups of the first row block write dgamma / dbeta.
+template <typename T, typename TY>
+__global__ void __launch_bounds__(256) bn_bwd_apply_fin_kernel(
+    const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
+    int rows_per_img, long long y_img_stride, const float* __restrict__ gamma,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, int vec_ok, T* __restrict__ dz,
+    const float* __restrict__ ws, int nsplit, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows_per_block) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    float acc[2 * KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+    if (c0 < C)
+        for (int s = rl; s < nsplit; s += RED_ROWS) {
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                if (c0 + e < C) {
+                    acc[e] += ws[((size_t)0 * nsplit + s) * C + c0 + e];
+                    acc[KC + e] += ws[((size_t)1 * nsplit + s) * C + c0 + e];
+                }
+            }
+        }
+    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    if (c0 >= ldz) return;
+    float mu[KC], iv[KC], gs[KC], k1[KC], k2[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        const int c = c0 + e;
+        mu[e] = 0.f; iv[e] = 0.f; gs[e] = 0.f; k1[e] = 0.f; k2[e] = 0.f;
+        if (c < C) {
+            mu[e] = save_mean[c]; iv[e] = save_invstd[c];
+            gs[e] = gamma[c] * iv[e];
+            k1[e] = acc[e] / (float)M;
+            k2[e] = acc[KC + e] / (float)M;
+            if (blockIdx.y == 0 && rl == 0) { dbeta[c] = acc[e]; dgamma[c] = acc[KC + e]; }
         }
     }
     const int m0 = blockIdx.y * rows_per_block;
@@ -961,8 +1103,9 @@ inline RedPlan red_plan(int M, int C, int kc) {
 
 using namespace odtk;
 
-static int g_bn_small_rows = 1024;        // odtk_debug_set key 4
-namespace odtk { void set_bn_small_rows(int rows) { g_bn_small_rows = rows; } }
+static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0)
+static bool g_bn_three_kernels = true;    // odtk_debug_set key 4, value -2: statistics + apply-with-finalize (two launches; A/B, tests); -1: back to three
+namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else g_bn_small_rows = rows; } }
 
 #define DT_SWITCH(dtype, T, ...)                                         \
     if ((dtype) == ODTK_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
@@ -1084,6 +1227,21 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     if (training) {
         DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
                                                (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
+        if (!g_bn_three_kernels) {                       // statistics, then apply with the finalize folded in
+            const int rpb = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
+            dim3 gridf(pl.colgroups, ceil_div(M, rpb));
+#define BN_APPLY_FIN(T, TY)                                                                                                  \
+    hipLaunchKernelGGL((bn_apply_fin_kernel<T, TY>), gridf, dim3(256), 0, st, (const T*)z, M, C, ldz, relu, (TY*)y, ldy,     \
+                       rows_per_img, y_img_stride, vec_ok, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, ws, \
+                       pl.nsplit, rpb)
+            if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) BN_APPLY_FIN(bf16_t, bf16_t);
+            else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) BN_APPLY_FIN(bf16_t, float);
+            else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) BN_APPLY_FIN(float, float);
+            else ODTK_REQUIRE(false, "bn_fwd: bad dtype");
+#undef BN_APPLY_FIN
+            ODTK_LAUNCH_CHECK();
+            return ODTK_OK;
+        }
     }
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M,
                                            C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
@@ -1134,6 +1292,21 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
         else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD_SMALL(float, float); }
         else ODTK_REQUIRE(false, "bn_bwd: bad dtype");
 #undef BN_BWD_SMALL
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
+    if (!g_bn_three_kernels) {                           // sums, then apply with the finalize folded in
+#define BN_BWD_FIN(T, TY)                                                                                                       \
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz,   \
+                       ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu, vec_ok, pl.rows_per_split, ws);             \
+    hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C,    \
+                       ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, ws, pl.nsplit,  \
+                       dgamma, dbeta, rows_per_block)
+        if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_BWD_FIN(bf16_t, bf16_t); }
+        else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_BWD_FIN(bf16_t, float); }
+        else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD_FIN(float, float); }
+        else ODTK_REQUIRE(false, "bn_bwd: bad dtype");
+#undef BN_BWD_FIN
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }

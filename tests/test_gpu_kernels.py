@@ -330,16 +330,19 @@ def test_maxpool2x2_recorded_argmax_equals_gather_path(geom, dt, dev):
 @pytest.mark.parametrize("shape", [(2 * 19 * 19, 1024, True), (2 * 38 * 38, 100, False), (3 * 5 * 5, 150, False),
                                    (2 * 3 * 3, 256, True),
                                    (6 * 38 * 38, 100, False), (14 * 19 * 19, 256, True)])   # M > 4096: split-row path
-@pytest.mark.parametrize("one_launch", [True, False], ids=["small-fused", "three-kernel"])
-def test_batchnorm(shape, dt, ydt, one_launch, dev):
-    """Maps of <= 1024 rows take the single-launch kernels (statistics + finalize + apply in one workgroup per 64 channels; here
-    the limit is raised to 4096 rows to cover more shapes); odtk_debug_set(4, 0) sends every map down the three-kernel path."""
+@pytest.mark.parametrize("launches", [1, 2, 3], ids=["one-launch", "two-launches", "three-launches"])
+def test_batchnorm(shape, dt, ydt, launches, dev):
+    """Maps of <= 1024 rows take the single-launch kernels (statistics + finalize + apply in one workgroup per 64 channels; here the limit is raised to
+    4096 rows to cover more shapes); larger maps three (statistics, finalize, apply); odtk_debug_set(4, -2) selects the two-launch variant (apply with
+    the finalize folded in -- measured slower, kept for A/B)."""
     ops = _ops()
-    ops.debug_set(4, 4096 if one_launch else 0)
+    ops.debug_set(4, 4096 if launches == 1 else 0)
+    ops.debug_set(4, -1 if launches == 3 else -2)
     try:
         _batchnorm_case(ops, shape, dt, ydt, dev)
     finally:
         ops.debug_set(4, 1024)
+        ops.debug_set(4, -1)
 
 
 def _batchnorm_case(ops, shape, dt, ydt, dev):

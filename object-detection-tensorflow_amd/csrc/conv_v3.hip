@@ -2115,7 +2115,9 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     int ksplit = 1;
     const int halo = 2 * a.dil * (a.W + 1);               // patch rows beyond the 256 of the tile
     // wide maps (conv2_x, W = 150): single-buffer variant, groups 0..3 / 4..8 of the next chunk ride on taps 3 / 6 (dbg bit 26 = off, A/B)
-    const bool v6_wide = halo > 160 && halo <= 320 && a.dil * a.W >= 144 && !(a.dbg & (1 << 26));
+    // (round 2: rows of 96 .. 143 pixels too -- CenterNet / FCOS 128, YOLOv3 104, YOLOv2 120 -- with their own early-refill group counts G1, G2)
+    const bool v6_wide = halo > 160 && halo <= 320 && a.dil * a.W >= 96 && !(a.dbg & (1 << 26));
+    const bool v6_wide_hi = v6_wide && a.dil * a.W >= 144;   // what the 512-pixel tile variants are instantiated for
     const bool v6_ok = !(a.dbg & 65536) && PT == 128 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
                        a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && (halo <= 160 || v6_wide) && a.Kdim == 9 * a.C;
     const int v6_min_tiles = (a.dbg >> 18) & 255;         // A/B (dbg bits 18-25): halo kernel instead of split-K from this many tiles on
@@ -2127,7 +2129,7 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     // Cout <= 64 on the halo kernel: 64 x 512 tiles (dbg bit 27 = off, A/B)
     if (PT == 64 && ksplit < 2 && !(a.dbg & 65536) && !(a.dbg & (1 << 27)) && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
         a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && a.Kdim == 9 * a.C &&
-        ((halo <= 160 && a.dil * a.W >= 64) || v6_wide) && ceil_div(a.M, 512) >= 2 * 256) {
+        ((halo <= 160 && a.dil * a.W >= 64) || v6_wide_hi) && ceil_div(a.M, 512) >= 2 * 256) {
         a.ksplit = -1;
         a.tiles_q = ceil_div(a.M, 512);
         if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<21, false, 2, 4, 1, 2, 4>), dim3(a.tiles_q), dim3(256), 0, st, a);
@@ -2156,7 +2158,7 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         // (measured, same box: conv3_2 fwd 198 -> 180 us, dgrad 215 -> 199, conv3_1 fwd 116 -> 106, conv2_1 fwd 164 -> 157, conv2_2 fwd 228 -> 224; the
         // wide variant with a masked / accumulating epilogue -- conv2_2 dgrad -- is 2 % SLOWER: 64 more operand registers -> not used there)
         const bool post512 = a.accumulate || a.mask;
-        if (!(a.dbg & (1 << 27)) && tq512 * a.tiles_p >= 2 * g_num_cu && a.dil * a.W >= 64 && (halo <= 160 || !post512)) {
+        if (!(a.dbg & (1 << 27)) && tq512 * a.tiles_p >= 2 * g_num_cu && a.dil * a.W >= 64 && (halo <= 160 || (!post512 && v6_wide_hi))) {
             a.tiles_q = tq512;
             if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<21, false, 2, 4, 1, 4, 4>), dim3(tq512 * a.tiles_p), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_gather_v6_kernel<26, false, 4, 9, 1, 4, 4>), dim3(tq512 * a.tiles_p), dim3(256), 0, st, a);
@@ -2171,7 +2173,10 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
             return 0;
         }
         if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<13, true, 0, 0>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 9>), dim3(grid), dim3(256), 0, st, a);
+        else if (a.dil * a.W >= 144) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 9>), dim3(grid), dim3(256), 0, st, a);
+        else if (a.dil * a.W >= 128) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 8>), dim3(grid), dim3(256), 0, st, a);
+        else if (a.dil * a.W >= 112) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 7>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 6>), dim3(grid), dim3(256), 0, st, a);
         return 0;
     }
     if ((a.dbg & 32768) && PT == 128 && a.C % 64 == 0 && a.Kdim % 64 == 0) {      // 4-wave hand-scheduled variant (dbg bit 15, A/B)

@@ -313,6 +313,7 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ z, 
         Chunk<T>::unpack(ld16(z + c0), sh);
         const int m0 = split * rows_per_split;
         int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
+#pragma unroll 4
         for (int m = m0 + rl; m < m1; m += RED_ROWS) {
             float f[KC];
             Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
@@ -574,6 +575,7 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
         }
         const int m0 = split * rows_per_split;
         int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
+#pragma unroll 2
         for (int m = m0 + rl; m < m1; m += RED_ROWS) {
             float f[KC];
             Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
@@ -1092,7 +1094,11 @@ inline RedPlan red_plan(int M, int C, int kc) {
     int maxs = ceil_div(M, 4 * RED_ROWS);
     if (maxs < 1) maxs = 1;
     if (want > maxs) want = maxs;
-    if (want > 256) want = 256;
+    // the partials live in the workspace: 2 x 256 x ceil64(C) floats (odtk_bn_workspace_bytes) = 256 splits at full width, more for narrow
+    // layers (32 channels: 512) -- Darknet's first layers are 7.4 M rows x 32 channels, 256 splits left every workgroup 900 dependent iterations
+    int cap = 256 * (((C + 63) / 64) * 64) / C;
+    if (cap > 1024) cap = 1024;
+    if (want > cap) want = cap;
     p.rows_per_split = ceil_div(M, want);
     p.nsplit = ceil_div(M, p.rows_per_split);
     return p;

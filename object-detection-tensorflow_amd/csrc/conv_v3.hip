@@ -2116,8 +2116,9 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     const int halo = 2 * a.dil * (a.W + 1);               // patch rows beyond the 256 of the tile
     // wide maps (conv2_x, W = 150): single-buffer variant, groups 0..3 / 4..8 of the next chunk ride on taps 3 / 6 (dbg bit 26 = off, A/B)
     // (round 2: rows of 96 .. 143 pixels too -- CenterNet / FCOS 128, YOLOv3 104, YOLOv2 120 -- with their own early-refill group counts G1, G2)
-    const bool v6_wide = halo > 160 && halo <= 320 && a.dil * a.W >= 96 && !(a.dbg & (1 << 26));
-    const bool v6_wide_hi = v6_wide && a.dil * a.W >= 144;   // what the 512-pixel tile variants are instantiated for
+    // (and rows of 160 .. 175 pixels -- conv2_x of the 320-pixel models -- on a 608-row patch)
+    const bool v6_wide = halo > 160 && halo <= 352 && a.dil * a.W >= 96 && !(a.dbg & (1 << 26));
+    const bool v6_wide_hi = v6_wide && a.dil * a.W >= 144 && halo <= 320;   // what the 512-pixel tile variants are instantiated for
     const bool v6_ok = !(a.dbg & 65536) && PT == 128 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
                        a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && (halo <= 160 || v6_wide) && a.Kdim == 9 * a.C;
     const int v6_min_tiles = (a.dbg >> 18) & 255;         // A/B (dbg bits 18-25): halo kernel instead of split-K from this many tiles on
@@ -2173,6 +2174,7 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
             return 0;
         }
         if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<13, true, 0, 0>), dim3(grid), dim3(256), 0, st, a);
+        else if (halo > 320) hipLaunchKernelGGL((conv_gather_v6_kernel<19, false, 5, 10>), dim3(grid), dim3(256), 0, st, a);
         else if (a.dil * a.W >= 144) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 9>), dim3(grid), dim3(256), 0, st, a);
         else if (a.dil * a.W >= 128) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 8>), dim3(grid), dim3(256), 0, st, a);
         else if (a.dil * a.W >= 112) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 7>), dim3(grid), dim3(256), 0, st, a);

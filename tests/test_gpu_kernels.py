@@ -100,6 +100,8 @@ V3_EXTRA_CASES = [
     (1, 40, 128, 128, 128, 3, 1, 1),  # ... rows of 128 pixels (G1 = 4, G2 = 8), two chunks
     (1, 30, 104, 192, 64, 3, 1, 1),   # ... 104 (G1 = 3, G2 = 6), three chunks, 64-row filter tile falls back to the 8-wave kernel in forward
     (2, 24, 120, 128, 160, 3, 1, 1),  # ... 120 (G1 = 3, G2 = 7)
+    (1, 21, 160, 128, 128, 3, 1, 1),  # ... 160 and 175: the 608-row patch (G1 = 5, G2 = 10)
+    (1, 12, 175, 64, 130, 3, 1, 1),
     (24, 75, 75, 64, 200, 3, 1, 1),   # 128 x 512 tiles of four 128 x 128 wave tiles (>= 2 rounds of 256 workgroups): ragged last tile, channel tail
     (24, 19, 19, 64, 512, 3, 1, 1),   # 128 x 192 tiles (136 workgroups of 256 pixels would leave CUs idle, 184 of 192 pixels fit one round)
     (6, 20, 17, 256, 512, 3, 1, 1),   # four-wave filter gradient (256 x 256 tiles, fixture wgrad-v8): two k tiles, nine column tiles, ragged last 32-pixel slab

@@ -668,8 +668,99 @@ class RefineDet320:
         return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
 
     # ------------------------------------------------------------------ checkpoints / data parallel
+    # ------------------------------------------------------------------ the reference's variable names / tf.train.Saver files
+    VGG_NAME_TYPOS = {'conv2_1.w': 'kenrel_conv2_1', 'conv3_1.b': 'bias_conv_3_1'}       # as spelt in the reference (RefineDet.py:251, :271; PFPNetR.py alike)
+    MOMENTUM_SLOT_SCOPE = 'inference/'      # the optimizer is created inside `with tf.variable_scope('inference')` (RefineDet.py:97, :176)
+
+    def _tf_scope(self, name):
+        """(variable scope, explicit layer name or None) of a layer of self.specs: default layer names (conv2d, conv2d_transpose, batch_normalization) are
+        numbered per enclosing scope in creation order"""
+        if '.' in name:
+            block = name.split('.')[0]
+            return {'arm': 'ARM', 'tcb': 'TCB', 'odm': 'ODM'}[block[:3]] + '/' + block, None
+        return 'feature_extractor', (name if name.startswith('conv') else None)
+
+    def reference_variable_map(self):
+        """our parameter / statistic name -> the variable name in the reference's graph (checked against the shim's graph: tests/golden/*_names.json)"""
+        out, count = OrderedDict(), {}
+
+        def numbered(scope, base):
+            k = count.get((scope, base), 0)
+            count[(scope, base)] = k + 1
+            return f'{scope}/{base}' + (f'_{k}' if k else '')
+        for name, kind, *_ in self.specs:
+            if kind == 'vgg':
+                out[name + '.w'] = 'feature_extractor/' + self.VGG_NAME_TYPOS.get(name + '.w', 'kernel_' + name)
+                out[name + '.b'] = 'feature_extractor/' + self.VGG_NAME_TYPOS.get(name + '.b', 'bias_' + name)
+                continue
+            scope, explicit = self._tf_scope(name)
+            layer = f'{scope}/{explicit}' if explicit else numbered(scope, 'conv2d_transpose' if kind == 'dconv' else 'conv2d')
+            bn = numbered(scope, 'batch_normalization')
+            out[name + '.w'], out[name + '.b'] = layer + '/kernel', layer + '/bias'
+            for a, t in (('gamma', 'gamma'), ('beta', 'beta'), ('mmean', 'moving_mean'), ('mvar', 'moving_variance')):
+                out[f'{name}.{a}'] = f'{bn}/{t}'
+        for k in ('feat1_l2_norm', 'feat2_l2_norm'):
+            if k in self.pinfo:
+                out[k] = 'feature_extractor/' + k
+        return out
+
+    def _logical(self, name, buf):
+        """parameter `name` out of a flat buffer (P or Mom) in TensorFlow's layout: kernels HWIO (transposed convs: [h, w, out, in]), un-padded"""
+        v = self.get_param(name, buf)
+        return np.ascontiguousarray((v.permute(1, 2, 3, 0) if name.endswith('.w') else v).numpy())
+
+    def export_tf_variables(self):
+        """what the reference's `tf.train.Saver()` would write: every global variable -- weights, moving statistics, global_step and the MomentumOptimizer slots"""
+        out = OrderedDict()
+        for ours, tfname in self.reference_variable_map().items():
+            if ours in self.pinfo:
+                out[tfname] = self._logical(ours, self.P)
+                out[f'{self.MOMENTUM_SLOT_SCOPE}{tfname}/Momentum'] = self._logical(ours, self.Mom)
+            else:
+                out[tfname] = self.stat(ours).detach().cpu().numpy().copy()
+        out['global_step'] = np.asarray(self.global_step, dtype=np.int32)
+        return out
+
+    def load_tf_checkpoint(self, path):
+        """`saver.restore(sess, path)` from the files of a reference-trained model (or ours)"""
+        from .tf_checkpoint import NewCheckpointReader
+        reader = NewCheckpointReader(str(path))
+        names = reader.get_variable_to_shape_map()
+        for ours, tfname in self.reference_variable_map().items():
+            if ours in self.pinfo:
+                v = torch.from_numpy(reader.get_tensor(tfname))                 # KeyError = Saver's NotFoundError
+                self.set_param(ours, v.permute(3, 0, 1, 2).contiguous() if ours.endswith('.w') else v)
+                slot = [k for k in names if k.endswith(tfname + '/Momentum')]
+                if slot:
+                    mv = torch.from_numpy(reader.get_tensor(slot[0]))
+                    dst = self.param(ours, self.Mom)
+                    if ours.endswith('.w'):
+                        mv = mv.permute(3, 0, 1, 2)
+                        dst.zero_()
+                        dst[..., : mv.shape[-1]] = mv.to(self.dev)
+                    else:
+                        dst.copy_(mv.to(self.dev).view(dst.shape))
+            else:
+                self.stat(ours).copy_(torch.from_numpy(reader.get_tensor(tfname)).to(self.dev))
+        if reader.has_tensor('global_step'):
+            self.global_step = int(reader.get_tensor('global_step'))
+        self._refresh_operand_copies()
+
     def save_weight(self, mode, path):
+        """config['checkpoint_format'] = 'tf' writes the reference's own files (`<path>-<step>.index` + `.data-00000-of-00001` + `checkpoint`, readable by its
+        `load_weight`); the default keeps one torch file `<path>-<step>`."""
         assert (mode in ['latest', 'best'])
+        if self.config.get('checkpoint_format', 'torch') == 'tf':
+            from . import tf_checkpoint
+            dirname = os.path.dirname(path)
+            if dirname and not os.path.exists(dirname):
+                os.makedirs(dirname)
+                print(dirname, 'does not exist, create it done')
+            prefix = path + '-' + str(self.global_step)
+            tf_checkpoint.write_bundle(prefix, self.export_tf_variables())
+            tf_checkpoint.update_checkpoint_state(prefix)
+            print('save', mode, 'model in', path, 'successfully')
+            return
         dirname = os.path.dirname(path)
         if dirname and not os.path.exists(dirname):
             os.makedirs(dirname)
@@ -680,6 +771,10 @@ class RefineDet320:
         print('save', mode, 'model in', path, 'successfully')
 
     def load_weight(self, path):
+        if os.path.exists(str(path) + '.index'):                 # a tf.train.Saver checkpoint prefix
+            self.load_tf_checkpoint(path)
+            print('load weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=True)
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):

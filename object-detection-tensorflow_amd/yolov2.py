@@ -115,6 +115,11 @@ class YOLOv2(RefineDet320):
         self._init_parameters(int(config.get('seed', 0)))
         self._build()
 
+    MOMENTUM_SLOT_SCOPE = ''                # the optimizer is created outside every variable scope (YOLOv2.py:168)
+
+    def reference_variable_map(self):
+        return reference_variable_map()
+
     def _input_hw(self):
         return self._hw
 

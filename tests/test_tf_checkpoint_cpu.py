@@ -309,3 +309,60 @@ def test_reader_on_files_of_an_independent_encoder(tmp_path):
             blk = n.split('_')[0]
             assert np.array_equal(m.get_param(n + '.w').permute(1, 2, 3, 0).numpy(), vgg[f'vgg_16/{blk}/{n}/weights'])
             assert np.array_equal(m.get_param(n + '.b').numpy(), vgg[f'vgg_16/{blk}/{n}/biases'])
+
+
+@pytest.mark.parametrize("kind", ["refinedet", "pfpnet", "yolov2"])
+def test_engine_models_reference_names_and_saver_round_trip(kind, tmp_path):
+    """RefineDet320 / PFPNetR / YOLOv2: the rule that derives the reference graph's variable names (default tf.layers names numbered per variable scope,
+    the VGG variables as the reference spells them) gives exactly the names of the graph the reference builds on the shim (tests/golden/*_names.json); a
+    `checkpoint_format='tf'` save writes tf.train.Saver files (weights HWIO, transposed convs [h, w, out, in], moving statistics, Momentum slots,
+    global_step) that a second model restores bit for bit"""
+    import json
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import mock_ops
+    import odtk
+    from odtk.tf_checkpoint import NewCheckpointReader
+    if kind == 'yolov2':
+        from oracle import yolov2_ref as YR
+        cfg = {'mode': 'train', 'is_pretraining': False, 'data_shape': [64, 64, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+               'data_format': 'channels_last', 'batch_size': 1, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'nms_score_threshold': 0.5,
+               'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'rescore_confidence': False, 'priors': YR.PRIORS, 'verbose': False, 'compute_dtype': 'f32',
+               'device': 'cpu', 'checkpoint_format': 'tf'}
+        prov = {'data_shape': [64, 64, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+        make = lambda seed: odtk.YOLOv2(dict(cfg, seed=seed), prov)          # noqa: E731
+    else:
+        cfg = {'mode': 'train', 'input_size': 64, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+               'nms_score_threshold': 0.1, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.45, 'pretraining_weight': '', 'verbose': False, 'compute_dtype': 'f32',
+               'device': 'cpu', 'checkpoint_format': 'tf'}
+        prov = {'data_shape': [64, 64, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+        cls = odtk.RefineDet320 if kind == 'refinedet' else odtk.PFPNetR
+        make = lambda seed: cls(dict(cfg, seed=seed), prov)                  # noqa: E731
+    with mock_ops.installed():
+        m = make(1)
+        names = m.reference_variable_map()
+        want = json.load(open(os.path.join(here, 'golden', f'{kind}_names.json')))
+        assert names == want
+        g = torch.Generator().manual_seed(5)
+        m.Mom.copy_(torch.randn(m.Mom.shape, generator=g) * 1e-3)
+        for k in m.sinfo:
+            m.stat(k).copy_(torch.rand(m.stat(k).shape, generator=g) + 0.5)
+        m.global_step = 37
+        prefix = str(tmp_path / 'ck' / kind)
+        m.save_weight('latest', prefix)
+        reader = NewCheckpointReader(prefix + '-37')
+        shapes = reader.get_variable_to_shape_map()
+        tf_vars = json.load(open(os.path.join(here, 'golden', f'{kind}_variables.json')))
+        assert set(tf_vars) <= set(shapes)                                   # every variable of the reference's graph is in the file ...
+        for n, meta in tf_vars.items():                                     # ... with the shape the reference's graph gives it (at this input size)
+            assert list(shapes[n]) == meta['shape'], (n, shapes[n], meta['shape'])
+        slot = m.MOMENTUM_SLOT_SCOPE + names[m.specs[-1][0] + '.w'] + '/Momentum'
+        assert slot in shapes and int(reader.get_tensor('global_step')) == 37
+        m2 = make(2)
+        assert not torch.equal(m2.P, m.P)
+        m2.load_weight(prefix + '-37')
+        assert torch.equal(m2.P, m.P) and torch.equal(m2.S, m.S) and m2.global_step == 37
+        for k in m.pinfo:                                                    # (the flat momentum buffer was filled including its padding: compare the variables)
+            assert torch.equal(m2.get_param(k, m2.Mom), m.get_param(k, m.Mom)), k

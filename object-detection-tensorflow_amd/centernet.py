@@ -498,19 +498,79 @@ class CenterNet:
         return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
 
     # ------------------------------------------------------------------ checkpoints / data parallel
+    def _logical(self, name, buf):
+        """parameter `name` out of a flat buffer in TensorFlow's layout: kernels HWIO (transposed convs [h, w, out, in]), un-padded"""
+        v = self.get_param(name, buf)
+        return np.ascontiguousarray((v.permute(1, 2, 3, 0) if name.endswith('.w') else v).numpy())
+
+    def export_tf_variables(self):
+        """what the reference's `tf.train.Saver()` (CenterNet.py:296-301) would write: weights, moving statistics, global_step and AdamOptimizer's state --
+        slots `<variable>/Adam` (m), `<variable>/Adam_1` (v) and the accumulators beta1_power / beta2_power (= beta^(t + 1) after t steps); the optimizer
+        is created outside every variable scope (:154)"""
+        out = OrderedDict()
+        for tfname, ours in reference_variable_map(self.num_classes).items():
+            if ours in self.pinfo:
+                out[tfname] = self._logical(ours, self.P)
+                out[tfname + '/Adam'] = self._logical(ours, self.M1)
+                out[tfname + '/Adam_1'] = self._logical(ours, self.M2)
+            else:
+                out[tfname] = self.stat(ours).detach().cpu().numpy().copy()
+        out['beta1_power'] = np.asarray(ADAM_B1 ** (self.global_step + 1), dtype=np.float32)
+        out['beta2_power'] = np.asarray(ADAM_B2 ** (self.global_step + 1), dtype=np.float32)
+        out['global_step'] = np.asarray(self.global_step, dtype=np.int32)
+        return out
+
+    def load_tf_checkpoint(self, path, backbone_only=False):
+        """`saver.restore` (CenterNet.py:321-327) from tf.train.Saver files; backbone_only = the `pretrained_saver` over the trainables of 'backone'"""
+        from .tf_checkpoint import NewCheckpointReader
+        reader = NewCheckpointReader(str(path))
+        for tfname, ours in reference_variable_map(self.num_classes).items():
+            if backbone_only and not (tfname.startswith('backone/') and ours in self.pinfo):
+                continue
+            v = torch.from_numpy(reader.get_tensor(tfname))                     # KeyError = Saver's NotFoundError
+            if ours in self.pinfo:
+                self.set_param(ours, v.permute(3, 0, 1, 2).contiguous() if ours.endswith('.w') else v)
+                for slot, buf in (('/Adam', self.M1), ('/Adam_1', self.M2)):
+                    if not backbone_only and reader.has_tensor(tfname + slot):
+                        mv = torch.from_numpy(reader.get_tensor(tfname + slot))
+                        dst = self.param(ours, buf)
+                        if ours.endswith('.w'):
+                            mv = mv.permute(3, 0, 1, 2)
+                            dst.zero_()
+                            dst[..., : mv.shape[-1]] = mv.to(self.dev)
+                        else:
+                            dst.copy_(mv.to(self.dev).view(dst.shape))
+            else:
+                self.stat(ours).copy_(v.to(self.dev))
+        if not backbone_only and reader.has_tensor('global_step'):
+            self.global_step = int(reader.get_tensor('global_step'))
+        self._refresh_operand_copies()
+
     def save_weight(self, mode, path):
-        """CenterNet.py:314-319 (one torch file `<path>-<step>`: parameters, moving statistics, Adam's moments and step)"""
+        """CenterNet.py:314-319: one torch file `<path>-<step>` (parameters, moving statistics, Adam's moments and step), or with
+        config['checkpoint_format'] = 'tf' the reference's own tf.train.Saver files"""
         assert (mode in ['latest', 'best'])
         dirname = os.path.dirname(path)
         if dirname and not os.path.exists(dirname):
             os.makedirs(dirname)
             print(dirname, 'does not exist, create it done')
+        if self.config.get('checkpoint_format', 'torch') == 'tf':
+            from . import tf_checkpoint
+            prefix = path + '-' + str(self.global_step)
+            tf_checkpoint.write_bundle(prefix, self.export_tf_variables())
+            tf_checkpoint.update_checkpoint_state(prefix)
+            print('save', mode, 'model in', path, 'successfully')
+            return
         blob = {'params': self.export_params(), 'adam_m': self.M1.detach().cpu(), 'adam_v': self.M2.detach().cpu(), 'global_step': self.global_step,
                 'layout': {k: (int(o), tuple(int(x) for x in shp)) for k, (o, shp) in self.pinfo.items()}}
         torch.save(blob, path + '-' + str(self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
     def load_weight(self, path):
+        if os.path.exists(str(path) + '.index'):                 # a tf.train.Saver checkpoint prefix
+            self.load_tf_checkpoint(path)
+            print('load weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=True)
         self.load_oracle_params(blob['params'])
         if tuple(blob['adam_m'].shape) == tuple(self.M1.shape) and dict(blob['layout']) == dict(self.pinfo):
@@ -520,6 +580,10 @@ class CenterNet:
 
     def load_pretrained_weight(self, path):
         """CenterNet.py:321-323: `pretrained_saver` restores the trainable variables under 'backone' (c0 .. c49)"""
+        if os.path.exists(str(path) + '.index'):
+            self.load_tf_checkpoint(path, backbone_only=True)
+            print('load pretrained weight', path, 'successfully')
+            return
         blob = torch.load(path, map_location='cpu', weights_only=True)['params']
         self.load_oracle_params({k: v for k, v in blob.items() if k in self.pinfo and int(k[1:].split('.')[0]) < 50})
         print('load pretrained weight', path, 'successfully')

@@ -366,3 +366,49 @@ def test_engine_models_reference_names_and_saver_round_trip(kind, tmp_path):
         assert torch.equal(m2.P, m.P) and torch.equal(m2.S, m.S) and m2.global_step == 37
         for k in m.pinfo:                                                    # (the flat momentum buffer was filled including its padding: compare the variables)
             assert torch.equal(m2.get_param(k, m2.Mom), m.get_param(k, m.Mom)), k
+
+
+def test_centernet_saver_round_trip_through_mocked_launches(tmp_path):
+    """CenterNet with `checkpoint_format='tf'`: tf.train.Saver files with every variable of the reference's graph (tests/golden/centernet_variables.json) in the
+    reference's shapes, AdamOptimizer's slots and beta-power accumulators; restore is bit-exact; `load_pretrained_weight` takes the backbone only"""
+    import json
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import mock_ops
+    import odtk
+    from odtk.tf_checkpoint import NewCheckpointReader
+    cfg = {'mode': 'train', 'input_size': 128, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+           'score_threshold': 0.1, 'top_k_results_output': 10, 'verbose': False, 'compute_dtype': 'f32', 'device': 'cpu', 'checkpoint_format': 'tf'}
+    prov = {'data_shape': [128, 128, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    with mock_ops.installed():
+        m = odtk.CenterNet(dict(cfg, seed=1), prov)
+        g = torch.Generator().manual_seed(6)
+        for k in m.pinfo:
+            m.param(k, m.M1).copy_(torch.randn(m.param(k, m.M1).shape, generator=g) * 1e-3)
+            m.param(k, m.M2).copy_(torch.rand(m.param(k, m.M2).shape, generator=g) * 1e-6)
+        for k in m.sinfo:
+            m.stat(k).copy_(torch.rand(m.stat(k).shape, generator=g) + 0.5)
+        m.global_step = 11
+        prefix = str(tmp_path / 'ck' / 'centernet')
+        m.save_weight('latest', prefix)
+        reader = NewCheckpointReader(prefix + '-11')
+        shapes = reader.get_variable_to_shape_map()
+        want = json.load(open(os.path.join(here, 'golden', 'centernet_variables.json')))
+        for n, meta in want.items():
+            assert list(shapes[n]) == meta['shape'], (n, shapes[n], meta['shape'])
+        assert 'backone/conv2d/kernel/Adam_1' in shapes and abs(float(reader.get_tensor('beta1_power')) - 0.9 ** 12) < 1e-7
+        m2 = odtk.CenterNet(dict(cfg, seed=2), prov)
+        m2.load_weight(prefix + '-11')
+        assert torch.equal(m2.S, m.S) and m2.global_step == 11
+        for k in m.pinfo:
+            assert torch.equal(m2.get_param(k), m.get_param(k)) and torch.equal(m2.get_param(k, m2.M1), m.get_param(k, m.M1)), k
+            assert torch.equal(m2.get_param(k, m2.M2), m.get_param(k, m.M2)), k
+        m3 = odtk.CenterNet(dict(cfg, seed=3), prov)
+        before = m3.export_params()
+        m3.load_pretrained_weight(prefix + '-11')
+        after, src = m3.export_params(), m.export_params()
+        for k in m.pinfo:
+            layer = int(k[1:].split('.')[0])
+            assert torch.equal(after[k], src[k] if layer < 50 else before[k]), k

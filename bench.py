@@ -213,6 +213,11 @@ def main():
     ap.add_argument('--kernel-dbg', type=int, default=0, help='A/B: odtk_debug_set(2, bits) dispatch switches of csrc/conv_v3.hip (bits >= 1<<26 only)')
     ap.add_argument('--debug-set', default='', help="A/B: comma list of KEY:VALUE for odtk_debug_set (keys that leave results intact: 3, 4, 5)")
     ap.add_argument('--bucket-mb', type=int, default=25, help='N > 1: gradient all-reduce bucket size')
+    ap.add_argument('--dp-world1', action='store_true',
+                    help='N = 1 only: run the data-parallel path (RCCL process group of ONE rank, gradient buckets, per-bucket backward graphs, '
+                         'an ncclAllReduce per bucket) on the one GPU -- the RCCL code path of N > 1 exercised where only one GPU exists')
+    ap.add_argument('--grad-dtype', default='f32', choices=['f32', 'bf16'],
+                    help='N > 1: all-reduce the gradient buckets as f32 (default, 105 MB/step) or as bf16 copies (52 MB/step)')
     ap.add_argument('--launch-check', action='store_true',
                     help='exercise ONLY the launcher / rendezvous / timing / one-JSON-line skeleton with a dummy all-reduce step '
                          '(gloo when there is no GPU); prints metric "launch-check", never a measurement')
@@ -232,11 +237,9 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    use_pg = world > 1 or args.dp_world1
+    if use_pg:
+        init_group('nccl', rank, world, dev)
 
     import odtk
     from odtk import ops
@@ -256,8 +259,8 @@ def main():
     }
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)
-    if world > 1:
-        model.attach_data_parallel(bucket_mb=args.bucket_mb, sync_bn=args.sync_bn)
+    if use_pg:
+        model.attach_data_parallel(bucket_mb=args.bucket_mb, sync_bn=args.sync_bn, grad_dtype=args.grad_dtype, force_collectives=args.dp_world1)
     images, gt = synthetic_batch(B, 1000 + rank, dev)
     model.set_batch(images, gt)
 
@@ -266,7 +269,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -312,7 +315,7 @@ def main():
     gc.enable()
     loss = final_loss_t
     comm = None
-    if world > 1:
+    if use_pg:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -349,7 +352,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         import torch.distributed as dist
         dist.destroy_process_group()
 
@@ -400,21 +403,21 @@ def launch_check(args, world, rank, local_rank):
     dev = torch.device('cuda', local_rank) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl' if use_gpu else 'gloo', rank=rank, world_size=world,
-                                **({'device_id': dev} if use_gpu else {}))
+    # on a GPU box the process group is RCCL even for ONE rank: that exercises RCCL's init against this driver (device_id binding, the dmabuf
+    # IPC setting HSA_ENABLE_IPC_MODE_LEGACY=0, the watchdog thread) and a real ncclAllReduce on the one GPU a builder box has
+    use_pg = world > 1 or use_gpu
+    if use_pg:
+        init_group('nccl' if use_gpu else 'gloo', rank, world, dev if use_gpu else None)
     buf = torch.ones(1 << 20, device=dev)
 
     def barrier():
         if use_gpu:
             torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
 
     def step():
-        if world > 1:
+        if use_pg:
             dist.all_reduce(buf)
             buf.mul_(1.0 / world)
     for _ in range(args.warmup):
@@ -425,7 +428,7 @@ def launch_check(args, world, rank, local_rank):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -435,12 +438,36 @@ def launch_check(args, world, rank, local_rank):
                           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                           'config': {'workload': 'launcher / rendezvous self-check (1 M-float all-reduce per step); NOT a measurement'},
-                          'comm': {'backend': dist.get_backend() if world > 1 else None,
-                                   'world_size': dist.get_world_size() if world > 1 else 1,
+                          'comm': {'backend': dist.get_backend() if use_pg else None,
+                                   'world_size': dist.get_world_size() if use_pg else 1,
                                    'launcher': os.environ.get('ODTK_BENCH_LAUNCHER', 'external'), 'allreduce_ok': ok}}), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def init_group(backend, rank, world, dev):
+    """torch.distributed rendezvous on 127.0.0.1 (the container hostname may not resolve); a failure is reported on stderr BY EVERY RANK with
+    what it tried, so that a dead N-GPU run names its cause instead of timing out silently."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this driver (RCCL needs it)
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300),
+                                **({'device_id': dev} if dev is not None else {}))
+        if backend == 'nccl':
+            # first collective = communicator creation: fail here, with a message, not inside the first training step
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            assert float(probe.item()) == float(world), probe
+    except Exception as e:                                        # noqa: BLE001
+        print(f'bench.py: rank {rank}/{world}: {backend} rendezvous / communicator set-up failed at '
+              f'{os.environ["MASTER_ADDR"]}:{os.environ["MASTER_PORT"]} (device {dev}, HSA_ENABLE_IPC_MODE_LEGACY='
+              f'{os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}): {type(e).__name__}: {e}', file=sys.stderr, flush=True)
+        raise
 
 
 def comm_metrics(model, args, lr, barrier, ms_step, dev):
@@ -458,6 +485,11 @@ def comm_metrics(model, args, lr, barrier, ms_step, dev):
         red.all_reduce_alone()
     barrier()
     t_ar = (time.perf_counter() - t0) / k * 1e3
+    # the steps without collectives train every replica on its own batch only: the replicas' weights would drift apart, so the model state
+    # (parameters, momentum, moving statistics, operand copies) is snapshotted here and put back afterwards -- these steps are UNTIMED
+    # diagnostics and leave no trace in the model
+    snap = {k: getattr(model, k).clone() for k in ('P', 'Mom', 'S', 'Pc') if isinstance(getattr(model, k, None), torch.Tensor)}
+    gstep = model.global_step
     red.enabled = False
     model.train_step(lr)
     barrier()
@@ -467,6 +499,10 @@ def comm_metrics(model, args, lr, barrier, ms_step, dev):
     barrier()
     t_nc = (time.perf_counter() - t0) / k * 1e3
     red.enabled = True
+    for k_, v_ in snap.items():
+        getattr(model, k_).copy_(v_)
+    model.global_step = gstep
+    model.refresh_wt()
     v = torch.tensor([t_ar, t_nc], device=dev)
     dist.all_reduce(v, op=dist.ReduceOp.MAX)
     t_ar, t_nc = (float(x) for x in v.tolist())
@@ -476,7 +512,9 @@ def comm_metrics(model, args, lr, barrier, ms_step, dev):
             'buckets': len(red.buckets), 'gradient_mb': round(nbytes / 1e6, 1),
             'allreduce_ms_per_step': round(t_ar, 3),
             'allreduce_busbw_gbps': round(nbytes * 2 * (w - 1) / w / (t_ar * 1e-3) / 1e9, 1),
-            'ms_per_step_without_comm': round(t_nc, 3), 'exposed_comm_ms': round(max(ms_step - t_nc, 0.0), 3),
+            'gradient_dtype': getattr(red, 'comm_dtype', 'f32'),
+            'ms_per_step_without_comm': round(t_nc, 3), 'without_comm_steps': 'untimed diagnostic steps; model state restored afterwards',
+            'exposed_comm_ms': round(max(ms_step - t_nc, 0.0), 3),
             'overlap_frac': round(min(max(1.0 - max(ms_step - t_nc, 0.0) / max(t_ar, 1e-9), 0.0), 1.0), 3)}
 
 

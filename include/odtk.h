@@ -285,6 +285,9 @@ int odtk_adam(float* p, float* m, float* v, const float* grad, long long n, floa
 int odtk_sum_f32(const float* in, long long n, float* out, void* stream);
 /* cast f32 -> dtype */
 int odtk_cast_from_f32(const float* in, void* out, long long n, int dtype, void* stream);
+/* cast dtype -> f32 (the bf16 gradient buckets of the data-parallel path are summed by RCCL as bf16 and widened back into the flat f32
+ * gradient buffer; replaces nothing in the reference, which is single-device: testSSD300.py:14) */
+int odtk_cast_to_f32(const void* in, int dtype, float* out, long long n, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Box side: priors, matching, loss, NMS, decode

@@ -36,6 +36,7 @@ MEAN = (0.485, 0.456, 0.406)                                  # CenterNet.py:52-
 STD = (0.229, 0.224, 0.225)
 STRIDE = 4.0                                                   # :126
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8                  # tf.train.AdamOptimizer defaults (:154)
+ADAM_SLOT_SCOPE = 'center_detector/'                            # optimizer.minimize is called inside this variable scope (CenterNet.py:131-156)
 
 
 def layer_specs(num_classes):
@@ -505,18 +506,19 @@ class CenterNet:
 
     def export_tf_variables(self):
         """what the reference's `tf.train.Saver()` (CenterNet.py:296-301) would write: weights, moving statistics, global_step and AdamOptimizer's state --
-        slots `<variable>/Adam` (m), `<variable>/Adam_1` (v) and the accumulators beta1_power / beta2_power (= beta^(t + 1) after t steps); the optimizer
-        is created outside every variable scope (:154)"""
+        slots `center_detector/<variable>/Adam` (m), `…/Adam_1` (v) and the accumulators `center_detector/beta1_power` / `beta2_power`
+        (= beta^(t + 1) after t steps): `optimizer.minimize` runs INSIDE `with tf.variable_scope('center_detector')` (:131-156), and both the slot
+        creator (`variable_scope(None, primary.op.name + '/Adam')`) and the non-slot accumulators take the enclosing scope as a prefix"""
         out = OrderedDict()
         for tfname, ours in reference_variable_map(self.num_classes).items():
             if ours in self.pinfo:
                 out[tfname] = self._logical(ours, self.P)
-                out[tfname + '/Adam'] = self._logical(ours, self.M1)
-                out[tfname + '/Adam_1'] = self._logical(ours, self.M2)
+                out[ADAM_SLOT_SCOPE + tfname + '/Adam'] = self._logical(ours, self.M1)
+                out[ADAM_SLOT_SCOPE + tfname + '/Adam_1'] = self._logical(ours, self.M2)
             else:
                 out[tfname] = self.stat(ours).detach().cpu().numpy().copy()
-        out['beta1_power'] = np.asarray(ADAM_B1 ** (self.global_step + 1), dtype=np.float32)
-        out['beta2_power'] = np.asarray(ADAM_B2 ** (self.global_step + 1), dtype=np.float32)
+        out[ADAM_SLOT_SCOPE + 'beta1_power'] = np.asarray(ADAM_B1 ** (self.global_step + 1), dtype=np.float32)
+        out[ADAM_SLOT_SCOPE + 'beta2_power'] = np.asarray(ADAM_B2 ** (self.global_step + 1), dtype=np.float32)
         out['global_step'] = np.asarray(self.global_step, dtype=np.int32)
         return out
 
@@ -524,6 +526,8 @@ class CenterNet:
         """`saver.restore` (CenterNet.py:321-327) from tf.train.Saver files; backbone_only = the `pretrained_saver` over the trainables of 'backone'"""
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
+        names = list(reader.get_variable_to_shape_map())
+        missing_slots = []
         for tfname, ours in reference_variable_map(self.num_classes).items():
             if backbone_only and not (tfname.startswith('backone/') and ours in self.pinfo):
                 continue
@@ -531,8 +535,14 @@ class CenterNet:
             if ours in self.pinfo:
                 self.set_param(ours, v.permute(3, 0, 1, 2).contiguous() if ours.endswith('.w') else v)
                 for slot, buf in (('/Adam', self.M1), ('/Adam_1', self.M2)):
-                    if not backbone_only and reader.has_tensor(tfname + slot):
-                        mv = torch.from_numpy(reader.get_tensor(tfname + slot))
+                    if backbone_only:
+                        continue
+                    # the slot's scope prefix is whatever scope the optimizer was created in ('center_detector/' in the reference): match by suffix
+                    found = [n for n in names if n.endswith(tfname + slot) and n[: len(n) - len(tfname + slot)] in ('', ADAM_SLOT_SCOPE)]
+                    if not found:
+                        missing_slots.append(tfname + slot)
+                    else:
+                        mv = torch.from_numpy(reader.get_tensor(found[0]))
                         dst = self.param(ours, buf)
                         if ours.endswith('.w'):
                             mv = mv.permute(3, 0, 1, 2)
@@ -544,6 +554,10 @@ class CenterNet:
                 self.stat(ours).copy_(v.to(self.dev))
         if not backbone_only and reader.has_tensor('global_step'):
             self.global_step = int(reader.get_tensor('global_step'))
+        if missing_slots:
+            import warnings
+            warnings.warn(f'{path}: {len(missing_slots)} Adam slot variables not in the checkpoint (e.g. {missing_slots[0]}): their moments stay as they are, '
+                          f'while global_step = {self.global_step} drives the bias correction', RuntimeWarning)
         self._refresh_operand_copies()
 
     def save_weight(self, mode, path):
@@ -575,6 +589,10 @@ class CenterNet:
         self.load_oracle_params(blob['params'])
         if tuple(blob['adam_m'].shape) == tuple(self.M1.shape) and dict(blob['layout']) == dict(self.pinfo):
             self.M1.copy_(blob['adam_m'].to(self.dev)); self.M2.copy_(blob['adam_v'].to(self.dev))
+        else:
+            import warnings
+            warnings.warn(f'{path}: parameter layout differs from this model ({len(blob["layout"])} vs {len(self.pinfo)} entries): Adam moments NOT restored',
+                          RuntimeWarning)
         self.global_step = int(blob.get('global_step', 0))
         print('load weight', path, 'successfully')
 
@@ -588,9 +606,9 @@ class CenterNet:
         self.load_oracle_params({k: v for k, v in blob.items() if k in self.pinfo and int(k[1:].split('.')[0]) < 50})
         print('load pretrained weight', path, 'successfully')
 
-    def attach_data_parallel(self, group=None, bucket_mb=25):
+    def attach_data_parallel(self, group=None, bucket_mb=25, grad_dtype='f32', force_collectives=False):
         from .dist import GradAllReducer
-        self.dist = GradAllReducer(self, group, bucket_mb)
+        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
         self.loss_divisor_batch = self.batch_size * self.dist.world
         return self.dist
 

@@ -1078,6 +1078,38 @@ __global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, l
     for (; i < n; i += step) out[i] = elem<T>::store(in[i]);
 }
 
+// 8 elements per thread and pass: two float4 <-> one 16-byte bf16 chunk (the gradient buckets of the data-parallel path: 26 M elements)
+__global__ void cast_f32_to_bf16_x8_kernel(const float4* __restrict__ in, uint4* __restrict__ out, long long n8) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n8; i += step) {
+        const float4 a = in[2 * i], b = in[2 * i + 1];
+        uint4 o;
+        o.x = (unsigned)f32_to_bf16(a.x) | ((unsigned)f32_to_bf16(a.y) << 16);
+        o.y = (unsigned)f32_to_bf16(a.z) | ((unsigned)f32_to_bf16(a.w) << 16);
+        o.z = (unsigned)f32_to_bf16(b.x) | ((unsigned)f32_to_bf16(b.y) << 16);
+        o.w = (unsigned)f32_to_bf16(b.z) | ((unsigned)f32_to_bf16(b.w) << 16);
+        out[i] = o;
+    }
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) out[i] = elem<T>::load(in[i]);
+}
+__global__ void cast_bf16_to_f32_x8_kernel(const uint4* __restrict__ in, float4* __restrict__ out, long long n8) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n8; i += step) {
+        const uint4 v = in[i];
+        out[2 * i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                                 __uint_as_float(v.y & 0xffff0000u));
+        out[2 * i + 1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16),
+                                     __uint_as_float(v.w & 0xffff0000u));
+    }
+}
+
 inline int grid_for(long long total, int threads, int cap = 8192) {
     long long b = (total + threads - 1) / threads;
     if (b > cap) b = cap;
@@ -1405,7 +1437,32 @@ extern "C" int odtk_sum_f32(const float* in, long long n, float* out, void* stre
 extern "C" int odtk_cast_from_f32(const float* in, void* out, long long n, int dtype, void* stream) {
     ODTK_REQUIRE(in && out, "cast: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == ODTK_BF16 && n >= 8 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+        const long long n8 = n / 8;
+        hipLaunchKernelGGL(cast_f32_to_bf16_x8_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const float4*)in, (uint4*)out, n8);
+        if (n % 8)
+            hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(1), dim3(64), 0, st, in + n8 * 8, (bf16_t*)out + n8 * 8, n % 8);
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(cast_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, (T*)out, n);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_cast_to_f32(const void* in, int dtype, float* out, long long n, void* stream) {
+    ODTK_REQUIRE(in && out && n >= 0, "cast: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return ODTK_OK;
+    if (dtype == ODTK_BF16 && n >= 8 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+        const long long n8 = n / 8;
+        hipLaunchKernelGGL(cast_bf16_to_f32_x8_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const uint4*)in, (float4*)out, n8);
+        if (n % 8)
+            hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(1), dim3(64), 0, st, (const bf16_t*)in + n8 * 8, out + n8 * 8, n % 8);
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(cast_to_f32_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const T*)in, out, n);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

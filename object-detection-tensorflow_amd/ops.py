@@ -323,6 +323,10 @@ def cast_from_f32(x, out):
     call("odtk_cast_from_f32", _p(x), _p(out), x.numel(), dt_of(out), _stream())
 
 
+def cast_to_f32(x, out):
+    call("odtk_cast_to_f32", _p(x), dt_of(x), _p(out), x.numel(), _stream())
+
+
 # ------------------------------------------------------------------ box side
 def ssd_priors(input_size, fsizes, nas, prior_hw_flat, device):
     """Returns (y1x1, y2x2, yx, hw, nmsbox) device tensors."""

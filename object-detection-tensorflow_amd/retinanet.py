@@ -589,9 +589,17 @@ class RetinaNet:
             print('load weight', path, 'successfully')
             return
         blob = torch.load(path, map_location='cpu', weights_only=True)
+        unknown = sorted(k for k in blob['params'] if k not in self.pinfo and k not in getattr(self, 'sinfo', {}))
+        if unknown:
+            raise ValueError(f'{path}: {len(unknown)} parameters of the checkpoint are not part of this model (e.g. {unknown[:3]}): '
+                             'it was written by a different layer layout')
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
             self.Mom.copy_(blob['momentum'].to(self.dev))
+        else:
+            import warnings
+            warnings.warn(f'{path}: the parameter layout of the checkpoint differs from this model ({len(blob["layout"])} vs {len(self.pinfo)} entries): '
+                          'momentum NOT restored (it stays as it is) although global_step is', RuntimeWarning)
         self.global_step = int(blob.get('global_step', 0))
         print('load weight', path, 'successfully')
 
@@ -607,9 +615,9 @@ class RetinaNet:
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < nb})
         print('load pretraining weight', path, 'successfully')
 
-    def attach_data_parallel(self, group=None, bucket_mb=25):
+    def attach_data_parallel(self, group=None, bucket_mb=25, grad_dtype='f32', force_collectives=False):
         from .dist import GradAllReducer
-        self.dist = GradAllReducer(self, group, bucket_mb)
+        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
         self.loss_divisor_batch = self.batch_size * self.dist.world
         return self.dist
 

@@ -631,7 +631,10 @@ class SSD300:
         """Backward pass as a generator: it hands back a layer name as soon as every gradient of that layer (and of all
         later layers) has been launched -- the data-parallel hooks and the segmented graph capture hang on these points."""
         a = self.acts
-        tail = self._tail if (self.sync_bn is None and self.wgrad_stream is None) else None
+        # data parallel: no head stream in backward -- with it no layer name could be handed back before the join, the readiness marks of
+        # pred* / conv11_2 .. conv6 would arrive in one burst and the buckets of the heads and extras (conv6 / conv7: ~6 M parameters) could
+        # not start their all-reduce under that part of the backward pass
+        tail = self._tail if (self.sync_bn is None and self.wgrad_stream is None and self.dist is None) else None
         evs = {}
         if tail is None:
             # heads (pred6 .. pred1): dpred -> BN bwd -> wgrad / dgrad into the feature map
@@ -822,7 +825,15 @@ class SSD300:
         finally:
             self._auto, self.use_graph = au, saved
         torch.cuda.synchronize()
-        au['t'].setdefault(mode, []).append(__import__('time').perf_counter() - t0)
+        dt = __import__('time').perf_counter() - t0
+        if self.dist is not None and self.dist.world > 1:
+            # every rank must pick the SAME launch mode (the bucket graphs and the eager backward issue their collectives at different points
+            # of the host timeline): decide on the slowest rank's timing
+            import torch.distributed as tdist
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX, group=self.dist.red.group)
+            dt = float(t.item())
+        au['t'].setdefault(mode, []).append(dt)
         au['left'] -= 1
         if au['left'] == 0:
             best = {m: min(v[1:]) for m, v in au['t'].items()}        # first step of a mode: one-off costs
@@ -996,18 +1007,27 @@ class SSD300:
             print('load weight', path, 'successfully')
             return
         blob = torch.load(path, map_location='cpu', weights_only=True)
+        unknown = sorted(k for k in blob['params'] if k not in self.pinfo and k not in getattr(self, 'sinfo', {}))
+        if unknown:
+            raise ValueError(f'{path}: {len(unknown)} parameters of the checkpoint are not part of this model (e.g. {unknown[:3]}): '
+                             'it was written by a different layer layout')
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
             self.Mom.copy_(blob['momentum'].to(self.dev))
+        else:
+            import warnings
+            warnings.warn(f'{path}: the parameter layout of the checkpoint differs from this model ({len(blob["layout"])} vs {len(self.pinfo)} entries): '
+                          'momentum NOT restored (it stays as it is) although global_step is', RuntimeWarning)
         self.global_step = int(blob.get('global_step', 0))
         print('load weight', path, 'successfully')
 
     # ------------------------------------------------------------------ data parallel
-    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False):
+    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False, grad_dtype='f32', force_collectives=False):
         """Shard images over ranks (one process per GPU); gradients are summed with bucketed
-        RCCL all-reduce overlapped with backward.  The loss divisor becomes the GLOBAL batch."""
+        RCCL all-reduce overlapped with backward.  The loss divisor becomes the GLOBAL batch.
+        grad_dtype 'bf16': the buckets travel as bf16 copies (half the xGMI bytes); force_collectives: issue them in a world of one rank too."""
         from .dist import GradAllReducer
-        self.dist = GradAllReducer(self, group, bucket_mb)
+        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
         self._graphs_invalidate()
         self.loss_divisor_batch = self.batch_size * self.dist.world
         if sync_bn:

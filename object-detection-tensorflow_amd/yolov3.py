@@ -497,9 +497,17 @@ class YOLOv3:
             print('load weight', path, 'successfully')
             return
         blob = torch.load(path, map_location='cpu', weights_only=True)
+        unknown = sorted(k for k in blob['params'] if k not in self.pinfo and k not in getattr(self, 'sinfo', {}))
+        if unknown:
+            raise ValueError(f'{path}: {len(unknown)} parameters of the checkpoint are not part of this model (e.g. {unknown[:3]}): '
+                             'it was written by a different layer layout')
         self.load_oracle_params(blob['params'])
         if tuple(blob['momentum'].shape) == tuple(self.Mom.shape) and dict(blob['layout']) == dict(self.pinfo):
             self.Mom.copy_(blob['momentum'].to(self.dev))
+        else:
+            import warnings
+            warnings.warn(f'{path}: the parameter layout of the checkpoint differs from this model ({len(blob["layout"])} vs {len(self.pinfo)} entries): '
+                          'momentum NOT restored (it stays as it is) although global_step is', RuntimeWarning)
         self.global_step = int(blob.get('global_step', 0))
         print('load weight', path, 'successfully')
 
@@ -513,12 +521,12 @@ class YOLOv3:
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < 52 and k in self.pinfo})
         print('load pretraining weight', path, 'successfully')
 
-    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False):
+    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False, grad_dtype='f32', force_collectives=False):
         """images sharded over ranks (one process per GPU); gradients summed with the bucketed RCCL all-reduce of dist.py,
         overlapped with the backward pass; the loss divisor becomes the GLOBAL batch.  sync_bn: batch statistics over all replicas
         (ops.SyncBN), i.e. exactly the single-device computation on the global batch"""
         from .dist import GradAllReducer
-        self.dist = GradAllReducer(self, group, bucket_mb)
+        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
         self.loss_divisor_batch = self.batch_size * self.dist.world
         if sync_bn:
             self.sync_bn = ops.SyncBN(group)

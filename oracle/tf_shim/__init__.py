@@ -63,6 +63,7 @@ class _State:
         self.model = None
         self.momentum = {}
         self.uid = 0
+        self.optimizer_scope = None    # variable scope open when optimizer.minimize() ran (prefix of slot / accumulator variable names)
 
 
 S = _State()
@@ -852,6 +853,9 @@ class _MomentumOptimizer:
         self.lr, self.mom = learning_rate, momentum
 
     def minimize(self, loss, global_step=None):
+        # slot variables (slot_creator: variable_scope(None, primary.op.name + '/' + slot)) and the non-slot accumulators (beta1_power ...)
+        # are created HERE, under whatever variable scope is open at this call: recorded so that tests can pin the prefix of their names
+        S.optimizer_scope = '/'.join(S.scope)
         S.pending.append(('minimize', self, loss, global_step))
         return ('train_op',)
 
@@ -864,6 +868,9 @@ class _AdamOptimizer:
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
 
     def minimize(self, loss, global_step=None):
+        # slot variables (slot_creator: variable_scope(None, primary.op.name + '/' + slot)) and the non-slot accumulators (beta1_power ...)
+        # are created HERE, under whatever variable scope is open at this call: recorded so that tests can pin the prefix of their names
+        S.optimizer_scope = '/'.join(S.scope)
         S.pending.append(('minimize', self, loss, global_step))
         return ('train_op',)
 

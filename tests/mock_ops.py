@@ -447,6 +447,10 @@ def cast_from_f32(x, out):
 
 
 # ---- box side through the oracles (autograd supplies the gradients the kernels return)
+def cast_to_f32(x, out):
+    out.copy_(x.float())
+
+
 def yolov3_workspace(preds, N, device):
     return torch.zeros(4, dtype=torch.uint8)
 

@@ -280,3 +280,50 @@ def test_engine_models_data_parallel_world2_on_cpu(kind, tmp_path):
         total = m.G.clone() if total is None else total + m.G
     torch.set_num_threads(threads)
     assert float((a['G'] - total).norm()) < 5e-2 * float(total.norm())
+
+
+def _bf16_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from odtk.dist import BucketAllReducer
+    sizes = [64, 1024, 64, 50048, 128]
+    segs, off = [], 0
+    for i, n in enumerate(sizes):
+        segs.append((f'l{i}', off, off + n)); off += n
+    g = torch.Generator().manual_seed(10 + rank)
+    mine = torch.randn(off, generator=g)
+    others = [torch.randn(off, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    flat = torch.zeros(off)
+    red = BucketAllReducer(flat, segs, None, bucket_bytes=100_000, comm_dtype='bf16', force_collectives=(world == 1))
+    ok = len(red.buckets) >= 2
+    for step in range(2):
+        flat.copy_(mine)
+        red.begin_step()
+        for name, _, _ in reversed(segs):
+            red.segment_ready(name)
+        red.finish_step()
+        # what the wire format gives: every rank's contribution rounded to bf16, summed (gloo sums bf16 pairwise; one more rounding)
+        exact = sum(o.to(torch.bfloat16).float() for o in others)
+        ok = ok and float((flat - exact).abs().max()) <= 2 ** -7 * float(exact.abs().max())
+        ok = ok and float((flat - sum(others)).abs().max()) <= 3 * 2 ** -8 * float(sum(o.abs() for o in others).max())
+    q.put((rank, ok, red.comm_dtype))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_bf16_gradient_buckets(world):
+    """comm_dtype='bf16': the buckets are narrowed, summed by the collective as bf16 and widened back; world 1 runs with
+    force_collectives (the single-GPU RCCL exercise of `bench.py --dp-world1`, here on gloo)"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    assert all(ok for _, ok, _ in res) and all(dt == 'bf16' for _, _, dt in res), res

@@ -1,6 +1,7 @@
 """odtk.tf_checkpoint (the stand-in for tf.train.Saver / NewCheckpointReader, SSD300.py:31, :464-504) on the CPU.
 No TensorFlow here, so the anchors are published ones: the RFC 3720 CRC32C vectors, a table assembled BY HAND from the
 LevelDB table-format description, a snappy stream written out by its format description; then writer <-> reader."""
+import contextlib
 import os
 import struct
 
@@ -398,7 +399,9 @@ def test_centernet_saver_round_trip_through_mocked_launches(tmp_path):
         want = json.load(open(os.path.join(here, 'golden', 'centernet_variables.json')))
         for n, meta in want.items():
             assert list(shapes[n]) == meta['shape'], (n, shapes[n], meta['shape'])
-        assert 'backone/conv2d/kernel/Adam_1' in shapes and abs(float(reader.get_tensor('beta1_power')) - 0.9 ** 12) < 1e-7
+        # slots and accumulators live under the scope optimizer.minimize ran in (CenterNet.py:131-156; tests/golden/optimizer_scopes.json)
+        assert 'center_detector/backone/conv2d/kernel/Adam_1' in shapes and 'backone/conv2d/kernel/Adam_1' not in shapes
+        assert abs(float(reader.get_tensor('center_detector/beta1_power')) - 0.9 ** 12) < 1e-7 and 'beta1_power' not in shapes
         m2 = odtk.CenterNet(dict(cfg, seed=2), prov)
         m2.load_weight(prefix + '-11')
         assert torch.equal(m2.S, m.S) and m2.global_step == 11
@@ -412,3 +415,70 @@ def test_centernet_saver_round_trip_through_mocked_launches(tmp_path):
         for k in m.pinfo:
             layer = int(k[1:].split('.')[0])
             assert torch.equal(after[k], src[k] if layer < 50 else before[k]), k
+
+
+@pytest.mark.parametrize("cls", ["SSD300", "SSD512", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "RefineDet320", "PFPNetR", "YOLOv2"])
+def test_optimizer_slot_scopes_follow_the_reference(cls, tmp_path):
+    """Slot variables (`/Momentum`, `/Adam`, `/Adam_1`) and Adam's beta-power accumulators carry the variable scope that is open where the reference
+    calls `optimizer.minimize` -- recorded by building the reference's own classes on the shim (tests/golden/optimizer_scopes.json,
+    make_golden_optimizer_scopes.py).  Every class must WRITE those names, and must RESTORE the optimizer state from a file that carries them."""
+    import json
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import mock_ops
+    import odtk
+    scope = json.load(open(os.path.join(here, 'golden', 'optimizer_scopes.json')))[cls]
+    prefix = scope + '/' if scope else ''
+    base = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+            'nms_score_threshold': 0.5, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'verbose': False, 'compute_dtype': 'f32', 'device': 'cpu',
+            'checkpoint_format': 'tf', 'use_graph': False, 'pretraining_weight': ''}
+    prov = {'data_shape': [64, 64, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    ctx = contextlib.nullcontext()
+    if cls in ('SSD300', 'SSD512'):
+        size = 300 if cls == 'SSD300' else 512
+        prov = dict(prov, data_shape=[size, size, 3])
+        cfg = base
+        if cls == 'SSD512':
+            from oracle import ssd512_ref as R5
+            ctx = R5.tables()
+    elif cls == 'YOLOv3':
+        from oracle import yolov3_ref as YR
+        cfg = dict(base, data_shape=[64, 64, 3], coord_scale=1, noobj_scale=1, obj_scale=5., class_scale=1., num_priors=3, priors=YR.PRIORS_PX)
+    elif cls == 'YOLOv2':
+        from oracle import yolov2_ref as YR2
+        cfg = dict(base, is_pretraining=False, data_shape=[64, 64, 3], coord_scale=1, noobj_scale=1, obj_scale=5., class_scale=1., rescore_confidence=False,
+                   priors=YR2.PRIORS)
+    elif cls == 'RetinaNet':
+        cfg = dict(base, is_bottleneck=True, residual_block_list=[3, 4, 6, 3], init_conv_filters=16, is_pretraining=False, data_shape=[128, 128, 3],
+                   gamma=2.0, alpha=0.25)
+    elif cls == 'FCOS':
+        cfg = dict(base, data_shape=[64, 64, 3])
+    elif cls == 'CenterNet':
+        cfg = dict(base, input_size=128, score_threshold=0.1, top_k_results_output=10)
+        prov = dict(prov, data_shape=[128, 128, 3])
+    else:
+        cfg = dict(base, input_size=64)
+    slot_kinds = ('/Adam', '/Adam_1') if cls == 'CenterNet' else ('/Momentum',)
+    with mock_ops.installed(), ctx:
+        m = getattr(odtk, cls)(dict(cfg, seed=1), prov)
+        state = [m.M1, m.M2] if cls == 'CenterNet' else [m.Mom]
+        g = torch.Generator().manual_seed(3)
+        for buf in state:
+            buf.copy_(torch.rand(buf.shape, generator=g) * 1e-3)
+        m.global_step = 5
+        out = m.export_tf_variables()
+        variables = {k for k in out if not k.endswith(slot_kinds) and not k.endswith(('beta1_power', 'beta2_power'))}
+        slots = [k for k in out if k.endswith(slot_kinds)]
+        assert slots and all(k.startswith(prefix) and k[len(prefix): k.rindex('/')] in variables for k in slots), (scope, slots[:3])
+        if scope:
+            assert not any(k[len(prefix):] in out for k in slots), 'a slot is also present without its scope'
+        if cls == 'CenterNet':
+            assert prefix + 'beta1_power' in out and prefix + 'beta2_power' in out and 'beta1_power' not in out
+        path = str(tmp_path / 'ck' / cls)
+        m.save_weight('latest', path)
+        m2 = getattr(odtk, cls)(dict(cfg, seed=2), prov)
+        m2.load_weight(path + '-5')
+        out2 = m2.export_tf_variables()               # the optimizer state came back from the scoped names
+        assert all(np.array_equal(out[k], out2[k]) for k in slots)

@@ -1,0 +1,128 @@
+"""BASELINE.json's configurations as constructors: the model class at the configuration's shape with a synthetic VOC-shaped batch
+ and random-init weights, shared by `bench.py --config ...`, the in-situ parity tests (tests/test_gpu_insitu_configs.py) and tools/.
+Nothing here imports oracle/ (bench.py's cpu_baseline leg does, separately).
+
+  ssd300     config 2: SSD300 VGG-16 300x300, batch 32 / GPU, bf16                                (testSSD300.py:15-46)
+  retinanet  config 3: RetinaNet ResNet-50-FPN 800x800, batch 16 on one GPU                       (testretinanet.py:22-42)
+  yolov3     config 4: YOLOv3 DarkNet-53 416x416, batch 64 over 8 GPUs = 8 / GPU                  (testYOLOv3.py:17-41)
+  fcos       config 5: FCOS 512x512, batch 128 over 8 GPUs = 16 / GPU                             (testfcos.py:20-32)
+  centernet  config 5: CenterNet DLA 512x512, batch 128 over 8 GPUs = 16 / GPU                    (testcenternet.py)
+"""
+import torch
+
+YOLO_PRIORS_PX = [[[10., 13.], [16, 30.], [33., 23.]], [[30., 61.], [62., 45.], [59., 119.]], [[116., 90.], [156., 198.], [373., 326.]]]
+
+# name -> (input size, images per GPU, dtype the class defaults to, learning rate of the driver script)
+SHAPES = {
+    'ssd300': (300, 32, 'bf16', 0.01),
+    'retinanet': (800, 16, 'f32', 1e-4),
+    'yolov3': (416, 8, 'bf16', 1e-4),
+    'fcos': (512, 16, 'f32', 1e-4),
+    'centernet': (512, 16, 'f32', 1e-4),
+}
+WORKLOAD = {
+    'ssd300': 'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
+    'retinanet': 'RetinaNet ResNet-50-FPN (reference widths 7/14/28/56 x4) 800x800 train step, batch {B}/GPU, 120 087 anchors (fwd + focal loss + bwd + SGD-momentum)',
+    'yolov3': 'YOLOv3 DarkNet-53 416x416 train step, batch {B}/GPU (config 4: 64 over 8 GPUs), 10 647 priors (fwd + loss + bwd + SGD-momentum)',
+    'fcos': 'FCOS group-norm ResNet-50-FPN 512x512 train step, batch {B}/GPU (config 5: 128 over 8 GPUs), 5 456 locations (fwd + loss + bwd + SGD-momentum)',
+    'centernet': 'CenterNet DLA 512x512 train step, batch {B}/GPU (config 5: 128 over 8 GPUs), 128x128x20 heat map (fwd + loss + bwd + Adam)',
+}
+METRIC = {
+    'ssd300': 'images/sec SSD300 VGG-16 batch=32 train',
+    'retinanet': 'images/sec RetinaNet ResNet-50-FPN 800x800 batch=16 train',
+    'yolov3': 'images/sec YOLOv3 DarkNet-53 416x416 batch=8/GPU train',
+    'fcos': 'images/sec FCOS 512x512 batch=16/GPU train',
+    'centernet': 'images/sec CenterNet 512x512 batch=16/GPU train',
+}
+
+
+def synthetic_gt(batch, input_size, seed, pad=60, max_obj=6, lo=0.1, hi=0.8):
+    """ground truth rows [yc, xc, h, w, class] in pixels, padded with -1 (utils/image_augmentor.py:24-27 of the reference)"""
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.full((batch, pad, 5), -1.0)
+    for i in range(batch):
+        n = int(torch.randint(1, max_obj + 1, (1,), generator=g))
+        h = torch.rand(n, generator=g) * (input_size * (hi - lo)) + input_size * lo
+        w = torch.rand(n, generator=g) * (input_size * (hi - lo)) + input_size * lo
+        yc = h / 2 + torch.rand(n, generator=g) * (input_size - h)
+        xc = w / 2 + torch.rand(n, generator=g) * (input_size - w)
+        cls = torch.randint(0, 20, (n,), generator=g).float()
+        gt[i, :n] = torch.stack([yc, xc, h, w, cls], 1)
+    return gt
+
+
+def synthetic_batch(name, batch, size, seed):
+    g = torch.Generator().manual_seed(seed)
+    if name == 'ssd300':
+        images = torch.rand(batch, size, size, 3, generator=g) * 255.
+        return images, synthetic_gt(batch, size, seed + 1, lo=0.1, hi=0.9)
+    images = (torch.rand(batch, size, size, 3, generator=g) * 255).round()
+    return images, synthetic_gt(batch, size, seed + 1, lo=0.05, hi=0.8 if name == 'yolov3' else 0.6)
+
+
+def config_of(name, batch=None, size=None, dtype=None, **extra):
+    size0, batch0, dtype0, _ = SHAPES[name]
+    size, batch, dtype = size or size0, batch or batch0, dtype or dtype0
+    base = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': batch,
+            'verbose': False, 'compute_dtype': dtype}
+    if name == 'ssd300':
+        cfg = dict(base, nms_score_threshold=0.5, nms_max_boxes=20, nms_iou_threshold=0.5, pretraining_weight='', seed=0)
+    elif name == 'retinanet':
+        cfg = dict(base, is_bottleneck=True, residual_block_list=[3, 4, 6, 3], init_conv_filters=16, is_pretraining=False, data_shape=[size, size, 3],
+                   gamma=2.0, alpha=0.25, nms_score_threshold=0.8, nms_max_boxes=10, nms_iou_threshold=0.45)
+    elif name == 'yolov3':
+        cfg = dict(base, data_shape=[size, size, 3], weight_decay=5e-4, coord_scale=1, noobj_scale=1, obj_scale=5., class_scale=1., num_priors=3,
+                   nms_score_threshold=0.5, nms_max_boxes=10, nms_iou_threshold=0.5, priors=YOLO_PRIORS_PX)
+    elif name == 'fcos':
+        cfg = dict(base, data_shape=[size, size, 3], nms_score_threshold=0.5, nms_max_boxes=10, nms_iou_threshold=0.45)
+    elif name == 'centernet':
+        cfg = dict(base, input_size=size, score_threshold=0.1, top_k_results_output=100)
+    else:
+        raise KeyError(name)
+    cfg.update(extra)
+    return cfg, size, batch, dtype
+
+
+def make(name, batch=None, size=None, dtype=None, seed=1000, **extra):
+    """-> dict(model, images, gt, lr, batch, size, dtype).  The batch is NOT loaded yet (call model.set_batch)."""
+    import odtk
+    cfg, size, batch, dtype = config_of(name, batch, size, dtype, **extra)
+    images, gt = synthetic_batch(name, batch, size, seed)
+    prov = {'data_shape': [size, size, 3], 'num_train': batch, 'num_val': 0, 'train_generator': [(images, gt)], 'val_generator': None}
+    cls = {'ssd300': 'SSD300', 'retinanet': 'RetinaNet', 'yolov3': 'YOLOv3', 'fcos': 'FCOS', 'centernet': 'CenterNet'}[name]
+    model = getattr(odtk, cls)(cfg, prov)
+    return dict(model=model, images=images, gt=gt, lr=SHAPES[name][3], batch=batch, size=size, dtype=dtype, name=name)
+
+
+def conv_layers(name, model):
+    """[(ConvDesc, cin, cout, k)] of every convolution LAUNCH GROUP of a step with the ALGORITHMIC channel counts (the descriptors carry
+    channel counts padded to whole 16-byte chunks: 7 -> 8, 3 -> 8, 85 -> 88 ...)."""
+    out = []
+    if name == 'ssd300':
+        for lname, c in model.convs.items():
+            out.append((model.desc[lname], c.cin if lname != 'conv1_1' else 3, c.cout, model.desc[lname].R))
+    elif name == 'yolov3':
+        for lname, cin, cout, k, s, _ in model.specs:
+            out.append((model.desc[lname], cin, cout, k))
+    elif name == 'retinanet':
+        for lname, cin, cout, k, *_ in model.specs:
+            out.append((model.desc[lname], cin, cout, k))
+    elif name == 'fcos':
+        spec = {s[0]: s for s in model.specs}
+        for lname, d in model.desc.items():                       # head layers: one launch per pyramid level ('l<k>@<level>')
+            s = spec[lname.split('@')[0]]
+            out.append((d, s[1], s[2], s[3]))
+    elif name == 'centernet':
+        for lname, kind, ci, co, k, s, _, ghost in model.specs:
+            if not ghost:
+                out.append((model.desc[lname], ci, co, k))     # transposed conv: d is its stride-2 conv (output = the layer's input)
+    return out
+
+
+def conv_flops_per_step(name, model):
+    """algorithmic conv FLOPs of one training step: forward + input gradient + filter gradient of every layer (the first layer has no input gradient)"""
+    total = 0.0
+    for i, (d, cin, cout, k) in enumerate(conv_layers(name, model)):
+        f = 2.0 * d.N * d.Ho * d.Wo * cout * cin * k * k
+        total += 3 * f if i > 0 else 2 * f
+    return total

@@ -14,7 +14,7 @@ BN_EPS, BN_MOM = 1e-3, 0.99
 def _storage(y):
     """the kernels get a raw pointer (here: into the middle of the [N][A][width] prediction tensor) and address past the view they were
     handed: (whole storage as a flat tensor, element offset of y in it)"""
-    return torch.empty(0, dtype=y.dtype).set_(y.untyped_storage()), y.storage_offset()
+    return torch.empty(0, dtype=y.dtype, device=y.device).set_(y.untyped_storage()), y.storage_offset()
 
 
 def _nhwc(rows, d_or_shape, C):
@@ -51,7 +51,7 @@ def conv2d_dgrad(d, dy, lddy, w_t, relu_src, dx, accumulate):
     Kp = lddy
     wt = w_t.float().reshape(d.C, d.R * d.S, Kp)
     w = wt.flip(1)[:, :, :d.K].permute(2, 1, 0).reshape(d.K, d.R, d.S, d.C)              # undo the flip / transpose of filter_prepare
-    x = torch.zeros(d.N, d.H, d.W, d.C, requires_grad=True)
+    x = torch.zeros(d.N, d.H, d.W, d.C, requires_grad=True, device=dy.device)
     out = _conv(x, w, d)
     g, = torch.autograd.grad(out, x, dy[:, :d.K].float().reshape(out.shape))
     g = g.reshape(-1, d.C)
@@ -63,7 +63,7 @@ def conv2d_dgrad(d, dy, lddy, w_t, relu_src, dx, accumulate):
 
 
 def conv2d_wgrad(d, x, dy, lddy, dw, dbias=None):
-    w = torch.zeros(d.K, d.R, d.S, d.C, requires_grad=True)
+    w = torch.zeros(d.K, d.R, d.S, d.C, requires_grad=True, device=x.device)
     out = _conv(_nhwc(x, (d.N, d.H, d.W), d.C), w, d)
     g, = torch.autograd.grad(out, w, dy[:, :d.K].float().reshape(out.shape))
     dw.view(-1)[: g.numel()] += g.reshape(-1)
@@ -77,30 +77,30 @@ class FilterPrepareBatch:
 
     def run(self):
         for (w, wt, K, R, S, C_, Kp) in self.entries:
-            full = torch.zeros(C_, R * S, Kp)
+            full = torch.zeros(C_, R * S, Kp, device=w.device)
             full[:, :, :K] = w.float().reshape(K, R * S, C_).permute(2, 1, 0).flip(1)
             wt.copy_(full.reshape(-1).to(wt.dtype))
 
 
 def preprocess(images, mean3, ldx, dtype, x):
     x.zero_()
-    x[:, :3] = (images.float() - torch.tensor(mean3, dtype=torch.float32)).reshape(-1, 3).to(x.dtype)
+    x[:, :3] = (images.float() - torch.tensor(mean3, dtype=torch.float32, device=images.device)).reshape(-1, 3).to(x.dtype)
 
 
 def _act(v, relu):
     return torch.relu(v) if relu == 1 else (torch.where(v > 0, v, 0.1 * v) if relu == 2 else v)
 
 
-def _strided_index(M, C_, ldy, rows_per_img, y_img_stride, base):
-    m = torch.arange(M)
-    return (base + (m // rows_per_img) * y_img_stride + (m % rows_per_img) * ldy).view(-1, 1) + torch.arange(C_).view(1, -1)
+def _strided_index(M, C_, ldy, rows_per_img, y_img_stride, base, device=None):
+    m = torch.arange(M, device=device)
+    return (base + (m // rows_per_img) * y_img_stride + (m % rows_per_img) * ldy).view(-1, 1) + torch.arange(C_, device=device).view(1, -1)
 
 
 def _read_rows(y, M, C_, ldy, rows_per_img, y_img_stride):
     if y_img_stride == 0 and rows_per_img == M and y.dim() == 2:
         return y[:M, :C_].float()
     flat, base = _storage(y)
-    return flat[_strided_index(M, C_, ldy, rows_per_img, y_img_stride, base).reshape(-1)].reshape(M, C_).float()
+    return flat[_strided_index(M, C_, ldy, rows_per_img, y_img_stride, base, y.device).reshape(-1)].reshape(M, C_).float()
 
 
 def _write_rows(y, vals, M, C_, ldy, rows_per_img, y_img_stride):
@@ -108,7 +108,7 @@ def _write_rows(y, vals, M, C_, ldy, rows_per_img, y_img_stride):
         y[:M, :C_] = vals.to(y.dtype)
         return
     flat, base = _storage(y)
-    flat[_strided_index(M, C_, ldy, rows_per_img, y_img_stride, base).reshape(-1)] = vals.reshape(-1).to(flat.dtype)
+    flat[_strided_index(M, C_, ldy, rows_per_img, y_img_stride, base, y.device).reshape(-1)] = vals.reshape(-1).to(flat.dtype)
 
 
 def bn_fwd(z, M, C_, ldz, gamma, beta, mmean, mvar, save_mean, save_invstd, training, relu, y, ldy, rows_per_img, y_img_stride, ws):
@@ -154,8 +154,8 @@ def upsample2x_bwd(dy, lddy, dx, lddx, N, H, W, C_, accumulate=False):
 
 def _bilinear(x_nhwc, Ho, Wo):
     n, h, w, c = x_nhwc.shape
-    fy = torch.arange(Ho, dtype=torch.float32) * (h / Ho)
-    fx = torch.arange(Wo, dtype=torch.float32) * (w / Wo)
+    fy = torch.arange(Ho, dtype=torch.float32, device=x_nhwc.device) * (h / Ho)
+    fx = torch.arange(Wo, dtype=torch.float32, device=x_nhwc.device) * (w / Wo)
     y0, x0 = torch.floor(fy).long(), torch.floor(fx).long()
     y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
     ly, lx = (fy - y0.float()).view(1, Ho, 1, 1), (fx - x0.float()).view(1, 1, Wo, 1)
@@ -170,7 +170,7 @@ def resize_bilinear_fwd(x, ldx, y, ldy, N, H, W, Ho, Wo, C_, accumulate=False):
 
 
 def resize_bilinear_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, accumulate=False):
-    x = torch.zeros(N, H, W, C_, requires_grad=True)
+    x = torch.zeros(N, H, W, C_, requires_grad=True, device=dy.device)
     g, = torch.autograd.grad(_bilinear(x, Ho, Wo), x, dy[:, :C_].float().reshape(N, Ho, Wo, C_))
     dx[:, :C_] = (g.reshape(-1, C_) + (dx[:, :C_].float() if accumulate else 0.)).to(dx.dtype)
 
@@ -179,8 +179,8 @@ def _bilinear2(x_nhwc, Ho, Wo, align_corners):
     n, h, w, c = x_nhwc.shape
     sy = (h - 1) / (Ho - 1) if (align_corners and Ho > 1) else h / Ho
     sx = (w - 1) / (Wo - 1) if (align_corners and Wo > 1) else w / Wo
-    fy = torch.arange(Ho, dtype=torch.float32) * torch.tensor(sy, dtype=torch.float32)
-    fx = torch.arange(Wo, dtype=torch.float32) * torch.tensor(sx, dtype=torch.float32)
+    fy = torch.arange(Ho, dtype=torch.float32, device=x_nhwc.device) * torch.tensor(sy, dtype=torch.float32)
+    fx = torch.arange(Wo, dtype=torch.float32, device=x_nhwc.device) * torch.tensor(sx, dtype=torch.float32)
     y0, x0 = torch.floor(fy).long(), torch.floor(fx).long()
     y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
     ly, lx = (fy - y0.float()).view(1, Ho, 1, 1), (fx - x0.float()).view(1, 1, Wo, 1)
@@ -195,7 +195,7 @@ def resize_bilinear2_fwd(x, ldx, y, ldy, N, H, W, Ho, Wo, C_, align_corners, acc
 
 
 def resize_bilinear2_bwd(dy, lddy, dx, lddx, N, H, W, Ho, Wo, C_, align_corners, accumulate=False, relu_src=None):
-    x = torch.zeros(N, H, W, C_, requires_grad=True)
+    x = torch.zeros(N, H, W, C_, requires_grad=True, device=dy.device)
     g, = torch.autograd.grad(_bilinear2(x, Ho, Wo, align_corners), x, dy[:, :C_].float().reshape(N, Ho, Wo, C_))
     g = g.reshape(-1, C_)
     if relu_src is not None:
@@ -232,7 +232,7 @@ def rows_to_f32(x, ldx, y, ldy, rows_per_img, y_img_stride, M, C_):
     flat, base = _storage(y)
     for n in range(M // rows_per_img):
         blk = x[n * rows_per_img:(n + 1) * rows_per_img, :C_].float()
-        idx = base + n * y_img_stride + torch.arange(rows_per_img).view(-1, 1) * ldy + torch.arange(C_).view(1, -1)
+        idx = base + n * y_img_stride + torch.arange(rows_per_img, device=y.device).view(-1, 1) * ldy + torch.arange(C_, device=y.device).view(1, -1)
         flat[idx.reshape(-1)] = blk.reshape(-1)
 
 
@@ -240,7 +240,7 @@ def rows_from_f32(y, ldy, rows_per_img, y_img_stride, x, ldx, M, C_):
     flat, base = _storage(y)
     x.zero_()
     for n in range(M // rows_per_img):
-        idx = base + n * y_img_stride + torch.arange(rows_per_img).view(-1, 1) * ldy + torch.arange(C_).view(1, -1)
+        idx = base + n * y_img_stride + torch.arange(rows_per_img, device=y.device).view(-1, 1) * ldy + torch.arange(C_, device=y.device).view(1, -1)
         x[n * rows_per_img:(n + 1) * rows_per_img, :C_] = flat[idx.reshape(-1)].reshape(rows_per_img, C_).to(x.dtype)
 
 
@@ -503,7 +503,7 @@ def scratch_slot(slot):
 # ---- CenterNet: input transform, 2x2 average pooling, Adam, loss / decode
 def preprocess_norm(images, div, mean3, std3, ldx, dtype, x):
     x.zero_()
-    v = (images.float() / div - torch.tensor(mean3, dtype=torch.float32)) / torch.tensor(std3, dtype=torch.float32)
+    v = (images.float() / div - torch.tensor(mean3, dtype=torch.float32, device=images.device)) / torch.tensor(std3, dtype=torch.float32, device=images.device)
     x[:, :3] = v.reshape(-1, 3).to(x.dtype)
 
 

@@ -271,3 +271,45 @@ def test_yolov2_two_ranks_one_gpu(tmp_path, dev):
     assert float((g - total).norm()) < 1e-4 * float(total.norm())          # f32 engine; filter gradients use float atomics
     after = p0 - 0.002 * (total + 1e-4 * p0)                                # first momentum step: accum = grad + wd * var
     assert float((a['P'].to(total.device) - after).norm()) < 1e-4 * float((after - p0).norm()) + 1e-7 * float(p0.norm())
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _bench_json(argv, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_world1_launch_check(dev):
+    """`bench.py --launch-check` on a GPU box builds a REAL RCCL process group (backend nccl, device_id binding, the dmabuf IPC environment) even for one
+    rank and runs ncclAllReduce on it -- the part of the N > 1 path that one GPU can execute."""
+    out = _bench_json(['--launch-check', '--gpus', '1', '--steps', '5', '--warmup', '2'])
+    assert out['metric'] == 'launch-check' and out['comm']['backend'] == 'nccl' and out['comm']['world_size'] == 1 and out['comm']['allreduce_ok']
+
+
+@pytest.mark.parametrize('grad_dtype', ['f32', 'bf16'])
+def test_rccl_world1_data_parallel_training_step(dev, grad_dtype):
+    """`bench.py --dp-world1`: the SSD300 data-parallel step with RCCL in a world of ONE rank -- gradient buckets, one backward HIP graph per bucket
+    captured thread-locally beside RCCL's watchdog, an ncclAllReduce per bucket launched between the replays, (bf16: narrowed / widened buckets) -- and
+    the loss stays that of the single-device step (the sum over one rank is the identity)."""
+    base = ['--gpus', '1', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-conv-events']
+    dp = _bench_json(base + ['--dp-world1', '--grad-dtype', grad_dtype])
+    one = _bench_json(base)
+    assert dp['comm']['backend'] == 'nccl' and dp['comm']['world_size'] == 1 and dp['comm']['buckets'] >= 3
+    assert dp['comm']['gradient_dtype'] == grad_dtype and dp['comm']['allreduce_ms_per_step'] > 0
+    assert 'bucket graphs' in dp['config']['launch'], dp['config']['launch']
+    tol = 2e-2 if grad_dtype == 'bf16' else 2e-3          # same seeds, same batch: f32 atomics order (and the bf16 wire format) only
+    assert abs(dp['config']['final_loss'] - one['config']['final_loss']) <= tol * abs(one['config']['final_loss']), (dp['config'], one['config'])

@@ -1,0 +1,55 @@
+"""BASELINE.json's configurations AT THEIR STATED SHAPES on the GPU: every launch of a whole training step of RetinaNet 800x800 batch 16,
+YOLOv3 416x416 batch 8 (config 4's per-GPU share), FCOS 512x512 batch 16 and CenterNet 512x512 batch 16 (config 5's per-GPU share) -- and of
+SSD300 300x300 batch 32 -- is shadowed in situ (tests/insitu.py): re-executed in plain f32 PyTorch from the engine's own stored inputs of that
+launch and compared.  Tile counts, persistent multi-tile walks, split-K decisions, pixel splits of the filter gradients and the 32-bit DMA offsets
+all change with the batch and map size, so the toy-shape model tests (tests/test_gpu_*_model.py: 64-160 px, batch 2) do not cover them.
+Each class is run on the engine it DEFAULTS to, and on its bf16 engine -- the kernel-level evidence behind every bf16 throughput figure quoted in
+BASELINE.md (what bf16 does to the gradients end to end is a property of the arithmetic, characterised separately: tests/test_gpu_engine_bf16.py,
+DESIGN.md 5).  The box-side launches are checked in the same pass: loss and d(prediction) against the oracle on the engine's own logits.
+
+Reference shapes: testretinanet.py:22-42, testYOLOv3.py:17-41, testfcos.py:20-32, testcenternet.py."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import insitu          # noqa: E402
+import mock_ops        # noqa: E402
+
+CASES = [('retinanet', 'f32'), ('yolov3', 'bf16'), ('fcos', 'f32'), ('centernet', 'f32'),          # the engine each class defaults to
+         ('ssd300', 'bf16'), ('retinanet', 'bf16'), ('yolov3', 'f32'), ('fcos', 'bf16'), ('centernet', 'bf16')]
+
+
+@pytest.mark.parametrize('name,dtype', CASES, ids=[f'{n}-{d}' for n, d in CASES])
+def test_every_launch_in_situ_at_baseline_shape(name, dtype):
+    import bench_configs as BC
+    torch.set_num_threads(16)
+    assert BC.SHAPES[name][2] == dtype or (name, dtype) in CASES[4:]
+    sh = insitu.Shadow()
+    with sh.installed():
+        r = BC.make(name, dtype=dtype, use_graph=False)
+        m = r['model']
+        size0, batch0, _, _ = BC.SHAPES[name]
+        assert r['size'] == size0 and r['batch'] == batch0                       # the stated shape, not a reduced one
+        if name == 'retinanet':
+            mock_ops.retina_loss.anchors = tuple(t.cpu() for t in m.anc)
+            assert m.num_anchor_boxes == 120087
+        m.set_batch(r['images'], r['gt'])
+        m.train_step(r['lr'])                     # un-shadowed first step: lazily grown scratch exists, momentum / moving statistics are non-trivial
+        sh.recording = True
+        loss = m.train_step(r['lr'])
+        sh.recording = False
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss).all())
+    rows = sh.check(insitu.default_tol(dtype), verbose=True, label=f'{name} {dtype} {size0}x{size0} batch {batch0}')
+    seen = {x['op'] for x in rows}
+    assert {'conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad'} <= seen and any(o.endswith('_loss') for o in seen)
+    n_conv = len(BC.conv_layers(name, m))
+    assert sum(1 for x in rows if x['op'] == 'conv2d_fwd') >= n_conv - 1 and sum(1 for x in rows if x['op'] == 'conv2d_wgrad' and x['out'] == 'dw') >= n_conv - 1
+    del m, r
+    torch.cuda.empty_cache()

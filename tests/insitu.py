@@ -55,6 +55,37 @@ PASS = {'ssd_match', 'softmax_ce_const', 'retina_match', 'nms_batched', 'scratch
 WHOLE_STORAGE_MAX = 1 << 30
 
 
+# Reductions whose terms cancel (the bias gradient of a convolution in front of a batch norm is sum(dz) = 0 in exact arithmetic; dgamma / dbeta of a
+# normalisation likewise sum signed terms): both sides return round-off, and an error relative to the RESULT says nothing.  For these outputs the
+# error is taken relative to the sum of the ABSOLUTE terms (what the forward error bound of a summation is stated against).
+def _bn_terms(a):
+    d = mock_ops._read_rows(a['dy'], a['M'], a['C_'], a['ldy'], a['rows_per_img'], a['y_img_stride'])
+    if a['relu']:
+        yv = mock_ops._read_rows(a['y'], a['M'], a['C_'], a['ldy'], a['rows_per_img'], a['y_img_stride'])
+        d = d * (yv > 0) if a['relu'] == 1 else torch.where(yv > 0, d, 0.1 * d)
+    xh = (a['z'][:a['M'], :a['C_']].float() - a['save_mean']) * a['save_invstd']
+    return d, xh
+
+
+def _gn_terms(a):
+    d = a['dy'][:, :a['C_']].float()
+    if a['relu']:
+        d = d * (a['y'][:, :a['C_']].float() > 0)
+    xh = mock_ops._gn_xhat(a['x'], a['N'], a['HW'], a['C_'], a['groups'], a['save'][:, :, 0], a['save'][:, :, 1]).reshape(a['N'] * a['HW'], a['C_'])
+    return d, xh
+
+
+COND = {
+    ('conv2d_wgrad', 'dbias'): lambda a: a['dy'][:, :a['d'].K].float().abs().sum(0),
+    ('bn_bwd', 'dbeta'): lambda a: _bn_terms(a)[0].abs().sum(0),
+    ('bn_bwd', 'dgamma'): lambda a: (lambda d, xh: (d * xh).abs().sum(0))(*_bn_terms(a)),
+    ('l2norm_bwd', 'dgamma'): lambda a: (lambda v, d: (d * v / torch.sqrt(torch.clamp((v * v).sum(1, keepdim=True), min=1e-12))).abs().sum().view(1))(
+        a['x'][:a['M'], :a['C_']].float(), a['dy'][:a['M'], :a['C_']].float()),
+    ('gn_bwd', 'dbeta'): lambda a: _gn_terms(a)[0].abs().sum(0),
+    ('gn_bwd', 'dgamma'): lambda a: (lambda d, xh: (d * xh).abs().sum(0))(*_gn_terms(a)),
+}
+
+
 def _map(obj, f):
     if isinstance(obj, torch.Tensor):
         return f(obj)
@@ -135,8 +166,9 @@ class Shadow:
         return flat.as_strided(t.shape, t.stride(), t.storage_offset())
 
     # ------------------------------------------------------------------ comparison
-    def _compare(self, op, pname, real, mock, snap, col=None):
-        """relative error (Frobenius) of the engine's output against the restatement's, over the elements the restatement wrote"""
+    def _compare(self, op, pname, real, mock, snap, col=None, scale=None):
+        """relative error (Frobenius) of the engine's output against the restatement's, over the elements the restatement wrote; `scale`: the
+        sum of absolute terms of a cancelling reduction (COND), which then replaces the restatement's own norm as the denominator"""
         if real is None or mock is None:
             return
         for r, m, s in zip(_flat(real, []), _flat(mock, []), _flat(snap, [])):
@@ -155,6 +187,9 @@ class Shadow:
             diff = torch.where(wrote, rf - mf, torch.zeros_like(rf))
             num = torch.sqrt((diff * diff).sum())
             den = torch.sqrt(torch.where(wrote, mf * mf, torch.zeros_like(mf)).sum())
+            if scale is not None:
+                sc = scale.detach().double().reshape(-1)[: mf.numel()]
+                den = torch.sqrt((sc * sc).sum())
             stray = (~wrote & (rf != sf)).sum()           # elements the engine changed and the restatement did not
             self.records.append(dict(op=op, seq=self.seq, out=pname, rel=(num / (den + 1e-30)).float(), den=den.float(), wrote=wrote.sum(), stray=stray,
                                      numel=r.numel(), dtype=str(r.dtype), exact=False, shape=tuple(r.shape)))
@@ -188,7 +223,9 @@ class Shadow:
             if name == 'maxpool2x2_fwd_idx':
                 mock_ops._POOL_ARGMAX[bound.arguments['idx'].data_ptr()] = mock_ops._POOL_ARGMAX.pop(margs['idx'].data_ptr())
             for o in outs:
-                self._compare(name, o[0], bound.arguments.get(o[0]), margs.get(o[0]), snap.get(o[0]), o[1] if len(o) > 1 else None)
+                cond = COND.get((name, o[0]))
+                scale = cond(margs) if (cond is not None and margs.get(o[0]) is not None) else None
+                self._compare(name, o[0], bound.arguments.get(o[0]), margs.get(o[0]), snap.get(o[0]), o[1] if len(o) > 1 else None, scale)
             self.seq += 1
             return r
         f.__name__ = name
@@ -243,7 +280,7 @@ class Shadow:
         if verbose:
             per_op = {}
             for r_ in rows:
-                a = per_op.setdefault(r_['op'] + ':' + r_['out'], [0, 0.0, 0.0])
+                a = per_op.setdefault(r_['op'] + ':' + r_['out'].split('[')[0], [0, 0.0, 0.0])
                 a[0] += 1; a[1] = max(a[1], r_['rel']); a[2] += r_.get('stray', 0.0)
             print(f'[in-situ {label}] {n} launches shadowed, {len(rows)} outputs compared; worst relative error per launch kind:')
             for k, (cnt, worst, stray) in sorted(per_op.items(), key=lambda kv: -kv[1][1]):
@@ -259,16 +296,20 @@ class Shadow:
 
 
 def default_tol(engine_dtype):
-    """bounds of ONE launch: bf16 engine -- one bf16 store of an f32-accurate value (2^-9 per element, ~1.1e-3 in the Frobenius norm; measured
-    1.0-1.7e-3 on SSD300) -> 3e-3; a buffer that is accumulated into is rounded twice -> 6e-3; f32 outputs of long reductions over bf16 operands
-    2e-3.  f32 engine: accumulation order only -> 2e-4 (f32 atomics over up to 2.5 M pixels included)."""
+    """bounds of ONE launch, set from what the BASELINE-shape runs measure (profiles/r03_insitu_configs.md) with a 5-10x margin -- a wrong tile or
+    a stale partial is O(1).  Both sides store through the same rounding, so a bf16 output differs only where the f32 accumulation order moves a value
+    across a rounding boundary (measured 4-7e-5); a bf16 buffer that is ACCUMULATED into is rounded twice by the engine and once by the restatement
+    (measured 2.8e-3 = one bf16 rounding of the first addend).  f32 engine: accumulation order only, f32 atomics over up to 2.5 M pixels included
+    (measured <= 1e-5).  Box-side losses and their gradients against the oracles on the engine's own logits: <= 1e-6 measured."""
+    twice = ('conv2d_dgrad', 'add2d', 'relu_bwd', 'upsample2x_bwd', 'resize_bilinear_fwd', 'resize_bilinear_bwd', 'copy_channels', 'l2norm_bwd', 'gn_bwd',
+             'bn_bwd', 'maxpool_bwd', 'resize_bilinear2_bwd', 'resize_bilinear2_fwd')
+
     def tol(row):
         if row['op'] in ON_CPU:
-            return 2e-3 if not row['out'].startswith('loss') else 2e-4      # gradients of mined / matched losses vs autograd of the oracle
+            return 1e-4
         if engine_dtype == 'f32':
-            return 2e-4
+            return 5e-5
         if row['dtype'] == 'torch.bfloat16':
-            return 6e-3 if row['op'] in ('conv2d_dgrad', 'add2d', 'relu_bwd', 'upsample2x_bwd', 'resize_bilinear_fwd', 'resize_bilinear_bwd', 'copy_channels',
-                                         'l2norm_bwd', 'gn_bwd', 'bn_bwd', 'maxpool_bwd', 'resize_bilinear2_bwd', 'resize_bilinear2_fwd') else 3e-3
-        return 2e-3
+            return 6e-3 if row['op'] in twice else 4e-4
+        return 2e-4
     return tol

@@ -15,12 +15,14 @@ import time
 
 
 def sysfs_sources():
-    out = {}
+    """hwmon files of EVERY amdgpu card of the node (a box shows all of the node's cards in sysfs, not only the one the container may use):
+    all are sampled, the card whose power moves with the run is the one reported"""
+    cards = []
     for dev in sorted(glob.glob('/sys/class/drm/card*/device')):
         hw = sorted(glob.glob(os.path.join(dev, 'hwmon', 'hwmon*')))
         if not hw:
             continue
-        h = hw[0]
+        h, out = hw[0], {'card': dev.split('/')[-2]}
         for key, names in (('power_uw', ('power1_average', 'power1_input')), ('sclk_hz', ('freq1_input',)), ('mclk_hz', ('freq2_input',)),
                            ('temp_mc', ('temp2_input', 'temp1_input'))):
             for n in names:
@@ -28,9 +30,20 @@ def sysfs_sources():
                 if os.path.exists(p):
                     out[key] = p
                     break
-        if 'power_uw' in out or 'sclk_hz' in out:
-            return out
-    return out
+        if 'power_uw' in out and 'sclk_hz' in out:
+            cards.append(out)
+    return cards
+
+
+def visible_pci_bus():
+    """PCI address (0000:bb:dd.f) of HIP device 0 of this container"""
+    try:
+        r = subprocess.run([sys.executable, '-c', 'import torch; p = torch.cuda.get_device_properties(0); '
+                            'print("%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id))'], capture_output=True, text=True, timeout=120)
+        out = r.stdout.strip().splitlines()
+        return out[-1] if out else None
+    except Exception:                                           # noqa: BLE001
+        return None
 
 
 def read_int(path):
@@ -66,17 +79,20 @@ def main():
     out_path = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     extra = sys.argv[3:]
-    src = sysfs_sources()
-    use_sysfs = 'power_uw' in src and 'sclk_hz' in src
+    cards = sysfs_sources()
+    use_sysfs = bool(cards)
     period = 0.02 if use_sysfs else 0.0
 
     def sample():
         if use_sysfs:
-            v = {'power_w': (read_int(src['power_uw']) or 0) / 1e6, 'sclk_mhz': (read_int(src['sclk_hz']) or 0) / 1e6}
-            if 'temp_mc' in src:
-                v['temp_c'] = (read_int(src['temp_mc']) or 0) / 1e3
-            return v
-        return smi_sample()
+            out = []
+            for src in cards:
+                v = {'power_w': (read_int(src['power_uw']) or 0) / 1e6, 'sclk_mhz': (read_int(src['sclk_hz']) or 0) / 1e6}
+                if 'temp_mc' in src:
+                    v['temp_c'] = (read_int(src['temp_mc']) or 0) / 1e3
+                out.append(v)
+            return out
+        return [smi_sample()]
 
     samples = []
     t0 = time.time()
@@ -96,6 +112,23 @@ def main():
         samples.append((time.time() - t0, 'after', sample()))
         time.sleep(period)
 
+    # the card under test: the one whose PCI address is the visible HIP device's (the node's other cards belong to other jobs and move too);
+    # fallback: the card whose power moved most through the run
+    ncard = len(samples[0][2])
+    spread = []
+    for c in range(ncard):
+        pwc = [x[2][c].get('power_w') or 0.0 for x in samples]
+        spread.append(max(pwc) - min(pwc))
+    pick = max(range(ncard), key=lambda c: spread[c])
+    bus = visible_pci_bus()
+    how = 'largest power spread'
+    if use_sysfs and bus:
+        for c, src_ in enumerate(cards):
+            if os.path.basename(os.path.realpath(os.path.join('/sys/class/drm', src_['card'], 'device'))).lower() == bus.lower():
+                pick, how = c, f'PCI {bus} = the visible HIP device'
+    samples = [(t, ph, v[pick]) for t, ph, v in samples]
+    src = cards[pick] if use_sysfs else {}
+    smi = smi_sample()
     pw = [s[2].get('power_w') for s in samples if s[2].get('power_w')]
     lo, hi = (min(pw), max(pw)) if pw else (0.0, 0.0)
     thr = lo + 0.5 * (hi - lo)
@@ -109,7 +142,8 @@ def main():
 
     with open(out_path, 'w') as f:
         f.write(f'# clock / power trace of `bench.py --steps {steps} {" ".join(extra)}`\n\n')
-        f.write(f'sampler: {"amdgpu hwmon sysfs, 20 ms period: " + json.dumps(src) if use_sysfs else "rocm-smi --showclocks --showpower --json, one process per sample"}\n\n')
+        f.write(f'sampler: {"amdgpu hwmon sysfs, 20 ms period, " + str(ncard) + " cards sampled, power spread per card " + str([round(x) for x in spread]) + " W; picked by " + how + " -> " + json.dumps(src) if use_sysfs else "rocm-smi --showclocks --showpower --json, one process per sample"}\n\n')
+        f.write(f'rocm-smi (the visible device, idle after the run): {json.dumps(smi)}\n\n')
         f.write(f'bench line: {json.dumps({k: bench.get(k) for k in ("value", "unit", "ms_per_step", "steps")})}\n\n')
         f.write(f'{len(samples)} samples over {samples[-1][0]:.1f} s; {len(busy)} of them under load (power >= {thr:.0f} W)\n\n')
         f.write('| phase | samples | shader clock MHz | socket power W | temperature C |\n|---|---|---|---|---|\n')

@@ -62,7 +62,7 @@ class ConvTimer:
 
     def install(self):
         ops = self.ops
-        for kind in ('conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad'):
+        for kind in ('conv2d_fwd', 'conv2d_fwd_pool2x2', 'conv2d_dgrad', 'conv2d_wgrad'):
             self._orig[kind] = getattr(ops, kind)
             setattr(ops, kind, self._wrap(kind))
 
@@ -81,7 +81,8 @@ class ConvTimer:
             s.record()
             r = orig(d, *args)
             e.record()
-            self.records.append((kind, self.ops.conv_last_kernel(), flops, s, e, abytes,
+            rkind = 'conv2d_fwd' if kind == 'conv2d_fwd_pool2x2' else kind      # conv + bias + ReLU + pool in one launch: the conv's FLOPs, its own time
+            self.records.append((rkind, self.ops.conv_last_kernel(), flops, s, e, abytes,
                                  (d.N, d.H, d.W, d.C, d.K, d.R, d.stride, d.dil)))
             return r
         return f
@@ -203,11 +204,13 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region')
+    ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region (the default at N = 1 since round 3)')
+    ap.add_argument('--graph', action='store_true', help='N = 1: replay forward + loss + backward from HIP graphs (A/B; measured 1-3 %% slower than eager launches)')
     ap.add_argument('--auto-launch', action='store_true', help="use_graph='auto': the faster of replay / eager launches, measured during warm-up")
     ap.add_argument('--wgrad-stream', action='store_true', help='A/B: filter gradients on a second HIP stream')
     ap.add_argument('--match-stream', action='store_true', help='A/B: box matching on a second HIP stream under the forward pass')
     ap.add_argument('--no-tail-stream', action='store_true', help='A/B: heads after the extra layers on one stream (round-1 order)')
+    ap.add_argument('--no-fuse-pool', action='store_true', help='A/B: conv1_2 and pool1 as two launches (the un-pooled map is stored and read back)')
     ap.add_argument('--sync-bn', action='store_true', help='N > 1: batch-norm statistics over all replicas (SURVEY 8e option B; eager launches)')
     ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
     ap.add_argument('--kernel-dbg', type=int, default=0, help='A/B: odtk_debug_set(2, bits) dispatch switches of csrc/conv_v3.hip (bits >= 1<<26 only)')
@@ -255,7 +258,7 @@ def main():
         'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
         'keep_prob': 0.5, 'batch_size': B, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20,
         'nms_iou_threshold': 0.5, 'pretraining_weight': os.path.join('.', 'vgg_16.ckpt'),
-        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else True,
+        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else (args.graph or args.gpus > 1 or args.dp_world1) and not args.eager, 'fuse_pool': not args.no_fuse_pool,
     }
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)

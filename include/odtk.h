@@ -88,6 +88,16 @@ typedef struct odtk_conv_desc {
 int odtk_conv2d_fwd(const odtk_conv_desc* d, const void* x, const void* w, const float* bias,
                     void* y, int relu, void* stream);
 
+/* odtk_conv2d_fwd followed by tf.layers.max_pooling2d(2, 2, 'same') in ONE launch where the kernel can (conv + bias + ReLU + pool1 of the VGG trunk,
+ * SSD300.py:201-209: the 369 MB bf16 map of conv1_2 at batch 32 is then never written nor read back).  y_pool [N][ceil(Ho/2)][ceil(Wo/2)][ld_pool]
+ * receives the pooled map, idx the recorded first arg-max in the format of odtk_maxpool2x2_fwd_idx (may be NULL outside training).  y may be NULL:
+ * the un-pooled output is then not stored at all -- only valid when nothing else reads it (training: the pool routes the gradient by idx, and
+ * the ReLU mask of the routed positions is the sign of the POOLED value).  Shapes the fused kernel does not cover run as the two launches
+ * (y must then be given; ODTK_ERR_ARG otherwise) -- odtk_conv2d_fwd_pool2x2_fused(d) tells which. */
+int odtk_conv2d_fwd_pool2x2(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu,
+                            void* y_pool, int ld_pool, void* idx, void* stream);
+int odtk_conv2d_fwd_pool2x2_fused(const odtk_conv_desc* d);
+
 /* dx[n,h,w,c] (+)= sum_{r,s,k} dy[n,ho,wo,k] * w[k,r,s,c]   (transposed conv of the fwd op)
  * w_t is the dgrad-layout filter produced by odtk_filter_to_dgrad: [C][R][S][Kp]
  * with taps flipped and Kp = dy pitch channels.  If relu_src != NULL the result is
@@ -151,6 +161,14 @@ int odtk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int ld,
 int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, void* dx, int N, int H, int W,
                      int C, int ld, int Ho, int Wo, int k, int stride, int pad_t, int pad_l,
                      int dtype, void* stream);
+/* Max pooling with OVERLAPPING windows (pool5 = tf.layers.max_pooling2d(3, 1, 'same'), SSD300.py:303) and a recorded arg-max: arg holds one uint32 per
+ * 16-byte output chunk, 4 bits per channel = the position r * k + s (k <= 3) of the first maximum of the window in scan order -- TF's MaxPoolGrad
+ * routing; odtk_maxpool_bwd_argmax then gathers dy over the windows that contain a pixel from arg + dy alone.  Results are identical to
+ * odtk_maxpool_fwd / odtk_maxpool_bwd. */
+int odtk_maxpool_fwd_argmax(const void* x, void* y, void* arg, int N, int H, int W, int C, int ld, int Ho, int Wo, int k, int stride,
+                            int pad_t, int pad_l, int dtype, void* stream);
+int odtk_maxpool_bwd_argmax(const void* arg, const void* dy, void* dx, int N, int H, int W, int C, int ld, int Ho, int Wo, int k, int stride,
+                            int pad_t, int pad_l, int dtype, void* stream);
 /* 2x2 / stride 2 / SAME (pad_before 0) pooling with a recorded arg-max (pool1..pool4): idx holds one uint16 per 16-byte
  * output chunk (2 bits per channel = the first window position holding the maximum, TF's gradient routing); the backward
  * pass then reads dy + idx only.  Results are identical to odtk_maxpool_fwd / _bwd. */

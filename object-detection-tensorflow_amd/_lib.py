@@ -48,6 +48,8 @@ SIGNATURES = {
     "odtk_scratch_slot": (_i, [_i]),
     "odtk_conv_last_kernel": (C.c_char_p, []),
     "odtk_conv2d_fwd": (_i, [_cd, _vp, _vp, _vp, _vp, _i, _vp]),
+    "odtk_conv2d_fwd_pool2x2": (_i, [_cd, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "odtk_conv2d_fwd_pool2x2_fused": (_i, [_cd]),
     "odtk_conv2d_dgrad": (_i, [_cd, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "odtk_conv2d_wgrad": (_i, [_cd, _vp, _vp, _i, _vp, _vp, _vp]),
     "odtk_filter_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -65,6 +67,8 @@ SIGNATURES = {
     "odtk_maxpool_fwd": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
     "odtk_maxpool_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "odtk_maxpool2x2_fwd_idx": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "odtk_maxpool_fwd_argmax": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "odtk_maxpool_bwd_argmax": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "odtk_maxpool2x2_bwd_idx": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "odtk_bn_moments": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "odtk_bn_fwd_given": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _ll, _vp, _vp]),

@@ -906,6 +906,47 @@ extern "C" int odtk_conv2d_fwd(const odtk_conv_desc* d, const void* x, const voi
     return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
 }
 
+static void fwd_args(GatherArgs& a, const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu) {
+    memset(&a, 0, sizeof(a));
+    a.x = (const char*)x; a.w = (const char*)w; a.bias = bias; a.mask = nullptr; a.y = (char*)y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.K = d->K; a.ldy = d->ldy; a.ldmask = 0;
+    a.R = d->R; a.S = d->S; a.ostride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+    a.idiv = 1;
+    a.M = d->N * d->Ho * d->Wo; a.Kdim = d->R * d->S * d->C; a.ldw = a.Kdim;
+    a.relu = relu; a.accumulate = 0;
+}
+
+extern "C" int odtk_conv2d_fwd_pool2x2_fused(const odtk_conv_desc* d) {
+    if (check_desc(d)) return 0;
+    GatherArgs a;
+    fwd_args(a, d, nullptr, nullptr, nullptr, nullptr, 1);
+    return (!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && gather_c64_supported(a, d->dtype, d->out_dtype)) ? 1 : 0;
+}
+
+extern "C" int odtk_maxpool2x2_fwd_idx(const void* x, void* y, void* idx, int N, int H, int W, int C, int ld, int Ho, int Wo, int dtype, void* stream);
+extern "C" int odtk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int ld, int Ho, int Wo, int k, int stride, int pad_t, int pad_l,
+                                int dtype, void* stream);
+
+extern "C" int odtk_conv2d_fwd_pool2x2(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu,
+                                       void* y_pool, int ld_pool, void* idx, void* stream) {
+    if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(x && w && y_pool, "conv2d_fwd_pool2x2: null pointer");
+    ODTK_REQUIRE(ld_pool % 8 == 0 && ld_pool >= d->K, "conv2d_fwd_pool2x2: ld_pool=%d must be a multiple of 8 and >= K=%d", ld_pool, d->K);
+    GatherArgs a;
+    fwd_args(a, d, x, w, bias, y, relu);
+    if (odtk_conv2d_fwd_pool2x2_fused(d) && idx != nullptr && ld_pool % 8 == 0) {
+        a.ypool = (char*)y_pool; a.pidx = (unsigned short*)idx; a.ldpool = ld_pool; a.pool_mode = y ? 1 : 2;
+        return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
+    }
+    ODTK_REQUIRE(y != nullptr, "conv2d_fwd_pool2x2: this shape runs as conv + pool and needs the un-pooled output buffer y");
+    ODTK_REQUIRE(ld_pool == d->ldy, "conv2d_fwd_pool2x2: the two-launch path needs ld_pool == ldy");
+    if (int e = dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream)) return e;
+    const int Hp = (d->Ho + 1) / 2, Wp = (d->Wo + 1) / 2;
+    if (idx) return odtk_maxpool2x2_fwd_idx(y, y_pool, idx, d->N, d->Ho, d->Wo, d->K, d->ldy, Hp, Wp, d->out_dtype, stream);
+    return odtk_maxpool_fwd(y, y_pool, d->N, d->Ho, d->Wo, d->K, d->ldy, Hp, Wp, 2, 2, 0, 0, d->out_dtype, stream);
+}
+
 extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t,
                                  const void* relu_src, void* dx, int accumulate, void* stream) {
     if (int e = check_desc(d)) return e;

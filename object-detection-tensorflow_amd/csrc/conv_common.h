@@ -144,6 +144,12 @@ struct GatherArgs {
     unsigned x_bytes, w_bytes;   // extents of x and w for the buffer-addressed DMA (range check = zero fill)
     int ksplit;        // split-K: blocks per tile (1 = off) and their f32 partial tiles [ksplit][M][ldy]
     float* ws;
+    // fused 2x2 / stride-2 max pooling of the (bias + ReLU) output in the epilogue (odtk_conv2d_fwd_pool2x2; conv3x3_c64k64_kernel only):
+    // pool_mode 0 = off, 1 = y AND the pooled map, 2 = the pooled map only (y is never written).  ypool [N][ceil(H/2)][ceil(W/2)][ldpool],
+    // pidx = the recorded first arg-max (2 bits per channel, one uint16 per 16-byte chunk: the format of odtk_maxpool2x2_fwd_idx)
+    char* ypool;
+    unsigned short* pidx;
+    int ldpool, pool_mode;
 };
 
 struct WgradArgs {
@@ -257,7 +263,7 @@ __device__ __forceinline__ void post_chunk(uint4& v, bool accumulate, bool relu,
 bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype);
 int launch_gather_v3(GatherArgs& a, hipStream_t st);
 int launch_gather_v4(GatherArgs& a, hipStream_t st);   // persistent, loader/compute wave-specialised
-bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype);   // resident-filter 64->64 3x3 kernel
+bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype);   // resident-filter 64->64 3x3 kernel (the only one with the fused pool)
 int launch_gather_c64(GatherArgs& a, hipStream_t st);
 bool gather_c8_supported(const GatherArgs& a, int dtype, int out_dtype);    // first-layer (3 -> 64) 3x3 kernel
 int launch_gather_c8(GatherArgs& a, hipStream_t st);

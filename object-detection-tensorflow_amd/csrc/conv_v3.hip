@@ -1707,16 +1707,66 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
                 }
         }
         asm volatile("" ::: "memory");          // wave-private patch, in-order LDS: only pins the compiler (TBAA)
+        if (a.pool_mode != 2) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int idx = r * 64 + lane;
-            const int pxl = idx >> 3, ch = idx & 7;
-            const int h = ch0 + 2 * wave + (pxl >> 5), w = cw0 + (pxl & 31);
-            uint4 v = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
-            if (h < a.H && w < a.W) {
-                const size_t m = (size_t)(cn * a.H + h) * a.W + w;
-                if (a.mask) post_chunk(v, false, false, mk[r], true, mk[r]);
-                *reinterpret_cast<uint4*>(a.y + (m * a.ldy + ch * 8) * 2) = v;
+            for (int r = 0; r < 8; ++r) {
+                const int idx = r * 64 + lane;
+                const int pxl = idx >> 3, ch = idx & 7;
+                const int h = ch0 + 2 * wave + (pxl >> 5), w = cw0 + (pxl & 31);
+                uint4 v = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
+                if (h < a.H && w < a.W) {
+                    const size_t m = (size_t)(cn * a.H + h) * a.W + w;
+                    if (a.mask) post_chunk(v, false, false, mk[r], true, mk[r]);
+                    *reinterpret_cast<uint4*>(a.y + (m * a.ldy + ch * 8) * 2) = v;
+                }
+            }
+        }
+        if (a.pool_mode) {
+            // fused tf.layers.max_pooling2d(2, 2, 'same') (SSD300.py:209): this wave's image holds tile rows 2w, 2w+1 -- both rows of 16 pooling
+            // windows (tile origins are even).  16 windows x 8 chunks = 128 tasks, two per lane: the four window pixels' chunks come back from
+            // the image, the FIRST maximum in scan order wins (strict >, as odtk_maxpool2x2_fwd_idx records it) and its position goes to pidx.
+            const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int task = r * 64 + lane;
+                const int pp = task >> 3, ch = task & 7;
+                const int h = ch0 + 2 * wave, w = cw0 + 2 * pp;
+                if (h < a.H && w < a.W) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int pxl = (t >> 1) * 32 + 2 * pp + (t & 1);
+                        v[t] = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
+                    }
+                    const bool in1 = w + 1 < a.W, in2 = h + 1 < a.H;
+                    const unsigned* u0 = reinterpret_cast<const unsigned*>(&v[0]);
+                    const unsigned* u1 = reinterpret_cast<const unsigned*>(&v[1]);
+                    const unsigned* u2 = reinterpret_cast<const unsigned*>(&v[2]);
+                    const unsigned* u3 = reinterpret_cast<const unsigned*>(&v[3]);
+                    uint4 best;
+                    unsigned* ub = reinterpret_cast<unsigned*>(&best);
+                    unsigned code = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned outw = 0;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const float x0 = half ? bf16_hi(u0[q]) : bf16_lo(u0[q]), x1 = half ? bf16_hi(u1[q]) : bf16_lo(u1[q]);
+                            const float x2 = half ? bf16_hi(u2[q]) : bf16_lo(u2[q]), x3 = half ? bf16_hi(u3[q]) : bf16_lo(u3[q]);
+                            float m = x0;
+                            unsigned am = 0;
+                            if (in1 && x1 > m) { m = x1; am = 1; }
+                            if (in2 && x2 > m) { m = x2; am = 2; }
+                            if (in1 && in2 && x3 > m) { m = x3; am = 3; }
+                            outw |= (__float_as_uint(m) >> 16) << (16 * half);       // m is one of the bf16 inputs: exact
+                            code |= am << (2 * (2 * q + half));
+                        }
+                        ub[q] = outw;
+                    }
+                    const size_t mo = (size_t)(cn * Hp + (h >> 1)) * Wp + (w >> 1);
+                    *reinterpret_cast<uint4*>(a.ypool + (mo * a.ldpool + ch * 8) * 2) = best;
+                    a.pidx[mo * 8 + ch] = (unsigned short)code;
+                }
             }
         }
         asm volatile("" ::: "memory");

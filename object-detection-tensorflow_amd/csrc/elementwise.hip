@@ -93,6 +93,83 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
     }
 }
 
+// Overlapping windows (pool5: 3x3 / stride 1) with a RECORDED arg-max: the forward pass also stores, per output chunk, 4 bits per channel = the
+// window position r * k + s of the first maximum in scan order (k <= 3); the backward pass is then a gather over the <= k x k windows that contain a
+// pixel which reads 4 B of codes + 16 B of dy per window -- instead of re-deriving every window's first maximum from up to k x k loads of x
+// (maxpool_bwd_kernel below: pool5 at batch 32 took 72 us for a 12-MB map).
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_argmax_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned* __restrict__ arg, int N, int H,
+                                                                 int W, int C, int ld, int Ho, int Wo, int k, int stride, int pad_t, int pad_l) {
+    constexpr int KC = Chunk<T>::N;
+    const int chunks = C / KC;
+    const unsigned total = (unsigned)N * Ho * Wo * chunks;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ch = (int)(i % (unsigned)chunks);
+        unsigned pix = i / (unsigned)chunks;
+        const int wo = (int)(pix % (unsigned)Wo); pix /= (unsigned)Wo;
+        const int ho = (int)(pix % (unsigned)Ho);
+        const int n = (int)(pix / (unsigned)Ho);
+        float best[KC];
+        unsigned code = 0;
+#pragma unroll
+        for (int e = 0; e < KC; ++e) best[e] = -INFINITY;
+        for (int r = 0; r < k; ++r) {
+            const int h = ho * stride - pad_t + r;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int s_ = 0; s_ < k; ++s_) {
+                const int w = wo * stride - pad_l + s_;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float f[KC];
+                Chunk<T>::unpack(ld16(x + ((size_t)(n * H + h) * W + w) * ld + ch * KC), f);
+                const unsigned pos = (unsigned)(r * k + s_);
+#pragma unroll
+                for (int e = 0; e < KC; ++e)
+                    if (f[e] > best[e]) {                     // strict >: the first maximum in scan order keeps the window
+                        best[e] = f[e];
+                        code = (code & ~(15u << (4 * e))) | (pos << (4 * e));
+                    }
+            }
+        }
+        st16(y + ((size_t)(n * Ho + ho) * Wo + wo) * ld + ch * KC, Chunk<T>::pack(best));
+        arg[i] = code;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_argmax_kernel(const unsigned* __restrict__ arg, const T* __restrict__ dy, T* __restrict__ dx, int N,
+                                                                 int H, int W, int C, int ld, int Ho, int Wo, int k, int stride, int pad_t, int pad_l) {
+    constexpr int KC = Chunk<T>::N;
+    const int chunks = C / KC;
+    const unsigned total = (unsigned)N * H * W * chunks;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ch = (int)(i % (unsigned)chunks);
+        unsigned pix = i / (unsigned)chunks;
+        const int w = (int)(pix % (unsigned)W); pix /= (unsigned)W;
+        const int h = (int)(pix % (unsigned)H);
+        const int n = (int)(pix / (unsigned)H);
+        float g[KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) g[e] = 0.f;
+        int ho_lo = (h + pad_t - k + 1 + stride - 1);
+        ho_lo = ho_lo < 0 ? 0 : ho_lo / stride;
+        int ho_hi = (h + pad_t) / stride; if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+        int wo_lo = (w + pad_l - k + 1 + stride - 1);
+        wo_lo = wo_lo < 0 ? 0 : wo_lo / stride;
+        int wo_hi = (w + pad_l) / stride; if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const size_t o = (size_t)(n * Ho + ho) * Wo + wo;
+                const unsigned code = arg[o * chunks + ch];
+                const unsigned pos = (unsigned)((h - (ho * stride - pad_t)) * k + (w - (wo * stride - pad_l)));   // this pixel's position in that window
+                float dv[KC];
+                Chunk<T>::unpack(ld16(dy + o * ld + ch * KC), dv);
+#pragma unroll
+                for (int e = 0; e < KC; ++e) g[e] += ((code >> (4 * e)) & 15u) == pos ? dv[e] : 0.f;
+            }
+        st16(dx + ((size_t)(n * H + h) * W + w) * ld + ch * KC, Chunk<T>::pack(g));
+    }
+}
+
 // gather formulation: (h,w) receives dy of window (ho,wo) iff it is the FIRST position of that
 // window (row-major scan) whose value equals the window max.
 template <typename T>
@@ -1198,6 +1275,34 @@ extern "C" int odtk_maxpool_bwd(const void* x, const void* y, const void* dy, vo
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
                                            (const T*)x, (const T*)y, (const T*)dy, (T*)dx, N, H, W, C, ld, Ho, Wo, k,
                                            stride, pad_t, pad_l);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_maxpool_fwd_argmax(const void* x, void* y, void* arg, int N, int H, int W, int C, int ld, int Ho, int Wo, int k, int stride,
+                                       int pad_t, int pad_l, int dtype, void* stream) {
+    ODTK_REQUIRE(x && y && arg, "maxpool_fwd_argmax: null pointer");
+    if (int e = pool_check(C, ld, dtype)) return e;
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(k >= 1 && k <= 3 && stride >= 1, "maxpool_fwd_argmax: window %d unsupported (4-bit position codes: k <= 3)", k);
+    const long long tot_o = (long long)N * Ho * Wo * (C / kc);
+    ODTK_REQUIRE(tot_o < (1ll << 31) && (long long)N * H * W * (C / kc) < (1ll << 31), "maxpool_fwd_argmax: tensor too large");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_fwd_argmax_kernel<T>, dim3(grid_for(tot_o, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)x, (T*)y, (unsigned*)arg, N, H, W, C, ld, Ho, Wo, k, stride, pad_t, pad_l);)
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_maxpool_bwd_argmax(const void* arg, const void* dy, void* dx, int N, int H, int W, int C, int ld, int Ho, int Wo, int k,
+                                       int stride, int pad_t, int pad_l, int dtype, void* stream) {
+    ODTK_REQUIRE(arg && dy && dx, "maxpool_bwd_argmax: null pointer");
+    if (int e = pool_check(C, ld, dtype)) return e;
+    const int kc = dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(k >= 1 && k <= 3 && stride >= 1, "maxpool_bwd_argmax: window %d unsupported", k);
+    const long long tot = (long long)N * H * W * (C / kc);
+    ODTK_REQUIRE(tot < (1ll << 31) && (long long)N * Ho * Wo * (C / kc) < (1ll << 31), "maxpool_bwd_argmax: tensor too large");
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_bwd_argmax_kernel<T>, dim3(grid_for(tot, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                                           (const unsigned*)arg, (const T*)dy, (T*)dx, N, H, W, C, ld, Ho, Wo, k, stride, pad_t, pad_l);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -83,6 +83,16 @@ def conv2d_fwd(d: ConvDesc, x, w, bias, y, relu: bool):
     call("odtk_conv2d_fwd", C.byref(d), _p(x), _p(w), _p(bias), _p(y), int(relu), _stream())
 
 
+def conv2d_fwd_pool2x2(d: ConvDesc, x, w, bias, y, relu: bool, y_pool, idx):
+    """conv (+ bias, ReLU) and the 2x2 / stride-2 SAME max pool behind it in one launch where libodtk can (include/odtk.h); y may be None: the
+    un-pooled output is then never stored"""
+    call("odtk_conv2d_fwd_pool2x2", C.byref(d), _p(x), _p(w), _p(bias), _p(y), int(relu), _p(y_pool), int(y_pool.shape[-1]), _p(idx), _stream())
+
+
+def conv2d_fwd_pool2x2_fused(d: ConvDesc) -> bool:
+    return bool(_lib.load().odtk_conv2d_fwd_pool2x2_fused(C.byref(d)))
+
+
 def conv2d_dgrad(d: ConvDesc, dy, lddy: int, w_t, relu_src, dx, accumulate: bool):
     call("odtk_conv2d_dgrad", C.byref(d), _p(dy), int(lddy), _p(w_t), _p(relu_src), _p(dx), int(accumulate),
          _stream())
@@ -151,6 +161,15 @@ def maxpool_fwd(x, y, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
 def maxpool_bwd(x, y, dy, dx, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
     call("odtk_maxpool_bwd", _p(x), _p(y), _p(dy), _p(dx), N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l,
          dt_of(x), _stream())
+
+
+def maxpool_fwd_argmax(x, y, arg, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
+    """max pooling (k <= 3, any stride: pool5's overlapping 3x3 / stride-1 windows) that records the arg-max (arg: int32 per 16-byte output chunk)"""
+    call("odtk_maxpool_fwd_argmax", _p(x), _p(y), _p(arg), N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l, dt_of(x), _stream())
+
+
+def maxpool_bwd_argmax(arg, dy, dx, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
+    call("odtk_maxpool_bwd_argmax", _p(arg), _p(dy), _p(dx), N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l, dt_of(dy), _stream())
 
 
 def maxpool2x2_fwd_idx(x, y, idx, N, H, W, C_, ld, Ho, Wo):

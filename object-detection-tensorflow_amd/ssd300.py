@@ -13,7 +13,9 @@ as torch tensors or numpy arrays -- exactly what utils/image_augmentor.py:24-27 
 
 Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' | 'f32'; default bf16 in train mode, f32 in test mode),
 'device', 'seed', 'verbose', 'test_subtract_mean' (False = reproduce the reference's test-mode feed quirk),
-'use_graph' (True, default: replay the step's kernel launches from HIP graphs after two eager steps | False | 'auto' = the faster of the two, measured),
+'use_graph' (False, default since round 3: eager launches -- measured 1-3 % FASTER than graph replay on every box once the step was down to ~200
+launches (profiles/r03e_launch_mode_ab.md) | True: replay the step's kernel launches from HIP graphs after two eager steps | 'auto' = the faster of the two,
+measured at start-up),
 'tail_stream' (True: the six heads run on a second stream beside the extra-layer chain).
 """
 from __future__ import annotations
@@ -201,7 +203,7 @@ class SSD300:
         # while calibrating) and keeps the faster mode: replay wins when the host cannot issue ~220 launches per step as
         # fast as the GPU retires them.  On a host that can, the two modes measured within 1 % of each other (9.63-9.66 ms
         # eager vs 9.75-9.82 ms replayed, same box), so replay -- which does not depend on the host -- is the default.
-        ug = config.get('use_graph', True)
+        ug = config.get('use_graph', False)
         self.use_graph = True if ug == 'auto' else bool(ug)
         self._auto = {'left': 2 * self.AUTO_STEPS, 't': {}} if ug == 'auto' else None
         # optional: filter gradients on a second HIP stream (wgrad(L) only needs dy(L) and the stored input of L, nothing
@@ -387,6 +389,7 @@ class SSD300:
         prev = 'input'
         self.vgg_plan = []
         self.pool_idx = {}                      # 2x2/s2 pools: recorded arg-max (uint16 per 16-byte output chunk)
+        self.pool_arg = {}                      # other pools (pool5): recorded arg-max (int32 per 16-byte output chunk)
         for item in VGG_SEQ:
             name = item[0]
             if name.startswith('conv'):
@@ -402,10 +405,22 @@ class SSD300:
                 self.vgg_plan.append(('pool', name, prev, k, s, pt))
                 if k == 2 and s == 2 and pt == 0 and self.mode == 'train' and bool(self.config.get('pool_index', True)):
                     self.pool_idx[name] = torch.zeros(N * Ho * Ho * (cur_c // ops.chunk(self.DT)), dtype=torch.int16, device=dev)
+                elif k <= 3 and self.mode == 'train' and bool(self.config.get('pool_index', True)):
+                    # overlapping windows (pool5, 3x3 / stride 1): 4-bit window positions, one int32 per 16-byte output chunk
+                    self.pool_arg[name] = torch.zeros(N * Ho * Ho * (cur_c // ops.chunk(self.DT)), dtype=torch.int32, device=dev)
                 H = Ho
             prev = name
             if name == 'conv4_3':
                 self.acts['feat1'] = _Act(N, H, H, 512, 512, dt, dev)
+        # conv -> 2x2 pool pairs that libodtk runs as ONE launch (conv1_2 + pool1: the 64 -> 64 halo kernel pools in its epilogue); config key
+        # 'fuse_pool' (default on), 'keep_unpooled' (default off: the un-pooled map is not even stored -- tests that inspect it turn it on)
+        self.fused_pool = {}
+        self.keep_unpooled = bool(self.config.get('keep_unpooled', False))
+        if self.mode == 'train' and bool(self.config.get('fuse_pool', True)):
+            for step in self.vgg_plan:
+                if step[0] == 'pool' and step[1] in self.pool_idx and step[2] != 'conv4_3' and step[2] in self.desc and \
+                        ops.conv2d_fwd_pool2x2_fused(self.desc[step[2]]):
+                    self.fused_pool[step[2]] = step[1]
         self.zbuf, self.bnsave = {}, {}
         max_ws = 0
         for (name, ci, co, k, s, d) in self.EXTRA_SEQ:
@@ -517,12 +532,23 @@ class SSD300:
         for step in self.vgg_plan:
             if step[0] == 'conv':
                 _, name, prev = step
+                if training and name in self.fused_pool:
+                    # conv + bias + ReLU + the 2x2 pool behind it in one launch; the un-pooled map is not stored (nothing else reads it: the
+                    # backward pass routes by the recorded arg-max and masks by the sign of the pooled value)
+                    pname = self.fused_pool[name]
+                    ops.conv2d_fwd_pool2x2(self.desc[name], a[prev].t, self._wslice(name + '.w', self.Pc), self.param(name + '.b'),
+                                           a[name].t if self.keep_unpooled else None, True, a[pname].t, self.pool_idx[pname])
+                    continue
                 self._conv_fwd(name, a[prev], a[name], self.param(name + '.b'), True)
             else:
                 _, name, prev, k, s, pt = step
                 x, y = a[prev], a[name]
+                if training and prev in self.fused_pool:
+                    continue
                 if training and name in self.pool_idx:
                     ops.maxpool2x2_fwd_idx(x.t, y.t, self.pool_idx[name], x.N, x.H, x.W, x.C, x.ld, y.H, y.W)
+                elif training and name in self.pool_arg:
+                    ops.maxpool_fwd_argmax(x.t, y.t, self.pool_arg[name], x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
                 else:
                     ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
         c43 = a['conv4_3']
@@ -682,6 +708,8 @@ class SSD300:
                 x, y = a[prev], a[name]
                 if name in self.pool_idx:
                     ops.maxpool2x2_bwd_idx(self.pool_idx[name], y.g, x.g, x.N, x.H, x.W, x.C, x.ld, y.H, y.W)
+                elif name in self.pool_arg:
+                    ops.maxpool_bwd_argmax(self.pool_arg[name], y.g, x.g, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
                 else:
                     ops.maxpool_bwd(x.t, y.t, y.g, x.g, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
                 if prev == 'conv4_3':       # second consumer: L2-norm -> pred1 (accumulate, ReLU mask)

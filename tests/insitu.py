@@ -26,7 +26,7 @@ import mock_ops  # noqa: E402
 
 # output parameters of every launch (names of tests/mock_ops.py's signatures); 'loss_parts:K' = only column(s) K of that tensor
 OUTPUTS = {
-    'conv2d_fwd': ['y'], 'conv2d_dgrad': ['dx'], 'conv2d_wgrad': ['dw', 'dbias'],
+    'conv2d_fwd': ['y'], 'conv2d_fwd_pool2x2': ['y', 'y_pool'], 'conv2d_dgrad': ['dx'], 'conv2d_wgrad': ['dw', 'dbias'],
     'preprocess': ['x'], 'preprocess_norm': ['x'],
     'bn_fwd': ['mmean', 'mvar', 'save_mean', 'save_invstd', 'y'], 'bn_bwd': ['dz', 'dgamma', 'dbeta'],
     'gn_fwd': ['y', 'save'], 'gn_bwd': ['dx', 'dgamma', 'dbeta'],
@@ -34,7 +34,7 @@ OUTPUTS = {
     'upsample2x_fwd': ['y'], 'upsample2x_bwd': ['dx'],
     'resize_bilinear_fwd': ['y'], 'resize_bilinear_bwd': ['dx'], 'resize_bilinear2_fwd': ['y'], 'resize_bilinear2_bwd': ['dx'],
     'copy_channels': ['dst'],
-    'maxpool_fwd': ['y'], 'maxpool_bwd': ['dx'], 'maxpool2x2_fwd_idx': ['y'], 'maxpool2x2_bwd_idx': ['dx'],
+    'maxpool_fwd': ['y'], 'maxpool_bwd': ['dx'], 'maxpool_fwd_argmax': ['y'], 'maxpool_bwd_argmax': ['dx'], 'maxpool2x2_fwd_idx': ['y'], 'maxpool2x2_bwd_idx': ['dx'],
     'avgpool2x2_fwd': ['y'], 'avgpool2x2_bwd': ['dx'],
     'rows_to_f32': ['y'], 'rows_from_f32': ['x'], 'exp_rows_to_f32': ['y'], 'exp_rows_bwd': ['dx'],
     'l2norm_fwd': ['y'], 'l2norm_bwd': ['dx', 'dgamma'],
@@ -49,7 +49,7 @@ OUTPUTS = {
 ON_CPU = {'ssd_loss', 'yolov3_loss', 'yolov2_loss', 'retina_loss', 'fcos_loss', 'centernet_loss', 'refinedet_loss'}
 # launches that are not shadowed: the mocked box-side front ends do nothing (the mocked loss matches / mines by itself through the oracle -- the
 # real kernels' indices are compared bit for bit by the kernel-level tests), workspaces, scratch selection, constant tables
-PASS = {'ssd_match', 'softmax_ce_const', 'retina_match', 'nms_batched', 'scratch_slot', 'ssd_priors', 'retina_anchors', 'gn_workspace', 'fcos_workspace',
+PASS = {'conv2d_fwd_pool2x2_fused', 'ssd_match', 'softmax_ce_const', 'retina_match', 'nms_batched', 'scratch_slot', 'ssd_priors', 'retina_anchors', 'gn_workspace', 'fcos_workspace',
         'yolov3_workspace', 'retina_match_workspace', 'centernet_workspace', 'yolov3_decode_candidates', 'fcos_decode_candidates', 'retina_decode',
         'refinedet_decode', 'centernet_decode', 'yolov2_decode_candidates'}
 WHOLE_STORAGE_MAX = 1 << 30
@@ -219,9 +219,13 @@ class Shadow:
                 self._depth -= 1
             if name == 'maxpool2x2_bwd_idx':              # the restatement keeps torch's arg-max of the forward launch, keyed by the index buffer
                 mock_ops._POOL_ARGMAX[margs['idx'].data_ptr()] = mock_ops._POOL_ARGMAX[bound.arguments['idx'].data_ptr()]
+            if name == 'maxpool_bwd_argmax':
+                mock_ops._POOL_ARGMAX[margs['arg'].data_ptr()] = mock_ops._POOL_ARGMAX[bound.arguments['arg'].data_ptr()]
             mock(**margs)
-            if name == 'maxpool2x2_fwd_idx':
+            if name in ('maxpool2x2_fwd_idx', 'conv2d_fwd_pool2x2') and margs.get('idx') is not None:
                 mock_ops._POOL_ARGMAX[bound.arguments['idx'].data_ptr()] = mock_ops._POOL_ARGMAX.pop(margs['idx'].data_ptr())
+            if name == 'maxpool_fwd_argmax':
+                mock_ops._POOL_ARGMAX[bound.arguments['arg'].data_ptr()] = mock_ops._POOL_ARGMAX.pop(margs['arg'].data_ptr())
             for o in outs:
                 cond = COND.get((name, o[0]))
                 scale = cond(margs) if (cond is not None and margs.get(o[0]) is not None) else None

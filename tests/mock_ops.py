@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS, BN_MOM = 1e-3, 0.99
+_POOL_ARGMAX = {}            # index buffer -> torch's arg-max of the forward pooling (the recorded routing of the 2x2 pools)
 
 
 def _storage(y):
@@ -45,6 +46,27 @@ def conv2d_fwd(d, x, w, bias, y, relu):
     if relu:
         out = torch.relu(out)
     y[:, :d.K] = out.reshape(-1, d.K).to(y.dtype)
+
+
+def conv2d_fwd_pool2x2(d, x, w, bias, y, relu, y_pool, idx):
+    out = _conv(_nhwc(x, (d.N, d.H, d.W), d.C), _conv_weights(w, d), d)
+    if bias is not None:
+        out = out + bias.float()
+    if relu:
+        out = torch.relu(out)
+    if y is not None:
+        y[:, :d.K] = out.reshape(-1, d.K).to(y.dtype)
+    Ho, Wo = (d.Ho + 1) // 2, (d.Wo + 1) // 2
+    v = out.to(y_pool.dtype).float()                             # the pool sees the STORED (rounded) activations
+    vp = F.pad(v.permute(0, 3, 1, 2), (0, 2 * Wo - d.Wo, 0, 2 * Ho - d.Ho), value=float('-inf'))
+    pooled, arg = F.max_pool2d(vp, 2, 2, return_indices=True)
+    if idx is not None:
+        _POOL_ARGMAX[idx.data_ptr()] = (arg, vp.shape)
+    y_pool[:, :d.K] = pooled.permute(0, 2, 3, 1).reshape(-1, d.K).to(y_pool.dtype)
+
+
+def conv2d_fwd_pool2x2_fused(d):
+    return True
 
 
 def conv2d_dgrad(d, dy, lddy, w_t, relu_src, dx, accumulate):
@@ -352,7 +374,18 @@ def retina_decode(pconf, pbox, yx, hw, thr):
 
 
 # ---- SSD300-specific launches
-_POOL_ARGMAX = {}
+
+
+def maxpool_fwd_argmax(x, y, arg, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
+    xr = x[:, :C_].float().reshape(N, H, W, C_)
+    y[:, :C_] = _pool(xr, k, stride, pad_t, pad_l, Ho, Wo).reshape(-1, C_).to(y.dtype)
+    _POOL_ARGMAX[arg.data_ptr()] = xr                         # the routing is re-derived from the stored input by autograd (first maximum, as TF)
+
+
+def maxpool_bwd_argmax(arg, dy, dx, N, H, W, C_, ld, Ho, Wo, k, stride, pad_t, pad_l):
+    xr = _POOL_ARGMAX[arg.data_ptr()].clone().requires_grad_(True)
+    g, = torch.autograd.grad(_pool(xr, k, stride, pad_t, pad_l, Ho, Wo), xr, dy[:, :C_].float().reshape(N, Ho, Wo, C_))
+    dx[:, :C_] = g.reshape(-1, C_).to(dx.dtype)
 
 
 def maxpool2x2_fwd_idx(x, y, idx, N, H, W, C_, ld, Ho, Wo):

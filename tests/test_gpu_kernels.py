@@ -782,3 +782,101 @@ def test_conv_halo_kernel_64_channel_tiles(case, dev):
     """Cout <= 64 on the raster-run halo kernel: 64 x 512 tiles (conv2_1's input gradient, 128 -> 64 channels at W = 150, batch 32); needs
     >= 512 pixel tiles, so the shapes are large; the third has a channel tail (40 of 64 filter rows) and a ragged last tile"""
     _conv_case(case, "bf16", dev)
+
+
+@pytest.mark.parametrize("geom", [(2, 16, 64, True), (3, 13, 70, True), (32, 300, 300, False), (5, 37, 45, True), (1, 8, 32, True)])
+def test_conv_relu_pool2x2_fused_equals_conv_then_pool(geom, dev):
+    """odtk_conv2d_fwd_pool2x2 (conv + bias + ReLU + tf.layers.max_pooling2d(2, 2, 'same'), SSD300.py:201-209, in the epilogue of the 64 -> 64 halo
+    kernel) against the two launches it replaces: the pooled map and the recorded arg-max are BIT-identical (the same accumulators, the same bf16
+    stores, first maximum in scan order), with and without the un-pooled output; odd sizes have windows that hang over the bottom / right edge.
+    (32, 300, 300) is conv1_2 + pool1 of SSD300 at batch 32: 45 000 tiles, persistent multi-tile walks.)"""
+    ops = _ops()
+    N, H, W, check_cpu = geom
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = to_rows(torch.randn(N, H, W, 64, generator=g), 64, torch.bfloat16, dev)
+    w = (torch.randn(64, 3, 3, 64, generator=g) * 0.06).to(torch.bfloat16).to(dev).reshape(-1).contiguous()
+    b = (torch.randn(64, generator=g) * 0.1).to(dev)
+    d = ops.conv_desc(N, H, W, 64, 64, 64, 64, 3, 1, 1)
+    assert ops.conv2d_fwd_pool2x2_fused(d)
+    Hp, Wp = (H + 1) // 2, (W + 1) // 2
+    nchunk = N * Hp * Wp * 8
+    y_ref = torch.zeros(N * H * W, 64, dtype=torch.bfloat16, device=dev)
+    p_ref = torch.zeros(N * Hp * Wp, 64, dtype=torch.bfloat16, device=dev)
+    i_ref = torch.zeros(nchunk, dtype=torch.int16, device=dev)
+    ops.conv2d_fwd(d, x, w, b, y_ref, True)
+    assert ops.conv_last_kernel() == 'conv3x3_c64k64_kernel'
+    ops.maxpool2x2_fwd_idx(y_ref, p_ref, i_ref, N, H, W, 64, 64, Hp, Wp)
+    for keep in (True, False):
+        y = torch.full((N * H * W, 64), 7.0, dtype=torch.bfloat16, device=dev) if keep else None
+        p = torch.full((N * Hp * Wp, 64), -3.0, dtype=torch.bfloat16, device=dev)
+        i = torch.full((nchunk,), -1, dtype=torch.int16, device=dev)
+        ops.conv2d_fwd_pool2x2(d, x, w, b, y, True, p, i)
+        torch.cuda.synchronize()
+        assert torch.equal(p, p_ref), f'pooled map differs (keep={keep})'
+        assert torch.equal(i, i_ref), f'arg-max codes differ (keep={keep})'
+        if keep:
+            assert torch.equal(y, y_ref)
+    if check_cpu:                                             # ... and the pair itself against plain torch
+        xr = x.float().cpu().reshape(N, H, W, 64)
+        wr = w.float().cpu().reshape(64, 3, 3, 64)
+        conv = torch.relu(_ref_conv(xr, wr, b.cpu(), 1, 1))
+        ref = F.max_pool2d(F.pad(conv.permute(0, 3, 1, 2), (0, 2 * Wp - W, 0, 2 * Hp - H), value=float('-inf')), 2, 2).permute(0, 2, 3, 1)
+        got = from_rows(p_ref, N, Hp, Wp, 64)
+        assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+def test_conv_pool2x2_unfused_shapes_run_as_two_launches(dev):
+    """a shape the fused kernel does not cover (128 channels) goes through conv + pool inside the same entry point; without the un-pooled buffer it is
+    refused loudly"""
+    ops = _ops()
+    from odtk._lib import OdtkError
+    N, H, W, C_, K = 2, 20, 22, 128, 128
+    g = torch.Generator().manual_seed(5)
+    x = to_rows(torch.randn(N, H, W, C_, generator=g), C_, torch.bfloat16, dev)
+    w = (torch.randn(K, 3, 3, C_, generator=g) * 0.05).to(torch.bfloat16).to(dev).reshape(-1).contiguous()
+    d = ops.conv_desc(N, H, W, C_, C_, K, K, 3, 1, 1)
+    assert not ops.conv2d_fwd_pool2x2_fused(d)
+    y = torch.zeros(N * H * W, K, dtype=torch.bfloat16, device=dev)
+    y2 = torch.zeros_like(y)
+    p = torch.zeros(N * (H // 2) * (W // 2), K, dtype=torch.bfloat16, device=dev)
+    p2 = torch.zeros_like(p)
+    i = torch.zeros(p.shape[0] * K // 8, dtype=torch.int16, device=dev)
+    i2 = torch.zeros_like(i)
+    ops.conv2d_fwd_pool2x2(d, x, w, None, y, True, p, i)
+    ops.conv2d_fwd(d, x, w, None, y2, True)
+    ops.maxpool2x2_fwd_idx(y2, p2, i2, N, H, W, K, K, H // 2, W // 2)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and torch.equal(p, p2) and torch.equal(i, i2)
+    with pytest.raises(OdtkError):
+        ops.conv2d_fwd_pool2x2(d, x, w, None, None, True, p, i)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(2, 19, 19, 64, 3, 1), (32, 19, 19, 512, 3, 1), (3, 9, 13, 40, 3, 2), (2, 12, 12, 16, 2, 2), (2, 7, 7, 8, 2, 1)])
+def test_maxpool_recorded_argmax_overlapping_windows(geom, dt, dev):
+    """odtk_maxpool_fwd_argmax / _bwd_argmax (pool5: 3x3 / stride 1 / SAME) against the gather path it replaces: identical outputs and identical routed
+    gradients (first maximum in scan order), ties included -- the inputs are quantised so that many windows hold repeated maxima"""
+    ops = _ops()
+    N, H, W, C_, k, s = geom
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(H + 7 * C_)
+    x = to_rows((torch.randn(N, H, W, C_, generator=g) * 2).round() / 2, C_, tdt, dev)          # half-integer values: ties
+    Ho, pt, _ = ops.same_pad(H, k, s)
+    Wo, pl, _ = ops.same_pad(W, k, s)
+    dy = to_rows(torch.randn(N, Ho, Wo, C_, generator=g), C_, tdt, dev)
+    kc = 4 if dt == "f32" else 8
+    y0, y1 = (torch.zeros(N * Ho * Wo, C_, dtype=tdt, device=dev) for _ in range(2))
+    dx0, dx1 = (torch.full((N * H * W, C_), 3.0, dtype=tdt, device=dev) for _ in range(2))
+    arg = torch.zeros(N * Ho * Wo * (C_ // kc), dtype=torch.int32, device=dev)
+    ops.maxpool_fwd(x, y0, N, H, W, C_, C_, Ho, Wo, k, s, pt, pl)
+    ops.maxpool_bwd(x, y0, dy, dx0, N, H, W, C_, C_, Ho, Wo, k, s, pt, pl)
+    ops.maxpool_fwd_argmax(x, y1, arg, N, H, W, C_, C_, Ho, Wo, k, s, pt, pl)
+    ops.maxpool_bwd_argmax(arg, dy, dx1, N, H, W, C_, C_, Ho, Wo, k, s, pt, pl)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    if dt == "f32":
+        assert torch.equal(dx0, dx1)
+    else:                                   # both sum <= 9 bf16 values in f32 and round once; the order of the windows is the same
+        assert float((dx0.float() - dx1.float()).abs().max()) <= 2 ** -7 * float(dx0.float().abs().max())
+    # every output's gradient lands exactly once
+    assert abs(float(dx1.float().sum()) - float(dy.float().sum())) <= 1e-2 * float(dy.float().abs().sum()) ** 0.5 + 1e-3 * float(dy.float().abs().sum())

@@ -65,7 +65,9 @@ def pair(dev):
     imgs, gt = R.synthetic_batch(B, 77)
     ms = {}
     for dt in ('f32', 'bf16'):
-        m = _model(dt, use_graph=False)
+        # keep_unpooled: the fused conv1_2 + pool1 launch also stores the un-pooled map these tests inspect layer by layer (the training default does
+        # not store it at all; that mode is shadowed launch by launch in tests/test_gpu_insitu_configs.py)
+        m = _model(dt, use_graph=False, keep_unpooled=True)
         m.load_oracle_params(p)
         m.set_batch(imgs, gt)
         m._step_front()

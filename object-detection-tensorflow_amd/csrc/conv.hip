@@ -990,6 +990,12 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }
+    if (!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && wgrad_c8_supported(a, d->dtype)) {
+        launch_wgrad_c8(a, (hipStream_t)stream);
+        g_last_kernel = "wgrad3x3_c8k64_kernel";
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     if (!g_force_regstage && g_v3_mode != 1 && wgrad_v3_supported(a, d->dtype)) {
         launch_wgrad_v3(a, (hipStream_t)stream);
         g_last_kernel = a.which == 8 ? "conv_wgrad_v8_kernel" : (a.which == 7 ? "conv_wgrad_v7_kernel" : "conv_wgrad_v3_kernel");

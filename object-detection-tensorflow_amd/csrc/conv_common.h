@@ -269,6 +269,8 @@ bool gather_c8_supported(const GatherArgs& a, int dtype, int out_dtype);    // f
 int launch_gather_c8(GatherArgs& a, hipStream_t st);
 bool wgrad_c64_supported(const WgradArgs& a, int dtype);                      // halo-patch 64->64 3x3 wgrad
 int launch_wgrad_c64(WgradArgs& a, hipStream_t st);
+bool wgrad_c8_supported(const WgradArgs& a, int dtype);                       // first layer (3(8) -> 64) filter gradient: wave-private strips
+int launch_wgrad_c8(WgradArgs& a, hipStream_t st);
 bool wgrad_v3_supported(const WgradArgs& a, int dtype);
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
 void set_wgrad_deterministic(bool on);  // odtk_debug_set key 5: deterministic split-reduce instead of float atomics

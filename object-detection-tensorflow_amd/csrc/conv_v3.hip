@@ -2109,6 +2109,177 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Filter gradient of the FIRST layer (conv1_1: 3x3 / stride 1 / pad 1, 8 (3 real + 5 zero) input channels -> 64; Conv2DBackpropFilter of
+// SSD300.py:193-200): dW is only 64 x 72 and the MFMA work is small (6 MFMAs per 16 pixels), but dy is 128 B per pixel -- 369 MB at batch 32 --
+// so the kernel is HBM-bound (415 MB with x; the first-generation kernel it replaces took 165 us = 2.5 TB/s).
+// Every WAVE is an independent worker (no block barrier inside the loop): it walks strips of 2 rows x 32 columns, LDS-DMAs the strip's 64 dy pixels
+// (8 pieces) and its own 4 x 34-pixel halo patch of x (one 16-byte chunk per pixel, 3 pieces) into a wave-private three-stage ring -- two strips
+// in flight behind the one being consumed, counted vmcnt -- and both MFMA operands come out of LDS through ds_read_b64_tr_b16:
+//   A = dy^T: 32 output channels x 16 pixels (the layout and swizzle of wgrad3x3_c64k64_kernel's dy tile);
+//   B = 32 columns = 4 taps x 8 channels: a transpose read delivers [4 pixels][16 columns] per 16-lane group, and because every lane supplies its
+//       own address, the two 8-byte quarters pairs of a group point at TWO DIFFERENT taps' pixels: column n = l31 is (tap 4 cb + (n >> 3), channel n & 7),
+//       i.e. dW column 32 cb + n of the [K][9 * 8] filter gradient; the lanes of taps 9 .. 11 (cb = 2) read a zero area.
+// 2 x 3 accumulator tiles per wave; at the end the four waves add them in LDS (ds_add_f32) and the workgroup flushes 64 x 72 + 64 float atomics.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wgrad3x3_c8k64_kernel(const WgradArgs a, const int strips_c, const int strips_per_img, const int total_strips,
+                                                             const FastDiv div_spi, const FastDiv div_sc) {
+    constexpr int PW = 34;
+    constexpr int DYB = 8192, XB = 3072, STG = DYB + XB, NST = 3, NPIECE = 11;
+    constexpr int ZB = 1280, WAVE_LDS = NST * STG + ZB;
+    __shared__ __attribute__((aligned(16))) char smem[4 * WAVE_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem)) + (unsigned)(wave * WAVE_LDS);
+    const unsigned zbase = wbase + NST * STG;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
+    // zero area (the taps 9 .. 11 of the third column block)
+    for (int i = lane; i < ZB / 16; i += 64) *reinterpret_cast<uint4*>(smem + wave * WAVE_LDS + NST * STG + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+    const int nworkers = gridDim.x * 4;
+    const int worker = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int my = worker < total_strips ? (total_strips - worker + nworkers - 1) / nworkers : 0;
+
+    // ---- DMA lane roles.  dy piece p: pixels 8p .. 8p+7 of the strip (row p >> 2, columns 8 (p & 3) + sub), logical chunk = physical ^ swizzle
+    const int sub = lane >> 3;
+    const int lc16 = ((lane & 7) ^ (((sub >> 1) & 1) << 2)) * 16;
+    const int dy_lane = sub * 128 + lc16;
+    // x piece q: patch pixels 64 q + lane (row-major over the 4 x 34 patch), one 16-byte chunk each
+    int xr[3], xc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int px = 64 * q + lane;
+        xr[q] = px < 4 * PW ? px / PW : 0x7FFF;
+        xc[q] = px % PW;
+    }
+    auto issue = [&](int v, int stage, bool en) __attribute__((always_inline)) {
+        // strip v -> image n, row pair, column block
+        const unsigned vv = (unsigned)(en ? v : 0);
+        const int n = (int)fdiv(vv, div_spi);
+        const int rem = (int)vv - n * strips_per_img;
+        const int rp = (int)fdiv((unsigned)rem, div_sc);
+        const int h0 = rp * 2, w0 = (rem - rp * strips_c) * 32;
+        const unsigned dst = wbase + (unsigned)(stage * STG);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int h = h0 + (p >> 2), w = w0 + 8 * (p & 3) + sub;
+            const bool ok = en && h < a.H && w < a.W;
+            const unsigned off = (unsigned)(((n * a.H + h) * a.W + w0 + 8 * (p & 3)) * 128 + dy_lane);
+            glds16_buf(rdy, ok ? off : 0xFFFFFFF0u, dst + (unsigned)p * 1024u);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int h = h0 - 1 + xr[q], w = w0 - 1 + xc[q];
+            const bool ok = en && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            const unsigned off = (unsigned)(((n * a.H + h) * a.W + w) * 16);
+            glds16_buf(rx, ok ? off : 0xFFFFFFF0u, dst + (unsigned)DYB + (unsigned)q * 1024u);
+        }
+    };
+
+    // ---- fragment lane roles (transpose reads): group g = lane >> 4, rr = pixel of the 4-pixel group, qq = 8-byte quarter
+    const int g = lane >> 4, c16 = lane & 15, rr = c16 >> 2, qq = c16 & 3;
+    const int lp = 8 * hi + rr;                                  // this lane's pixel inside a 16-pixel k-step
+    // A (dy^T), k block kb: channels kb*32 + 16 (g&1) + 4 qq .. : chunk = kb*4 + 2 (g&1) + (qq >> 1), byte 8 (qq & 1); swizzle by ((pixel >> 1) & 1)
+    unsigned aoff[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int chunk = kb * 4 + 2 * (g & 1) + (qq >> 1);
+        aoff[kb] = (unsigned)(lp * 128 + ((chunk ^ (((lp >> 1) & 1) << 2)) << 4) + 8 * (qq & 1));     // (16 s + 4 does not change (pixel >> 1) & 1)
+    }
+    // B (x), column block cb: tap = 4 cb + 2 (g&1) + (qq >> 1); patch pixel of strip pixel kp: ((kp >> 5) + dr) * 34 + (kp & 31) + ds
+    unsigned boff[3];
+    bool bzero[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+        const int tap = 4 * cb + 2 * (g & 1) + (qq >> 1);
+        const int dr = tap / 3, ds = tap - dr * 3;
+        bzero[cb] = tap >= 9;
+        boff[cb] = bzero[cb] ? (unsigned)(lp * 16 + 8 * (qq & 1)) : (unsigned)((dr * PW + ds + lp) * 16 + 8 * (qq & 1));
+    }
+
+    f32x16_v acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+
+    // prologue: strips 0 and 1 (every issue is exactly NPIECE pieces, also past the end: counted vmcnt)
+    issue(worker, 0, my > 0);
+    issue(worker + nworkers, 1, my > 1);
+    int st = 0;
+    for (int it = 0; it < my; ++it) {
+        const int stn = st >= 1 ? st - 1 : NST - 1;              // (st + 2) % 3: the stage consumed in the previous iteration
+        issue(worker + (it + 2) * nworkers, stn, it + 2 < my);
+        wait_vmcnt<2 * NPIECE>();                                // strip `it` has landed; two newer strips may stay in flight
+        const unsigned sD = wbase + (unsigned)(st * STG), sX = sD + DYB;
+        unsigned ab[2], bb[3];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) ab[kb] = sD + aoff[kb];
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) bb[cb] = (bzero[cb] ? zbase : sX) + boff[cb];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            // k-step s_: strip pixels 16 s_ .. 16 s_ + 15 = strip row s_ >> 1, columns 16 (s_ & 1) ..
+            uint4 pf[2], qf[3];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint2 lo = lds_tr16(ab[kb] + (unsigned)(s_ * 2048)), hi4 = lds_tr16(ab[kb] + (unsigned)(s_ * 2048 + 512));
+                pf[kb] = make_uint4(lo.x, lo.y, hi4.x, hi4.y);
+            }
+            const unsigned xo = (unsigned)(((s_ >> 1) * PW + 16 * (s_ & 1)) * 16);
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const uint2 lo = lds_tr16(bb[cb] + xo), hi4 = lds_tr16(bb[cb] + xo + 64u);
+                qf[cb] = make_uint4(lo.x, lo.y, hi4.x, hi4.y);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) Mma<bf16_t>::run(pf[kb], qf[cb], acc[kb][cb]);
+                const unsigned dd[4] = {pf[kb].x, pf[kb].y, pf[kb].z, pf[kb].w};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) bsum[kb] = dot2_bf16_ones(dd[h], bsum[kb]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every read of this stage has returned before a later issue overwrites it
+        st = st == NST - 1 ? 0 : st + 1;
+    }
+    wait_vmcnt<0>();
+    block_barrier();
+    // ---- the four waves' partial sums meet in LDS (the ring is dead now), then 64 x 72 + 64 float atomics per workgroup
+    float* red = reinterpret_cast<float*>(smem);
+    for (int i = tid; i < 64 * 72 + 64; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) {
+            const int col = 32 * cb + l31;
+            if (col < 72) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = kb * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                    atomicAdd(red + k * 72 + col, acc[kb][cb][e]);
+                }
+            }
+        }
+        const float t = bsum[kb] + __shfl_xor(bsum[kb], 32);
+        if (hi == 0) atomicAdd(red + 64 * 72 + kb * 32 + l31, t);
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 72; i += 256) {
+        const float v = red[i];
+        if (v != 0.f) atomicAdd(a.dw + i, v);
+    }
+    if (a.dbias != nullptr && tid < 64) {
+        const float v = red[64 * 72 + tid];
+        if (v != 0.f) atomicAdd(a.dbias + tid, v);
+    }
+}
+
 }  // namespace
 
 // per-device f32 scratch of the split-K path, grown on demand.  Calls are stream-ordered by the caller like everything
@@ -2313,6 +2484,24 @@ int launch_wgrad_c64(WgradArgs& a, hipStream_t st) {
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
     hipLaunchKernelGGL(wgrad3x3_c64k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)),
                        make_fastdiv((unsigned)tc));
+    return 0;
+}
+
+bool wgrad_c8_supported(const WgradArgs& a, int dtype) {
+    return dtype == ODTK_BF16 && a.C == 8 && a.ldx == 8 && a.K == 64 && a.lddy == 64 && a.R == 3 && a.S == 3 && a.dil == 1 && a.stride == 1 &&
+           a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo && a.RSC == 72 && (long long)a.N * a.H * a.W * 128 < (1ll << 32) - 65536;
+}
+
+int launch_wgrad_c8(WgradArgs& a, hipStream_t st) {
+    if (g_num_cu == 0) query_num_cu();
+    const int sc = ceil_div(a.W, 32), sr = ceil_div(a.H, 2);
+    const int spi = sc * sr, total = a.N * spi;
+    int grid = ceil_div(total, 4 * 8);                         // >= 8 strips per wave before a second workgroup per CU would pay its flush
+    if (grid > g_num_cu) grid = g_num_cu;
+    if (grid < 1) grid = 1;
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
+    a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    hipLaunchKernelGGL(wgrad3x3_c8k64_kernel, dim3(grid), dim3(256), 0, st, a, sc, spi, total, make_fastdiv((unsigned)spi), make_fastdiv((unsigned)sc));
     return 0;
 }
 

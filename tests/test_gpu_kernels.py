@@ -880,3 +880,35 @@ def test_maxpool_recorded_argmax_overlapping_windows(geom, dt, dev):
         assert float((dx0.float() - dx1.float()).abs().max()) <= 2 ** -7 * float(dx0.float().abs().max())
     # every output's gradient lands exactly once
     assert abs(float(dx1.float().sum()) - float(dy.float().sum())) <= 1e-2 * float(dy.float().abs().sum()) ** 0.5 + 1e-3 * float(dy.float().abs().sum())
+
+
+@pytest.mark.parametrize("geom", [(2, 20, 20), (3, 37, 45), (30, 45, 70), (32, 300, 300), (1, 2, 33), (5, 7, 300)])
+def test_first_layer_filter_gradient_kernel(geom, dev):
+    """wgrad3x3_c8k64_kernel (conv1_1's Conv2DBackpropFilter, SSD300.py:193-200: 8 = 3 + 5 zero input channels -> 64; every wave walks its own strips of
+    2 rows x 32 columns through a private three-stage LDS ring) against plain torch: dW [64][3][3][8] and the fused bias gradient, ragged right / bottom
+    edges, odd heights (a strip with one row), fewer strips than waves, and conv1_1 itself at batch 32 (48 000 strips, 47 per wave)."""
+    ops = _ops()
+    N, H, W = geom
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randn(N, H, W, 8, generator=g).to(torch.bfloat16).float()
+    x[..., 3:] = 0                                              # the layout of conv1_1's input: three real channels in one chunk
+    dy = torch.randn(N, H, W, 64, generator=g).to(torch.bfloat16).float()
+    d = ops.conv_desc(N, H, W, 8, 8, 64, 64, 3, 1, 1)
+    xd, dyd = to_rows(x, 8, torch.bfloat16, dev), to_rows(dy, 64, torch.bfloat16, dev)
+    dw = torch.zeros(64, 3, 3, 8, device=dev)
+    db = torch.zeros(64, device=dev)
+    dw[0, 0, 0, 0] = 5.0                                        # the kernel ACCUMULATES into dw / dbias
+    db[3] = -2.0
+    ops.conv2d_wgrad(d, xd, dyd, 64, dw, db)
+    assert ops.conv_last_kernel() == 'wgrad3x3_c8k64_kernel'
+    torch.cuda.synchronize()
+    wr = torch.zeros(64, 3, 3, 8, requires_grad=True)
+    _ref_conv(x, wr, None, 1, 1).backward(dy)
+    ref = wr.grad.clone()
+    ref[0, 0, 0, 0] += 5.0
+    scale = float(ref.abs().max()) + 1e-6
+    assert float((dw.cpu() - ref).abs().max()) <= 2e-3 * scale, (float((dw.cpu() - ref).abs().max()), scale)
+    assert float(dw.cpu()[..., 3:].abs().max()) == 0.0          # zero input channels: exactly zero gradient
+    db_ref = dy.reshape(-1, 64).sum(0)
+    db_ref[3] -= 2.0
+    assert float((db.cpu() - db_ref).abs().max()) <= 2e-3 * (float(db_ref.abs().max()) + 1.0)

@@ -54,11 +54,12 @@ def synthetic_batch(batch, seed, device):
 class ConvTimer:
     """Wraps the three conv entry points with HIP events on the launch stream."""
 
-    def __init__(self, ops):
+    def __init__(self, ops, alg=None):
         self.ops = ops
         self.records = []            # (kind, kernel, flops, start_evt, end_evt, algorithmic bytes)
         self.enabled = False
         self._orig = {}
+        self.alg = alg or {}         # id(ConvDesc) -> (cin, cout): ALGORITHMIC channel counts (descriptors carry chunk-padded ones: 7 -> 8, 3 -> 8)
 
     def install(self):
         ops = self.ops
@@ -72,8 +73,11 @@ class ConvTimer:
         def f(d, *args):
             if not self.enabled:
                 return orig(d, *args)
-            c_alg = 3 if (d.H == 300 and d.C <= 8) else d.C          # conv1_1: 3 real input channels (padded to one chunk)
-            flops = 2.0 * d.N * d.Ho * d.Wo * d.K * d.R * d.S * c_alg    # algorithmic: 2*M*Cout*R*S*Cin for each pass
+            if id(d) in self.alg:
+                c_alg, k_alg = self.alg[id(d)]
+            else:
+                c_alg, k_alg = (3 if (d.H == 300 and d.C <= 8) else d.C), d.K    # conv1_1: 3 real input channels (padded to one chunk)
+            flops = 2.0 * d.N * d.Ho * d.Wo * k_alg * d.R * d.S * c_alg  # algorithmic: 2*M*Cout*R*S*Cin for each pass
             esz = 2 if d.dtype == 0 else 4
             # algorithmic HBM bytes: every operand once (x, y / dy, dx as bf16; filter as bf16, dW as f32)
             abytes = (d.N * d.H * d.W * d.C + d.N * d.Ho * d.Wo * d.K) * esz + d.K * d.R * d.S * d.C * (4 if kind == 'conv2d_wgrad' else esz)
@@ -144,7 +148,7 @@ class ConvTimer:
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
         fl, t, n, ab = per_kernel[dom]
         t_trim = trimmed_kernel[dom][1]
-        pmc = pmc_traffic(dom)
+        pmc = pmc_traffic(dom) if getattr(self, 'use_pmc', True) else None       # (the committed PMC passes are of the SSD300 command only)
         tot_f = sum(v[0] for v in per_kernel.values()); tot_t = sum(v[1] for v in per_kernel.values())
         return {
             'bound': 'mfma', 'kernel': dom,
@@ -200,8 +204,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--config', default='ssd300', choices=['ssd300', 'retinanet', 'yolov3', 'fcos', 'centernet'],
+                    help="BASELINE.json's configuration: ssd300 = config 2 (the headline metric, the default); retinanet = config 3 (800x800, batch 16); "
+                         'yolov3 = config 4 (416x416, 8 / GPU); fcos | centernet = config 5 (512x512, 16 / GPU) -- bench_configs.py')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s)')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32'], help='engine (default: the one the model class defaults to: bf16 for ssd300 / yolov3, f32 else)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region (the default at N = 1 since round 3)')
@@ -236,6 +243,13 @@ def main():
                          f'(or drop the launcher: `python bench.py --gpus N` starts its own ranks)')
     if args.launch_check:
         return launch_check(args, world, rank, local_rank)
+    import bench_configs as BC
+    if args.batch is None:
+        args.batch = BC.SHAPES[args.config][1]
+    if args.dtype is None:
+        args.dtype = BC.SHAPES[args.config][2]
+    if args.config != 'ssd300':
+        return bench_other(args, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -358,6 +372,114 @@ def main():
     if use_pg:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def bench_other(args, world, rank, local_rank):
+    """`--config retinanet | yolov3 | fcos | centernet`: the same contract for BASELINE.json's configurations 3-5 (one full training step of the model
+    class at its stated shape on a resident synthetic batch; weak scaling, one rank per GPU, bucketed RCCL gradient all-reduce)."""
+    import bench_configs as BC
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        init_group('nccl', rank, world, dev)
+    from odtk import ops
+    name = args.config
+    r = BC.make(name, batch=args.batch, dtype=args.dtype, seed=1000 + rank, use_graph=False)
+    model, B, lr = r['model'], r['batch'], r['lr']
+    if world > 1:
+        model.attach_data_parallel(bucket_mb=args.bucket_mb, grad_dtype=args.grad_dtype)
+    model.set_batch(r['images'], r['gt'])
+    alg = {id(d): (cin, cout) for d, cin, cout, _ in BC.conv_layers(name, model)}
+    timer = ConvTimer(ops, alg)
+    timer.use_pmc = False
+    timer.install()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        loss = model.train_step(lr)
+    import gc
+    gc.collect(); gc.disable()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = model.train_step(lr)
+    barrier()
+    dt = time.perf_counter() - t0
+    final_loss = float(loss.item() if hasattr(loss, 'item') else loss)
+    ev_steps = min(args.steps, 3) + 1
+    if not args.no_conv_events:
+        timer.enabled = True
+        for _ in range(ev_steps):
+            model.train_step(lr)
+        torch.cuda.synchronize()
+        timer.enabled = False
+    gc.enable()
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        value = B * world * args.steps / dt
+        flops_step = BC.conv_flops_per_step(name, model)
+        peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
+        out = {'metric': BC.METRIC[name], 'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 2),
+               'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+               'data': 'synthetic',
+               'config': {'workload': BC.WORKLOAD[name].format(B=B), 'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
+                          'launch': 'eager', 'algorithmic_conv_gflop_per_image': round(flops_step / B / 1e9, 2),
+                          'engine_note': None if args.dtype == 'bf16' else 'f32 engine (the class default): exact-f32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s'}}
+        if timer.records:
+            rf = timer.roofline(ev_steps, peak, value / world * (flops_step / B) / peak)
+            rf['measured_on'] = f'{ev_steps} eager steps right after the timed region (HIP events per conv launch on the launch stream; plain per-launch mean without the first)'
+            rf['peak_note'] = 'dense bf16 MFMA' if args.dtype == 'bf16' else 'f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)'
+            out['roofline'] = rf
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_other(name)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline_other(name):
+    """The model's CPU oracle (oracle/<model>_net_ref.py: PyTorch-CPU restatement of the reference graph, pinned on two training steps of the reference's own
+    class) timed on a BOUNDED sample of the same workload: full training steps at the configuration's resolution and a batch of 2 (one warm-up, then steps
+    until ~20 s are spent, at most 3)."""
+    import importlib
+    import bench_configs as BC
+    mod = importlib.import_module({'retinanet': 'oracle.retinanet_net_ref', 'yolov3': 'oracle.yolov3_net_ref', 'fcos': 'oracle.fcos_net_ref',
+                                   'centernet': 'oracle.centernet_net_ref'}[name])
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    size = BC.SHAPES[name][0]
+    bs = 2
+    images, gt = BC.synthetic_batch(name, bs, size, 7)
+    p = mod.init_params(0)
+    state = {'t': 0, 'm': {}, 'v': {}} if name == 'centernet' else {k: torch.zeros_like(v) for k, v in p.items()}
+    lr = BC.SHAPES[name][3]
+    t_w = time.perf_counter()
+    mod.train_step(p, state, images, gt, lr)                      # warm-up
+    t_w = time.perf_counter() - t_w
+    t0 = time.perf_counter()
+    n = 0
+    while n < 1 or (time.perf_counter() - t0 + t_w < 25 and n < 3):
+        mod.train_step(p, state, images, gt, lr)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(bs * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'mkldnn': bool(torch.backends.mkldnn.is_available() and torch.backends.mkldnn.enabled),
+            'sample': f'{n} full train step(s) at {size}x{size}, batch {bs} after one warm-up step (same synthetic generator), PyTorch-CPU fp32 oracle '
+                      f'({mod.__name__}); the reference TF-1.13 graph itself cannot run here (no tensorflow)'}
 
 
 def _free_port():

@@ -17,8 +17,8 @@ SHAPES = {
     'ssd300': (300, 32, 'bf16', 0.01),
     'retinanet': (800, 16, 'f32', 1e-4),
     'yolov3': (416, 8, 'bf16', 1e-4),
-    'fcos': (512, 16, 'f32', 1e-4),
-    'centernet': (512, 16, 'f32', 1e-4),
+    'fcos': (512, 16, 'bf16', 1e-4),          # bf16 engine by default since round 3 (steady state; a run from random initialisation warms up in f32: warmup.py)
+    'centernet': (512, 16, 'bf16', 1e-4),
 }
 WORKLOAD = {
     'ssd300': 'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',

@@ -31,6 +31,7 @@ import torch
 
 from . import heads, ops
 from ._lib import BF16, F32
+from .warmup import F32Warmup
 
 MEAN = (0.485, 0.456, 0.406)                                  # CenterNet.py:52-53
 STD = (0.229, 0.224, 0.225)
@@ -82,7 +83,8 @@ class _Act:
         self.g = None                                          # gradient buffer (train mode, allocated by _build_backward)
 
 
-class CenterNet:
+class CenterNet(F32Warmup):
+    OPT_BUFFERS = ('M1', 'M2')
     def __init__(self, config, data_provider):
         assert config['mode'] in ['train', 'test']
         assert config['data_format'] in ['channels_first', 'channels_last']
@@ -112,7 +114,9 @@ class CenterNet:
             self.top_k_results_output = config['top_k_results_output']
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'f32')]
+        # engine: bf16 by default on the GPU since round 3 (warmup.py: the first f32_warmup_steps optimizer steps of a run from random initialisation go through
+        # an f32 twin); an explicit 'compute_dtype' is taken literally; the CPU stand-in of the library (host-logic tests) stays on f32
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16' if torch.device(config.get('device', 'cuda:0')).type == 'cuda' else 'f32')]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0
@@ -123,6 +127,7 @@ class CenterNet:
         self.specs = layer_specs(self.num_classes)
         self._init_parameters(int(config.get('seed', 0)))
         self._build()
+        self._warmup_setup(config, data_provider, 'compute_dtype' in config)
 
     # ------------------------------------------------------------------ parameters
     def _wshape(self, spec):
@@ -191,6 +196,8 @@ class CenterNet:
         return v
 
     def load_oracle_params(self, p):
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()
         for k, v in p.items():
             if k in self.pinfo:
                 if k.endswith('.b') and self._layer_kind[k[:-2]] == 'dconv' and float(torch.as_tensor(v).abs().max()) != 0.0:
@@ -430,7 +437,7 @@ class CenterNet:
                 self._fold(x, acc)
 
     # ------------------------------------------------------------------ public: training
-    def set_batch(self, images, ground_truth):
+    def _set_batch_engine(self, images, ground_truth):
         images = torch.as_tensor(images, dtype=torch.float32)
         if self.data_format == 'channels_first' and images.shape[1] == 3:
             images = images.permute(0, 2, 3, 1)
@@ -441,7 +448,7 @@ class CenterNet:
             self.gt = torch.zeros(gt.shape, device=self.dev)
         self.gt.copy_(gt, non_blocking=True)
 
-    def train_step(self, lr):
+    def _train_step_engine(self, lr):
         """one AdamOptimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor"""
         if self.dist is not None:
             self.dist.begin_step()
@@ -524,6 +531,8 @@ class CenterNet:
 
     def load_tf_checkpoint(self, path, backbone_only=False):
         """`saver.restore` (CenterNet.py:321-327) from tf.train.Saver files; backbone_only = the `pretrained_saver` over the trainables of 'backone'"""
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
         names = list(reader.get_variable_to_shape_map())
@@ -560,7 +569,7 @@ class CenterNet:
                           f'while global_step = {self.global_step} drives the bias correction', RuntimeWarning)
         self._refresh_operand_copies()
 
-    def save_weight(self, mode, path):
+    def _save_weight_engine(self, mode, path):
         """CenterNet.py:314-319: one torch file `<path>-<step>` (parameters, moving statistics, Adam's moments and step), or with
         config['checkpoint_format'] = 'tf' the reference's own tf.train.Saver files"""
         assert (mode in ['latest', 'best'])

@@ -801,17 +801,20 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fin_kernel(
 // 512-thread workgroup per 8 chunks of channels (64 row lanes x 8 chunk lanes) sums its columns, finalizes them in
 // registers and walks the rows a second time (L2 hits) to apply.  Same formulas as the three-kernel path; the
 // summation order differs (one block instead of row splits), so results agree to f32 round-off, not bit for bit.
-constexpr int SM_ROWS = 64;
 
-template <int NV>
-__device__ __forceinline__ void block_rowlane_reduce64(float (&v)[NV], float* sm /*[64][8][NV]*/, int rl, int cl) {
+// CL chunk lanes (8 channels each in bf16) x 512 / CL row lanes.  CL = 8 is the round-2 shape (one workgroup per 64 channels, 64 row lanes: a 800-row map
+// is 13 dependent iterations per pass on 2-4 workgroups -- 20-60 us per launch in the round-2 timeline); CL = 1 gives one workgroup per 16-byte channel
+// chunk and 512 row lanes: 16-64 workgroups, 2 iterations.
+template <int NV, int CL>
+__device__ __forceinline__ void block_rowlane_reduce_small(float (&v)[NV], float* sm /*[512 / CL][CL][NV]*/, int rl, int cl) {
+    constexpr int RL = 512 / CL;
 #pragma unroll
-    for (int e = 0; e < NV; ++e) sm[(rl * 8 + cl) * NV + e] = v[e];
+    for (int e = 0; e < NV; ++e) sm[(rl * CL + cl) * NV + e] = v[e];
     __syncthreads();
-    for (int s = SM_ROWS / 2; s > 0; s >>= 1) {
+    for (int s = RL / 2; s > 0; s >>= 1) {
         if (rl < s) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) sm[(rl * 8 + cl) * NV + e] += sm[((rl + s) * 8 + cl) * NV + e];
+            for (int e = 0; e < NV; ++e) sm[(rl * CL + cl) * NV + e] += sm[((rl + s) * CL + cl) * NV + e];
         }
         __syncthreads();
     }
@@ -819,15 +822,16 @@ __device__ __forceinline__ void block_rowlane_reduce64(float (&v)[NV], float* sm
     for (int e = 0; e < NV; ++e) v[e] = sm[cl * NV + e];
 }
 
-template <typename T, typename TY>
+template <typename T, typename TY, int CL>
 __global__ void __launch_bounds__(512) bn_fwd_small_kernel(
     const T* __restrict__ z, int M, int C, int ldz, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ save_mean, float* __restrict__ save_invstd,
     int relu, TY* __restrict__ y, int ldy, int rows_per_img, long long y_img_stride, int vec_ok) {
     constexpr int KC = Chunk<T>::N;
-    __shared__ float sm[SM_ROWS * 8 * 2 * KC];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    constexpr int SM_ROWS = 512 / CL;
+    __shared__ float sm[512 * 2 * KC];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c0 = (blockIdx.x * CL + cl) * KC;
     float acc[2 * KC], sh[KC];
 #pragma unroll
     for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
@@ -847,7 +851,7 @@ __global__ void __launch_bounds__(512) bn_fwd_small_kernel(
             }
         }
     }
-    block_rowlane_reduce64<2 * KC>(acc, sm, rl, cl);
+    block_rowlane_reduce_small<2 * KC, CL>(acc, sm, rl, cl);
     if (c0 >= C) return;
     float sc[KC], of[KC];
 #pragma unroll
@@ -901,16 +905,17 @@ __global__ void __launch_bounds__(512) bn_fwd_small_kernel(
     }
 }
 
-template <typename T, typename TY>
+template <typename T, typename TY, int CL>
 __global__ void __launch_bounds__(512) bn_bwd_small_kernel(
     const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
     int rows_per_img, long long y_img_stride, const float* __restrict__ gamma, const float* __restrict__ save_mean,
     const float* __restrict__ save_invstd, int relu, int vec_ok, T* __restrict__ dz, float* __restrict__ dgamma,
     float* __restrict__ dbeta) {
     constexpr int KC = Chunk<T>::N;
-    __shared__ float sm[SM_ROWS * 8 * 2 * KC];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    constexpr int SM_ROWS = 512 / CL;
+    __shared__ float sm[512 * 2 * KC];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c0 = (blockIdx.x * CL + cl) * KC;
     float acc[2 * KC], mu[KC], iv[KC];
 #pragma unroll
     for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
@@ -933,7 +938,7 @@ __global__ void __launch_bounds__(512) bn_bwd_small_kernel(
             }
         }
     }
-    block_rowlane_reduce64<2 * KC>(acc, sm, rl, cl);
+    block_rowlane_reduce_small<2 * KC, CL>(acc, sm, rl, cl);
     if (c0 >= ldz) return;
     float gs[KC], k1[KC], k2[KC];
 #pragma unroll
@@ -1219,8 +1224,9 @@ inline RedPlan red_plan(int M, int C, int kc) {
 using namespace odtk;
 
 static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0)
+static bool g_bn_small_wide = false;      // odtk_debug_set key 4, value -3: the single-launch kernels in their 64-channel shape only (A/B); -4: back
 static bool g_bn_three_kernels = true;    // odtk_debug_set key 4, value -2: statistics + apply-with-finalize (two launches; A/B, tests); -1: back to three
-namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else g_bn_small_rows = rows; } }
+namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else g_bn_small_rows = rows; } }
 
 #define DT_SWITCH(dtype, T, ...)                                         \
     if ((dtype) == ODTK_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
@@ -1354,9 +1360,14 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 &&
                        ((uintptr_t)y % 16) == 0;
     if (training && M <= g_bn_small_rows) {              // small map: statistics, finalize and apply in one launch
+        // few column groups (C <= 512): one workgroup per 16-byte channel chunk, 512 row lanes (odtk_debug_set key 4, value -3 / -4: the 64-channel shape, A/B)
 #define BN_SMALL(T, TY)                                                                                                      \
-    hipLaunchKernelGGL((bn_fwd_small_kernel<T, TY>), dim3(pl.colgroups), dim3(512), 0, st, (const T*)z, M, C, ldz, gamma, beta, \
-                       moving_mean, moving_var, save_mean, save_invstd, relu, (TY*)y, ldy, rows_per_img, y_img_stride, vec_ok)
+    do { if (pl.colgroups < 16 && !g_bn_small_wide)                                                                          \
+        hipLaunchKernelGGL((bn_fwd_small_kernel<T, TY, 1>), dim3(ceil_div(C, kc)), dim3(512), 0, st, (const T*)z, M, C, ldz, gamma, beta, \
+                           moving_mean, moving_var, save_mean, save_invstd, relu, (TY*)y, ldy, rows_per_img, y_img_stride, vec_ok); \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((bn_fwd_small_kernel<T, TY, 8>), dim3(pl.colgroups), dim3(512), 0, st, (const T*)z, M, C, ldz, gamma, beta, \
+                           moving_mean, moving_var, save_mean, save_invstd, relu, (TY*)y, ldy, rows_per_img, y_img_stride, vec_ok); } while (0)
         if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) BN_SMALL(bf16_t, bf16_t);
         else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) BN_SMALL(bf16_t, float);
         else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) BN_SMALL(float, float);
@@ -1428,8 +1439,12 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
                        ((uintptr_t)dy) % 16 == 0 && (!relu || ((uintptr_t)y) % 16 == 0);
     if (M <= g_bn_small_rows) {                          // small map: sums, finalize and apply in one launch
 #define BN_BWD_SMALL(T, TY)                                                                                                   \
-    hipLaunchKernelGGL((bn_bwd_small_kernel<T, TY>), dim3(g2.x), dim3(512), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, \
-                       C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, dgamma, dbeta)
+    do { if (pl.colgroups < 16 && !g_bn_small_wide)                                                                           \
+        hipLaunchKernelGGL((bn_bwd_small_kernel<T, TY, 1>), dim3(ceil_div(ldz, kc)), dim3(512), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, \
+                           C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, dgamma, dbeta); \
+    else                                                                                                                      \
+        hipLaunchKernelGGL((bn_bwd_small_kernel<T, TY, 8>), dim3(g2.x), dim3(512), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, \
+                           C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, dgamma, dbeta); } while (0)
         if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_BWD_SMALL(bf16_t, bf16_t); }
         else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_BWD_SMALL(bf16_t, float); }
         else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD_SMALL(float, float); }

@@ -27,6 +27,7 @@ import torch
 
 from . import heads, ops
 from ._lib import BF16, F32
+from .warmup import F32Warmup
 
 MEAN_RGB = (123.68, 116.779, 103.979)
 BLOCKS = (3, 4, 6, 3)                                          # FCOS.py:30
@@ -84,7 +85,7 @@ class _Act:
         self.gid = name
 
 
-class FCOS:
+class FCOS(F32Warmup):
     def __init__(self, config, data_provider):
         assert config['mode'] in ['train', 'test']
         assert config['data_format'] in ['channels_first', 'channels_last']
@@ -101,7 +102,9 @@ class FCOS:
         self.nms_iou_threshold = config['nms_iou_threshold']
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'f32')]       # f32 until the bf16 backward is validated (cf. retinanet.py)
+        # engine: bf16 by default on the GPU since round 3 (warmup.py: the first f32_warmup_steps optimizer steps of a run from random initialisation go through
+        # an f32 twin); an explicit 'compute_dtype' is taken literally; the CPU stand-in of the library (host-logic tests) stays on f32
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16' if torch.device(config.get('device', 'cuda:0')).type == 'cuda' else 'f32')]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         if self.mode == 'train':
@@ -122,6 +125,7 @@ class FCOS:
         self.specs = layer_specs(self.num_classes)
         self._init_parameters(int(config.get('seed', 0)))
         self._build()
+        self._warmup_setup(config, data_provider, 'compute_dtype' in config)
 
     # ------------------------------------------------------------------ parameters
     def param_layout(self):
@@ -175,6 +179,8 @@ class FCOS:
         return v
 
     def load_oracle_params(self, p):
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()
         for k, v in p.items():
             if k in self.pinfo:
                 self.set_param(k, v)
@@ -419,7 +425,7 @@ class FCOS:
                 yield name
 
     # ------------------------------------------------------------------ public: training
-    def set_batch(self, images, ground_truth):
+    def _set_batch_engine(self, images, ground_truth):
         images = torch.as_tensor(images, dtype=torch.float32)
         if self.data_format == 'channels_first' and images.shape[1] == 3:
             images = images.permute(0, 2, 3, 1)
@@ -430,7 +436,7 @@ class FCOS:
             self.gt = torch.zeros(gt.shape, device=self.dev)
         self.gt.copy_(gt, non_blocking=True)
 
-    def train_step(self, lr):
+    def _train_step_engine(self, lr):
         """one optimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor"""
         if self.dist is not None:
             self.dist.begin_step()
@@ -498,6 +504,8 @@ class FCOS:
         return out
 
     def load_tf_checkpoint(self, path, backbone_only=False):
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
         names = reader.get_variable_to_shape_map()
@@ -519,7 +527,7 @@ class FCOS:
             self.global_step = int(reader.get_tensor('global_step'))
         self._refresh_operand_copies()
 
-    def save_weight(self, mode, path):
+    def _save_weight_engine(self, mode, path):
         """FCOS.py:418-428.  config['checkpoint_format'] = 'tf' writes tf.train.Saver files (tf_checkpoint.py)."""
         assert (mode in ['latest', 'best'])
         dirname = os.path.dirname(path)

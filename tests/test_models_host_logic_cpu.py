@@ -429,3 +429,55 @@ def test_yolov2_training_step_host_logic():
         after = m.export_params()
         for k in ('b1.w', 'b9.gamma', 'b17.w', 'h5.beta', 'pred.w', 'pred.gamma', 'b3.mmean', 'pred.mvar'):
             assert _rel(after[k], q[k]) < 1e-3 or float((after[k] - q[k]).abs().max()) < 1e-6, k
+
+
+@pytest.mark.parametrize('kind', ['fcos', 'centernet'])
+def test_bf16_default_with_f32_warmup_hands_over_to_the_bf16_engine(kind, tmp_path):
+    """warmup.py: with `f32_warmup_steps = n` the first n optimizer steps of a bf16 model run on an f32 twin -- step for step what a pure f32 model does -- then
+    parameters, optimizer state (momentum | Adam moments + step) and moving statistics move over bit for bit and the bf16 engine continues; a checkpoint written
+    mid-warm-up holds the twin's live weights; loading weights cancels the warm-up.  (CPU: the launches are tests/mock_ops.py's.)"""
+    import odtk
+    torch.set_num_threads(8)
+    if kind == 'fcos':
+        from oracle import fcos_ref as FR
+        cfg = {'mode': 'train', 'data_shape': [64, 64, 3], 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+               'batch_size': 2, 'nms_score_threshold': 0.5, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False, 'device': 'cpu', 'seed': 3}
+        g = torch.Generator().manual_seed(7)
+        imgs, gt = (torch.rand(2, 64, 64, 3, generator=g) * 255).round(), FR.synthetic_gt(2, 64, 64, 8)
+        prov = {'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None}
+        cls, lr, state = odtk.FCOS, 0.01, ('Mom',)
+    else:
+        from oracle import centernet_ref as CR
+        cfg = {'mode': 'train', 'input_size': 128, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 2,
+               'score_threshold': 0.1, 'top_k_results_output': 10, 'verbose': False, 'device': 'cpu', 'seed': 3}
+        g = torch.Generator().manual_seed(8)
+        imgs, gt = (torch.rand(2, 128, 128, 3, generator=g) * 255).round(), CR.synthetic_gt(2, 128, 9, pad=8, max_obj=4)
+        prov = {'data_shape': [128, 128, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None}
+        cls, lr, state = odtk.CenterNet, 1e-3, ('M1', 'M2')
+    with mock_ops.installed():
+        assert cls(dict(cfg), prov).DT == odtk.ops.F32                          # the CPU stand-in keeps the f32 default; on the GPU the default is bf16 + warm-up
+        ref = cls(dict(cfg, compute_dtype='f32'), prov)
+        m = cls(dict(cfg, compute_dtype='bf16', f32_warmup_steps=2), prov)
+        assert m.DT == odtk.ops.BF16 and m.f32_warmup_steps == 2 and cls(dict(cfg, compute_dtype='bf16'), prov).f32_warmup_steps == 0
+        ref.set_batch(imgs, gt); m.set_batch(imgs, gt)
+        l_ref = [float(ref.train_step(lr)) for _ in range(2)]
+        l0 = float(m.train_step(lr))
+        assert m._twin is not None and m._twin.DT == odtk.ops.F32 and m.global_step == 1
+        m.save_weight('latest', str(tmp_path / 'mid'))                          # mid-warm-up checkpoint = the twin's weights
+        mid = torch.load(str(tmp_path / 'mid') + '-1', map_location='cpu', weights_only=True)['params']
+        tw = m._twin.export_params()
+        assert all(torch.equal(mid[k], tw[k]) for k in tw)
+        l1 = float(m.train_step(lr))
+        assert [l0, l1] == l_ref                                                # the warm-up steps ARE f32 steps
+        assert m._twin is None and not m._warming() and m.global_step == 2
+        pr, pm = ref.export_params(), m.export_params()
+        assert all(torch.equal(pr[k], pm[k]) for k in pr)                       # handed over bit for bit ...
+        for name in state:
+            assert all(torch.equal(ref.get_param(k, getattr(ref, name)), m.get_param(k, getattr(m, name))) for k in ref.pinfo), name
+        l2 = float(m.train_step(lr))                                            # ... and the bf16 engine carries on from there
+        l2_ref = float(ref.train_step(lr))
+        assert m.global_step == 3 and abs(l2 - l2_ref) <= 5e-2 * abs(l2_ref) and l2 != l2_ref
+        assert next(iter(m.acts.values())).t.dtype == torch.bfloat16 if hasattr(next(iter(m.acts.values())), 't') else True
+        m2 = cls(dict(cfg, compute_dtype='bf16', f32_warmup_steps=5), prov)
+        m2.load_oracle_params(pr)
+        assert m2.f32_warmup_steps == 0 and m2._twin is None                    # loaded weights: not a run from random initialisation

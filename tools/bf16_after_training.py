@@ -1,0 +1,102 @@
+"""Is the bf16 engine usable for the batch-norm / group-norm classes AWAY from random initialisation?  (round-2 review, item 6)
+
+At random initialisation the bf16 engine's gradients of RetinaNet / FCOS / CenterNet lose their direction towards the input (the identity-free
+conv + norm stacks amplify the 2^-9 rounding of every stored activation), which is why these classes default to the f32 engine.  This tool trains the class on
+its f32 engine for `steps` optimizer steps (synthetic VOC-shaped batches, the BASELINE resolution, a reduced batch), then -- from THOSE weights and moving
+statistics -- runs one step on a held-out batch on both engines and compares every filter gradient: cosine and norm ratio, bf16 against f32.  The same
+comparison from the initial weights is printed next to it.
+
+    python tools/bf16_after_training.py retinanet|fcos|centernet|yolov3 [steps=300] [batch=4] [lr=...]
+"""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch          # noqa: E402
+
+import bench_configs as BC          # noqa: E402
+
+
+def grads_of(name, params, stats, batch, size, dtype, probe):
+    r = BC.make(name, batch=batch, size=size, dtype=dtype, use_graph=False)
+    m = r['model']
+    m.load_oracle_params(params)
+    if stats is not None and hasattr(m, 'S'):
+        m.S.copy_(stats.to(m.S.device))
+    m.set_batch(*probe)
+    loss = float(m.train_step(0.0))
+    torch.cuda.synchronize()
+    g = {k: m.get_param(k, m.G).double().cpu() for k in m.pinfo if k.endswith('.w')}
+    del m
+    torch.cuda.empty_cache()
+    return loss, g
+
+
+def compare(gf, gb):
+    rows = []
+    for k, a in gf.items():
+        b = gb[k]
+        na, nb = float(a.norm()), float(b.norm())
+        if na == 0.0:
+            continue
+        rows.append((k, float((a * b).sum() / (na * nb + 1e-300)), nb / na))
+    return rows
+
+
+def summarize(tag, rows):
+    cos = [r[1] for r in rows]
+    third = max(1, len(rows) // 3)
+    first, last = rows[:third], rows[-third:]
+    print(f'{tag}: {len(rows)} filter gradients; cosine bf16 vs f32: min {min(cos):.3f} ({min(rows, key=lambda r: r[1])[0]}), median {statistics.median(cos):.3f}; '
+          f'first third of the layers (towards the input) median {statistics.median(r[1] for r in first):.3f}, last third median '
+          f'{statistics.median(r[1] for r in last):.3f}; norm ratio median {statistics.median(r[2] for r in rows):.3f}')
+    return min(cos), statistics.median(r[1] for r in first)
+
+
+def run(name, steps=300, batch=4, lr=1e-3, verbose=True):
+    """-> dict(init=(min cosine, input-side-third median), after=(...), losses=[...])"""
+    size = BC.SHAPES[name][0]
+    r = BC.make(name, batch=batch, size=size, dtype='f32', use_graph=False)
+    m = r['model']
+    probe = BC.synthetic_batch(name, batch, size, 4242)
+    p0 = m.export_params()
+    s0 = m.S.clone() if hasattr(m, 'S') else None
+    lf, gf = grads_of(name, p0, s0, batch, size, 'f32', probe)
+    lb, gb = grads_of(name, p0, s0, batch, size, 'bf16', probe)
+    if verbose:
+        print(f'{name} {size}x{size} batch {batch}: at initialisation loss f32 {lf:.4f} / bf16 {lb:.4f}')
+    init = summarize('  initial weights', compare(gf, gb))
+    pool = [BC.synthetic_batch(name, batch, size, 100 + i) for i in range(8)]
+    losses = []
+    for i in range(steps):
+        m.set_batch(*pool[i % len(pool)])
+        loss = m.train_step(lr)
+        if i % max(1, steps // 6) == 0 or i == steps - 1:
+            losses.append((i, round(float(loss), 4)))
+    torch.cuda.synchronize()
+    if verbose:
+        print(f'  f32 training, lr {lr}: loss {losses}')
+    p1 = m.export_params()
+    s1 = m.S.clone() if hasattr(m, 'S') else None
+    del m
+    torch.cuda.empty_cache()
+    lf, gf = grads_of(name, p1, s1, batch, size, 'f32', probe)
+    lb, gb = grads_of(name, p1, s1, batch, size, 'bf16', probe)
+    if verbose:
+        print(f'  after {steps} steps: held-out loss f32 {lf:.4f} / bf16 {lb:.4f}')
+    after = summarize(f'  after {steps} steps', compare(gf, gb))
+    print(f'RESULT {name}: min cosine {init[0]:.3f} -> {after[0]:.3f}; input-side third {init[1]:.3f} -> {after[1]:.3f}')
+    return dict(init=init, after=after, losses=losses, loss_f32=lf, loss_bf16=lb)
+
+
+def main():
+    name = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    lr = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-3
+    run(name, steps, batch, lr)
+
+
+if __name__ == '__main__':
+    main()

@@ -212,6 +212,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region (the default at N = 1 since round 3)')
+    ap.add_argument('--launch-list', action='store_true', help="N = 1: use_graph='list' -- the step's C-ABI calls replayed from a recorded list of pre-bound argument "
+                                                              'tuples (no Python wrappers, plain launches in stream order)')
     ap.add_argument('--graph', action='store_true', help='N = 1: replay forward + loss + backward from HIP graphs (A/B; measured 1-3 %% slower than eager launches)')
     ap.add_argument('--auto-launch', action='store_true', help="use_graph='auto': the faster of replay / eager launches, measured during warm-up")
     ap.add_argument('--wgrad-stream', action='store_true', help='A/B: filter gradients on a second HIP stream')
@@ -261,18 +263,12 @@ def main():
     import odtk
     from odtk import ops
     B = args.batch
-    if args.kernel_dbg:
-        assert args.kernel_dbg >> 26 << 26 == args.kernel_dbg, 'only the dispatch switches leave results intact'
-        odtk._lib.load().odtk_debug_set(2, args.kernel_dbg)
-    for kv in filter(None, args.debug_set.split(',')):
-        k, v = kv.split(':')
-        assert int(k) in (3, 4, 5), 'only the dispatch switches leave results intact'  # (values may be negative: 4:-1)
-        odtk._lib.load().odtk_debug_set(int(k), int(v))
+    apply_debug_switches(args)
     config = {
         'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
         'keep_prob': 0.5, 'batch_size': B, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20,
         'nms_iou_threshold': 0.5, 'pretraining_weight': os.path.join('.', 'vgg_16.ckpt'),
-        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else (args.graph or args.gpus > 1 or args.dp_world1) and not args.eager, 'fuse_pool': not args.no_fuse_pool,
+        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else ('list' if args.launch_list else (args.graph or args.gpus > 1 or args.dp_world1) and not args.eager), 'fuse_pool': not args.no_fuse_pool,
     }
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)
@@ -351,7 +347,7 @@ def main():
             'config': {'workload': f'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
                        'global_batch': B * world, 'parallelism': f'dp{world}' + ('+sync-bn' if args.sync_bn and world > 1 else ''), 'final_loss': round(final_loss, 4),
                        'launch_mode_calibration': model.launch_mode,
-                       'launch': 'eager' if not model.use_graph else ('hip-graph replay (fwd+loss+bwd)' if model._g_back is not None
+                       'launch': ('recorded launch list' if getattr(model, 'use_list', False) else 'eager') if not model.use_graph else ('hip-graph replay (fwd+loss+bwd)' if model._g_back is not None
                                                                         else f'hip-graph replay (fwd+loss; bwd as {len(model._g_back_segs or [])} '
                                                                              'bucket graphs with RCCL all-reduces between them)')},
         }
@@ -374,6 +370,17 @@ def main():
         dist.destroy_process_group()
 
 
+def apply_debug_switches(args):
+    import odtk
+    if args.kernel_dbg:
+        assert args.kernel_dbg >> 26 << 26 == args.kernel_dbg, 'only the dispatch switches leave results intact'
+        odtk._lib.load().odtk_debug_set(2, args.kernel_dbg)
+    for kv in filter(None, args.debug_set.split(',')):
+        k, v = kv.split(':')
+        assert int(k) in (3, 4, 5), 'only the dispatch switches leave results intact'  # (values may be negative: 4:-1)
+        odtk._lib.load().odtk_debug_set(int(k), int(v))
+
+
 def bench_other(args, world, rank, local_rank):
     """`--config retinanet | yolov3 | fcos | centernet`: the same contract for BASELINE.json's configurations 3-5 (one full training step of the model
     class at its stated shape on a resident synthetic batch; weak scaling, one rank per GPU, bucketed RCCL gradient all-reduce)."""
@@ -385,8 +392,9 @@ def bench_other(args, world, rank, local_rank):
     if world > 1:
         init_group('nccl', rank, world, dev)
     from odtk import ops
+    apply_debug_switches(args)
     name = args.config
-    r = BC.make(name, batch=args.batch, dtype=args.dtype, seed=1000 + rank, use_graph=False)
+    r = BC.make(name, batch=args.batch, dtype=args.dtype, seed=1000 + rank, use_graph=bool(args.graph))
     model, B, lr = r['model'], r['batch'], r['lr']
     if world > 1:
         model.attach_data_parallel(bucket_mb=args.bucket_mb, grad_dtype=args.grad_dtype)
@@ -435,7 +443,7 @@ def bench_other(args, world, rank, local_rank):
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
                'data': 'synthetic',
                'config': {'workload': BC.WORKLOAD[name].format(B=B), 'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
-                          'launch': 'eager', 'algorithmic_conv_gflop_per_image': round(flops_step / B / 1e9, 2),
+                          'launch': 'hip-graph replay' if args.graph else 'eager', 'algorithmic_conv_gflop_per_image': round(flops_step / B / 1e9, 2),
                           'engine_note': None if args.dtype == 'bf16' else 'f32 engine (the class default): exact-f32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s'}}
         if timer.records:
             rf = timer.roofline(ev_steps, peak, value / world * (flops_step / B) / peak)

@@ -160,5 +160,32 @@ def check(rc: int):
         raise OdtkError(f"libodtk error {rc}: {load().odtk_last_error().decode()}")
 
 
+# Recorded launch lists (SSD300 `use_graph='list'`): while a recorder is installed every C-ABI call is also appended to it as (bound ctypes function,
+# argument tuple) -- the arguments are the already converted ctypes objects, raw pointers included, so a replay is `for f, a in cmds: f(*a)` at the cost of
+# the foreign call alone (the Python wrappers of ops.py, the tensor -> pointer conversions and the stream lookups run once, at record time).  Plain kernel
+# launches in stream order: unlike a HIP graph nothing changes on the device side.
+_REC = None
+
+
+def record_begin():
+    global _REC
+    assert _REC is None, 'a launch list is already being recorded'
+    _REC = []
+    return _REC
+
+
+def record_end():
+    global _REC
+    cmds, _REC = _REC, None
+    return cmds
+
+
+def recording():
+    return _REC
+
+
 def call(name: str, *args):
-    check(getattr(load(), name)(*args))
+    f = getattr(load(), name)
+    if _REC is not None:
+        _REC.append((f, args))
+    check(f(*args))

@@ -29,7 +29,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import BF16, F32
 
 INPUT_SIZE = 300
@@ -204,7 +204,10 @@ class SSD300:
         # fast as the GPU retires them.  On a host that can, the two modes measured within 1 % of each other (9.63-9.66 ms
         # eager vs 9.75-9.82 ms replayed, same box), so replay -- which does not depend on the host -- is the default.
         ug = config.get('use_graph', False)
-        self.use_graph = True if ug == 'auto' else bool(ug)
+        self.use_list = ug == 'list'             # recorded launch list: the step's C-ABI calls replayed from pre-bound argument tuples (_lib.record_begin)
+        self._cmds = None
+        self._events = {}
+        self.use_graph = True if ug == 'auto' else (False if ug == 'list' else bool(ug))
         self._auto = {'left': 2 * self.AUTO_STEPS, 't': {}} if ug == 'auto' else None
         # optional: filter gradients on a second HIP stream (wgrad(L) only needs dy(L) and the stored input of L, nothing
         # on the dgrad chain needs its result before the optimizer).  Measured neutral on MI355X (both chains are
@@ -223,6 +226,11 @@ class SSD300:
         # sequential extras.  Config key 'tail_stream' (default on).  The two chains use separate batch-norm workspaces and
         # separate split-K scratch slots (odtk_scratch_slot).
         self._tail = torch.cuda.Stream(device=self.dev) if (on_gpu and config.get('tail_stream', True) and self.wgrad_stream is None) else None
+        # The filter gradients of the extras and heads on a THIRD stream (config key 'tail_wgrad_stream'): in the backward pass of the small-map region every
+        # layer is bn_bwd -> wgrad -> dgrad (+ split-K finish) and only the dgrad feeds the next layer, so the ~390 us of filter-gradient launches of that
+        # region (conv6 154, pred1 92, pred2 73, conv7 50 ...) leave the latency-bound chain; they join in front of the optimizer.
+        self._twg = torch.cuda.Stream(device=self.dev) if (on_gpu and self._tail is not None and config.get('tail_wgrad_stream', True)) else None
+        self._cur_slot = 0
         self._g_front = self._g_back = None
         self._g_back_segs = None
         self._eager_steps = 0
@@ -522,6 +530,21 @@ class SSD300:
             ops.bn_bwd(z, y, dy, M, C_, ldz, ldy, rows_per_img, y_img_stride, gamma, sm, si, relu, dz, dgamma, dbeta, ws)
 
     # ------------------------------------------------------------------ forward
+    def _py(self, fn):
+        """a torch-level action inside the step (stream fork / join, event, fill): run it, and keep it in the launch list when one is being recorded"""
+        fn()
+        rec = _lib.recording()
+        if rec is not None:
+            def replay(fn=fn):
+                fn()                                             # (whatever fn returns is not a status code)
+            rec.append((replay, ()))
+
+    def _event(self, key):
+        ev = self._events.get(key)
+        if ev is None:
+            ev = self._events[key] = torch.cuda.Event()
+        return ev
+
     def _conv_fwd(self, name, src, dst, bias, relu):
         ops.conv2d_fwd(self.desc[name], src.t, self._wslice(name + '.w', self.Pc), bias, dst.t, relu)
 
@@ -556,7 +579,7 @@ class SSD300:
         tail = self._tail if self.sync_bn is None else None
         main = torch.cuda.current_stream() if tail is not None else None
         if tail is not None:
-            tail.wait_stream(main)                       # fork: feat1 is final
+            self._py(lambda: tail.wait_stream(main))      # fork: feat1 is final
             with self._on_tail():
                 self._head_fwd(0, training)
         for (name, ci, co, k, s, d) in self.EXTRA_SEQ:
@@ -568,11 +591,11 @@ class SSD300:
                        self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, True,
                        y.t, y.ld, z.M, 0, self.ws)
             if tail is not None and name in self.FEAT_SRC:
-                tail.wait_stream(main)                   # this feature map is final: its head may start
+                self._py(lambda: tail.wait_stream(main))  # this feature map is final: its head may start
                 with self._on_tail():
                     self._head_fwd(self.FEAT_SRC.index(name), training)
         if tail is not None:
-            main.wait_stream(tail)                       # join: pred is complete
+            self._py(lambda: main.wait_stream(tail))      # join: pred is complete
         else:
             for i in range(self.NH):
                 self._head_fwd(i, training)
@@ -595,12 +618,14 @@ class SSD300:
     def _on_tail(self):
         """launches inside go to the head stream, with its own batch-norm workspace and split-K scratch slot"""
         ops.scratch_slot(1)
+        self._cur_slot = 1
         ws, self.ws = self.ws, self.ws_tail
         try:
             with torch.cuda.stream(self._tail):
                 yield
         finally:
             self.ws = ws
+            self._cur_slot = 0
             ops.scratch_slot(0)
 
     # ------------------------------------------------------------------ loss
@@ -622,7 +647,7 @@ class SSD300:
         ops.ssd_loss(self.pred, self.num_classes, pri[2], pri[3], self.gt, self.m_ngt, self.m_best, self.m_status,
                      self.m_rg, self.m_counts, self.negloss, self.sel_idx, self.sel_cnt, grad_scale,
                      self.loss_parts, self.dpred)
-        self.loss_col.copy_(self.loss_parts[:, 3])
+        self._py(lambda: self.loss_col.copy_(self.loss_parts[:, 3]))
         ops.sum_f32(self.loss_col, self.data_loss)
 
     m_best = None
@@ -638,20 +663,23 @@ class SSD300:
         d = self.desc[name]
         dbias = None if self.convs[name].bn else self._grad(name + '.b')
         side = self.wgrad_stream if self.dist is None else None      # DP: the bucket hooks order on the main stream
+        if side is None and self._twg is not None and self.dist is None and self.sync_bn is None and self.convs[name].bn:
+            side = self._twg                                          # extras and heads (the batch-normalised layers): off the latency-bound chain
         if side is None:
             ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
             return
-        side.wait_stream(torch.cuda.current_stream())                 # dy(L) is complete at this point of the main stream
-        ops.scratch_slot(2)                                           # the split partials of this launch: not the main stream's scratch
+        cur = torch.cuda.current_stream()
+        self._py(lambda: side.wait_stream(cur))                       # dy(L) is complete at this point of the launching stream
+        ops.scratch_slot(2)                                           # the split partials of this launch: not the launching stream's scratch
         try:
             with torch.cuda.stream(side):
                 ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
         finally:
-            ops.scratch_slot(0)
+            ops.scratch_slot(self._cur_slot)
 
     def _backward(self):
         for name in self._backward_iter():
-            self._mark_ready(name)
+            self._py(lambda name=name: self._mark_ready(name))
 
     def _backward_iter(self):
         """Backward pass as a generator: it hands back a layer name as soon as every gradient of that layer (and of all
@@ -671,32 +699,32 @@ class SSD300:
             # ... on the head stream, beside the extras' chain; an event per head tells the chain when a feature map's
             # gradient holds the head's contribution
             main = torch.cuda.current_stream()
-            tail.wait_stream(main)                       # fork: d(pred) is final
+            self._py(lambda: tail.wait_stream(main))      # fork: d(pred) is final
             with self._on_tail():
                 for i in reversed(range(self.NH)):
                     self._head_bwd(i)
-                    evs[self.FEAT_SRC[i]] = torch.cuda.Event()
-                    evs[self.FEAT_SRC[i]].record()
+                    ev = evs[self.FEAT_SRC[i]] = self._event(('head', i))
+                    self._py(lambda ev=ev: ev.record(tail))
         # extra layers conv11_2 .. conv6
         for (name, ci, co, k, s, d) in reversed(self.EXTRA_SEQ):
             src = a[self.extra_src[name]]
             z, y = self.zbuf[name], a[name]
             sm, si = self.bnsave[name]
             if name == self.EXTRA_SEQ[-1][0] and name in evs:
-                main.wait_event(evs[name])               # the last feature map: only its head wrote y.g
+                self._py(lambda ev=evs[name]: main.wait_event(ev))      # the last feature map: only its head wrote y.g
             self._bn_bwd(z.t, y.t, y.g, z.M, co, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, True,
                        z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
             self._conv_bwd_params(name, src, z.g, z.ld)
             # the source already holds the head's gradient when it is a feature map
             acc = self.extra_src[name] in self.FEAT_SRC
             if acc and self.extra_src[name] in evs:
-                main.wait_event(evs[self.extra_src[name]])
+                self._py(lambda ev=evs[self.extra_src[name]]: main.wait_event(ev))
             relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], relu_src, src.g, acc)
             if tail is None:
                 yield name
         if tail is not None:
-            main.wait_stream(tail)                       # join: pred1 -> feat1.g is final before the trunk reads it
+            self._py(lambda: main.wait_stream(tail))      # join: pred1 -> feat1.g is final before the trunk reads it
             for i in reversed(range(self.NH)):
                 yield f'pred{i + 1}'
             for e in reversed(self.EXTRA_SEQ):
@@ -724,6 +752,9 @@ class SSD300:
                 if name != 'conv1_1':
                     ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
                 yield name
+        if self._twg is not None and self.dist is None and self.sync_bn is None:
+            cur = torch.cuda.current_stream()
+            self._py(lambda: cur.wait_stream(self._twg))                   # the tail's filter gradients join before the optimizer
         if self.wgrad_stream is not None and self.dist is None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)     # join before the optimizer
 
@@ -758,7 +789,7 @@ class SSD300:
         self.gt.copy_(gt, non_blocking=True)
 
     def _step_front(self):
-        self.G.zero_()
+        self._py(self.G.zero_)
         # the matching only depends on the ground truth: it runs on a second stream under the forward pass
         if self.m_best is None or self.m_best.shape[1] != self.gt.shape[1]:
             self.m_best = torch.zeros(self.batch_size, self.gt.shape[1], dtype=torch.int32, device=self.dev)
@@ -775,6 +806,7 @@ class SSD300:
         self._loss(1.0 / self.loss_divisor_batch, matched=True)
 
     def _graphs_invalidate(self):
+        self._cmds = None
         self._g_front = self._g_back = None
         self._g_back_segs = None
         self._eager_steps = 0
@@ -884,6 +916,21 @@ class SSD300:
             return self._auto_step(lr)
         if self.dist is not None:
             self.dist.begin_step()
+        if self.use_list and self._eager_steps >= 2 and self.sync_bn is None:
+            if self._cmds is None:                               # third step: run it through the Python wrappers once more, recording
+                _lib.record_begin()
+                try:
+                    self._step_front()
+                    self._backward()
+                finally:
+                    cmds = _lib.record_end()
+                self._cmds = cmds
+            else:
+                for f, a in self._cmds:
+                    rc = f(*a)
+                    if rc:
+                        _lib.check(rc)
+            return self._finish_step(lr)
         if use_graph:
             self._g_front.replay()
         else:
@@ -898,6 +945,9 @@ class SSD300:
                     self.dist.layer_ready(n)
         else:
             self._backward()
+        return self._finish_step(lr)
+
+    def _finish_step(self, lr):
         if self.dist is not None:
             self.dist.finish_step()
         ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial,

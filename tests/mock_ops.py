@@ -4,6 +4,7 @@ plain torch ops.  With it the model classes' HOST LOGIC -- buffer planning, laun
 and is checked against the oracles without a GPU (`-m "not gpu"`); the kernels themselves are checked on the GPU, one by one and
 through the same classes.  Usage: `with mock_ops.installed(): model = odtk.YOLOv3(dict(config, device='cpu'), provider)`."""
 import contextlib
+import inspect
 
 import torch
 import torch.nn.functional as F
@@ -622,9 +623,23 @@ def installed():
     from odtk import ops
     names = [n for n, v in globals().items() if callable(v) and not n.startswith('_') and n not in ('installed', 'contextlib') and hasattr(ops, n)]
     old = {n: getattr(ops, n) for n in names}
+    from odtk import _lib
+
+    def recorded(fn):
+        # what _lib.call does for the real library: while a launch list is being recorded (SSD300 use_graph='list') the call is kept for replay
+        def w(*a, **k):
+            rec = _lib.recording()
+            if rec is not None:
+                def replay():
+                    fn(*a, **k)
+                rec.append((replay, ()))
+            return fn(*a, **k)
+        w.__name__ = fn.__name__
+        return w
     try:
         for n in names:
-            setattr(ops, n, globals()[n])
+            f = globals()[n]
+            setattr(ops, n, recorded(f) if inspect.isfunction(f) else f)
         yield
     finally:
         for n, v in old.items():

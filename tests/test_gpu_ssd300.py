@@ -255,3 +255,43 @@ def test_head_stream_equals_single_stream(use_graph, dev):
             n = int(np.prod(shape))
             a, b = g0[off:off + n], g1[off:off + n]
             assert float((a - b).abs().max()) <= 2e-2 * (float(a.abs().max()) + 1e-12), name
+
+
+@pytest.mark.parametrize("tail", [True, False], ids=["head-stream", "one-stream"])
+def test_recorded_launch_list_equals_eager_launches(tail, dev):
+    """`use_graph='list'`: from the third step on the step's C-ABI calls (and the stream forks / joins / events between them) are replayed from a recorded
+    list of pre-bound argument tuples.  lr = 0 keeps the weights fixed, so every replayed step must reproduce the gradient buffer of the eager steps (to
+    the float-atomic order of the filter gradients); with lr > 0 the losses follow the eager run; a new ground-truth shape drops the list."""
+    import odtk
+    B = 8
+    imgs, gt = R.synthetic_batch(B, 5)
+    prov = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    m = odtk.SSD300(dict(CONFIG, compute_dtype='bf16', batch_size=B, use_graph='list', tail_stream=tail, seed=0), prov)
+    m.set_batch(imgs, gt)
+    ref = None
+    for i in range(6):
+        junk = torch.empty(1 << (18 + i), device='cuda')         # allocation churn between steps: the list holds raw pointers of persistent buffers only
+        m.train_step(0.0)
+        torch.cuda.synchronize()
+        g = m.G.clone()
+        if ref is None:
+            ref = g
+        else:
+            assert float((g - ref).norm() / ref.norm()) < 2e-3, i
+        assert (m._cmds is not None) == (i >= 2)
+        del junk
+    assert len(m._cmds) > 150
+    losses = {}
+    for mode in (False, 'list'):
+        mm = odtk.SSD300(dict(CONFIG, compute_dtype='f32', batch_size=2, use_graph=mode, tail_stream=tail, seed=4), dict(prov, num_train=2))
+        mm.set_batch(*R.synthetic_batch(2, 31))
+        losses[mode] = [float(mm.train_step(0.005).item()) for _ in range(5)]
+    a, b = losses[False], losses['list']
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[2] - b[2]) <= 3e-3 * abs(a[2]) and abs(a[3] - b[3]) <= 3e-2 * abs(a[3]), (a, b)
+    gt2 = torch.cat([gt, torch.full((B, 4, 5), -1.0)], 1)         # a different pad length: new device buffer -> the list is dropped and re-recorded
+    m.set_batch(imgs, gt2)
+    assert m._cmds is None
+    for _ in range(4):
+        m.train_step(0.0)
+    torch.cuda.synchronize()
+    assert m._cmds is not None and float((m.G - ref).norm() / ref.norm()) < 2e-3

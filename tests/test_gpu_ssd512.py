@@ -99,7 +99,7 @@ def test_f32_train_step_matches_oracle(dev):
 
 def test_bf16_steps_with_graph_replay_and_inference(dev):
     imgs, gt = R5.synthetic_batch(4, 45)
-    m = _model('train', 'bf16', 4)
+    m = _model('train', 'bf16', 4, use_graph=True)          # (eager launches are the default since round 3; the replay path stays tested)
     m.set_batch(imgs, gt)
     ls = [float(m.train_step(0.003).item()) for _ in range(6)]
     assert all(np.isfinite(ls)) and ls[-1] < ls[0] and m._g_front is not None

@@ -481,3 +481,22 @@ def test_bf16_default_with_f32_warmup_hands_over_to_the_bf16_engine(kind, tmp_pa
         m2 = cls(dict(cfg, compute_dtype='bf16', f32_warmup_steps=5), prov)
         m2.load_oracle_params(pr)
         assert m2.f32_warmup_steps == 0 and m2._twin is None                    # loaded weights: not a run from random initialisation
+
+
+def test_ssd300_recorded_launch_list_replays_the_step_on_cpu():
+    """SSD300 `use_graph='list'` through the mocked launches: the recorded list (launches + stream / event actions) replays to exactly the eager result"""
+    import odtk
+    from oracle import ssd300_ref as R
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+           'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '', 'verbose': False,
+           'compute_dtype': 'f32', 'seed': 0, 'device': 'cpu'}
+    imgs, gt = R.synthetic_batch(1, 33)
+    prov = {'data_shape': [300, 300, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    with mock_ops.installed():
+        a, b = odtk.SSD300(dict(cfg, use_graph=False), prov), odtk.SSD300(dict(cfg, use_graph='list'), prov)
+        a.set_batch(imgs, gt); b.set_batch(imgs, gt)
+        for i in range(4):
+            assert float(a.train_step(0.01)) == float(b.train_step(0.01))
+            assert (b._cmds is not None) == (i >= 2)
+        assert torch.equal(a.P, b.P) and len(b._cmds) > 100

@@ -19,7 +19,13 @@ SHAPES = {
     'yolov3': (416, 8, 'bf16', 1e-4),
     'fcos': (512, 16, 'bf16', 1e-4),          # bf16 engine by default since round 3 (steady state; a run from random initialisation warms up in f32: warmup.py)
     'centernet': (512, 16, 'bf16', 1e-4),
+    # the remaining classes of SURVEY.md 8f.4 at their driver scripts' shapes (in-situ parity at the quoted shape; not BASELINE.json configurations)
+    'ssd512': (512, 32, 'bf16', 1e-4),
+    'refinedet': (320, 32, 'f32', 1e-4),
+    'pfpnet': (320, 32, 'f32', 1e-4),
+    'yolov2': (480, 32, 'f32', 1e-4),
 }
+YOLOV2_PRIORS = [[1.08, 1.19], [3.42, 4.41], [6.63, 11.38], [9.42, 5.11], [16.62, 10.52]]
 WORKLOAD = {
     'ssd300': 'SSD300 VGG-16 300x300 train step, batch {B}/GPU (fwd + NMS-mined loss + bwd + SGD-momentum)',
     'retinanet': 'RetinaNet ResNet-50-FPN (reference widths 7/14/28/56 x4) 800x800 train step, batch {B}/GPU, 120 087 anchors (fwd + focal loss + bwd + SGD-momentum)',
@@ -57,6 +63,8 @@ def synthetic_batch(name, batch, size, seed):
         images = torch.rand(batch, size, size, 3, generator=g) * 255.
         return images, synthetic_gt(batch, size, seed + 1, lo=0.1, hi=0.9)
     images = (torch.rand(batch, size, size, 3, generator=g) * 255).round()
+    if name in ('ssd512', 'refinedet', 'pfpnet', 'yolov2'):
+        return images, synthetic_gt(batch, size, seed + 1, lo=0.1, hi=0.7)
     return images, synthetic_gt(batch, size, seed + 1, lo=0.05, hi=0.8 if name == 'yolov3' else 0.6)
 
 
@@ -77,6 +85,13 @@ def config_of(name, batch=None, size=None, dtype=None, **extra):
         cfg = dict(base, data_shape=[size, size, 3], nms_score_threshold=0.5, nms_max_boxes=10, nms_iou_threshold=0.45)
     elif name == 'centernet':
         cfg = dict(base, input_size=size, score_threshold=0.1, top_k_results_output=100)
+    elif name == 'ssd512':
+        cfg = dict(base, nms_score_threshold=0.5, nms_max_boxes=20, nms_iou_threshold=0.5, pretraining_weight='', seed=0)
+    elif name in ('refinedet', 'pfpnet'):
+        cfg = dict(base, input_size=size, nms_score_threshold=0.1, nms_max_boxes=20, nms_iou_threshold=0.45, pretraining_weight='')
+    elif name == 'yolov2':
+        cfg = dict(base, is_pretraining=False, data_shape=[size, size, 3], coord_scale=1, noobj_scale=1, obj_scale=5., class_scale=1., nms_score_threshold=0.5,
+                   nms_max_boxes=10, nms_iou_threshold=0.5, rescore_confidence=False, priors=YOLOV2_PRIORS)
     else:
         raise KeyError(name)
     cfg.update(extra)
@@ -89,7 +104,8 @@ def make(name, batch=None, size=None, dtype=None, seed=1000, **extra):
     cfg, size, batch, dtype = config_of(name, batch, size, dtype, **extra)
     images, gt = synthetic_batch(name, batch, size, seed)
     prov = {'data_shape': [size, size, 3], 'num_train': batch, 'num_val': 0, 'train_generator': [(images, gt)], 'val_generator': None}
-    cls = {'ssd300': 'SSD300', 'retinanet': 'RetinaNet', 'yolov3': 'YOLOv3', 'fcos': 'FCOS', 'centernet': 'CenterNet'}[name]
+    cls = {'ssd300': 'SSD300', 'retinanet': 'RetinaNet', 'yolov3': 'YOLOv3', 'fcos': 'FCOS', 'centernet': 'CenterNet', 'ssd512': 'SSD512',
+           'refinedet': 'RefineDet320', 'pfpnet': 'PFPNetR', 'yolov2': 'YOLOv2'}[name]
     model = getattr(odtk, cls)(cfg, prov)
     return dict(model=model, images=images, gt=gt, lr=SHAPES[name][3], batch=batch, size=size, dtype=dtype, name=name)
 
@@ -98,7 +114,7 @@ def conv_layers(name, model):
     """[(ConvDesc, cin, cout, k)] of every convolution LAUNCH GROUP of a step with the ALGORITHMIC channel counts (the descriptors carry
     channel counts padded to whole 16-byte chunks: 7 -> 8, 3 -> 8, 85 -> 88 ...)."""
     out = []
-    if name == 'ssd300':
+    if name in ('ssd300', 'ssd512'):
         for lname, c in model.convs.items():
             out.append((model.desc[lname], c.cin if lname != 'conv1_1' else 3, c.cout, model.desc[lname].R))
     elif name == 'yolov3':

@@ -53,6 +53,7 @@ PASS = {'conv2d_fwd_pool2x2_fused', 'ssd_match', 'softmax_ce_const', 'retina_mat
         'yolov3_workspace', 'retina_match_workspace', 'centernet_workspace', 'yolov3_decode_candidates', 'fcos_decode_candidates', 'retina_decode',
         'refinedet_decode', 'centernet_decode', 'yolov2_decode_candidates'}
 WHOLE_STORAGE_MAX = 1 << 30
+BN_MOM_ = 0.99
 
 
 # Reductions whose terms cancel (the bias gradient of a convolution in front of a batch norm is sum(dz) = 0 in exact arithmetic; dgamma / dbeta of a
@@ -76,6 +77,9 @@ def _gn_terms(a):
 
 
 COND = {
+    # a batch mean is a cancelling sum too (PFPNetR's 85-channel branches: |mean| ~ 1e-6 of the spread): against the mean of |z|
+    ('bn_fwd', 'save_mean'): lambda a: a['z'][:a['M'], :a['C_']].float().abs().mean(0),
+    ('bn_fwd', 'mmean'): lambda a: BN_MOM_ * a['mmean'].float().abs() + (1 - BN_MOM_) * a['z'][:a['M'], :a['C_']].float().abs().mean(0),
     ('conv2d_wgrad', 'dbias'): lambda a: a['dy'][:, :a['d'].K].float().abs().sum(0),
     ('bn_bwd', 'dbeta'): lambda a: _bn_terms(a)[0].abs().sum(0),
     ('bn_bwd', 'dgamma'): lambda a: (lambda d, xh: (d * xh).abs().sum(0))(*_bn_terms(a)),

@@ -25,17 +25,24 @@ CASES = [('retinanet', 'f32'), ('yolov3', 'bf16'), ('fcos', 'bf16'), ('centernet
          ('ssd300', 'bf16'), ('retinanet', 'bf16'), ('yolov3', 'f32'), ('fcos', 'f32'), ('centernet', 'f32')]
 
 
+# the classes of SURVEY.md 8f.4 at the shapes their throughput is quoted on: SSD512 512x512 b32, RefineDet320 / PFPNetR 320x320 b32, YOLOv2 480x480 b32
+CASES += [('ssd512', 'bf16'), ('refinedet', 'bf16'), ('pfpnet', 'bf16'), ('yolov2', 'bf16'), ('refinedet', 'f32'), ('pfpnet', 'f32'), ('yolov2', 'f32')]
+
+
 @pytest.mark.parametrize('name,dtype', CASES, ids=[f'{n}-{d}' for n, d in CASES])
 def test_every_launch_in_situ_at_baseline_shape(name, dtype):
     import bench_configs as BC
     torch.set_num_threads(16)
-    assert BC.SHAPES[name][2] == dtype or (name, dtype) in CASES[4:]
     sh = insitu.Shadow()
     with sh.installed():
         r = BC.make(name, dtype=dtype, use_graph=False)
         m = r['model']
         size0, batch0, _, _ = BC.SHAPES[name]
         assert r['size'] == size0 and r['batch'] == batch0                       # the stated shape, not a reduced one
+        if name == 'ssd512':
+            from oracle import ssd512_ref as R5
+            tables = R5.tables()
+            tables.__enter__()                  # the shadowed box-side launches call the oracle, which reads the swapped SSD512 tables
         if name == 'retinanet':
             mock_ops.retina_loss.anchors = tuple(t.cpu() for t in m.anc)
             assert m.num_anchor_boxes == 120087
@@ -45,11 +52,15 @@ def test_every_launch_in_situ_at_baseline_shape(name, dtype):
         loss = m.train_step(r['lr'])
         sh.recording = False
         torch.cuda.synchronize()
-    assert bool(torch.isfinite(loss).all())
+    if name == 'ssd512':
+        tables.__exit__(None, None, None)
+    assert bool(torch.isfinite(torch.as_tensor(loss)).all())
     rows = sh.check(insitu.default_tol(dtype), verbose=True, label=f'{name} {dtype} {size0}x{size0} batch {batch0}')
     seen = {x['op'] for x in rows}
     assert {'conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad'} <= seen and any(o.endswith('_loss') for o in seen)
     n_conv = len(BC.conv_layers(name, m))
-    assert sum(1 for x in rows if x['op'] == 'conv2d_fwd') >= n_conv - 1 and sum(1 for x in rows if x['op'] == 'conv2d_wgrad' and x['out'] == 'dw') >= n_conv - 1
+    if n_conv:
+        assert sum(1 for x in rows if x['op'] in ('conv2d_fwd', 'conv2d_fwd_pool2x2') and x['out'] in ('y', 'y_pool')) >= n_conv - 1
+        assert sum(1 for x in rows if x['op'] == 'conv2d_wgrad' and x['out'] == 'dw') >= n_conv - 1
     del m, r
     torch.cuda.empty_cache()

@@ -115,8 +115,17 @@ def test_f32_inference_detections_equal_oracle(dev):
     assert len(want[0]) > 0 and len(got[0]) == len(want[0])
     assert np.array_equal(got[2], want[2].numpy())
     np.testing.assert_allclose(got[0], want[0].numpy(), atol=2e-3)
-    # boxes = anchor (up to 800 px here) * exp(t): 1e-3 in t is ~1 px.  Scores that differ by < 1e-3 between two candidates may swap
-    # their NMS order (the pick lists then differ in that slot): a few rows may hold the neighbour's box
+    # boxes = anchor (up to 800 px here) * exp(t): 1e-3 in t is ~1 px, and scores that differ by < 1e-3 between two candidates may swap their NMS
+    # order between engine and oracle.  So the inference tail is held to EQUALITY where that is well defined: the oracle's decode + per-class NMS run on
+    # the ENGINE's own logits must give the engine's detections row for row (class ids and pick order identical, scores 1e-5, boxes 0.05 px) ...
+    pc_e, pb_e = m.pconf.cpu()[0], m.pbox.cpu()[0]
+    conf_e, boxes_e, keep_e, _ = RR.decode_candidates(pb_e[:, :2], pb_e[:, 2:], pc_e, anc, thr)
+    same = DC.per_class_nms(conf_e, boxes_e, 20, thr, 10, 0.45, row_mask=keep_e)
+    assert np.array_equal(got[2], same[2].numpy()) and len(got[0]) == len(same[0])
+    np.testing.assert_allclose(got[0], same[0].numpy(), atol=1e-5)
+    assert float(np.abs(got[1] - same[1].numpy()).max()) <= 0.05 + 1e-5 * float(np.abs(same[1].numpy()).max())
+    # ... and against the free-running oracle every row within the box-size-relative bound that 2e-3 on the logits allows, except rows whose pick
+    # swapped with a near-tied neighbour (reported, at most one in twenty)
     w = want[1].numpy()
     row_ok = (np.abs(got[1] - w) <= 2.0 + 5e-3 * np.abs(w)).all(axis=1)
     assert row_ok.mean() >= 0.95, row_ok.mean()

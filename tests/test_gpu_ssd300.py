@@ -52,8 +52,10 @@ def test_inference_parity_f32(dev):
         s_ref, b_ref, c_ref = R.test_one_image(p, imgs[:1], thr, 20, 0.5)
         assert c.tolist() == c_ref.tolist()
         if len(s_ref):
-            assert float(np.abs(s - s_ref).max()) < 1e-3
-            assert float(np.abs(b - b_ref).max()) < 1e-3 * 300          # 1e-3 of the image size
+            # north_star: "boxes/scores within 1e-3 of the TF1.13 reference" -- read as 1e-3 absolute on the scores (probabilities) and 1e-3 of the
+            # image size on the boxes (0.3 px).  The f32 engine is held to tighter bounds than that: scores 5e-4, boxes 0.1 px (measured 0.05 px).
+            assert float(np.abs(s - s_ref).max()) < 5e-4, float(np.abs(s - s_ref).max())
+            assert float(np.abs(b - b_ref).max()) < 0.1, float(np.abs(b - b_ref).max())
     assert s.dtype == np.float32 and b.shape[1] == 4 and c.dtype == np.int32
 
 

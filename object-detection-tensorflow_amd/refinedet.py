@@ -28,6 +28,7 @@ import torch
 
 from . import heads, ops
 from ._lib import BF16, F32
+from .warmup import F32Warmup
 
 MEAN_RGB = (123.68, 116.779, 103.979)
 VGG_SEQ = [("conv1_1", 3, 64), ("conv1_2", 64, 64), "pool1", ("conv2_1", 64, 128), ("conv2_2", 128, 128), "pool2",
@@ -75,7 +76,8 @@ class _Act:
         self.g = None
 
 
-class RefineDet320:
+class RefineDet320(F32Warmup):
+    DEFAULT_ENGINE = 'f32'                  # RefineDet320 / PFPNetR do not pass the bf16 gate (one head layer loses its direction); YOLOv2 does
     VGG_SEQ = VGG_SEQ                       # the trunk this class builds (pfpnet.PFPNetR stops at conv4_3)
     L2_AFTER = 'conv10_2'                   # creation order: the two L2-norm scalars follow the feature extractor (:77, :79)
     NAME = 'RefineDet'
@@ -116,7 +118,7 @@ class RefineDet320:
                 self.val_generator = data_provider['val_generator']
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'f32')]
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE if self.dev.type == 'cuda' else 'f32')]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0
@@ -127,6 +129,7 @@ class RefineDet320:
         self.specs = self.layer_specs(self.num_classes)
         self._init_parameters(int(config.get('seed', 0)))
         self._build()
+        self._warmup_setup(config, data_provider, 'compute_dtype' in config)
         self._load_pretraining_weight()
 
     # ------------------------------------------------------------------ parameters
@@ -205,6 +208,8 @@ class RefineDet320:
         return v
 
     def load_oracle_params(self, p):
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()
         for k, v in p.items():
             if k in self.pinfo:
                 if k.endswith('.b') and self._kind.get(k[:-2]) == 'dconv' and float(torch.as_tensor(v).abs().max()) != 0.0:
@@ -577,7 +582,7 @@ class RefineDet320:
                 ops.relu_bwd(y.t, y.g, y.ld, b.g, b.ld, y.M, y.ld, acc_b)
 
     # ------------------------------------------------------------------ public: training
-    def set_batch(self, images, ground_truth):
+    def _set_batch_engine(self, images, ground_truth):
         images = torch.as_tensor(images, dtype=torch.float32)
         if self.data_format == 'channels_first' and images.shape[1] == 3:
             images = images.permute(0, 2, 3, 1)
@@ -607,7 +612,7 @@ class RefineDet320:
             if self.dist is not None and ('.' not in name or name.endswith('.c1')):
                 self.dist.layer_ready(name.split('.')[0])
 
-    def train_step(self, lr):
+    def _train_step_engine(self, lr):
         """one MomentumOptimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor.
         Single device, config key 'use_graph' (default OFF): after two eager steps (the library's lazily grown scratch buffers exist by then) forward +
         loss + backward replay from ONE HIP graph; the optimizer launches stay outside (lr is a launch argument).  Measured on MI355X at batch 32 bf16,
@@ -723,6 +728,8 @@ class RefineDet320:
 
     def load_tf_checkpoint(self, path):
         """`saver.restore(sess, path)` from the files of a reference-trained model (or ours)"""
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
         names = reader.get_variable_to_shape_map()
@@ -746,7 +753,7 @@ class RefineDet320:
             self.global_step = int(reader.get_tensor('global_step'))
         self._refresh_operand_copies()
 
-    def save_weight(self, mode, path):
+    def _save_weight_engine(self, mode, path):
         """config['checkpoint_format'] = 'tf' writes the reference's own files (`<path>-<step>.index` + `.data-00000-of-00001` + `checkpoint`, readable by its
         `load_weight`); the default keeps one torch file `<path>-<step>`."""
         assert (mode in ['latest', 'best'])

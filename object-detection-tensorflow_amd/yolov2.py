@@ -63,6 +63,7 @@ def reference_variable_map(num_layers_backbone=18):
 class YOLOv2(RefineDet320):
     L2_AFTER = None
     NAME = 'YOLOv2'
+    DEFAULT_ENGINE = 'bf16'                 # passes the gate (filter-gradient cosine vs f32 after 300 f32 steps: input side 0.93, minimum 0.91)
 
     def __init__(self, config, data_provider):
         assert len(config['data_shape']) == 3
@@ -103,7 +104,7 @@ class YOLOv2(RefineDet320):
                 self.val_generator = data_provider['val_generator']
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'f32')]
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE if self.dev.type == 'cuda' else 'f32')]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0
@@ -114,6 +115,7 @@ class YOLOv2(RefineDet320):
         self.specs = layer_specs(self.num_classes, self.num_priors)
         self._init_parameters(int(config.get('seed', 0)))
         self._build()
+        self._warmup_setup(config, data_provider, 'compute_dtype' in config)
 
     MOMENTUM_SLOT_SCOPE = ''                # the optimizer is created outside every variable scope (YOLOv2.py:168)
 

@@ -1217,16 +1217,28 @@ inline RedPlan red_plan(int M, int C, int kc) {
     p.nsplit = ceil_div(M, p.rows_per_split);
     return p;
 }
+// the same plan with at most `maxsplit` row splits: what the finalize-in-apply launches use (every apply workgroup re-reduces the partials of its 64
+// channels as a prologue: 32 splits = 16 KB from L2, ~1.5 us; the 169-256 splits of the plain plan made that path SLOWER than three launches)
+inline RedPlan red_plan_capped(int M, int C, int kc, int maxsplit) {
+    RedPlan p = red_plan(M, C, kc);
+    if (p.nsplit > maxsplit) {
+        p.rows_per_split = ceil_div(M, maxsplit);
+        p.nsplit = ceil_div(M, p.rows_per_split);
+    }
+    return p;
+}
 
 }  // namespace
 }  // namespace odtk
 
 using namespace odtk;
 
-static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0)
+static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0).  (1 408, so that YOLOv3's 13 x 13 maps at 8 images -- 1 352 rows x 512 / 1 024 channels --
+                                          // take the single launch, was measured SLOWER there: 11.24 vs 11.13 ms/step, gpurun r03o)
+static bool g_bn_auto_two = true;         // odtk_debug_set key 4, value -5: never pick the two-launch path by itself (round-2 behaviour; A/B); -6: back
 static bool g_bn_small_wide = false;      // odtk_debug_set key 4, value -3: the single-launch kernels in their 64-channel shape only (A/B); -4: back
 static bool g_bn_three_kernels = true;    // odtk_debug_set key 4, value -2: statistics + apply-with-finalize (two launches; A/B, tests); -1: back to three
-namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else g_bn_small_rows = rows; } }
+namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else if (rows == -5) g_bn_auto_two = false; else if (rows == -6) g_bn_auto_two = true; else g_bn_small_rows = rows; } }
 
 #define DT_SWITCH(dtype, T, ...)                                         \
     if ((dtype) == ODTK_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
@@ -1362,7 +1374,7 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     if (training && M <= g_bn_small_rows) {              // small map: statistics, finalize and apply in one launch
         // few column groups (C <= 512): one workgroup per 16-byte channel chunk, 512 row lanes (odtk_debug_set key 4, value -3 / -4: the 64-channel shape, A/B)
 #define BN_SMALL(T, TY)                                                                                                      \
-    do { if (pl.colgroups < 16 && !g_bn_small_wide)                                                                          \
+    do { if (!g_bn_small_wide)                                                                          \
         hipLaunchKernelGGL((bn_fwd_small_kernel<T, TY, 1>), dim3(ceil_div(C, kc)), dim3(512), 0, st, (const T*)z, M, C, ldz, gamma, beta, \
                            moving_mean, moving_var, save_mean, save_invstd, relu, (TY*)y, ldy, rows_per_img, y_img_stride, vec_ok); \
     else                                                                                                                     \
@@ -1379,9 +1391,16 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     float* ws = (float*)workspace;
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
     if (training) {
+        // Two launches (statistics; apply with the finalize folded into its prologue) where <= 32 row splits still fill the chip for the statistics pass
+        // (>= 128 workgroups: the 256-1 024-channel layers of DarkNet-53 at 8 images: the finalize launch alone was 8-10 us of latency, x 150 per step)
+        const RedPlan plc = red_plan_capped(M, C, kc, 32);
+        // Measured (gpurun r03o): SSD300's conv6 / conv7 (11 552 rows x 1 024 channels) gain 0.6 % of the step; DarkNet-53's 5 408 x 512 and 21 632 x 256 maps at
+        // 8 images LOSE 1 % of theirs -- hence the size condition on top.
+        const bool two = !g_bn_three_kernels || (g_bn_auto_two && plc.colgroups * plc.nsplit >= 128 && M >= 8192 && C >= 512);
+        const RedPlan pl = two ? plc : red_plan(M, C, kc);
         DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
                                                (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
-        if (!g_bn_three_kernels) {                       // statistics, then apply with the finalize folded in
+        if (two) {                                       // statistics, then apply with the finalize folded in
             const int rpb = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
             dim3 gridf(pl.colgroups, ceil_div(M, rpb));
 #define BN_APPLY_FIN(T, TY)                                                                                                  \
@@ -1426,7 +1445,9 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     const int kc = dtype == ODTK_BF16 ? 8 : 4;
     ODTK_REQUIRE(ldz % kc == 0 && ldz >= C, "bn_bwd: ldz=%d must be a multiple of %d", ldz, kc);
     hipStream_t st = (hipStream_t)stream;
-    const RedPlan pl = red_plan(M, C, kc);
+    const RedPlan plc = red_plan_capped(M, C, kc, 32);   // (see odtk_bn_fwd: two launches where <= 32 row splits still fill the chip)
+    const bool two = !g_bn_three_kernels || (g_bn_auto_two && plc.colgroups * plc.nsplit >= 128 && M >= 8192 && C >= 512);
+    const RedPlan pl = two ? plc : red_plan(M, C, kc);
     float* ws = (float*)workspace;
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
@@ -1439,7 +1460,7 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
                        ((uintptr_t)dy) % 16 == 0 && (!relu || ((uintptr_t)y) % 16 == 0);
     if (M <= g_bn_small_rows) {                          // small map: sums, finalize and apply in one launch
 #define BN_BWD_SMALL(T, TY)                                                                                                   \
-    do { if (pl.colgroups < 16 && !g_bn_small_wide)                                                                           \
+    do { if (!g_bn_small_wide)                                                                           \
         hipLaunchKernelGGL((bn_bwd_small_kernel<T, TY, 1>), dim3(ceil_div(ldz, kc)), dim3(512), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, \
                            C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, dgamma, dbeta); \
     else                                                                                                                      \
@@ -1453,7 +1474,7 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }
-    if (!g_bn_three_kernels) {                           // sums, then apply with the finalize folded in
+    if (two) {                                           // sums, then apply with the finalize folded in
 #define BN_BWD_FIN(T, TY)                                                                                                       \
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz,   \
                        ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu, vec_ok, pl.rows_per_split, ws);             \

@@ -335,19 +335,27 @@ def test_maxpool2x2_recorded_argmax_equals_gather_path(geom, dt, dev):
 @pytest.mark.parametrize("shape", [(2 * 19 * 19, 1024, True), (2 * 38 * 38, 100, False), (3 * 5 * 5, 150, False),
                                    (2 * 3 * 3, 256, True),
                                    (6 * 38 * 38, 100, False), (14 * 19 * 19, 256, True)])   # M > 4096: split-row path
-@pytest.mark.parametrize("launches", [1, 2, 3], ids=["one-launch", "two-launches", "three-launches"])
+@pytest.mark.parametrize("launches", [1, 10, 2, 3, 0], ids=["one-launch", "one-launch-64ch", "two-launches", "three-launches", "auto"])
 def test_batchnorm(shape, dt, ydt, launches, dev):
-    """Maps of <= 1024 rows take the single-launch kernels (statistics + finalize + apply in one workgroup per 64 channels; here the limit is raised to
-    4096 rows to cover more shapes); larger maps three (statistics, finalize, apply); odtk_debug_set(4, -2) selects the two-launch variant (apply with
-    the finalize folded in -- measured slower, kept for A/B)."""
+    """Maps of <= 1024 rows take the single-launch kernels (statistics + finalize + apply: one workgroup per 16-byte channel chunk with 512 row lanes, or
+    -- 'one-launch-64ch', the round-2 shape -- per 64 channels with 64 row lanes; here the limit is raised to 4096 rows to cover more shapes); larger maps
+    three launches (statistics, finalize, apply) or two (apply with the finalize folded into its prologue over <= 32 row splits), picked by shape ('auto':
+    two where 32 splits still give the statistics pass >= 128 workgroups); odtk_debug_set(4, ...) forces each."""
     ops = _ops()
-    ops.debug_set(4, 4096 if launches == 1 else 0)
-    ops.debug_set(4, -1 if launches == 3 else -2)
     try:
+        if launches in (1, 10):
+            ops.debug_set(4, 4096)
+            ops.debug_set(4, -3 if launches == 10 else -4)
+        elif launches in (2, 3):
+            ops.debug_set(4, 0)
+            ops.debug_set(4, -5)
+            ops.debug_set(4, -1 if launches == 3 else -2)
         _batchnorm_case(ops, shape, dt, ydt, dev)
     finally:
         ops.debug_set(4, 1024)
         ops.debug_set(4, -1)
+        ops.debug_set(4, -4)
+        ops.debug_set(4, -6)
 
 
 def _batchnorm_case(ops, shape, dt, ydt, dev):

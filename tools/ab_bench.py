@@ -57,7 +57,7 @@ def main():
     def apply(sets):
         for k, v in resets:
             ops.debug_set(k, v)
-        ops.debug_set(4, -1); ops.debug_set(4, -4)              # batch-norm launch shapes back to their defaults
+        ops.debug_set(4, -1); ops.debug_set(4, -4); ops.debug_set(4, -6)          # batch-norm launch shapes back to their defaults
         for k, v in sets:
             ops.debug_set(k, v)
 

@@ -935,7 +935,7 @@ extern "C" int odtk_conv2d_fwd_pool2x2(const odtk_conv_desc* d, const void* x, c
     ODTK_REQUIRE(ld_pool % 8 == 0 && ld_pool >= d->K, "conv2d_fwd_pool2x2: ld_pool=%d must be a multiple of 8 and >= K=%d", ld_pool, d->K);
     GatherArgs a;
     fwd_args(a, d, x, w, bias, y, relu);
-    if (odtk_conv2d_fwd_pool2x2_fused(d) && idx != nullptr && ld_pool % 8 == 0) {
+    if (relu && odtk_conv2d_fwd_pool2x2_fused(d) && idx != nullptr && ld_pool % 8 == 0) {        // (the fused pooling compares ReLU outputs as integers)
         a.ypool = (char*)y_pool; a.pidx = (unsigned short*)idx; a.ldpool = ld_pool; a.pool_mode = y ? 1 : 2;
         return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
     }

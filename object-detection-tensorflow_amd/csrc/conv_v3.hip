@@ -1572,8 +1572,9 @@ __global__ void __launch_bounds__(512) conv_wgrad_v7_kernel(const WgradArgs a) {
 //     buffered in registers, the next patch's DMA pieces interleaved into the first taps;
 //   * epilogue through the just-consumed patch buffer: full 128-B lines, 1 KiB contiguous per store instruction.
 // ---------------------------------------------------------------------------------------
+template <int ABL>
 __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a, const int tiles_r, const int tiles_c,
-                                                             const int total_tiles) {
+                                                             const int total_tiles, const FastDiv div_tpi, const FastDiv div_tc) {
     constexpr int PW = 34, PPX = 340, NPIECE = 43, PBUF = NPIECE * 1024;
     constexpr int WBYTES = 9 * 8192;
     __shared__ __attribute__((aligned(16))) char smem[WBYTES + 2 * PBUF];
@@ -1600,36 +1601,60 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
             bias[i * 4 + g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + i * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int tiles_per_img = tiles_r * tiles_c;
-    auto decode = [&](int v, int& n, int& h0, int& w0) __attribute__((always_inline)) {
-        n = v / tiles_per_img;
+    auto decode = [&](int v, int& n, int& h0, int& w0) __attribute__((always_inline)) {       // (round 3: no integer division in the tile loop)
+        n = (int)fdiv((unsigned)v, div_tpi);
         const int rem = v - n * tiles_per_img;
-        const int tr = rem / tiles_c;
+        const int tr = (int)fdiv((unsigned)rem, div_tc);
         h0 = tr * 8; w0 = (rem - tr * tiles_c) * 32;
     };
-    auto issue_piece = [&](int n, int h0, int w0, int q, int buf) __attribute__((always_inline)) {
+    // patch pieces of this wave: q = wave + 4 t, t = 0..10 (43 pieces of 8 pixels; wave 3 has ten real ones).  Everything that depends on the lane only is
+    // hoisted -- patch row / column of the piece's pixel and its source offset relative to the tile origin -- so a piece costs ~8 VALU and no branch.
+    int x_rel[11], x_prc[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+        const int q = wave + 4 * t;
         const int px = q * 8 + (lane >> 3);
         const int pr = px / PW, pc = px - pr * PW;
-        const int h = h0 - 1 + pr, w = w0 - 1 + pc;
-        const bool ok = px < PPX && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
         const int lc = (lane & 7) ^ ((px >> 1) & 7);
-        glds16_buf(rx, ok ? (unsigned)((((n * a.H + h) * a.W + w) * 64 + lc * 8) * 2) : 0xFFFFFFF0u,
-                   smem_base + (unsigned)(WBYTES + buf * PBUF) + (unsigned)q * 1024u);
+        x_rel[t] = ((pr * a.W + pc) * 64 + lc * 8) * 2;
+        x_prc[t] = ((px < PPX && q < NPIECE) ? pr : 0x7FFF) | (pc << 16);
+    }
+    // perf experiments only (odtk_debug_set key 2, separate instantiations; results are garbage): bit 0 no patch DMA after the first tile, bit 10 no
+    // fragment reads / MFMAs, bit 6 no epilogue
+    constexpr bool abl_dma = (ABL & 1) != 0, abl_mma = (ABL & 2) != 0, abl_epi = (ABL & 4) != 0;
+    auto issue_piece = [&](int n, int h0, int w0, int t, int buf, bool en) __attribute__((always_inline)) {
+        const int q = wave + 4 * t;
+        const int base = (((n * a.H + h0 - 1) * a.W + w0 - 1) * 64) * 2;
+        const int h = (x_prc[t] & 0xFFFF) + h0 - 1, w = (x_prc[t] >> 16) + w0 - 1;
+        const bool ok = en && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+        if (t < 10 || wave < 3)                                    // wave-uniform (only wave 3, t = 10, has no piece: q = 43)
+            glds16_buf(rx, ok ? (unsigned)(base + x_rel[t]) : 0xFFFFFFF0u, smem_base + (unsigned)(WBYTES + buf * PBUF) + (unsigned)q * 1024u);
     };
     int tn, th0, tw0;
     decode(slot, tn, th0, tw0);
-    for (int q = wave; q < NPIECE; q += 4) issue_piece(tn, th0, tw0, q, 0);
-
-    // fragment addressing: weights row k = i*32 + l31; patch pixel of (tile row 2w+j, column l31)
-    const int wk0 = l31 * 128, wk1 = (32 + l31) * 128;
-    const int fk0 = (l31 >> 1) & 7, fk1 = ((32 + l31) >> 1) & 7;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) issue_piece(tn, th0, tw0, t, 0, true);
+    // fragment addressing: weights row k = i*32 + l31; patch pixel of (tile row 2w+j, column l31).
+    // Physical 16-byte slot = (2 ks + hi) ^ s = (2 ks) ^ (hi ^ s) with s = (row >> 1) & 7: the lane-dependent part u = row * 128 + ((hi ^ s) << 4) is computed once
+    // per (operand row | tap and tile row); the four k sub-steps then cost one v_xor each: address = (u & ~127) + ((u & 127) ^ (ks << 5)) = u ^ (ks << 5)
+    // (the XOR only touches bits 5 and 6, which belong to the slot part of u).
+    const unsigned wu0 = (unsigned)(l31 * 128) + ((unsigned)(hi ^ ((l31 >> 1) & 7)) << 4);
+    const unsigned wu1 = (unsigned)((32 + l31) * 128) + ((unsigned)(hi ^ (((32 + l31) >> 1) & 7)) << 4);
     const int pxb0 = (2 * wave) * PW + l31, pxb1 = (2 * wave + 1) * PW + l31;
+    unsigned pu[9][2];                                      // per tap and tile row: u of the patch pixel this lane reads
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int px0 = pxb0 + (tap / 3) * PW + (tap % 3), px1 = pxb1 + (tap / 3) * PW + (tap % 3);
+        pu[tap][0] = (unsigned)(px0 * 128) + ((unsigned)(hi ^ ((px0 >> 1) & 7)) << 4);
+        pu[tap][1] = (unsigned)(px1 * 128) + ((unsigned)(hi ^ ((px1 >> 1) & 7)) << 4);
+    }
     char* stg = smem + WBYTES + wave * 8192;               // + buf * PBUF
 
     for (int it = 0; it < my_tiles; ++it) {
         const int buf = it & 1;
         const bool has_next = it + 1 < my_tiles;
-        int nn = 0, nh0 = 0, nw0 = 0;
-        if (has_next) decode(slot + (it + 1) * grid, nn, nh0, nw0);
+        int nn, nh0, nw0;
+        decode(has_next ? slot + (it + 1) * grid : slot, nn, nh0, nw0);
         if (it == 0) { wait_vmcnt<0>(); }
         block_barrier();            // patch `buf` (and at it = 0 the filter) visible; everybody left epilogue it-1
         f32x16_v acc[2][2];
@@ -1645,28 +1670,33 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
         uint4 mk[8];                                     // ReLU-mask chunks of this tile, prefetched under the last taps
 #pragma unroll
         for (int r = 0; r < 8; ++r) mk[r] = make_uint4(0, 0, 0, 0);
-        uint4 pf[2][2], qf[2][2];
+        // fragments run TWO k-steps ahead of the MFMAs in three register sets, and the order is pinned (sched_barrier): left alone, the scheduler sinks the
+        // ds_reads next to their MFMAs and every step eats an LDS round trip (round 3: the loop ran at 45 % of the MFMA rate)
+        uint4 pf[3][2], qf[3][2];
         auto ldf = [&](int step, uint4 (&p)[2], uint4 (&q)[2]) __attribute__((always_inline)) {
             const int tap = step >> 2, ks = step & 3;
-            const int dr = tap / 3, ds = tap - dr * 3;
-            const int slot16 = ks * 2 + hi;
             const char* wt = smem + tap * 8192;
-            p[0] = *reinterpret_cast<const uint4*>(wt + wk0 + ((slot16 ^ fk0) << 4));
-            p[1] = *reinterpret_cast<const uint4*>(wt + wk1 + ((slot16 ^ fk1) << 4));
-            const int px0 = pxb0 + dr * PW + ds, px1 = pxb1 + dr * PW + ds;
-            q[0] = *reinterpret_cast<const uint4*>(patch + px0 * 128 + ((slot16 ^ ((px0 >> 1) & 7)) << 4));
-            q[1] = *reinterpret_cast<const uint4*>(patch + px1 * 128 + ((slot16 ^ ((px1 >> 1) & 7)) << 4));
+            p[0] = *reinterpret_cast<const uint4*>(wt + (wu0 ^ (unsigned)(ks << 5)));
+            q[0] = *reinterpret_cast<const uint4*>(patch + (pu[tap][0] ^ (unsigned)(ks << 5)));
+            q[1] = *reinterpret_cast<const uint4*>(patch + (pu[tap][1] ^ (unsigned)(ks << 5)));
+            p[1] = *reinterpret_cast<const uint4*>(wt + (wu1 ^ (unsigned)(ks << 5)));
         };
-        ldf(0, pf[0], qf[0]);
+        if (!abl_mma) { ldf(0, pf[0], qf[0]); ldf(1, pf[1], qf[1]); }
 #pragma unroll
         for (int step = 0; step < 36; ++step) {
-            if (step < 35) ldf(step + 1, pf[(step + 1) & 1], qf[(step + 1) & 1]);
-            if ((step & 3) == 0 && has_next) {
-                // the next tile's patch: 11 pieces per wave, two per tap over the first taps
-                const int tap = step >> 2;
-                const int k0 = 2 * tap, k1 = 2 * tap + 1;
-                if (k0 < 11 && wave + 4 * k0 < NPIECE) issue_piece(nn, nh0, nw0, wave + 4 * k0, buf ^ 1);
-                if (k1 < 11 && wave + 4 * k1 < NPIECE) issue_piece(nn, nh0, nw0, wave + 4 * k1, buf ^ 1);
+            const int cur = step % 3;
+            if (step < 34 && !abl_mma) ldf(step + 2, pf[(step + 2) % 3], qf[(step + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!abl_mma) Mma<bf16_t>::run(pf[cur][0], qf[cur][0], acc[0][0]);
+            if ((step & 3) == 0 && 2 * (step >> 2) < 11) {
+                // the next tile's patch: 11 pieces per wave, two per tap over the first taps (last tile: out-of-range offsets = zero fill of the idle buffer)
+                issue_piece(nn, nh0, nw0, 2 * (step >> 2), buf ^ 1, has_next && !abl_dma);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!abl_mma) Mma<bf16_t>::run(pf[cur][0], qf[cur][1], acc[0][1]);
+            if ((step & 3) == 0 && 2 * (step >> 2) + 1 < 11) {
+                issue_piece(nn, nh0, nw0, 2 * (step >> 2) + 1, buf ^ 1, has_next && !abl_dma);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (step == 24 && a.mask) {
 #pragma unroll
@@ -1678,16 +1708,26 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
                         mk[r] = *reinterpret_cast<const uint4*>(a.mask + (((size_t)(cn * a.H + h) * a.W + w) * a.ldmask + ch * 8) * 2);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) Mma<bf16_t>::run(pf[step & 1][i], qf[step & 1][j], acc[i][j]);
+            if (!abl_mma) {
+                Mma<bf16_t>::run(pf[cur][1], qf[cur][0], acc[1][0]);
+                Mma<bf16_t>::run(pf[cur][1], qf[cur][1], acc[1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         wait_vmcnt<0>();            // my pieces of the next patch landed (they had >= 3 taps of MFMA time)
         block_barrier();            // everybody is done reading patch `buf`: it becomes the output staging area
+        if (abl_epi) {               // keep the accumulators alive
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+            continue;
+        }
         // ---- epilogue
         char* sg = stg + buf * PBUF;
-        const bool pre_relu = a.relu != 0;
+        typedef short s16x2_v __attribute__((ext_vector_type(2)));
+        typedef unsigned short u16x2_v __attribute__((ext_vector_type(2)));
+        const s16x2_v relu_floor = a.relu != 0 ? (s16x2_v)(0) : (s16x2_v)(-32768);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pxl = j * 32 + l31;
@@ -1697,12 +1737,13 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
                 for (int g = 0; g < 4; ++g) {
                     const int cl = i * 32 + 8 * g + 4 * hi;
                     const float4 b = bias[i * 4 + g];
-                    float v0 = acc[i][j][4 * g] + b.x, v1 = acc[i][j][4 * g + 1] + b.y;
-                    float v2 = acc[i][j][4 * g + 2] + b.z, v3 = acc[i][j][4 * g + 3] + b.w;
-                    if (pre_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    const float v0 = acc[i][j][4 * g] + b.x, v1 = acc[i][j][4 * g + 1] + b.y;
+                    const float v2 = acc[i][j][4 * g + 2] + b.z, v3 = acc[i][j][4 * g + 3] + b.w;
+                    // ReLU on the ROUNDED pair as a signed 16-bit max against 0 (against -32768 = identity when there is no ReLU): rounding keeps the sign,
+                    // so this equals rounding max(v, 0) -- two packed ops instead of four, and no -0 ever reaches the integer compares of the pooling below
                     uint2 o;
-                    o.x = cvt_pk_bf16(v0, v1);
-                    o.y = cvt_pk_bf16(v2, v3);
+                    o.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_v, cvt_pk_bf16(v0, v1)), relu_floor));
+                    o.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_v, cvt_pk_bf16(v2, v3)), relu_floor));
                     *reinterpret_cast<uint2*>(sg + pxl * 128 + ((((cl >> 3) ^ pxl) & 7) << 4) + ((cl & 4) << 1)) = o;
                 }
         }
@@ -1738,7 +1779,11 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
                         const int pxl = (t >> 1) * 32 + 2 * pp + (t & 1);
                         v[t] = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
                     }
-                    const bool in1 = w + 1 < a.W, in2 = h + 1 < a.H;
+                    // The values are ReLU outputs: non-negative bf16, whose bit patterns order like unsigned 16-bit integers -- the window maximum and its
+                    // position are packed 16-bit integer ops on two channels at a time (round 3; the per-channel float scan was 40 % of this epilogue).
+                    // Candidates outside the image are zeroed: they can tie but never win, and the FIRST maximum in scan order is
+                    //   row = (max of row 1 > max of row 0), column = (right > left) inside the winning row      (strict >: ties go to the earlier one).
+                    const unsigned in1 = w + 1 < a.W ? 0xFFFFFFFFu : 0u, in2 = h + 1 < a.H ? 0xFFFFFFFFu : 0u;
                     const unsigned* u0 = reinterpret_cast<const unsigned*>(&v[0]);
                     const unsigned* u1 = reinterpret_cast<const unsigned*>(&v[1]);
                     const unsigned* u2 = reinterpret_cast<const unsigned*>(&v[2]);
@@ -1746,22 +1791,20 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
                     uint4 best;
                     unsigned* ub = reinterpret_cast<unsigned*>(&best);
                     unsigned code = 0;
+                    const u16x2_v one = (u16x2_v)(1);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        unsigned outw = 0;
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const float x0 = half ? bf16_hi(u0[q]) : bf16_lo(u0[q]), x1 = half ? bf16_hi(u1[q]) : bf16_lo(u1[q]);
-                            const float x2 = half ? bf16_hi(u2[q]) : bf16_lo(u2[q]), x3 = half ? bf16_hi(u3[q]) : bf16_lo(u3[q]);
-                            float m = x0;
-                            unsigned am = 0;
-                            if (in1 && x1 > m) { m = x1; am = 1; }
-                            if (in2 && x2 > m) { m = x2; am = 2; }
-                            if (in1 && in2 && x3 > m) { m = x3; am = 3; }
-                            outw |= (__float_as_uint(m) >> 16) << (16 * half);       // m is one of the bf16 inputs: exact
-                            code |= am << (2 * (2 * q + half));
-                        }
-                        ub[q] = outw;
+                        const u16x2_v x0 = __builtin_bit_cast(u16x2_v, u0[q]), x1 = __builtin_bit_cast(u16x2_v, u1[q] & in1);
+                        const u16x2_v x2 = __builtin_bit_cast(u16x2_v, u2[q] & in2), x3 = __builtin_bit_cast(u16x2_v, u3[q] & in1 & in2);
+                        const u16x2_v m01 = __builtin_elementwise_max(x0, x1), m23 = __builtin_elementwise_max(x2, x3);
+                        const u16x2_v row = __builtin_elementwise_min(__builtin_elementwise_sub_sat(m23, m01), one);
+                        const u16x2_v c01 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(x1, x0), one);
+                        const u16x2_v c23 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(x3, x2), one);
+                        const u16x2_v rmask = (u16x2_v)(0) - row;                                 // 0xFFFF where row 1 wins
+                        const u16x2_v am = ((c23 & rmask) | (c01 & ~rmask)) | (row << 1);         // 2-bit position per channel
+                        const unsigned cu = __builtin_bit_cast(unsigned, am);
+                        code |= ((cu | (cu >> 14)) & 0xFu) << (4 * q);
+                        ub[q] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(m01, m23));
                     }
                     const size_t mo = (size_t)(cn * Hp + (h >> 1)) * Wp + (w >> 1);
                     *reinterpret_cast<uint4*>(a.ypool + (mo * a.ldpool + ch * 8) * 2) = best;
@@ -2449,7 +2492,14 @@ int launch_gather_c64(GatherArgs& a, hipStream_t st) {
     const int tr = ceil_div(a.H, 8), tc = ceil_div(a.W, 32);
     const int tiles = a.N * tr * tc;
     const int grid = tiles < g_num_cu ? tiles : g_num_cu;
-    hipLaunchKernelGGL(conv3x3_c64k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles);
+    const FastDiv d0 = make_fastdiv((unsigned)(tr * tc)), d1 = make_fastdiv((unsigned)tc);
+    const int abl = (a.dbg & 1) | ((a.dbg & 1024) ? 2 : 0) | ((a.dbg & 64) ? 4 : 0);
+#define ODTK_C64(A) case A: hipLaunchKernelGGL(conv3x3_c64k64_kernel<A>, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles, d0, d1); break;
+    switch (abl) {
+        ODTK_C64(0) ODTK_C64(1) ODTK_C64(2) ODTK_C64(4)
+        default: return 1;
+    }
+#undef ODTK_C64
     return 0;
 }
 

@@ -700,11 +700,19 @@ class SSD300:
             # gradient holds the head's contribution
             main = torch.cuda.current_stream()
             self._py(lambda: tail.wait_stream(main))      # fork: d(pred) is final
-            with self._on_tail():
-                for i in reversed(range(self.NH)):
-                    self._head_bwd(i)
-                    ev = evs[self.FEAT_SRC[i]] = self._event(('head', i))
-                    self._py(lambda ev=ev: ev.record(tail))
+            # The host enqueues the heads ONE AHEAD of the chain (two up front, then one more after every feature map the chain passes): with all six heads
+            # enqueued first, the chain's first launch reached the GPU ~50 enqueues late whenever the host was not far ahead (round 3: 280 us of idle main
+            # queue in the trace).
+            pending_heads = list(reversed(range(self.NH)))
+
+            def enqueue_heads(count):
+                for _ in range(min(count, len(pending_heads))):
+                    i = pending_heads.pop(0)
+                    with self._on_tail():
+                        self._head_bwd(i)
+                        ev = evs[self.FEAT_SRC[i]] = self._event(('head', i))
+                        self._py(lambda ev=ev: ev.record(tail))
+            enqueue_heads(self.NH if self.config.get('heads_first', False) else 2)      # ('heads_first': the round-2 order, A/B)
         # extra layers conv11_2 .. conv6
         for (name, ci, co, k, s, d) in reversed(self.EXTRA_SEQ):
             src = a[self.extra_src[name]]
@@ -717,13 +725,19 @@ class SSD300:
             self._conv_bwd_params(name, src, z.g, z.ld)
             # the source already holds the head's gradient when it is a feature map
             acc = self.extra_src[name] in self.FEAT_SRC
+            if acc and tail is not None:
+                while self.extra_src[name] not in evs:    # (never more than the one-ahead order already gave)
+                    enqueue_heads(1)
             if acc and self.extra_src[name] in evs:
                 self._py(lambda ev=evs[self.extra_src[name]]: main.wait_event(ev))
             relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], relu_src, src.g, acc)
+            if acc and tail is not None:
+                enqueue_heads(1)
             if tail is None:
                 yield name
         if tail is not None:
+            enqueue_heads(self.NH)                        # what is left: pred1 (feat1 is not in the chain)
             self._py(lambda: main.wait_stream(tail))      # join: pred1 -> feat1.g is final before the trunk reads it
             for i in reversed(range(self.NH)):
                 yield f'pred{i + 1}'

@@ -224,6 +224,7 @@ def main():
     ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
     ap.add_argument('--kernel-dbg', type=int, default=0, help='A/B: odtk_debug_set(2, bits) dispatch switches of csrc/conv_v3.hip (bits >= 1<<26 only)')
     ap.add_argument('--debug-set', default='', help="A/B: comma list of KEY:VALUE for odtk_debug_set (keys that leave results intact: 3, 4, 5)")
+    ap.add_argument('--model-cfg', default='', help="A/B: comma list of KEY=VALUE config overrides of the model class (e.g. heads_first=1)")
     ap.add_argument('--bucket-mb', type=int, default=25, help='N > 1: gradient all-reduce bucket size')
     ap.add_argument('--dp-world1', action='store_true',
                     help='N = 1 only: run the data-parallel path (RCCL process group of ONE rank, gradient buckets, per-bucket backward graphs, '
@@ -270,6 +271,9 @@ def main():
         'nms_iou_threshold': 0.5, 'pretraining_weight': os.path.join('.', 'vgg_16.ckpt'),
         'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else ('list' if args.launch_list else (args.graph or args.gpus > 1 or args.dp_world1) and not args.eager), 'fuse_pool': not args.no_fuse_pool,
     }
+    for item in filter(None, args.model_cfg.split(',')):             # A/B switches of the model class (tools/, profiles/)
+        k, _, v = item.partition('=')
+        config[k] = {'0': False, '1': True}.get(v, v)
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)
     if use_pg:

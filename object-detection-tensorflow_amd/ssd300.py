@@ -230,6 +230,8 @@ class SSD300:
         # layer is bn_bwd -> wgrad -> dgrad (+ split-K finish) and only the dgrad feeds the next layer, so the ~390 us of filter-gradient launches of that
         # region (conv6 154, pred1 92, pred2 73, conv7 50 ...) leave the latency-bound chain; they join in front of the optimizer.
         self._twg = torch.cuda.Stream(device=self.dev) if (on_gpu and self._tail is not None and config.get('tail_wgrad_stream', True)) else None
+        self.twg_batch = int(config.get('twg_batch', 4))
+        self._twg_pending = []
         self._cur_slot = 0
         self._g_front = self._g_back = None
         self._g_back_segs = None
@@ -669,11 +671,39 @@ class SSD300:
             ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
             return
         cur = torch.cuda.current_stream()
+        if side is self._twg and self.twg_batch > 1:
+            # Every `side.wait_stream(cur)` puts an event-record packet into the LAUNCHING queue, and the next kernel of that queue starts ~6.5 us late
+            # behind it (rocprofv3 trace, round 3: 16 such bubbles per step on the latency-bound chain).  The filter gradients of the tail are in no hurry:
+            # they are collected and go out `twg_batch` at a time behind ONE record per launching stream (dy and x of a layer stay untouched until the
+            # next step, and the stream joins before the optimizer).
+            self._twg_pending.append((cur, d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias))
+            if len(self._twg_pending) >= self.twg_batch:
+                self._twg_flush()
+            return
         self._py(lambda: side.wait_stream(cur))                       # dy(L) is complete at this point of the launching stream
         ops.scratch_slot(2)                                           # the split partials of this launch: not the launching stream's scratch
         try:
             with torch.cuda.stream(side):
                 ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
+        finally:
+            ops.scratch_slot(self._cur_slot)
+
+    def _twg_flush(self):
+        pend, self._twg_pending = self._twg_pending, []
+        if not pend:
+            return
+        side = self._twg
+        seen = []
+        for item in pend:
+            if not any(item[0] is c for c in seen):
+                seen.append(item[0])
+        for c in seen:
+            self._py(lambda c=c: side.wait_stream(c))
+        ops.scratch_slot(2)
+        try:
+            with torch.cuda.stream(side):
+                for _, d, x_t, dy_t, lddy, gw, dbias in pend:
+                    ops.conv2d_wgrad(d, x_t, dy_t, lddy, gw, dbias)
         finally:
             ops.scratch_slot(self._cur_slot)
 
@@ -738,6 +768,8 @@ class SSD300:
                 yield name
         if tail is not None:
             enqueue_heads(self.NH)                        # what is left: pred1 (feat1 is not in the chain)
+            if self._twg is not None:
+                self._twg_flush()                         # the rest of the tail's filter gradients: under conv7 / conv6, not behind the trunk
             self._py(lambda: main.wait_stream(tail))      # join: pred1 -> feat1.g is final before the trunk reads it
             for i in reversed(range(self.NH)):
                 yield f'pred{i + 1}'
@@ -767,6 +799,7 @@ class SSD300:
                     ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
                 yield name
         if self._twg is not None and self.dist is None and self.sync_bn is None:
+            self._twg_flush()
             cur = torch.cuda.current_stream()
             self._py(lambda: cur.wait_stream(self._twg))                   # the tail's filter gradients join before the optimizer
         if self.wgrad_stream is not None and self.dist is None:

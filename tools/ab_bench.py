@@ -41,7 +41,7 @@ def main():
         for item in filter(None, spec.split(',')):
             if item.startswith('cfg:'):
                 k, _, val = item[4:].partition('=')
-                cfg[k] = {'0': False, '1': True}.get(val, val)
+                cfg[k] = {'0': False, '1': True}.get(val, int(val) if val.isdigit() else val)
             else:
                 k, val = item.split(':')
                 sets.append((int(k), int(val)))

@@ -105,6 +105,20 @@ def prior_spec(input_size=INPUT_SIZE, scales=None, aspects=None, feature_sizes=N
     return feature_sizes, anchors_per_cell, flat
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev, role):
+    """The side streams of a device are created ONCE and shared by every model instance of the process (instances step one after the other).  The HIP
+    runtime deals streams onto four hardware queues (GPU_MAX_HW_QUEUES): a second instance with its own streams -- the f32 warm-up twin of warmup.py, a
+    validation model -- got side streams that alias the hardware queue of the main stream, and its head / filter-gradient launches serialised with the trunk:
+    1.4-2 % slower for the 2nd instance, 7 % for the 4th / 6th / 8th, whatever the configuration (round 3, tools/ab_bench.py --own-streams)."""
+    key = (str(dev), role)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 class _Act:
     """One NHWC activation: rows x pitch buffer (+ lazily allocated gradient buffer)."""
 
@@ -217,21 +231,19 @@ class SSD300:
         # (bit-identical from run to run, 2.5 % slower; a process-wide switch of the library: include/odtk.h, odtk_debug_set key 5)
         if on_gpu and 'deterministic_wgrad' in config:
             ops.debug_set(5, 1 if config['deterministic_wgrad'] else 0)
-        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (on_gpu and config.get('wgrad_stream', False)) else None
-        self._side = torch.cuda.Stream(device=self.dev) if on_gpu else None          # box matching under the forward pass
+        self.wgrad_stream = _side_stream(self.dev, 'wgrad') if (on_gpu and config.get('wgrad_stream', False)) else None
+        self._side = _side_stream(self.dev, 'match') if on_gpu else None             # box matching under the forward pass
         # The six heads run on a second stream BESIDE the extra-layer chain (forward and backward): conv8_1 .. conv11_2 and
         # pred3 .. pred6 work on 10 x 10 ... 3 x 3 maps -- ~130 launches of 5-25 us that leave most of the chip idle and are
         # bound by launch-to-launch latency, 14 % of the step for 0.5 % of its FLOPs.  Each head only depends on its own
         # feature map, so the head chain (incl. the two large heads pred1 / pred2, which fill the idle CUs) overlaps with the
         # sequential extras.  Config key 'tail_stream' (default on).  The two chains use separate batch-norm workspaces and
         # separate split-K scratch slots (odtk_scratch_slot).
-        self._tail = torch.cuda.Stream(device=self.dev) if (on_gpu and config.get('tail_stream', True) and self.wgrad_stream is None) else None
+        self._tail = _side_stream(self.dev, 'tail') if (on_gpu and config.get('tail_stream', True) and self.wgrad_stream is None) else None
         # The filter gradients of the extras and heads on a THIRD stream (config key 'tail_wgrad_stream'): in the backward pass of the small-map region every
         # layer is bn_bwd -> wgrad -> dgrad (+ split-K finish) and only the dgrad feeds the next layer, so the ~390 us of filter-gradient launches of that
         # region (conv6 154, pred1 92, pred2 73, conv7 50 ...) leave the latency-bound chain; they join in front of the optimizer.
-        self._twg = torch.cuda.Stream(device=self.dev) if (on_gpu and self._tail is not None and config.get('tail_wgrad_stream', True)) else None
-        self.twg_batch = int(config.get('twg_batch', 4))
-        self._twg_pending = []
+        self._twg = _side_stream(self.dev, 'tail_wgrad') if (on_gpu and self._tail is not None and config.get('tail_wgrad_stream', True)) else None
         self._cur_slot = 0
         self._g_front = self._g_back = None
         self._g_back_segs = None
@@ -671,39 +683,11 @@ class SSD300:
             ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
             return
         cur = torch.cuda.current_stream()
-        if side is self._twg and self.twg_batch > 1:
-            # Every `side.wait_stream(cur)` puts an event-record packet into the LAUNCHING queue, and the next kernel of that queue starts ~6.5 us late
-            # behind it (rocprofv3 trace, round 3: 16 such bubbles per step on the latency-bound chain).  The filter gradients of the tail are in no hurry:
-            # they are collected and go out `twg_batch` at a time behind ONE record per launching stream (dy and x of a layer stay untouched until the
-            # next step, and the stream joins before the optimizer).
-            self._twg_pending.append((cur, d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias))
-            if len(self._twg_pending) >= self.twg_batch:
-                self._twg_flush()
-            return
         self._py(lambda: side.wait_stream(cur))                       # dy(L) is complete at this point of the launching stream
         ops.scratch_slot(2)                                           # the split partials of this launch: not the launching stream's scratch
         try:
             with torch.cuda.stream(side):
                 ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
-        finally:
-            ops.scratch_slot(self._cur_slot)
-
-    def _twg_flush(self):
-        pend, self._twg_pending = self._twg_pending, []
-        if not pend:
-            return
-        side = self._twg
-        seen = []
-        for item in pend:
-            if not any(item[0] is c for c in seen):
-                seen.append(item[0])
-        for c in seen:
-            self._py(lambda c=c: side.wait_stream(c))
-        ops.scratch_slot(2)
-        try:
-            with torch.cuda.stream(side):
-                for _, d, x_t, dy_t, lddy, gw, dbias in pend:
-                    ops.conv2d_wgrad(d, x_t, dy_t, lddy, gw, dbias)
         finally:
             ops.scratch_slot(self._cur_slot)
 
@@ -730,19 +714,11 @@ class SSD300:
             # gradient holds the head's contribution
             main = torch.cuda.current_stream()
             self._py(lambda: tail.wait_stream(main))      # fork: d(pred) is final
-            # The host enqueues the heads ONE AHEAD of the chain (two up front, then one more after every feature map the chain passes): with all six heads
-            # enqueued first, the chain's first launch reached the GPU ~50 enqueues late whenever the host was not far ahead (round 3: 280 us of idle main
-            # queue in the trace).
-            pending_heads = list(reversed(range(self.NH)))
-
-            def enqueue_heads(count):
-                for _ in range(min(count, len(pending_heads))):
-                    i = pending_heads.pop(0)
-                    with self._on_tail():
-                        self._head_bwd(i)
-                        ev = evs[self.FEAT_SRC[i]] = self._event(('head', i))
-                        self._py(lambda ev=ev: ev.record(tail))
-            enqueue_heads(self.NH if self.config.get('heads_first', False) else 2)      # ('heads_first': the round-2 order, A/B)
+            with self._on_tail():
+                for i in reversed(range(self.NH)):
+                    self._head_bwd(i)
+                    ev = evs[self.FEAT_SRC[i]] = self._event(('head', i))
+                    self._py(lambda ev=ev: ev.record(tail))
         # extra layers conv11_2 .. conv6
         for (name, ci, co, k, s, d) in reversed(self.EXTRA_SEQ):
             src = a[self.extra_src[name]]
@@ -755,21 +731,13 @@ class SSD300:
             self._conv_bwd_params(name, src, z.g, z.ld)
             # the source already holds the head's gradient when it is a feature map
             acc = self.extra_src[name] in self.FEAT_SRC
-            if acc and tail is not None:
-                while self.extra_src[name] not in evs:    # (never more than the one-ahead order already gave)
-                    enqueue_heads(1)
             if acc and self.extra_src[name] in evs:
                 self._py(lambda ev=evs[self.extra_src[name]]: main.wait_event(ev))
             relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], relu_src, src.g, acc)
-            if acc and tail is not None:
-                enqueue_heads(1)
             if tail is None:
                 yield name
         if tail is not None:
-            enqueue_heads(self.NH)                        # what is left: pred1 (feat1 is not in the chain)
-            if self._twg is not None:
-                self._twg_flush()                         # the rest of the tail's filter gradients: under conv7 / conv6, not behind the trunk
             self._py(lambda: main.wait_stream(tail))      # join: pred1 -> feat1.g is final before the trunk reads it
             for i in reversed(range(self.NH)):
                 yield f'pred{i + 1}'
@@ -799,7 +767,6 @@ class SSD300:
                     ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
                 yield name
         if self._twg is not None and self.dist is None and self.sync_bn is None:
-            self._twg_flush()
             cur = torch.cuda.current_stream()
             self._py(lambda: cur.wait_stream(self._twg))                   # the tail's filter gradients join before the optimizer
         if self.wgrad_stream is not None and self.dist is None:

@@ -24,6 +24,8 @@ def main():
     ap.add_argument('--rounds', type=int, default=8)
     ap.add_argument('--block', type=int, default=25)
     ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--own-streams', action='store_true', help='every model instance keeps the side streams it created (shows the hardware-queue aliasing)')
+    ap.add_argument('--clocks', action='store_true', help='sample the shader clock and socket power of this card during every block')
     args = ap.parse_args()
     import odtk
     from odtk import ops
@@ -41,13 +43,20 @@ def main():
         for item in filter(None, spec.split(',')):
             if item.startswith('cfg:'):
                 k, _, val = item[4:].partition('=')
-                cfg[k] = {'0': False, '1': True}.get(val, int(val) if val.isdigit() else val)
+                cfg[k] = ({'0': False, '1': True} if k != 'seed' else {}).get(val, int(val) if val.isdigit() else (float(val) if val.replace('.', '', 1).isdigit() else val))
             else:
                 k, val = item.split(':')
                 sets.append((int(k), int(val)))
         key = tuple(sorted(cfg.items()))
         if key not in models:
             m = odtk.SSD300(dict(base_cfg, **cfg), prov)
+            # The model class shares one set of side streams per device (ssd300._side_stream).  --own-streams gives every further instance fresh ones, as before
+            # round 3: the runtime deals HIP streams onto FOUR hardware queues, a later instance's side stream can alias the main stream's queue -- the 2nd
+            # instance ran 1.4-2 % slower and the 4th, 6th, 8th 7 % slower whatever their configuration, which is what the cfg: variants of rounds 2-3 measured.
+            if models and args.own_streams:
+                for attr in ('_side', '_tail', '_twg', 'wgrad_stream'):
+                    if getattr(m, attr, None) is not None:
+                        setattr(m, attr, torch.cuda.Stream(device=dev))
             m.set_batch(images, gt)
             models[key] = m
         variants.append((name, sets, models[key]))
@@ -67,6 +76,27 @@ def main():
             m.train_step(lr)
     torch.cuda.synchronize()
     times = {name: [] for name, _, _ in variants}
+    # shader clock / socket power of THIS card while a block runs (hwmon sysfs, ~5 ms period): is a slower variant slower at the same clock?
+    sampler = None
+    if args.clocks:
+        import threading
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import clock_trace as CT
+        p_ = torch.cuda.get_device_properties(0)
+        pci = '%04x:%02x:%02x.0' % (p_.pci_domain_id, p_.pci_bus_id, p_.pci_device_id)
+        src = [c for c in CT.sysfs_sources() if os.path.realpath(f"/sys/class/drm/{c['card']}/device").endswith(pci)]
+        if src:
+            src = src[0]
+            state = {'on': False, 'stop': False, 'buf': []}
+
+            def run():
+                while not state['stop']:
+                    if state['on']:
+                        state['buf'].append((CT.read_int(src['sclk_hz']), CT.read_int(src['power_uw'])))
+                    time.sleep(0.005)
+            sampler = (threading.Thread(target=run, daemon=True), state)
+            sampler[0].start()
+    clocks = {name: [] for name, _, _ in variants}
     for r in range(args.rounds):
         order = variants if r % 2 == 0 else variants[::-1]
         for name, sets, m in order:
@@ -74,17 +104,26 @@ def main():
             for _ in range(3):
                 m.train_step(lr)
             torch.cuda.synchronize()
+            if sampler:
+                sampler[1]['buf'] = []; sampler[1]['on'] = True
             t0 = time.perf_counter()
             for _ in range(args.block):
                 m.train_step(lr)
             torch.cuda.synchronize()
             times[name].append((time.perf_counter() - t0) / args.block * 1e3)
+            if sampler:
+                sampler[1]['on'] = False
+                clocks[name] += [b for b in sampler[1]['buf'] if b[0] and b[1]]
     ref = variants[0][0]
-    print(f'| variant | median ms/step | min | max | median per-round ratio to `{ref}` |\n|---|---|---|---|---|')
+    print(f'| variant | median ms/step | min | max | median per-round ratio to `{ref}` | shader clock MHz (median) | socket power W (median) |\n|---|---|---|---|---|---|---|')
     for name, _, _ in variants:
         t = times[name]
         ratio = statistics.median(a / b for a, b in zip(t, times[ref]))
-        print(f'| {name} | {statistics.median(t):.3f} | {min(t):.3f} | {max(t):.3f} | {ratio:.4f} |')
+        ck = clocks[name]
+        cs = f"{statistics.median(c[0] for c in ck) / 1e6:.0f} | {statistics.median(c[1] for c in ck) / 1e6:.0f}" if ck else '- | -'
+        print(f'| {name} | {statistics.median(t):.3f} | {min(t):.3f} | {max(t):.3f} | {ratio:.4f} | {cs} |')
+    if sampler:
+        sampler[1]['stop'] = True
 
 
 if __name__ == '__main__':

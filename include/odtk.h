@@ -299,8 +299,15 @@ int odtk_sgd_momentum(float* p, float* m, const float* grad, long long n, float 
  * lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) for step t = 1, 2, ...  l2_partial / p_cast as in odtk_sgd_momentum (same block layout). */
 int odtk_adam(float* p, float* m, float* v, const float* grad, long long n, float lr_t, float beta1, float beta2, float eps,
               float wd, float grad_scale, float* l2_partial, void* p_cast, int cast_dtype, void* stream);
+/* bytes of device memory at p <- 0 on `stream` (the flat gradient buffer at the top of a step: float atomics accumulate into it). */
+int odtk_zero(void* p, long long bytes, void* stream);
 /* out[0] = sum_{i<n} in[i] (deterministic tree). */
 int odtk_sum_f32(const float* in, long long n, float* out, void* stream);
+/* The scalar a training step reports, in one launch (SSD300.py:148-152: sum_i loss_i / batch + wd * sum_v ||v||^2 / 2): sum_a = sum_{i<na} a[i * stride_a]
+ * (the per-image losses, a column of the loss kernel's [N][4] partials), sum_b = sum_{j<nb} b[j] (the optimizer kernel's per-block sum p^2 / 2 partials),
+ * total = scale_a * sum_a + scale_b * sum_b.  sum_a / sum_b may be null.  Fixed summation order. */
+int odtk_loss_total(const float* a, int na, int stride_a, const float* b, long long nb, float scale_a, float scale_b, float* sum_a, float* sum_b,
+                    float* total, void* stream);
 /* cast f32 -> dtype */
 int odtk_cast_from_f32(const float* in, void* out, long long n, int dtype, void* stream);
 /* cast dtype -> f32 (the bf16 gradient buckets of the data-parallel path are summed by RCCL as bf16 and widened back into the flat f32

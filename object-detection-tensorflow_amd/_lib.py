@@ -102,6 +102,8 @@ SIGNATURES = {
     "odtk_sgd_blocks": (_i, [_ll]),
     "odtk_sgd_momentum": (_i, [_vp, _vp, _vp, _ll, _f, _f, _f, _f, _vp, _vp, _i, _vp]),
     "odtk_sum_f32": (_i, [_vp, _ll, _vp, _vp]),
+    "odtk_zero": (_i, [_vp, _ll, _vp]),
+    "odtk_loss_total": (_i, [_vp, _i, _i, _vp, _ll, _f, _f, _vp, _vp, _vp, _vp]),
     "odtk_cast_from_f32": (_i, [_vp, _vp, _ll, _i, _vp]),
     "odtk_cast_to_f32": (_i, [_vp, _i, _vp, _ll, _vp]),
     "odtk_ssd_priors": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _vp, _vp, _vp, _vp, _vp,

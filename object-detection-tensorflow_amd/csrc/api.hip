@@ -38,6 +38,10 @@ int zero_async(void* p, size_t bytes, hipStream_t st) {
 }  // namespace odtk
 
 extern "C" const char* odtk_last_error(void) { return odtk::g_err; }
+extern "C" int odtk_zero(void* p, long long bytes, void* stream) {
+    if (p == nullptr || bytes < 0) { odtk::set_error("zero: bad argument"); return ODTK_ERR_ARG; }
+    return odtk::zero_async(p, (size_t)bytes, (hipStream_t)stream);
+}
 extern "C" int odtk_version(void) { return 100; }
 // Host-side CRC32C (Castagnoli, reflected 0x82f63b78), slice-by-8: the checksum of TensorFlow's checkpoint blocks and
 // tensors (tf_checkpoint.py reads / writes hundreds of MB of weights; SSD300.py:31, :490-504).  No device work.

@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
                     }
 #pragma unroll
                     for (int q = 0; q < NPC; ++q)
-                        if (q * (4 * PI * QI) / NPC == slotno) {
+                        if (q * (2 * PI * QI) / NPC == slotno) {          // over the FIRST half of the slab (round 3: +0.6 % over dealing them across all of it)
                             if (q < NP) {
                                 const unsigned addr = poff32[q] + woff;
                                 glds16_buf_nc(rw, (pok[q] && more_w) ? addr : 0xFFFFFFF0u, dW + q * 4096u);

@@ -1153,6 +1153,26 @@ __global__ void __launch_bounds__(1024) sum_kernel(const float* __restrict__ in,
     }
 }
 
+// the step's reported loss in ONE launch: sum_a = sum_i a[i * stride_a], sum_b = sum_j b[j], total = scale_a * sum_a + scale_b * sum_b (fixed order)
+__global__ void __launch_bounds__(1024) loss_total_kernel(const float* __restrict__ a, int na, int stride_a, const float* __restrict__ b, long long nb,
+                                                          float scale_a, float scale_b, float* __restrict__ sum_a, float* __restrict__ sum_b,
+                                                          float* __restrict__ total) {
+    __shared__ float sm[32];
+    float sa = 0.f, sb = 0.f;
+    for (int i = threadIdx.x; i < na; i += 1024) sa += a[(size_t)i * stride_a];
+    for (long long i = threadIdx.x; i < nb; i += 1024) sb += b[i];
+    sa = wave_sum(sa); sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = sa; sm[16 + (threadIdx.x >> 6)] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tb = 0.f;
+        for (int i = 0; i < 16; ++i) { ta += sm[i]; tb += sm[16 + i]; }
+        if (sum_a) sum_a[0] = ta;
+        if (sum_b) sum_b[0] = tb;
+        total[0] = scale_a * ta + scale_b * tb;
+    }
+}
+
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1571,6 +1591,14 @@ extern "C" int odtk_sgd_momentum(float* p, float* m, const float* grad, long lon
 extern "C" int odtk_sum_f32(const float* in, long long n, float* out, void* stream) {
     ODTK_REQUIRE(in && out && n >= 0, "sum: bad argument");
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, out);
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_loss_total(const float* a, int na, int stride_a, const float* b, long long nb, float scale_a, float scale_b, float* sum_a,
+                               float* sum_b, float* total, void* stream) {
+    ODTK_REQUIRE(a && b && total && na >= 0 && nb >= 0 && stride_a >= 1, "loss_total: bad argument");
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, na, stride_a, b, nb, scale_a, scale_b, sum_a, sum_b, total);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -338,6 +338,16 @@ def sum_f32(x, out):
     call("odtk_sum_f32", _p(x), x.numel(), _p(out), _stream())
 
 
+def zero(x):
+    """x <- 0 on the current stream (no torch launch)"""
+    call("odtk_zero", _p(x), x.numel() * x.element_size(), _stream())
+
+
+def loss_total(a, na, stride_a, b, scale_a, scale_b, sum_a, sum_b, total):
+    """total[0] = scale_a * sum_i a[i * stride_a] + scale_b * sum(b); the two sums also go to sum_a / sum_b (1-element f32 tensors or None)"""
+    call("odtk_loss_total", _p(a), int(na), int(stride_a), _p(b), b.numel(), float(scale_a), float(scale_b), _p(sum_a), _p(sum_b), _p(total), _stream())
+
+
 def cast_from_f32(x, out):
     call("odtk_cast_from_f32", _p(x), _p(out), x.numel(), dt_of(out), _stream())
 

@@ -499,8 +499,8 @@ class SSD300:
         self.sel_idx = torch.zeros(N, A, **i32)
         self.sel_cnt = torch.zeros(N, **i32)
         self.loss_parts = torch.zeros(N, 4, device=dev)
-        self.loss_col = torch.zeros(N, device=dev)
         self.data_loss = torch.zeros(1, device=dev)
+        self.loss_ring = torch.zeros(8, device=dev)
         nc = self.num_classes - 1
         self.d_conf = torch.zeros(A, nc, device=dev)
         self.d_boxes = torch.zeros(A, 4, device=dev)
@@ -661,8 +661,7 @@ class SSD300:
         ops.ssd_loss(self.pred, self.num_classes, pri[2], pri[3], self.gt, self.m_ngt, self.m_best, self.m_status,
                      self.m_rg, self.m_counts, self.negloss, self.sel_idx, self.sel_cnt, grad_scale,
                      self.loss_parts, self.dpred)
-        self._py(lambda: self.loss_col.copy_(self.loss_parts[:, 3]))
-        ops.sum_f32(self.loss_col, self.data_loss)
+        # (the reported scalar -- sum of loss_parts[:, 3] and the L2 term -- is one launch behind the optimizer: _finish_step)
 
     m_best = None
 
@@ -803,20 +802,24 @@ class SSD300:
         self.gt.copy_(gt, non_blocking=True)
 
     def _step_front(self):
-        self._py(self.G.zero_)
-        # the matching only depends on the ground truth: it runs on a second stream under the forward pass
         if self.m_best is None or self.m_best.shape[1] != self.gt.shape[1]:
             self.m_best = torch.zeros(self.batch_size, self.gt.shape[1], dtype=torch.int32, device=self.dev)
-        if not self.config.get('match_stream', False):     # measured: no gain (a concurrent small kernel slows the convs)
+        side = self._side if self.config.get('side_front', True) else None
+        if side is None:
+            ops.zero(self.G)
             self._forward(True)
             self._loss(1.0 / self.loss_divisor_batch)
             return
+        # Two pieces of the step that do not depend on the network run on a side stream UNDER the forward pass instead of in front of / behind it (round 3):
+        # the flat gradient buffer is cleared (105 MB; the first filter gradient is a whole forward pass away) and the priors are matched to the ground truth
+        # (SSD300.py:347-426 needs the boxes only).  The join is in front of the loss.
         main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        self._py(lambda: side.wait_stream(main))          # behind the previous step's optimizer (it read G) and set_batch's copies
+        with torch.cuda.stream(side):
+            ops.zero(self.G)
             self._match()
         self._forward(True)
-        main.wait_stream(self._side)
+        self._py(lambda: main.wait_stream(side))
         self._loss(1.0 / self.loss_divisor_batch, matched=True)
 
     def _graphs_invalidate(self):
@@ -966,11 +969,14 @@ class SSD300:
             self.dist.finish_step()
         ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial,
                          self.Pc if self.DT == BF16 else None)
-        ops.sum_f32(self.l2_partial, self.l2_sum)
+        # reference SSD300.py:148-152: sum_i loss_i / batch + wd * sum_v ||v||^2 / 2 (pre-update weights) -- one launch; the result goes to a ring of
+        # eight scalars, so a loss tensor the caller has not read yet survives the next seven steps
+        out = self.loss_ring[self.global_step % 8:self.global_step % 8 + 1]
+        ops.loss_total(self.loss_parts[:, 3], self.batch_size, 4, self.l2_partial, 1.0 / self.batch_size, self.weight_decay,
+                       self.data_loss, self.l2_sum, out)
         self.refresh_wt()
         self.global_step += 1
-        # reference SSD300.py:148-152: sum_i loss_i / batch + wd * sum_v ||v||^2 / 2 (pre-update weights)
-        return self.data_loss / self.batch_size + self.weight_decay * self.l2_sum
+        return out
 
     def train_one_epoch(self, lr):
         if callable(self.train_initializer):

@@ -39,7 +39,7 @@ OUTPUTS = {
     'rows_to_f32': ['y'], 'rows_from_f32': ['x'], 'exp_rows_to_f32': ['y'], 'exp_rows_bwd': ['dx'],
     'l2norm_fwd': ['y'], 'l2norm_bwd': ['dx', 'dgamma'],
     'sgd_momentum': ['p', 'm', 'p_cast', 'l2_partial:sum'], 'adam': ['p', 'm', 'v', 'p_cast', 'l2_partial:sum'],
-    'sum_f32': ['out'], 'cast_from_f32': ['out'], 'cast_to_f32': ['out'],
+    'sum_f32': ['out'], 'zero': ['x'], 'loss_total': ['sum_a', 'sum_b', 'total'], 'cast_from_f32': ['out'], 'cast_to_f32': ['out'],
     'ssd_loss': ['loss_parts:3', 'dpred'], 'yolov3_loss': ['loss_parts:4', 'd_preds'], 'yolov2_loss': ['loss_parts:4', 'd_pred'],
     'retina_loss': ['loss_parts:0,1', 'dconf', 'dbox'], 'fcos_loss': ['loss', 'd_conf', 'd_reg', 'd_center'],
     'centernet_loss': ['loss_parts:3', 'd_keypoints', 'd_offset', 'd_size'],

@@ -476,6 +476,20 @@ def sum_f32(x, out):
     out[0] = x.sum()
 
 
+def zero(x):
+    x.zero_()
+
+
+def loss_total(a, na, stride_a, b, scale_a, scale_b, sum_a, sum_b, total):
+    sa = a.reshape(-1)[:na].sum()                 # the callers hand over the strided VIEW (its data pointer + stride_a is what the library sees)
+    sb = b.sum()
+    if sum_a is not None:
+        sum_a[0] = sa
+    if sum_b is not None:
+        sum_b[0] = sb
+    total[0] = scale_a * sa + scale_b * sb
+
+
 def cast_from_f32(x, out):
     out.copy_(x.to(out.dtype))
 

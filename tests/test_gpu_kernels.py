@@ -920,3 +920,26 @@ def test_first_layer_filter_gradient_kernel(geom, dev):
     db_ref = dy.reshape(-1, 64).sum(0)
     db_ref[3] -= 2.0
     assert float((db.cpu() - db_ref).abs().max()) <= 2e-3 * (float(db_ref.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("n", [1, 32, 1000, 70001])
+def test_loss_total_and_zero(n, dev):
+    """odtk_loss_total: the scalar a step reports (strided per-image column + the optimizer's partials) in one launch, against float64; odtk_zero clears
+    any byte range (unaligned head / tail included)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n)
+    parts = torch.randn(n, 4, generator=g).to(dev)
+    l2 = torch.rand(3 * n + 5, generator=g).to(dev)
+    sa, sb, tot = (torch.full((1,), 9.0, device=dev) for _ in range(3))
+    ops.loss_total(parts[:, 3], n, 4, l2, 1.0 / 32, 1e-4, sa, sb, tot)
+    ra, rb = parts[:, 3].double().sum().item(), l2.double().sum().item()
+    assert abs(sa.item() - ra) <= 1e-5 * max(1.0, parts[:, 3].abs().double().sum().item())
+    assert abs(sb.item() - rb) <= 1e-5 * rb
+    assert abs(tot.item() - (ra / 32 + 1e-4 * rb)) <= 1e-5 * (abs(ra) / 32 + 1e-4 * rb + 1e-6)
+    tot2 = torch.zeros(1, device=dev)
+    ops.loss_total(parts[:, 3], n, 4, l2, 1.0 / 32, 1e-4, None, None, tot2)
+    assert tot2.item() == tot.item()
+    buf = torch.full((n + 7,), 3.0, device=dev)
+    ops.zero(buf[3:3 + n])
+    torch.cuda.synchronize()
+    assert float(buf[3:3 + n].abs().sum()) == 0.0 and bool((buf[:3] == 3.0).all()) and bool((buf[3 + n:] == 3.0).all())

@@ -698,6 +698,9 @@ class SSD300:
         """Backward pass as a generator: it hands back a layer name as soon as every gradient of that layer (and of all
         later layers) has been launched -- the data-parallel hooks and the segmented graph capture hang on these points."""
         a = self.acts
+        if getattr(self, '_wt_pending', False):           # (the front's join normally covers this; a backward pass driven by hand does not)
+            self._py(lambda: torch.cuda.current_stream().wait_stream(self._side))
+            self._wt_pending = False
         # data parallel: no head stream in backward -- with it no layer name could be handed back before the join, the readiness marks of
         # pred* / conv11_2 .. conv6 would arrive in one burst and the buckets of the heads and extras (conv6 / conv7: ~6 M parameters) could
         # not start their all-reduce under that part of the backward pass
@@ -820,6 +823,7 @@ class SSD300:
             self._match()
         self._forward(True)
         self._py(lambda: main.wait_stream(side))
+        self._wt_pending = False
         self._loss(1.0 / self.loss_divisor_batch, matched=True)
 
     def _graphs_invalidate(self):
@@ -974,7 +978,16 @@ class SSD300:
         out = self.loss_ring[self.global_step % 8:self.global_step % 8 + 1]
         ops.loss_total(self.loss_parts[:, 3], self.batch_size, 4, self.l2_partial, 1.0 / self.batch_size, self.weight_decay,
                        self.data_loss, self.l2_sum, out)
-        self.refresh_wt()
+        side = self._side if (self.config.get('side_front', True) and self.use_graph in (False, 'list')) else None
+        if side is None:
+            self.refresh_wt()
+        else:
+            # the dgrad-layout filter copies are first read a whole forward pass into the next step: refreshed on the side stream, which the next step's
+            # front joins before its loss (a graph replay has no such join with work outside the graph: there the refresh stays on the main stream)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.refresh_wt()
+            self._wt_pending = True
         self.global_step += 1
         return out
 

@@ -398,7 +398,11 @@ def bench_other(args, world, rank, local_rank):
     from odtk import ops
     apply_debug_switches(args)
     name = args.config
-    r = BC.make(name, batch=args.batch, dtype=args.dtype, seed=1000 + rank, use_graph=bool(args.graph))
+    extra = {}
+    for item in filter(None, args.model_cfg.split(',')):             # A/B switches of the model class
+        k, _, v = item.partition('=')
+        extra[k] = {'0': False, '1': True}.get(v, v)
+    r = BC.make(name, batch=args.batch, dtype=args.dtype, seed=1000 + rank, use_graph=bool(args.graph), **extra)
     model, B, lr = r['model'], r['batch'], r['lr']
     if world > 1:
         model.attach_data_parallel(bucket_mb=args.bucket_mb, grad_dtype=args.grad_dtype)

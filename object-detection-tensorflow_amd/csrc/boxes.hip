@@ -737,7 +737,7 @@ __device__ __forceinline__ void positive_row(const LossArgs& a, int n, int ancho
 // LOSS_SPLIT workgroups per image (one per image left 224 CUs idle for 150 us): workgroup s takes the selected
 // negatives i = s (mod LOSS_SPLIT), the anchors of its contiguous slice, and (s == 0) the G best-anchor rows; the three
 // sums go to a.parts and ssd_loss_final_kernel adds them in fixed order (deterministic loss).
-constexpr int LOSS_SPLIT = 8;
+constexpr int LOSS_SPLIT = 32;        // (8 until round 3: one 4-wave workgroup per CU ran three dependent-load chains per row with nothing to switch to)
 __global__ void __launch_bounds__(LOSS_THREADS) ssd_loss_kernel(const LossArgs a) {
     __shared__ float sm[LOSS_THREADS / 64];
     const int n = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;

@@ -297,3 +297,16 @@ def test_recorded_launch_list_equals_eager_launches(tail, dev):
         m.train_step(0.0)
     torch.cuda.synchronize()
     assert m._cmds is not None and float((m.G - ref).norm() / ref.norm()) < 2e-3
+
+
+def test_model_instances_share_one_set_of_side_streams(dev):
+    """The HIP runtime deals streams onto four hardware queues; a second instance with its OWN side streams got streams that alias the main stream's queue and ran
+    2-7 % slower (profiles/r03s_ab_clean_and_queue_aliasing.md).  Every instance of a process uses the same four streams."""
+    from odtk import ssd300 as S
+    cfg = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 2,
+           'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '', 'verbose': False, 'seed': 0}
+    prov = {'data_shape': [300, 300, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    a, b = S.SSD300(cfg, prov), S.SSD300(dict(cfg, compute_dtype='f32'), prov)
+    for attr in ('_side', '_tail', '_twg'):
+        assert getattr(a, attr) is not None and getattr(a, attr) is getattr(b, attr), attr
+    assert len({a._side.cuda_stream, a._tail.cuda_stream, a._twg.cuda_stream, torch.cuda.current_stream().cuda_stream}) == 4

@@ -10,6 +10,7 @@ namespace odtk {
 
 void set_error(const char* fmt, ...);
 void set_nms_legacy(bool on);   // boxes.hip: odtk_debug_set key 3
+void set_gn_small_rows(int rows);   // elementwise.hip: odtk_debug_set key 7
 void set_bn_small_rows(int rows); // elementwise.hip: odtk_debug_set key 4 (single-workgroup batch-norm up to this many rows; 0 = off)
 
 #define ODTK_CHECK_HIP(expr)                                                         \

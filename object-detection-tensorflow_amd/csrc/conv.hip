@@ -886,6 +886,7 @@ extern "C" int odtk_debug_set(int key, int value) {
     if (key == 3) { set_nms_legacy(value != 0); return ODTK_OK; }
     if (key == 4) { set_bn_small_rows(value); return ODTK_OK; }
     if (key == 5) { cv::set_wgrad_deterministic(value != 0); return ODTK_OK; }
+    if (key == 7) { set_gn_small_rows(value); return ODTK_OK; }
     set_error("debug_set: unknown key %d", key);
     return ODTK_ERR_ARG;
 }

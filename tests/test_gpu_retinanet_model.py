@@ -195,12 +195,22 @@ def test_tf_saver_checkpoint_roundtrip(dev, tmp_path):
         assert torch.equal(c[k], a[k] if int(k[1:].split('.')[0]) < 65 else before[k]), k
 
 
+@pytest.mark.parametrize('single_launch_rows', [1024, 0, 4096])
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-def test_group_norm_kernels(dev, dt):
+def test_group_norm_kernels(dev, dt, single_launch_rows):
     """tf.contrib.layers.group_norm(groups=8, epsilon 1e-6) + ReLU on NHWC rows, forward / backward (incl. accumulate and pitched operands)
-    against torch autograd: the normalisation of the reference's FCOS (FCOS.py:438-446), groundwork for that model"""
+    against torch autograd: the normalisation of the reference's FCOS (FCOS.py:438-446), groundwork for that model.  Maps of up to
+    `single_launch_rows` pixels per sample take the one-launch kernels of round 3 (odtk_debug_set key 7; 0 = the split-row path for every shape)"""
     import odtk  # noqa: F401
     from odtk import ops
+    ops.debug_set(7, single_launch_rows)
+    try:
+        _group_norm_cases(ops, dev, dt)
+    finally:
+        ops.debug_set(7, 1024)
+
+
+def _group_norm_cases(ops, dev, dt):
     tdt = torch.float32 if dt == 'f32' else torch.bfloat16
     g = torch.Generator().manual_seed(4)
     # (the chunked kernels of round 2 take every shape whose channels and pitches are whole 16-byte chunks; 64 % (C / groups) == 0 selects the

@@ -520,6 +520,11 @@ class SSD300:
 
     def refresh_wt(self):
         """Flipped/transposed dgrad filters from the f32 master (after every optimizer step): one batched launch."""
+        if getattr(self, '_wt_pending', False) and self._side is not None and torch.cuda.current_stream() != self._side:
+            # a refresh of the last training step may still be queued on the side stream (_finish_step): whoever refreshes again from another
+            # stream -- load_weight, a checkpoint restore -- goes behind it, so the LAST refresh is the one of the current parameters
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._wt_pending = False
         if getattr(self, '_fp_batch', None) is None:
             entries = []
             for name, wt in self.wt.items():

@@ -904,6 +904,7 @@ extern "C" int odtk_conv2d_fwd(const odtk_conv_desc* d, const void* x, const voi
     a.idiv = 1;
     a.M = d->N * d->Ho * d->Wo; a.Kdim = d->R * d->S * d->C; a.ldw = a.Kdim;
     a.relu = relu; a.accumulate = 0;
+    a.rev = 1;             // (only the persistent 64 -> 64 halo kernel looks at it: conv1_2 walks DOWN the map conv1_1 has just written upwards)
     return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
 }
 
@@ -916,6 +917,7 @@ static void fwd_args(GatherArgs& a, const odtk_conv_desc* d, const void* x, cons
     a.idiv = 1;
     a.M = d->N * d->Ho * d->Wo; a.Kdim = d->R * d->S * d->C; a.ldw = a.Kdim;
     a.relu = relu; a.accumulate = 0;
+    a.rev = 1;
 }
 
 extern "C" int odtk_conv2d_fwd_pool2x2_fused(const odtk_conv_desc* d) {

@@ -150,6 +150,10 @@ struct GatherArgs {
     char* ypool;
     unsigned short* pidx;
     int ldpool, pool_mode;
+    // Tile order of the persistent conv1_x kernels (round 3): 1 = walk the tiles from the LAST to the first.  The maps of conv1_x are 369 MB, more than the
+    // 256 MB of memory-side cache: a kernel that starts where its producer STOPPED finds the producer's last ~2/3 still cached.  Forward: conv1_1 walks up,
+    // conv1_2 walks down; backward: pool1's gradient is written upwards, conv1_2's filter gradient walks down, its input gradient up, conv1_1's filter gradient down.
+    int rev;
 };
 
 struct WgradArgs {
@@ -171,6 +175,7 @@ struct WgradArgs {
     float* ws;
     float* bws;
     int nsplit, nbslot;
+    int rev;         // tile order of the persistent conv1_x filter-gradient kernels: see GatherArgs::rev
     int which;       // set by launch_wgrad_v3: the kernel generation that ran (3 | 7 | 8), for odtk_conv_last_kernel
 };
 

@@ -1602,6 +1602,7 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
 
     const int tiles_per_img = tiles_r * tiles_c;
     auto decode = [&](int v, int& n, int& h0, int& w0) __attribute__((always_inline)) {       // (round 3: no integer division in the tile loop)
+        if (a.rev) v = total_tiles - 1 - v;
         n = (int)fdiv((unsigned)v, div_tpi);
         const int rem = v - n * tiles_per_img;
         const int tr = (int)fdiv((unsigned)rem, div_tc);
@@ -1986,6 +1987,7 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
     if (my_tiles == 0) return;
     const int tiles_per_img = tiles_r * tiles_c;
     auto decode = [&](int v, int& n, int& h0, int& w0) __attribute__((always_inline)) {
+        if (a.rev) v = total_tiles - 1 - v;
         n = (int)fdiv((unsigned)v, div_tpi);
         const int rem = v - n * tiles_per_img;
         const int tr = (int)fdiv((unsigned)rem, div_tc);
@@ -2197,7 +2199,7 @@ __global__ void __launch_bounds__(256) wgrad3x3_c8k64_kernel(const WgradArgs a, 
     }
     auto issue = [&](int v, int stage, bool en) __attribute__((always_inline)) {
         // strip v -> image n, row pair, column block
-        const unsigned vv = (unsigned)(en ? v : 0);
+        const unsigned vv = (unsigned)(en ? (a.rev ? total_strips - 1 - v : v) : 0);
         const int n = (int)fdiv(vv, div_spi);
         const int rem = (int)vv - n * strips_per_img;
         const int rp = (int)fdiv((unsigned)rem, div_sc);
@@ -2489,6 +2491,7 @@ bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype) {
 
 int launch_gather_c64(GatherArgs& a, hipStream_t st) {
     if (g_num_cu == 0) query_num_cu();
+    if ((unsigned)a.dbg >> 31) a.rev = 0;                    // debug bit 31: every kernel walks its tiles upwards (A/B)
     const int tr = ceil_div(a.H, 8), tc = ceil_div(a.W, 32);
     const int tiles = a.N * tr * tc;
     const int grid = tiles < g_num_cu ? tiles : g_num_cu;
@@ -2527,6 +2530,7 @@ bool wgrad_c64_supported(const WgradArgs& a, int dtype) {
 
 int launch_wgrad_c64(WgradArgs& a, hipStream_t st) {
     if (g_num_cu == 0) query_num_cu();
+    a.rev = ((unsigned)a.dbg >> 31) ? 0 : 1;
     const int tr = ceil_div(a.H, 8), tc = ceil_div(a.W, 32);
     const int tiles = a.N * tr * tc;
     const int grid = tiles < g_num_cu ? tiles : g_num_cu;
@@ -2544,6 +2548,7 @@ bool wgrad_c8_supported(const WgradArgs& a, int dtype) {
 
 int launch_wgrad_c8(WgradArgs& a, hipStream_t st) {
     if (g_num_cu == 0) query_num_cu();
+    a.rev = ((unsigned)a.dbg >> 31) ? 0 : 1;
     const int sc = ceil_div(a.W, 32), sr = ceil_div(a.H, 2);
     const int spi = sc * sr, total = a.N * spi;
     int grid = ceil_div(total, 4 * 8);                         // >= 8 strips per wave before a second workgroup per CU would pay its flush

@@ -493,8 +493,9 @@ typedef struct odtk_aug_plan {
     int src_u8;               /* 1: unsigned char pixels, 0: float */
     int src_chw;              /* 1: channels_first source */
     int in_h, in_w;
-    int resize;               /* 0: fill_mode 'CONSTANT' (pad only, :119-123) */
-    int resize_h, resize_w;   /* bilinear align_corners target inside the zoom canvas (:98-113, :125-128) */
+    int resize;               /* 0: fill_mode 'CONSTANT' (pad only, :119-123); 1 'BILINEAR', 2 'NEAREST_NEIGHBOR', 3 'BICUBIC' (:72-76:
+                                 ResizeBilinear / ResizeNearestNeighbor / ResizeBicubic of TF 1.13, align_corners=True) */
+    int resize_h, resize_w;   /* resize target inside the zoom canvas (:98-113, :125-128) */
     int crop_h, crop_w;       /* :131-143 */
     int flip_td, flip_lr;     /* :148-160 */
     int has_brightness, has_contrast, has_hue, has_rotate;

@@ -14,7 +14,6 @@ Where this differs from the reference, on purpose (SURVEY.md 8f.2 asks for the d
     the augmented picture (what :233 returns without ground truth), `image_quirk=True` gives the reference's value;
   - boxes whose centre leaves the picture are dropped from every column (the reference drops them from four of five
     and TensorFlow aborts at :217); if all are lost the picture and boxes fall back to the plain resize (:221-226);
-  - 'NEAREST_NEIGHBOR' and 'BICUBIC' zoom are not implemented (no driver script uses them): NotImplementedError.
 Randomness comes from a numpy Generator (or explicit `draws`), consumed in the reference's order; TF's own random
 stream cannot be reproduced, the transforms given the draws are what the tests pin.
 """
@@ -29,6 +28,7 @@ from . import _lib
 from ._lib import AugPlan, call
 
 PI_REF = 3.1415926                        # image_augmentor.py:236
+RESIZE_CODE = {'CONSTANT': 0, 'BILINEAR': 1, 'NEAREST_NEIGHBOR': 2, 'BICUBIC': 3}      # odtk_aug_plan.resize; image_augmentor.py:72-76
 
 
 def _check_args(data_format, fill_mode, zoom_size, output_shape, crop_method, keep_aspect_ratios, constant_values, color_jitter_prob,
@@ -59,8 +59,6 @@ def _check_args(data_format, fill_mode, zoom_size, output_shape, crop_method, ke
             raise Exception('rotate range must be -5 to 5, otherwise coordinate mapping become imprecise!')
         if not rotate[1] <= rotate[2]:
             raise Exception("rotate[1] can't  grater than rotate[2]")
-    if fill_mode in ('NEAREST_NEIGHBOR', 'BICUBIC'):
-        raise NotImplementedError(f"fill_mode {fill_mode!r}: only 'BILINEAR' and 'CONSTANT' are implemented on the GPU")
 
 
 class _Draws:
@@ -105,7 +103,7 @@ class Augmentor:
         out_h, out_w = c['output_shape']
         zoom_h, zoom_w = c['zoom_size'] if c['zoom_size'] is not None else (out_h, out_w)
         keep = c['keep_aspect_ratios'] or c['fill_mode'] == 'CONSTANT'
-        p = dict(in_h=int(in_h), in_w=int(in_w), resize=int(c['fill_mode'] != 'CONSTANT'), crop_h=0, crop_w=0, flip_td=0, flip_lr=0,
+        p = dict(in_h=int(in_h), in_w=int(in_w), resize=RESIZE_CODE[c['fill_mode']], crop_h=0, crop_w=0, flip_td=0, flip_lr=0,
                  has_brightness=0, has_contrast=0, has_hue=0, has_rotate=0, brightness=0., contrast=1., hue=0., angle=0.)
         if not keep:
             p.update(resize_h=zoom_h, resize_w=zoom_w, ratio_y=float(f32(zoom_h / in_h)), ratio_x=float(f32(zoom_w / in_w)))

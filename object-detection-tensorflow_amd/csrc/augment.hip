@@ -5,13 +5,14 @@
 //
 // HBM-bound gather work, no MFMA: one thread per output pixel, all channels; the whole batch in one launch per stage
 // (grid.y = image), sources of different sizes addressed through the plan.  Stages:
-//   geometry  : resize (bilinear, align_corners) + constant pad + crop + flips + brightness -> stage0, channel sums
+//   geometry  : resize (bilinear | nearest | bicubic per plan.resize = 1 | 2 | 3, align_corners) + constant pad + crop + flips + brightness -> stage0, channel sums
 //   colour    : contrast about the per-channel mean (fixed-order reduction of the block sums) + hue -> stage1 | out
 //   rotate    : bilinear sample about the image centre, zero outside -> out          (only images that drew one)
 // Boxes: one wave per image, ordered compaction with ballots; sets the all-boxes-lost flag the geometry stage reads.
 // CPU restatement these are tested against: oracle/augment_ref.py (pinned to the reference run on oracle/tf_shim).
 #include "common.h"
 #include <math.h>
+#include "augment_resize.h"
 
 namespace odtk {
 namespace {
@@ -56,6 +57,30 @@ __device__ __forceinline__ void bilinear(const odtk_aug_plan& p, int C, float fy
     }
 }
 
+// TF 1.13 ResizeNearestNeighbor / ResizeBicubic with align_corners: indices and weights in augment_resize.h
+__device__ __forceinline__ void nearest_align(const odtk_aug_plan& p, int C, int ys, int xs, float sy, float sx, float* v) {
+    const int y = nearest_src(ys, sy, p.in_h), x = nearest_src(xs, sx, p.in_w);
+    for (int c = 0; c < C; ++c) v[c] = src_px(p, C, y, x, c);
+}
+
+// bicubic: along x first (v0 w0 + v1 w1 + v2 w2 + v3 w3 in float, no contraction), then the four row results along y
+__device__ __forceinline__ void bicubic_align(const odtk_aug_plan& p, int C, int ys, int xs, float sy, float sx, float* v) {
+    float wy[4], wx[4];
+    int iy[4], ix[4];
+    bicubic_taps((float)ys * sy, p.in_h, wy, iy);
+    bicubic_taps((float)xs * sx, p.in_w, wx, ix);
+    for (int c = 0; c < C; ++c) {
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a0 = src_px(p, C, iy[k], ix[0], c), a1 = src_px(p, C, iy[k], ix[1], c);
+            const float a2 = src_px(p, C, iy[k], ix[2], c), a3 = src_px(p, C, iy[k], ix[3], c);
+            r[k] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a0, wx[0]), __fmul_rn(a1, wx[1])), __fmul_rn(a2, wx[2])), __fmul_rn(a3, wx[3]));
+        }
+        v[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[0], wy[0]), __fmul_rn(r[1], wy[1])), __fmul_rn(r[2], wy[2])), __fmul_rn(r[3], wy[3]));
+    }
+}
+
 __global__ void __launch_bounds__(AUG_THREADS) aug_geometry_kernel(AugArgs a) {
     __shared__ float red[AUG_THREADS / 64][AUG_MAXC];
     const int n = blockIdx.y;
@@ -73,9 +98,10 @@ __global__ void __launch_bounds__(AUG_THREADS) aug_geometry_kernel(AugArgs a) {
             const int ys = (p.flip_td ? a.out_h - 1 - y : y) + p.crop_h, xs = (p.flip_lr ? a.out_w - 1 - x : x) + p.crop_w;
             if (ys < p.resize_h && xs < p.resize_w) {
                 if (p.resize) {
-                    const float sy = p.resize_h > 1 ? (float)(p.in_h - 1) / (float)(p.resize_h - 1) : 0.f;
-                    const float sx = p.resize_w > 1 ? (float)(p.in_w - 1) / (float)(p.resize_w - 1) : 0.f;
-                    bilinear(p, a.C, (float)ys * sy, (float)xs * sx, p.in_h - 1, p.in_w - 1, true, v);
+                    const float sy = resize_scale_align(p.in_h, p.resize_h), sx = resize_scale_align(p.in_w, p.resize_w);
+                    if (p.resize == 2) nearest_align(p, a.C, ys, xs, sy, sx, v);
+                    else if (p.resize == 3) bicubic_align(p, a.C, ys, xs, sy, sx, v);
+                    else bilinear(p, a.C, (float)ys * sy, (float)xs * sx, p.in_h - 1, p.in_w - 1, true, v);
                 } else {
                     for (int c = 0; c < a.C; ++c) v[c] = src_px(p, a.C, ys, xs, c);
                 }

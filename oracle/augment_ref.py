@@ -2,7 +2,8 @@
 
 Follows /root/reference/utils/image_augmentor.py:
   * argument checks ...................... :29-59
-  * zoom / keep-aspect resize + pad ...... :87-129   (bilinear, align_corners=True; boxes scaled by the same ratios)
+  * zoom / keep-aspect resize + pad ...... :87-129   (bilinear / nearest / bicubic per fill_mode :72-76, align_corners=True;
+                                           boxes scaled by the same ratios)
   * crop (only with zoom_size) ........... :131-146
   * flips ................................ :148-172   (box: max' = out - min - 1, min' = out - max - 1)
   * colour jitter ........................ :173-188   (brightness +U(0,.3), contrast U(.8,1.2), hue U(-.1,.1))
@@ -83,7 +84,7 @@ def plan(input_shape, output_shape, zoom_size, crop_method, flip_prob, fill_mode
     zh, zw = (int(zoom_size[0]), int(zoom_size[1])) if zoom_size is not None else (out_h, out_w)
     if fill_mode == 'CONSTANT':
         keep_aspect_ratios = True
-    p = dict(in_h=in_h, in_w=in_w, out_h=out_h, out_w=out_w, zoom_h=zh, zoom_w=zw, resize=fill_mode != 'CONSTANT')
+    p = dict(in_h=in_h, in_w=in_w, out_h=out_h, out_w=out_w, zoom_h=zh, zoom_w=zw, resize=fill_mode != 'CONSTANT', method=fill_mode)
     if keep_aspect_ratios:
         if fill_mode != 'CONSTANT':
             if zh / in_h < zw / in_w:
@@ -141,6 +142,69 @@ def resize_bilinear_align(img, oh, ow):
     top = tl + (tr - tl) * lx
     bot = bl + (br - bl) * lx
     return top + (bot - top) * ly
+
+
+def _resize_scale(n_in, n_out, align_corners=True):
+    """CalculateResizeScale (tensorflow/core/kernels/image_resizer_state.h)"""
+    return np.float32((n_in - 1) / np.float32(n_out - 1)) if (align_corners and n_out > 1) else np.float32(n_in / np.float32(n_out))
+
+
+def resize_nearest_align(img, oh, ow, align_corners=True):
+    """TF 1.13 ResizeNearestNeighbor (resize_nearest_neighbor_op.cc): in = min(roundf(out * scale), in_size - 1) with
+    align_corners (floorf without); image_augmentor.py:72,98-101 / :114-117 call it with align_corners=True."""
+    H, W, _ = img.shape
+
+    def src(n_in, n_out):
+        pos = np.arange(n_out, dtype=np.float32) * _resize_scale(n_in, n_out, align_corners)
+        idx = np.where(pos - np.floor(pos) >= np.float32(0.5), np.floor(pos) + 1, np.floor(pos)) if align_corners else np.floor(pos)
+        return np.minimum(idx.astype(np.int64), n_in - 1)
+    return img[src(H, oh)][:, src(W, ow)]
+
+
+_BICUBIC_TABLE = None
+
+
+def _bicubic_table():
+    """InitCoeffsTable of resize_bicubic_op.cc: 1 025 pairs, [2i] the kernel on |x| <= 1, [2i+1] on 1 <= |x| <= 2, A = -0.75;
+    x is a float, the polynomial is evaluated in double and stored as float"""
+    global _BICUBIC_TABLE
+    if _BICUBIC_TABLE is None:
+        A = -0.75
+        t = np.zeros((1025, 2), np.float32)
+        for i in range(1025):
+            x = float(np.float32(i * 1.0 / 1024))
+            t[i, 0] = ((A + 2) * x - (A + 3)) * x * x + 1
+            x = float(np.float32(x + 1.0))
+            t[i, 1] = ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+        _BICUBIC_TABLE = t
+    return _BICUBIC_TABLE
+
+
+def _bicubic_taps(n_in, n_out, align_corners=True):
+    """GetWeightsAndIndices of resize_bicubic_op.cc for every output position: ([n_out,4] f32 weights, [n_out,4] indices)"""
+    tab = _bicubic_table()
+    scale = _resize_scale(n_in, n_out, align_corners)
+    pos = (np.arange(n_out, dtype=np.float32) * scale).astype(np.float32)        # scale * out_loc, a float product
+    loc = pos.astype(np.int64)                                                   # const int64 in_loc = scale * out_loc
+    delta = (pos - loc.astype(np.float32)).astype(np.float32)
+    off = np.rint((delta * np.float32(1024)).astype(np.float32)).astype(np.int64)   # lrintf: round half to even
+    w = np.stack([tab[off, 1], tab[off, 0], tab[1024 - off, 0], tab[1024 - off, 1]], -1)
+    idx = np.clip(np.stack([loc - 1, loc, loc + 1, loc + 2], -1), 0, n_in - 1)
+    return w, idx
+
+
+def resize_bicubic_align(img, oh, ow, align_corners=True):
+    """TF 1.13 ResizeBicubic: per output row the four source rows are interpolated along x (v0 w0 + v1 w1 + v2 w2 + v3 w3 in
+    float), then the four results along y with the same expression."""
+    H, W, _ = img.shape
+    wy, iy = _bicubic_taps(H, oh, align_corners)
+    wx, ix = _bicubic_taps(W, ow, align_corners)
+    wx_t = torch.from_numpy(wx).view(1, ow, 4, 1)
+    rows = img[:, torch.from_numpy(ix)]                                   # [H, ow, 4, C]
+    horiz = rows[:, :, 0] * wx_t[:, :, 0] + rows[:, :, 1] * wx_t[:, :, 1] + rows[:, :, 2] * wx_t[:, :, 2] + rows[:, :, 3] * wx_t[:, :, 3]
+    wy_t = torch.from_numpy(wy).view(oh, 4, 1, 1)
+    col = horiz[torch.from_numpy(iy)]                                      # [oh, 4, ow, C]
+    return col[:, 0] * wy_t[:, 0] + col[:, 1] * wy_t[:, 1] + col[:, 2] * wy_t[:, 2] + col[:, 3] * wy_t[:, 3]
 
 
 def resize_bilinear_legacy(img, oh, ow):
@@ -205,7 +269,8 @@ def augment_image(image, p, constant_values=0.):
     """the image chain of one image (HWC f32) under plan p."""
     img = image
     if p['resize']:
-        img = resize_bilinear_align(img, p['resize_h'], p['resize_w'])
+        img = {'NEAREST_NEIGHBOR': resize_nearest_align, 'BICUBIC': resize_bicubic_align}.get(p.get('method'), resize_bilinear_align)(
+            img, p['resize_h'], p['resize_w'])
     canvas = torch.full((p['zoom_h'], p['zoom_w'], img.shape[2]), float(constant_values))
     canvas[:img.shape[0], :img.shape[1]] = img[:p['zoom_h'], :p['zoom_w']]
     img = canvas[p['crop_h']:p['crop_h'] + p['out_h'], p['crop_w']:p['crop_w'] + p['out_w']]

@@ -712,12 +712,62 @@ class _ResizeMethod:
 
 
 def _resize_images(images, size, method='bilinear', align_corners=False, preserve_aspect_ratio=False):
-    """tf.image.resize_images on one HWC image; bilinear with align_corners=True is what the reference uses."""
-    assert method == 'bilinear' and not preserve_aspect_ratio
+    """tf.image.resize_images on one HWC image; bilinear with align_corners=True is what the reference's drivers use,
+    'nearest' / 'bicubic' are the other two fill modes of utils/image_augmentor.py:72-76."""
+    assert method in ('bilinear', 'nearest', 'bicubic') and not preserve_aspect_ratio
     h, w = int(size[0]), int(size[1])
+    if method == 'nearest':
+        return _resize_one_nearest(images, h, w, bool(align_corners))
+    if method == 'bicubic':
+        return _resize_one_bicubic(images, h, w, bool(align_corners))
     x = images.permute(2, 0, 1).unsqueeze(0)
     y = F.interpolate(x, size=(h, w), mode='bilinear', align_corners=bool(align_corners))
     return y.squeeze(0).permute(1, 2, 0).contiguous()
+
+
+def _resize_scale(n_in, n_out, align_corners):
+    """CalculateResizeScale (tensorflow/core/kernels/image_resizer_state.h), a float"""
+    return np.float32((n_in - 1) / np.float32(n_out - 1)) if (align_corners and n_out > 1) else np.float32(n_in / np.float32(n_out))
+
+
+def _resize_one_nearest(img, oh, ow, align_corners):
+    """ResizeNearestNeighbor (TF 1.13, no half-pixel centres): source index = round-half-away(dst * scale) with align_corners,
+    floor(dst * scale) without, capped at in - 1.  The result keeps the input's values (and, in TensorFlow, its dtype)."""
+    def src(n_in, n_out):
+        pos = (np.arange(n_out, dtype=np.float32) * _resize_scale(n_in, n_out, align_corners)).astype(np.float32)
+        idx = np.floor(pos + np.float32(0.5)) if align_corners else np.floor(pos)          # positions are >= 0: roundf = floor(x + .5)
+        return torch.from_numpy(np.minimum(idx.astype(np.int64), n_in - 1))
+    return img.index_select(0, src(img.shape[0], oh)).index_select(1, src(img.shape[1], ow)).contiguous()
+
+
+def _bicubic_matrix(n_in, n_out, align_corners):
+    """one axis of ResizeBicubic (TF 1.13) as an [n_out, n_in] matrix: Keys kernel with A = -0.75 evaluated at the 1/1024 grid
+    point nearest to the fractional position (the kernel reads a 1 025-entry table, lrintf = round-half-even), four taps at
+    floor - 1 .. floor + 2 clamped to the picture (weights of clamped taps add up on the border pixel)."""
+    a = -0.75
+    def inner(x):           # |x| <= 1
+        return ((a + 2.) * x - (a + 3.)) * x * x + 1.
+    def outer(x):           # 1 <= |x| <= 2
+        return ((a * x - 5. * a) * x + 8. * a) * x - 4. * a
+    scale = _resize_scale(n_in, n_out, align_corners)
+    m = np.zeros((n_out, n_in), np.float64)
+    for o in range(n_out):
+        pos = np.float32(scale * np.float32(o))
+        base = int(pos)
+        frac = float(np.float32(pos - np.float32(base)))
+        t = float(np.rint(np.float32(frac * 1024.))) / 1024.
+        wts = [np.float32(outer(t + 1.)), np.float32(inner(t)), np.float32(inner(1. - t)), np.float32(outer(2. - t))]   # t = k/1024: exact
+        for k, wt in enumerate(wts):
+            m[o, min(n_in - 1, max(0, base - 1 + k))] += float(wt)
+    return m
+
+
+def _resize_one_bicubic(img, oh, ow, align_corners):
+    """rows of the horizontal pass first, then the vertical one (the kernel's order); done in double, returned as f32"""
+    x = img.detach().double().numpy()
+    my, mx = _bicubic_matrix(x.shape[0], oh, align_corners), _bicubic_matrix(x.shape[1], ow, align_corners)
+    y = np.einsum('oh,hwc->owc', my, np.einsum('pw,hwc->hpc', mx, x))
+    return torch.from_numpy(y.astype(np.float32)).contiguous()
 
 
 def _adjust_contrast(images, contrast_factor):

@@ -4,7 +4,8 @@ eager TF-1.x shim (oracle/tf_shim), with tf.random_uniform scripted (tf_shim.RAN
 reproducible.  Each case is run twice, as the reference allows: with ground truth (returns the boxes) and without
 (returns the augmented image, image_augmentor.py:233).
 
-Run in the build container (needs /root/reference):   python tests/golden/make_golden_augment.py
+Run in the build container (needs /root/reference):   python tests/golden/make_golden_augment.py [all|base|methods]
+('methods' writes tests/golden/augment_zoom_methods.npz: the NEAREST_NEIGHBOR / BICUBIC fill modes, added in round 3)
 tests/test_oracle_golden.py checks oracle/augment_ref.py against the fixture; tests/test_gpu_augment.py the kernels.
 """
 import json
@@ -45,6 +46,30 @@ CASES = [
 ]
 
 
+# the two fill modes no driver script uses (image_augmentor.py:72-76): tf.image.resize_images with NEAREST_NEIGHBOR / BICUBIC,
+# align_corners=True, through the shim's restatement of the TF 1.13 kernels -> tests/golden/augment_zoom_methods.npz
+CASES_METHODS = [
+    ('nearest_zoom_crop_flip', (40, 50), dict(output_shape=[32, 32], zoom_size=[40, 44], crop_method='random', flip_prob=[0.5, 0.5],
+                                              fill_mode='NEAREST_NEIGHBOR', keep_aspect_ratios=False),
+     [4, 6, 0.2, 0.9]),
+    ('nearest_up_keep_aspect', (21, 17), dict(output_shape=[40, 40], zoom_size=[48, 44], crop_method='center', fill_mode='NEAREST_NEIGHBOR',
+                                              keep_aspect_ratios=True, constant_values=9.),
+     []),
+    ('nearest_plain', (37, 50), dict(output_shape=[30, 30], fill_mode='NEAREST_NEIGHBOR'), []),
+    ('bicubic_zoom_crop_flip', (40, 50), dict(output_shape=[32, 32], zoom_size=[40, 44], crop_method='random', flip_prob=[0.5, 0.5],
+                                              fill_mode='BICUBIC', keep_aspect_ratios=False),
+     [3, 5, 0.9, 0.2]),
+    ('bicubic_up_keep_aspect', (21, 17), dict(output_shape=[40, 40], zoom_size=[48, 44], crop_method='random', fill_mode='BICUBIC',
+                                              keep_aspect_ratios=True, constant_values=127.),
+     [5, 1]),
+    ('bicubic_down_colour', (61, 47), dict(output_shape=[28, 24], fill_mode='BICUBIC', color_jitter_prob=1.0),
+     [0.0, 0.0, 0.0, 0.2, 0.9, -0.05]),
+    ('bicubic_channels_first', (20, 26), dict(output_shape=[16, 16], zoom_size=[18, 20], crop_method='random', flip_prob=[0.5, 0.5],
+                                              fill_mode='BICUBIC', data_format='channels_first'),
+     [1, 2, 0.7, 0.1]),
+]
+
+
 def boxes_for(h, w, g, n):
     """n boxes well inside the image so that no centre is lost (the only inputs the reference survives, :217)"""
     yc = (0.35 + 0.3 * torch.rand(n, generator=g)) * h
@@ -55,13 +80,11 @@ def boxes_for(h, w, g, n):
     return torch.stack([yc - bh / 2, yc + bh / 2, xc - bw / 2, xc + bw / 2, cls], -1)
 
 
-def main():
-    tf_shim.install()
-    ref = tf_shim.load_reference_module('/root/reference/utils/image_augmentor.py', 'reference_image_augmentor')
-    g = torch.Generator().manual_seed(77)
+def run_cases(ref, cases, seed, fname):
+    g = torch.Generator().manual_seed(seed)
     out = {}
     meta = []
-    for name, (h, w), kw, draws in CASES:
+    for name, (h, w), kw, draws in cases:
         kw = dict(kw)
         fmt = kw.pop('data_format', 'channels_last')
         img = (torch.rand(h, w, 3, generator=g) * 255).round()
@@ -86,7 +109,17 @@ def main():
         meta.append(dict(name=name, hw=[h, w], data_format=fmt, kwargs=kw, draws=list(draws)))
         print(name, tuple(aug.shape), ret_gt[:3].tolist())
     out['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    np.savez_compressed(os.path.join(OUT, 'augment.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def main():
+    tf_shim.install()
+    ref = tf_shim.load_reference_module('/root/reference/utils/image_augmentor.py', 'reference_image_augmentor')
+    which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if which in ('all', 'base'):
+        run_cases(ref, CASES, 77, 'augment.npz')
+    if which in ('all', 'methods'):
+        run_cases(ref, CASES_METHODS, 78, 'augment_zoom_methods.npz')
     tf_shim.uninstall()
 
 

@@ -2,7 +2,8 @@
   * the golden cases produced by the reference's own image_augmentor with scripted draws (tests/golden/augment.npz);
   * batches of pictures of different sizes / dtypes against oracle/augment_ref.py on the same draws;
   * size-independent properties at the driver scripts' full sizes (flip = mirror bit-exact, rotate keeps boxes on blobs).
-Tolerances: boxes 1e-4 px; pixels 2e-3 on the 0..255 scale (bilinear / colour arithmetic order), 2e-2 for rotated noise."""
+Tolerances: boxes 1e-4 px; pixels 2e-3 on the 0..255 scale (bilinear / bicubic / colour arithmetic order), 2e-2 for rotated noise;
+nearest-neighbour pictures without colour jitter are copies of source pixels and compared exactly."""
 import json
 import os
 
@@ -23,16 +24,17 @@ def _aug():
     return augment
 
 
-def _golden():
-    g = np.load(os.path.join(GOLD, 'augment.npz'))
+def _golden(fname='augment.npz'):
+    g = np.load(os.path.join(GOLD, fname))
     return g, json.loads(bytes(g['meta']).decode())
 
 
+@pytest.mark.parametrize('fname', ['augment.npz', 'augment_zoom_methods.npz'], ids=['driver-modes', 'nearest-bicubic'])
 @pytest.mark.parametrize('u8', [False, True], ids=['f32-src', 'u8-src'])
-def test_golden_cases_vs_reference(u8):
+def test_golden_cases_vs_reference(u8, fname):
     A = _aug()
     dev = torch.device('cuda:0')
-    g, meta = _golden()
+    g, meta = _golden(fname)
     for m in meta:
         n = m['name']
         src = torch.from_numpy(g[f'{n}_image'])
@@ -46,6 +48,8 @@ def test_golden_cases_vs_reference(u8):
         if m['kwargs'].get('rotate') is not None and m['data_format'] == 'channels_first':
             want = want.transpose(2, 0, 1)
         np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-3, err_msg=n)
+        if m['kwargs']['fill_mode'] == 'NEAREST_NEIGHBOR' and m['kwargs'].get('color_jitter_prob') is None:
+            assert np.array_equal(out.cpu().numpy(), want), n      # source pixels (and the pad constant) copied, nothing computed
         only = A.image_augmentor(img, [h, w, 3], m['data_format'], draws=m['draws'], **{k: v for k, v in m['kwargs'].items() if k != 'rotate'}) \
             if m['kwargs'].get('rotate') is None else None
         if only is not None:
@@ -62,6 +66,10 @@ CONFIGS = [
          keep_aspect_ratios=True, constant_values=114., color_jitter_prob=0.7, rotate=[0.6, -5., 5.]),
     dict(output_shape=[48, 48], zoom_size=[56, 60], crop_method='center', fill_mode='BILINEAR'),
     dict(output_shape=[72, 80], fill_mode='CONSTANT', constant_values=3., flip_prob=[0.5, 0.5]),               # pad only
+    dict(output_shape=[64, 96], zoom_size=[80, 120], crop_method='random', flip_prob=[0.5, 0.5], fill_mode='NEAREST_NEIGHBOR',
+         keep_aspect_ratios=True, constant_values=114., color_jitter_prob=0.7),
+    dict(output_shape=[300, 300], zoom_size=[330, 340], crop_method='random', flip_prob=[0.5, 0.5], fill_mode='BICUBIC',
+         keep_aspect_ratios=False, color_jitter_prob=0.5),
 ]
 
 
@@ -177,5 +185,5 @@ def test_argument_errors_match_reference_messages():
         A.image_augmentor(img, [20, 30, 3], 'channels_last', [10, 10], zoom_size=[12, 12], crop_method='corner')
     with pytest.raises(Exception, match="rotate\\[1\\] can't  grater than rotate\\[2\\]"):
         A.image_augmentor(img, [20, 30, 3], 'channels_last', [10, 10], rotate=[.5, 3., -3.])
-    with pytest.raises(NotImplementedError):
-        A.image_augmentor(img, [20, 30, 3], 'channels_last', [10, 10], fill_mode='BICUBIC')
+    with pytest.raises(Exception, match="fill_mode must in"):
+        A.image_augmentor(img, [20, 30, 3], 'channels_last', [10, 10], fill_mode='LANCZOS')

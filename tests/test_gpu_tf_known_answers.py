@@ -59,6 +59,34 @@ def test_augmentor_resize_align_corners(dev):
     assert torch.allclose(out.float().cpu().reshape(5, 4, 3), want, atol=1e-5)
 
 
+def test_augmentor_resize_nearest_align_corners(dev):
+    from odtk import augment as A
+    img = torch.from_numpy(K.RESIZE_ALIGN_IN).repeat(1, 1, 3).to(dev).contiguous()
+    out = A.image_augmentor(img, [3, 2, 3], 'channels_last', output_shape=[5, 4], fill_mode='NEAREST_NEIGHBOR')
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu().reshape(5, 4, 3), torch.from_numpy(K.RESIZE_ALIGN_NEAREST_OUT).repeat(1, 1, 3))
+
+
+def test_augmentor_hue_contrast_rotate_tables(dev):
+    """TensorFlow's AdjustHueTest / AdjustContrastTest / test_rotate_even|odd tables through the augmentor kernels (scripted draws: only
+    the wanted colour op fires; the picture is not resized: output_shape = its size)"""
+    from odtk import augment as A
+    x = torch.from_numpy(K.HUE_IN).to(dev).contiguous()
+    for delta, want in K.HUE_CASES:                 # draws: bcs[3] (only hue < 0.5), hue delta
+        out = A.image_augmentor(x, [2, 2, 3], 'channels_last', output_shape=[2, 2], color_jitter_prob=0.5, draws=[0.9, 0.9, 0.1, delta])
+        torch.cuda.synchronize()
+        assert float((out.cpu() - torch.from_numpy(want)).abs().max()) <= 0.5 + 1e-3       # the table is truncated to integers
+    out = A.image_augmentor(x, [2, 2, 3], 'channels_last', output_shape=[2, 2], color_jitter_prob=0.5, draws=[0.9, 0.1, 0.9, K.CONTRAST_FACTOR])
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu(), torch.from_numpy(K.CONTRAST_OUT), atol=1e-3)
+    for n, want in ((6, K.ROTATE_EVEN_OUT), (5, K.ROTATE_ODD_OUT)):
+        img = torch.arange(n * n, dtype=torch.float32).view(n, n, 1).repeat(1, 1, 3).to(dev).contiguous()
+        out = A.image_augmentor(img, [n, n, 3], 'channels_last', output_shape=[n, n], rotate=[1.0, 90., 90.], draws=[0.0, 90.0])
+        torch.cuda.synchronize()
+        # the reference's pi (3.1415926, image_augmentor.py:236) is 5e-8 short of a quarter turn: source coordinates within 2e-7 px of the integers
+        assert torch.allclose(out.cpu(), torch.from_numpy(want).unsqueeze(-1).repeat(1, 1, 3), atol=1e-3)
+
+
 def test_fused_batch_norm_training_statistics(dev):
     ops = _ops()
     e = K.BN_EXPECT

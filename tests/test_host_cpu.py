@@ -113,9 +113,13 @@ def test_augmentor_plan_matches_oracle_plan():
             dict(output_shape=[64, 96], zoom_size=[80, 120], crop_method='random', flip_prob=[0.5, 0.5], fill_mode='BILINEAR',
                  keep_aspect_ratios=True, constant_values=1., color_jitter_prob=0.7, rotate=[0.6, -5., 5.]),
             dict(output_shape=[48, 48], zoom_size=[56, 60], crop_method='center', fill_mode='BILINEAR'),
-            dict(output_shape=[72, 80], fill_mode='CONSTANT', flip_prob=[0.5, 0.5])]
+            dict(output_shape=[72, 80], fill_mode='CONSTANT', flip_prob=[0.5, 0.5]),
+            dict(output_shape=[64, 96], zoom_size=[80, 120], crop_method='random', fill_mode='NEAREST_NEIGHBOR', keep_aspect_ratios=True,
+                 constant_values=1.),
+            dict(output_shape=[48, 48], zoom_size=[56, 60], crop_method='center', fill_mode='BICUBIC', color_jitter_prob=0.3)]
     for cfg in cfgs:
         aug = A.Augmentor('channels_last', **cfg)
+        assert aug.plan(33, 44, A._Draws([0] * 14))['resize'] == {'CONSTANT': 0, 'BILINEAR': 1, 'NEAREST_NEIGHBOR': 2, 'BICUBIC': 3}[cfg['fill_mode']]
         for _ in range(50):
             h, w = int(rng.integers(20, 600)), int(rng.integers(20, 600))
             draws = [int(rng.integers(0, 8)), int(rng.integers(0, 8))] if cfg.get('zoom_size') and cfg['crop_method'] == 'random' else []
@@ -131,6 +135,41 @@ def test_augmentor_plan_matches_oracle_plan():
             for k in ('brightness', 'contrast', 'hue'):
                 assert (ref[k] is not None) == bool(mine['has_' + k]) and (ref[k] is None or ref[k] == mine[k])
             assert (ref['angle'] is not None) == bool(mine['has_rotate']) and (ref['angle'] is None or ref['angle'] == mine['angle'])
+
+
+def test_augmentor_resize_arithmetic_matches_oracle(tmp_path):
+    """csrc/augment_resize.h (what aug_geometry_kernel executes for NEAREST_NEIGHBOR / BICUBIC: scale, source indices, the four
+    bicubic weights and their clamped taps) compiled for the host with g++ and compared with oracle/augment_ref.py: indices equal,
+    weights bit-equal, for up- and down-scaling, sizes of 1 and the sizes of the driver scripts"""
+    import ctypes as C
+    import os
+    import subprocess
+    import numpy as np
+    from oracle import augment_ref as AR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / 'libaugresize.so')
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', '-I',
+                           os.path.join(root, 'object-detection-tensorflow_amd', 'csrc'), os.path.join(root, 'tests', 'augment_resize_host.cpp'), '-o', so])
+    lib = C.CDLL(so)
+    lib.odtk_test_resize_scale.restype = C.c_float
+    rng = np.random.default_rng(11)
+    sizes = [(3, 5), (2, 4), (6, 8), (375, 300), (500, 300), (333, 416), (37, 1), (1, 9), (300, 300), (97, 512), (1024, 77)]
+    sizes += [(int(rng.integers(1, 700)), int(rng.integers(1, 700))) for _ in range(60)]
+    for n_in, n_out in sizes:
+        if n_out > 1:
+            assert np.float32(lib.odtk_test_resize_scale(n_in, n_out)) == AR._resize_scale(n_in, n_out), (n_in, n_out)
+        idx = np.zeros(n_out, np.int32)
+        lib.odtk_test_nearest_indices(n_in, n_out, idx.ctypes.data_as(C.c_void_p))
+        img = np.arange(n_in, dtype=np.float32).reshape(n_in, 1, 1)
+        import torch
+        want = AR.resize_nearest_align(torch.from_numpy(img), n_out, 1).reshape(-1).numpy().astype(np.int32)
+        assert np.array_equal(idx, want), (n_in, n_out)
+        w = np.zeros((n_out, 4), np.float32)
+        ti = np.zeros((n_out, 4), np.int32)
+        lib.odtk_test_bicubic_taps(n_in, n_out, w.ctypes.data_as(C.c_void_p), ti.ctypes.data_as(C.c_void_p))
+        ww, wi = AR._bicubic_taps(n_in, n_out)
+        assert np.array_equal(ti, wi.astype(np.int32)), (n_in, n_out)
+        assert np.array_equal(w.view(np.uint32), ww.view(np.uint32)), (n_in, n_out, float(np.abs(w - ww).max()))
 
 
 def test_retinanet_layer_specs_and_priors_match_oracle_and_reference_graph():

@@ -208,17 +208,18 @@ def test_full_inference_branches_vs_reference():
     assert np.array_equal(c.numpy(), d['class_id']) and np.array_equal(s.numpy(), d['scores']) and np.array_equal(b.numpy(), d['bbox'])
 
 
-def augment_cases():
+def augment_cases(fname='augment.npz'):
     import json
-    g = np.load(os.path.join(GOLD, 'augment.npz'))
+    g = np.load(os.path.join(GOLD, fname))
     return g, json.loads(bytes(g['meta']).decode())
 
 
-def test_augmentor_vs_reference_image_augmentor():
+@pytest.mark.parametrize('fname', ['augment.npz', 'augment_zoom_methods.npz'])
+def test_augmentor_vs_reference_image_augmentor(fname):
     """oracle/augment_ref.py against the reference's own image_augmentor run with scripted draws: boxes to 1e-4 px,
     images to 2e-3 on the 0..255 scale (the colour and rotate image ops come from the shim's restated TF kernels)"""
     from oracle import augment_ref as A
-    g, meta = augment_cases()
+    g, meta = augment_cases(fname)
     for m in meta:
         n = m['name']
         img = torch.from_numpy(g[f'{n}_image'].astype(np.float32))

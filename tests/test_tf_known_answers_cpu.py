@@ -62,6 +62,60 @@ def test_resize_bilinear_align_corners():
     assert torch.allclose(tf_shim.image.resize_images(x, [5, 4], 'bilinear', align_corners=True), want, atol=1e-6)
 
 
+def test_resize_nearest_align_corners():
+    x, want = torch.from_numpy(K.RESIZE_ALIGN_IN), torch.from_numpy(K.RESIZE_ALIGN_NEAREST_OUT)
+    assert torch.equal(AR.resize_nearest_align(x, 5, 4), want)
+    assert torch.equal(tf_shim.image.resize_images(x, [5, 4], 'nearest', align_corners=True), want)
+
+
+def test_resize_bicubic_table_kernel():
+    """TF's testResizeUpBicubic (align_corners=False): all 64 table values are met to the rounding of the table (0.5), by the oracle's
+    gather form and by the shim's matrix form; the two forms agree to 1e-4 with each other, also with align_corners=True"""
+    x, want = torch.from_numpy(K.RESIZE_BICUBIC_IN), torch.from_numpy(K.RESIZE_BICUBIC_OUT)
+    a = AR.resize_bicubic_align(x, 8, 8, align_corners=False)
+    b = tf_shim.image.resize_images(x, [8, 8], 'bicubic', align_corners=False)
+    assert float((a - want).abs().max()) <= 0.5 and float((b - want).abs().max()) <= 0.5
+    assert float((a - b).abs().max()) <= 1e-4
+    g = torch.Generator().manual_seed(5)
+    img = (torch.rand(37, 50, 3, generator=g) * 255).round()
+    for (oh, ow) in ((44, 61), (20, 33), (37, 50), (1, 7)):
+        d = (AR.resize_bicubic_align(img, oh, ow) - tf_shim.image.resize_images(img, [oh, ow], 'bicubic', align_corners=True)).abs().max()
+        assert float(d) <= 2e-4, (oh, ow, float(d))
+        assert torch.equal(AR.resize_nearest_align(img, oh, ow), tf_shim.image.resize_images(img, [oh, ow], 'nearest', align_corners=True))
+    assert torch.equal(AR.resize_bicubic_align(img, 37, 50), img)            # same size: delta 0 -> weights (0, 1, 0, 0)
+
+
+def _to_u8(y):
+    """convert_image_dtype(float -> uint8, saturate=True): trunc(clip(y) * 255.5), y in 0..1"""
+    return torch.floor(y.clamp(0., 1.) * 255.5).clamp(max=255.)
+
+
+def test_adjust_hue_tables():
+    x = torch.from_numpy(K.HUE_IN)
+    for delta, want in K.HUE_CASES:
+        for fn in (AR.adjust_hue, tf_shim.image.adjust_hue):
+            assert torch.equal(_to_u8(fn(x / 255., delta)), torch.from_numpy(want)), (delta, fn)
+            # scale-free in the value range (the augmentor works on 0..255 pictures): same table within the truncation of the conversion
+            assert float((fn(x, delta) - torch.from_numpy(want)).abs().max()) <= 0.5 + 1e-3
+
+
+def test_adjust_contrast_tables():
+    x, want = torch.from_numpy(K.CONTRAST_IN), torch.from_numpy(K.CONTRAST_OUT)
+    got_shim = tf_shim.image.adjust_contrast(x, K.CONTRAST_FACTOR)
+    mean = x.mean(dim=(0, 1), keepdim=True)                               # oracle/augment_ref.augment_image's expression
+    got_oracle = (x - mean) * K.CONTRAST_FACTOR + mean
+    assert torch.allclose(got_shim, want, atol=1e-4) and torch.allclose(got_oracle, want, atol=1e-4)
+    assert torch.equal(_to_u8(got_oracle / 255.), torch.from_numpy(K.CONTRAST_OUT_U8))
+
+
+def test_rotate_quarter_turn_tables():
+    import math
+    for n, want in ((6, K.ROTATE_EVEN_OUT), (5, K.ROTATE_ODD_OUT)):
+        img = torch.arange(n * n, dtype=torch.float32).view(n, n, 1)
+        assert torch.allclose(AR.rotate_bilinear(img, math.pi / 2)[..., 0], torch.from_numpy(want), atol=1e-4)
+        assert torch.allclose(tf_shim.contrib.image.rotate(img, math.pi / 2, 'BILINEAR')[..., 0], torch.from_numpy(want), atol=1e-4)
+
+
 def test_fused_batch_norm_training_statistics():
     e = K.BN_EXPECT
     x = torch.from_numpy(K.BN_X)                                    # NHWC [2,1,1,1]

@@ -32,6 +32,36 @@ RESIZE_LEGACY_OUT = np.array([64.0, 48.0, 32.0, 32.0, 48.0, 48.0, 48.0, 48.0, 32
 RESIZE_ALIGN_IN = np.array([6, 3, 3, 6, 6, 9], np.float32).reshape(3, 2, 1)
 RESIZE_ALIGN_OUT = np.array([6.0, 5.0, 4.0, 3.0, 4.5, 4.5, 4.5, 4.5, 3.0, 4.0, 5.0, 6.0, 4.5, 5.5, 6.5, 7.5, 6.0, 7.0, 8.0, 9.0], np.float32).reshape(5, 4, 1)
 
+# testResizeUpAlignCornersTrue, expected_data[ResizeMethod.NEAREST_NEIGHBOR] on the same 3 x 2 input: source = round(dst * scale)
+RESIZE_ALIGN_NEAREST_OUT = np.array([6.0, 6.0, 3.0, 3.0, 3.0, 3.0, 6.0, 6.0, 3.0, 3.0, 6.0, 6.0, 6.0, 6.0, 9.0, 9.0, 6.0, 6.0, 9.0, 9.0],
+                                    np.float32).reshape(5, 4, 1)
+# testResizeUpBicubic: 6 x 6 u8 -> 8 x 8, align_corners=False, compared with atol=1 there (the table holds rounded integers)
+RESIZE_BICUBIC_IN = np.array([128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 128, 64, 64, 128, 128,
+                              50, 50, 100, 100, 50, 50, 100, 100, 50, 50, 100, 100, 50, 50, 100, 100, 50, 50, 100, 100], np.float32).reshape(6, 6, 1)
+RESIZE_BICUBIC_OUT = np.array([128, 135, 96, 55, 64, 114, 134, 128, 78, 81, 68, 52, 57, 118, 144, 136, 55, 49, 79, 109, 103, 89, 83, 84,
+                               74, 70, 95, 122, 115, 69, 49, 55, 100, 105, 75, 43, 50, 89, 105, 100, 57, 54, 74, 96, 91, 65, 55, 58,
+                               70, 69, 75, 81, 80, 72, 69, 70, 105, 112, 75, 36, 45, 92, 111, 105], np.float32).reshape(8, 8, 1)
+
+# ---- tensorflow/python/ops/image_ops_test.py, AdjustHueTest / AdjustContrastTest -------------------------------------------------
+# testAdjustNegativeHue / testAdjustPositiveHue: 2 x 2 RGB u8 picture, delta -0.25 / +0.25.  TensorFlow converts u8 -> float (x / 255),
+# shifts the hue, and converts back with convert_image_dtype(saturate=True): trunc(y * 255.5) -- the tables hold those integers.
+HUE_IN = np.array([0, 5, 13, 54, 135, 226, 37, 8, 234, 90, 255, 1], np.float32).reshape(2, 2, 3)
+HUE_CASES = [(-0.25, np.array([0, 13, 1, 54, 226, 59, 8, 234, 150, 255, 39, 1], np.float32).reshape(2, 2, 3)),
+             (0.25, np.array([13, 0, 11, 226, 54, 221, 234, 8, 92, 1, 217, 255], np.float32).reshape(2, 2, 3))]
+# testDoubleContrastFloat: the same picture / 255, contrast_factor 2 about the PER-CHANNEL mean (45.25, 100.75, 118.5)
+CONTRAST_IN = HUE_IN
+CONTRAST_FACTOR = 2.0
+CONTRAST_OUT = np.array([-45.25, -90.75, -92.5, 62.75, 169.25, 333.5, 28.75, -84.75, 349.5, 134.75, 409.25, -116.5], np.float32).reshape(2, 2, 3)
+# testDoubleContrastUint8: the u8 form of the same case (saturating conversion of the table above)
+CONTRAST_OUT_U8 = np.array([0, 0, 0, 62, 169, 255, 28, 0, 255, 135, 255, 0], np.float32).reshape(2, 2, 3)
+
+# ---- tensorflow/contrib/image/python/kernel_tests/image_ops_test.py, test_rotate_even / test_rotate_odd ---------------------------
+# range(36) as 6 x 6 (range(25) as 5 x 5) turned by pi / 2: counter-clockwise about ((w - 1) / 2, (h - 1) / 2); at a quarter turn every
+# source coordinate is an integer, so the BILINEAR mode the augmentor uses returns the same table as the test's NEAREST
+ROTATE_EVEN_OUT = np.array([[5, 11, 17, 23, 29, 35], [4, 10, 16, 22, 28, 34], [3, 9, 15, 21, 27, 33], [2, 8, 14, 20, 26, 32],
+                            [1, 7, 13, 19, 25, 31], [0, 6, 12, 18, 24, 30]], np.float32)
+ROTATE_ODD_OUT = np.array([[4, 9, 14, 19, 24], [3, 8, 13, 18, 23], [2, 7, 12, 17, 22], [1, 6, 11, 16, 21], [0, 5, 10, 15, 20]], np.float32)
+
 # ---- tensorflow/docs_src/api_guides/python/nn.md ("Convolution": the SAME / VALID diagram) ---------------------------------
 # input width 13, filter width 6, stride 5:  VALID keeps 2 windows and drops 12, 13;  SAME pads 1 left and 2 right -> 3 windows:
 #     pad| 0 |1 2 3 4 5 6 7 8 9 10 11 12 13| 0 0 |pad       out = ceil(13 / 5) = 3, total = (3 - 1) * 5 + 6 - 13 = 3, before = 3 // 2

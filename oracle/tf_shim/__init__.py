@@ -36,6 +36,13 @@ class TFTensor(torch.Tensor):
     def get_shape(self):
         return list(self.shape)
 
+    # tf.Tensor arithmetic converts a Python list operand (LH_RCNN.py:146: `pos_proposal / norm_factor`)
+    def __truediv__(self, o):
+        return torch.Tensor.__truediv__(self, _t(o, self.dtype) if isinstance(o, (list, tuple)) else o)
+
+    def __mul__(self, o):
+        return torch.Tensor.__mul__(self, _t(o, self.dtype) if isinstance(o, (list, tuple)) else o)
+
 
 def _t(x, dtype=None):
     if isinstance(x, torch.Tensor):
@@ -267,8 +274,19 @@ def argmin(x, axis=0, output_type=None):
     return r if output_type is None else r.to(output_type)
 
 
+GATHER_OOB_ZERO = False     # tf.gather's documented device difference: the CPU kernel raises on an out-of-range index, the GPU kernel stores 0
+
+
 def gather(params, indices):
     idx = _t(indices).long()
+    if GATHER_OOB_ZERO and idx.numel() and params.dim() >= 1:
+        n = params.shape[0]
+        ok = (idx >= 0) & (idx < n)
+        if not bool(ok.all()):
+            if n == 0:
+                return torch.zeros(tuple(idx.shape) + tuple(params.shape[1:]), dtype=params.dtype)
+            out = params[idx.clamp(0, n - 1)]
+            return torch.where(ok.view(tuple(idx.shape) + (1,) * (params.dim() - 1)), out, torch.zeros_like(out))
     return params[idx]
 
 
@@ -373,6 +391,18 @@ def cond(pred, true_fn, false_fn):
                 pass
             del S.pending[n:]
     return out
+
+
+def case(pred_fn_pairs, default=None, exclusive=False):
+    """tf.case(exclusive=False): the value of the first pair whose predicate holds, else default().  NOTE (LH_RCNN.py:194-201): the
+    reference's branch functions return operations / tensors that were built OUTSIDE the case (`lambda: train_rpn_op`); in a TF-1.x
+    graph such an op is not gated by the predicate -- cond_v1 only adds a control edge from the branch's pivot identity to it -- so every
+    one of them runs on every step whichever branch is selected.  The shim is eager: whatever was built before the case has already
+    registered its updates, which is that behaviour."""
+    for pred, fn in pred_fn_pairs:
+        if bool(pred):
+            return fn()
+    return default()
 
 
 def while_loop(cond_fn, body, loop_vars):
@@ -581,6 +611,41 @@ class _Layers:
             w = get_variable('kernel', initializer=_glorot_uniform((kernel_size, kernel_size, ci, filters), _Layers.gen))
             b = get_variable('bias', shape=[filters], initializer=bias_initializer)
         return _conv_nhwc(inputs, w, strides, dilation_rate) + b
+
+    @staticmethod
+    def separable_conv2d(inputs, filters, kernel_size, strides=1, padding='valid', name=None, data_format='channels_last', use_bias=True,
+                         dilation_rate=1):
+        """tf.layers.separable_conv2d (depth_multiplier 1): depthwise_kernel [kh, kw, in, 1] then pointwise_kernel [1, 1, in, filters],
+        both glorot-uniform, created in that order; SAME padding per axis (kernel_size may be [kh, kw])"""
+        assert padding == 'same' and data_format == 'channels_last' and strides == 1 and dilation_rate == 1
+        kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+        ci, filters = inputs.shape[-1], int(filters)
+        with variable_scope(name, default_name='separable_conv2d'):
+            lim = math.sqrt(6.0 / (kh * kw * ci + kh * kw * 1))
+            dw = get_variable('depthwise_kernel', initializer=(torch.rand((kh, kw, ci, 1), generator=_Layers.gen) * 2 - 1) * lim)
+            pw = get_variable('pointwise_kernel', initializer=_glorot_uniform((1, 1, ci, filters), _Layers.gen))
+            b = get_variable('bias', shape=[filters]) if use_bias else None
+        (pt, pb), (pl, pr) = _same_pad(inputs.shape[1], kh, 1), _same_pad(inputs.shape[2], kw, 1)
+        xc = F.pad(inputs.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+        y = F.conv2d(xc, dw.permute(2, 3, 0, 1), None, groups=ci)                 # [ci, 1, kh, kw]
+        y = F.conv2d(y, pw.permute(3, 2, 0, 1), None)
+        y = y.permute(0, 2, 3, 1)
+        return y + b if b is not None else y
+
+    @staticmethod
+    def dense(inputs, units, name=None, activation=None):
+        """tf.layers.dense: kernel [in, units] (glorot-uniform), bias zeros"""
+        ci, units = inputs.shape[-1], int(units)
+        with variable_scope(name, default_name='dense'):
+            lim = math.sqrt(6.0 / (ci + units))
+            w = get_variable('kernel', initializer=(torch.rand((ci, units), generator=_Layers.gen) * 2 - 1) * lim)
+            b = get_variable('bias', shape=[units])
+        y = inputs @ w + b
+        return activation(y) if activation is not None else y
+
+    @staticmethod
+    def flatten(inputs):
+        return inputs.reshape(inputs.shape[0], -1)
 
     @staticmethod
     def batch_normalization(inputs, axis=3, training=False, momentum=0.99, epsilon=1e-3):
@@ -838,6 +903,42 @@ def _resize_bilinear(images, size, align_corners=False):
     return top * (1 - ly) + bot * ly
 
 
+def _crop_and_resize(image, boxes, box_ind, crop_size, method='bilinear', extrapolation_value=0.):
+    """tf.image.crop_and_resize (crop_and_resize_op.cc, TF 1.13), bilinear: for crop row y of box [y1, x1, y2, x2] (normalised) the source row is
+    y1 (H - 1) + y (y2 - y1)(H - 1) / (crop_h - 1)  (0.5 (y1 + y2)(H - 1) when crop_h == 1); a sample whose row or column falls outside
+    [0, H - 1] x [0, W - 1] is the extrapolation value; otherwise top + (bottom - top) * y_lerp of (tl + (tr - tl) * x_lerp) rows with
+    floor / ceil neighbours.  Differentiable in `image` (autograd)."""
+    assert method == 'bilinear'
+    n, H, W, C = image.shape
+    ch, cw = int(crop_size[0]), int(crop_size[1])
+    boxes = _t(boxes, float32).detach()
+    bi = _t(box_ind).long()
+    R = boxes.shape[0]
+    if R == 0:
+        return image.new_zeros((0, ch, cw, C))
+    y1, x1, y2, x2 = boxes[:, 0:1], boxes[:, 1:2], boxes[:, 2:3], boxes[:, 3:4]
+    gy = torch.arange(ch, dtype=float32).view(1, ch)
+    gx = torch.arange(cw, dtype=float32).view(1, cw)
+    in_y = y1 * (H - 1) + gy * ((y2 - y1) * (H - 1) / (ch - 1)) if ch > 1 else 0.5 * (y1 + y2) * (H - 1) + gy * 0
+    in_x = x1 * (W - 1) + gx * ((x2 - x1) * (W - 1) / (cw - 1)) if cw > 1 else 0.5 * (x1 + x2) * (W - 1) + gx * 0
+    oky = (in_y >= 0) & (in_y <= H - 1)
+    okx = (in_x >= 0) & (in_x <= W - 1)
+    ty = torch.floor(in_y).clamp(0, H - 1).long(); by = torch.ceil(in_y).clamp(0, H - 1).long()
+    lx_ = torch.floor(in_x).clamp(0, W - 1).long(); rx = torch.ceil(in_x).clamp(0, W - 1).long()
+    ly = (in_y - torch.floor(in_y)).view(R, ch, 1, 1)
+    lx = (in_x - torch.floor(in_x)).view(R, 1, cw, 1)
+    b = bi.view(R, 1, 1)
+
+    def px(yy, xx):
+        return image[b, yy.view(R, ch, 1), xx.view(R, 1, cw)]               # [R, ch, cw, C]
+    top = px(ty, lx_) + (px(ty, rx) - px(ty, lx_)) * lx
+    bot = px(by, lx_) + (px(by, rx) - px(by, lx_)) * lx
+    val = top + (bot - top) * ly
+    ok = (oky.view(R, ch, 1) & okx.view(R, 1, cw)).unsqueeze(-1)
+    return torch.where(ok, val, torch.full_like(val, float(extrapolation_value)))
+
+
+_Image.crop_and_resize = staticmethod(_crop_and_resize)
 _Image.resize_bilinear = staticmethod(_resize_bilinear)
 _Image.resize_nearest_neighbor = staticmethod(_resize_nearest_neighbor)
 _Image.adjust_brightness = staticmethod(lambda images, delta: images + delta)
@@ -910,6 +1011,24 @@ class _MomentumOptimizer:
         return ('train_op',)
 
 
+def _opt_compute_gradients(self, loss, var_list=None):
+    """optimizer.compute_gradients(loss, var_list): [(grad, var)]; gradients are taken when the step is flushed (all variables at their
+    pre-update values), here only the request is recorded"""
+    vars_ = list(var_list) if var_list is not None else [S.variables[n] for n in S.trainable]
+    return [(('grad_of', loss, i), v) for i, v in enumerate(vars_)]
+
+
+def _opt_apply_gradients(self, grads_and_vars, global_step=None):
+    S.optimizer_scope = '/'.join(S.scope)
+    loss = grads_and_vars[0][0][1]
+    S.pending.append(('apply', self, loss, [v for _, v in grads_and_vars], global_step))
+    return ('train_op',)
+
+
+_MomentumOptimizer.compute_gradients = _opt_compute_gradients
+_MomentumOptimizer.apply_gradients = _opt_apply_gradients
+
+
 class _AdamOptimizer:
     """tf.train.AdamOptimizer(lr): beta1 0.9, beta2 0.999, epsilon 1e-8; ApplyAdam:
     lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  var -= lr_t m / (sqrt(v) + eps)"""
@@ -980,6 +1099,23 @@ def _flush(apply_):
                     acc = S.momentum.setdefault(n, torch.zeros_like(v))
                     acc.mul_(opt.mom).add_(g)                    # accum = m*accum + grad
                     v.sub_(lr * acc)                              # var -= lr*accum
+                if gstep is not None:
+                    gstep.add_(1)
+    # compute_gradients / apply_gradients pairs (LH_RCNN.py:184-191): every requested gradient first, then every update
+    applies = [item for item in pend if item[0] == 'apply']
+    if applies:
+        byid = {id(v): n for n, v in S.variables.items()}
+        todo = []
+        for _, opt, loss, vars_, gstep in applies:
+            todo.append((opt, vars_, torch.autograd.grad(loss, vars_, allow_unused=True, retain_graph=True), gstep))
+        with torch.no_grad():
+            for opt, vars_, grads, gstep in todo:
+                for v, g in zip(vars_, grads):
+                    if g is None:
+                        g = torch.zeros_like(v)
+                    acc = S.momentum.setdefault(byid[id(v)], torch.zeros_like(v))
+                    acc.mul_(opt.mom).add_(g)
+                    v.sub_(float(opt.lr) * acc)
                 if gstep is not None:
                     gstep.add_(1)
     with torch.no_grad():

@@ -609,3 +609,70 @@ def test_yolov2_two_training_steps_and_detections_match_reference_class():
     assert len(scores) == len(g['det_scores']) > 0 and np.array_equal(cid.numpy(), g['det_class'])
     np.testing.assert_allclose(scores.numpy(), g['det_scores'], atol=1e-5)
     np.testing.assert_allclose(bbox.numpy(), g['det_bbox'], atol=1e-2)
+
+
+def _lhrcnn_batches():
+    from oracle import lhrcnn_ref as LR
+    out = []
+    for s in (901, 900):                                  # tests/golden/make_golden_lhrcnn.py: batches()
+        g = torch.Generator().manual_seed(s)
+        out.append(((torch.rand(2, 320, 416, 3, generator=g) * 255).round(), LR.synthetic_gt(2, 320, 416, s + 10)))
+    return out
+
+
+def test_lhrcnn_train_steps_vs_reference_class():
+    """oracle/lhrcnn_ref.train_step against two training steps of the reference's own LHRCNN class on the shim (GPU gather semantics, both optimizer
+    ops on every step): both losses of both steps, a subsample of every parameter kind and the moving statistics after the first step"""
+    from oracle import lhrcnn_ref as LR
+    g = np.load(os.path.join(GOLD, 'lhrcnn_train.npz'))
+    data = _lhrcnn_batches()
+    p = LR.init_params(71)
+    mom = {k: torch.zeros_like(v) for k, v in p.items()}
+    assert g['global_steps'].tolist() == [0, 1]            # the counter moved on step 1 although the schedule says "RPN only": train_rcnn_op ran
+    for step in range(2):
+        rpn, rcnn = LR.train_step(p, mom, data[step][0], data[step][1], 0.003)
+        tol = 1e-5 if step == 0 else 1e-3                  # the second step starts from parameters that agree to 1e-7: selections may flip on near-ties
+        assert abs(rpn - g['rpn_losses'][step]) <= tol * abs(g['rpn_losses'][step]), (step, rpn, g['rpn_losses'][step])
+        assert abs(rcnn - g['rcnn_losses'][step]) <= tol * abs(g['rcnn_losses'][step]), (step, rcnn, g['rcnn_losses'][step])
+        if step == 0:
+            for key in [k for k in g.files if '__' in k]:
+                name = key.replace('__', '.')
+                flat = p[name].contiguous().reshape(-1)
+                got = flat[::max(1, flat.numel() // 1024)].numpy()
+                np.testing.assert_allclose(got, g[key], rtol=0, atol=2e-6 * max(1.0, float(np.abs(g[key]).max())), err_msg=name)
+
+
+def test_lhrcnn_detections_vs_reference_class():
+    """oracle/lhrcnn_ref.detect against the reference class's test_one_image on the shim: same detections in the same order"""
+    from oracle import lhrcnn_ref as LR
+    g = np.load(os.path.join(GOLD, 'lhrcnn_detect.npz'))
+    p = LR.init_params(71)
+    for k in g.files:
+        if k.startswith('stat__'):
+            p[k[6:].replace('__', '.')] = torch.from_numpy(g[k])
+    img = torch.from_numpy(g['image']).float() / 127.5 - 1.        # the class's feed bypasses its own normalisation (LH_RCNN.py:68-69, :467)
+    s, b, c = LR.detect(p, img, float(g['score_threshold']), 20, 0.45, int(g['post_nms_proposal']))
+    assert np.array_equal(c.numpy(), g['class_id']) and len(s) >= 8
+    np.testing.assert_allclose(s.numpy(), g['scores'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(b.numpy(), g['bbox'], rtol=2e-6, atol=1e-3)
+
+
+def test_lhrcnn_variables_of_the_reference_graph():
+    """names / shapes / trainable flags of the reference graph's variables against oracle/lhrcnn_ref.layer_specs (creation order)"""
+    import json
+    from oracle import lhrcnn_ref as LR
+    V = json.load(open(os.path.join(GOLD, 'lhrcnn_variables.json')))
+    names = json.load(open(os.path.join(GOLD, 'lhrcnn_names.json')))
+    p = LR.init_params(0)
+    assert set(names) == set(p)
+    for k, tfn in names.items():
+        want = list(p[k].shape)
+        if k.endswith('.dw'):
+            want = want + [1]
+        elif k.endswith('.w'):
+            want = [want[1], want[2], want[3], want[0]] if len(want) == 4 else want[::-1]
+        assert V[tfn]['shape'] == want, (k, tfn)
+        assert V[tfn]['trainable'] == (not k.endswith(('.mmean', '.mvar')))
+    assert len(V) == len(names) + 1 and V['global_step']['trainable'] is False
+    assert names['stage3_sconv8.gamma'] == 'feature_extractor/stage3/batch_normalization_7/gamma'
+    assert names['state5_conv2_2.dw'] == 'rcnn/state5_conv2_2/depthwise_kernel' and names['rcnn_pbbox.w'] == 'rcnn/rcnn_pbbox/kernel'

@@ -509,6 +509,64 @@ int odtk_augment_boxes(const odtk_aug_plan* plans, const float* gt_in, const int
 int odtk_augment_images(const odtk_aug_plan* plans, const int* fallback, int N, int C, int zoom_h, int zoom_w, int out_h,
                         int out_w, float constant_value, int out_chw, float* out, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Light-Head R-CNN (last entry): what LH_RCNN.py needs beyond the convolution / batch-norm / pool / NMS entry points above.
+ * csrc/lhrcnn.hip; CPU restatement: oracle/lhrcnn_ref.py (pinned on the reference's own class).
+ * --------------------------------------------------------------------------------------------- */
+/* The depthwise half of tf.layers.separable_conv2d (LH_RCNN.py:551-567; depth multiplier 1, stride 1, SAME, odd kh x kw -- 3x3, 1x15, 15x1):
+ * y[n,h,w,c] (+)= sum_{r,s} x[n, h + r - (kh-1)/2, w + s - (kw-1)/2, c] * filter[r][s][c]; filter is the f32 master [kh][kw][C]; x / y NHWC rows of
+ * pitch ldx / ldy in `dtype`.  flip != 0 mirrors the taps: with dy as x this is the INPUT gradient of the same op.  The pointwise half is a 1x1
+ * odtk_conv2d_*. */
+int odtk_depthwise_conv(const void* x, int ldx, const float* filter, void* y, int ldy, int N, int H, int W, int C, int kh, int kw, int flip,
+                        int accumulate, int dtype, void* stream);
+/* dfilter[r][s][c] += sum_{n,h,w} x[n, h + r - (kh-1)/2, w + s - (kw-1)/2, c] * dy[n,h,w,c]   (float atomics over pixel slices; kh * kw <= 16) */
+int odtk_depthwise_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dfilter, int N, int H, int W, int C, int kh, int kw, int dtype,
+                         void* stream);
+/* LHRCNN._compute_one_image_loss, first half (LH_RCNN.py:263-389), one workgroup per image.  Anchors: the A anchors that lie inside the picture
+ * (:87-97) as [A][2] arrays, anchor_row[A] = their row in the prediction tensors conf [N][A_full][2] / bbox [N][A_full][4].  gt [N][P][5] = yc, xc, h, w,
+ * class, padded with -1 (the number of boxes is the index of the first smallest yc, :265).  Per image: counts[8] = {G, n_pos, n_neg, k_pos = min(n_pos,
+ * 128), k_neg = min(n_neg, 256 - k_pos)}; status[A] (3 best anchor of a box, 1 IoU > 0.5, 2 IoU < 0.3, 0 neither); the POSITIVE list in the reference's
+ * order -- the G best anchors in box order (duplicates kept), then the status-1 anchors in anchor order -- as pos_anchor / pos_gt / pos_label / pos_score
+ * (softmax of the two RPN outputs, column 0) / pos_box (y1,x1,y2,x2 of the anchor) / pos_valid; the NEGATIVE list (status 2, anchor order) with its
+ * cross entropy against label 1 as score.  Label of a best row = label[anchor index] if that index < G else 0: tf.gather with the GPU kernel's
+ * out-of-range rule (:337).  cap >= A + P is the lists' row pitch.  Feed both lists to odtk_nms_batched (IoU 0.7, max_out = counts[3] / counts[4]). */
+int odtk_lhrcnn_match(const float* y1x1, const float* y2x2, const float* yx, const float* hw, const int* anchor_row, int A, int A_full,
+                      const float* conf, const float* gt, int N, int P, int cap, int* counts, unsigned char* status, int* pos_anchor, int* pos_gt,
+                      int* pos_label, float* pos_score, float* pos_box, unsigned char* pos_valid, int* neg_anchor, float* neg_score, float* neg_box,
+                      unsigned char* neg_valid, void* stream);
+/* Second half (:390-440) on the NMS picks sel_pos [N][128] / cnt_pos [N], sel_neg [N][256] / cnt_neg [N] (indices into the lists): loss_parts [N][4] =
+ * {mean CE of the picked negatives, mean CE of the picked positives, 10 * mean smooth-L1 of their box codes, the sum}; d_conf / d_bbox = gradient of
+ * grad_scale * sum_n total_n, fully written.  The R-CNN stage's inputs (:140-152) in fixed slots of 256 rows per image (positives first): roi_prop the
+ * proposal clamped to [0, img_h - 1] x [0, img_w - 1], roi_box the same divided by (img_h - 1, img_w - 1, ..), roi_img (image, -1 = empty row), roi_label
+ * (num_classes - 1 = background for negatives), roi_kind (1 | 2 | 0), roi_truth ((g_yx - p_yx) / p_yx -- sic, :430 -- and log(g_hw / p_hw)),
+ * roi_counts [N][2]. */
+int odtk_lhrcnn_rpn_loss(const float* y1x1, const float* y2x2, const float* yx, const float* hw, const int* anchor_row, int A, int A_full,
+                         const float* conf, const float* bbox, const float* gt, int N, int P, int cap, int num_classes, const int* pos_anchor,
+                         const int* pos_gt, const int* pos_label, const int* neg_anchor, const int* sel_pos, const int* cnt_pos, const int* sel_neg,
+                         const int* cnt_neg, float grad_scale, int img_h, int img_w, float* loss_parts, float* d_conf, float* d_bbox, float* roi_box,
+                         float* roi_prop, float* roi_truth, int* roi_img, int* roi_label, int* roi_kind, int* roi_counts, void* stream);
+/* tf.image.crop_and_resize(feat, boxes, box_ind, [crop, crop]) (bilinear, extrapolation value 0; :146-149, :162) on NHWC rows: out row r =
+ * [crop][crop][C] (pitch ldo, pad columns untouched); box_img[r] < 0 writes a zero row.  _bwd: the image gradient into d_feat (f32 [N*H*W][ldf], zeroed
+ * by the call, float atomics). */
+int odtk_crop_and_resize_fwd(const void* feat, int ldf, int N, int H, int W, int C, const float* boxes, const int* box_img, int R, int crop, void* out,
+                             int ldo, int dtype, void* stream);
+int odtk_crop_and_resize_bwd(const void* d_out, int ldo, int N, int H, int W, int C, const float* boxes, const int* box_img, int R, int crop, float* d_feat,
+                             int ldf, int dtype, void* stream);
+/* :167-170 on the 256-row slots of odtk_lhrcnn_rpn_loss: softmax cross entropy of every filled row (mean over ALL filled rows of the batch) and smooth L1
+ * of the positive rows against roi_truth (mean over all positives); logits [N*256][ldl] (C classes), pbbox [N*256][ldb]; loss_parts [N][2] = this
+ * image's share of the two means (sum over n = the loss); d_logits / d_pbbox fully written (scaled by grad_scale). */
+int odtk_lhrcnn_rcnn_loss(const float* logits, int ldl, const float* pbbox, int ldb, int N, int C, const int* roi_label, const int* roi_kind,
+                          const float* roi_truth, const int* roi_counts, float grad_scale, float* loss_parts, float* d_logits, float* d_pbbox, void* stream);
+/* Test mode (:134-138, :153-164, :203-236) around odtk_nms_batched: proposals (decoded, clamped) and objectness of the kept anchors of image 0;
+ * the picked proposals as crop rows (cap rows, roi_img -1 beyond cnt[0]); softmax / background filter / box decode of the head's outputs with
+ * cand [R][C-1] = foreground row && confidence >= threshold. */
+int odtk_lhrcnn_rpn_decode(const float* yx, const float* hw, const int* anchor_row, int A, int A_full, const float* conf, const float* bbox, int img_h,
+                           int img_w, float* prop, float* score, void* stream);
+int odtk_lhrcnn_gather_rois(const float* prop, const int* sel, const int* cnt, int cap, int img_h, int img_w, float* roi_box, float* roi_prop, int* roi_img,
+                            void* stream);
+int odtk_lhrcnn_rcnn_decode(const float* logits, int ldl, const float* pbbox, int ldb, const float* roi_prop, const int* roi_img, int R, int C,
+                            float score_threshold, float* conf, float* boxes, unsigned char* cand, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ reached through the C-ABI in ``include/odtk.h`` (``libodtk.so``).
 from . import _lib                      # noqa: F401
 from ._lib import BF16, F32, OdtkError  # noqa: F401
 
-__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "SSD512", "RefineDet320", "PFPNetR", "YOLOv2"]
+__all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "SSD512", "RefineDet320", "PFPNetR", "YOLOv2", "LHRCNN"]
 
 
 def __getattr__(name):
@@ -40,4 +40,7 @@ def __getattr__(name):
     if name == "CenterNet":
         from .centernet import CenterNet
         return CenterNet
+    if name == "LHRCNN":
+        from .lhrcnn import LHRCNN
+        return LHRCNN
     raise AttributeError(name)

@@ -134,6 +134,16 @@ SIGNATURES = {
     "odtk_augment_boxes": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "odtk_augment_images": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "odtk_ssd_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "odtk_depthwise_conv": (_i, [_vp, _i, _vp, _vp, _i] + [_i] * 9 + [_vp]),
+    "odtk_depthwise_wgrad": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 7 + [_vp]),
+    "odtk_lhrcnn_match": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i] + [_vp] * 13),
+    "odtk_lhrcnn_rpn_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i] + [_vp] * 8 + [_f, _i, _i] + [_vp] * 11),
+    "odtk_crop_and_resize_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "odtk_crop_and_resize_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "odtk_lhrcnn_rcnn_loss": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "odtk_lhrcnn_rpn_decode": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "odtk_lhrcnn_gather_rois": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "odtk_lhrcnn_rcnn_decode": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

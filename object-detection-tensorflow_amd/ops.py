@@ -580,3 +580,72 @@ def yolov3_decode_candidates(preds, priors_flat, decode_scale):
     call("odtk_yolov3_decode_candidates", _ptr_array(preds), _yolo_shapes(preds), _farr(priors_flat), _farr(decode_scale), P, E - 5,
          _p(conf), _p(bbox), _stream())
     return conf, bbox
+
+
+# ------------------------------------------------------------------ Light-Head R-CNN (csrc/lhrcnn.hip)
+def depthwise_conv(x, ldx, filt, y, ldy, N, H, W, C_, kh, kw, flip=False, accumulate=False):
+    """depthwise half of tf.layers.separable_conv2d (stride 1, SAME); flip: the input gradient; filt: f32 [kh][kw][C]"""
+    call("odtk_depthwise_conv", _p(x), ldx, _p(filt), _p(y), ldy, N, H, W, C_, kh, kw, int(flip), int(accumulate), dt_of(x), _stream())
+
+
+def depthwise_wgrad(x, ldx, dy, lddy, dfilt, N, H, W, C_, kh, kw):
+    call("odtk_depthwise_wgrad", _p(x), ldx, _p(dy), lddy, _p(dfilt), N, H, W, C_, kh, kw, dt_of(x), _stream())
+
+
+def lhrcnn_match(anc, conf, gt, ws):
+    """anc: dict(y1x1, y2x2, yx, hw [A,2] f32, row [A] i32, A_full); conf [N, A_full, 2]; gt [N, P, 5]; ws: lhrcnn_workspace(...)"""
+    N, P = gt.shape[0], gt.shape[1]
+    A = anc['yx'].shape[0]
+    call("odtk_lhrcnn_match", _p(anc['y1x1']), _p(anc['y2x2']), _p(anc['yx']), _p(anc['hw']), _p(anc['row']), A, anc['A_full'], _p(conf), _p(gt), N, P,
+         ws['cap'], _p(ws['counts']), _p(ws['status']), _p(ws['pos_anchor']), _p(ws['pos_gt']), _p(ws['pos_label']), _p(ws['pos_score']), _p(ws['pos_box']),
+         _p(ws['pos_valid']), _p(ws['neg_anchor']), _p(ws['neg_score']), _p(ws['neg_box']), _p(ws['neg_valid']), _stream())
+
+
+def lhrcnn_rpn_loss(anc, conf, bbox, gt, ws, num_classes, grad_scale, img_h, img_w, d_conf, d_bbox):
+    N, P = gt.shape[0], gt.shape[1]
+    A = anc['yx'].shape[0]
+    call("odtk_lhrcnn_rpn_loss", _p(anc['y1x1']), _p(anc['y2x2']), _p(anc['yx']), _p(anc['hw']), _p(anc['row']), A, anc['A_full'], _p(conf), _p(bbox), _p(gt),
+         N, P, ws['cap'], num_classes, _p(ws['pos_anchor']), _p(ws['pos_gt']), _p(ws['pos_label']), _p(ws['neg_anchor']), _p(ws['sel_pos']), _p(ws['cnt_pos']),
+         _p(ws['sel_neg']), _p(ws['cnt_neg']), float(grad_scale), int(img_h), int(img_w), _p(ws['rpn_parts']), _p(d_conf), _p(d_bbox), _p(ws['roi_box']),
+         _p(ws['roi_prop']), _p(ws['roi_truth']), _p(ws['roi_img']), _p(ws['roi_label']), _p(ws['roi_kind']), _p(ws['roi_counts']), _stream())
+
+
+def lhrcnn_workspace(N, A, P, device):
+    """the buffers of one RPN loss evaluation: candidate lists (row pitch cap = A + P), NMS picks, the 256-row R-CNN slots of every image"""
+    cap = A + P
+    i32, f32, u8 = torch.int32, torch.float32, torch.uint8
+    z = lambda *s, dtype=f32: torch.zeros(*s, dtype=dtype, device=device)      # noqa: E731
+    return dict(cap=cap, counts=z(N, 8, dtype=i32), status=z(N, A, dtype=u8),
+                pos_anchor=z(N, cap, dtype=i32), pos_gt=z(N, cap, dtype=i32), pos_label=z(N, cap, dtype=i32), pos_score=z(N, cap), pos_box=z(N, cap, 4),
+                pos_valid=z(N, cap, dtype=u8), neg_anchor=z(N, cap, dtype=i32), neg_score=z(N, cap), neg_box=z(N, cap, 4), neg_valid=z(N, cap, dtype=u8),
+                sel_pos=z(N, 128, dtype=i32), cnt_pos=z(N, dtype=i32), sel_neg=z(N, 256, dtype=i32), cnt_neg=z(N, dtype=i32), rpn_parts=z(N, 4),
+                roi_box=z(N * 256, 4), roi_prop=z(N * 256, 4), roi_truth=z(N * 256, 4), roi_img=z(N * 256, dtype=i32), roi_label=z(N * 256, dtype=i32),
+                roi_kind=z(N * 256, dtype=i32), roi_counts=z(N, 2, dtype=i32), rcnn_parts=z(N, 2))
+
+
+def crop_and_resize_fwd(feat, ldf, N, H, W, C_, boxes, box_img, crop, out, ldo):
+    call("odtk_crop_and_resize_fwd", _p(feat), ldf, N, H, W, C_, _p(boxes), _p(box_img), boxes.shape[0], crop, _p(out), ldo, dt_of(feat), _stream())
+
+
+def crop_and_resize_bwd(d_out, ldo, N, H, W, C_, boxes, box_img, crop, d_feat, ldf):
+    """d_feat: f32 [N*H*W, ldf], zeroed by the call"""
+    call("odtk_crop_and_resize_bwd", _p(d_out), ldo, N, H, W, C_, _p(boxes), _p(box_img), boxes.shape[0], crop, _p(d_feat), ldf, dt_of(d_out), _stream())
+
+
+def lhrcnn_rcnn_loss(logits, ldl, pbbox, ldb, N, Cn, ws, grad_scale, d_logits, d_pbbox):
+    call("odtk_lhrcnn_rcnn_loss", _p(logits), ldl, _p(pbbox), ldb, N, Cn, _p(ws['roi_label']), _p(ws['roi_kind']), _p(ws['roi_truth']), _p(ws['roi_counts']),
+         float(grad_scale), _p(ws['rcnn_parts']), _p(d_logits), _p(d_pbbox), _stream())
+
+
+def lhrcnn_rpn_decode(anc, conf0, bbox0, img_h, img_w, prop, score):
+    call("odtk_lhrcnn_rpn_decode", _p(anc['yx']), _p(anc['hw']), _p(anc['row']), anc['yx'].shape[0], anc['A_full'], _p(conf0), _p(bbox0), int(img_h), int(img_w),
+         _p(prop), _p(score), _stream())
+
+
+def lhrcnn_gather_rois(prop, sel, cnt, img_h, img_w, roi_box, roi_prop, roi_img):
+    call("odtk_lhrcnn_gather_rois", _p(prop), _p(sel), _p(cnt), roi_img.shape[0], int(img_h), int(img_w), _p(roi_box), _p(roi_prop), _p(roi_img), _stream())
+
+
+def lhrcnn_rcnn_decode(logits, ldl, pbbox, ldb, roi_prop, roi_img, Cn, thr, conf, boxes, cand):
+    call("odtk_lhrcnn_rcnn_decode", _p(logits), ldl, _p(pbbox), ldb, _p(roi_prop), _p(roi_img), roi_img.shape[0], Cn, float(thr), _p(conf), _p(boxes), _p(cand),
+         _stream())

@@ -138,6 +138,9 @@ class RefineDet320(F32Warmup):
         kout, kin = (cout, cin) if kind != 'dconv' else (cin, cout)
         return (kout, k, k, ops.pad_to(kin, self.chunk)), kin
 
+    def _extra_layer_params(self, spec):
+        return ()
+
     def _init_parameters(self, seed):
         pinfo, sinfo = OrderedDict(), OrderedDict()
         off = soff = 0
@@ -151,6 +154,8 @@ class RefineDet320(F32Warmup):
             name, kind, cout = spec[0], spec[1], spec[3]
             wshape, kin = self._wshape(spec)
             self._kin[name], self._kind[name] = kin, kind
+            for extra, shape in self._extra_layer_params(spec):       # e.g. the depthwise filter of a separable layer (lhrcnn.LHRCNN), created first
+                add(extra, shape)
             add(name + '.w', wshape); add(name + '.b', (cout,))
             if kind != 'vgg':
                 add(name + '.gamma', (cout,)); add(name + '.beta', (cout,))
@@ -342,8 +347,18 @@ class RefineDet320(F32Warmup):
             assert all(a.M == y.M for a in srcs)
             self.plan.append(('concat', tuple(srcs), y))
             return y
+        def dw(name, src, kh, kw, stop_grad=False):
+            """the depthwise half of tf.layers.separable_conv2d (filter `name`.dw [kh][kw][C], stride 1, SAME); the pointwise half is the 1x1 `bn` that follows.
+            stop_grad: the input gradient is not formed (a consumer whose loss does not train the producer, LH_RCNN.py:190-191)"""
+            mid = act(name + '.dw', src.H, src.W, src.C)
+            self.plan.append(('dw', name, src, mid, kh, kw, stop_grad))
+            return mid
+
+        def sink(a):
+            """`a` is read by a stage outside the plan, which writes a.g before the backward plan runs"""
+            self.plan.append(('sink', a))
         from types import SimpleNamespace
-        self._build_model(SimpleNamespace(vgg=vgg, bn=bn, pool=pool, l2norm=l2norm, resize=resize, avgpool=avgpool, add=add, concat=concat, act=act))
+        self._build_model(SimpleNamespace(vgg=vgg, bn=bn, pool=pool, l2norm=l2norm, resize=resize, avgpool=avgpool, add=add, concat=concat, act=act, dw=dw, sink=sink))
         self.ws = torch.zeros(self._max_ws, dtype=torch.uint8, device=dev)
         self.wt, entries = {}, []
         for sp in self.specs:
@@ -461,6 +476,12 @@ class RefineDet320(F32Warmup):
                 _, srcs, y = op
                 assert id(y) in written
                 self.bplan.append(('concat', tuple((a, emit(a)) for a in srcs), y))
+            elif kind == 'dw':
+                _, name, src, mid, kh, kw, stop = op
+                assert id(mid) in written, name
+                self.bplan.append(('dw', name, src, mid, kh, kw, stop, False if stop else emit(src)))
+            elif kind == 'sink':
+                emit(op[1])
             else:
                 _, a, b, y = op
                 assert id(y) in written
@@ -468,11 +489,19 @@ class RefineDet320(F32Warmup):
         self.gt = None
 
     # ------------------------------------------------------------------ forward / loss / backward
-    def _forward(self, training, subtract_mean=True):
+    def _preprocess_input(self, subtract_mean):
         ops.preprocess(self.images, MEAN_RGB if subtract_mean else (0., 0., 0.), self.input.ld, self.DT, self.input.t)
+
+    def _forward(self, training, subtract_mean=True):
+        self._preprocess_input(subtract_mean)
         for op in self.plan:
             kind = op[0]
-            if kind == 'vgg':
+            if kind == 'sink':
+                continue
+            if kind == 'dw':
+                _, name, src, mid, kh, kw, _ = op
+                ops.depthwise_conv(src.t, src.ld, self.param(name + '.dw'), mid.t, mid.ld, src.N, src.H, src.W, src.C, kh, kw)
+            elif kind == 'vgg':
                 _, name, src, y = op
                 ops.conv2d_fwd(self.desc[name], src.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), y.t, True)
             elif kind == 'bn':
@@ -576,6 +605,12 @@ class RefineDet320(F32Warmup):
                 for a, acc in srcs:
                     ops.copy_channels(y.g, y.ld, off, a.g, a.ld, 0, y.M, a.C, acc, a.t if a.vgg else None)
                     off += a.C
+            elif kind == 'dw':
+                _, name, src, mid, kh, kw, stop, acc = op
+                ops.depthwise_wgrad(src.t, src.ld, mid.g, mid.ld, self._flat(name + '.dw', self.G), src.N, src.H, src.W, src.C, kh, kw)
+                if not stop:
+                    ops.depthwise_conv(mid.g, mid.ld, self.param(name + '.dw'), src.g, src.ld, src.N, src.H, src.W, src.C, kh, kw, True, acc)
+                yield name + '.dw'
             else:
                 _, (a, acc_a), (b, acc_b), y = op
                 ops.relu_bwd(y.t, y.g, y.ld, a.g, a.ld, y.M, y.ld, acc_a)

@@ -676,3 +676,126 @@ def yolov2_decode_candidates(pred0, priors_flat, stride):
     from oracle import yolov2_ref as YR
     P = pred0.shape[2]
     return YR.decode(pred0, [[priors_flat[2 * k], priors_flat[2 * k + 1]] for k in range(P)])
+
+
+# ---- Light-Head R-CNN (csrc/lhrcnn.hip): pixel kernels in plain torch, the RPN loss by the oracle (the mocked match / NMS in front of it do nothing)
+def depthwise_conv(x, ldx, filt, y, ldy, N, H, W, C_, kh, kw, flip=False, accumulate=False):
+    w = filt.float().reshape(kh, kw, C_)
+    if flip:
+        w = w.flip(0, 1)
+    xin = x[:, :C_].float().reshape(N, H, W, C_).permute(0, 3, 1, 2)
+    out = F.conv2d(F.pad(xin, ((kw - 1) // 2, kw // 2, (kh - 1) // 2, kh // 2)), w.permute(2, 0, 1).unsqueeze(1), None, groups=C_)
+    out = out.permute(0, 2, 3, 1).reshape(-1, C_)
+    y[:, :C_] = ((y[:, :C_].float() + out) if accumulate else out).to(y.dtype)
+
+
+def depthwise_wgrad(x, ldx, dy, lddy, dfilt, N, H, W, C_, kh, kw):
+    w = torch.zeros(C_, 1, kh, kw, requires_grad=True)
+    xin = x[:, :C_].float().reshape(N, H, W, C_).permute(0, 3, 1, 2)
+    out = F.conv2d(F.pad(xin, ((kw - 1) // 2, kw // 2, (kh - 1) // 2, kh // 2)), w, None, groups=C_)
+    g, = torch.autograd.grad(out, w, dy[:, :C_].float().reshape(N, H, W, C_).permute(0, 3, 1, 2))
+    dfilt.view(-1)[: kh * kw * C_] += g.squeeze(1).permute(1, 2, 0).reshape(-1)
+
+
+def lhrcnn_match(anc, conf, gt, ws):
+    return None
+
+
+def lhrcnn_rpn_loss(anc, conf, bbox, gt, ws, num_classes, grad_scale, img_h, img_w, d_conf, d_bbox):
+    """matching, both NMS, the loss, its gradients and the R-CNN slots by the oracle's rpn_one_image"""
+    from oracle import lhrcnn_ref as LR
+    N = gt.shape[0]
+    row = anc['row'].long()
+    a = dict(y1x1=anc['y1x1'], y2x2=anc['y2x2'], yx=anc['yx'], hw=anc['hw'])
+    cf = conf.detach().clone().requires_grad_(True)
+    bb = bbox.detach().clone().requires_grad_(True)
+    tot = 0.
+    lim = torch.tensor([img_h - 1., img_w - 1., img_h - 1., img_w - 1.])
+    for k in ('roi_box', 'roi_prop', 'roi_truth'):
+        ws[k].zero_()
+    ws['roi_img'].fill_(-1); ws['roi_label'].fill_(-1); ws['roi_kind'].zero_()
+    for i in range(N):
+        loss, pos_prop, pos_lab, truth, neg_prop = LR.rpn_one_image(bb[i, row, :2], bb[i, row, 2:], cf[i, row], a, gt[i])
+        tot = tot + loss
+        ws['rpn_parts'][i, 3] = loss.detach()
+        kp, kn = pos_prop.shape[0], neg_prop.shape[0]
+        s = i * 256
+        prop = torch.cat([pos_prop, neg_prop]).detach()
+        prop = torch.minimum(torch.clamp(prop, min=0.), lim)
+        ws['roi_prop'][s: s + kp + kn] = prop
+        ws['roi_box'][s: s + kp + kn] = prop / lim
+        ws['roi_truth'][s: s + kp] = truth.detach()
+        ws['roi_img'][s: s + kp + kn] = i
+        ws['roi_label'][s: s + kp] = pos_lab.to(torch.int32)
+        ws['roi_label'][s + kp: s + kp + kn] = num_classes - 1
+        ws['roi_kind'][s: s + kp] = 1
+        ws['roi_kind'][s + kp: s + kp + kn] = 2
+        ws['roi_counts'][i, 0], ws['roi_counts'][i, 1] = kp, kn
+    g1, g2 = torch.autograd.grad(tot * grad_scale, [cf, bb])
+    d_conf.copy_(g1); d_bbox.copy_(g2)
+
+
+def crop_and_resize_fwd(feat, ldf, N, H, W, C_, boxes, box_img, crop, out, ldo):
+    from oracle import lhrcnn_ref as LR
+    f = feat[:, :C_].float().reshape(N, H, W, C_)
+    live = box_img >= 0
+    v = LR.crop_and_resize(f, boxes, box_img.clamp(min=0), crop).reshape(boxes.shape[0], -1)
+    out[:, : crop * crop * C_] = (v * live.view(-1, 1)).to(out.dtype)
+
+
+def crop_and_resize_bwd(d_out, ldo, N, H, W, C_, boxes, box_img, crop, d_feat, ldf):
+    from oracle import lhrcnn_ref as LR
+    f = torch.zeros(N, H, W, C_, requires_grad=True)
+    live = box_img >= 0
+    v = LR.crop_and_resize(f, boxes, box_img.clamp(min=0), crop).reshape(boxes.shape[0], -1)
+    g, = torch.autograd.grad(v, f, d_out[:, : crop * crop * C_].float() * live.view(-1, 1))
+    d_feat.zero_()
+    d_feat[:, :C_] = g.reshape(-1, C_)
+
+
+def lhrcnn_rcnn_loss(logits, ldl, pbbox, ldb, N, Cn, ws, grad_scale, d_logits, d_pbbox):
+    kind, label = ws['roi_kind'], ws['roi_label'].long()
+    z = logits[:, :Cn].detach().float().clone().requires_grad_(True)
+    b = pbbox[:, :4].detach().float().clone().requires_grad_(True)
+    live, pos = kind != 0, kind == 1
+    lse = torch.logsumexp(z, dim=1)
+    ce = (lse - z.gather(1, label.clamp(min=0).view(-1, 1)).squeeze(1)) * live
+    d = b - ws['roi_truth']
+    sl1 = torch.where(d.abs() < 1., 0.5 * d * d, d.abs() - 0.5).sum(-1) * pos
+    rows, npos = int(live.sum()), int(pos.sum())
+    per_ce, per_box = ce.view(N, 256).sum(1) / rows, sl1.view(N, 256).sum(1) / npos
+    ws['rcnn_parts'][:, 0], ws['rcnn_parts'][:, 1] = per_ce.detach(), per_box.detach()
+    g1, g2 = torch.autograd.grad((per_ce.sum() + per_box.sum()) * grad_scale, [z, b])
+    d_logits.zero_(); d_pbbox.zero_()
+    d_logits[:, :Cn] = g1.to(d_logits.dtype); d_pbbox[:, :4] = g2.to(d_pbbox.dtype)
+
+
+def lhrcnn_rpn_decode(anc, conf0, bbox0, img_h, img_w, prop, score):
+    row = anc['row'].long()
+    p = bbox0[row]
+    yx = p[:, :2] * anc['hw'] + anc['yx']
+    hw = torch.exp(p[:, 2:]) * anc['hw']
+    lim = torch.tensor([img_h - 1., img_w - 1., img_h - 1., img_w - 1.])
+    prop.copy_(torch.minimum(torch.clamp(torch.cat([yx - hw / 2., yx + hw / 2.], -1), min=0.), lim))
+    score.copy_(torch.softmax(conf0[row], -1)[:, 0])
+
+
+def lhrcnn_gather_rois(prop, sel, cnt, img_h, img_w, roi_box, roi_prop, roi_img):
+    k = min(int(cnt[0]), roi_img.shape[0])
+    lim = torch.tensor([img_h - 1., img_w - 1., img_h - 1., img_w - 1.])
+    roi_prop.zero_(); roi_box.zero_(); roi_img.fill_(-1)
+    roi_prop[:k] = prop[sel.view(-1)[:k].long()]
+    roi_box[:k] = roi_prop[:k] / lim
+    roi_img[:k] = 0
+
+
+def lhrcnn_rcnn_decode(logits, ldl, pbbox, ldb, roi_prop, roi_img, Cn, thr, conf, boxes, cand):
+    live = roi_img >= 0
+    cf = torch.softmax(logits[:, :Cn].float(), -1)
+    fg = (cf.argmax(-1) < Cn - 1) & live
+    conf.copy_(cf[:, : Cn - 1] * live.view(-1, 1))
+    cand.copy_(((cf[:, : Cn - 1] >= thr) & fg.view(-1, 1)).to(cand.dtype))
+    p_yx, p_hw = roi_prop[:, 0:2] / 2. + roi_prop[:, 2:4] / 2., roi_prop[:, 2:4] - roi_prop[:, 0:2]
+    t = pbbox[:, :4].float()
+    yx, hw = t[:, :2] * p_hw + p_yx, p_hw * torch.exp(t[:, 2:])
+    boxes.copy_(torch.cat([yx - hw / 2., yx + hw / 2.], -1) * live.view(-1, 1))

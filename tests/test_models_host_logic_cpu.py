@@ -508,3 +508,74 @@ def test_ssd300_recorded_launch_list_replays_the_step_on_cpu():
             assert float(a.train_step(0.01)) == float(b.train_step(0.01))
             assert (b._cmds is not None) == (i >= 2)
         assert torch.equal(a.P, b.P) and len(b._cmds) > 100
+
+
+def _lhrcnn_cfg(mode, batch, **kw):
+    cfg = {'data_shape': [320, 416, 3], 'mode': mode, 'is_pretraining': False, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
+           'keep_prob': 0.5, 'batch_size': batch, 'rpn_first_step': 60000, 'rcnn_first_step': 100000, 'rpn_second_step': 160000, 'nms_score_threshold': 0.5,
+           'nms_max_boxes': 20, 'nms_iou_threshold': 0.45, 'post_nms_proposal': 500, 'verbose': False, 'device': 'cpu'}
+    cfg.update(kw)
+    return cfg
+
+
+def test_lhrcnn_training_step_host_logic():
+    """LHRCNN: conv / separable (depthwise plan entry + 1x1 layer) / pool chain, the RPN heads writing the f32 prediction tensors, the light head that reads c4
+    without sending a gradient back, the R-CNN stage outside the plan (crop rows in 256-row slots, three dense layers as 1x1 convolutions, their backward), BOTH
+    momentum updates -- two training steps on the CPU mock against oracle/lhrcnn_ref.train_step (pinned on the reference's own class, tests/golden/lhrcnn_train.npz);
+    the reference's variable names; which loss the schedule reports"""
+    import json
+    import odtk
+    from oracle import lhrcnn_ref as LR
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(901)
+    imgs = (torch.rand(2, 320, 416, 3, generator=g) * 255).round()
+    gt = LR.synthetic_gt(2, 320, 416, 911)
+    p = LR.init_params(71)
+    names = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'lhrcnn_names.json')))
+    with mock_ops.installed():
+        m = odtk.LHRCNN(_lhrcnn_cfg('train', 2, rpn_first_step=1), {'data_shape': [320, 416, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)],
+                                                                     'val_generator': None})
+        assert m.reference_variable_map() == names
+        assert [(s[0], s[1], s[2], s[3], s[4], s[5]) for s in m.table] == [s[:6] for s in LR.layer_specs()]
+        anc = LR.anchors(10, 13, 320, 416)
+        assert torch.equal(m.anc['yx'], anc['yx']) and torch.equal(m.anc['hw'], anc['hw']) and torch.equal(m.anc['row'].long(), torch.nonzero(anc['keep']).flatten())
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        q = {k: v.clone() for k, v in p.items()}
+        mom = {k: torch.zeros_like(v) for k, v in p.items()}
+        for step in range(2):
+            loss = float(m.train_step(0.003))
+            rpn, rcnn = LR.train_step(q, mom, imgs, gt, 0.003)
+            got_rpn, got_rcnn = float(m.last_losses[0]), float(m.last_losses[1])
+            tol = 1e-4 if step == 0 else 2e-3
+            assert abs(got_rpn - rpn) < tol * abs(rpn) and abs(got_rcnn - rcnn) < tol * abs(rcnn), (step, got_rpn, rpn, got_rcnn, rcnn)
+            assert loss == (got_rpn if step == 0 else got_rcnn)                  # rpn_first_step = 1: step 0 reports rpn_loss, step 1 rcnn_loss
+            if step == 0:
+                after = m.export_params()
+                assert set(after) == set(q)
+                worst = max(((k, _rel(after[k], q[k])) for k in q if not (k.endswith('.b') and float(q[k].abs().max()) == 0.)), key=lambda t: t[1])
+                print('worst relative parameter error after one step', worst)
+                for k in q:
+                    assert _rel(after[k], q[k]) < 2e-3 or float((after[k] - q[k]).abs().max()) < 2e-6, (k, _rel(after[k], q[k]))
+        assert m.global_step == 2
+
+
+def test_lhrcnn_inference_host_logic():
+    """LHRCNN.test_one_image on the CPU mock against the detections of the reference's own class (tests/golden/lhrcnn_detect.npz): the feed quirk (normalised
+    pictures go in as they are), proposal NMS, crop rows, dense head, per-class NMS"""
+    import numpy as np
+    import odtk
+    from oracle import lhrcnn_ref as LR
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'lhrcnn_detect.npz'))
+    p = LR.init_params(71)
+    for k in g.files:
+        if k.startswith('stat__'):
+            p[k[6:].replace('__', '.')] = torch.from_numpy(g[k])
+    with mock_ops.installed():
+        m = odtk.LHRCNN(_lhrcnn_cfg('test', 1, nms_score_threshold=float(g['score_threshold']), post_nms_proposal=int(g['post_nms_proposal'])), None)
+        m.load_oracle_params(p)
+        img = torch.from_numpy(g['image']).float() / 127.5 - 1.
+        scores, bbox, cid = m.test_one_image(img.numpy())
+    assert np.array_equal(cid, g['class_id'])
+    np.testing.assert_allclose(scores, g['scores'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(bbox, g['bbox'], rtol=1e-5, atol=2e-3)

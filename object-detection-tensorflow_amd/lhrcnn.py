@@ -392,8 +392,37 @@ class LHRCNN(RefineDet320):
             return np.ascontiguousarray(v.reshape(v.shape[0], v.shape[3]).t().numpy())   # [in, units]
         return np.ascontiguousarray((v.permute(1, 2, 3, 0) if name.endswith('.w') else v).numpy())
 
+    @staticmethod
+    def _from_tf(ours, arr):
+        v = torch.from_numpy(np.asarray(arr))
+        if ours.endswith('.dw'):
+            return v.squeeze(-1)                                                      # [kh, kw, C, 1]
+        if ours.endswith('.w'):
+            return v.permute(3, 0, 1, 2).contiguous() if v.dim() == 4 else v.t().contiguous().reshape(v.shape[1], 1, 1, v.shape[0])
+        return v
+
     def load_tf_checkpoint(self, path):
-        raise NotImplementedError("LHRCNN: reading tf.train.Saver files is wired for the other classes only (torch checkpoints: load_weight)")
+        """`saver.restore(sess, path)` from the files of a reference-trained model (or ours): weights, moving statistics, Momentum slots, global_step"""
+        from .tf_checkpoint import NewCheckpointReader
+        reader = NewCheckpointReader(str(path))
+        names = reader.get_variable_to_shape_map()
+        for ours, tfname in self.reference_variable_map().items():
+            if ours in self.pinfo:
+                self.set_param(ours, self._from_tf(ours, reader.get_tensor(tfname)))      # KeyError = Saver's NotFoundError
+                slot = [k for k in names if k.endswith(tfname + '/Momentum')]
+                if slot:
+                    mv = self._from_tf(ours, reader.get_tensor(slot[0]))
+                    dst = self.param(ours, self.Mom)
+                    if ours.endswith('.w'):
+                        dst.zero_()
+                        dst[..., : mv.shape[-1]] = mv.to(self.dev)
+                    else:
+                        dst.copy_(mv.to(self.dev).view(dst.shape))
+            else:
+                self.stat(ours).copy_(torch.from_numpy(reader.get_tensor(tfname)).to(self.dev))
+        if reader.has_tensor('global_step'):
+            self.global_step = int(reader.get_tensor('global_step'))
+        self._refresh_operand_copies()
 
     def load_pretraining_weight(self, path):
         """`self.pretraining_weight_saver.restore` (LH_RCNN.py:448-449, :511-513): the trainables of scope 'feature_extractor' from a tf.train.Saver checkpoint"""

@@ -23,6 +23,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 CLASSES = {
     'CenterNet': ('CenterNet.py', 'make_golden_centernet_net'),
     'FCOS': ('FCOS.py', 'make_golden_fcos_net'),
+    'LHRCNN': ('LH_RCNN.py', 'make_golden_lhrcnn'),
     'PFPNetR': ('PFPNetR.py', 'make_golden_pfpnet'),
     'RefineDet320': ('RefineDet.py', 'make_golden_refinedet_net'),
     'RetinaNet': ('RetinaNet.py', 'make_golden_retinanet_net'),
@@ -43,6 +44,7 @@ def build(cls, ref_file, gen):
     if cls == 'CenterNet':
         tf_shim.TRACE_DEAD_COND_BRANCHES = True
         sys.modules['tensorflow'].cond = tf_shim.cond
+    tf_shim.GATHER_OOB_ZERO = cls == 'LHRCNN'          # LH_RCNN.py:337 only executes with tf.gather's GPU behaviour (oracle/lhrcnn_ref.py header)
     ref = tf_shim.load_reference_module('/root/reference/' + ref_file, 'reference_scope_' + cls)
     mod = importlib.import_module(gen)
     data = mod.batches()
@@ -56,11 +58,21 @@ def build(cls, ref_file, gen):
         prov['data_shape'] = mod.CONFIG['data_shape']
     getattr(ref, cls)(dict(mod.CONFIG), prov)
     tf_shim.TRACE_DEAD_COND_BRANCHES = False
+    tf_shim.GATHER_OOB_ZERO = False
     return tf_shim.S.optimizer_scope
 
 
 def main():
     out = {}
+    only = sys.argv[1:]                       # `make_golden_optimizer_scopes.py LHRCNN`: rebuild these classes only, keep the other entries of the file
+    if only:
+        out = json.load(open(os.path.join(OUT, 'optimizer_scopes.json')))
+        for cls in only:
+            out[cls] = build(cls, *CLASSES[cls])
+            print(cls, repr(out[cls]))
+        with open(os.path.join(OUT, 'optimizer_scopes.json'), 'w') as f:
+            json.dump(out, f, indent=0, sort_keys=True)
+        return
     for cls, (ref_file, gen) in CLASSES.items():
         out[cls] = build(cls, ref_file, gen)
         print(cls, repr(out[cls]))

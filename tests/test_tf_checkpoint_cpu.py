@@ -482,3 +482,51 @@ def test_optimizer_slot_scopes_follow_the_reference(cls, tmp_path):
         m2.load_weight(path + '-5')
         out2 = m2.export_tf_variables()               # the optimizer state came back from the scoped names
         assert all(np.array_equal(out[k], out2[k]) for k in slots)
+
+
+def test_lhrcnn_reference_names_and_saver_round_trip(tmp_path):
+    """LHRCNN: the rule-derived names equal those of the graph the reference builds on the shim (tests/golden/lhrcnn_names.json, checked in
+    test_models_host_logic_cpu); a `checkpoint_format='tf'` save writes every variable of that graph with its shape (depthwise kernels [kh, kw, C, 1], dense
+    kernels [in, units]), the Momentum slots under 'rcnn/' (the scope open where the reference builds its optimizer, LH_RCNN.py:98, :171) and global_step; a
+    second model restores all of it bit for bit"""
+    import json
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import mock_ops
+    import odtk
+    from odtk.tf_checkpoint import NewCheckpointReader
+    cfg = {'data_shape': [320, 416, 3], 'mode': 'train', 'is_pretraining': False, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
+           'keep_prob': 0.5, 'batch_size': 1, 'rpn_first_step': 60000, 'rcnn_first_step': 100000, 'rpn_second_step': 160000, 'nms_score_threshold': 0.5,
+           'nms_max_boxes': 20, 'nms_iou_threshold': 0.45, 'post_nms_proposal': 500, 'verbose': False, 'device': 'cpu', 'checkpoint_format': 'tf'}
+    prov = {'data_shape': [320, 416, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    with mock_ops.installed():
+        m = odtk.LHRCNN(dict(cfg, seed=1), prov)
+        names = m.reference_variable_map()
+        g = torch.Generator().manual_seed(5)
+        m.Mom.copy_(torch.randn(m.Mom.shape, generator=g) * 1e-3)
+        for k in m.sinfo:
+            m.stat(k).copy_(torch.rand(m.stat(k).shape, generator=g) + 0.5)
+        m.global_step = 41
+        prefix = str(tmp_path / 'ck' / 'lhrcnn')
+        m.save_weight('latest', prefix)
+        reader = NewCheckpointReader(prefix + '-41')
+        shapes = reader.get_variable_to_shape_map()
+        tf_vars = json.load(open(os.path.join(here, 'golden', 'lhrcnn_variables.json')))
+        assert set(tf_vars) <= set(shapes)
+        for n, meta in tf_vars.items():
+            assert list(shapes[n]) == meta['shape'], (n, shapes[n], meta['shape'])
+        scope = json.load(open(os.path.join(here, 'golden', 'optimizer_scopes.json')))['LHRCNN']       # recorded on the reference's own class
+        assert scope == 'rcnn' and m.MOMENTUM_SLOT_SCOPE == scope + '/'
+        for ours in ('conv1.w', 'stage3_sconv4.dw', 'rpn_pbbox.gamma', 'state5_conv2_2.w', 'roi_feat_dense.w', 'rcnn_pbbox.b'):
+            assert 'rcnn/' + names[ours] + '/Momentum' in shapes, ours
+        assert int(reader.get_tensor('global_step')) == 41
+        m2 = odtk.LHRCNN(dict(cfg, seed=2), prov)
+        assert not torch.equal(m2.P, m.P)
+        m2.load_weight(prefix + '-41')
+        assert torch.equal(m2.S, m.S) and m2.global_step == 41
+        for k in m.pinfo:
+            if k.endswith('.b') and k[:-2] in m._sep:
+                continue                                                      # the engine's inert bias of a separable layer: not a variable of the graph
+            assert torch.equal(m2.get_param(k), m.get_param(k)) and torch.equal(m2.get_param(k, m2.Mom), m.get_param(k, m.Mom)), k

@@ -88,6 +88,107 @@ __global__ void __launch_bounds__(LH_THREADS) depthwise_wgrad_kernel(const T* __
     }
 }
 
+// Four channels per thread (16-byte f32 / 8-byte bf16 accesses, 32-bit index arithmetic): the shapes of the model (C = 144, 288, 576, 256) all divide by 4.
+// First version (one element per thread, 64-bit div / mod per element): 8.8 ms of the 84.7-ms step at 700 x 1100 x 32 for each of the two kernels
+// (profiles/r03zzzz_lhrcnn_700x1100_b32_kernel_trace.md).
+template <typename T> struct vec4;
+template <> struct vec4<float> {
+    __device__ static float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static void store(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct vec4<bf16_t> {
+    __device__ static float4 load(const bf16_t* p) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return make_float4(bf16_to_f32((bf16_t)(u.x & 0xffffu)), bf16_to_f32((bf16_t)(u.x >> 16)), bf16_to_f32((bf16_t)(u.y & 0xffffu)), bf16_to_f32((bf16_t)(u.y >> 16)));
+    }
+    __device__ static void store(bf16_t* p, float4 v) {
+        uint2 u;
+        u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(LH_THREADS) depthwise4_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ f, T* __restrict__ y, int ldy,
+                                                                int M, int H, int W, int C, int kh, int kw, int flip, int accumulate) {
+    const int cq = C >> 2;                                     // channel quads per pixel
+    const unsigned i = blockIdx.x * LH_THREADS + threadIdx.x;
+    if (i >= (unsigned)M * (unsigned)cq) return;
+    const int m = (int)(i / (unsigned)cq), c = ((int)(i - (unsigned)m * (unsigned)cq)) << 2;
+    const int w = m % W, h = (m / W) % H;
+    const int ph = (kh - 1) / 2, pw = (kw - 1) / 2;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < kh; ++r) {
+        const int hh = h + r - ph;
+        if (hh < 0 || hh >= H) continue;
+        for (int s = 0; s < kw; ++s) {
+            const int ww = w + s - pw;
+            if (ww < 0 || ww >= W) continue;
+            const int fr = flip ? kh - 1 - r : r, fs = flip ? kw - 1 - s : s;
+            const float4 xv = vec4<T>::load(x + (size_t)(m + (hh - h) * W + (ww - w)) * ldx + c);
+            const float4 fv = *reinterpret_cast<const float4*>(f + (size_t)(fr * kw + fs) * C + c);
+            acc.x += xv.x * fv.x; acc.y += xv.y * fv.y; acc.z += xv.z * fv.z; acc.w += xv.w * fv.w;
+        }
+    }
+    T* o = y + (size_t)m * ldy + c;
+    if (accumulate) {
+        const float4 old = vec4<T>::load(o);
+        acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+    }
+    vec4<T>::store(o, acc);
+}
+
+// filter gradient, four channels per thread: threads = (channel quad, pixel slice) with all 256 lanes in use for any C; the taps are reduced one at a
+// time through 4 KiB of LDS (one float4 per thread), the first slice adds the sums into dfilter
+template <typename T>
+__global__ void __launch_bounds__(LH_THREADS) depthwise_wgrad4_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, float* __restrict__ df,
+                                                                      int M, int H, int W, int C, int kh, int kw, int pix_per_block, int cq_per_block) {
+    __shared__ float4 red[LH_THREADS];
+    const int slices = LH_THREADS / cq_per_block;
+    const int q = threadIdx.x % cq_per_block, slice = threadIdx.x / cq_per_block;
+    const int c = (blockIdx.x * cq_per_block + q) << 2;
+    const bool live = slice < slices && c < C;
+    const int m0 = blockIdx.y * pix_per_block, m1 = min(M, m0 + pix_per_block);
+    const int ph = (kh - 1) / 2, pw = (kw - 1) / 2, taps = kh * kw;
+    float4 acc[DW_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < DW_MAX_TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        for (int m = m0 + slice; m < m1; m += slices) {
+            const float4 g = vec4<T>::load(dy + (size_t)m * lddy + c);
+            const int w = m % W, h = (m / W) % H;
+#pragma unroll
+            for (int t = 0; t < DW_MAX_TAPS; ++t) {
+                if (t < taps) {
+                    const int dh = t / kw - ph, dw = t % kw - pw;
+                    if (h + dh >= 0 && h + dh < H && w + dw >= 0 && w + dw < W) {
+                        const float4 xv = vec4<T>::load(x + (size_t)(m + dh * W + dw) * ldx + c);
+                        acc[t].x += g.x * xv.x; acc[t].y += g.y * xv.y; acc[t].z += g.z * xv.z; acc[t].w += g.w * xv.w;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < DW_MAX_TAPS; ++t) {
+        if (t < taps) {                                   // uniform
+            red[threadIdx.x] = acc[t];
+            __syncthreads();
+            if (slice == 0 && c < C) {
+                float4 s = red[q];
+                for (int k = 1; k < slices; ++k) {
+                    const float4 v = red[k * cq_per_block + q];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                float* o = df + (size_t)t * C + c;
+                atomicAdd(o, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ RPN: matching and candidate lists
 struct LhAnchors {
     const float *y1x1, *y2x2, *yx, *hw;     // [A][2] each: the anchors INSIDE the picture (LH_RCNN.py:87-97), in anchor order
@@ -506,8 +607,19 @@ extern "C" int odtk_depthwise_conv(const void* x, int ldx, const float* filter, 
     ODTK_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && ldy >= C, "depthwise_conv: N=%d H=%d W=%d C=%d ldx=%d ldy=%d out of range", N, H, W, C, ldx, ldy);
     ODTK_REQUIRE(kh > 0 && kw > 0 && (kh & 1) && (kw & 1), "depthwise_conv: %dx%d taps (odd sizes: SAME padding is symmetric)", kh, kw);
     const long long total = (long long)N * H * W * C;
-    const dim3 grid((unsigned)((total + LH_THREADS - 1) / LH_THREADS));
     hipStream_t st = (hipStream_t)stream;
+    const int vchunk = dtype == ODTK_F32 ? 4 : 4;
+    if ((C & 3) == 0 && ldx % vchunk == 0 && ldy % vchunk == 0 && total / 4 < (1ll << 31) && (long long)N * H * W < (1ll << 30)) {     // four channels per thread
+        const long long quads = total / 4;
+        const dim3 g4((unsigned)((quads + LH_THREADS - 1) / LH_THREADS));
+        if (dtype == ODTK_F32)
+            hipLaunchKernelGGL(depthwise4_kernel<float>, g4, dim3(LH_THREADS), 0, st, (const float*)x, ldx, filter, (float*)y, ldy, N * H * W, H, W, C, kh, kw, flip, accumulate);
+        else
+            hipLaunchKernelGGL(depthwise4_kernel<bf16_t>, g4, dim3(LH_THREADS), 0, st, (const bf16_t*)x, ldx, filter, (bf16_t*)y, ldy, N * H * W, H, W, C, kh, kw, flip, accumulate);
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
+    const dim3 grid((unsigned)((total + LH_THREADS - 1) / LH_THREADS));
     if (dtype == ODTK_F32)
         hipLaunchKernelGGL(depthwise_kernel<float>, grid, dim3(LH_THREADS), 0, st, (const float*)x, ldx, filter, (float*)y, ldy, N, H, W, C, kh, kw, flip, accumulate);
     else
@@ -522,6 +634,24 @@ extern "C" int odtk_depthwise_wgrad(const void* x, int ldx, const void* dy, int 
     ODTK_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && lddy >= C, "depthwise_wgrad: N=%d H=%d W=%d C=%d out of range", N, H, W, C);
     ODTK_REQUIRE(kh > 0 && kw > 0 && (kh & 1) && (kw & 1) && kh * kw <= DW_MAX_TAPS, "depthwise_wgrad: %dx%d taps (odd sizes, at most %d taps)", kh, kw, DW_MAX_TAPS);
     const long long M = (long long)N * H * W;
+    if ((C & 3) == 0 && ldx % 4 == 0 && lddy % 4 == 0 && M < (1ll << 30)) {                       // four channels per thread, every lane busy
+        const int cq = C >> 2;
+        const int cq_per_block = cq >= LH_THREADS ? LH_THREADS : cq;                                // C <= 1024: one block column owns all channels of its pixels
+        const int cblocks = ceil_div(cq, cq_per_block);
+        const int slices = LH_THREADS / cq_per_block;
+        int splits = (int)min((long long)max(1, 2048 / cblocks), (M + 64 * slices - 1) / (64 * slices));
+        const int per = (int)((M + splits - 1) / splits);
+        splits = (int)((M + per - 1) / per);
+        hipStream_t st4 = (hipStream_t)stream;
+        if (dtype == ODTK_F32)
+            hipLaunchKernelGGL(depthwise_wgrad4_kernel<float>, dim3(cblocks, splits), dim3(LH_THREADS), 0, st4, (const float*)x, ldx, (const float*)dy, lddy, dfilter, (int)M, H, W,
+                               C, kh, kw, per, cq_per_block);
+        else
+            hipLaunchKernelGGL(depthwise_wgrad4_kernel<bf16_t>, dim3(cblocks, splits), dim3(LH_THREADS), 0, st4, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, dfilter, (int)M, H,
+                               W, C, kh, kw, per, cq_per_block);
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     const int ctiles = ceil_div(C, DW_CH);
     int splits = (int)min((long long)max(1, 2048 / ctiles), (M + 255) / 256);
     const int per = (int)((M + splits - 1) / splits);

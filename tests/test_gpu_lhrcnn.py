@@ -31,7 +31,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-@pytest.mark.parametrize('kh,kw,C,H,W', [(3, 3, 144, 20, 26), (1, 15, 576, 10, 13), (15, 1, 256, 10, 13), (3, 3, 24, 7, 5)])
+@pytest.mark.parametrize('kh,kw,C,H,W', [(3, 3, 144, 20, 26), (1, 15, 576, 10, 13), (15, 1, 256, 10, 13), (3, 3, 24, 7, 5), (3, 3, 23, 9, 6), (5, 3, 1028, 6, 7)])
 def test_depthwise_kernels(kh, kw, C, H, W, dt):
     ops = _ops()
     dtype = torch.float32 if dt == 'f32' else torch.bfloat16

@@ -19,7 +19,8 @@ reference's own class): BOTH optimizer ops run on every step -- backbone + RPN m
 reach the backbone (its variable list stops at 'rcnn', :190) -- global_step advances every step, and the schedule keys only choose which of the two losses
 train_one_epoch REPORTS.  One fused momentum launch per variable group covers that.  The label of a box's best anchor is tf.gather's GPU result (0 when the
 anchor index is out of range, :337); the R-CNN centre target is divided by the proposal's centre (:430).
-f32 engine only for now (the loss kernels read f32 head outputs).
+f32 engine only for now (the loss kernels read f32 head outputs).  Data parallel: `attach_data_parallel` (bucketed all-reduce of the flat gradient buffer, the
+dense layers' bucket first); each replica normalises the R-CNN loss by its own row counts.
 """
 from __future__ import annotations
 
@@ -252,7 +253,9 @@ class LHRCNN(RefineDet320):
         f = self.feat
         ops.crop_and_resize_fwd(f.t, f.ld, N, f.H, f.W, f.C, ws['roi_box'], ws['roi_img'], CROP, st.roi, st.ldr)
         self._dense_fwd(st)
-        ops.lhrcnn_rcnn_loss(st.logits, st.ldl, st.pbbox, st.ldb, N, self.num_classes, ws, 1.0, st.d_logits, st.d_pbbox)
+        # data parallel: every replica takes the R-CNN means over ITS rows (the row counts live on the device; as with the batch-norm statistics each replica is
+        # the reference computation on its own images) and the summed gradients are divided by the number of replicas; the RPN loss is a per-image mean
+        ops.lhrcnn_rcnn_loss(st.logits, st.ldl, st.pbbox, st.ldb, N, self.num_classes, ws, float(self.batch_size) / self.loss_divisor_batch, st.d_logits, st.d_pbbox)
         # backward of the three dense layers: filter / bias gradients, then d(fc1) through its ReLU, then d(roi rows), then the image gradient of the crop
         G = self.G
         ops.conv2d_wgrad(st.desc['rcnn_pconf'], st.fc1, st.d_logits, st.ldl, self._flat('rcnn_pconf.w', G), self._flat('rcnn_pconf.b', G))
@@ -268,8 +271,14 @@ class LHRCNN(RefineDet320):
         self.G.zero_()
         self._forward(True)
         self._rpn_loss, self._rcnn_loss = self._loss_step()
-        for _ in self._backward_iter():
-            pass
+        if self.dist is not None:
+            self.dist.layer_ready('roi_feat_dense')            # the three dense layers are the last segments of the flat gradient buffer
+        for name in self._backward_iter():
+            # a separable layer is complete when its depthwise filter gradient has been launched (the 'dw' entry follows its 1x1 layer in the backward plan)
+            if self.dist is not None:
+                base = name[:-3] if name.endswith('.dw') else name
+                if name.endswith('.dw') or base not in self._sep:
+                    self.dist.layer_ready(base)
 
     def _reported(self, step):
         """the loss tf.case selects for the report (LH_RCNN.py:198-203, :471-478)"""
@@ -281,9 +290,12 @@ class LHRCNN(RefineDet320):
 
     def _train_step_engine(self, lr):
         """one step of BOTH optimizer ops (module docstring); returns the loss the schedule reports, data term + weight decay * l2 of that op's variables"""
-        assert self.dist is None, "LHRCNN: data parallel is not wired up for this class"
+        if self.dist is not None:
+            self.dist.begin_step()
         self._step_body()
         self._eager_steps += 1
+        if self.dist is not None:
+            self.dist.finish_step()
         b = self.pinfo[RCNN_FIRST + '.dw'][0]                   # backbone + RPN variables | 'rcnn' variables
         pc = None
         nb = ops.sgd_blocks(b)

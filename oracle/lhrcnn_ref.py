@@ -255,8 +255,11 @@ def crop_and_resize(feat_nhwc, boxes, box_ind, crop=CROP):
         return feat_nhwc.new_zeros((0, crop, crop, C))
     b = boxes.detach()
     grid = torch.arange(crop, dtype=torch.float32).view(1, crop)
-    in_y = b[:, 0:1] * (H - 1) + grid * ((b[:, 2:3] - b[:, 0:1]) * (H - 1) / (crop - 1))
-    in_x = b[:, 1:2] * (W - 1) + grid * ((b[:, 3:4] - b[:, 1:2]) * (W - 1) / (crop - 1))
+    if crop > 1:
+        in_y = b[:, 0:1] * (H - 1) + grid * ((b[:, 2:3] - b[:, 0:1]) * (H - 1) / (crop - 1))
+        in_x = b[:, 1:2] * (W - 1) + grid * ((b[:, 3:4] - b[:, 1:2]) * (W - 1) / (crop - 1))
+    else:                                                         # one sample at the centre of the box
+        in_y, in_x = 0.5 * (b[:, 0:1] + b[:, 2:3]) * (H - 1), 0.5 * (b[:, 1:2] + b[:, 3:4]) * (W - 1)
     ok = ((in_y >= 0) & (in_y <= H - 1)).view(R, crop, 1, 1) & ((in_x >= 0) & (in_x <= W - 1)).view(R, 1, crop, 1)
     y0, x0 = torch.floor(in_y), torch.floor(in_x)
     ly, lx = (in_y - y0).view(R, crop, 1, 1), (in_x - x0).view(R, 1, crop, 1)

@@ -221,6 +221,14 @@ def _engine_cpu_model(kind, rank):
         batch = ((torch.rand(1, 128, 160, 3, generator=g) * 255).round(), YR.synthetic_gt(1, 128, 950 + rank, pad=6, max_obj=3))
         with mock_ops.installed():
             m = odtk.YOLOv2(cfg, {'data_shape': [128, 160, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+    elif kind == 'lhrcnn':
+        from oracle import lhrcnn_ref as LR
+        cfg = {'data_shape': [320, 416, 3], 'mode': 'train', 'is_pretraining': False, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
+               'keep_prob': 0.5, 'batch_size': 1, 'rpn_first_step': 60000, 'rcnn_first_step': 100000, 'rpn_second_step': 160000, 'nms_score_threshold': 0.5,
+               'nms_max_boxes': 20, 'nms_iou_threshold': 0.45, 'post_nms_proposal': 500, 'verbose': False, 'device': 'cpu', 'seed': 3}
+        batch = ((torch.rand(1, 320, 416, 3, generator=g) * 255).round(), LR.synthetic_gt(1, 320, 416, 950 + rank))
+        with mock_ops.installed():
+            m = odtk.LHRCNN(cfg, {'data_shape': [320, 416, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
     else:
         from oracle import refinedet_ref as FR
         cfg = {'mode': 'train', 'input_size': 320, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
@@ -250,9 +258,10 @@ def _engine_model_worker(kind, rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["yolov2", "pfpnet"])
+@pytest.mark.parametrize("kind", ["yolov2", "pfpnet", "lhrcnn"])
 def test_engine_models_data_parallel_world2_on_cpu(kind, tmp_path):
-    """YOLOv2 and PFPNetR (refinedet.py's engine: per-layer readiness reported while the backward plan runs, L2-norm scalars and multi-consumer
+    """YOLOv2, PFPNetR and LHRCNN (the latter: the R-CNN stage outside the plan reports the dense layers first, a separable layer is ready behind its depthwise
+    entry) (refinedet.py's engine: per-layer readiness reported while the backward plan runs, L2-norm scalars and multi-consumer
     gradient buffers included) on two gloo ranks with every libodtk launch mocked: replicas end identical, several buckets were exchanged, and the
     exchanged gradient is the sum of the ranks' local gradients with the loss divided by the GLOBAL batch"""
     import sys

@@ -87,6 +87,19 @@ def test_augmentor_hue_contrast_rotate_tables(dev):
         assert torch.allclose(out.cpu(), torch.from_numpy(want).unsqueeze(-1).repeat(1, 1, 3), atol=1e-3)
 
 
+def test_crop_and_resize_tables(dev):
+    """TensorFlow's crop_and_resize_op_test.cc tables through odtk_crop_and_resize_fwd (f32 and bf16 storage: every table value is exact in bf16)"""
+    ops = _ops()
+    for dtype in (torch.float32, torch.bfloat16):
+        feat = torch.zeros(4, 8, dtype=dtype, device=dev)
+        feat[:, 0] = torch.from_numpy(K.CROP_IN).reshape(4).to(dtype).to(dev)
+        for box, crop, want in K.CROP_CASES:
+            out = torch.full((1, 16), 9.0, dtype=dtype, device=dev)
+            ops.crop_and_resize_fwd(feat, 8, 1, 2, 2, 1, torch.tensor([box], device=dev), torch.zeros(1, dtype=torch.int32, device=dev), crop, out, 16)
+            torch.cuda.synchronize()
+            assert out[0, : crop * crop].float().cpu().tolist() == [float(v) for v in want], (box, dtype)
+
+
 def test_fused_batch_norm_training_statistics(dev):
     ops = _ops()
     e = K.BN_EXPECT

@@ -116,6 +116,16 @@ def test_rotate_quarter_turn_tables():
         assert torch.allclose(tf_shim.contrib.image.rotate(img, math.pi / 2, 'BILINEAR')[..., 0], torch.from_numpy(want), atol=1e-4)
 
 
+def test_crop_and_resize_tables():
+    from oracle import lhrcnn_ref as LR
+    img = torch.from_numpy(K.CROP_IN)
+    for box, crop, want in K.CROP_CASES:
+        b = torch.tensor([box], dtype=torch.float32)
+        want = torch.tensor(want, dtype=torch.float32)
+        assert torch.equal(LR.crop_and_resize(img, b, torch.zeros(1), crop).flatten(), want), box
+        assert torch.equal(tf_shim.image.crop_and_resize(img, b, torch.zeros(1, dtype=torch.int32), [crop, crop]).flatten(), want), box
+
+
 def test_fused_batch_norm_training_statistics():
     e = K.BN_EXPECT
     x = torch.from_numpy(K.BN_X)                                    # NHWC [2,1,1,1]

@@ -62,6 +62,15 @@ ROTATE_EVEN_OUT = np.array([[5, 11, 17, 23, 29, 35], [4, 10, 16, 22, 28, 34], [3
                             [1, 7, 13, 19, 25, 31], [0, 6, 12, 18, 24, 30]], np.float32)
 ROTATE_ODD_OUT = np.array([[4, 9, 14, 19, 24], [3, 8, 13, 18, 23], [2, 7, 12, 17, 22], [1, 6, 11, 16, 21], [0, 5, 10, 15, 20]], np.float32)
 
+# ---- tensorflow/core/kernels/crop_and_resize_op_test.cc -----------------------------------------------------------------------------
+# the 2 x 2 picture [[1, 2], [3, 4]]: TestCropAndResize2x2To3x3 (whole picture), 2x2To1x1 (one sample at the box centre), 2x2To3x3Flipped
+# (box [1, 1, 0, 0] mirrors both axes), 2x2To3x3Extrapolated (box [-1, -1, 1, 1]: samples outside the picture take the extrapolation value, 0 here)
+CROP_IN = np.array([1., 2., 3., 4.], np.float32).reshape(1, 2, 2, 1)
+CROP_CASES = [([0., 0., 1., 1.], 3, [1, 1.5, 2, 2, 2.5, 3, 3, 3.5, 4]),
+              ([0., 0., 1., 1.], 1, [2.5]),
+              ([1., 1., 0., 0.], 3, [4, 3.5, 3, 3, 2.5, 2, 2, 1.5, 1]),
+              ([-1., -1., 1., 1.], 3, [0, 0, 0, 0, 1, 2, 0, 3, 4])]
+
 # ---- tensorflow/docs_src/api_guides/python/nn.md ("Convolution": the SAME / VALID diagram) ---------------------------------
 # input width 13, filter width 6, stride 5:  VALID keeps 2 windows and drops 12, 13;  SAME pads 1 left and 2 right -> 3 windows:
 #     pad| 0 |1 2 3 4 5 6 7 8 9 10 11 12 13| 0 0 |pad       out = ceil(13 / 5) = 3, total = (3 - 1) * 5 + 6 - 13 = 3, before = 3 // 2

@@ -254,10 +254,13 @@ def crop_and_resize(feat_nhwc, boxes, box_ind, crop=CROP):
     if R == 0:
         return feat_nhwc.new_zeros((0, crop, crop, C))
     b = boxes.detach()
-    grid = torch.arange(crop, dtype=torch.float32).view(1, crop)
+    grid = torch.arange(crop, dtype=torch.float32, device=b.device).view(1, crop)
     if crop > 1:
-        in_y = b[:, 0:1] * (H - 1) + grid * ((b[:, 2:3] - b[:, 0:1]) * (H - 1) / (crop - 1))
-        in_x = b[:, 1:2] * (W - 1) + grid * ((b[:, 3:4] - b[:, 1:2]) * (W - 1) / (crop - 1))
+        # the divisor is a TENSOR on purpose: torch turns `tensor / python_scalar` into a multiplication by the rounded reciprocal on the GPU, one ulp off the
+        # division the TensorFlow kernel (and odtk_crop_and_resize_*) performs -- enough to move a sample across the picture's last row when a box ends at 1.0
+        steps = torch.full((1, 1), float(crop - 1), dtype=torch.float32, device=b.device)
+        in_y = b[:, 0:1] * (H - 1) + grid * ((b[:, 2:3] - b[:, 0:1]) * (H - 1) / steps)
+        in_x = b[:, 1:2] * (W - 1) + grid * ((b[:, 3:4] - b[:, 1:2]) * (W - 1) / steps)
     else:                                                         # one sample at the centre of the box
         in_y, in_x = 0.5 * (b[:, 0:1] + b[:, 2:3]) * (H - 1), 0.5 * (b[:, 1:2] + b[:, 3:4]) * (W - 1)
     ok = ((in_y >= 0) & (in_y <= H - 1)).view(R, crop, 1, 1) & ((in_x >= 0) & (in_x <= W - 1)).view(R, 1, crop, 1)
@@ -269,7 +272,7 @@ def crop_and_resize(feat_nhwc, boxes, box_ind, crop=CROP):
     tl, tr, bl, br = feat_nhwc[bi, y0i, x0i], feat_nhwc[bi, y0i, x1i], feat_nhwc[bi, y1i, x0i], feat_nhwc[bi, y1i, x1i]
     top = tl + (tr - tl) * lx
     bot = bl + (br - bl) * lx
-    return torch.where(ok, top + (bot - top) * ly, torch.zeros(()))
+    return torch.where(ok, top + (bot - top) * ly, feat_nhwc.new_zeros(()))
 
 
 def head(p, roi_flat):

@@ -44,14 +44,16 @@ OUTPUTS = {
     'retina_loss': ['loss_parts:0,1', 'dconf', 'dbox'], 'fcos_loss': ['loss', 'd_conf', 'd_reg', 'd_center'],
     'centernet_loss': ['loss_parts:3', 'd_keypoints', 'd_offset', 'd_size'],
     'refinedet_loss': ['loss_parts:6', 'd_arm_loc', 'd_arm_conf', 'd_odm_loc', 'd_odm_conf'],
+    'depthwise_conv': ['y'], 'depthwise_wgrad': ['dfilt'], 'crop_and_resize_fwd': ['out'], 'crop_and_resize_bwd': ['d_feat'],
+    'lhrcnn_rpn_loss': ['d_conf', 'd_bbox'], 'lhrcnn_rcnn_loss': ['d_logits', 'd_pbbox'],
 }
 # launches whose restatement calls the CPU oracles
-ON_CPU = {'ssd_loss', 'yolov3_loss', 'yolov2_loss', 'retina_loss', 'fcos_loss', 'centernet_loss', 'refinedet_loss'}
+ON_CPU = {'ssd_loss', 'yolov3_loss', 'yolov2_loss', 'retina_loss', 'fcos_loss', 'centernet_loss', 'refinedet_loss', 'lhrcnn_rpn_loss'}
 # launches that are not shadowed: the mocked box-side front ends do nothing (the mocked loss matches / mines by itself through the oracle -- the
 # real kernels' indices are compared bit for bit by the kernel-level tests), workspaces, scratch selection, constant tables
 PASS = {'conv2d_fwd_pool2x2_fused', 'ssd_match', 'softmax_ce_const', 'retina_match', 'nms_batched', 'scratch_slot', 'ssd_priors', 'retina_anchors', 'gn_workspace', 'fcos_workspace',
         'yolov3_workspace', 'retina_match_workspace', 'centernet_workspace', 'yolov3_decode_candidates', 'fcos_decode_candidates', 'retina_decode',
-        'refinedet_decode', 'centernet_decode', 'yolov2_decode_candidates'}
+        'refinedet_decode', 'centernet_decode', 'yolov2_decode_candidates', 'lhrcnn_match', 'lhrcnn_rpn_decode', 'lhrcnn_gather_rois', 'lhrcnn_rcnn_decode'}
 WHOLE_STORAGE_MAX = 1 << 30
 BN_MOM_ = 0.99
 
@@ -95,6 +97,8 @@ def _map(obj, f):
         return f(obj)
     if isinstance(obj, (list, tuple)):
         return type(obj)(_map(o, f) for o in obj)
+    if isinstance(obj, dict):                                # LHRCNN hands its anchors and its workspace over as dicts of tensors
+        return {k: _map(v, f) for k, v in obj.items()}
     return obj
 
 

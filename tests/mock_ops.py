@@ -690,7 +690,7 @@ def depthwise_conv(x, ldx, filt, y, ldy, N, H, W, C_, kh, kw, flip=False, accumu
 
 
 def depthwise_wgrad(x, ldx, dy, lddy, dfilt, N, H, W, C_, kh, kw):
-    w = torch.zeros(C_, 1, kh, kw, requires_grad=True)
+    w = torch.zeros(C_, 1, kh, kw, requires_grad=True, device=x.device)
     xin = x[:, :C_].float().reshape(N, H, W, C_).permute(0, 3, 1, 2)
     out = F.conv2d(F.pad(xin, ((kw - 1) // 2, kw // 2, (kh - 1) // 2, kh // 2)), w, None, groups=C_)
     g, = torch.autograd.grad(out, w, dy[:, :C_].float().reshape(N, H, W, C_).permute(0, 3, 1, 2))
@@ -745,7 +745,7 @@ def crop_and_resize_fwd(feat, ldf, N, H, W, C_, boxes, box_img, crop, out, ldo):
 
 def crop_and_resize_bwd(d_out, ldo, N, H, W, C_, boxes, box_img, crop, d_feat, ldf):
     from oracle import lhrcnn_ref as LR
-    f = torch.zeros(N, H, W, C_, requires_grad=True)
+    f = torch.zeros(N, H, W, C_, requires_grad=True, device=d_out.device)
     live = box_img >= 0
     v = LR.crop_and_resize(f, boxes, box_img.clamp(min=0), crop).reshape(boxes.shape[0], -1)
     g, = torch.autograd.grad(v, f, d_out[:, : crop * crop * C_].float() * live.view(-1, 1))

@@ -69,13 +69,17 @@ def test_crop_and_resize_kernels(dt):
     ops = _ops()
     dtype = torch.float32 if dt == 'f32' else torch.bfloat16
     g = torch.Generator().manual_seed(5)
-    N, H, W, C, R, crop = 2, 10, 13, 490, 40, 7
+    N, H, W, C, R, crop = 2, 22, 35, 490, 40, 7
     ld = ops.pad_to(C, 8)
     feat = torch.zeros(N * H * W, ld, dtype=dtype)
     feat[:, :C] = torch.randn(N * H * W, C, generator=g).to(dtype)
     y1, x1 = torch.rand(R, generator=g) * 0.7 - 0.1, torch.rand(R, generator=g) * 0.7 - 0.1        # some boxes start / end outside [0, 1]
     boxes = torch.stack([y1, x1, y1 + 0.1 + torch.rand(R, generator=g) * 0.6, x1 + 0.1 + torch.rand(R, generator=g) * 0.6], 1)
     boxes[3] = torch.tensor([0., 0., 1., 1.]); boxes[4] = torch.tensor([0.25, 0.5, 0.25, 0.5])       # the whole picture; a degenerate box
+    # proposals clamped to the picture end exactly at 0.0 / 1.0: their last sample row / column sits ON the border, where one ulp decides inside / outside
+    edge = torch.rand(12, 4, generator=g)
+    edge[:, 2:] = 1.0; edge[:6, :2] *= 0.9; edge[6:, :2] = 0.0; edge[6:, 2:] = 0.3 + 0.7 * torch.rand(6, 2, generator=g)
+    boxes[8:20] = edge
     img = torch.randint(0, N, (R,), generator=g).to(torch.int32)
     img[7] = -1; img[R - 1] = -1
     ldo = ops.pad_to(crop * crop * C, 8)
@@ -270,3 +274,45 @@ def test_detections_vs_reference_class():
     # north_star: boxes / scores within 1e-3 (scores absolute; box coordinates relative to the box's longer side -- this head's random-weight boxes reach 2 000 px;
     # measured: scores 1.2e-4, profiles/r03zzzz_lhrcnn_gpu_tests.md)
     assert es < 1e-3 and eb < 1e-3, (es, eb)
+
+
+def test_every_launch_in_situ_at_the_driver_shape():
+    """testlhrcnn.py's shape -- 700 x 1100, batch 32 -- on the GPU: every launch of a whole training step is re-executed in plain f32 PyTorch from the engine's
+    own stored inputs of that launch and compared (tests/insitu.py, as for the other classes in tests/test_gpu_insitu_configs.py): 27 convolutions / dense
+    layers forward, filter and input gradients, 24 batch norms, 32 + 17 depthwise launches, the crop and its gradient over 8 192 rows, the RPN loss against
+    the oracle on the engine's own predictions (CPU), the R-CNN loss, both momentum launches.  The toy-shape cases above do not see the tile counts, pixel
+    splits and 32-bit offsets of this size."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import insitu
+    import odtk
+    torch.set_num_threads(16)
+    H, W, B = 700, 1100, 32
+    g = torch.Generator().manual_seed(7)
+    imgs = (torch.rand(B, H, W, 3, generator=g) * 255).round()
+    gt = LR.synthetic_gt(B, H, W, 8, pad=60, max_obj=6)
+    sh = insitu.Shadow()
+    with sh.installed():
+        m = odtk.LHRCNN(_cfg('train', B, data_shape=[H, W, 3]), {'data_shape': [H, W, 3], 'num_train': B, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+        m.set_batch(imgs, gt)
+        m.train_step(0.003)                      # un-shadowed first step: lazily grown scratch exists, momentum / moving statistics are non-trivial
+        sh.recording = True
+        loss = m.train_step(0.003)
+        sh.recording = False
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss).all())
+    rows = sh.check(insitu.default_tol('f32'), verbose=True, label=f'lhrcnn f32 {H}x{W} batch {B}')
+    seen = {x['op'] for x in rows}
+    assert {'conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad', 'depthwise_conv', 'depthwise_wgrad', 'crop_and_resize_fwd', 'crop_and_resize_bwd', 'lhrcnn_rpn_loss',
+            'lhrcnn_rcnn_loss', 'bn_fwd', 'bn_bwd', 'sgd_momentum'} <= seen
+    assert sum(1 for x in rows if x['op'] == 'depthwise_conv') == 32 and sum(1 for x in rows if x['op'] == 'conv2d_wgrad' and x['out'] == 'dw') == 27
+    if os.path.isdir('gpurun_out'):
+        per = {}
+        for r_ in rows:
+            a = per.setdefault(r_['op'] + ':' + r_['out'].split('[')[0], [0, 0.0])
+            a[0] += 1; a[1] = max(a[1], r_['rel'])
+        with open('gpurun_out/lhrcnn_insitu.txt', 'w') as f:
+            f.write(f'lhrcnn f32 {H}x{W} batch {B}: {len(rows)} outputs of {sh.seq} launches\n' + '\n'.join(f'{k} x{c} worst {w:.3e}' for k, (c, w) in sorted(per.items(), key=lambda kv: -kv[1][1])) + '\n')
+    del m
+    torch.cuda.empty_cache()

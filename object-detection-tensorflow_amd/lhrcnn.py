@@ -19,7 +19,7 @@ reference's own class): BOTH optimizer ops run on every step -- backbone + RPN m
 reach the backbone (its variable list stops at 'rcnn', :190) -- global_step advances every step, and the schedule keys only choose which of the two losses
 train_one_epoch REPORTS.  One fused momentum launch per variable group covers that.  The label of a box's best anchor is tf.gather's GPU result (0 when the
 anchor index is out of range, :337); the R-CNN centre target is divided by the proposal's centre (:430).
-f32 engine only for now (the loss kernels read f32 head outputs).  Data parallel: `attach_data_parallel` (bucketed all-reduce of the flat gradient buffer, the
+f32 engine by default; `compute_dtype='bf16'` is an opt-in that has not run on the GPU as a whole yet (see __init__).  Data parallel: `attach_data_parallel` (bucketed all-reduce of the flat gradient buffer, the
 dense layers' bucket first); each replica normalises the R-CNN loss by its own row counts.
 """
 from __future__ import annotations
@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from . import heads, ops
-from ._lib import F32
+from ._lib import BF16, F32
 from .refinedet import RefineDet320
 
 ANCHOR_SCALES = [32, 64, 128, 256, 512]
@@ -101,6 +101,14 @@ class _Stage:
             self.d_pbbox = torch.zeros(rows, self.ldb, dtype=dt, device=dev)
             self.d_fc1 = torch.zeros(rows, 2048, dtype=dt, device=dev)
             self.d_roi = torch.zeros(rows, self.ldr, dtype=dt, device=dev)
+        # the loss / decode kernels read and write f32: on the bf16 engine the head's outputs and their gradients pass through f32 twins
+        f32 = dt == torch.float32
+        self.logits32 = self.logits if f32 else torch.zeros(rows, self.ldl, device=dev)
+        self.pbbox32 = self.pbbox if f32 else torch.zeros(rows, self.ldb, device=dev)
+        if pad is not None:
+            self.d_logits32 = self.d_logits if f32 else torch.zeros(rows, self.ldl, device=dev)
+            self.d_pbbox32 = self.d_pbbox if f32 else torch.zeros(rows, self.ldb, device=dev)
+            self.d_feat32 = None if f32 else torch.zeros(m.feat.M, m.feat.ld, device=dev)
 
 
 class LHRCNN(RefineDet320):
@@ -145,8 +153,11 @@ class LHRCNN(RefineDet320):
                 self.val_generator = data_provider['val_generator']
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        assert config.get('compute_dtype', 'f32') == 'f32', "LHRCNN runs on the f32 engine (its loss kernels read f32 head outputs)"
-        self.DT, self.tdt = F32, torch.float32
+        # 'bf16' (opt-in, end of round 3): the engine's bf16 kernels everywhere, the head's outputs widened to f32 in front of the loss / decode kernels.  Built from
+        # launches that are each verified on MI355X (bf16 storage of the depthwise / crop kernels, the bf16 convolutions, the casts) but NOT yet run as a whole on
+        # the GPU, and not put through the gradient-direction gate of DESIGN.md 5: f32 stays the default.
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE)]
+        self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0
         self.dist = None
@@ -162,7 +173,7 @@ class LHRCNN(RefineDet320):
         for n, (kh, kw, cin) in self._sep.items():
             self.set_param(n + '.dw', torch.randn(kh, kw, cin, generator=g) * (2.0 / (kh * kw)) ** 0.5)
         self._build()
-        self._warmup_setup(config, data_provider, True)
+        self._warmup_setup(dict(config, f32_warmup_steps=config.get('f32_warmup_steps', 0)), data_provider, True)
         self._infer = None
 
     # ------------------------------------------------------------------ parameters
@@ -238,6 +249,9 @@ class LHRCNN(RefineDet320):
         ops.conv2d_fwd(st.desc['roi_feat_dense'], st.roi, self._flat('roi_feat_dense.w', P), self.param('roi_feat_dense.b'), st.fc1, True)
         ops.conv2d_fwd(st.desc['rcnn_pconf'], st.fc1, self._flat('rcnn_pconf.w', P), self.param('rcnn_pconf.b'), st.logits, False)
         ops.conv2d_fwd(st.desc['rcnn_pbbox'], st.fc1, self._flat('rcnn_pbbox.w', P), self.param('rcnn_pbbox.b'), st.pbbox, False)
+        if self.DT == BF16:
+            ops.cast_to_f32(st.logits, st.logits32)
+            ops.cast_to_f32(st.pbbox, st.pbbox32)
 
     def _loss_step(self):
         """RPN loss (gradients into the prediction tensors' gradient buffers), then the whole R-CNN stage forward AND backward down to d(rcnn_feat);
@@ -255,7 +269,10 @@ class LHRCNN(RefineDet320):
         self._dense_fwd(st)
         # data parallel: every replica takes the R-CNN means over ITS rows (the row counts live on the device; as with the batch-norm statistics each replica is
         # the reference computation on its own images) and the summed gradients are divided by the number of replicas; the RPN loss is a per-image mean
-        ops.lhrcnn_rcnn_loss(st.logits, st.ldl, st.pbbox, st.ldb, N, self.num_classes, ws, float(self.batch_size) / self.loss_divisor_batch, st.d_logits, st.d_pbbox)
+        ops.lhrcnn_rcnn_loss(st.logits32, st.ldl, st.pbbox32, st.ldb, N, self.num_classes, ws, float(self.batch_size) / self.loss_divisor_batch, st.d_logits32, st.d_pbbox32)
+        if self.DT == BF16:
+            ops.cast_from_f32(st.d_logits32, st.d_logits)
+            ops.cast_from_f32(st.d_pbbox32, st.d_pbbox)
         # backward of the three dense layers: filter / bias gradients, then d(fc1) through its ReLU, then d(roi rows), then the image gradient of the crop
         G = self.G
         ops.conv2d_wgrad(st.desc['rcnn_pconf'], st.fc1, st.d_logits, st.ldl, self._flat('rcnn_pconf.w', G), self._flat('rcnn_pconf.b', G))
@@ -264,7 +281,11 @@ class LHRCNN(RefineDet320):
         ops.conv2d_dgrad(st.desc['rcnn_pbbox'], st.d_pbbox, st.ldb, self.wt['rcnn_pbbox'], st.fc1, st.d_fc1, True)
         ops.conv2d_wgrad(st.desc['roi_feat_dense'], st.roi, st.d_fc1, 2048, self._flat('roi_feat_dense.w', G), self._flat('roi_feat_dense.b', G))
         ops.conv2d_dgrad(st.desc['roi_feat_dense'], st.d_fc1, 2048, self.wt['roi_feat_dense'], None, st.d_roi, False)
-        ops.crop_and_resize_bwd(st.d_roi, st.ldr, N, f.H, f.W, f.C, ws['roi_box'], ws['roi_img'], CROP, f.g, f.ld)
+        if self.DT == BF16:
+            ops.crop_and_resize_bwd(st.d_roi, st.ldr, N, f.H, f.W, f.C, ws['roi_box'], ws['roi_img'], CROP, st.d_feat32, f.ld)
+            ops.cast_from_f32(st.d_feat32, f.g)
+        else:
+            ops.crop_and_resize_bwd(st.d_roi, st.ldr, N, f.H, f.W, f.C, ws['roi_box'], ws['roi_img'], CROP, f.g, f.ld)
         return ws['rpn_parts'][:, 3].sum() / self.batch_size, ws['rcnn_parts'].sum()
 
     def _step_body(self):
@@ -297,10 +318,10 @@ class LHRCNN(RefineDet320):
         if self.dist is not None:
             self.dist.finish_step()
         b = self.pinfo[RCNN_FIRST + '.dw'][0]                   # backbone + RPN variables | 'rcnn' variables
-        pc = None
+        bf = self.DT == BF16
         nb = ops.sgd_blocks(b)
-        ops.sgd_momentum(self.P[:b], self.Mom[:b], self.G[:b], lr, 0.9, self.weight_decay, 1.0, self.l2_partial[:nb], pc)
-        ops.sgd_momentum(self.P[b:], self.Mom[b:], self.G[b:], lr, 0.9, self.weight_decay, 1.0, self.l2_partial[nb:], pc)
+        ops.sgd_momentum(self.P[:b], self.Mom[:b], self.G[:b], lr, 0.9, self.weight_decay, 1.0, self.l2_partial[:nb], self.Pc[:b] if bf else None)
+        ops.sgd_momentum(self.P[b:], self.Mom[b:], self.G[b:], lr, 0.9, self.weight_decay, 1.0, self.l2_partial[nb:], self.Pc[b:] if bf else None)
         ops.sum_f32(self.l2_partial[:nb], self.l2_sum)
         ops.sum_f32(self.l2_partial[nb:], self.l2_sum2)
         self._fp_batch.run()
@@ -365,7 +386,7 @@ class LHRCNN(RefineDet320):
         f = self.feat
         ops.crop_and_resize_fwd(f.t, f.ld, 1, f.H, f.W, f.C, st.roi_box, st.roi_img, CROP, st.roi, st.ldr)
         self._dense_fwd(st)
-        ops.lhrcnn_rcnn_decode(st.logits, st.ldl, st.pbbox, st.ldb, st.roi_prop, st.roi_img, self.num_classes, self.nms_score_threshold, st.conf, st.boxes, st.cand)
+        ops.lhrcnn_rcnn_decode(st.logits32, st.ldl, st.pbbox32, st.ldb, st.roi_prop, st.roi_img, self.num_classes, self.nms_score_threshold, st.conf, st.boxes, st.cand)
         scores, bbox, cid = heads._per_class_nms(st.conf, st.boxes, st.cand, self.num_classes - 1, self.nms_max_boxes, self.nms_iou_threshold)
         return [scores.cpu().numpy(), bbox.cpu().numpy().reshape(-1, 4), cid.cpu().numpy()]
 

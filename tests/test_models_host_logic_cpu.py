@@ -579,3 +579,51 @@ def test_lhrcnn_inference_host_logic():
     assert np.array_equal(cid, g['class_id'])
     np.testing.assert_allclose(scores, g['scores'], rtol=0, atol=1e-5)
     np.testing.assert_allclose(bbox, g['bbox'], rtol=1e-5, atol=2e-3)
+
+
+def test_lhrcnn_bf16_engine_host_logic():
+    """LHRCNN with compute_dtype='bf16' (opt-in): bf16 activations and operand copies, the dense head's outputs widened to f32 in front of the loss kernels and
+    their gradients narrowed behind them, the crop's image gradient through an f32 scratch, both momentum launches refreshing their half of the bf16 parameter
+    copy -- one training step and inference on the CPU mock stay within bf16 noise of the oracle"""
+    import numpy as np
+    import odtk
+    from oracle import lhrcnn_ref as LR
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(901)
+    imgs = (torch.rand(2, 320, 416, 3, generator=g) * 255).round()
+    gt = LR.synthetic_gt(2, 320, 416, 911)
+    p = LR.init_params(71)
+    with mock_ops.installed():
+        m = odtk.LHRCNN(_lhrcnn_cfg('train', 2, compute_dtype='bf16'), {'data_shape': [320, 416, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)],
+                                                                          'val_generator': None})
+        assert m.tdt == torch.bfloat16 and m.feat.t.dtype == torch.bfloat16 and m.loss is None and m.f32_warmup_steps == 0
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        before = m.P.clone()
+        m.train_step(0.003)
+        q = {k: v.clone() for k, v in p.items()}
+        rpn, rcnn = LR.train_step(q, {k: torch.zeros_like(v) for k, v in p.items()}, imgs, gt, 0.003)
+        got_rpn, got_rcnn = float(m.last_losses[0]), float(m.last_losses[1])
+        # At random initialisation the 20-layer batch-norm stack amplifies the bf16 rounding of every stored activation (rcnn_feat differs by 16 % from the f32
+        # engine's here), the two NMS then pick different anchors and the R-CNN stage sees different proposals: the losses are only loosely comparable (what the
+        # f32 warm-up of the other batch-norm classes exists for, DESIGN.md 5).  What IS exact is the plumbing this engine adds:
+        assert abs(got_rpn - rpn) < 0.2 * abs(rpn) and 0.2 * rcnn < got_rcnn < 5. * rcnn, (got_rpn, rpn, got_rcnn, rcnn)
+        st = m.loss
+        assert st.logits.dtype == torch.bfloat16 and st.roi.dtype == torch.bfloat16 and st.logits32.dtype == torch.float32
+        assert torch.equal(st.logits32, st.logits.float()) and torch.equal(st.pbbox32, st.pbbox.float())            # widened in front of the loss kernel
+        assert torch.equal(st.d_logits.float(), st.d_logits32.to(torch.bfloat16).float()) and float(st.d_logits32.abs().max()) > 0   # narrowed behind it
+        assert torch.equal(st.d_pbbox.float(), st.d_pbbox32.to(torch.bfloat16).float())
+        assert torch.equal(m.feat.g.float(), st.d_feat32.to(torch.bfloat16).float()) and float(st.d_feat32.abs().max()) > 0    # the crop's image gradient
+        assert bool(torch.isfinite(m.P).all()) and not torch.equal(m.P, before)
+        assert torch.equal(m.Pc.float(), m.P.to(torch.bfloat16).float())          # both halves of the operand copy were refreshed by their momentum launch
+        b = m.pinfo['state5_conv1_1.dw'][0]
+        assert float((m.P[:b] - before[:b]).abs().max()) > 0 and float((m.P[b:] - before[b:]).abs().max()) > 0           # both variable groups moved
+    gd = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'lhrcnn_detect.npz'))
+    for k in gd.files:
+        if k.startswith('stat__'):
+            p[k[6:].replace('__', '.')] = torch.from_numpy(gd[k])
+    with mock_ops.installed():
+        mt = odtk.LHRCNN(_lhrcnn_cfg('test', 1, nms_score_threshold=float(gd['score_threshold']), post_nms_proposal=int(gd['post_nms_proposal']), compute_dtype='bf16'), None)
+        mt.load_oracle_params(p)
+        scores, bbox, cid = mt.test_one_image((torch.from_numpy(gd['image']).float() / 127.5 - 1.).numpy())
+    assert len(scores) > 0.5 * len(gd['scores']) and np.isfinite(bbox).all() and scores.max() <= 1.0

@@ -676,3 +676,50 @@ def test_lhrcnn_variables_of_the_reference_graph():
     assert len(V) == len(names) + 1 and V['global_step']['trainable'] is False
     assert names['stage3_sconv8.gamma'] == 'feature_extractor/stage3/batch_normalization_7/gamma'
     assert names['state5_conv2_2.dw'] == 'rcnn/state5_conv2_2/depthwise_kernel' and names['rcnn_pbbox.w'] == 'rcnn/rcnn_pbbox/kernel'
+
+
+def test_lhrcnn_rpn_selection_properties():
+    """size-independent properties of oracle/lhrcnn_ref.rpn_one_image at the driver's shape (700 x 1100: 6 818 of 11 550 anchors inside the picture): every kept
+    anchor lies inside; the G best anchors lead the positive list; picks are unique and within the 128 / 256 budgets; the loss only depends on the picked rows"""
+    from oracle import lhrcnn_ref as LR
+    H, W = 700, 1100
+    anc = LR.anchors(22, 35, H, W)
+    assert int(anc['keep'].sum()) == 6818 and anc['keep'].numel() == 11550
+    assert bool((anc['y1x1'] >= 0).all()) and bool((anc['y2x2'][:, 0] <= H - 2).all()) and bool((anc['y2x2'][:, 1] <= W - 2).all())
+    g = torch.Generator().manual_seed(4)
+    A = anc['yx'].shape[0]
+    conf = torch.randn(A, 2, generator=g).requires_grad_(True)
+    bbox = (torch.randn(A, 4, generator=g) * 0.3).requires_grad_(True)
+    gt = LR.synthetic_gt(1, H, W, 5, pad=60, max_obj=6)[0]
+    loss, pos_prop, pos_lab, truth, neg_prop, d = LR.rpn_one_image(bbox[:, :2], bbox[:, 2:], conf, anc, gt, detail=True)
+    G = d['G']
+    assert G == int((gt[:, 0] >= 0).sum()) and torch.equal(d['pos_a'][:G], d['best_a']) and torch.equal(d['pos_gi'][:G], torch.arange(G))
+    assert len(set(d['pa'].tolist())) == len(d['pa']) <= 128 and len(set(d['na'].tolist())) == len(d['na']) <= 256 - min(len(d['pos_a']), 128)
+    assert not set(d['pa'].tolist()) & set(d['na'].tolist())
+    assert bool((d['iou'].t()[d['na']].max(1).values < 0.3).all())
+    assert pos_prop.shape == (len(d['pa']), 4) and neg_prop.shape == (len(d['na']), 4) and truth.shape == pos_prop.shape and bool(torch.isfinite(loss))
+    g1, g2 = torch.autograd.grad(loss, [conf, bbox])
+    touched = torch.zeros(A, dtype=torch.bool)
+    touched[d['pa']] = True; touched[d['na']] = True
+    assert float(g1[~touched].abs().max()) == 0.0 and float(g2[~touched].abs().max()) == 0.0 and float(g2[d['na']].abs().max()) == 0.0
+    assert float(g1[touched].abs().min()) > 0.0
+    # labels of the best rows follow tf.gather's GPU rule: label[anchor index] when the index is < G, else 0
+    want = [int(gt[a, 4]) if a < G else 0 for a in d['best_a'].tolist()]
+    k = [i for i, s in enumerate(d['sel_p'].tolist()) if s < G]
+    assert [int(pos_lab[i]) for i in k] == [want[d['sel_p'][i]] for i in k]
+
+
+def test_resize_kernels_properties():
+    """the augmentor's NEAREST / BICUBIC restatements at the driver scripts' sizes: a constant picture stays constant (the four table weights sum to 1 to float
+    rounding), same-size is the identity, nearest only copies source pixels, bicubic overshoot stays within the Keys kernel's bound"""
+    from oracle import augment_ref as A
+    g = torch.Generator().manual_seed(9)
+    img = (torch.rand(375, 500, 3, generator=g) * 255).round()
+    const = torch.full((375, 500, 3), 93.0)
+    assert float((A.resize_bicubic_align(const, 300, 300) - 93.0).abs().max()) < 2e-5 and torch.equal(A.resize_nearest_align(const, 300, 300), const[:300, :300])
+    assert torch.equal(A.resize_bicubic_align(img, 375, 500), img) and torch.equal(A.resize_nearest_align(img, 375, 500), img)
+    near = A.resize_nearest_align(img, 700, 1100)
+    assert set(near.unique().tolist()) <= set(img.unique().tolist()) and torch.equal(near[0, 0], img[0, 0]) and torch.equal(near[-1, -1], img[-1, -1])
+    cub = A.resize_bicubic_align(img, 700, 1100)
+    assert torch.equal(cub[0, 0], img[0, 0]) and torch.allclose(cub[-1, -1], img[-1, -1], atol=1e-3)            # align_corners: the corners map onto the corners
+    assert float(cub.min()) > -0.3 * 255 and float(cub.max()) < 1.3 * 255

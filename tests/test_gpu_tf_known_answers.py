@@ -1,6 +1,8 @@
 """GPU: TensorFlow's own known answers (tests/tf_known_answers.py) against the HIP kernels, through the C-ABI:
 NonMaxSuppression op-test vectors on both NMS engines, the ResizeImagesTest tables on odtk_resize_bilinear_fwd (TF-1.x grid) and on
 the augmentor's align_corners=True resize, the fused-batch-norm statistics on odtk_bn_fwd."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -87,6 +89,9 @@ def test_augmentor_hue_contrast_rotate_tables(dev):
         assert torch.allclose(out.cpu(), torch.from_numpy(want).unsqueeze(-1).repeat(1, 1, 3), atol=1e-3)
 
 
+@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
+    "written after the round's GPU minutes were spent, never run on hardware (ODTK_RUN_UNVERIFIED=1 runs it): the same tables are checked on the oracle and the shim "
+    "(tests/test_tf_known_answers_cpu.py) and the kernel is checked against the oracle in tests/test_gpu_lhrcnn.py, bit-equal over 8 192 rows in situ"))
 def test_crop_and_resize_tables(dev):
     """TensorFlow's crop_and_resize_op_test.cc tables through odtk_crop_and_resize_fwd (f32 and bf16 storage: every table value is exact in bf16)"""
     ops = _ops()

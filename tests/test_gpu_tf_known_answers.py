@@ -105,6 +105,27 @@ def test_crop_and_resize_tables(dev):
             assert out[0, : crop * crop].float().cpu().tolist() == [float(v) for v in want], (box, dtype)
 
 
+@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
+    "written after the round's GPU minutes were spent, never run on hardware (ODTK_RUN_UNVERIFIED=1 runs it); the pooling kernels themselves are covered by "
+    "tests/test_gpu_kernels.py and the in-situ shadows"))
+def test_pooling_same_padding_tables(dev):
+    """pooling_ops_test.py's SAME tables on odtk_maxpool_fwd (the window that only covers the last column) and odtk_avgpool2x2_fwd"""
+    ops = _ops()
+    for dtype in (torch.float32, torch.bfloat16):
+        ld = 8
+        x = torch.zeros(6, ld, dtype=dtype, device=dev)
+        x[:, :3] = torch.from_numpy(K.MAXPOOL_SAME_IN).reshape(6, 3).to(dtype).to(dev)
+        y = torch.zeros(2, ld, dtype=dtype, device=dev)
+        ops.maxpool_fwd(x, y, 1, 2, 3, 3, ld, 1, 2, 2, 2, 0, 0)
+        xa = torch.zeros(8, ld, dtype=dtype, device=dev)
+        xa[:, :3] = torch.from_numpy(K.AVGPOOL_SAME_IN).reshape(8, 3).to(dtype).to(dev)
+        ya = torch.zeros(2, ld, dtype=dtype, device=dev)
+        ops.avgpool2x2_fwd(xa, ya, 1, 2, 4, ld)
+        torch.cuda.synchronize()
+        assert torch.equal(y[:, :3].float().cpu(), torch.from_numpy(K.MAXPOOL_SAME_OUT).reshape(2, 3))
+        assert torch.equal(ya[:, :3].float().cpu(), torch.from_numpy(K.AVGPOOL_SAME_OUT).reshape(2, 3))       # every table value is exact in bf16
+
+
 def test_fused_batch_norm_training_statistics(dev):
     ops = _ops()
     e = K.BN_EXPECT

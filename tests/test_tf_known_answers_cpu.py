@@ -126,6 +126,22 @@ def test_crop_and_resize_tables():
         assert torch.equal(tf_shim.image.crop_and_resize(img, b, torch.zeros(1, dtype=torch.int32), [crop, crop]).flatten(), want), box
 
 
+def test_pooling_same_padding_tables():
+    import mock_ops
+    x, want = torch.from_numpy(K.MAXPOOL_SAME_IN), torch.from_numpy(K.MAXPOOL_SAME_OUT)
+    assert torch.equal(R.maxpool_same(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1), want)
+    assert torch.equal(tf_shim.layers.max_pooling2d(x, 2, 2, 'same', 'channels_last'), want)
+    rows, y = torch.zeros(6, 4), torch.zeros(2, 4)
+    rows[:, :3] = x.view(6, 3)
+    mock_ops.maxpool_fwd(rows, y, 1, 2, 3, 3, 4, 1, 2, 2, 2, 0, 0)
+    assert torch.equal(y[:, :3], want.view(2, 3))
+    xa, wa = torch.from_numpy(K.AVGPOOL_SAME_IN), torch.from_numpy(K.AVGPOOL_SAME_OUT)
+    assert torch.equal(tf_shim.layers.average_pooling2d(xa, 2, 2, 'same', 'channels_last'), wa)
+    rows, y = xa.view(8, 3).clone(), torch.zeros(2, 3)
+    mock_ops.avgpool2x2_fwd(rows, y, 1, 2, 4, 3)
+    assert torch.equal(y, wa.view(2, 3))
+
+
 def test_fused_batch_norm_training_statistics():
     e = K.BN_EXPECT
     x = torch.from_numpy(K.BN_X)                                    # NHWC [2,1,1,1]

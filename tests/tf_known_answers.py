@@ -71,6 +71,14 @@ CROP_CASES = [([0., 0., 1., 1.], 3, [1, 1.5, 2, 2, 2.5, 3, 3, 3.5, 4]),
               ([1., 1., 0., 0.], 3, [4, 3.5, 3, 3, 2.5, 2, 2, 1.5, 1]),
               ([-1., -1., 1., 1.], 3, [0, 0, 0, 0, 1, 2, 0, 3, 4])]
 
+# ---- tensorflow/python/kernel_tests/pooling_ops_test.py, _testMaxPoolSamePadding / _testAvgPoolSamePadding -----------------------------
+# input 1 .. 18 as [1, 2, 3, 3], 2 x 2 window, stride 2, SAME: the second window only covers the last column (the padding is on the right), -> 13 .. 18
+MAXPOOL_SAME_IN = np.arange(1, 19, dtype=np.float32).reshape(1, 2, 3, 3)
+MAXPOOL_SAME_OUT = np.array([13., 14., 15., 16., 17., 18.], np.float32).reshape(1, 1, 2, 3)
+# input 1 .. 24 as [1, 2, 4, 3], 2 x 2 average, stride 2, SAME -> 8.5, 9.5, 10.5, 14.5, 15.5, 16.5
+AVGPOOL_SAME_IN = np.arange(1, 25, dtype=np.float32).reshape(1, 2, 4, 3)
+AVGPOOL_SAME_OUT = np.array([8.5, 9.5, 10.5, 14.5, 15.5, 16.5], np.float32).reshape(1, 1, 2, 3)
+
 # ---- tensorflow/docs_src/api_guides/python/nn.md ("Convolution": the SAME / VALID diagram) ---------------------------------
 # input width 13, filter width 6, stride 5:  VALID keeps 2 windows and drops 12, 13;  SAME pads 1 left and 2 right -> 3 windows:
 #     pad| 0 |1 2 3 4 5 6 7 8 9 10 11 12 13| 0 0 |pad       out = ceil(13 / 5) = 3, total = (3 - 1) * 5 + 6 - 13 = 3, before = 3 // 2

@@ -126,6 +126,24 @@ def test_pooling_same_padding_tables(dev):
         assert torch.equal(ya[:, :3].float().cpu(), torch.from_numpy(K.AVGPOOL_SAME_OUT).reshape(2, 3))       # every table value is exact in bf16
 
 
+@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
+    "written after the round's GPU minutes were spent, never run on hardware (ODTK_RUN_UNVERIFIED=1 runs it); the same table pins the oracle, the shim and the "
+    "mocked launch on the CPU, and every convolution kernel is checked against torch in tests/test_gpu_kernels.py"))
+def test_conv2d_orientation_and_filter_layout(dev):
+    """conv_ops_test.py's testConv2D2x2Filter table on odtk_conv2d_fwd (f32 engine), the 2 x 2 filter embedded in the centre / bottom-right taps of a 3 x 3
+    one (SAME padding of a 3 x 3 filter pads one cell on every side: taps (1..2, 1..2) read x[h + 0..1, w + 0..1])"""
+    ops = _ops()
+    x, f, want = torch.from_numpy(K.CONV_IN), torch.from_numpy(K.CONV_FILTER_HWIO), torch.from_numpy(K.CONV_VALID_OUT)
+    d = ops.conv_desc(1, 2, 3, 4, 4, 3, 4, 3, 1, 1, ops.F32, ops.F32)
+    rows = torch.zeros(6, 4); rows[:, :3] = x.view(6, 3)
+    w = torch.zeros(3, 3, 3, 4)                       # [K][R][S][C padded to one chunk]
+    w[:, 1:, 1:, :3] = f.permute(3, 0, 1, 2)
+    y = torch.zeros(6, 4, device=dev)
+    ops.conv2d_fwd(d, rows.to(dev), w.reshape(-1).to(dev), None, y, False)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().view(2, 3, 4)[:1, :2, :3], want[0])          # integers below 2^24: exact in f32 whatever the summation order
+
+
 def test_fused_batch_norm_training_statistics(dev):
     ops = _ops()
     e = K.BN_EXPECT

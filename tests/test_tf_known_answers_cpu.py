@@ -126,6 +126,24 @@ def test_crop_and_resize_tables():
         assert torch.equal(tf_shim.image.crop_and_resize(img, b, torch.zeros(1, dtype=torch.int32), [crop, crop]).flatten(), want), box
 
 
+def test_conv2d_orientation_and_filter_layout():
+    """TensorFlow's conv2d is a cross-correlation over an HWIO filter: conv_ops_test.py's 2 x 2 table on the oracle, the shim and the mocked launch (the golden
+    fixtures cannot pin this: the shim that produced them defines its convolution through the same torch call)"""
+    import mock_ops
+    import odtk  # noqa: F401
+    from odtk import ops
+    x, f, want = torch.from_numpy(K.CONV_IN), torch.from_numpy(K.CONV_FILTER_HWIO), torch.from_numpy(K.CONV_VALID_OUT)
+    w_krsc = f.permute(3, 0, 1, 2).contiguous()
+    assert torch.equal(R.conv2d_same(x.permute(0, 3, 1, 2), w_krsc, None)[:, :, :1, :2].permute(0, 2, 3, 1), want)
+    assert torch.equal(tf_shim.nn.conv2d(x, f, [1, 1, 1, 1], 'SAME')[:, :1, :2], want)
+    d = ops.conv_desc(1, 2, 3, 4, 4, 3, 4, 2, 1, 1, ops.F32, ops.F32)
+    rows = torch.zeros(6, 4); rows[:, :3] = x.view(6, 3)
+    wp = torch.zeros(3, 2, 2, 4); wp[..., :3] = w_krsc
+    y = torch.zeros(6, 4)
+    mock_ops.conv2d_fwd(d, rows, wp.reshape(-1), None, y, False)
+    assert torch.equal(y.view(2, 3, 4)[:1, :2, :3], want[0])
+
+
 def test_pooling_same_padding_tables():
     import mock_ops
     x, want = torch.from_numpy(K.MAXPOOL_SAME_IN), torch.from_numpy(K.MAXPOOL_SAME_OUT)

@@ -71,6 +71,13 @@ CROP_CASES = [([0., 0., 1., 1.], 3, [1, 1.5, 2, 2, 2.5, 3, 3, 3.5, 4]),
               ([1., 1., 0., 0.], 3, [4, 3.5, 3, 3, 2.5, 2, 2, 1.5, 1]),
               ([-1., -1., 1., 1.], 3, [0, 0, 0, 0, 1, 2, 0, 3, 4])]
 
+# ---- tensorflow/python/kernel_tests/conv_ops_test.py, testConv2D2x2Filter --------------------------------------------------------------
+# input 1 .. 18 as [1, 2, 3, 3], filter 1 .. 36 as [2, 2, 3, 3] (HWIO), stride 1, VALID: cross-correlation (no tap flip), 6 outputs.
+# (With SAME padding a 2 x 2 filter pads bottom / right only: the VALID outputs are the [0:1, 0:2] corner of the SAME result.)
+CONV_IN = np.arange(1, 19, dtype=np.float32).reshape(1, 2, 3, 3)
+CONV_FILTER_HWIO = np.arange(1, 37, dtype=np.float32).reshape(2, 2, 3, 3)
+CONV_VALID_OUT = np.array([2271., 2367., 2463., 2901., 3033., 3165.], np.float32).reshape(1, 1, 2, 3)
+
 # ---- tensorflow/python/kernel_tests/pooling_ops_test.py, _testMaxPoolSamePadding / _testAvgPoolSamePadding -----------------------------
 # input 1 .. 18 as [1, 2, 3, 3], 2 x 2 window, stride 2, SAME: the second window only covers the last column (the padding is on the right), -> 13 .. 18
 MAXPOOL_SAME_IN = np.arange(1, 19, dtype=np.float32).reshape(1, 2, 3, 3)

@@ -144,6 +144,23 @@ def test_conv2d_orientation_and_filter_layout(dev):
     assert torch.equal(y.cpu().view(2, 3, 4)[:1, :2, :3], want[0])          # integers below 2^24: exact in f32 whatever the summation order
 
 
+@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
+    "written after the round's GPU minutes were spent, never run on hardware (ODTK_RUN_UNVERIFIED=1 runs it); the optimizer launch is covered by every whole-model "
+    "test against the oracles and by the in-situ shadows"))
+def test_momentum_optimizer_update_rule(dev):
+    """momentum_test.py's doBasic on odtk_sgd_momentum (weight decay 0, gradient scale 1; the buffers padded to one 64-element segment)"""
+    ops = _ops()
+    p_ = torch.zeros(64, device=dev); m_ = torch.zeros(64, device=dev); g_ = torch.zeros(64, device=dev)
+    p_[:2] = torch.from_numpy(K.MOMENTUM_VAR0).to(dev); g_[:2] = torch.from_numpy(K.MOMENTUM_GRAD).to(dev)
+    part = torch.zeros(ops.sgd_blocks(64), device=dev)
+    for step in range(2):
+        ops.sgd_momentum(p_, m_, g_, K.MOMENTUM_LR, K.MOMENTUM_M, 0.0, 1.0, part, None)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p_[:2].cpu().numpy(), K.MOMENTUM_AFTER[step], rtol=1e-6)
+        np.testing.assert_allclose(m_[:2].cpu().numpy(), K.MOMENTUM_ACCUM[step], rtol=1e-6)
+        assert float(p_[2:].abs().max()) == 0.0
+
+
 def test_fused_batch_norm_training_statistics(dev):
     ops = _ops()
     e = K.BN_EXPECT

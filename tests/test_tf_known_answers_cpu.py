@@ -144,6 +144,25 @@ def test_conv2d_orientation_and_filter_layout():
     assert torch.equal(y.view(2, 3, 4)[:1, :2, :3], want[0])
 
 
+def test_momentum_optimizer_update_rule():
+    """momentum_test.py's doBasic on the mocked fused optimizer launch (weight decay 0, gradient scale 1) and on the shim's optimizer (through a one-variable model)"""
+    import mock_ops
+    p_, m_, g_ = torch.from_numpy(K.MOMENTUM_VAR0).clone(), torch.zeros(2), torch.from_numpy(K.MOMENTUM_GRAD).clone()
+    for step in range(2):
+        mock_ops.sgd_momentum(p_, m_, g_, K.MOMENTUM_LR, K.MOMENTUM_M, 0.0, 1.0, torch.zeros(4), None)
+        np.testing.assert_allclose(p_.numpy(), K.MOMENTUM_AFTER[step], rtol=1e-6)
+        np.testing.assert_allclose(m_.numpy(), K.MOMENTUM_ACCUM[step], rtol=1e-6)
+    tf_shim.reset()
+    v = tf_shim.get_variable('v0', initializer=torch.from_numpy(K.MOMENTUM_VAR0).clone())
+    opt = tf_shim.train.MomentumOptimizer(K.MOMENTUM_LR, K.MOMENTUM_M)
+    for step in range(2):
+        tf_shim.S.pending = []
+        opt.minimize((v * torch.from_numpy(K.MOMENTUM_GRAD)).sum())
+        tf_shim._flush(True)
+        np.testing.assert_allclose(v.detach().numpy(), K.MOMENTUM_AFTER[step], rtol=1e-6)
+    tf_shim.reset()
+
+
 def test_pooling_same_padding_tables():
     import mock_ops
     x, want = torch.from_numpy(K.MAXPOOL_SAME_IN), torch.from_numpy(K.MAXPOOL_SAME_OUT)

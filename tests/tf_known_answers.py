@@ -71,6 +71,15 @@ CROP_CASES = [([0., 0., 1., 1.], 3, [1, 1.5, 2, 2, 2.5, 3, 3, 3.5, 4]),
               ([1., 1., 0., 0.], 3, [4, 3.5, 3, 3, 2.5, 2, 2, 1.5, 1]),
               ([-1., -1., 1., 1.], 3, [0, 0, 0, 0, 1, 2, 0, 3, 4])]
 
+# ---- tensorflow/python/training/momentum_test.py, testBasic (doBasic) ------------------------------------------------------------------
+# learning_rate 2.0, momentum 0.9, var0 = [1, 2] with gradient [0.1, 0.1] every step: accum = 0.9 * accum + g; var -= lr * accum
+#   step 1: accum 0.1, var0 = [1 - 0.1 * 2, 2 - 0.1 * 2];  step 2: accum 0.9 * 0.1 + 0.1, var0 = [1 - 0.1 * 2 - (0.9 * 0.1 + 0.1) * 2, ...]
+MOMENTUM_LR, MOMENTUM_M = 2.0, 0.9
+MOMENTUM_VAR0, MOMENTUM_GRAD = np.array([1.0, 2.0], np.float32), np.array([0.1, 0.1], np.float32)
+MOMENTUM_AFTER = [np.array([1.0 - 0.1 * 2.0, 2.0 - 0.1 * 2.0], np.float32),
+                  np.array([1.0 - 0.1 * 2.0 - (0.9 * 0.1 + 0.1) * 2.0, 2.0 - 0.1 * 2.0 - (0.9 * 0.1 + 0.1) * 2.0], np.float32)]
+MOMENTUM_ACCUM = [np.array([0.1, 0.1], np.float32), np.array([0.9 * 0.1 + 0.1, 0.9 * 0.1 + 0.1], np.float32)]
+
 # ---- tensorflow/python/kernel_tests/conv_ops_test.py, testConv2D2x2Filter --------------------------------------------------------------
 # input 1 .. 18 as [1, 2, 3, 3], filter 1 .. 36 as [2, 2, 3, 3] (HWIO), stride 1, VALID: cross-correlation (no tap flip), 6 outputs.
 # (With SAME padding a 2 x 2 filter pads bottom / right only: the VALID outputs are the [0:1, 0:2] corner of the SAME result.)

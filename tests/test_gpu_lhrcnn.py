@@ -307,7 +307,13 @@ def test_every_launch_in_situ_at_the_driver_shape(dtype):
         sh.recording = False
         torch.cuda.synchronize()
     assert bool(torch.isfinite(loss).all())
-    rows = sh.check(insitu.default_tol(dtype), verbose=True, label=f'lhrcnn {dtype} {H}x{W} batch {B}')
+    base_tol = insitu.default_tol(dtype)
+
+    def tol(row):
+        # the oracle recomputes the NMS scores from the engine's logits with another exp / log: two overlapping candidates whose scores differ in the last bit
+        # may swap, which moves two of a picture's 256 gradient rows (relative error sqrt(2 / (32 * 256)) = 1.6e-2 per swap); measured: no swap, 6.6e-8
+        return 5e-2 if row['op'] == 'lhrcnn_rpn_loss' else base_tol(row)
+    rows = sh.check(tol, verbose=True, label=f'lhrcnn {dtype} {H}x{W} batch {B}')
     seen = {x['op'] for x in rows}
     assert {'conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad', 'depthwise_conv', 'depthwise_wgrad', 'crop_and_resize_fwd', 'crop_and_resize_bwd', 'lhrcnn_rpn_loss',
             'lhrcnn_rcnn_loss', 'bn_fwd', 'bn_bwd', 'sgd_momentum'} <= seen

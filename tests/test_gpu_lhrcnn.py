@@ -224,10 +224,12 @@ def test_training_steps_vs_oracle():
         got_rpn, got_rcnn = float(m.last_losses[0]), float(m.last_losses[1])
         tol = 2e-4 if step == 0 else 5e-2       # step 2 starts from parameters that agree to ~1e-6: an NMS pick or a 0.5 / 0.3 IoU decision on a near-tie may flip (the
         #                                          reference-vs-oracle fixture saw 1.3 % from one such flip), measured 3 runs: within 5e-3
-        assert abs(got_rpn - rpn) < tol * abs(rpn) and abs(got_rcnn - rcnn) < tol * abs(rcnn), (step, got_rpn, rpn, got_rcnn, rcnn)
+        # the R-CNN loss gets a looser first-step bound than the RPN loss: crops of proposals clamped to the picture put their last sample row ON the border, where
+        # the last bits of the proposal decide inside / extrapolated (tests/test_hip_cpu.py has the measurement); measured here: 2e-4 on both
+        assert abs(got_rpn - rpn) < tol * abs(rpn) and abs(got_rcnn - rcnn) < max(tol, 5e-3) * abs(rcnn), (step, got_rpn, rpn, got_rcnn, rcnn)
         assert loss == (got_rpn if step == 0 else got_rcnn)
         if step == 0:
-            assert abs(got_rpn - gold['rpn_losses'][0]) < 2e-4 * gold['rpn_losses'][0] and abs(got_rcnn - gold['rcnn_losses'][0]) < 2e-4 * gold['rcnn_losses'][0]
+            assert abs(got_rpn - gold['rpn_losses'][0]) < 2e-4 * gold['rpn_losses'][0] and abs(got_rcnn - gold['rcnn_losses'][0]) < 5e-3 * gold['rcnn_losses'][0]
             # the UPDATE of every variable (lr * momentum-accumulated gradient; moving statistics: their 1 % move) against the oracle's, relative to the
             # largest entry of that update -- the bound of the other classes' whole-model tests (batch-norm backward over 2 x 10 x 13 samples amplifies the
             # summation-order differences of the f32 convolutions)

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
 #include <algorithm>
@@ -19,8 +20,17 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
 struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -28,6 +38,12 @@ constexpr hipError_t hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "no error (CPU emulation)"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : 2; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
+template <typename F> inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 
 #define __global__
 #define __device__
@@ -42,6 +58,20 @@ using std::min;
 inline float __fmul_rn(float a, float b) { return a * b; }      // (built with -ffp-contract=off: no fused multiply-add, as in the device build)
 inline float __fadd_rn(float a, float b) { return a + b; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
+inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+inline unsigned atomicMax(unsigned* p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
+inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
+inline unsigned atomicOr(unsigned* p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
 inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 
@@ -67,6 +97,9 @@ struct Block {
     std::function<void()> body;
 };
 inline Block*& current() { static Block* b = nullptr; return b; }
+// dynamic shared memory (the 4th launch argument): the backend rewrites `extern __shared__ T name[];` into `T* name = (T*)hipcpu::dynamic_smem();`
+inline std::vector<unsigned long long>& dyn_buf() { static std::vector<unsigned long long> v; return v; }
+inline void* dynamic_smem() { return dyn_buf().data(); }
 inline void yield() { Block* b = current(); swapcontext(&b->cur->uc, &b->sched); }
 inline void trampoline() {
     Block* b = current();
@@ -102,9 +135,10 @@ inline void run_block(Block& b) {
     current() = nullptr;
 }
 template <typename F>
-inline void launch(dim3 grid, dim3 block, F&& f) {
+inline void launch(dim3 grid, dim3 block, size_t shmem, F&& f) {
     static Block b;                                   // fibers (and their stacks) are reused from launch to launch
     b.dim = block; b.grid = grid;
+    if (dyn_buf().size() * 8 < shmem + 16) dyn_buf().resize(shmem / 8 + 2);
     b.body = std::function<void()>(f);
     for (unsigned z = 0; z < grid.z; ++z)
         for (unsigned y = 0; y < grid.y; ++y)
@@ -157,4 +191,34 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipcpu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+template <typename T>
+inline T __shfl(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "shuffle of at most 8 bytes");
+    unsigned long long bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    const unsigned long long* all = hipcpu::exchange(bits);
+    T out;
+    memcpy(&out, &all[(unsigned)src_lane & 63u], sizeof(T));
+    return out;
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned delta) {
+    static_assert(sizeof(T) <= 8, "shuffle of at most 8 bytes");
+    unsigned long long bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    const unsigned long long* all = hipcpu::exchange(bits);
+    const unsigned lane = hipcpu::flat_tid() % 64, src = lane + delta;
+    T out;
+    memcpy(&out, &all[src < 64 ? src : lane], sizeof(T));
+    return out;
+}
+inline int __any(int pred) { return __ballot(pred) != 0ull; }
+inline int __all(int pred) { return __ballot(pred) == ~0ull; }
+// compile-only stand-ins for csrc/boxes.hip (its NMS kernels are NOT run under the emulation: they rely on the implicit lock-step of a wave between fences)
+inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipcpu::launch((grid), (block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); })

@@ -1,11 +1,15 @@
 """TEST INFRASTRUCTURE ONLY: the non-MFMA kernels of libodtk compiled with g++ against tests/hip_cpu/hip/hip_runtime.h (workgroups run one after the other, their
 threads as fibers that switch at __syncthreads / wave shuffles / ballots) and bound to odtk.ops, so that the test bodies written for the GPU run on the CPU from
-the SAME kernel source.  `with installed():` patches, for the entry points the CPU build exports (csrc/lhrcnn.hip, csrc/augment.hip), the pointer / stream helpers
-of odtk.ops and its C-ABI call; odtk_nms_batched (csrc/boxes.hip: DPP and LDS-DMA code, not emulated) is replaced by the oracle's NMS with the kernel's operand
-addressing."""
+the SAME kernel source.  `with installed():` patches, for the entry points the CPU build exports, the pointer / stream helpers of odtk.ops and its C-ABI call.
+Built: csrc/lhrcnn.hip, augment.hip, elementwise.hip, dense_heads.hip, retina.hip, refinedet.hip, centernet_net.hip.  Not built: csrc/conv*.hip (MFMA, LDS-DMA),
+csrc/boxes.hip (DPP, code that relies on the implicit lock-step of a wave between fences) -- odtk_nms_batched is replaced by the oracle's NMS with the kernel's
+operand addressing -- and csrc/api.hip (device queries; its two helpers are tests/hip_cpu/stubs.cpp).
+The only change made to a source on its way into the build: `extern __shared__ T name[];` (dynamic LDS: one line in dense_heads.hip) becomes
+`T* name = reinterpret_cast<T*>(hipcpu::dynamic_smem());`, the buffer being sized from the launch's 4th argument."""
 import contextlib
 import ctypes as C
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -15,45 +19,79 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, 'object-detection-tensorflow_amd', 'csrc')
-SOURCES = [os.path.join(CSRC, 'lhrcnn.hip'), os.path.join(CSRC, 'augment.hip'), os.path.join(HERE, 'hip_cpu', 'stubs.cpp')]
+KERNEL_FILES = ['lhrcnn.hip', 'augment.hip', 'elementwise.hip', 'dense_heads.hip', 'retina.hip', 'refinedet.hip', 'centernet_net.hip', 'boxes.hip']
+DYN_SMEM = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\([^)]*\)\)\)\s+)?([A-Za-z_ ]+[A-Za-z_])\s+([A-Za-z_0-9]+)\[\];')
 _LIB = None
 
 
 def build():
-    """g++ build of the kernel sources, cached next to the temp dir by the newest source time stamp"""
+    """g++ build of the kernel sources, cached in the temp dir by the newest source time stamp"""
     global _LIB
     if _LIB is not None:
         return _LIB
-    deps = SOURCES + [os.path.join(HERE, 'hip_cpu', 'hip', 'hip_runtime.h'), os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'augment_resize.h'),
-                      os.path.join(ROOT, 'include', 'odtk.h')]
+    srcs = [os.path.join(CSRC, f) for f in KERNEL_FILES]
+    deps = srcs + [os.path.join(HERE, 'hip_cpu', 'stubs.cpp'), os.path.join(HERE, 'hip_cpu', 'hip', 'hip_runtime.h'), os.path.join(CSRC, 'common.h'),
+                   os.path.join(CSRC, 'augment_resize.h'), os.path.join(ROOT, 'include', 'odtk.h'), os.path.abspath(__file__)]
     stamp = int(max(os.path.getmtime(f) for f in deps))
     so = os.path.join(tempfile.gettempdir(), f'libodtk_cpu_{os.getuid()}_{stamp}.so')
     if not os.path.exists(so):
+        work = tempfile.mkdtemp(prefix='odtk_cpu_build_')
+        copies = []
+        for f in srcs:
+            text = open(f).read()
+            text = DYN_SMEM.sub(lambda m: f'{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipcpu::dynamic_smem());', text)
+            dst = os.path.join(work, os.path.basename(f) + '.cpp')
+            open(dst, 'w').write(text)
+            copies.append(dst)
         tmp = so + f'.{os.getpid()}.tmp'
-        subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-x', 'c++', '-I', os.path.join(HERE, 'hip_cpu'), '-I', CSRC]
-                              + SOURCES + ['-o', tmp])
+        subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-I', os.path.join(HERE, 'hip_cpu'), '-I', CSRC]
+                              + copies + [os.path.join(HERE, 'hip_cpu', 'stubs.cpp'), '-o', tmp])
         os.replace(tmp, so)
     _LIB = C.CDLL(so)
     return _LIB
 
 
+def _flat(t):
+    """(whole storage of t as a flat tensor, element offset of t in it): the kernels get a raw pointer and address past the view they were handed"""
+    return torch.empty(0, dtype=t.dtype).set_(t.untyped_storage()), t.storage_offset()
+
+
 def _nms_batched(boxes, box_stride, scores, score_bstride, score_estride, valid, valid_bstride, valid_estride, valid_value, n, B, max_out_dev, max_out_stride,
                  max_out_const, iou_thr, out_idx, cap, out_cnt):
+    """odtk_nms_batched's operand addressing (include/odtk.h) around the oracle's NonMaxSuppressionV3"""
     sys.path.insert(0, ROOT)
     from oracle import ssd300_ref as R
-    bx, sc = boxes.reshape(-1), scores.reshape(-1)
-    vd = valid.reshape(-1) if valid is not None else None
+    bx, b0 = _flat(boxes)
+    sc, s0 = _flat(scores)
+    vd, v0 = _flat(valid) if valid is not None else (None, 0)
+    mo, m0 = _flat(max_out_dev) if max_out_dev is not None else (None, 0)
+    oi, o0 = _flat(out_idx)
+    oc, c0 = _flat(out_cnt)
     idx = torch.arange(n)
     for b in range(B):
-        bb = bx[b * box_stride: b * box_stride + 4 * n].reshape(n, 4)
-        ss = sc[b * score_bstride + idx * score_estride]
-        ok = torch.ones(n, dtype=torch.bool) if vd is None else (vd[b * valid_bstride + idx * valid_estride] == valid_value)
+        bb = bx[b0 + b * box_stride: b0 + b * box_stride + 4 * n].reshape(n, 4)
+        ss = sc[s0 + b * score_bstride + idx * score_estride]
+        ok = torch.ones(n, dtype=torch.bool) if vd is None else (vd[v0 + b * valid_bstride + idx * valid_estride] == valid_value)
         rows = torch.nonzero(ok).flatten()
-        k_max = int(max_out_dev.reshape(-1)[b * max_out_stride]) if max_out_dev is not None else int(max_out_const)
+        k_max = int(mo[m0 + b * max_out_stride]) if mo is not None else int(max_out_const)
         sel = torch.from_numpy(R.nms(bb[rows].numpy(), ss[rows].numpy(), k_max, float(iou_thr)).astype('int64'))
         k = min(sel.numel(), cap)
-        out_idx.view(B, cap)[b, :k] = rows[sel[:k]].to(out_idx.dtype)
-        out_cnt.view(-1)[b] = k
+        oi[o0 + b * cap: o0 + b * cap + k] = rows[sel[:k]].to(oi.dtype)
+        oc[c0 + b] = k
+
+
+class _Lib:
+    """what odtk._lib.load() hands out while the emulation is installed: the CPU build first, the real library for host-only helpers it does not have"""
+
+    def __init__(self, cpu, real):
+        self._cpu, self._real = cpu, real
+
+    def __getattr__(self, name):
+        if hasattr(self._cpu, name):
+            return getattr(self._cpu, name)
+        if self._real is None:
+            raise AttributeError(name)
+        return getattr(self._real, name)
 
 
 @contextlib.contextmanager
@@ -68,17 +106,33 @@ def installed():
 
     def call(name, *args):
         if not hasattr(lib, name):
-            raise RuntimeError(f'{name} is not part of the CPU-emulated build (only csrc/lhrcnn.hip and csrc/augment.hip are)')
+            raise RuntimeError(f'{name} is not part of the CPU-emulated build ({", ".join(KERNEL_FILES)})')
         rc = getattr(lib, name)(*args)
         if rc != 0:
             raise _lib.OdtkError(f'libodtk (CPU emulation) error {rc}: {lib.odtk_last_error().decode()}')
-    old = dict(call=ops.call, _p=ops._p, _stream=ops._stream, nms=ops.nms_batched, sync=torch.cuda.synchronize)
+    old = dict(call=ops.call, _p=ops._p, _stream=ops._stream, nms=ops.nms_batched, sync=torch.cuda.synchronize, load=_lib.load)
+    try:
+        real = _lib.load()
+    except Exception:                                        # noqa: BLE001 -- no GPU build next to the package: the CPU build alone
+        real = None
+    proxy = _Lib(lib, real)
     ops.call = call
     ops._p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     ops._stream = lambda: None
     ops.nms_batched = _nms_batched
+    _lib.load = lambda: proxy
     torch.cuda.synchronize = lambda *a, **k: None
+    # `t.to(device)` is a COPY in the GPU test bodies (host -> device); towards the CPU torch hands back the same tensor, and a kernel that updates its
+    # operand in place would then also change the test's reference copy
+    orig_to = torch.Tensor.to
+
+    def to_copy(self, *a, **k):
+        r = orig_to(self, *a, **k)
+        dev_arg = (a and isinstance(a[0], (torch.device, str))) or 'device' in k
+        return r.clone() if (dev_arg and r.data_ptr() == self.data_ptr() and r.numel()) else r
+    torch.Tensor.to = to_copy
     try:
         yield names
     finally:
-        ops.call, ops._p, ops._stream, ops.nms_batched, torch.cuda.synchronize = old['call'], old['_p'], old['_stream'], old['nms'], old['sync']
+        torch.Tensor.to = orig_to
+        ops.call, ops._p, ops._stream, ops.nms_batched, torch.cuda.synchronize, _lib.load = old['call'], old['_p'], old['_stream'], old['nms'], old['sync'], old['load']

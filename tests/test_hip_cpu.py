@@ -183,3 +183,66 @@ def test_augmentor_kernels_from_source_vs_reference(augment_on_cpu, fname):
             np.testing.assert_allclose(torch.Tensor(out).numpy(), want, rtol=0, atol=2e-3, err_msg=n)
             if m['kwargs']['fill_mode'] == 'NEAREST_NEIGHBOR' and m['kwargs'].get('color_jitter_prob') is None:
                 assert np.array_equal(torch.Tensor(out).numpy(), want), n
+
+
+# ------------------------------------------------------------------------------------------------------------------ the other non-MFMA files from source
+# elementwise.hip (batch norm in its one / two / three-launch forms, pools with recorded arg-max, L2-norm, column sums, the fused optimizer, resize, channel copies,
+# preprocess), boxes.hip WITHOUT its NMS kernels (priors, matching, SSD loss, decode), retina.hip, dense_heads.hip, refinedet.hip: the GPU test bodies, device = CPU.
+CPU = torch.device('cpu')
+
+
+def _run(module, name, **kw):
+    mod = __import__(module)
+    with HC.installed():
+        getattr(mod, name)(dev=CPU, **kw)
+
+
+@pytest.mark.parametrize('launches', [1, 10, 2, 3, 0], ids=['one-launch', 'one-launch-64ch', 'two-launches', 'three-launches', 'auto'])
+@pytest.mark.parametrize('shape,dt,ydt', [((2 * 19 * 19, 1024, True), 'f32', 'f32'), ((3 * 5 * 5, 150, False), 'bf16', 'bf16'), ((6 * 38 * 38, 100, False), 'bf16', 'f32')])
+def test_batchnorm_from_source(shape, dt, ydt, launches):
+    _run('test_gpu_kernels', 'test_batchnorm', shape=shape, dt=dt, ydt=ydt, launches=launches)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_pools_from_source(dt):
+    _run('test_gpu_kernels', 'test_maxpool', geom=(2, 19, 19, 32, 3, 1), dt=dt)
+    _run('test_gpu_kernels', 'test_maxpool', geom=(1, 38, 38, 8, 2, 2), dt=dt)
+    _run('test_gpu_kernels', 'test_maxpool2x2_recorded_argmax_equals_gather_path', geom=(3, 9, 13, 40), dt=dt)
+    _run('test_gpu_kernels', 'test_maxpool_recorded_argmax_overlapping_windows', geom=(3, 9, 13, 40, 3, 2), dt=dt)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_l2norm_colsum_sgd_resize_copy_from_source(dt):
+    _run('test_gpu_kernels', 'test_l2norm_colsum_sgd', dt=dt)
+    _run('test_gpu_kernels', 'test_resize_bilinear_align_corners_any_scale', geom=(1, 10, 12, 3, 5, 16, True), dt=dt)
+    _run('test_gpu_kernels', 'test_copy_channels_unaligned_concat', dt=dt)
+
+
+def test_ssd_box_side_from_source():
+    _run('test_gpu_kernels', 'test_preprocess')
+    _run('test_gpu_kernels', 'test_priors_bit_exact')
+    _run('test_gpu_kernels', 'test_match_bit_exact')
+    _run('test_gpu_kernels', 'test_ssd_loss_and_grad_vs_oracle')
+    _run('test_gpu_kernels', 'test_decode_and_detect_vs_oracle')
+    _run('test_gpu_kernels', 'test_loss_total_and_zero', n=1000)
+
+
+def test_retina_box_side_from_source():
+    _run('test_gpu_retina', 'test_retina_anchors_bit_exact', data_shape=[320, 256, 3])
+    _run('test_gpu_retina', 'test_retina_match_indices_bit_exact', data_shape=[320, 256, 3], seed=1)
+    _run('test_gpu_retina', 'test_retina_loss_vs_reference_golden')
+    _run('test_gpu_retina', 'test_retina_loss_and_grad_vs_oracle', data_shape=[320, 256, 3], gamma=2.0)
+    _run('test_gpu_retina', 'test_retina_decode_candidates')
+
+
+def test_dense_heads_from_source():
+    for name in ('test_centernet_loss_golden_inputs', 'test_fcos_loss_golden_inputs', 'test_yolov3_loss_golden_inputs', 'test_fcos_decode_candidates',
+                 'test_yolov3_decode_candidates', 'test_full_inference_tails_vs_reference', 'test_fcos_loss_config5_shape', 'test_yolov3_loss_config4_shape'):
+        _run('test_gpu_dense_heads', name)
+    _run('test_gpu_dense_heads', 'test_centernet_decode', img=1, shift=3.0, thr=0.1, topk=100)
+
+
+def test_refinedet_box_side_from_source():
+    _run('test_gpu_refinedet', 'test_anchors_bit_exact', size=320)
+    _run('test_gpu_refinedet', 'test_loss_matches_reference_numbers_and_oracle_gradients')
+    _run('test_gpu_refinedet', 'test_inference_tail_matches_reference_detections')

@@ -246,3 +246,50 @@ def test_refinedet_box_side_from_source():
     _run('test_gpu_refinedet', 'test_anchors_bit_exact', size=320)
     _run('test_gpu_refinedet', 'test_loss_matches_reference_numbers_and_oracle_gradients')
     _run('test_gpu_refinedet', 'test_inference_tail_matches_reference_detections')
+
+
+def test_tensorflow_op_test_tables_on_the_kernels_from_source(augment_on_cpu):
+    """TensorFlow's own tables (tests/tf_known_answers.py) on the kernel source: the three GPU cases that have not run on hardware yet (crop_and_resize, SAME pooling,
+    the momentum update), the TF-1.x resize grid, the fused batch-norm statistics -- through the bodies of tests/test_gpu_tf_known_answers.py"""
+    import test_gpu_tf_known_answers as T
+    with HC.installed():
+        T.test_crop_and_resize_tables(CPU)
+        T.test_pooling_same_padding_tables(CPU)
+        T.test_momentum_optimizer_update_rule(CPU)
+        T.test_fused_batch_norm_training_statistics(CPU)
+        for dt in ('f32', 'bf16'):
+            T.test_resize_bilinear_legacy_grid(dt, CPU)
+
+
+def test_whole_class_bf16_engine_with_the_kernels_from_source(lh_kernels_in_the_mock):
+    """the opt-in bf16 engine of LHRCNN (never run on hardware as a whole) for one training step and one inference with the LH_RCNN kernels executing from source on
+    bf16 storage: depthwise4<bf16>, crop rows in bf16, the head's outputs widened to f32 in front of lh_rcnn_loss_kernel, the crop gradient through its f32 scratch"""
+    import odtk
+    from oracle import lhrcnn_ref as LR
+    from test_models_host_logic_cpu import _lhrcnn_cfg
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(901)
+    imgs = (torch.rand(2, 320, 416, 3, generator=g) * 255).round()
+    gt = LR.synthetic_gt(2, 320, 416, 911)
+    p = LR.init_params(71)
+    m = odtk.LHRCNN(_lhrcnn_cfg('train', 2, compute_dtype='bf16'), {'data_shape': [320, 416, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+    m.load_oracle_params(p)
+    m.set_batch(imgs, gt)
+    before = m.P.clone()
+    m.train_step(0.003)
+    rpn, rcnn = LR.losses(p, imgs, gt)
+    st = m.loss
+    assert abs(float(m.last_losses[0]) - float(rpn)) < 0.2 * float(rpn) and 0.2 * float(rcnn) < float(m.last_losses[1]) < 5. * float(rcnn)
+    assert st.roi.dtype == torch.bfloat16 and float(st.roi.float().abs().max()) > 0 and torch.equal(st.logits32, st.logits.float())
+    assert torch.equal(st.d_logits.float(), st.d_logits32.to(torch.bfloat16).float()) and torch.equal(m.feat.g.float(), st.d_feat32.to(torch.bfloat16).float())
+    kp, kn = [int(v) for v in st.ws['roi_counts'].sum(0)]
+    assert 0 < kp <= 2 * 128 and 0 < kn and float(st.roi[256 + int(st.ws['roi_counts'][1].sum()):].float().abs().max()) == 0.0        # empty slots are zero rows
+    assert bool(torch.isfinite(m.P).all()) and not torch.equal(m.P, before)
+    gd = np.load(os.path.join(HERE, 'golden', 'lhrcnn_detect.npz'))
+    for k in gd.files:
+        if k.startswith('stat__'):
+            p[k[6:].replace('__', '.')] = torch.from_numpy(gd[k])
+    mt = odtk.LHRCNN(_lhrcnn_cfg('test', 1, nms_score_threshold=float(gd['score_threshold']), post_nms_proposal=int(gd['post_nms_proposal']), compute_dtype='bf16'), None)
+    mt.load_oracle_params(p)
+    scores, bbox, cid = mt.test_one_image((torch.from_numpy(gd['image']).float() / 127.5 - 1.).numpy())
+    assert len(scores) > 0.5 * len(gd['scores']) and np.isfinite(bbox).all()

@@ -693,6 +693,166 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
     fin[C + c] = s2 / (float)M;
 }
 
+// ---- statistics + finalize in ONE launch (opt-in, odtk_debug_set key 4 value -7; default off, not yet measured on the GPU) ----------------------------------
+// YOLOv3 at 8 images / GPU spends 1.45 of its 11.1 ms in the 150 finalize launches of a step (profiles/r03k_yolov3_416_b8_kernel_trace.md: 10 us each for a few
+// hundred channels).  Folding the finalize into the APPLY prologue was slower (every apply workgroup re-reduces 169-256 partials, round 3); here the workgroup that
+// writes the LAST partial of a column group finishes that group: partials -> __threadfence -> ticket (one int per column group, self-resetting, library-owned per
+// stream) -> the last arriver sums the nsplit partials of its 8 chunks in a fixed order (same result whatever the arrival order) and writes what the finalize
+// kernels write.  The statistics loops below are copies of bn_stats_kernel / bn_bwd_stats_kernel: those stay byte-identical.
+template <int KC>
+__device__ __forceinline__ bool bn_ticket_is_last(int* __restrict__ tickets, int nsplit) {
+    __shared__ int s_last;
+    __threadfence();                                   // this workgroup's partials are visible device-wide before its ticket is drawn
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1) == nsplit - 1;
+    __syncthreads();
+    if (s_last) __threadfence();
+    return s_last != 0;
+}
+// sums of the [2][nsplit][C] partials for the 8 * KC channels of column group blockIdx.x: result valid in the threads with lane == 0
+template <int KC>
+__device__ __forceinline__ void bn_ticket_reduce(const float* __restrict__ ws, int nsplit, int C, int& c, int& lane, float& s1, float& s2) {
+    constexpr int CH = 8 * KC, LANES = 256 / CH;
+    __shared__ float sm[2][LANES][CH];
+    const int ch = threadIdx.x % CH;
+    lane = threadIdx.x / CH;
+    c = blockIdx.x * CH + ch;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+        for (int s = lane; s < nsplit; s += LANES) {      // device-scope loads: the partials were written by other compute units
+            a1 += __hip_atomic_load(ws + ((size_t)0 * nsplit + s) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a2 += __hip_atomic_load(ws + ((size_t)1 * nsplit + s) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    sm[0][lane][ch] = a1;
+    sm[1][lane][ch] = a2;
+    __syncthreads();
+    s1 = 0.f; s2 = 0.f;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < LANES; ++k) { s1 += sm[0][k][ch]; s2 += sm[1][k][ch]; }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_stats_fin_kernel(const T* __restrict__ z, int M, int C, int ldz, int rows_per_split, float* __restrict__ ws,
+                                                           int* __restrict__ tickets, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, float* __restrict__ fin) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    float acc[2 * KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        float sh[KC];
+        Chunk<T>::unpack(ld16(z + c0), sh);
+        const int m0 = split * rows_per_split;
+        int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
+#pragma unroll 4
+        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                const float d = f[e] - sh[e];
+                acc[e] += d;
+                acc[KC + e] += d * d;
+            }
+        }
+    }
+    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    if (rl == 0 && c0 < C) {
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            if (c0 + e < C) {
+                ws[((size_t)0 * nsplit + split) * C + c0 + e] = acc[e];
+                ws[((size_t)1 * nsplit + split) * C + c0 + e] = acc[KC + e];
+            }
+        }
+    }
+    if (!bn_ticket_is_last<KC>(tickets, nsplit)) return;
+    int c, lane;
+    float s1, s2;
+    bn_ticket_reduce<KC>(ws, nsplit, C, c, lane, s1, s2);
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;       // every workgroup of this column group has drawn: ready for the next launch
+    if (c >= C || lane != 0) return;
+    const float d = s1 / (float)M;                        // (bn_finalize_kernel's arithmetic)
+    const float mean = elem<T>::load(z[c]) + d;
+    const float var = fmaxf(s2 / (float)M - d * d, 0.f);
+    save_mean[c] = mean;
+    save_invstd[c] = rsqrtf(var + 1e-3f);
+    const float unb = var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+    mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
+    mvar[c] = mvar[c] * 0.99f + unb * (1.f - 0.99f);
+    const float sc = rsqrtf(var + 1e-3f) * gamma[c];
+    fin[c] = sc;
+    fin[C + c] = beta[c] - mean * sc;
+}
+
+template <typename T, typename TY>
+__global__ void __launch_bounds__(256) bn_bwd_stats_fin_kernel(
+    const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
+    int rows_per_img, long long y_img_stride, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, int relu, int vec_ok, int rows_per_split, float* __restrict__ ws,
+    int* __restrict__ tickets, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ fin) {
+    constexpr int KC = Chunk<T>::N;
+    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + cl) * KC;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    float acc[2 * KC];
+#pragma unroll
+    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        float mu[KC], iv[KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            mu[e] = c0 + e < C ? save_mean[c0 + e] : 0.f;
+            iv[e] = c0 + e < C ? save_invstd[c0 + e] : 0.f;
+        }
+        const int m0 = split * rows_per_split;
+        int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
+#pragma unroll 2
+        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+            float f[KC];
+            Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
+            const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
+            float d[KC];
+            bn_load_dy<T, TY>(y, dy, oo, c0, C, relu, vec_ok, d);
+#pragma unroll
+            for (int e = 0; e < KC; ++e) {
+                if (c0 + e >= C) continue;
+                acc[e] += d[e];
+                acc[KC + e] += d[e] * ((f[e] - mu[e]) * iv[e]);
+            }
+        }
+    }
+    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    if (rl == 0 && c0 < C) {
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            if (c0 + e < C) {
+                ws[((size_t)0 * nsplit + split) * C + c0 + e] = acc[e];
+                ws[((size_t)1 * nsplit + split) * C + c0 + e] = acc[KC + e];
+            }
+        }
+    }
+    if (!bn_ticket_is_last<KC>(tickets, nsplit)) return;
+    int c, lane;
+    float s1, s2;
+    bn_ticket_reduce<KC>(ws, nsplit, C, c, lane, s1, s2);
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
+    if (c >= C || lane != 0) return;
+    dbeta[c] = s1;                                        // (bn_bwd_finalize_kernel's outputs)
+    dgamma[c] = s2;
+    fin[c] = s1 / (float)M;
+    fin[C + c] = s2 / (float)M;
+}
+
 template <typename T, typename TY>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
@@ -1258,7 +1418,33 @@ static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0). 
 static bool g_bn_auto_two = true;         // odtk_debug_set key 4, value -5: never pick the two-launch path by itself (round-2 behaviour; A/B); -6: back
 static bool g_bn_small_wide = false;      // odtk_debug_set key 4, value -3: the single-launch kernels in their 64-channel shape only (A/B); -4: back
 static bool g_bn_three_kernels = true;    // odtk_debug_set key 4, value -2: statistics + apply-with-finalize (two launches; A/B, tests); -1: back to three
-namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else if (rows == -5) g_bn_auto_two = false; else if (rows == -6) g_bn_auto_two = true; else g_bn_small_rows = rows; } }
+static bool g_bn_ticket = false;          // odtk_debug_set key 4, value -7: where three launches would run, the statistics launch finishes its column groups by
+                                          // ticket and the finalize launch is dropped (bn_stats_fin_kernel; NOT yet measured on the GPU); -8: back (default)
+namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else if (rows == -5) g_bn_auto_two = false; else if (rows == -6) g_bn_auto_two = true; else if (rows == -7) g_bn_ticket = true; else if (rows == -8) g_bn_ticket = false; else g_bn_small_rows = rows; } }
+
+// Tickets of the statistics-with-finalize launches: one zero-initialised, self-resetting int per column group, in a library-owned buffer per (device, stream) --
+// launches on ONE stream are ordered and share a set; a caller with concurrent streams (SSD300's head stream) gets one set per stream, at most 8 per device
+// (a ninth stream falls back to the three launches).  Never freed or moved (captured graphs point into it).
+constexpr int BN_TICKET_SETS = 8, BN_TICKET_INTS = 4096;
+static int* g_bn_tickets[16] = {};
+static hipStream_t g_bn_ticket_stream[16][BN_TICKET_SETS];
+static int g_bn_ticket_used[16] = {};
+static int* bn_tickets_for(hipStream_t st, int colgroups) {
+    if (colgroups > BN_TICKET_INTS) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!g_bn_tickets[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)BN_TICKET_SETS * BN_TICKET_INTS * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, (size_t)BN_TICKET_SETS * BN_TICKET_INTS * sizeof(int)) != hipSuccess) return nullptr;     // synchronous, once per device
+        g_bn_tickets[dev] = (int*)p;
+    }
+    for (int i = 0; i < g_bn_ticket_used[dev]; ++i)
+        if (g_bn_ticket_stream[dev][i] == st) return g_bn_tickets[dev] + (size_t)i * BN_TICKET_INTS;
+    if (g_bn_ticket_used[dev] == BN_TICKET_SETS) return nullptr;
+    g_bn_ticket_stream[dev][g_bn_ticket_used[dev]] = st;
+    return g_bn_tickets[dev] + (size_t)(g_bn_ticket_used[dev]++) * BN_TICKET_INTS;
+}
 
 #define DT_SWITCH(dtype, T, ...)                                         \
     if ((dtype) == ODTK_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
@@ -1410,6 +1596,7 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     }
     float* ws = (float*)workspace;
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    bool ticketed = false;
     if (training) {
         // Two launches (statistics; apply with the finalize folded into its prologue) where <= 32 row splits still fill the chip for the statistics pass
         // (>= 128 workgroups: the 256-1 024-channel layers of DarkNet-53 at 8 images: the finalize launch alone was 8-10 us of latency, x 150 per step)
@@ -1418,8 +1605,15 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
         // 8 images LOSE 1 % of theirs -- hence the size condition on top.
         const bool two = !g_bn_three_kernels || (g_bn_auto_two && plc.colgroups * plc.nsplit >= 128 && M >= 8192 && C >= 512);
         const RedPlan pl = two ? plc : red_plan(M, C, kc);
+        int* tickets = (!two && g_bn_ticket) ? bn_tickets_for(st, pl.colgroups) : nullptr;
+        if (tickets) {                                   // statistics + finalize of each column group by its last workgroup; the apply launch follows below
+            DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_fin_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st, (const T*)z, M, C, ldz,
+                                                   pl.rows_per_split, ws, tickets, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, fin);)
+            ticketed = true;
+        } else {
         DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
                                                (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
+        }
         if (two) {                                       // statistics, then apply with the finalize folded in
             const int rpb = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
             dim3 gridf(pl.colgroups, ceil_div(M, rpb));
@@ -1436,9 +1630,11 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
             return ODTK_OK;
         }
     }
+    if (!ticketed) {
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M,
                                            C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
                                            pl.nsplit, fin);)
+    }
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
     const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
@@ -1506,6 +1702,20 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
         else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD_FIN(float, float); }
         else ODTK_REQUIRE(false, "bn_bwd: bad dtype");
 #undef BN_BWD_FIN
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
+    if (int* tickets = g_bn_ticket ? bn_tickets_for(st, pl.colgroups) : nullptr) {       // sums + finalize by ticket, then the apply launch
+#define BN_BWD_TICKET(T, TY)                                                                                                      \
+    hipLaunchKernelGGL((bn_bwd_stats_fin_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz, ldy,   \
+                       rows_per_img, y_img_stride, save_mean, save_invstd, relu, vec_ok, pl.rows_per_split, ws, tickets, dgamma, dbeta, fin); \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz, ldy,       \
+                       rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, fin, rows_per_block)
+        if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_BWD_TICKET(bf16_t, bf16_t); }
+        else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_BWD_TICKET(bf16_t, float); }
+        else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD_TICKET(float, float); }
+        else ODTK_REQUIRE(false, "bn_bwd: bad dtype");
+#undef BN_BWD_TICKET
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }

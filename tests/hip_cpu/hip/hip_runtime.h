@@ -38,6 +38,7 @@ constexpr hipError_t hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "no error (CPU emulation)"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : 2; }
 template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
@@ -99,6 +100,7 @@ struct Block {
 inline Block*& current() { static Block* b = nullptr; return b; }
 // dynamic shared memory (the 4th launch argument): the backend rewrites `extern __shared__ T name[];` into `T* name = (T*)hipcpu::dynamic_smem();`
 inline std::vector<unsigned long long>& dyn_buf() { static std::vector<unsigned long long> v; return v; }
+inline long long& launch_counter() { static long long n = 0; return n; }      // kernel launches so far (tests assert launch counts with it)
 inline void* dynamic_smem() { return dyn_buf().data(); }
 inline void yield() { Block* b = current(); swapcontext(&b->cur->uc, &b->sched); }
 inline void trampoline() {
@@ -137,6 +139,7 @@ inline void run_block(Block& b) {
 template <typename F>
 inline void launch(dim3 grid, dim3 block, size_t shmem, F&& f) {
     static Block b;                                   // fibers (and their stacks) are reused from launch to launch
+    launch_counter()++;
     b.dim = block; b.grid = grid;
     if (dyn_buf().size() * 8 < shmem + 16) dyn_buf().resize(shmem / 8 + 2);
     b.body = std::function<void()>(f);
@@ -167,6 +170,7 @@ inline const unsigned long long* exchange(unsigned long long mine) {
 #define gridDim (hipcpu::current()->grid)
 #define threadIdx (hipcpu::current()->cur->thread)
 
+inline void __threadfence() {}          // one OS thread, workgroups one after the other: every earlier store is visible
 inline void __syncthreads() {
     hipcpu::Block* b = hipcpu::current();
     const int gen = b->gen;

@@ -17,10 +17,11 @@ extern "C" const char* odtk_last_error(void) { return odtk::g_err; }
 // the three host-side entry points of csrc/conv.hip / api.hip that the emulated files' tests use (the convolution files themselves are not built)
 extern "C" int odtk_debug_set(int key, int value) {
     if (key == 3) { odtk::set_nms_legacy(value != 0); return ODTK_OK; }
-    if (key == 4) { odtk::set_bn_small_rows(value); return ODTK_OK; }
+    if (key == 4) { odtk::set_bn_small_rows(value); return ODTK_OK; }      // (incl. -7 / -8: the ticket finalize)
     if (key == 7) { odtk::set_gn_small_rows(value); return ODTK_OK; }
     odtk::set_error("debug_set (CPU emulation): key %d belongs to the convolution files", key);
     return ODTK_ERR_ARG;
 }
 extern "C" int odtk_zero(void* p, long long bytes, void*) { memset(p, 0, (size_t)bytes); return ODTK_OK; }
 extern "C" int odtk_version(void) { return 100; }
+extern "C" long long hipcpu_launch_count(void) { return hipcpu::launch_counter(); }

@@ -6,6 +6,8 @@ order); bf16 path 2e-2 (operands rounded to bf16, f32 accumulate) against a refe
 same bf16-rounded operands."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -335,7 +337,10 @@ def test_maxpool2x2_recorded_argmax_equals_gather_path(geom, dt, dev):
 @pytest.mark.parametrize("shape", [(2 * 19 * 19, 1024, True), (2 * 38 * 38, 100, False), (3 * 5 * 5, 150, False),
                                    (2 * 3 * 3, 256, True),
                                    (6 * 38 * 38, 100, False), (14 * 19 * 19, 256, True)])   # M > 4096: split-row path
-@pytest.mark.parametrize("launches", [1, 10, 2, 3, 0], ids=["one-launch", "one-launch-64ch", "two-launches", "three-launches", "auto"])
+@pytest.mark.parametrize("launches", [1, 10, 2, 3, 0, pytest.param(4, marks=pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
+    "the ticket finalize (odtk_debug_set(4, -7): statistics launch finishes its column groups, no finalize launch) was written after the round's GPU minutes were "
+    "spent: green on the kernel source under the CPU emulation (tests/test_hip_cpu.py), never run on hardware, where its fences matter; ODTK_RUN_UNVERIFIED=1 runs it")))],
+                         ids=["one-launch", "one-launch-64ch", "two-launches", "three-launches", "auto", "ticket"])
 def test_batchnorm(shape, dt, ydt, launches, dev):
     """Maps of <= 1024 rows take the single-launch kernels (statistics + finalize + apply: one workgroup per 16-byte channel chunk with 512 row lanes, or
     -- 'one-launch-64ch', the round-2 shape -- per 64 channels with 64 row lanes; here the limit is raised to 4096 rows to cover more shapes); larger maps
@@ -346,16 +351,21 @@ def test_batchnorm(shape, dt, ydt, launches, dev):
         if launches in (1, 10):
             ops.debug_set(4, 4096)
             ops.debug_set(4, -3 if launches == 10 else -4)
-        elif launches in (2, 3):
+        elif launches in (2, 3, 4):
             ops.debug_set(4, 0)
             ops.debug_set(4, -5)
-            ops.debug_set(4, -1 if launches == 3 else -2)
+            ops.debug_set(4, -1 if launches in (3, 4) else -2)
+            if launches == 4:
+                ops.debug_set(4, -7)                      # where three launches would run: statistics + finalize by ticket, then apply
         _batchnorm_case(ops, shape, dt, ydt, dev)
+        if launches == 4:
+            _batchnorm_case(ops, shape, dt, ydt, dev)     # a second pass on the same stream: the tickets have reset themselves
     finally:
         ops.debug_set(4, 1024)
         ops.debug_set(4, -1)
         ops.debug_set(4, -4)
         ops.debug_set(4, -6)
+        ops.debug_set(4, -8)
 
 
 def _batchnorm_case(ops, shape, dt, ydt, dev):

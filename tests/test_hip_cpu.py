@@ -197,8 +197,9 @@ def _run(module, name, **kw):
         getattr(mod, name)(dev=CPU, **kw)
 
 
-@pytest.mark.parametrize('launches', [1, 10, 2, 3, 0], ids=['one-launch', 'one-launch-64ch', 'two-launches', 'three-launches', 'auto'])
-@pytest.mark.parametrize('shape,dt,ydt', [((2 * 19 * 19, 1024, True), 'f32', 'f32'), ((3 * 5 * 5, 150, False), 'bf16', 'bf16'), ((6 * 38 * 38, 100, False), 'bf16', 'f32')])
+@pytest.mark.parametrize('launches', [1, 10, 2, 3, 0, 4], ids=['one-launch', 'one-launch-64ch', 'two-launches', 'three-launches', 'auto', 'ticket'])
+@pytest.mark.parametrize('shape,dt,ydt', [((2 * 19 * 19, 1024, True), 'f32', 'f32'), ((3 * 5 * 5, 150, False), 'bf16', 'bf16'), ((6 * 38 * 38, 100, False), 'bf16', 'f32'),
+                                          ((14 * 19 * 19, 256, True), 'bf16', 'bf16')])
 def test_batchnorm_from_source(shape, dt, ydt, launches):
     _run('test_gpu_kernels', 'test_batchnorm', shape=shape, dt=dt, ydt=ydt, launches=launches)
 
@@ -293,3 +294,36 @@ def test_whole_class_bf16_engine_with_the_kernels_from_source(lh_kernels_in_the_
     mt.load_oracle_params(p)
     scores, bbox, cid = mt.test_one_image((torch.from_numpy(gd['image']).float() / 127.5 - 1.).numpy())
     assert len(scores) > 0.5 * len(gd['scores']) and np.isfinite(bbox).all()
+
+
+def test_ticket_finalize_drops_the_finalize_launches():
+    """odtk_debug_set(4, -7): a training-mode batch norm of a large map is 2 launches forward (statistics with the ticket finalize, apply) and 2 backward instead
+    of 3 + 3, with the same outputs as the three-launch path to summation-order rounding"""
+    import odtk  # noqa: F401
+    from odtk import ops
+    lib = HC.build()
+    lib.hipcpu_launch_count.restype = __import__('ctypes').c_longlong
+    g = torch.Generator().manual_seed(1)
+    M, C = 14 * 19 * 19, 256
+    z = torch.randn(M, C, generator=g) * 2 + 0.5
+    dy = torch.randn(M, C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    res = {}
+    with HC.installed():
+        for mode in ('three', 'ticket'):
+            ops.debug_set(4, 0); ops.debug_set(4, -5); ops.debug_set(4, -1); ops.debug_set(4, -7 if mode == 'ticket' else -8)
+            try:
+                mm, mv, sm, si = torch.zeros(C), torch.ones(C), torch.zeros(C), torch.zeros(C)
+                ws = torch.zeros(ops.bn_workspace_bytes(M, C), dtype=torch.uint8)
+                y, dz, dg, db = torch.zeros(M, C), torch.zeros(M, C), torch.zeros(C), torch.zeros(C)
+                n0 = lib.hipcpu_launch_count()
+                ops.bn_fwd(z, M, C, C, gamma, beta, mm, mv, sm, si, True, 1, y, C, M, 0, ws)
+                n1 = lib.hipcpu_launch_count()
+                ops.bn_bwd(z, y, dy, M, C, C, C, M, 0, gamma, sm, si, 1, dz, dg, db, ws)
+                n2 = lib.hipcpu_launch_count()
+                res[mode] = (n1 - n0, n2 - n1, y, dz, dg, db, mm, mv, sm, si)
+            finally:
+                ops.debug_set(4, 1024); ops.debug_set(4, -6); ops.debug_set(4, -8)
+    assert res['three'][:2] == (3, 3) and res['ticket'][:2] == (2, 2), (res['three'][:2], res['ticket'][:2])
+    for a, b in zip(res['three'][2:], res['ticket'][2:]):
+        assert float((a - b).abs().max()) <= 1e-5 * (float(a.abs().max()) + 1e-6)

@@ -7,6 +7,11 @@ TAG=${1:-r04a}; R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 ODTK_RUN_UNVERIFIED=1 timeout 300 python -m pytest tests/test_gpu_lhrcnn.py tests/test_gpu_tf_known_answers.py -q -s -k "(in_situ and bf16) or crop_and_resize_tables or pooling_same or conv2d_orientation or momentum_optimizer" > $O/lhrcnn_bf16_insitu.log 2>&1; tail -3 $O/lhrcnn_bf16_insitu.log | cut -c1-300
 timeout 120 python tools/lhrcnn_bench.py 32 5 700 1100 f32 2>&1 | tail -1 | tee $O/lhrcnn_bench_f32.log
 timeout 120 python tools/lhrcnn_bench.py 32 5 700 1100 bf16 2>&1 | tail -1 | tee $O/lhrcnn_bench_bf16.log
-# 2. kernel trace of the f32 step with the vectorised depthwise kernels (profiles/r03zzzz_lhrcnn_700x1100_b32_kernel_trace.md has the first version)
+# 2. batch norm with the finalize launch folded into the statistics launch by ticket (odtk_debug_set(4, -7), default off): first its parity on hardware (the
+#    fences are what the CPU emulation cannot see), then YOLOv3 at config 4's per-GPU share with and without it (profiles/r03k: 150 finalize launches = 1.45 of 11.1 ms)
+ODTK_RUN_UNVERIFIED=1 timeout 600 python -m pytest tests/test_gpu_kernels.py -q -k "batchnorm and ticket" > $O/bn_ticket_tests.log 2>&1; tail -2 $O/bn_ticket_tests.log | cut -c1-200
+for sw in "" "--debug-set 4:-7"; do timeout 300 python bench.py --config yolov3 --steps 30 --warmup 5 --no-cpu-baseline $sw 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('yolov3 [$sw]', d['value'], d['ms_per_step'])" | tee -a $O/yolov3_bn_ticket_ab.log; done
+for sw in "" "--debug-set 4:-7"; do timeout 300 python bench.py --config retinanet --steps 6 --warmup 2 --no-cpu-baseline $sw 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet [$sw]', d['value'], d['ms_per_step'])" | tee -a $O/yolov3_bn_ticket_ab.log; done
+# 3. kernel trace of the f32 step with the vectorised depthwise kernels (profiles/r03zzzz_lhrcnn_700x1100_b32_kernel_trace.md has the first version)
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $O/trace -- python tools/lhrcnn_bench.py 32 3 > $O/trace.log 2>&1
 python tools/summarize_trace_csv.py $O/trace 5 > $O/lhrcnn_trace.md; rm -rf $O/trace; head -14 $O/lhrcnn_trace.md | cut -c1-160

@@ -197,11 +197,17 @@ def _run(module, name, **kw):
         getattr(mod, name)(dev=CPU, **kw)
 
 
-@pytest.mark.parametrize('launches', [1, 10, 2, 3, 0, 4], ids=['one-launch', 'one-launch-64ch', 'two-launches', 'three-launches', 'auto', 'ticket'])
-@pytest.mark.parametrize('shape,dt,ydt', [((2 * 19 * 19, 1024, True), 'f32', 'f32'), ((3 * 5 * 5, 150, False), 'bf16', 'bf16'), ((6 * 38 * 38, 100, False), 'bf16', 'f32'),
-                                          ((14 * 19 * 19, 256, True), 'bf16', 'bf16')])
-def test_batchnorm_from_source(shape, dt, ydt, launches):
-    _run('test_gpu_kernels', 'test_batchnorm', shape=shape, dt=dt, ydt=ydt, launches=launches)
+_BN_SHAPES = {'a': ((2 * 19 * 19, 1024, True), 'f32', 'f32'), 'b': ((3 * 5 * 5, 150, False), 'bf16', 'bf16'), 'c': ((6 * 38 * 38, 100, False), 'bf16', 'f32'),
+              'd': ((14 * 19 * 19, 256, True), 'bf16', 'bf16')}
+_BN_MODES = {'one-launch': 1, 'one-launch-64ch': 10, 'two-launches': 2, 'three-launches': 3, 'auto': 0, 'ticket': 4}
+
+
+@pytest.mark.parametrize('case', ['a-one-launch', 'b-one-launch', 'a-one-launch-64ch', 'a-two-launches', 'c-two-launches', 'a-three-launches', 'c-three-launches', 'd-three-launches',
+                                  'a-auto', 'd-auto', 'a-ticket', 'b-ticket', 'c-ticket', 'd-ticket'])
+def test_batchnorm_from_source(case):
+    shape, mode = case.split('-', 1)
+    sh, dt, ydt = _BN_SHAPES[shape]
+    _run('test_gpu_kernels', 'test_batchnorm', shape=sh, dt=dt, ydt=ydt, launches=_BN_MODES[mode])
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])

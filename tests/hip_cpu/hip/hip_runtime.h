@@ -119,7 +119,7 @@ inline void run_block(Block& b) {
         Fiber& f = b.fibers[t];
         f.done = false;
         f.thread = dim3(t % b.dim.x, (t / b.dim.x) % b.dim.y, t / (b.dim.x * b.dim.y));
-        if (f.stack.empty()) f.stack.resize(256 * 1024);
+        if (f.stack.empty()) f.stack.resize(192 * 1024);      // (512 threads x 192 KiB = 96 MiB at most, shared by all launches)
         getcontext(&f.uc);
         f.uc.uc_stack.ss_sp = f.stack.data();
         f.uc.uc_stack.ss_size = f.stack.size();
@@ -136,9 +136,10 @@ inline void run_block(Block& b) {
     }
     current() = nullptr;
 }
+inline Block& the_block() { static Block b; return b; }
 template <typename F>
 inline void launch(dim3 grid, dim3 block, size_t shmem, F&& f) {
-    static Block b;                                   // fibers (and their stacks) are reused from launch to launch
+    Block& b = the_block();                           // ONE set of fibers (and stacks) for every launch site: launches never overlap
     launch_counter()++;
     b.dim = block; b.grid = grid;
     if (dyn_buf().size() * 8 < shmem + 16) dyn_buf().resize(shmem / 8 + 2);

@@ -11,6 +11,7 @@ timeout 120 python tools/lhrcnn_bench.py 32 5 700 1100 bf16 2>&1 | tail -1 | tee
 #    fences are what the CPU emulation cannot see), then YOLOv3 at config 4's per-GPU share with and without it (profiles/r03k: 150 finalize launches = 1.45 of 11.1 ms)
 ODTK_RUN_UNVERIFIED=1 timeout 600 python -m pytest tests/test_gpu_kernels.py -q -k "batchnorm and ticket" > $O/bn_ticket_tests.log 2>&1; tail -2 $O/bn_ticket_tests.log | cut -c1-200
 for sw in "" "--debug-set 4:-7"; do timeout 300 python bench.py --config yolov3 --steps 30 --warmup 5 --no-cpu-baseline $sw 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('yolov3 [$sw]', d['value'], d['ms_per_step'])" | tee -a $O/yolov3_bn_ticket_ab.log; done
+for sw in "" "--debug-set 4:-7" "" "--debug-set 4:-7"; do timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-conv-events $sw 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ssd300 [$sw]', d['value'], d['ms_per_step'])" | tee -a $O/yolov3_bn_ticket_ab.log; done     # (7 layers of the SSD300 step take the three-launch batch norm; tools/ab_bench.py resolves 0.3 % if this looks promising)
 for sw in "" "--debug-set 4:-7"; do timeout 300 python bench.py --config retinanet --steps 6 --warmup 2 --no-cpu-baseline $sw 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('retinanet [$sw]', d['value'], d['ms_per_step'])" | tee -a $O/yolov3_bn_ticket_ab.log; done
 # 3. kernel trace of the f32 step with the vectorised depthwise kernels (profiles/r03zzzz_lhrcnn_700x1100_b32_kernel_trace.md has the first version)
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $O/trace -- python tools/lhrcnn_bench.py 32 3 > $O/trace.log 2>&1

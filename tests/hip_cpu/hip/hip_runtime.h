@@ -222,6 +222,7 @@ inline int __all(int pred) { return __ballot(pred) == ~0ull; }
 // compile-only stand-ins for csrc/boxes.hip (its NMS kernels are NOT run under the emulation: they rely on the implicit lock-step of a wave between fences)
 inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))

@@ -339,8 +339,10 @@ def test_maxpool2x2_recorded_argmax_equals_gather_path(geom, dt, dev):
                                    (6 * 38 * 38, 100, False), (14 * 19 * 19, 256, True)])   # M > 4096: split-row path
 @pytest.mark.parametrize("launches", [1, 10, 2, 3, 0, pytest.param(4, marks=pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
     "the ticket finalize (odtk_debug_set(4, -7): statistics launch finishes its column groups, no finalize launch) was written after the round's GPU minutes were "
-    "spent: green on the kernel source under the CPU emulation (tests/test_hip_cpu.py), never run on hardware, where its fences matter; ODTK_RUN_UNVERIFIED=1 runs it")))],
-                         ids=["one-launch", "one-launch-64ch", "two-launches", "three-launches", "auto", "ticket"])
+    "spent: green on the kernel source under the CPU emulation (tests/test_hip_cpu.py), never run on hardware, where its fences matter; ODTK_RUN_UNVERIFIED=1 runs it"))),
+                                      pytest.param(5, marks=pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
+    "the fence-free ticket finalize (odtk_debug_set(4, -9)): as 'ticket', never run on hardware")))],
+                         ids=["one-launch", "one-launch-64ch", "two-launches", "three-launches", "auto", "ticket", "ticket-nofence"])
 def test_batchnorm(shape, dt, ydt, launches, dev):
     """Maps of <= 1024 rows take the single-launch kernels (statistics + finalize + apply: one workgroup per 16-byte channel chunk with 512 row lanes, or
     -- 'one-launch-64ch', the round-2 shape -- per 64 channels with 64 row lanes; here the limit is raised to 4096 rows to cover more shapes); larger maps
@@ -351,14 +353,14 @@ def test_batchnorm(shape, dt, ydt, launches, dev):
         if launches in (1, 10):
             ops.debug_set(4, 4096)
             ops.debug_set(4, -3 if launches == 10 else -4)
-        elif launches in (2, 3, 4):
+        elif launches in (2, 3, 4, 5):
             ops.debug_set(4, 0)
             ops.debug_set(4, -5)
-            ops.debug_set(4, -1 if launches in (3, 4) else -2)
-            if launches == 4:
-                ops.debug_set(4, -7)                      # where three launches would run: statistics + finalize by ticket, then apply
+            ops.debug_set(4, -1 if launches in (3, 4, 5) else -2)
+            if launches in (4, 5):
+                ops.debug_set(4, -7 if launches == 4 else -9)    # where three launches would run: statistics + finalize by ticket, then apply
         _batchnorm_case(ops, shape, dt, ydt, dev)
-        if launches == 4:
+        if launches in (4, 5):
             _batchnorm_case(ops, shape, dt, ydt, dev)     # a second pass on the same stream: the tickets have reset themselves
     finally:
         ops.debug_set(4, 1024)

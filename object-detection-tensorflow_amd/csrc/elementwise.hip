@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(256) bn_stats_fin_kernel(const T* __restrict__
     int c, lane;
     float s1, s2;
     bn_ticket_reduce<KC>(ws, nsplit, C, c, lane, s1, s2);
-    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;       // every workgroup of this column group has drawn: ready for the next launch
+    if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // every workgroup of this column group has drawn: ready for the next launch
     if (c >= C || lane != 0) return;
     const float d = s1 / (float)M;                        // (bn_finalize_kernel's arithmetic)
     const float mean = elem<T>::load(z[c]) + d;
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_fin_kernel(
     int c, lane;
     float s1, s2;
     bn_ticket_reduce<KC>(ws, nsplit, C, c, lane, s1, s2);
-    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
+    if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c >= C || lane != 0) return;
     dbeta[c] = s1;                                        // (bn_bwd_finalize_kernel's outputs)
     dgamma[c] = s2;
@@ -2731,7 +2731,7 @@ __device__ __forceinline__ bool gn_ticket_is_last(int* __restrict__ tickets, int
     __syncthreads();
     if (threadIdx.x == 0) {
         s_last = atomicAdd(&tickets[idx], 1) == nsplit - 1;
-        if (s_last) tickets[idx] = 0;                  // every workgroup of this (sample, column group) has drawn: ready for the next launch
+        if (s_last) __hip_atomic_store(&tickets[idx], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                  // every workgroup of this (sample, column group) has drawn: ready for the next launch
     }
     __syncthreads();
     if (s_last && !nofence) __threadfence();

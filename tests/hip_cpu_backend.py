@@ -80,6 +80,9 @@ def _nms_batched(boxes, box_stride, scores, score_bstride, score_estride, valid,
         oc[c0 + b] = k
 
 
+CALLED = set()            # entry points run through the emulation so far in this process (coverage report: ODTK_EMU_COVERAGE=<file>)
+
+
 class _Lib:
     """what odtk._lib.load() hands out while the emulation is installed: the CPU build first, the real library for host-only helpers it does not have"""
 
@@ -88,6 +91,8 @@ class _Lib:
 
     def __getattr__(self, name):
         if hasattr(self._cpu, name):
+            if name.startswith('odtk_'):
+                CALLED.add(name)                              # (handed out to be called: augment.py and the *_workspace_bytes helpers come this way)
             return getattr(self._cpu, name)
         if self._real is None:
             raise AttributeError(name)
@@ -107,6 +112,7 @@ def installed():
     def call(name, *args):
         if not hasattr(lib, name):
             raise RuntimeError(f'{name} is not part of the CPU-emulated build ({", ".join(KERNEL_FILES)})')
+        CALLED.add(name)
         rc = getattr(lib, name)(*args)
         if rc != 0:
             raise _lib.OdtkError(f'libodtk (CPU emulation) error {rc}: {lib.odtk_last_error().decode()}')

@@ -149,10 +149,15 @@ def augment_on_cpu(monkeypatch):
         f.restype, f.argtypes = _lib.SIGNATURES[n]
 
     def call(name, *args):
+        HC.CALLED.add(name)
         rc = getattr(lib, name)(*args)
         assert rc == 0, lib.odtk_last_error().decode()
+
+    def call_ll(name, *args):
+        HC.CALLED.add(name)
+        return int(getattr(lib, name)(*args))
     monkeypatch.setattr(augment, 'call', call)
-    monkeypatch.setattr(augment, 'call_ll', lambda name, *args: int(getattr(lib, name)(*args)))
+    monkeypatch.setattr(augment, 'call_ll', call_ll)
     monkeypatch.setattr(augment._lib, 'load', lambda: lib)
     monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: type('S', (), {'cuda_stream': 0})())
     monkeypatch.setattr(torch.Tensor, 'record_stream', lambda self, s: None)
@@ -390,3 +395,139 @@ def test_group_norm_ticket_finalize_is_bit_equal_and_drops_the_finalize_launches
                 assert res[mode, rep][:2] == (2, 3), (mode, rep, res[mode, rep][:2])
                 for a, b in zip(res['three', 0][2:], res[mode, rep][2:]):
                     assert torch.equal(a, b)
+
+
+def test_yolov2_box_side_from_source():
+    _run('test_gpu_yolov2', 'test_loss_kernel_matches_oracle', geom=(2, 6, 7, 3, 4))
+    _run('test_gpu_yolov2', 'test_loss_kernel_matches_oracle', geom=(2, 15, 15, 5, 20))
+    _run('test_gpu_yolov2', 'test_decode_candidates_and_detections')
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_pyramid_glue_and_centernet_elementwise_from_source(dt):
+    """add2d / upsample2x (YOLOv3's routes), the gather backward of the feature-map resize (RetinaNet / FCOS pyramids), CenterNet's preprocess_norm /
+    avgpool backward / residual add + ReLU"""
+    _run('test_gpu_yolov3', 'test_glue_kernels', dt=dt)
+    _run('test_gpu_yolov3', 'test_resize_bilinear_feature_maps', dt=dt)
+    _run('test_gpu_centernet_model', 'test_elementwise_kernels', dt=dt)
+
+
+def test_adam_from_source():
+    _run('test_gpu_centernet_model', 'test_adam_kernel_three_steps')
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2 * 13 * 13, 96, True), (5000, 40, False)])
+def test_global_batch_norm_entry_points_from_source(shape, dt):
+    """odtk_bn_moments / _fwd_given / _bwd_sums / _bwd_given (ops.SyncBN, SURVEY.md 8e option B) with the two exchanges done by hand: two replicas with half the
+    rows each compute what odtk_bn_fwd / odtk_bn_bwd compute on all rows"""
+    import odtk  # noqa: F401
+    from odtk import ops
+    M, C, relu = shape
+    tdt = torch.float32 if dt == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(2 * M, C, generator=g) * 1.5 + 0.3).to(tdt)
+    dy = torch.randn(2 * M, C, generator=g).to(tdt)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    with HC.installed():
+        p = ops._p
+        ws = torch.zeros(ops.bn_workspace_bytes(2 * M, C), dtype=torch.uint8)
+        # one device, all rows
+        mm, mv, sm, si = torch.zeros(C), torch.ones(C), torch.zeros(C), torch.zeros(C)
+        y, dz, dg, db = torch.zeros(2 * M, C, dtype=tdt), torch.zeros(2 * M, C, dtype=tdt), torch.zeros(C), torch.zeros(C)
+        ops.bn_fwd(z, 2 * M, C, C, gamma, beta, mm, mv, sm, si, True, int(relu), y, C, 2 * M, 0, ws)
+        ops.bn_bwd(z, y, dy, 2 * M, C, C, C, 2 * M, 0, gamma, sm, si, int(relu), dz, dg, db, ws)
+        # two replicas
+        zs, dys = [z[:M].clone(), z[M:].clone()], [dy[:M].clone(), dy[M:].clone()]
+        mom = torch.zeros(2, 2, C)
+        for r in range(2):
+            ops.call('odtk_bn_moments', p(zs[r]), M, C, C, ops.dt_of(zs[r]), p(mom[r][0]), p(mom[r][1]), p(ws), None)
+        st = [dict(mm=torch.zeros(C), mv=torch.ones(C), sm=torch.zeros(C), si=torch.zeros(C), y=torch.zeros(M, C, dtype=tdt), dz=torch.zeros(M, C, dtype=tdt),
+                   sums=torch.zeros(2 * C)) for _ in range(2)]
+        for r in range(2):
+            d = st[r]
+            ops.call('odtk_bn_fwd_given', p(zs[r]), M, C, C, ops.dt_of(zs[r]), p(gamma), p(beta), p(mom), 2, p(d['mm']), p(d['mv']), p(d['sm']), p(d['si']),
+                     int(relu), p(d['y']), ops.dt_of(d['y']), C, M, 0, p(ws), None)
+            d['y1'] = y[r * M:(r + 1) * M].clone()          # the ReLU mask of the one-device pass: an activation a rounding away from zero must not flip
+            ops.call('odtk_bn_bwd_sums', p(zs[r]), p(d['y1']), p(dys[r]), M, C, C, ops.dt_of(zs[r]), ops.dt_of(dys[r]), C, M, 0, p(d['sm']), p(d['si']), int(relu),
+                     p(d['sums']), p(ws), None)
+        glob = st[0]['sums'] + st[1]['sums']
+        for r in range(2):
+            d = st[r]
+            ops.call('odtk_bn_bwd_given', p(zs[r]), p(d['y1']), p(dys[r]), M, C, C, ops.dt_of(zs[r]), ops.dt_of(dys[r]), C, M, 0, p(gamma), p(d['sm']), p(d['si']),
+                     int(relu), p(glob), 2 * M, p(d['dz']), p(ws), None)
+    tol = 2e-5 if dt == 'f32' else 2e-2
+
+    def close(a, b, t=tol):
+        assert float((a.float() - b.float()).abs().max()) <= t * (float(b.float().abs().max()) + 1e-6), float((a.float() - b.float()).abs().max())
+    for r in range(2):
+        d = st[r]
+        close(d['sm'], sm, 2e-5); close(d['si'], si, 2e-4); close(d['mm'], mm, 2e-5); close(d['mv'], mv, 2e-4)
+        close(d['y'], y[r * M:(r + 1) * M])
+        close(d['dz'], dz[r * M:(r + 1) * M])
+    if dt == 'f32':                                         # (bf16: a ReLU mask taken from y rounded differently in a few entries moves the sums)
+        close(glob[:C], db, 1e-4); close(glob[C:], dg, 1e-4)
+    else:
+        close(glob[:C], db, 3e-2); close(glob[C:], dg, 3e-2)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_row_glue_kernels_from_source(dt):
+    """exp rows (FCOS.py:363) and its chain rule, conv rows <-> f32 prediction tensors (RetinaNet.py:184-186), casts, relu(a + b) and the ReLU gradient taken
+    from the output (RefineDet.py:371): each against the torch expression, pitched operands"""
+    import odtk  # noqa: F401
+    from odtk import ops
+    tdt = torch.float32 if dt == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    M, C, ld = 3 * 35, 4, 8
+    with HC.installed():
+        x = torch.randn(M, ld, generator=g).to(tdt)
+        y = torch.zeros(M, C)
+        ops.exp_rows_to_f32(x, ld, y, M, C)
+        assert torch.allclose(y, torch.exp(x[:, :C].float()), rtol=1e-6, atol=0)
+        dy = torch.randn(M, C, generator=g)
+        dx = torch.full((M, ld), 7., dtype=tdt)
+        ops.exp_rows_bwd(dy, y, dx, ld, M, C)
+        assert torch.equal(dx[:, :C], (dy * y).to(tdt)) and not dx[:, C:].any()
+        # three images of 35 rows into a prediction tensor [3][100][C] at row offset 20
+        pred = torch.zeros(3, 100, C)
+        ops.rows_to_f32(x, ld, pred[:, 20:], C, 35, 100 * C, M, C)
+        assert torch.equal(pred[:, 20:55], x[:, :C].float().view(3, 35, C)) and not pred[:, :20].any() and not pred[:, 55:].any()
+        back = torch.full((M, ld), 3., dtype=tdt)
+        ops.rows_from_f32(pred[:, 20:], C, 35, 100 * C, back, ld, M, C)
+        assert torch.equal(back[:, :C], x[:, :C]) and not back[:, C:].any()
+        f = torch.randn(1000, generator=g)
+        o = torch.zeros(1000, dtype=tdt); ops.cast_from_f32(f, o)
+        assert torch.equal(o, f.to(tdt))
+        w = torch.zeros(1000); ops.cast_to_f32(o, w)
+        assert torch.equal(w, o.float())
+        Cc, lda, ldb = 16, 24, 16
+        a, b = torch.randn(50, lda, generator=g).to(tdt), torch.randn(50, ldb, generator=g).to(tdt)
+        r = torch.zeros(50, Cc, dtype=tdt)
+        ops.add_relu_fwd(a, lda, b, ldb, r, Cc, 50, Cc)
+        assert torch.equal(r, torch.relu(a[:, :Cc].float() + b[:, :Cc].float()).to(tdt))
+        d = torch.randn(50, Cc, generator=g).to(tdt)
+        prev = torch.randn(50, lda, generator=g).to(tdt)
+        for acc in (False, True):
+            out = prev.clone()
+            ops.relu_bwd(r, d, Cc, out, lda, 50, Cc, acc)
+            want = torch.where(r > 0, d.float(), torch.zeros(())) + (prev[:, :Cc].float() if acc else 0.)
+            assert torch.equal(out[:, :Cc], want.to(tdt)) and torch.equal(out[:, Cc:], prev[:, Cc:])
+
+
+def test_zz_emulation_coverage_report():
+    """(runs last in this file) which C-ABI entry points of the emulated build the tests above actually executed; written to $ODTK_EMU_COVERAGE when set"""
+    import odtk  # noqa: F401
+    from odtk import _lib
+    with HC.installed() as names:
+        pass
+    ran = sorted(HC.CALLED & set(names))
+    out = os.environ.get('ODTK_EMU_COVERAGE')
+    if out:
+        with open(out, 'w') as f:
+            f.write(f'{len(ran)} of {len(names)} emulated entry points executed ({len(_lib.SIGNATURES)} in the library)\n')
+            f.write('executed: ' + ' '.join(ran) + '\n')
+            f.write('not executed: ' + ' '.join(sorted(set(names) - set(ran))) + '\n')
+    if len(HC.CALLED) > 20:                                # the whole file ran in this process
+        missing = set(names) - set(ran) - {'odtk_nms_batched', 'odtk_last_error', 'odtk_version'}      # (NMS: DPP kernels, replaced -- hip_cpu_backend.py)
+        assert not missing, sorted(missing)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # First GPU call of the next round: what the second session of round 3 left unverified on hardware (its GPU minutes were spent), in order of value.
 #   bash tools/gpu_round4_first.sh <tag>   -> gpurun_out/<tag>/...
+# About 18 minutes of box time as written (18 bench processes of 25-40 s, three test selections, one trace): run it under `gpurun --timeout 1500`, or
+# comment out sections -- 1 (LHRCNN bf16) and 2 (batch-norm ticket on YOLOv3) carry the most.
 set -u
 TAG=${1:-r04a}; R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 # 1. LHRCNN's opt-in bf16 engine: every launch of a step in situ at 700 x 1100 batch 32, then its step time next to the f32 engine's

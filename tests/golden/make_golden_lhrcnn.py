@@ -92,16 +92,17 @@ def push(V, tfname, p):
             V[n].copy_(to_tf(k, p[k]))
 
 
-def train_run(ref, p0, data, first_step):
+def train_run(ref, p0, data, first_step, config=None):
     tf_shim.reset()
     state = {'i': 0}
+    config = config or CONFIG
 
     class It:
         def get_next(self):
             im, g = data[state['i'] % 2]
             return tf_shim.wrap(im.clone()), tf_shim.wrap(g.clone())
-    prov = {'data_shape': [H, W, 3], 'num_train': 4, 'num_val': 0, 'train_generator': (lambda: None, It()), 'val_generator': None}
-    m = ref.LHRCNN(dict(CONFIG, rpn_first_step=first_step), prov)
+    prov = {'data_shape': list(config['data_shape']), 'num_train': 2 * config['batch_size'], 'num_val': 0, 'train_generator': (lambda: None, It()), 'val_generator': None}
+    m = ref.LHRCNN(dict(config, rpn_first_step=first_step), prov)
     V = tf_shim.S.variables
     tfname = name_map(V)
     push(V, tfname, p0)
@@ -113,6 +114,48 @@ def train_run(ref, p0, data, first_step):
         if step == 0:
             after1 = {k: from_tf(k, V[n].detach().clone()) for k, n in tfname.items()}
     return m, V, tfname, losses, steps, after1
+
+
+# A second training fixture away from the first one's settings: another picture shape (8 x 15 feature map), three pictures, 5 classes, up to five objects, a
+# larger weight decay, other seeds -> lhrcnn_train_b.npz (`python tests/golden/make_golden_lhrcnn.py b` writes only this one).
+CASE_B = dict(H=256, W=480, batch=3, num_classes=5, weight_decay=5e-4, seeds=(501, 502), seed_params=73, lr=0.002, max_obj=5, pad=8)
+
+
+def batches_b():
+    c, out = CASE_B, []
+    for s in c['seeds']:
+        g = torch.Generator().manual_seed(s)
+        gt = LR.synthetic_gt(c['batch'], c['H'], c['W'], s + 10, pad=c['pad'], max_obj=c['max_obj'])
+        gt[..., 4] = torch.where(gt[..., 4] >= 0, gt[..., 4] % c['num_classes'], gt[..., 4])
+        out.append(((torch.rand(c['batch'], c['H'], c['W'], 3, generator=g) * 255).round(), gt))
+    return out
+
+
+def main_b():
+    global LR_STEP
+    c = CASE_B
+    tf_shim.install()
+    tf_shim.GATHER_OOB_ZERO = True
+    ref = tf_shim.load_reference_module('/root/reference/LH_RCNN.py', 'reference_LHRCNN')
+    config = dict(CONFIG, data_shape=[c['H'], c['W'], 3], batch_size=c['batch'], num_classes=c['num_classes'], weight_decay=c['weight_decay'])
+    p0 = LR.init_params(c['seed_params'], num_classes=c['num_classes'] + 1)
+    data = batches_b()
+    keep_lr, LR_STEP = LR_STEP, c['lr']
+    try:
+        _, V, _, rpn_losses, steps, after1 = train_run(ref, p0, data, 60000, config)
+        assert int(V['global_step']) == 2 and steps == [0, 1]
+        _, _, _, rcnn_losses, _, _ = train_run(ref, p0, data, 0, config)
+    finally:
+        LR_STEP = keep_lr
+    out = dict(rpn_losses=np.asarray(rpn_losses, np.float64), rcnn_losses=np.asarray(rcnn_losses, np.float64), global_steps=np.asarray(steps),
+               case=np.asarray(json.dumps(c)))
+    for key in KEEP:
+        flat = after1[key].contiguous().reshape(-1)
+        out[key.replace('.', '__')] = flat[::max(1, flat.numel() // 1024)].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'lhrcnn_train_b.npz'), **out)
+    print('case b: rpn', rpn_losses, 'rcnn', rcnn_losses)
+    tf_shim.GATHER_OOB_ZERO = False
+    tf_shim.uninstall()
 
 
 def main():
@@ -162,4 +205,8 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:] == ['b']:
+        main_b()
+    else:
+        main()
+        main_b()

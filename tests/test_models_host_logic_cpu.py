@@ -560,6 +560,38 @@ def test_lhrcnn_training_step_host_logic():
         assert m.global_step == 2
 
 
+def test_lhrcnn_second_configuration_against_the_reference_fixture():
+    """the class on the CPU mock in the second pinned configuration (tests/golden/lhrcnn_train_b.npz: 256 x 480, batch 3, 5 classes, up to five objects, weight
+    decay 5e-4, lr 0.002) DIRECTLY against the numbers of the reference's own class: both losses of the first step, the sub-sampled variables after it"""
+    import json
+    import numpy as np
+    import odtk
+    from oracle import lhrcnn_ref as LR
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'lhrcnn_train_b.npz'))
+    c = json.loads(str(g['case']))
+    gen = torch.Generator().manual_seed(c['seeds'][0])
+    gt = LR.synthetic_gt(c['batch'], c['H'], c['W'], c['seeds'][0] + 10, pad=c['pad'], max_obj=c['max_obj'])
+    gt[..., 4] = torch.where(gt[..., 4] >= 0, gt[..., 4] % c['num_classes'], gt[..., 4])
+    imgs = (torch.rand(c['batch'], c['H'], c['W'], 3, generator=gen) * 255).round()
+    p = LR.init_params(c['seed_params'], num_classes=c['num_classes'] + 1)
+    shape = [c['H'], c['W'], 3]
+    with mock_ops.installed():
+        m = odtk.LHRCNN(_lhrcnn_cfg('train', c['batch'], data_shape=shape, num_classes=c['num_classes'], weight_decay=c['weight_decay']),
+                        {'data_shape': shape, 'num_train': c['batch'], 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+        m.load_oracle_params(p)
+        m.set_batch(imgs, gt)
+        m.train_step(c['lr'])
+        got_rpn, got_rcnn = float(m.last_losses[0]), float(m.last_losses[1])
+        assert abs(got_rpn - g['rpn_losses'][0]) < 1e-4 * g['rpn_losses'][0] and abs(got_rcnn - g['rcnn_losses'][0]) < 1e-4 * g['rcnn_losses'][0], (got_rpn, got_rcnn)
+        after = m.export_params()
+    for key in [k for k in g.files if '__' in k]:
+        name = key.replace('__', '.')
+        flat = after[name].contiguous().reshape(-1)
+        got = flat[::max(1, flat.numel() // 1024)].numpy()
+        np.testing.assert_allclose(got, g[key], rtol=0, atol=5e-6 * max(1.0, float(np.abs(g[key]).max())), err_msg=name)
+
+
 def test_lhrcnn_inference_host_logic():
     """LHRCNN.test_one_image on the CPU mock against the detections of the reference's own class (tests/golden/lhrcnn_detect.npz): the feed quirk (normalised
     pictures go in as they are), proposal NMS, crop rows, dense head, per-class NMS"""

@@ -642,6 +642,35 @@ def test_lhrcnn_train_steps_vs_reference_class():
                 np.testing.assert_allclose(got, g[key], rtol=0, atol=2e-6 * max(1.0, float(np.abs(g[key]).max())), err_msg=name)
 
 
+def test_lhrcnn_train_steps_vs_reference_class_second_configuration():
+    """the same on the second fixture (tests/golden/make_golden_lhrcnn.py CASE_B): 256 x 480 pictures (8 x 15 feature map), batch 3, 5 classes, up to five
+    objects per picture, weight decay 5e-4, other seeds -- the settings the first fixture leaves at the driver's values"""
+    import json
+    from oracle import lhrcnn_ref as LR
+    g = np.load(os.path.join(GOLD, 'lhrcnn_train_b.npz'))
+    c = json.loads(str(g['case']))
+    data = []
+    for s in c['seeds']:
+        gen = torch.Generator().manual_seed(s)
+        gt = LR.synthetic_gt(c['batch'], c['H'], c['W'], s + 10, pad=c['pad'], max_obj=c['max_obj'])
+        gt[..., 4] = torch.where(gt[..., 4] >= 0, gt[..., 4] % c['num_classes'], gt[..., 4])
+        data.append(((torch.rand(c['batch'], c['H'], c['W'], 3, generator=gen) * 255).round(), gt))
+    p = LR.init_params(c['seed_params'], num_classes=c['num_classes'] + 1)
+    mom = {k: torch.zeros_like(v) for k, v in p.items()}
+    assert g['global_steps'].tolist() == [0, 1]
+    for step in range(2):
+        rpn, rcnn = LR.train_step(p, mom, data[step][0], data[step][1], c['lr'], weight_decay=c['weight_decay'])
+        tol = 1e-5 if step == 0 else 1e-3
+        assert abs(rpn - g['rpn_losses'][step]) <= tol * abs(g['rpn_losses'][step]), (step, rpn, g['rpn_losses'][step])
+        assert abs(rcnn - g['rcnn_losses'][step]) <= tol * abs(g['rcnn_losses'][step]), (step, rcnn, g['rcnn_losses'][step])
+        if step == 0:
+            for key in [k for k in g.files if '__' in k]:
+                name = key.replace('__', '.')
+                flat = p[name].contiguous().reshape(-1)
+                got = flat[::max(1, flat.numel() // 1024)].numpy()
+                np.testing.assert_allclose(got, g[key], rtol=0, atol=2e-6 * max(1.0, float(np.abs(g[key]).max())), err_msg=name)
+
+
 def test_lhrcnn_detections_vs_reference_class():
     """oracle/lhrcnn_ref.detect against the reference class's test_one_image on the shim: same detections in the same order"""
     from oracle import lhrcnn_ref as LR

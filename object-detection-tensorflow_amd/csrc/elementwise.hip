@@ -1445,7 +1445,8 @@ static int* bn_tickets_for(hipStream_t st, int colgroups) {
     if (!g_bn_tickets[dev]) {
         void* p = nullptr;
         if (hipMalloc(&p, (size_t)BN_TICKET_SETS * BN_TICKET_INTS * sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, (size_t)BN_TICKET_SETS * BN_TICKET_INTS * sizeof(int)) != hipSuccess) return nullptr;     // synchronous, once per device
+        if (hipMemset(p, 0, (size_t)BN_TICKET_SETS * BN_TICKET_INTS * sizeof(int)) != hipSuccess) return nullptr;     // once per device
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;      // the callers' streams are non-blocking ones: the fill has landed before they launch
         g_bn_tickets[dev] = (int*)p;
     }
     for (int i = 0; i < g_bn_ticket_used[dev]; ++i)

@@ -53,9 +53,13 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  * key 3 = single-kernel NMS (value != 0);
  * key 4 = batch norm: maps of up to `value` rows run statistics + finalize + apply in ONE launch (default 1024, 0 = never); larger maps take three
  *         (statistics, finalize, apply); value -2 = two (apply with the finalize folded in: measured slower, A/B only), -1 = back to three;
+ *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back; -7 = where three
+ *         launches would run, the statistics launch finishes its column groups by ticket (2 launches; device-scope fences), -9 = the same without fences
+ *         (write-through partials), -8 = back (default; neither has run on hardware yet);
  * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
  *         run, 2.5 % slower on the SSD300 step) instead of float atomics into dw (the default);
- * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never) */
+ * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never); -7 / -9 / -8 as key 4
+ *         for the bf16 maps whose groups lie inside 64-channel blocks */
 int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to
  * every later call of this thread until the slot changes.  Calls on ONE stream are ordered and share slot 0; a caller that

@@ -223,12 +223,12 @@ def _engine_cpu_model(kind, rank):
             m = odtk.YOLOv2(cfg, {'data_shape': [128, 160, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
     elif kind == 'lhrcnn':
         from oracle import lhrcnn_ref as LR
-        cfg = {'data_shape': [320, 416, 3], 'mode': 'train', 'is_pretraining': False, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
+        cfg = {'data_shape': [224, 288, 3], 'mode': 'train', 'is_pretraining': False, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
                'keep_prob': 0.5, 'batch_size': 1, 'rpn_first_step': 60000, 'rcnn_first_step': 100000, 'rpn_second_step': 160000, 'nms_score_threshold': 0.5,
                'nms_max_boxes': 20, 'nms_iou_threshold': 0.45, 'post_nms_proposal': 500, 'verbose': False, 'device': 'cpu', 'seed': 3}
-        batch = ((torch.rand(1, 320, 416, 3, generator=g) * 255).round(), LR.synthetic_gt(1, 320, 416, 950 + rank))
+        batch = ((torch.rand(1, 224, 288, 3, generator=g) * 255).round(), LR.synthetic_gt(1, 224, 288, 950 + rank))
         with mock_ops.installed():
-            m = odtk.LHRCNN(cfg, {'data_shape': [320, 416, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+            m = odtk.LHRCNN(cfg, {'data_shape': [224, 288, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
     else:
         from oracle import refinedet_ref as FR
         cfg = {'mode': 'train', 'input_size': 320, 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,

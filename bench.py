@@ -199,6 +199,57 @@ def pmc_traffic(kernel):
     return None
 
 
+class ClockSampler:
+    """Shader clock of the visible GPU over the timed region: the amdgpu hwmon file `freq1_input` of the card whose PCI address is HIP device
+    `index`, read every 10 ms by a daemon thread (one small file read per sample).  `summary()` is None where the box has no such sysfs file."""
+
+    def __init__(self, index):
+        import glob
+        self.path = None
+        self.samples = []
+        self._stop = False
+        self._thread = None
+        try:
+            p = torch.cuda.get_device_properties(index)
+            bdf = '%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            for dev in sorted(glob.glob('/sys/class/drm/card*/device')):
+                if os.path.basename(os.path.realpath(dev)) != bdf:
+                    continue
+                for h in sorted(glob.glob(os.path.join(dev, 'hwmon', 'hwmon*'))):
+                    f = os.path.join(h, 'freq1_input')
+                    if os.path.exists(f):
+                        self.path = f
+        except Exception:                                        # noqa: BLE001
+            self.path = None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                with open(self.path) as f:
+                    self.samples.append(int(f.read().strip()) / 1e6)
+            except Exception:                                    # noqa: BLE001
+                pass
+            time.sleep(0.01)
+
+    def start(self):
+        if self.path is not None:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {'median': round(v[len(v) // 2], 0), 'min': round(v[0], 0), 'max': round(v[-1], 0), 'samples': len(v),
+                'source': 'amdgpu hwmon freq1_input of the visible device, 10 ms period, over the timed region'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -208,7 +259,7 @@ def main():
                     help="BASELINE.json's configuration: ssd300 = config 2 (the headline metric, the default); retinanet = config 3 (800x800, batch 16); "
                          'yolov3 = config 4 (416x416, 8 / GPU); fcos | centernet = config 5 (512x512, 16 / GPU) -- bench_configs.py')
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s)')
-    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32'], help='engine (default: the one the model class defaults to: bf16 for ssd300 / yolov3, f32 else)')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32'], help='engine (default: the one the model class defaults to in training mode: bf16 for ssd300 / yolov3 / fcos / centernet, f32 for retinanet)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region (the default at N = 1 since round 3)')
@@ -269,7 +320,7 @@ def main():
         'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4,
         'keep_prob': 0.5, 'batch_size': B, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20,
         'nms_iou_threshold': 0.5, 'pretraining_weight': os.path.join('.', 'vgg_16.ckpt'),
-        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else ('list' if args.launch_list else (args.graph or args.gpus > 1 or args.dp_world1) and not args.eager), 'fuse_pool': not args.no_fuse_pool,
+        'compute_dtype': args.dtype, 'verbose': False, 'seed': 0, 'wgrad_stream': args.wgrad_stream, 'match_stream': args.match_stream, 'tail_stream': not args.no_tail_stream, 'use_graph': 'auto' if args.auto_launch else ('list' if args.launch_list else bool(args.graph) and not args.eager), 'fuse_pool': not args.no_fuse_pool,
     }
     for item in filter(None, args.model_cfg.split(',')):             # A/B switches of the model class (tools/, profiles/)
         k, _, v = item.partition('=')
@@ -307,28 +358,36 @@ def main():
     gc.collect()
     gc.disable()               # a generation-2 collection in the launching thread is a 10-30 ms host stall; with eager launches
     barrier()                  # (the HIP-event pass below) the GPU runs dry behind it and the stall lands in some kernel's events
+    clock = ClockSampler(local_rank)
+    clock.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = model.train_step(lr)
     barrier()
     dt = time.perf_counter() - t0
+    clock.stop()
     final_loss_t = loss
     # roofline pass: the SAME step launched eagerly with HIP events around every conv launch on the launch
     # stream (graph replay cannot carry per-kernel events; the kernels and their durations are identical)
     if not args.no_conv_events:
-        saved = model.use_graph
-        saved_side = model.wgrad_stream
+        # ONE stream for this pass: the head stream, the tail filter-gradient stream, the optional filter-gradient stream and the side-stream front / tail
+        # of the step are all switched off, so every conv kernel is timed with the chip to itself and the per-kernel table is not deflated by kernels
+        # that share CUs (round 3 left the head / tail streams on: `conv_ms_per_step` exceeded `ms_per_step`).  The timed region above is untouched.
+        saved = (model.use_graph, model.wgrad_stream, model._tail, model._twg, model.config.get('side_front', True))
+        torch.cuda.synchronize()
         model.use_graph = False
-        model.wgrad_stream = None            # one stream: every conv kernel is timed with the chip to itself
+        model.wgrad_stream = model._tail = model._twg = None
+        model.config['side_front'] = False
         timer.enabled = True
         ev_steps = min(args.steps, 5) + 1
+        t1 = time.perf_counter()
         for _ in range(ev_steps):
             model.train_step(lr)
         torch.cuda.synchronize()
+        single_stream_ms = (time.perf_counter() - t1) / ev_steps * 1e3
         timer.enabled = False
         gc.enable()
-        model.use_graph = saved
-        model.wgrad_stream = saved_side
+        model.use_graph, model.wgrad_stream, model._tail, model._twg, model.config['side_front'] = saved
     gc.enable()
     loss = final_loss_t
     comm = None
@@ -361,9 +420,11 @@ def main():
             if args.conv_table:
                 with open(args.conv_table, 'w') as f:
                     f.write(timer.table(min(args.steps, 5) + 1) + '\n')
-            out['roofline']['measured_on'] = (f'{min(args.steps, 5) + 1} eager steps right after the timed region '
-                                              '(HIP events per conv launch on the launch stream; plain per-launch mean without the first eager step; '
-                                              '*_trimmed additionally drops the slowest sample of every launch)')
+            out['roofline']['measured_on'] = (f'{min(args.steps, 5) + 1} eager SINGLE-STREAM steps right after the timed region (head / tail / side streams off: '
+                                              'every conv launch has the chip to itself; HIP events per conv launch on the launch stream; plain per-launch mean '
+                                              'without the first eager step; *_trimmed additionally drops the slowest sample of every launch)')
+            out['roofline']['single_stream_ms_per_step'] = round(single_stream_ms, 3)   # incl. the event records: an upper bound of conv_ms_per_step
+        out['sclk_mhz'] = clock.summary()
         if comm is not None:
             out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:

@@ -42,24 +42,21 @@ unsigned int odtk_crc32c(const void* data, long long n, unsigned int crc);
 /* number of compute units / name of the current device (host out pointers) */
 int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
 /* test/debug knobs: key 0 = force the register-staged conv gather kernel (value != 0);
- * key 1 = conv engine: 0 auto, 1 legacy 4-wave kernels, 2 8-wave v3 wherever supported, 3 persistent v4;
+ * key 1 = conv engine: 0 auto, 1 legacy 4-wave kernels, 2 8-wave v3 wherever supported;
  * key 2 = A/B bits of the conv kernels: bits 0-3 ablations (skip DMA / one slab; RESULTS WRONG), 5 no fragment double
  *         buffering, 6 no early/late DMA stagger, 7 "landed early" protocol, 8 64-bit global addressing for the LDS-DMA,
  *         9 no XCD remap (wgrad), 10 s_setprio, 11 no 64->64 / first-layer halo kernels, 12 per-lane tap walk,
- *         13 no split-K, 14 interleaved slab body, 15 4-wave kernel (v5), 16 no raster-run halo kernel (v6), 17 256x256 wgrad tile (v7),
+ *         13 no split-K, 14 interleaved slab body, 16 no raster-run halo kernel (v6),
  *         18-25 = n: halo kernel instead of split-K on layers with >= n tiles (0 = split-K policy as is), 26 no wide (W <= 159) halo
  *         variant, 27 no 128x512 halo tiles, 28 no 128x192 halo tiles, 29 no four-wave filter-gradient kernel (v8), 30 v8 also on
  *         short pixel ranges;
  * key 3 = single-kernel NMS (value != 0);
  * key 4 = batch norm: maps of up to `value` rows run statistics + finalize + apply in ONE launch (default 1024, 0 = never); larger maps take three
  *         (statistics, finalize, apply); value -2 = two (apply with the finalize folded in: measured slower, A/B only), -1 = back to three;
- *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back; -7 = where three
- *         launches would run, the statistics launch finishes its column groups by ticket (2 launches; device-scope fences), -9 = the same without fences
- *         (write-through partials), -8 = back (default; neither has run on hardware yet);
+ *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back;
  * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
  *         run, 2.5 % slower on the SSD300 step) instead of float atomics into dw (the default);
- * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never); -7 / -9 / -8 as key 4
- *         for the bf16 maps whose groups lie inside 64-channel blocks */
+ * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never) */
 int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to
  * every later call of this thread until the slot changes.  Calls on ONE stream are ordered and share slot 0; a caller that
@@ -350,7 +347,7 @@ int odtk_softmax_ce_const(const float* pred, long long rows, int C, int ld, int 
  * (u8, NULL = all valid) must equal `valid_value`; max_out from max_out_dev[b*max_out_stride]
  * (device ints) or, when NULL, max_out_const.  Selected ORIGINAL indices in pick order go to
  * out_idx[b*cap + j], the count to out_cnt[b].  Bit-exact vs the reference kernel for distinct
- * scores; equal scores are visited lower index first.  n <= 16384. */
+ * scores; equal scores are visited lower index first.  n <= 32768 (above 16384 a global-memory work area of the single-workgroup kernel is used). */
 int odtk_nms_batched(const float* boxes, long long box_stride, const float* scores,
                      long long score_bstride, int score_estride, const unsigned char* valid,
                      long long valid_bstride, int valid_estride, int valid_value, int n, int B,

@@ -116,7 +116,8 @@ class CenterNet(F32Warmup):
         self.dev = torch.device(config.get('device', 'cuda:0'))
         # engine: bf16 by default on the GPU since round 3 (warmup.py: the first f32_warmup_steps optimizer steps of a run from random initialisation go through
         # an f32 twin); an explicit 'compute_dtype' is taken literally; the CPU stand-in of the library (host-logic tests) stays on f32
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16' if torch.device(config.get('device', 'cuda:0')).type == 'cuda' else 'f32')]
+        # (mode 'test' keeps f32 unless asked otherwise, as ssd300.py does: the bf16 gate checks training gradients, not thresholded detections)
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16' if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0
@@ -209,6 +210,7 @@ class CenterNet(F32Warmup):
         self._refresh_operand_copies()
 
     def export_params(self):
+        self._sync_from_twin()
         out = OrderedDict((k, self.get_param(k)) for k in self.pinfo)
         for k in self.sinfo:
             out[k] = self.stat(k).detach().cpu().clone()
@@ -516,6 +518,7 @@ class CenterNet(F32Warmup):
         slots `center_detector/<variable>/Adam` (m), `…/Adam_1` (v) and the accumulators `center_detector/beta1_power` / `beta2_power`
         (= beta^(t + 1) after t steps): `optimizer.minimize` runs INSIDE `with tf.variable_scope('center_detector')` (:131-156), and both the slot
         creator (`variable_scope(None, primary.op.name + '/Adam')`) and the non-slot accumulators take the enclosing scope as a prefix"""
+        self._sync_from_twin()
         out = OrderedDict()
         for tfname, ours in reference_variable_map(self.num_classes).items():
             if ours in self.pinfo:

@@ -783,7 +783,7 @@ __global__ void __launch_bounds__(256) filter_prepare_batched_kernel(const FpIte
 static bool g_force_regstage = false;   // debugging knob (odtk_debug_set key 0)
 static thread_local const char* g_last_kernel = "";   // name of the conv kernel the last conv call launched (odtk_conv_last_kernel)
 static int g_dbg = 0;                   // key 2: perf-experiment bits forwarded to the kernels (results are wrong when set)
-static int g_v3_mode = 0;               // key 1: 0 = auto, 1 = legacy 4-wave kernels only, 2 = 8-wave v3 wherever supported, 3 = persistent v4 wherever supported
+static int g_v3_mode = 0;               // key 1: 0 = auto, 1 = legacy 4-wave kernels only, 2 = 8-wave v3 wherever supported
 
 template <typename T, typename TO>
 int launch_gather(const GatherArgs& a, int PT, hipStream_t st) {
@@ -829,11 +829,9 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
     }
     if (!g_force_regstage && g_v3_mode != 1 && gather_v3_supported(a, dtype, out_dtype) &&
         (g_v3_mode >= 2 || gather_v3_auto(a))) {
-        const bool v4 = g_v3_mode == 3 && a.idiv == 1;       // the persistent variant has no strided-dgrad tap walk
         a.ksplit = 1;
-        if (int e = v4 ? launch_gather_v4(a, st) : launch_gather_v3(a, st)) return e;
-        g_last_kernel = v4 ? (a.K <= 64 ? "conv_gather_v4_kernel<64>" : "conv_gather_v4_kernel<128>")
-                        : a.ksplit > 1 ? (a.K <= 64 ? "conv_gather_v3_kernel<64>+splitk" : "conv_gather_v3_kernel<128>+splitk")
+        if (int e = launch_gather_v3(a, st)) return e;
+        g_last_kernel = a.ksplit > 1 ? (a.K <= 64 ? "conv_gather_v3_kernel<64>+splitk" : "conv_gather_v3_kernel<128>+splitk")
                         : a.ksplit < 0 ? "conv_gather_v6_kernel"
                                        : (a.K <= 64 ? "conv_gather_v3_kernel<64>" : "conv_gather_v3_kernel<128>");
         ODTK_LAUNCH_CHECK();
@@ -1001,7 +999,7 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     }
     if (!g_force_regstage && g_v3_mode != 1 && wgrad_v3_supported(a, d->dtype)) {
         launch_wgrad_v3(a, (hipStream_t)stream);
-        g_last_kernel = a.which == 8 ? "conv_wgrad_v8_kernel" : (a.which == 7 ? "conv_wgrad_v7_kernel" : "conv_wgrad_v3_kernel");
+        g_last_kernel = a.which == 8 ? "conv_wgrad_v8_kernel" : "conv_wgrad_v3_kernel";
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }

@@ -176,7 +176,7 @@ struct WgradArgs {
     float* bws;
     int nsplit, nbslot;
     int rev;         // tile order of the persistent conv1_x filter-gradient kernels: see GatherArgs::rev
-    int which;       // set by launch_wgrad_v3: the kernel generation that ran (3 | 7 | 8), for odtk_conv_last_kernel
+    int which;       // set by launch_wgrad_v3: the kernel generation that ran (3 | 8), for odtk_conv_last_kernel
 };
 
 // 16 bytes of zeros that padded / out-of-range LDS-DMA lanes fetch instead of branching
@@ -267,7 +267,6 @@ __device__ __forceinline__ void post_chunk(uint4& v, bool accumulate, bool relu,
 // 8-wave / 3-stage LDS ring kernels (conv_v3.hip)
 bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype);
 int launch_gather_v3(GatherArgs& a, hipStream_t st);
-int launch_gather_v4(GatherArgs& a, hipStream_t st);   // persistent, loader/compute wave-specialised
 bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype);   // resident-filter 64->64 3x3 kernel (the only one with the fused pool)
 int launch_gather_c64(GatherArgs& a, hipStream_t st);
 bool gather_c8_supported(const GatherArgs& a, int dtype, int out_dtype);    // first-layer (3 -> 64) 3x3 kernel

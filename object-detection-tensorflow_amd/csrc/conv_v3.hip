@@ -463,168 +463,6 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
-// "v5": the same 128 (channels) x 256 (pixels) tile and 3-slab LDS ring on FOUR waves (one per SIMD, 2 x 2, every wave
-// 64 x 128 = 8 MFMA tiles, 128 accumulator registers): 0.75 fragment reads per MFMA instead of 1.0, half as many
-// barrier participants.  One wave per SIMD only overlaps with itself, so the slab body is one scheduling region with
-// the hand-dealt order of the conv1_2 wgrad kernel: per MFMA at most one ds_read_b128 of the next sub-step and, on
-// every third slot, one LDS-DMA piece of slab kt+2.  C % 64 == 0 (wave-uniform tap walk), buffer-addressed DMA.
-// ---------------------------------------------------------------------------------------
-template <int PT>
-__global__ void __launch_bounds__(256) conv_gather_v5_kernel(const GatherArgs a) {
-    constexpr int QT = 256, NTHR = 256;
-    constexpr int PI = PT / 64, QI = 4;                 // wave tile (PT/2) x 128
-    constexpr int NQ = QT / 32, NP = PT / 32;           // DMA pieces per wave and slab: pixel rows r0 + 32 i, filter rows
-    constexpr int NDMA = NQ + NP;
-    constexpr int STAGE = (PT + QT) * 128, NST = 3;
-    constexpr int NMMA = 4 * PI * QI;                   // MFMAs per wave and slab
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wp = wave & 1, wq = wave >> 1;
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
-    const int p0 = tp * PT, q0 = tq * QT;
-    const int nk = (a.Kdim + 63) >> 6;
-    const int r0 = tid >> 3;                            // DMA rows r0 + 32 i
-    const int cc = (tid & 7) ^ swz_g(r0);
-    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rw = make_rsrc(a.w, a.w_bytes);
-    unsigned qoff32[NQ], qmask[NQ], poff32[NP];
-    bool pok[NP];
-    const int HoWo = a.Ho * a.Wo;
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const int m = q0 + r0 + 32 * i;
-        qmask[i] = 0; qoff32[i] = 0;
-        if (m < a.M) {
-            const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HoWo;
-            const int ho = (int)fdiv((unsigned)rem, a.div_wo), wo = rem - ho * a.Wo;
-            const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
-            const int hq = a.idiv == 2 ? hb >> 1 : hb, wq2 = a.idiv == 2 ? wb >> 1 : wb;       // stride-2 dgrad: see v3
-            qoff32[i] = (unsigned)(((n * a.H + hq) * a.W + wq2) * a.ldx * 2 + cc * 16);
-            unsigned rm = 0, cm = 0;
-            for (int r = 0; r < a.R; ++r) {
-                const int hn = hb + r * a.dil;
-                if (a.idiv == 2 ? (hn >= 0 && !(hn & 1) && (hn >> 1) < a.H) : (unsigned)hn < (unsigned)a.H) rm |= 1u << r;
-            }
-            for (int s2 = 0; s2 < a.S; ++s2) {
-                const int wn = wb + s2 * a.dil;
-                if (a.idiv == 2 ? (wn >= 0 && !(wn & 1) && (wn >> 1) < a.W) : (unsigned)wn < (unsigned)a.W) cm |= 1u << s2;
-            }
-            unsigned mk = 0;
-            for (int r = 0; r < a.R; ++r)
-                if ((rm >> r) & 1u) mk |= cm << (r * a.S);
-            qmask[i] = mk;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int row = p0 + r0 + 32 * i;
-        pok[i] = row < a.K;
-        poff32[i] = (unsigned)(row * a.ldw * 2 + cc * 16);
-    }
-    int s_klin = 0, s_kc = 0, s_ks = 0, s_kr = 0;
-    // piece q of slab (s_kr, s_ks, s_kc) into stage `stage`
-    auto piece = [&](int q, unsigned dP, unsigned toff32, unsigned tapbit, unsigned woff) __attribute__((always_inline)) {
-        if (q < NQ) {
-            const unsigned addr = qoff32[q] + toff32;
-            glds16_buf_nc(rx, (qmask[q] & tapbit) ? addr : 0xFFFFFFF0u, dP + PT * 128 + q * 4096u);
-        } else {
-            const unsigned addr = poff32[q - NQ] + woff;
-            glds16_buf_nc(rw, pok[q - NQ] ? addr : 0xFFFFFFF0u, dP + (q - NQ) * 4096u);
-        }
-    };
-    auto slab_consts = [&](int stage, unsigned& dP, unsigned& toff32, unsigned& tapbit, unsigned& woff) __attribute__((always_inline)) {
-        dP = smem_base + (unsigned)stage * STAGE + wave_u * 1024u;
-        const int sr = a.idiv == 2 ? (s_kr + 1) >> 1 : s_kr * a.dil, ss = a.idiv == 2 ? (s_ks + 1) >> 1 : s_ks * a.dil;
-        toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + s_kc * 2);
-        tapbit = 1u << (s_kr * a.S + s_ks);
-        woff = (unsigned)(s_klin * 2);
-    };
-    auto advance = [&]() __attribute__((always_inline)) {
-        s_klin += 64;
-        s_kc += 64;
-        if (s_kc >= a.C) {
-            s_kc = 0;
-            if (++s_ks == a.S) { s_ks = 0; ++s_kr; }
-        }
-    };
-    auto issue_all = [&](int stage) __attribute__((always_inline)) {
-        unsigned dP, toff32, tapbit, woff;
-        slab_consts(stage, dP, toff32, tapbit, woff);
-#pragma unroll
-        for (int q = 0; q < NDMA; ++q) piece(q, dP, toff32, tapbit, woff);
-        advance();
-    };
-
-    f32x16_v acc[PI][QI];
-#pragma unroll
-    for (int i = 0; i < PI; ++i)
-#pragma unroll
-        for (int j = 0; j < QI; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    issue_all(0);
-    if (nk > 1) issue_all(1);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int prow0 = wp * (PT / 2), qrow0 = wq * 128;
-    unsigned pofs[PI], qofs[QI];
-#pragma unroll
-    for (int i = 0; i < PI; ++i) { const int row = prow0 + i * 32 + l31; pofs[i] = (unsigned)(row * 128) | ((unsigned)swz_g(row) << 16); }
-#pragma unroll
-    for (int j = 0; j < QI; ++j) { const int row = qrow0 + j * 32 + l31; qofs[j] = (unsigned)(row * 128) | ((unsigned)swz_g(row) << 16); }
-    auto slab = [&](auto ISSUE, int stage_c, int stage_n) __attribute__((always_inline)) {
-        constexpr bool do_issue = decltype(ISSUE)::value;
-        const char* sP = smem + stage_c * STAGE;
-        const char* sQ = sP + PT * 128;
-        uint4 pf[2][PI], qf[2][QI];
-        auto rd = [&](int ks, int r) __attribute__((always_inline)) {       // read #r of sub-step ks: P.., then Q..
-            const int slot = ks * 2 + hi;
-            if (r < PI) pf[ks & 1][r] = *reinterpret_cast<const uint4*>(sP + (pofs[r] & 0xFFFFu) + (((unsigned)slot ^ (pofs[r] >> 16)) << 4));
-            else qf[ks & 1][r - PI] = *reinterpret_cast<const uint4*>(sQ + (qofs[r - PI] & 0xFFFFu) + (((unsigned)slot ^ (qofs[r - PI] >> 16)) << 4));
-        };
-        unsigned dP = 0, toff32 = 0, tapbit = 0, woff = 0;
-        if (do_issue) slab_consts(stage_n, dP, toff32, tapbit, woff);
-#pragma unroll
-        for (int r = 0; r < PI + QI; ++r) rd(0, r);
-        static_for<4>([&](auto KS) __attribute__((always_inline)) {
-            constexpr int ks = decltype(KS)::value;
-#pragma unroll
-            for (int j = 0; j < QI; ++j)
-#pragma unroll
-                for (int i = 0; i < PI; ++i) {
-                    const int mi = j * PI + i;                       // MFMA # inside the sub-step (0 .. PI*QI-1)
-                    const int slotno = ks * (PI * QI) + mi;
-                    Mma<bf16_t>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
-                    if (ks < 3) {
-#pragma unroll
-                        for (int r = 0; r < PI + QI; ++r)
-                            if (r * (PI * QI) / (PI + QI) == mi) rd(ks + 1, r);
-                    }
-                    if (do_issue) {
-#pragma unroll
-                        for (int q = 0; q < NDMA; ++q)
-                            if (q * NMMA / NDMA == slotno) piece(q, dP, toff32, tapbit, woff);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        });
-        if (do_issue) advance();
-    };
-    int st_c = 0, st_n = 2;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
-        block_barrier();
-        if (kt + 2 < nk) slab(std::integral_constant<bool, true>{}, st_c, st_n);
-        else slab(std::integral_constant<bool, false>{}, st_c, st_n);
-        st_c = st_c == 2 ? 0 : st_c + 1;
-        st_n = st_n == 2 ? 0 : st_n + 1;
-    }
-    block_barrier();
-    epilogue_bf16<PT, QT, NTHR, PI, QI>(a, smem, acc, p0, q0, prow0, qrow0, tid);
-}
-
-// ---------------------------------------------------------------------------------------
 // "v6": raster-run halo gather for 3x3 / stride 1 / pad 1 layers (C % 64 == 0, W <= 79): the v5 tile and schedule, but
 // the PIXEL operand is no longer gathered once per tap.  The 256 output pixels of a tile are a contiguous run m0.. of the
 // (n, h, w) raster, so the inputs of ALL nine taps lie in the contiguous run m0 - d(W + 1) .. m0 + 255 + d(W + 1): that patch
@@ -880,259 +718,6 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const GatherArgs a) 
 }
 
 
-// ---------------------------------------------------------------------------------------
-// Persistent, wave-specialised gather kernel ("v4"): forward conv and stride-1 dgrad.
-//
-// One 768-thread workgroup per CU, launched once per CU and looping over output tiles:
-//   waves 0-7  COMPUTE: 2 (channels) x 4 (pixels) wave grid over a PT x 256 tile; per k-slab they
-//              only wait at the slab barrier, read fragments (ds_read_b128) and issue MFMAs;
-//   waves 8-11 LOADERS: issue every LDS-DMA piece (12 | 10 per wave per slab) into a 3-slab ring,
-//              two slabs ahead of the compute waves, and wait (counted vmcnt) for slab g before
-//              arriving at barrier g.  The loaders walk the flat (tile, slab) sequence of the
-//              block, so the first slabs of the NEXT tile land while the compute waves run the
-//              epilogue of the current one: no per-tile prologue, no workgroup turnover.
-// Epilogue (compute waves, no workgroup barrier): each wave rounds its 16-pixel x (PT/2)-channel
-// quarter tiles to bf16 through a private 2-KiB (1-KiB) LDS patch and stores full 128-B (64-B)
-// row segments, 16 B per lane; bias / ReLU-mask operands are prefetched before the last slab.
-// LDS: 3 x 48 KiB ring + 8 x 2 KiB patches = 160 KiB (PT = 128).
-// ---------------------------------------------------------------------------------------
-template <int PT>
-__global__ void __launch_bounds__(768) conv_gather_v4_kernel(const GatherArgs a, const int total_tiles) {
-    constexpr int QT = 256;
-    constexpr int PI = PT / 64, QI = 2;
-    constexpr int STAGE = (PT + QT) * 128;
-    constexpr int NST = 3;
-    constexpr int RING = NST * STAGE;
-    constexpr int WC = PT / 2;                         // channels per compute wave
-    constexpr int ROWB = WC * 2;                       // bytes per pixel row of a wave's patch (128 | 64)
-    constexpr int CPR = ROWB / 16;                     // 16-B chunks per patch row (8 | 4)
-    constexpr int WSTG = 16 * ROWB;                    // patch = 16 pixels
-    constexpr int KPL = (16 * CPR) / 64;               // chunks per lane per round (2 | 1)
-    constexpr int NPRE = 4 * KPL;                      // prefetched epilogue operands (= PI * 4)
-    constexpr int NQ = QT / 32;                        // Q pieces per loader wave per slab (8)
-    constexpr int NP = PT / 32;                        // P pieces per loader wave per slab (4 | 2)
-    constexpr int NL = NQ + NP;
-    static_assert(NPRE == PI * 4, "bias / mask prefetch share registers");
-    __shared__ __attribute__((aligned(16))) char smem[RING + 8 * WSTG];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grid = gridDim.x;
-    const int slot = xcd_remap(blockIdx.x, grid);
-    const int nk = (a.dbg & 8) ? 1 : (a.Kdim + 63) >> 6;
-    const int my_tiles = slot < total_tiles ? (total_tiles - slot + grid - 1) / grid : 0;
-    const int G = my_tiles * nk;                       // slabs (= barriers) of this block
-    if (G == 0) return;
-
-    if (wave >= 8) {
-        // ================================ loader waves ================================
-        const int L = wave - 8;
-        const int row_lo = L * 8 + (lane >> 3);        // rows row_lo + 32*i of both operand slabs
-        const int cc = (lane & 7) ^ swz_g(row_lo);     // logical 16-B chunk fetched by this lane
-        const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-        const char* zero = reinterpret_cast<const char*>(g_zero_page);
-        const int HoWo = a.Ho * a.Wo;
-        int kc0, ks0, kr0;
-        {
-            const int klin0 = cc * 8;
-            const int rs = klin0 / a.C;
-            kc0 = klin0 - rs * a.C;
-            kr0 = rs / a.S;
-            ks0 = rs - kr0 * a.S;
-        }
-        long long qoff[NQ], poff[NP];
-        unsigned qmask[NQ], pok = 0;
-        int klin = 0, kc = 0, ks = 0, kr = 0;
-        auto setup_tile = [&](int v) __attribute__((always_inline)) {
-            const int tq = v / a.tiles_p, tp = v - tq * a.tiles_p;
-            const int p0 = tp * PT, q0 = tq * QT;
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int m = q0 + row_lo + 32 * i;
-                qoff[i] = 0; qmask[i] = 0;
-                if (m < a.M) {
-                    const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HoWo;
-                    const int ho = (int)fdiv((unsigned)rem, a.div_wo), wo = rem - ho * a.Wo;
-                    const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
-                    qoff[i] = ((long long)(n * a.H + hb) * a.W + wb) * a.ldx * 2ll;
-                    unsigned rm = 0, cm = 0;
-                    for (int r = 0; r < a.R; ++r)
-                        if ((unsigned)(hb + r * a.dil) < (unsigned)a.H) rm |= 1u << r;
-                    for (int s2 = 0; s2 < a.S; ++s2)
-                        if ((unsigned)(wb + s2 * a.dil) < (unsigned)a.W) cm |= 1u << s2;
-                    unsigned mk = 0;
-                    for (int r = 0; r < a.R; ++r)
-                        if ((rm >> r) & 1u) mk |= cm << (r * a.S);
-                    qmask[i] = mk;
-                }
-            }
-            pok = 0;
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int row = p0 + row_lo + 32 * i;
-                if (row < a.K) pok |= 1u << i;
-                poff[i] = (long long)row * a.ldw * 2ll;
-            }
-            klin = cc * 8; kc = kc0; ks = ks0; kr = kr0;
-        };
-        int it_i = 0, kt_i = 0;                         // tile / slab of the next slab to issue
-        auto issue = [&](int stage) __attribute__((always_inline)) {
-            const unsigned sP = smem_base + (unsigned)stage * STAGE + (unsigned)L * 1024u;
-            const unsigned sQ = sP + PT * 128;
-            const bool kv = kr < a.R;
-            const int tap = kr * a.S + ks;
-            const long long toff = ((long long)(kr * a.dil) * a.W + ks * a.dil) * a.ldx * 2ll + (long long)kc * 2ll;
-            const bool first = klin < 64;
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const bool ok = kv && ((qmask[i] >> tap) & 1u);
-                const char* src = ok ? a.x + qoff[i] + toff : zero;
-                if ((a.dbg & 1) && !first) src = zero;
-                glds16(src, sQ + i * 4096u);
-            }
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const bool ok = kv && ((pok >> i) & 1u);
-                const char* src = ok ? a.w + poff[i] + (long long)klin * 2ll : zero;
-                if ((a.dbg & 2) && !first) src = zero;
-                glds16(src, sP + i * 4096u);
-            }
-            klin += 64;
-            kc += 64;
-            while (kc >= a.C) {
-                kc -= a.C;
-                if (++ks == a.S) { ks = 0; ++kr; }
-            }
-            if (++kt_i == nk) {
-                kt_i = 0;
-                if (++it_i < my_tiles) setup_tile(slot + it_i * grid);
-            }
-        };
-        setup_tile(slot);
-        issue(0);
-        if (G > 1) issue(1);
-        int st_n = 2;
-        for (int g = 0; g < G; ++g) {
-            if (g + 1 < G) wait_vmcnt<NL>(); else wait_vmcnt<0>();     // slab g landed (this wave's pieces)
-            block_barrier();          // publish slab g; every compute wave has finished slab g-1 (= stage st_n)
-            if (g + 2 < G && !((a.dbg & 4) && g > 0)) issue(st_n);
-            st_n = st_n == 2 ? 0 : st_n + 1;
-        }
-        return;
-    }
-
-    // ================================== compute waves ==================================
-    const int wp = wave & 1, wq = wave >> 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    char* stg = smem + RING + wave * WSTG;
-    int st_c = 0;
-    for (int it = 0; it < my_tiles; ++it) {
-        const int v = slot + it * grid;
-        const int tq = v / a.tiles_p, tp = v - tq * a.tiles_p;
-        const int p0 = tp * PT, q0 = tq * QT;
-        f32x16_v acc[PI][QI];
-#pragma unroll
-        for (int i = 0; i < PI; ++i)
-#pragma unroll
-            for (int j = 0; j < QI; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        uint4 pre[NPRE];
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) pre[i] = make_uint4(0, 0, 0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            block_barrier();                            // slab (it, kt) is in stage st_c
-            if (kt == nk - 1) {
-                // prefetch the epilogue operands under the last slab's MFMAs
-                if (a.bias) {
-#pragma unroll
-                    for (int i = 0; i < PI; ++i)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int c = p0 + wp * WC + i * 32 + 8 * g + 4 * hi;
-                            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (c + 3 < a.K) b = *reinterpret_cast<const float4*>(a.bias + c);
-                            else {
-                                if (c < a.K) b.x = a.bias[c];
-                                if (c + 1 < a.K) b.y = a.bias[c + 1];
-                                if (c + 2 < a.K) b.z = a.bias[c + 2];
-                            }
-                            pre[i * 4 + g] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w));
-                        }
-                } else if (a.mask) {
-#pragma unroll
-                    for (int rd = 0; rd < 4; ++rd)
-#pragma unroll
-                        for (int k = 0; k < KPL; ++k) {
-                            const int idx = lane + 64 * k;
-                            const int px = idx / CPR, ch = idx % CPR;
-                            const int m = q0 + wq * 64 + (rd >> 1) * 32 + (rd & 1) * 16 + px, c0 = p0 + wp * WC + ch * 8;
-                            if (m < a.M && c0 < a.ldy)
-                                pre[rd * KPL + k] = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
-                        }
-                }
-            }
-            const char* sP = smem + st_c * STAGE;
-            mma_slab<bf16_t, PI, QI, true>(sP, sP + PT * 128, wp * WC, wq * 64, lane, acc);
-            st_c = st_c == 2 ? 0 : st_c + 1;
-        }
-        // ---- epilogue: 4 rounds of 16 pixels through the wave's private LDS patch
-        const bool pre_relu = a.relu && !a.accumulate;
-#pragma unroll
-        for (int j = 0; j < QI; ++j) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if ((l31 >> 4) == h) {
-                    const int px = l31 & 15;
-#pragma unroll
-                    for (int i = 0; i < PI; ++i)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int cl = i * 32 + 8 * g + 4 * hi;
-                            float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
-                            if (a.bias) {
-                                const uint4 b = pre[i * 4 + g];
-                                v0 += __uint_as_float(b.x); v1 += __uint_as_float(b.y);
-                                v2 += __uint_as_float(b.z); v3 += __uint_as_float(b.w);
-                            }
-                            if (pre_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                            uint2 o;
-                            o.x = cvt_pk_bf16(v0, v1);
-                            o.y = cvt_pk_bf16(v2, v3);
-                            *reinterpret_cast<uint2*>(stg + px * ROWB + ((((cl >> 3) ^ px) & (CPR - 1)) << 4) + ((cl & 4) << 1)) = o;
-                        }
-                }
-                // the patch is private to this wave and LDS executes a wave's accesses in order; the clobbers only
-                // stop the COMPILER from moving the 16-B reads across the 8-B writes (different types: TBAA)
-                asm volatile("" ::: "memory");
-                const int rd = j * 2 + h;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) {
-                    const int idx = lane + 64 * k;
-                    const int px = idx / CPR, ch = idx % CPR;
-                    const int m = q0 + wq * 64 + j * 32 + h * 16 + px, c0 = p0 + wp * WC + ch * 8;
-                    uint4 v = *reinterpret_cast<const uint4*>(stg + px * ROWB + (((ch ^ px) & (CPR - 1)) << 4));
-                    if (m < a.M && c0 < a.ldy) {
-                        char* yp = a.y + ((size_t)m * a.ldy + c0) * 2;
-                        if (a.accumulate || a.mask) {
-                            uint4 old = make_uint4(0, 0, 0, 0), mk = make_uint4(0, 0, 0, 0);
-                            if (a.accumulate) old = *reinterpret_cast<const uint4*>(yp);
-                            if (a.mask) {
-                                if (a.bias) mk = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
-                                else mk = pre[rd * KPL + k];
-                            }
-                            post_chunk(v, a.accumulate != 0, a.relu != 0, old, a.mask != nullptr, mk);
-                        }
-                        *reinterpret_cast<uint4*>(yp) = v;
-                    }
-                }
-                asm volatile("" ::: "memory");
-            }
-        }
-    }
-}
-
-
 // Partial filter-gradient tile of one wave -> ws[split] in full 16-byte, row-contiguous stores: the MFMA accumulator layout has a
 // lane own 4 consecutive K ROWS of one column, so storing it directly is one dword per lane and instruction (256 per lane for a
 // 128 x 128 wave tile -- measured 3.5 % of the step slower than float atomics); 32 rows at a time go through a wave-private LDS
@@ -1383,181 +968,6 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
     d4[i] = o;
 }
-
-// ---------------------------------------------------------------------------------------
-// "v7" filter gradient: the v3 kernel with a 256 (k) x 256 (columns) tile -- two 128-channel dy sub-slabs next to the two
-// 128-column x sub-slabs, 32 pixels per k-slab, every wave 128 x 64 (8 accumulator tiles): 4 LDS-DMA pieces and 24
-// transpose reads per 16 MFMAs instead of 6 and 32.  For Cout >= 256; the pixel-split count absorbs the coarser tiles.
-// ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) conv_wgrad_v7_kernel(const WgradArgs a) {
-    constexpr int PI = 4, QI = 2;
-    constexpr int PKE = 32;                          // pixels per k-slab
-    constexpr int OPB = PKE * 256;                   // bytes per 128-channel operand sub-slab (8 KiB)
-    constexpr int STAGE = 4 * OPB;                   // two P + two Q sub-slabs
-    constexpr int NST = 3;
-    constexpr int NDMA = 4;
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = wave & 1, wq = wave >> 1;
-    // 1-D grid, XCD-aware order: an XCD's contiguous range of virtual ids covers whole pixel splits, so the
-    // tiles that re-read the same dy / x pixel slabs (same split, different tile) share one L2
-    const int ntiles = a.tiles_p * a.tiles_q;
-    const int vb = (a.dbg & 512) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    const int split = vb / ntiles, tile = vb - split * ntiles;
-    const int tq = tile / a.tiles_p, tp = tile - tq * a.tiles_p;
-    const int p0 = tp * 256, q0 = tq * 256;
-    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
-
-    // DMA lane role: pixel row dr of the piece, logical 16-B chunk dch (source-side swizzle)
-    const int dr = lane >> 4;
-    const int dch = (lane & 15) ^ (dr << 2);
-    const int pch = p0 + dch * 8;                    // + 128 for the second P sub-slab
-    const bool p_col_ok[2] = {pch < a.lddy, pch + 128 < a.lddy};
-    int dh[2], dw_[2], qc[2];
-    bool q_col_ok[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int j0 = q0 + s * 128 + dch * 8;
-        q_col_ok[s] = j0 < a.RSC;
-        int qr = 0, qs = 0; qc[s] = 0;
-        if (q_col_ok[s]) {
-            const int rs = j0 / a.C;
-            qc[s] = j0 - rs * a.C;
-            qr = rs / a.S;
-            qs = rs - qr * a.S;
-        }
-        dh[s] = qr * a.dil - a.pad_t;
-        dw_[s] = qs * a.dil - a.pad_l;
-    }
-    const int HoWo = a.Ho * a.Wo;
-    const int iters_total = (a.P + PKE - 1) / PKE;
-    const int it0 = split * a.iters_per_split;
-    int it1 = it0 + a.iters_per_split;
-    if (it1 > iters_total) it1 = iters_total;
-    if (it0 >= it1) return;
-
-    auto issue = [&](int it, int stage) __attribute__((always_inline)) {
-        const unsigned sP = smem_base + (unsigned)stage * STAGE;
-        const int piece = wave;                       // 8 pieces of 4 pixels per sub-slab, one per wave
-        const int p = it * PKE + piece * 4 + dr;
-        const bool pin = p < a.P;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            glds16_buf(rdy, (pin && p_col_ok[s]) ? (unsigned)((p * a.lddy + pch + s * 128) * 2) : 0xFFFFFFF0u,
-                       sP + (unsigned)(s * OPB) + (unsigned)piece * 1024u);
-        const unsigned n = fdiv((unsigned)p, a.div_howo);
-        const unsigned rem = (unsigned)p - n * (unsigned)HoWo;
-        const unsigned ho = fdiv(rem, a.div_wo);
-        const unsigned wo = rem - ho * (unsigned)a.Wo;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int hi = (int)ho * a.stride + dh[s], wi = (int)wo * a.stride + dw_[s];
-            const bool ok = pin && q_col_ok[s] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            glds16_buf(rx, ok ? (unsigned)(((((int)n * a.H + hi) * a.W + wi) * a.ldx + qc[s]) * 2) : 0xFFFFFFF0u,
-                       sP + (unsigned)((2 + s) * OPB) + (unsigned)piece * 1024u);
-        }
-    };
-
-    // transpose-read lane role (see conv_wgrad_dma_kernel): group g = lane>>4, c = lane&15
-    const int g = lane >> 4, c = lane & 15;
-    const int rr = c >> 2;
-    unsigned pfo[PI], qfo[QI];
-#pragma unroll
-    for (int i = 0; i < PI; ++i) {
-        const int ch = (i * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
-        pfo[i] = (unsigned)(wp * OPB + (2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < QI; ++j) {
-        const int ch = ((wq & 1) * 64 + j * 32 + 16 * (g & 1)) / 8 + ((c & 3) >> 1);
-        qfo[j] = (unsigned)((2 + (wq >> 1)) * OPB + (2 * (g >> 1)) * 1024 + (rr * 16 + (ch ^ (rr << 2))) * 16 + (c & 1) * 8);
-    }
-
-    f32x16_v acc[PI][QI];
-#pragma unroll
-    for (int i = 0; i < PI; ++i)
-#pragma unroll
-        for (int j = 0; j < QI; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const bool do_bias = a.dbias != nullptr && tq == 0 && wq == 0;     // wave-uniform
-    float bsum[PI] = {0.f, 0.f, 0.f, 0.f};
-
-    const int nk = it1 - it0;
-    issue(it0, 0);
-    if (nk > 1) issue(it0 + 1, 1);
-    int st_c = 0, st_n = 2;
-    const bool late = wave >= 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
-        block_barrier();
-        const bool do_issue = kt + 2 < nk;
-        if (do_issue && !late) issue(it0 + kt + 2, st_n);
-        const unsigned sS = smem_base + (unsigned)st_c * STAGE;
-        uint4 pf[2][PI], qf[2][QI];
-        auto ldf = [&](int ks, uint4 (&p)[PI], uint4 (&q)[QI]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < PI; ++i) {
-                const uint2 lo = lds_tr16(sS + ks * 4096u + pfo[i]);
-                const uint2 hi2 = lds_tr16(sS + ks * 4096u + 1024u + pfo[i]);
-                p[i] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
-            }
-#pragma unroll
-            for (int j = 0; j < QI; ++j) {
-                const uint2 lo = lds_tr16(sS + ks * 4096u + qfo[j]);
-                const uint2 hi2 = lds_tr16(sS + ks * 4096u + 1024u + qfo[j]);
-                q[j] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
-            }
-        };
-        ldf(0, pf[0], qf[0]);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks < 1) ldf(ks + 1, pf[(ks + 1) & 1], qf[(ks + 1) & 1]);
-#pragma unroll
-            for (int i = 0; i < PI; ++i)
-#pragma unroll
-                for (int j = 0; j < QI; ++j) Mma<bf16_t>::run(pf[ks & 1][i], qf[ks & 1][j], acc[i][j]);
-            if (do_bias) {
-#pragma unroll
-                for (int i = 0; i < PI; ++i) {
-                    const unsigned* d = reinterpret_cast<const unsigned*>(&pf[ks & 1][i]);
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) bsum[i] += bf16_lo(d[h]) + bf16_hi(d[h]);
-                }
-            }
-        }
-        if (do_issue && late) issue(it0 + kt + 2, st_n);
-        st_c = st_c == 2 ? 0 : st_c + 1;
-        st_n = st_n == 2 ? 0 : st_n + 1;
-    }
-
-    const int l31 = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < QI; ++j) {
-        const int col = q0 + wq * 64 + j * 32 + l31;
-        if (col >= a.RSC) continue;
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = p0 + wp * 128 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
-            }
-        }
-    }
-    if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const float t = bsum[i] + __shfl_xor(bsum[i], 32);       // both k halves
-            const int k = p0 + wp * 128 + i * 32 + l31;
-            if (hi == 0 && k < a.K) atomicAdd(a.dbias + k, t);
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (conv1_2 forward and its dgrad:
@@ -2433,8 +1843,11 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         }
         // 128 x 192 tiles where 256-pixel tiles leave a quarter of the CUs idle and 192-pixel tiles still fit one round (conv5_x: 184 -> 244
         // workgroups of 3/4 the work, 56 -> 50 us); dbg bit 28 = off (A/B)
+        // (round 4: whenever 192-pixel tiles need less time by rounds x (pixels + ~32 of prologue / epilogue per tile) -- conv4_1's input gradient: 362 tiles of
+        //  256 pixels = 2 rounds at 71 % -> 482 of 192 = 2 rounds of 3/4 the work; conv6 forward: 368 -> 488)
         const int tq192 = ceil_div(a.M, 192);
-        if (!(a.dbg & (1 << 28)) && halo <= 160 && tiles < g_num_cu && tq192 * a.tiles_p <= g_num_cu && tq192 * a.tiles_p > tiles) {
+        const long long cost256 = (long long)ceil_div(tiles, g_num_cu) * (256 + 32), cost192 = (long long)ceil_div(tq192 * a.tiles_p, g_num_cu) * (192 + 32);
+        if (!(a.dbg & (1 << 28)) && halo <= 160 && cost192 < cost256) {
             a.tiles_q = tq192;
             hipLaunchKernelGGL((conv_gather_v6_kernel<11, true, 0, 0, 2, 2, 3>), dim3(tq192 * a.tiles_p), dim3(256), 0, st, a);
             return 0;
@@ -2445,10 +1858,6 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         else if (a.dil * a.W >= 128) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 8>), dim3(grid), dim3(256), 0, st, a);
         else if (a.dil * a.W >= 112) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 7>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 6>), dim3(grid), dim3(256), 0, st, a);
-        return 0;
-    }
-    if ((a.dbg & 32768) && PT == 128 && a.C % 64 == 0 && a.Kdim % 64 == 0) {      // 4-wave hand-scheduled variant (dbg bit 15, A/B)
-        hipLaunchKernelGGL(conv_gather_v5_kernel<128>, dim3(grid), dim3(256), 0, st, a);
         return 0;
     }
     const bool db = (a.dbg & 32) == 0;      // fragment double buffering (default on; dbg bit 5 turns it off)
@@ -2467,18 +1876,6 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     } while (0)
     if (PT == 64) ODTK_V3(64); else ODTK_V3(128);
 #undef ODTK_V3
-    return 0;
-}
-
-int launch_gather_v4(GatherArgs& a, hipStream_t st) {
-    if (g_num_cu == 0) query_num_cu();
-    const int PT = a.K <= 64 ? 64 : 128;
-    a.tiles_p = ceil_div(a.K, PT);
-    a.tiles_q = ceil_div(a.M, 256);
-    const int tiles = a.tiles_p * a.tiles_q;
-    const int grid = tiles < g_num_cu ? tiles : g_num_cu;
-    if (PT == 64) hipLaunchKernelGGL(conv_gather_v4_kernel<64>, dim3(grid), dim3(768), 0, st, a, tiles);
-    else hipLaunchKernelGGL(conv_gather_v4_kernel<128>, dim3(grid), dim3(768), 0, st, a, tiles);
     return 0;
 }
 
@@ -2852,33 +2249,7 @@ bool launch_wgrad_v8(WgradArgs& a, hipStream_t st) {
     return true;
 }
 
-int launch_wgrad_v7(WgradArgs& a, hipStream_t st) {
-    a.tiles_p = ceil_div(a.K, 256);
-    a.tiles_q = ceil_div(a.RSC, 256);
-    const int tiles = a.tiles_p * a.tiles_q;
-    const int iters_total = ceil_div(a.P, 32);
-    if (g_num_cu == 0) query_num_cu();
-    int best_s = 1;
-    double best_t = 1e30;
-    const int smax = iters_total < 8 ? 1 : iters_total / 8;
-    for (int s = 1; s <= smax && s <= 1024; ++s) {      // rounds x (slabs x ~1.0 us + prologue and 64 K float atomics per block)
-        const int ips = ceil_div(iters_total, s);
-        const int sp = ceil_div(iters_total, ips);
-        const double rounds = (double)ceil_div(tiles * sp, g_num_cu);
-        const double tt = rounds * (ips * 1.0 + 10.0);
-        if (tt < best_t - 1e-9) { best_t = tt; best_s = sp; }
-    }
-    a.iters_per_split = ceil_div(iters_total, best_s);
-    const int splits = ceil_div(iters_total, a.iters_per_split);
-    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
-    a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
-    hipLaunchKernelGGL(conv_wgrad_v7_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
-    a.which = 7;
-    return 0;
-}
-
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
-    if (a.K >= 256 && (a.dbg & 131072)) return launch_wgrad_v7(a, st);       // 256 x 256 tile (dbg bit 17, A/B)
     // four-wave kernel with 128 x 128 wave tiles: Cout a multiple of 256 (no tile waste) and long pixel ranges per block
     // (dbg bit 29 = off, bit 30 = also with short ranges: A/B)
     if (!(a.dbg & (1 << 29)) && a.K % 256 == 0 && a.RSC % 256 == 0 && launch_wgrad_v8(a, st)) return 0;

@@ -693,175 +693,6 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
     fin[C + c] = s2 / (float)M;
 }
 
-// ---- statistics + finalize in ONE launch (opt-in, odtk_debug_set key 4 value -7; default off, not yet measured on the GPU) ----------------------------------
-// YOLOv3 at 8 images / GPU spends 1.45 of its 11.1 ms in the 150 finalize launches of a step (profiles/r03k_yolov3_416_b8_kernel_trace.md: 10 us each for a few
-// hundred channels).  Folding the finalize into the APPLY prologue was slower (every apply workgroup re-reduces 169-256 partials, round 3); here the workgroup that
-// writes the LAST partial of a column group finishes that group: partials -> __threadfence -> ticket (one int per column group, self-resetting, library-owned per
-// stream) -> the last arriver sums the nsplit partials of its 8 chunks in a fixed order (same result whatever the arrival order) and writes what the finalize
-// kernels write.  The statistics loops below are copies of bn_stats_kernel / bn_bwd_stats_kernel: those stay byte-identical.
-// `nofence` (odtk_debug_set value -9 instead of -7): round 2 measured a ticket scheme with a device-scope fence in every workgroup SLOWER than the launch it
-// saved (YOLOv3 11.7 -> 15.9 ms; the release fence writes back the XCD's whole L2).  Without fences the partials are stored as agent-scope
-// relaxed atomics (write-through, sc1), the workgroup waits for its stores to be acknowledged (s_waitcnt 0) before the barrier that precedes the ticket draw,
-// and the last arriver reads them with agent-scope loads (bn_ticket_reduce already does): no L2 write-back or invalidate anywhere.
-__device__ __forceinline__ void ticket_store(float* p, float v, int nofence) {
-    if (nofence) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <int KC>
-__device__ __forceinline__ bool bn_ticket_is_last(int* __restrict__ tickets, int nsplit, int nofence) {
-    __shared__ int s_last;
-    if (nofence) __builtin_amdgcn_s_waitcnt(0);        // every counter to zero: this thread's write-through partials are acknowledged
-    else __threadfence();                              // this workgroup's partials are visible device-wide before its ticket is drawn
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1) == nsplit - 1;
-    __syncthreads();
-    if (s_last && !nofence) __threadfence();
-    return s_last != 0;
-}
-// sums of the [2][nsplit][C] partials for the 8 * KC channels of column group blockIdx.x: result valid in the threads with lane == 0
-template <int KC>
-__device__ __forceinline__ void bn_ticket_reduce(const float* __restrict__ ws, int nsplit, int C, int& c, int& lane, float& s1, float& s2) {
-    constexpr int CH = 8 * KC, LANES = 256 / CH;
-    __shared__ float sm[2][LANES][CH];
-    const int ch = threadIdx.x % CH;
-    lane = threadIdx.x / CH;
-    c = blockIdx.x * CH + ch;
-    float a1 = 0.f, a2 = 0.f;
-    if (c < C) {
-        for (int s = lane; s < nsplit; s += LANES) {      // device-scope loads: the partials were written by other compute units
-            a1 += __hip_atomic_load(ws + ((size_t)0 * nsplit + s) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a2 += __hip_atomic_load(ws + ((size_t)1 * nsplit + s) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    sm[0][lane][ch] = a1;
-    sm[1][lane][ch] = a2;
-    __syncthreads();
-    s1 = 0.f; s2 = 0.f;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < LANES; ++k) { s1 += sm[0][k][ch]; s2 += sm[1][k][ch]; }
-    }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) bn_stats_fin_kernel(const T* __restrict__ z, int M, int C, int ldz, int rows_per_split, float* __restrict__ ws,
-                                                           int* __restrict__ tickets, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ save_mean,
-                                                           float* __restrict__ save_invstd, float* __restrict__ fin, int nofence) {
-    constexpr int KC = Chunk<T>::N;
-    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c0 = (blockIdx.x * 8 + cl) * KC;
-    const int split = blockIdx.y, nsplit = gridDim.y;
-    float acc[2 * KC];
-#pragma unroll
-    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
-    if (c0 < C) {
-        float sh[KC];
-        Chunk<T>::unpack(ld16(z + c0), sh);
-        const int m0 = split * rows_per_split;
-        int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
-#pragma unroll 4
-        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
-            float f[KC];
-            Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
-#pragma unroll
-            for (int e = 0; e < KC; ++e) {
-                const float d = f[e] - sh[e];
-                acc[e] += d;
-                acc[KC + e] += d * d;
-            }
-        }
-    }
-    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
-    if (rl == 0 && c0 < C) {
-#pragma unroll
-        for (int e = 0; e < KC; ++e) {
-            if (c0 + e < C) {
-                ticket_store(&ws[((size_t)0 * nsplit + split) * C + c0 + e], acc[e], nofence);
-                ticket_store(&ws[((size_t)1 * nsplit + split) * C + c0 + e], acc[KC + e], nofence);
-            }
-        }
-    }
-    if (!bn_ticket_is_last<KC>(tickets, nsplit, nofence)) return;
-    int c, lane;
-    float s1, s2;
-    bn_ticket_reduce<KC>(ws, nsplit, C, c, lane, s1, s2);
-    if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // every workgroup of this column group has drawn: ready for the next launch
-    if (c >= C || lane != 0) return;
-    const float d = s1 / (float)M;                        // (bn_finalize_kernel's arithmetic)
-    const float mean = elem<T>::load(z[c]) + d;
-    const float var = fmaxf(s2 / (float)M - d * d, 0.f);
-    save_mean[c] = mean;
-    save_invstd[c] = rsqrtf(var + 1e-3f);
-    const float unb = var * ((float)M / (float)(M > 1 ? M - 1 : 1));
-    mmean[c] = mmean[c] * 0.99f + mean * (1.f - 0.99f);
-    mvar[c] = mvar[c] * 0.99f + unb * (1.f - 0.99f);
-    const float sc = rsqrtf(var + 1e-3f) * gamma[c];
-    fin[c] = sc;
-    fin[C + c] = beta[c] - mean * sc;
-}
-
-template <typename T, typename TY>
-__global__ void __launch_bounds__(256) bn_bwd_stats_fin_kernel(
-    const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
-    int rows_per_img, long long y_img_stride, const float* __restrict__ save_mean,
-    const float* __restrict__ save_invstd, int relu, int vec_ok, int rows_per_split, float* __restrict__ ws,
-    int* __restrict__ tickets, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ fin, int nofence) {
-    constexpr int KC = Chunk<T>::N;
-    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c0 = (blockIdx.x * 8 + cl) * KC;
-    const int split = blockIdx.y, nsplit = gridDim.y;
-    float acc[2 * KC];
-#pragma unroll
-    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
-    if (c0 < C) {
-        float mu[KC], iv[KC];
-#pragma unroll
-        for (int e = 0; e < KC; ++e) {
-            mu[e] = c0 + e < C ? save_mean[c0 + e] : 0.f;
-            iv[e] = c0 + e < C ? save_invstd[c0 + e] : 0.f;
-        }
-        const int m0 = split * rows_per_split;
-        int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
-#pragma unroll 2
-        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
-            float f[KC];
-            Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
-            const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
-            float d[KC];
-            bn_load_dy<T, TY>(y, dy, oo, c0, C, relu, vec_ok, d);
-#pragma unroll
-            for (int e = 0; e < KC; ++e) {
-                if (c0 + e >= C) continue;
-                acc[e] += d[e];
-                acc[KC + e] += d[e] * ((f[e] - mu[e]) * iv[e]);
-            }
-        }
-    }
-    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
-    if (rl == 0 && c0 < C) {
-#pragma unroll
-        for (int e = 0; e < KC; ++e) {
-            if (c0 + e < C) {
-                ticket_store(&ws[((size_t)0 * nsplit + split) * C + c0 + e], acc[e], nofence);
-                ticket_store(&ws[((size_t)1 * nsplit + split) * C + c0 + e], acc[KC + e], nofence);
-            }
-        }
-    }
-    if (!bn_ticket_is_last<KC>(tickets, nsplit, nofence)) return;
-    int c, lane;
-    float s1, s2;
-    bn_ticket_reduce<KC>(ws, nsplit, C, c, lane, s1, s2);
-    if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (c >= C || lane != 0) return;
-    dbeta[c] = s1;                                        // (bn_bwd_finalize_kernel's outputs)
-    dgamma[c] = s2;
-    fin[c] = s1 / (float)M;
-    fin[C + c] = s2 / (float)M;
-}
-
 template <typename T, typename TY>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const T* __restrict__ z, const TY* __restrict__ y, const TY* __restrict__ dy, int M, int C, int ldz, int ldy,
@@ -1427,34 +1258,7 @@ static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0). 
 static bool g_bn_auto_two = true;         // odtk_debug_set key 4, value -5: never pick the two-launch path by itself (round-2 behaviour; A/B); -6: back
 static bool g_bn_small_wide = false;      // odtk_debug_set key 4, value -3: the single-launch kernels in their 64-channel shape only (A/B); -4: back
 static bool g_bn_three_kernels = true;    // odtk_debug_set key 4, value -2: statistics + apply-with-finalize (two launches; A/B, tests); -1: back to three
-static int g_bn_ticket = 0;               // odtk_debug_set key 4, value -7: where three launches would run, the statistics launch finishes its column groups by
-                                          // ticket and the finalize launch is dropped (bn_stats_fin_kernel; NOT yet measured on the GPU); -9: the same without fences (bn_ticket_is_last); -8: back (default)
-namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else if (rows == -5) g_bn_auto_two = false; else if (rows == -6) g_bn_auto_two = true; else if (rows == -7) g_bn_ticket = 1; else if (rows == -9) g_bn_ticket = 2; else if (rows == -8) g_bn_ticket = 0; else g_bn_small_rows = rows; } }
-
-// Tickets of the statistics-with-finalize launches: one zero-initialised, self-resetting int per column group, in a library-owned buffer per (device, stream) --
-// launches on ONE stream are ordered and share a set; a caller with concurrent streams (SSD300's head stream) gets one set per stream, at most 8 per device
-// (a ninth stream falls back to the three launches).  Never freed or moved (captured graphs point into it).
-constexpr int BN_TICKET_SETS = 8, BN_TICKET_INTS = 4096;
-static int* g_bn_tickets[16] = {};
-static hipStream_t g_bn_ticket_stream[16][BN_TICKET_SETS];
-static int g_bn_ticket_used[16] = {};
-static int* bn_tickets_for(hipStream_t st, int colgroups) {
-    if (colgroups > BN_TICKET_INTS) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!g_bn_tickets[dev]) {
-        void* p = nullptr;
-        if (hipMalloc(&p, (size_t)BN_TICKET_SETS * BN_TICKET_INTS * sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, (size_t)BN_TICKET_SETS * BN_TICKET_INTS * sizeof(int)) != hipSuccess) return nullptr;     // once per device
-        if (hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;      // the callers' streams are non-blocking ones: the fill has landed before they launch
-        g_bn_tickets[dev] = (int*)p;
-    }
-    for (int i = 0; i < g_bn_ticket_used[dev]; ++i)
-        if (g_bn_ticket_stream[dev][i] == st) return g_bn_tickets[dev] + (size_t)i * BN_TICKET_INTS;
-    if (g_bn_ticket_used[dev] == BN_TICKET_SETS) return nullptr;
-    g_bn_ticket_stream[dev][g_bn_ticket_used[dev]] = st;
-    return g_bn_tickets[dev] + (size_t)(g_bn_ticket_used[dev]++) * BN_TICKET_INTS;
-}
+namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else if (rows == -5) g_bn_auto_two = false; else if (rows == -6) g_bn_auto_two = true; else g_bn_small_rows = rows; } }
 
 #define DT_SWITCH(dtype, T, ...)                                         \
     if ((dtype) == ODTK_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
@@ -1606,7 +1410,6 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
     }
     float* ws = (float*)workspace;
     float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
-    bool ticketed = false;
     if (training) {
         // Two launches (statistics; apply with the finalize folded into its prologue) where <= 32 row splits still fill the chip for the statistics pass
         // (>= 128 workgroups: the 256-1 024-channel layers of DarkNet-53 at 8 images: the finalize launch alone was 8-10 us of latency, x 150 per step)
@@ -1615,16 +1418,8 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
         // 8 images LOSE 1 % of theirs -- hence the size condition on top.
         const bool two = !g_bn_three_kernels || (g_bn_auto_two && plc.colgroups * plc.nsplit >= 128 && M >= 8192 && C >= 512);
         const RedPlan pl = two ? plc : red_plan(M, C, kc);
-        int* tickets = (!two && g_bn_ticket) ? bn_tickets_for(st, pl.colgroups) : nullptr;
-        if (tickets) {                                   // statistics + finalize of each column group by its last workgroup; the apply launch follows below
-            DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_fin_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st, (const T*)z, M, C, ldz,
-                                                   pl.rows_per_split, ws, tickets, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, fin,
-                                                   g_bn_ticket == 2);)
-            ticketed = true;
-        } else {
         DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
                                                (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
-        }
         if (two) {                                       // statistics, then apply with the finalize folded in
             const int rpb = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
             dim3 gridf(pl.colgroups, ceil_div(M, rpb));
@@ -1641,11 +1436,9 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
             return ODTK_OK;
         }
     }
-    if (!ticketed) {
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M,
                                            C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
                                            pl.nsplit, fin);)
-    }
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
     const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
@@ -1713,21 +1506,6 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
         else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD_FIN(float, float); }
         else ODTK_REQUIRE(false, "bn_bwd: bad dtype");
 #undef BN_BWD_FIN
-        ODTK_LAUNCH_CHECK();
-        return ODTK_OK;
-    }
-    if (int* tickets = g_bn_ticket ? bn_tickets_for(st, pl.colgroups) : nullptr) {       // sums + finalize by ticket, then the apply launch
-#define BN_BWD_TICKET(T, TY)                                                                                                      \
-    hipLaunchKernelGGL((bn_bwd_stats_fin_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz, ldy,   \
-                       rows_per_img, y_img_stride, save_mean, save_invstd, relu, vec_ok, pl.rows_per_split, ws, tickets, dgamma, dbeta, fin, \
-                       g_bn_ticket == 2);                                                                                             \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz, ldy,       \
-                       rows_per_img, y_img_stride, gamma, save_mean, save_invstd, relu, vec_ok, (T*)dz, fin, rows_per_block)
-        if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_BWD_TICKET(bf16_t, bf16_t); }
-        else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_BWD_TICKET(bf16_t, float); }
-        else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_BWD_TICKET(float, float); }
-        else ODTK_REQUIRE(false, "bn_bwd: bad dtype");
-#undef BN_BWD_TICKET
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }
@@ -2720,172 +2498,6 @@ __global__ void __launch_bounds__(256) gn_chunk_bwd_finalize_kernel(int HW, int 
     }
 }
 
-// ---- channel sums + the group finalize in ONE launch (opt-in, odtk_debug_set key 7 value -7; default off, NOT yet measured on the GPU) ---------------------------
-// The batch-norm ticket scheme above for the group norms whose column group is one 64-channel finalize block (bf16 rows, 64 % (C / groups) == 0: every FCOS
-// layer): one ticket per (sample, column group); the workgroup that writes the last of the nsplit partials runs gn_chunk_finalize64_kernel's /
-// gn_chunk_bwd_finalize64_kernel's arithmetic for that block (same split lanes, same summation order: bit-equal to the three launches), so a large-map group
-// norm is 2 + 2 launches (+ the parameter-gradient one) instead of 3 + 3.  The statistics loops are copies: the measured kernels stay byte-identical.
-__device__ __forceinline__ bool gn_ticket_is_last(int* __restrict__ tickets, int idx, int nsplit, int nofence) {
-    __shared__ int s_last;
-    if (nofence) __builtin_amdgcn_s_waitcnt(0);        // (bn_ticket_is_last: the fence-free variant)
-    else __threadfence();                              // this workgroup's partials are visible device-wide before its ticket is drawn
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s_last = atomicAdd(&tickets[idx], 1) == nsplit - 1;
-        if (s_last) __hip_atomic_store(&tickets[idx], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                  // every workgroup of this (sample, column group) has drawn: ready for the next launch
-    }
-    __syncthreads();
-    if (s_last && !nofence) __threadfence();
-    return s_last != 0;
-}
-__device__ __forceinline__ float gn_ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <typename T>
-__global__ void __launch_bounds__(256) gn_chunk_stats_fin_kernel(const T* __restrict__ x, int ldx, int HW, int C, int Cp, int groups, int rows_per_split,
-                                                                 float* __restrict__ ws, int* __restrict__ tickets, float* __restrict__ st, int nofence) {
-    constexpr int KC = Chunk<T>::N;
-    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c0 = (blockIdx.x * 8 + cl) * KC;
-    const int split = blockIdx.y, nsplit = gridDim.y, n = blockIdx.z;
-    const T* xs = x + (size_t)n * HW * ldx;
-    float acc[2 * KC];
-#pragma unroll
-    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
-    if (c0 < C) {
-        float sh[KC];
-        Chunk<T>::unpack(ld16(xs + c0), sh);
-        const int m0 = split * rows_per_split;
-        int m1 = m0 + rows_per_split; if (m1 > HW) m1 = HW;
-#pragma unroll 4
-        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
-            float f[KC];
-            Chunk<T>::unpack(ld16(xs + (size_t)m * ldx + c0), f);
-#pragma unroll
-            for (int e = 0; e < KC; ++e) {
-                const float d = f[e] - sh[e];
-                acc[e] += d;
-                acc[KC + e] += d * d;
-            }
-        }
-    }
-    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
-    if (rl == 0 && c0 < C) {
-        float* w = ws + ((size_t)(n * nsplit + split) * 2) * Cp + c0;
-#pragma unroll
-        for (int e = 0; e < KC; ++e) { ticket_store(w + e, acc[e], nofence); ticket_store(w + Cp + e, acc[KC + e], nofence); }
-    }
-    if (!gn_ticket_is_last(tickets, n * gridDim.x + blockIdx.x, nsplit, nofence)) return;
-    // (gn_chunk_finalize64_kernel for 64-channel block blockIdx.x of sample n; launched only where 8 * KC == 64)
-    __shared__ float s_a[4][64], s_b[4][64];
-    __shared__ double s_x[64], s_xx[64];
-    const int fc = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + fc, cg = C / groups;
-    float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int s = sl; s < nsplit; s += 4) {
-            const float* w = ws + ((size_t)(n * nsplit + s) * 2) * Cp + c;
-            a += gn_ld_dev(w); b += gn_ld_dev(w + Cp);
-        }
-    s_a[sl][fc] = a; s_b[sl][fc] = b;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        const double s1 = ((double)s_a[0][fc] + (double)s_a[1][fc]) + ((double)s_a[2][fc] + (double)s_a[3][fc]);
-        const double s2 = ((double)s_b[0][fc] + (double)s_b[1][fc]) + ((double)s_b[2][fc] + (double)s_b[3][fc]);
-        const double sh = (double)elem<T>::load(x[(size_t)n * HW * ldx + c]);
-        s_x[fc] = s1 + (double)HW * sh;
-        s_xx[fc] = s2 + 2.0 * sh * s1 + (double)HW * sh * sh;
-    }
-    __syncthreads();
-    const int gl = threadIdx.x;
-    if (gl < 64 / cg && blockIdx.x * 64 + gl * cg < C) {
-        double sx = 0.0, sxx = 0.0;
-        for (int j = 0; j < cg; ++j) { sx += s_x[gl * cg + j]; sxx += s_xx[gl * cg + j]; }
-        const double cnt = (double)HW * cg;
-        const double mean = sx / cnt;
-        double var = sxx / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const int g = (blockIdx.x * 64) / cg + gl;
-        st[((size_t)n * groups + g) * 2] = (float)mean;
-        st[((size_t)n * groups + g) * 2 + 1] = rsqrtf((float)var + 1e-6f);
-    }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) gn_chunk_bwd_stats_fin_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y, const T* __restrict__ dy, int ldy,
-                                                                     int HW, int C, int Cp, int groups, const float* __restrict__ save, int relu,
-                                                                     int rows_per_split, float* __restrict__ ws, int* __restrict__ tickets,
-                                                                     const float* __restrict__ gamma, float* __restrict__ part, float* __restrict__ st,
-                                                                     int nofence) {
-    constexpr int KC = Chunk<T>::N;
-    __shared__ float sm[RED_ROWS * 8 * 2 * KC];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c0 = (blockIdx.x * 8 + cl) * KC;
-    const int split = blockIdx.y, nsplit = gridDim.y, n = blockIdx.z, cg = C / groups;
-    float acc[2 * KC];
-#pragma unroll
-    for (int e = 0; e < 2 * KC; ++e) acc[e] = 0.f;
-    if (c0 < C) {
-        float mu[KC], rs[KC];
-#pragma unroll
-        for (int e = 0; e < KC; ++e) {
-            const int g = (c0 + e) / cg;
-            mu[e] = save[((size_t)n * groups + g) * 2]; rs[e] = save[((size_t)n * groups + g) * 2 + 1];
-        }
-        const size_t base = (size_t)n * HW;
-        const int m0 = split * rows_per_split;
-        int m1 = m0 + rows_per_split; if (m1 > HW) m1 = HW;
-#pragma unroll 2
-        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
-            float f[KC], d[KC], yy[KC];
-            Chunk<T>::unpack(ld16(x + (base + m) * ldx + c0), f);
-            Chunk<T>::unpack(ld16(dy + (base + m) * ldy + c0), d);
-            if (relu) Chunk<T>::unpack(ld16(y + (base + m) * ldy + c0), yy);
-#pragma unroll
-            for (int e = 0; e < KC; ++e) {
-                const float dd = (relu && !(yy[e] > 0.f)) ? 0.f : d[e];
-                acc[e] += dd;
-                acc[KC + e] += dd * ((f[e] - mu[e]) * rs[e]);
-            }
-        }
-    }
-    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
-    if (rl == 0 && c0 < C) {
-        float* w = ws + ((size_t)(n * nsplit + split) * 2) * Cp + c0;
-#pragma unroll
-        for (int e = 0; e < KC; ++e) { ticket_store(w + e, acc[e], nofence); ticket_store(w + Cp + e, acc[KC + e], nofence); }
-    }
-    if (!gn_ticket_is_last(tickets, n * gridDim.x + blockIdx.x, nsplit, nofence)) return;
-    // (gn_chunk_bwd_finalize64_kernel for 64-channel block blockIdx.x of sample n)
-    __shared__ float s_a[4][64], s_b[4][64], s_gb[64], s_gg[64];
-    const int fc = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + fc;
-    float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int s = sl; s < nsplit; s += 4) {
-            const float* w = ws + ((size_t)(n * nsplit + s) * 2) * Cp + c;
-            a += gn_ld_dev(w); b += gn_ld_dev(w + Cp);
-        }
-    s_a[sl][fc] = a; s_b[sl][fc] = b;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        const float sb = (s_a[0][fc] + s_a[1][fc]) + (s_a[2][fc] + s_a[3][fc]);
-        const float sg = (s_b[0][fc] + s_b[1][fc]) + (s_b[2][fc] + s_b[3][fc]);
-        part[((size_t)n * 2 + 0) * C + c] = sg;
-        part[((size_t)n * 2 + 1) * C + c] = sb;
-        s_gb[fc] = gamma[c] * sb;
-        s_gg[fc] = gamma[c] * sg;
-    }
-    __syncthreads();
-    const int gl = threadIdx.x;
-    if (gl < 64 / cg && blockIdx.x * 64 + gl * cg < C) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int j = 0; j < cg; ++j) { a1 += s_gb[gl * cg + j]; a2 += s_gg[gl * cg + j]; }
-        const float cnt = (float)HW * (float)cg;
-        const int g = (blockIdx.x * 64) / cg + gl;
-        st[((size_t)n * groups + g) * 2] = a1 / cnt;
-        st[((size_t)n * groups + g) * 2 + 1] = a2 / cnt;
-    }
-}
-
 template <typename T>
 __global__ void __launch_bounds__(256) gn_chunk_bwd_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y, const T* __restrict__ dy, int ldy,
                                                                  T* __restrict__ dx, int lddx, int HW, int C, int groups, const float* __restrict__ gamma,
@@ -3117,9 +2729,7 @@ static int gn_scratch(size_t bytes, float** out) {
 
 static int g_gn_small_rows = 1024;      // odtk_debug_set key 7: group norms of maps with at most this many pixels per sample run as one launch (0 = never)
 namespace odtk {
-static int g_gn_ticket = 0;             // odtk_debug_set key 7, value -7: the channel-sum launch of a large-map bf16 group norm finishes its 64-channel blocks by ticket
-                                        // and the finalize launch is dropped (gn_chunk_stats_fin_kernel; NOT yet measured on the GPU); -9: without fences; -8: back (default)
-void set_gn_small_rows(int rows) { if (rows == -7) g_gn_ticket = 1; else if (rows == -9) g_gn_ticket = 2; else if (rows == -8) g_gn_ticket = 0; else g_gn_small_rows = rows < 0 ? 0 : rows; }
+void set_gn_small_rows(int rows) { g_gn_small_rows = rows < 0 ? 0 : rows; }
 }  // namespace odtk
 struct GnPlan { int kc, colgroups, Cp, nsplit, rows_per_split, rows_per_block; bool chunked; };
 static GnPlan gn_plan(int N, int HW, int C, int dtype, std::initializer_list<int> pitches, std::initializer_list<const void*> ptrs) {
@@ -3172,15 +2782,6 @@ extern "C" int odtk_gn_fwd(const void* x, int ldx, void* y, int ldy, int N, int 
         if (int e = gn_scratch((wsn + stn) * sizeof(float), &scr)) return e;
         float* stat = save_mean_rstd ? save_mean_rstd : scr + wsn;
         const bool fin64 = 64 % (C / groups) == 0;             // whole groups inside a 64-channel block
-        if (int* tickets = (g_gn_ticket && fin64 && pl.kc == 8) ? bn_tickets_for(st, pl.colgroups * N) : nullptr) {
-            DT_SWITCH(dtype, T,
-                      hipLaunchKernelGGL(gn_chunk_stats_fin_kernel<T>, dim3(pl.colgroups, pl.nsplit, N), dim3(256), 0, st, (const T*)x, ldx, HW, C, pl.Cp,
-                                         groups, pl.rows_per_split, scr, tickets, stat, g_gn_ticket == 2);
-                      hipLaunchKernelGGL(gn_chunk_apply_kernel<T>, dim3(pl.colgroups, ceil_div(HW, pl.rows_per_block), N), dim3(256), 0, st, (const T*)x, ldx,
-                                         (T*)y, ldy, HW, C, groups, gamma, beta, relu, stat, pl.rows_per_block);)
-            ODTK_LAUNCH_CHECK();
-            return ODTK_OK;
-        }
         DT_SWITCH(dtype, T,
                   hipLaunchKernelGGL(gn_chunk_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit, N), dim3(256), 0, st, (const T*)x, ldx, HW, C, pl.Cp,
                                      pl.rows_per_split, scr);
@@ -3219,16 +2820,6 @@ extern "C" int odtk_gn_bwd(const void* x, int ldx, const void* y, const void* dy
         if (int e = gn_scratch((wsn + stn) * sizeof(float), &scr)) return e;
         float* stat = scr + wsn;
         const bool fin64 = 64 % (C / groups) == 0;
-        int* tickets = (g_gn_ticket && fin64 && pl.kc == 8) ? bn_tickets_for(st, pl.colgroups * N) : nullptr;
-        if (tickets) {
-            DT_SWITCH(dtype, T,
-                      hipLaunchKernelGGL(gn_chunk_bwd_stats_fin_kernel<T>, dim3(pl.colgroups, pl.nsplit, N), dim3(256), 0, st, (const T*)x, ldx, (const T*)y,
-                                         (const T*)dy, ldy, HW, C, pl.Cp, groups, save_mean_rstd, relu, pl.rows_per_split, scr, tickets, gamma, part, stat,
-                                         g_gn_ticket == 2);
-                      hipLaunchKernelGGL(gn_chunk_bwd_apply_kernel<T>, dim3(pl.colgroups, ceil_div(HW, pl.rows_per_block), N), dim3(256), 0, st, (const T*)x,
-                                         ldx, (const T*)y, (const T*)dy, ldy, (T*)dx, lddx, HW, C, groups, gamma, save_mean_rstd, stat, relu, accumulate & 1,
-                                         pl.rows_per_block);)
-        } else
         DT_SWITCH(dtype, T,
                   hipLaunchKernelGGL(gn_chunk_bwd_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit, N), dim3(256), 0, st, (const T*)x, ldx, (const T*)y,
                                      (const T*)dy, ldy, HW, C, pl.Cp, groups, save_mean_rstd, relu, pl.rows_per_split, scr);

@@ -13,6 +13,8 @@ Works on CPU tensors with the gloo backend too (tests/test_dist_cpu.py, world_si
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -52,12 +54,16 @@ class BucketAllReducer:
                 size = 0
         self.index = {name: i for i, (name, _, _) in enumerate(self.segments)}
         self.enabled = True            # False: walk the buckets without launching collectives (bench.py: step time without comm)
+        # optional callable -> context manager under which a bucket's narrowing cast and collective are issued (ssd300._comm_launch: a launch stream that
+        # waits for every stream carrying gradient kernels, so that the model keeps its side streams under data parallel); None = the current stream
+        self.launch_ctx = None
         self.begin_step()
 
     def begin_step(self):
         self.next_bucket = 0
         self.lowest_ready = len(self.segments)
         self.handles = []
+        self.launch_log = []           # (start, end) of the buckets in the order this step closed them (tests: the order does not depend on the streams)
         self._staged = []
 
     def segment_ready(self, name):
@@ -66,21 +72,29 @@ class BucketAllReducer:
         while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][2] >= self.lowest_ready:
             s, e, _ = self.buckets[self.next_bucket]
             if (self.world > 1 or self.force) and self.enabled:
-                buf = self.flat[s:e]
-                if self.stage is not None:
-                    buf = self.stage[s:e]
-                    self._narrow(self.flat[s:e], buf)          # on the current stream, which the collective's stream waits for
-                    self._staged.append((s, e))
-                self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                with (self.launch_ctx() if self.launch_ctx is not None else contextlib.nullcontext()):
+                    buf = self.flat[s:e]
+                    if self.stage is not None:
+                        buf = self.stage[s:e]
+                        self._narrow(self.flat[s:e], buf)      # on the launching stream, which the collective's stream waits for
+                        self._staged.append((s, e))
+                    self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.launch_log.append((s, e))
             self.next_bucket += 1
 
     def bucket_bytes(self):
         return [(e - s) * self.flat.element_size() for s, e, _ in self.buckets]
 
     def all_reduce_alone(self):
-        """Every bucket's all-reduce back to back with nothing to overlap with (bench.py: the collective's own time)."""
+        """Every bucket's all-reduce back to back with nothing to overlap with.  TIMING ONLY (bench.py: the collective's own time): it sums
+        whatever the gradient buffer holds and, with a narrowed communication dtype, leaves the result in the staging copy without widening it
+        back -- never call it inside a training step."""
+        assert not self.handles and not self._staged, 'all_reduce_alone() inside a step: it is a timing helper, not part of the data path'
         if self.world > 1 or self.force:
-            src = self.flat if self.stage is None else self.stage
+            src = self.flat
+            if self.stage is not None:
+                src = self.stage
+                self._narrow(self.flat, self.stage)          # the same bytes and arithmetic as the real path (never uninitialised memory)
             hs = [dist.all_reduce(src[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e, _ in self.buckets]
             for h in hs:
                 h.wait()

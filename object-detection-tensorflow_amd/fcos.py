@@ -104,7 +104,8 @@ class FCOS(F32Warmup):
         self.dev = torch.device(config.get('device', 'cuda:0'))
         # engine: bf16 by default on the GPU since round 3 (warmup.py: the first f32_warmup_steps optimizer steps of a run from random initialisation go through
         # an f32 twin); an explicit 'compute_dtype' is taken literally; the CPU stand-in of the library (host-logic tests) stays on f32
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16' if torch.device(config.get('device', 'cuda:0')).type == 'cuda' else 'f32')]
+        # (mode 'test' keeps f32 unless asked otherwise, as ssd300.py does: the bf16 gate checks training gradients, not thresholded detections)
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16' if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         if self.mode == 'train':
@@ -187,6 +188,7 @@ class FCOS(F32Warmup):
         self._refresh_operand_copies()
 
     def export_params(self):
+        self._sync_from_twin()
         return OrderedDict((k, self.get_param(k)) for k in self.pinfo)
 
     def _refresh_operand_copies(self):
@@ -496,6 +498,7 @@ class FCOS(F32Warmup):
     def export_tf_variables(self):
         """what the reference's `tf.train.Saver()` (FCOS.py:390-394) writes: every variable under its name (reference_variable_map),
         global_step, and the momentum slots `<variable>/Momentum` created under the 'head' scope of the graph (:111, :188)"""
+        self._sync_from_twin()
         out = OrderedDict()
         for tfname, ours in reference_variable_map().items():
             out[tfname] = self._logical(ours, self.P)

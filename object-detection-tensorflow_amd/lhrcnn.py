@@ -436,6 +436,8 @@ class LHRCNN(RefineDet320):
 
     def load_tf_checkpoint(self, path):
         """`saver.restore(sess, path)` from the files of a reference-trained model (or ours): weights, moving statistics, Momentum slots, global_step"""
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()                                   # weights are loaded: the run does not start from random initialisation
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
         names = reader.get_variable_to_shape_map()
@@ -459,6 +461,8 @@ class LHRCNN(RefineDet320):
 
     def load_pretraining_weight(self, path):
         """`self.pretraining_weight_saver.restore` (LH_RCNN.py:448-449, :511-513): the trainables of scope 'feature_extractor' from a tf.train.Saver checkpoint"""
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()                                   # weights are loaded: the run does not start from random initialisation
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
         for ours, tfname in self.reference_variable_map().items():

@@ -613,6 +613,9 @@ def lhrcnn_rpn_loss(anc, conf, bbox, gt, ws, num_classes, grad_scale, img_h, img
 def lhrcnn_workspace(N, A, P, device):
     """the buffers of one RPN loss evaluation: candidate lists (row pitch cap = A + P), NMS picks, the 256-row R-CNN slots of every image"""
     cap = A + P
+    if cap > 32768:
+        raise ValueError(f'LHRCNN: {A} anchors inside the picture + {P} ground-truth slots = {cap} NMS candidates per image; odtk_nms_batched takes at most 32768 '
+                         '(smaller pictures, a larger stride or fewer anchor shapes)')
     i32, f32, u8 = torch.int32, torch.float32, torch.uint8
     z = lambda *s, dtype=f32: torch.zeros(*s, dtype=dtype, device=device)      # noqa: E731
     return dict(cap=cap, counts=z(N, 8, dtype=i32), status=z(N, A, dtype=u8),

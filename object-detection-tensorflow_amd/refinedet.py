@@ -118,7 +118,7 @@ class RefineDet320(F32Warmup):
                 self.val_generator = data_provider['val_generator']
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE if self.dev.type == 'cuda' else 'f32')]
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0
@@ -225,6 +225,7 @@ class RefineDet320(F32Warmup):
         self._refresh_operand_copies()
 
     def export_params(self):
+        self._sync_from_twin()
         out = OrderedDict((k, self.get_param(k)) for k in self.pinfo)
         for k in self.sinfo:
             out[k] = self.stat(k).detach().cpu().clone()
@@ -241,6 +242,8 @@ class RefineDet320(F32Warmup):
         path = self.pretraining_weight
         if not path or not (os.path.exists(str(path)) or os.path.exists(str(path) + '.index')):
             return
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()                                   # weights are loaded: the run does not start from random initialisation
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
         for l in self.VGG_SEQ:
@@ -751,6 +754,7 @@ class RefineDet320(F32Warmup):
 
     def export_tf_variables(self):
         """what the reference's `tf.train.Saver()` would write: every global variable -- weights, moving statistics, global_step and the MomentumOptimizer slots"""
+        self._sync_from_twin()
         out = OrderedDict()
         for ours, tfname in self.reference_variable_map().items():
             if ours in self.pinfo:

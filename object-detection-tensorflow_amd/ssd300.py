@@ -680,8 +680,11 @@ class SSD300:
         it is left at zero and only sees weight decay."""
         d = self.desc[name]
         dbias = None if self.convs[name].bn else self._grad(name + '.b')
-        side = self.wgrad_stream if self.dist is None else None      # DP: the bucket hooks order on the main stream
-        if side is None and self._twg is not None and self.dist is None and self.sync_bn is None and self.convs[name].bn:
+        # data parallel: the SAME streams as the single-device step (round 4) -- a bucket's all-reduce is launched from a stream that waits for every
+        # stream carrying gradient kernels (_comm_launch); only the per-bucket graph replay (use_graph with dist) still runs one stream
+        multi = self._dp_multi_stream()
+        side = self.wgrad_stream if multi else None
+        if side is None and self._twg is not None and multi and self.sync_bn is None and self.convs[name].bn:
             side = self._twg                                          # extras and heads (the batch-normalised layers): off the latency-bound chain
         if side is None:
             ops.conv2d_wgrad(d, x.t, dy_t, lddy, self._grad(name + '.w'), dbias)
@@ -706,10 +709,11 @@ class SSD300:
         if getattr(self, '_wt_pending', False):           # (the front's join normally covers this; a backward pass driven by hand does not)
             self._py(lambda: torch.cuda.current_stream().wait_stream(self._side))
             self._wt_pending = False
-        # data parallel: no head stream in backward -- with it no layer name could be handed back before the join, the readiness marks of
-        # pred* / conv11_2 .. conv6 would arrive in one burst and the buckets of the heads and extras (conv6 / conv7: ~6 M parameters) could
-        # not start their all-reduce under that part of the backward pass
-        tail = self._tail if (self.sync_bn is None and self.wgrad_stream is None and self.dist is None) else None
+        # data parallel (round 4): the head stream stays on.  Layer names are handed back in the order their launches were ENQUEUED (pred6 .. pred1 on the head
+        # stream, then conv11_2 .. conv6 on the main stream -- still suffix-first in the flat gradient buffer); a bucket that closes is all-reduced from a launch
+        # stream that waits for the main, head and filter-gradient streams (_comm_launch), so readiness is an event on the stream that ran the kernels, not a
+        # position in the main chain.  Per-bucket graph replay (use_graph with dist) keeps the single-stream backward of round 3.
+        tail = self._tail if (self.sync_bn is None and self.wgrad_stream is None and self._dp_multi_stream()) else None
         evs = {}
         if tail is None:
             # heads (pred6 .. pred1): dpred -> BN bwd -> wgrad / dgrad into the feature map
@@ -721,11 +725,12 @@ class SSD300:
             # gradient holds the head's contribution
             main = torch.cuda.current_stream()
             self._py(lambda: tail.wait_stream(main))      # fork: d(pred) is final
-            with self._on_tail():
-                for i in reversed(range(self.NH)):
+            for i in reversed(range(self.NH)):
+                with self._on_tail():
                     self._head_bwd(i)
                     ev = evs[self.FEAT_SRC[i]] = self._event(('head', i))
                     self._py(lambda ev=ev: ev.record(tail))
+                yield f'pred{i + 1}'                      # (outside the stream context: whoever resumes us runs on the main stream)
         # extra layers conv11_2 .. conv6
         for (name, ci, co, k, s, d) in reversed(self.EXTRA_SEQ):
             src = a[self.extra_src[name]]
@@ -742,14 +747,9 @@ class SSD300:
                 self._py(lambda ev=evs[self.extra_src[name]]: main.wait_event(ev))
             relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], relu_src, src.g, acc)
-            if tail is None:
-                yield name
+            yield name
         if tail is not None:
             self._py(lambda: main.wait_stream(tail))      # join: pred1 -> feat1.g is final before the trunk reads it
-            for i in reversed(range(self.NH)):
-                yield f'pred{i + 1}'
-            for e in reversed(self.EXTRA_SEQ):
-                yield e[0]
         # VGG trunk
         for step in reversed(self.vgg_plan):
             if step[0] == 'pool':
@@ -773,10 +773,10 @@ class SSD300:
                 if name != 'conv1_1':
                     ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
                 yield name
-        if self._twg is not None and self.dist is None and self.sync_bn is None:
+        if self._twg is not None and self._dp_multi_stream() and self.sync_bn is None:
             cur = torch.cuda.current_stream()
             self._py(lambda: cur.wait_stream(self._twg))                   # the tail's filter gradients join before the optimizer
-        if self.wgrad_stream is not None and self.dist is None:
+        if self.wgrad_stream is not None and self._dp_multi_stream():
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)     # join before the optimizer
 
     def _head_bwd(self, i):
@@ -795,6 +795,30 @@ class SSD300:
     def _mark_ready(self, layer_name):
         if self.dist is not None:
             self.dist.layer_ready(layer_name)
+
+    def _dp_multi_stream(self):
+        """True when the backward pass may use the head / filter-gradient streams: always on one device; under data parallel with eager launches
+        (the default) too -- only the per-bucket graph replay keeps the single-stream backward (a captured segment cannot end with a forked stream)"""
+        return self.dist is None or not self.use_graph
+
+    @contextlib.contextmanager
+    def _comm_launch(self):
+        """Context under which dist.py launches a bucket's collective.  torch.distributed orders a collective behind the CURRENT stream at the call; the
+        gradient kernels of the bucket's layers may sit on the main, head, tail-filter-gradient or filter-gradient stream.  The call is therefore made from
+        the tail-filter-gradient stream after it has been told to wait for the others at this point: its own work (the extras' / heads' filter gradients)
+        is what the bucket is waiting for anyway, nothing on it is latency-critical (it joins in front of the optimizer), and the main chain itself waits
+        for nothing.  No extra stream: the HIP runtime deals streams onto four hardware queues and a fifth would alias the main stream's.
+        (Round 3 dropped the side streams under data parallel instead: +5.3 % / +1.1 % on the step before a byte crossed xGMI.)"""
+        if (self._tail is None and self._twg is None and self.wgrad_stream is None) or not self._dp_multi_stream():
+            yield                                         # one stream carries everything: the current stream is the right one
+            return
+        main = torch.cuda.current_stream()
+        c = self._twg if self._twg is not None else (self.wgrad_stream if self.wgrad_stream is not None else main)
+        for st in (main, self._tail, self._twg, self.wgrad_stream):
+            if st is not None and st != c:
+                c.wait_stream(st)
+        with torch.cuda.stream(c):
+            yield
 
     # ------------------------------------------------------------------ public: training
     def set_batch(self, images, ground_truth):
@@ -965,6 +989,11 @@ class SSD300:
                         _lib.check(rc)
             return self._finish_step(lr)
         if use_graph:
+            if getattr(self, '_wt_pending', False):
+                # the last EAGER step (use_graph='auto' calibrates with eager ones) queued the refresh of the dgrad filter copies on the side stream;
+                # nothing inside a captured graph orders its nodes behind work outside it: join here, once
+                torch.cuda.current_stream().wait_stream(self._side)
+                self._wt_pending = False
             self._g_front.replay()
         else:
             self._step_front()
@@ -1151,6 +1180,7 @@ class SSD300:
         grad_dtype 'bf16': the buckets travel as bf16 copies (half the xGMI bytes); force_collectives: issue them in a world of one rank too."""
         from .dist import GradAllReducer
         self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
+        self.dist.red.launch_ctx = self._comm_launch
         self._graphs_invalidate()
         self.loss_divisor_batch = self.batch_size * self.dist.world
         if sync_bn:

@@ -39,6 +39,11 @@ class F32Warmup:
             torch.cuda.empty_cache()
         self.f32_warmup_steps = 0
 
+    def _sync_from_twin(self):
+        """mid-warm-up the live weights are the twin's: whoever reads this instance's buffers (export_params, export_tf_variables, save_weight) syncs first"""
+        if getattr(self, '_twin', None) is not None:
+            self._copy_state(self._twin, self)
+
     @staticmethod
     def _copy_state(src, dst):
         # the flat buffers of the two engines differ in the input-channel padding of the filters (16-byte chunks: 8 bf16 | 4 f32): copy variable by variable
@@ -69,8 +74,7 @@ class F32Warmup:
         return self._twin
 
     def save_weight(self, mode, path):
-        if self._twin is not None:                               # mid-warm-up: the live weights are the twin's
-            self._copy_state(self._twin, self)
+        self._sync_from_twin()                                   # mid-warm-up: the live weights are the twin's
         return self._save_weight_engine(mode, path)
 
     def set_batch(self, images, ground_truth):

@@ -104,7 +104,7 @@ class YOLOv2(RefineDet320):
                 self.val_generator = data_provider['val_generator']
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE if self.dev.type == 'cuda' else 'f32')]
+        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0
@@ -171,6 +171,8 @@ class YOLOv2(RefineDet320):
 
     def load_pretraining_weight(self, path):
         """`self.pretraining_weight_saver.restore` (YOLOv2.py:206-208, :355-357): the trainables of scope 'backone' from a tf.train.Saver checkpoint"""
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()                                   # weights are loaded: the run does not start from random initialisation
         from .tf_checkpoint import NewCheckpointReader
         reader = NewCheckpointReader(str(path))
         names = reference_variable_map()

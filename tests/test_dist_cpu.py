@@ -336,3 +336,110 @@ def test_bf16_gradient_buckets(world):
     for p in procs:
         p.join(30)
     assert all(ok for _, ok, _ in res) and all(dt == 'bf16' for _, _, dt in res), res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# SSD300 itself: the data-parallel step keeps the streams of the single-device step (round 4)
+def _ssd300_dp_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import contextlib
+    import sys
+    from unittest import mock
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import mock_ops
+    import odtk
+    from oracle import ssd300_ref as R
+    torch.set_num_threads(4)
+    log = []
+
+    class FakeStream:                                     # the CPU executes in program order: a stream is a label, a wait is a log line
+        def __init__(self, name):
+            self.name = name
+
+        def wait_stream(self, other):
+            log.append(('wait', self.name, other.name))
+
+        def wait_event(self, ev):
+            log.append(('wait', self.name, ev.on))
+
+    class FakeEvent:
+        on = None
+
+        def record(self, st):
+            self.on = st.name
+
+    main = FakeStream('main')
+    cur = [main]
+
+    @contextlib.contextmanager
+    def on_stream(s):
+        prev, cur[0] = cur[0], s
+        try:
+            yield
+        finally:
+            cur[0] = prev
+    cfg = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+           'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '', 'verbose': False,
+           'compute_dtype': 'f32', 'seed': 0, 'use_graph': False, 'device': 'cpu'}
+    imgs, gt = R.synthetic_batch(1, 40 + rank)
+    real_all_reduce = dist.all_reduce
+
+    def spy(buf, **kw):
+        log.append(('all_reduce', cur[0].name, int(buf.numel())))
+        return real_all_reduce(buf, **kw)
+    out = {}
+    for mode in ('streams', 'single'):
+        del log[:]
+        with mock_ops.installed(), mock.patch.object(torch.cuda, 'current_stream', lambda *a: cur[0]), mock.patch.object(torch.cuda, 'stream', on_stream), \
+                mock.patch.object(torch.cuda, 'Event', FakeEvent), mock.patch.object(dist, 'all_reduce', spy):
+            m = odtk.SSD300(cfg, {'data_shape': [300, 300, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+            if mode == 'streams':                          # what the GPU build has: head stream + tail filter-gradient stream
+                m._tail, m._twg = FakeStream('tail'), FakeStream('twg')
+                m.ws_tail = torch.zeros_like(m.ws)
+            red = m.attach_data_parallel(bucket_mb=8)
+            marks = []
+            real_ready = red.layer_ready
+            red.layer_ready = lambda name: (marks.append(name), real_ready(name))[1]
+            m.set_batch(imgs, gt)
+            loss = float(m.train_step(0.01))
+        out[mode] = {'G': m.G.clone(), 'P': m.P.clone(), 'loss': loss, 'order': list(red.red.launch_log), 'marks': marks, 'log': list(log),
+                     'index': dict(red.red.index), 'nbuckets': len(red.red.buckets)}
+    torch.save(out, os.path.join(out_dir, f'ssd300_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_ssd300_data_parallel_step_keeps_its_streams_world2(tmp_path):
+    """SSD300 on two gloo ranks, every libodtk launch mocked, with the head stream and the tail filter-gradient stream present (labels on the CPU) and without:
+    the readiness marks arrive suffix-first in both, the buckets close in the SAME order, every collective is launched from the filter-gradient stream after
+    that stream was told to wait for the main and head streams (the main chain never waits for a collective before the optimizer), and parameters / gradients
+    after the step are identical in both modes and on both ranks"""
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_ssd300_dp_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=1200)
+        assert p.exitcode == 0
+    a, b = torch.load(os.path.join(tmp_path, 'ssd300_0.pt')), torch.load(os.path.join(tmp_path, 'ssd300_1.pt'))
+    for r in (a, b):
+        s, o = r['streams'], r['single']
+        assert s['nbuckets'] >= 3 and len(s['order']) == s['nbuckets']
+        assert s['order'] == o['order']                                   # bucket launch order: unchanged by the streams
+        for mode in (s, o):
+            idx = [mode['index'][n] for n in mode['marks']]
+            assert idx == sorted(idx, reverse=True) and len(set(idx)) == len(idx) == len(mode['index'])      # every layer once, suffix-first
+            assert mode['order'] == sorted(mode['order'], reverse=True)
+        assert s['marks'] == o['marks']
+        assert torch.equal(s['G'], o['G']) and torch.equal(s['P'], o['P']) and s['loss'] == o['loss']
+        # where the collectives were launched from, and what that stream waited for right before
+        ar = [i for i, e in enumerate(s['log']) if e[0] == 'all_reduce']
+        assert len(ar) == s['nbuckets'] and all(s['log'][i][1] == 'twg' for i in ar)
+        for i in ar:
+            assert ('wait', 'twg', 'main') in s['log'][max(0, i - 3):i] and ('wait', 'twg', 'tail') in s['log'][max(0, i - 3):i]
+        assert not any(e[0] == 'wait' and e[1] == 'main' and e[2] == 'twg' for e in s['log'][:ar[0]])
+        assert all(e[1] == 'main' for e in o['log'] if e[0] == 'all_reduce')
+    assert torch.equal(a['streams']['P'], b['streams']['P']) and torch.equal(a['streams']['G'], b['streams']['G'])

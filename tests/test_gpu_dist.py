@@ -300,17 +300,18 @@ def test_rccl_world1_launch_check(dev):
     assert out['metric'] == 'launch-check' and out['comm']['backend'] == 'nccl' and out['comm']['world_size'] == 1 and out['comm']['allreduce_ok']
 
 
-@pytest.mark.parametrize('grad_dtype', ['f32', 'bf16'])
-def test_rccl_world1_data_parallel_training_step(dev, grad_dtype):
-    """`bench.py --dp-world1`: the SSD300 data-parallel step with RCCL in a world of ONE rank -- gradient buckets, one backward HIP graph per bucket
-    captured thread-locally beside RCCL's watchdog, an ncclAllReduce per bucket launched between the replays, (bf16: narrowed / widened buckets) -- and
-    the loss stays that of the single-device step (the sum over one rank is the identity)."""
+@pytest.mark.parametrize('grad_dtype,launch', [('f32', 'eager'), ('bf16', 'eager'), ('f32', 'graph')])
+def test_rccl_world1_data_parallel_training_step(dev, grad_dtype, launch):
+    """`bench.py --dp-world1`: the SSD300 data-parallel step with RCCL in a world of ONE rank -- gradient buckets, an ncclAllReduce per bucket launched from
+    the filter-gradient stream while the backward pass keeps the head / filter-gradient streams of the single-device step (eager launches, the default since
+    round 4); `--graph`: one backward HIP graph per bucket captured thread-locally beside RCCL's watchdog, the all-reduces between the replays; (bf16:
+    narrowed / widened buckets) -- and the loss stays that of the single-device step (the sum over one rank is the identity)."""
     base = ['--gpus', '1', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-conv-events']
-    dp = _bench_json(base + ['--dp-world1', '--grad-dtype', grad_dtype])
+    dp = _bench_json(base + ['--dp-world1', '--grad-dtype', grad_dtype] + (['--graph'] if launch == 'graph' else []))
     one = _bench_json(base)
     assert dp['comm']['backend'] == 'nccl' and dp['comm']['world_size'] == 1 and dp['comm']['buckets'] >= 3
     assert dp['comm']['gradient_dtype'] == grad_dtype and dp['comm']['allreduce_ms_per_step'] > 0
-    assert 'bucket graphs' in dp['config']['launch'], dp['config']['launch']
+    assert ('bucket graphs' in dp['config']['launch']) if launch == 'graph' else (dp['config']['launch'] == 'eager'), dp['config']['launch']
     # same seeds, same batch, six optimizer steps of the bf16 engine at lr 0.01 from random initialisation: the float atomics of the filter gradients
     # make two runs of the SAME configuration differ by ~0.5 % by then (measured 0.65 % between this pair), so this is a sanity bound, not a parity bound
     tol = 3e-2

@@ -256,8 +256,6 @@ def test_training_steps_vs_oracle():
     assert m.global_step == 2
 
 
-@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason='second pinned configuration, written after the round-3 GPU minutes were spent: green on the '
-                    'CPU mock (tests/test_models_host_logic_cpu.py), not yet on hardware; tools/gpu_round4_first.sh runs it')
 def test_first_step_in_the_second_pinned_configuration():
     """256 x 480, batch 3, 5 classes, up to five objects, weight decay 5e-4, lr 0.002 (tests/golden/lhrcnn_train_b.npz, produced by the reference's own class): both
     losses of the first step against the reference's numbers (2e-4; R-CNN 5e-3, as above), the sub-sampled variables after it to 1e-3 of their largest entry"""
@@ -314,10 +312,7 @@ def test_detections_vs_reference_class():
     assert es < 1e-3 and eb < 1e-3, (es, eb)
 
 
-@pytest.mark.parametrize('dtype', ['f32', pytest.param('bf16', marks=pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
-    "compute_dtype='bf16' of LHRCNN was added after the round's GPU minutes were spent: every launch it uses is verified on its own (bf16 storage of the "
-    "depthwise / crop kernels above, the bf16 convolutions and casts of the other classes) but the class has not run on the GPU as a whole; "
-    "ODTK_RUN_UNVERIFIED=1 runs this case")))])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_every_launch_in_situ_at_the_driver_shape(dtype):
     """testlhrcnn.py's shape -- 700 x 1100, batch 32 -- on the GPU: every launch of a whole training step is re-executed in plain f32 PyTorch from the engine's
     own stored inputs of that launch and compared (tests/insitu.py, as for the other classes in tests/test_gpu_insitu_configs.py): 27 convolutions / dense
@@ -349,7 +344,14 @@ def test_every_launch_in_situ_at_the_driver_shape(dtype):
     def tol(row):
         # the oracle recomputes the NMS scores from the engine's logits with another exp / log: two overlapping candidates whose scores differ in the last bit
         # may swap, which moves two of a picture's 256 gradient rows (relative error sqrt(2 / (32 * 256)) = 1.6e-2 per swap); measured: no swap, 6.6e-8
-        return 5e-2 if row['op'] == 'lhrcnn_rpn_loss' else base_tol(row)
+        if row['op'] == 'lhrcnn_rpn_loss':
+            return 5e-2
+        # bf16 engine: x / 127.5 - 1 of an integer pixel value is rounded to bf16 by the kernel and by the restatement from f32 values that may differ in the last
+        # f32 bit (division + subtraction vs torch's own order): where such a value sits on a bf16 rounding tie the two stores differ by ONE bf16 ulp, 2^-7 at
+        # |x| ~ 1 relative to the largest element (measured on MI355X, round 4: exactly 7.8125e-3 on 24.6 M pixels); a wrong pixel would be O(1)
+        if row['op'] == 'preprocess_norm' and dtype == 'bf16':
+            return 8e-3
+        return base_tol(row)
     rows = sh.check(tol, verbose=True, label=f'lhrcnn {dtype} {H}x{W} batch {B}')
     seen = {x['op'] for x in rows}
     assert {'conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad', 'depthwise_conv', 'depthwise_wgrad', 'crop_and_resize_fwd', 'crop_and_resize_bwd', 'lhrcnn_rpn_loss',

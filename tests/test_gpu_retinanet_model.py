@@ -210,41 +210,6 @@ def test_group_norm_kernels(dev, dt, single_launch_rows):
         ops.debug_set(7, 1024)
 
 
-@pytest.mark.skipif(__import__('os').environ.get('ODTK_RUN_UNVERIFIED') != '1', reason='written after the round-3 GPU minutes ran out: verified under the CPU '
-                    'emulation (tests/test_hip_cpu.py), not yet on hardware; tools/gpu_round4_first.sh runs it')
-@pytest.mark.parametrize('on', [-7, -9], ids=['fenced', 'nofence'])
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
-def test_group_norm_kernels_ticket_finalize(dev, dt, on):
-    """odtk_debug_set(7, -7 | -9 = without fences): the channel-sum launch finishes its 64-channel blocks by ticket (bf16 shapes with 64 % (C / groups) == 0; the others keep the three
-    launches), against torch autograd, and bit-equal to the three launches on a large map, twice in a row (the tickets reset themselves)"""
-    import odtk  # noqa: F401
-    from odtk import ops
-    ops.debug_set(7, 0)
-    try:
-        ops.debug_set(7, on)
-        _group_norm_cases(ops, dev, dt)
-        g = torch.Generator().manual_seed(2)
-        N, HW, C, groups = 16, 64 * 64, 256, 32
-        tdt = torch.float32 if dt == 'f32' else torch.bfloat16
-        x = (torch.randn(N * HW, C, generator=g) * 2 + 0.7).to(tdt).to(dev)
-        dy = torch.randn(N * HW, C, generator=g).to(tdt).to(dev)
-        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.2 * torch.randn(C, generator=g)).to(dev)
-        res = []
-        for mode in (-8, on, on):
-            ops.debug_set(7, mode)
-            y, dx = torch.zeros_like(x), torch.zeros_like(x)
-            save, dg, db = torch.zeros(N, groups, 2, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-            ops.gn_fwd(x, C, y, C, N, HW, C, groups, gamma, beta, 1, save)
-            ops.gn_bwd(x, C, y, dy, C, dx, C, N, HW, C, groups, gamma, save, 1, False, dg, db, ops.gn_workspace(N, C, dev))
-            torch.cuda.synchronize()
-            res.append((y, dx, save, dg, db))
-        for other in res[1:]:
-            for a, b in zip(res[0], other):
-                assert torch.equal(a, b)
-    finally:
-        ops.debug_set(7, 1024); ops.debug_set(7, -8)
-
-
 def _group_norm_cases(ops, dev, dt):
     tdt = torch.float32 if dt == 'f32' else torch.bfloat16
     g = torch.Generator().manual_seed(4)

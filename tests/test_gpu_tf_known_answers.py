@@ -89,9 +89,6 @@ def test_augmentor_hue_contrast_rotate_tables(dev):
         assert torch.allclose(out.cpu(), torch.from_numpy(want).unsqueeze(-1).repeat(1, 1, 3), atol=1e-3)
 
 
-@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
-    "written after the round's GPU minutes were spent, never run on hardware (ODTK_RUN_UNVERIFIED=1 runs it): the same tables are checked on the oracle and the shim "
-    "(tests/test_tf_known_answers_cpu.py) and the kernel is checked against the oracle in tests/test_gpu_lhrcnn.py, bit-equal over 8 192 rows in situ"))
 def test_crop_and_resize_tables(dev):
     """TensorFlow's crop_and_resize_op_test.cc tables through odtk_crop_and_resize_fwd (f32 and bf16 storage: every table value is exact in bf16)"""
     ops = _ops()
@@ -105,9 +102,6 @@ def test_crop_and_resize_tables(dev):
             assert out[0, : crop * crop].float().cpu().tolist() == [float(v) for v in want], (box, dtype)
 
 
-@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
-    "written after the round's GPU minutes were spent, never run on hardware (ODTK_RUN_UNVERIFIED=1 runs it); it passes on the kernel SOURCE under the CPU "
-    "emulation (tests/test_hip_cpu.py), which also caught its first version asking for 3 channels where the launch wants whole 16-byte chunks"))
 def test_pooling_same_padding_tables(dev):
     """pooling_ops_test.py's SAME tables on odtk_maxpool_fwd (the window that only covers the last column) and odtk_avgpool2x2_fwd"""
     ops = _ops()
@@ -126,9 +120,6 @@ def test_pooling_same_padding_tables(dev):
         assert torch.equal(ya[:, :3].float().cpu(), torch.from_numpy(K.AVGPOOL_SAME_OUT).reshape(2, 3))       # every table value is exact in bf16
 
 
-@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
-    "written after the round's GPU minutes were spent, never run on hardware (ODTK_RUN_UNVERIFIED=1 runs it); the same table pins the oracle, the shim and the "
-    "mocked launch on the CPU, and every convolution kernel is checked against torch in tests/test_gpu_kernels.py"))
 def test_conv2d_orientation_and_filter_layout(dev):
     """conv_ops_test.py's testConv2D2x2Filter table on odtk_conv2d_fwd (f32 engine), the 2 x 2 filter embedded in the centre / bottom-right taps of a 3 x 3
     one (SAME padding of a 3 x 3 filter pads one cell on every side: taps (1..2, 1..2) read x[h + 0..1, w + 0..1])"""
@@ -144,9 +135,6 @@ def test_conv2d_orientation_and_filter_layout(dev):
     assert torch.equal(y.cpu().view(2, 3, 4)[:1, :2, :3], want[0])          # integers below 2^24: exact in f32 whatever the summation order
 
 
-@pytest.mark.skipif(os.environ.get('ODTK_RUN_UNVERIFIED') != '1', reason=(
-    "written after the round's GPU minutes were spent, never run on hardware (ODTK_RUN_UNVERIFIED=1 runs it); the optimizer launch is covered by every whole-model "
-    "test against the oracles and by the in-situ shadows"))
 def test_momentum_optimizer_update_rule(dev):
     """momentum_test.py's doBasic on odtk_sgd_momentum (weight decay 0, gradient scale 1; the buffers padded to one 64-element segment)"""
     ops = _ops()

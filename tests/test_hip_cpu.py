@@ -205,11 +205,11 @@ def _run(module, name, **kw):
 
 _BN_SHAPES = {'a': ((2 * 19 * 19, 1024, True), 'f32', 'f32'), 'b': ((3 * 5 * 5, 150, False), 'bf16', 'bf16'), 'c': ((6 * 38 * 38, 100, False), 'bf16', 'f32'),
               'd': ((14 * 19 * 19, 256, True), 'bf16', 'bf16')}
-_BN_MODES = {'one-launch': 1, 'one-launch-64ch': 10, 'two-launches': 2, 'three-launches': 3, 'auto': 0, 'ticket': 4, 'ticket-nofence': 5}
+_BN_MODES = {'one-launch': 1, 'one-launch-64ch': 10, 'two-launches': 2, 'three-launches': 3, 'auto': 0}
 
 
 @pytest.mark.parametrize('case', ['a-one-launch', 'b-one-launch', 'a-one-launch-64ch', 'a-two-launches', 'c-two-launches', 'a-three-launches', 'c-three-launches', 'd-three-launches',
-                                  'a-auto', 'd-auto', 'a-ticket', 'b-ticket', 'c-ticket', 'd-ticket', 'a-ticket-nofence', 'c-ticket-nofence', 'd-ticket-nofence'])
+                                  'a-auto', 'd-auto'])
 def test_batchnorm_from_source(case):
     shape, mode = case.split('-', 1)
     sh, dt, ydt = _BN_SHAPES[shape]
@@ -308,94 +308,19 @@ def test_whole_class_bf16_engine_with_the_kernels_from_source(lh_kernels_in_the_
     assert len(scores) > 0.5 * len(gd['scores']) and np.isfinite(bbox).all()
 
 
-def test_ticket_finalize_drops_the_finalize_launches():
-    """odtk_debug_set(4, -7): a training-mode batch norm of a large map is 2 launches forward (statistics with the ticket finalize, apply) and 2 backward instead
-    of 3 + 3, with the same outputs as the three-launch path to summation-order rounding"""
-    import odtk  # noqa: F401
-    from odtk import ops
-    lib = HC.build()
-    lib.hipcpu_launch_count.restype = __import__('ctypes').c_longlong
-    g = torch.Generator().manual_seed(1)
-    M, C = 14 * 19 * 19, 256
-    z = torch.randn(M, C, generator=g) * 2 + 0.5
-    dy = torch.randn(M, C, generator=g)
-    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
-    res = {}
-    with HC.installed():
-        for mode in ('three', 'ticket', 'nofence'):
-            ops.debug_set(4, 0); ops.debug_set(4, -5); ops.debug_set(4, -1); ops.debug_set(4, {'three': -8, 'ticket': -7, 'nofence': -9}[mode])
-            try:
-                mm, mv, sm, si = torch.zeros(C), torch.ones(C), torch.zeros(C), torch.zeros(C)
-                ws = torch.zeros(ops.bn_workspace_bytes(M, C), dtype=torch.uint8)
-                y, dz, dg, db = torch.zeros(M, C), torch.zeros(M, C), torch.zeros(C), torch.zeros(C)
-                n0 = lib.hipcpu_launch_count()
-                ops.bn_fwd(z, M, C, C, gamma, beta, mm, mv, sm, si, True, 1, y, C, M, 0, ws)
-                n1 = lib.hipcpu_launch_count()
-                ops.bn_bwd(z, y, dy, M, C, C, C, M, 0, gamma, sm, si, 1, dz, dg, db, ws)
-                n2 = lib.hipcpu_launch_count()
-                res[mode] = (n1 - n0, n2 - n1, y, dz, dg, db, mm, mv, sm, si)
-            finally:
-                ops.debug_set(4, 1024); ops.debug_set(4, -6); ops.debug_set(4, -8)
-    assert res['three'][:2] == (3, 3) and res['ticket'][:2] == (2, 2) and res['nofence'][:2] == (2, 2), (res['three'][:2], res['ticket'][:2], res['nofence'][:2])
-    for mode in ('ticket', 'nofence'):
-        for a, b in zip(res['three'][2:], res[mode][2:]):
-            assert float((a - b).abs().max()) <= 1e-5 * (float(a.abs().max()) + 1e-6)
-
-
-@pytest.mark.parametrize('mode', ['one-launch', 'three-launches', 'ticket', 'ticket-nofence'])
+@pytest.mark.parametrize('mode', ['one-launch', 'three-launches'])
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_group_norm_from_source(dt, mode):
-    """the group-norm kernels (FCOS head) against torch autograd through the GPU test's own cases; 'ticket' = odtk_debug_set(7, -7), which only the bf16 shapes
-    whose groups sit inside 64-channel blocks take (the others run the three launches)"""
+    """the group-norm kernels (FCOS head) against torch autograd through the GPU test's own cases"""
     import odtk  # noqa: F401
     from odtk import ops
     import test_gpu_retinanet_model as mod
     with HC.installed():
         ops.debug_set(7, 1024 if mode == 'one-launch' else 0)
-        ops.debug_set(7, {'ticket': -7, 'ticket-nofence': -9}.get(mode, -8))
         try:
             mod._group_norm_cases(ops, CPU, dt)
         finally:
-            ops.debug_set(7, 1024); ops.debug_set(7, -8)
-
-
-def test_group_norm_ticket_finalize_is_bit_equal_and_drops_the_finalize_launches():
-    """odtk_debug_set(7, -7): a large-map bf16 group norm is 2 launches forward and 2 (+ the parameter-gradient one) backward instead of 3 and 3 (+ 1); the
-    finalizing workgroup sums the partials in the finalize kernel's own order, so every output is bit-equal to the three-launch path"""
-    import ctypes
-    import odtk  # noqa: F401
-    from odtk import ops
-    lib = HC.build()
-    lib.hipcpu_launch_count.restype = ctypes.c_longlong
-    g = torch.Generator().manual_seed(2)
-    res = {}
-    for (N, HW, C, ld, groups) in [(3, 40 * 40, 256, 256, 32), (2, 33 * 31, 128, 136, 32), (2, 64 * 48, 16, 16, 8)]:
-        x = (torch.randn(N * HW, ld, generator=g) * 2 + 0.7).bfloat16()
-        dy = torch.randn(N * HW, ld, generator=g).bfloat16()
-        gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
-        with HC.installed():
-            ops.debug_set(7, 0)
-            try:
-                for mode in ('three', 'ticket', 'nofence'):
-                    ops.debug_set(7, {'three': -8, 'ticket': -7, 'nofence': -9}[mode])
-                    for rep in range(2):                       # twice: the tickets reset themselves
-                        y, dx = torch.zeros(N * HW, ld, dtype=torch.bfloat16), torch.zeros(N * HW, ld, dtype=torch.bfloat16)
-                        save, dg, db = torch.zeros(N, groups, 2), torch.zeros(C), torch.zeros(C)
-                        ws = ops.gn_workspace(N, C, CPU)
-                        n0 = lib.hipcpu_launch_count()
-                        ops.gn_fwd(x, ld, y, ld, N, HW, C, groups, gamma, beta, 1, save)
-                        n1 = lib.hipcpu_launch_count()
-                        ops.gn_bwd(x, ld, y, dy, ld, dx, ld, N, HW, C, groups, gamma, save, 1, False, dg, db, ws)
-                        n2 = lib.hipcpu_launch_count()
-                        res[mode, rep] = (n1 - n0, n2 - n1, y, dx, save, dg, db)
-            finally:
-                ops.debug_set(7, 1024); ops.debug_set(7, -8)
-        assert res['three', 0][:2] == (3, 4), res['three', 0][:2]
-        for mode in ('ticket', 'nofence'):
-            for rep in range(2):
-                assert res[mode, rep][:2] == (2, 3), (mode, rep, res[mode, rep][:2])
-                for a, b in zip(res['three', 0][2:], res[mode, rep][2:]):
-                    assert torch.equal(a, b)
+            ops.debug_set(7, 1024)
 
 
 def test_yolov2_box_side_from_source():

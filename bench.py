@@ -274,7 +274,7 @@ def main():
     ap.add_argument('--sync-bn', action='store_true', help='N > 1: batch-norm statistics over all replicas (SURVEY 8e option B; eager launches)')
     ap.add_argument('--conv-table', default=None, help='write the per-layer conv launch table (eager roofline pass) to this file')
     ap.add_argument('--kernel-dbg', type=int, default=0, help='A/B: odtk_debug_set(2, bits) dispatch switches of csrc/conv_v3.hip (bits >= 1<<26 only)')
-    ap.add_argument('--debug-set', default='', help="A/B: comma list of KEY:VALUE for odtk_debug_set (keys that leave results intact: 3, 4, 5, 7)")
+    ap.add_argument('--debug-set', default='', help="A/B: comma list of KEY:VALUE for odtk_debug_set (keys that leave results intact: 3, 4, 5, 6, 7)")
     ap.add_argument('--model-cfg', default='', help="A/B: comma list of KEY=VALUE config overrides of the model class (e.g. heads_first=1)")
     ap.add_argument('--bucket-mb', type=int, default=25, help='N > 1: gradient all-reduce bucket size')
     ap.add_argument('--dp-world1', action='store_true',
@@ -442,7 +442,7 @@ def apply_debug_switches(args):
         odtk._lib.load().odtk_debug_set(2, args.kernel_dbg)
     for kv in filter(None, args.debug_set.split(',')):
         k, v = kv.split(':')
-        assert int(k) in (3, 4, 5, 7), 'only the dispatch switches leave results intact'  # (values may be negative: 4:-1)
+        assert int(k) in (3, 4, 5, 6, 7), 'only the dispatch switches leave results intact'  # (values may be negative: 4:-1)
         odtk._lib.load().odtk_debug_set(int(k), int(v))
 
 

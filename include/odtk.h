@@ -46,7 +46,8 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  * key 2 = A/B bits of the conv kernels: bits 0-3 ablations (skip DMA / one slab; RESULTS WRONG), 5 no fragment double
  *         buffering, 6 no early/late DMA stagger, 7 "landed early" protocol, 8 64-bit global addressing for the LDS-DMA,
  *         9 no XCD remap (wgrad), 10 s_setprio, 11 no 64->64 / first-layer halo kernels, 12 per-lane tap walk,
- *         13 no split-K, 14 interleaved slab body, 16 no raster-run halo kernel (v6),
+ *         13 no split-K, 14 interleaved slab body, 15 block-pair halo filter gradient on any size (tests), 16 no raster-run halo kernel (v6),
+ *         17 no block-pair halo filter gradient (the 64x64 halo wgrad kernel only where C = K = 64),
  *         18-25 = n: halo kernel instead of split-K on layers with >= n tiles (0 = split-K policy as is), 26 no wide (W <= 159) halo
  *         variant, 27 no 128x512 halo tiles, 28 no 128x192 halo tiles, 29 no four-wave filter-gradient kernel (v8), 30 v8 also on
  *         short pixel ranges;
@@ -56,6 +57,7 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back;
  * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
  *         run, 2.5 % slower on the SSD300 step) instead of float atomics into dw (the default);
+ * key 6 = dispatch A/B switches of the convolution kernels that leave results intact (none defined at present);
  * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never) */
 int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to

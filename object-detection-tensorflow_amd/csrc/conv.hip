@@ -783,6 +783,7 @@ __global__ void __launch_bounds__(256) filter_prepare_batched_kernel(const FpIte
 static bool g_force_regstage = false;   // debugging knob (odtk_debug_set key 0)
 static thread_local const char* g_last_kernel = "";   // name of the conv kernel the last conv call launched (odtk_conv_last_kernel)
 static int g_dbg = 0;                   // key 2: perf-experiment bits forwarded to the kernels (results are wrong when set)
+static int g_dbg2 = 0;                  // key 6: dispatch A/B switches of the conv kernels that leave results intact
 static int g_v3_mode = 0;               // key 1: 0 = auto, 1 = legacy 4-wave kernels only, 2 = 8-wave v3 wherever supported
 
 template <typename T, typename TO>
@@ -813,6 +814,7 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
     a.div_howo = make_fastdiv((unsigned)(a.Ho * a.Wo));
     a.div_wo = make_fastdiv((unsigned)a.Wo);
     a.dbg = g_dbg;
+    a.dbg2 = g_dbg2;
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * dtype_size(dtype));
     a.w_bytes = (unsigned)((size_t)ceil_div(a.K, 1) * a.ldw * dtype_size(dtype));
     if (!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && gather_c64_supported(a, dtype, out_dtype)) {
@@ -881,6 +883,7 @@ extern "C" int odtk_debug_set(int key, int value) {
     if (key == 0) { g_force_regstage = value != 0; return ODTK_OK; }
     if (key == 1) { g_v3_mode = value; return ODTK_OK; }
     if (key == 2) { g_dbg = value; return ODTK_OK; }
+    if (key == 6) { g_dbg2 = value; return ODTK_OK; }
     if (key == 3) { set_nms_legacy(value != 0); return ODTK_OK; }
     if (key == 4) { set_bn_small_rows(value); return ODTK_OK; }
     if (key == 5) { cv::set_wgrad_deterministic(value != 0); return ODTK_OK; }

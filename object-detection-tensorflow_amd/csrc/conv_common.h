@@ -141,6 +141,7 @@ struct GatherArgs {
     int tiles_p, tiles_q;
     FastDiv div_howo, div_wo;
     int dbg;           // perf experiments only (odtk_debug_set key 2): bit0 skip pixel-operand DMA, bit1 skip filter DMA after slab 0
+    int dbg2;          // dispatch A/B switches that leave results intact (odtk_debug_set key 6): none defined at present
     unsigned x_bytes, w_bytes;   // extents of x and w for the buffer-addressed DMA (range check = zero fill)
     int ksplit;        // split-K: blocks per tile (1 = off) and their f32 partial tiles [ksplit][M][ldy]
     float* ws;

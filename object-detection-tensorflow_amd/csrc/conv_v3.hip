@@ -482,6 +482,8 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 // 1, 4, 4 = a 128 x 512 tile of four 128 x 128 wave tiles (0.5 reads per MFMA, round 2: the 75- and 150-pixel maps, whose time is LDS
 // bandwidth); 2, 2, 3 = 128 x 192 (conv5_x: 244 instead of 184 tiles for 256 CUs); 1, 2, 4 = 64 x 512 for Cout <= 64
 // (conv2_1's input gradient, 128 -> 64 channels at W = 150: it ran on the 8-wave gather kernel at 490 TFLOP/s).
+// (Round 4, measured and removed: a FOURTH filter stage where the patch leaves 16 KiB free -- conv4_x on an 11-group patch pair, the single-buffer variants of
+// W = 75 -- with slab kt + 3 issued and two slabs' pieces in flight across a barrier: bit-identical, 1-3 % SLOWER on every layer, profiles/r04k_*.)
 template <int NPP, bool DBUF, int G1, int G2, int WP = 2, int PI = 2, int QI = 4>
 __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a) {
     constexpr int PT = WP * PI * 32, QT = (4 / WP) * QI * 32, NTHR = 256;
@@ -1382,7 +1384,8 @@ __global__ void __launch_bounds__(256) conv3x3_c8k64_kernel(const GatherArgs a, 
 // 144 MFMAs per tile, one barrier per tile, and adds it to dW with float atomics once at the end.  Bias gradient fused.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a, const int tiles_r, const int tiles_c,
-                                                              const int total_tiles, const FastDiv div_tpi, const FastDiv div_tc) {
+                                                              const int total_tiles, const FastDiv div_tpi, const FastDiv div_tc, const int npairs,
+                                                              const int ncb) {
     constexpr int PW = 34, PPX = 340, NPX = 44, NPD = 32;          // patch (43 + 1 pad -> 11 per wave) / dy-tile DMA pieces (8 px x 128 B)
     constexpr int DBUF = NPD * 1024, XBUF = NPX * 1024, STAGE = DBUF + XBUF;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -1391,8 +1394,13 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
     const int kb = wave & 1, ch_half = wave >> 1;                  // 32 output channels x 32 input channels, all 9 taps
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
-    const int grid = gridDim.x;
-    const int slot = xcd_remap(blockIdx.x, grid);
+    // Round 4: any C, K that are multiples of 64 -- the workgroup owns ONE (64-channel block of x, 64-channel block of dy) pair of dW, i.e. the conv1_2
+    // problem on rows of ldx / lddy elements at a channel offset; consecutive block slots are the pairs of the same tile walk, so the workgroups that
+    // fetch the same dy tile / x patch run next to each other on one XCD (xcd_remap) and share it in that L2.
+    const int vslot = xcd_remap(blockIdx.x, gridDim.x);
+    const int pair = vslot % npairs, slot = vslot / npairs, grid = gridDim.x / npairs;
+    const int cblk = pair % ncb, kblk = pair / ncb;
+    const int xp = a.ldx * 2, dp = a.lddy * 2;                     // row pitches in bytes
     const int my_tiles = slot < total_tiles ? (total_tiles - slot + grid - 1) / grid : 0;
     if (my_tiles == 0) return;
     const int tiles_per_img = tiles_r * tiles_c;
@@ -1411,24 +1419,24 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
     const int sub = lane >> 3;
     const int lc16 = ((lane & 7) ^ (((sub >> 1) & 1) << 2)) * 16;
     const int dy_col = wave * 8 + sub;
-    const int dy_rel = dy_col * 128 + lc16;
+    const int dy_rel = dy_col * dp + kblk * 128 + lc16;
     int x_rel[11], x_prc[11];
     static_for<11>([&](auto TT) __attribute__((always_inline)) {
         constexpr int tt = decltype(TT)::value;
         const int px = (wave + 4 * tt) * 8 + sub;
         const int pr = px / PW, pc = px - pr * PW;
-        x_rel[tt] = (pr * a.W + pc) * 128 + lc16;
+        x_rel[tt] = (pr * a.W + pc) * xp + cblk * 128 + lc16;
         x_prc[tt] = (px < PPX ? pr : 0x7FFF) | (pc << 16);
     });
     auto dma_off = [&](int s, int n, int h0, int w0, bool en) __attribute__((always_inline)) -> unsigned {
         if (s < 8) {
-            const int base = ((n * a.H + h0 + s) * a.W + w0) * 128;
+            const int base = ((n * a.H + h0 + s) * a.W + w0) * dp;
             const bool ok = en && (h0 + s < a.H) && (w0 + dy_col < a.W);
             const unsigned addr = (unsigned)(base + dy_rel);
             return ok ? addr : 0xFFFFFFF0u;
         } else {
             const int tt = s - 8;
-            const int base = ((n * a.H + h0 - 1) * a.W + w0 - 1) * 128;
+            const int base = ((n * a.H + h0 - 1) * a.W + w0 - 1) * xp;
             const int h = (x_prc[tt] & 0xFFFF) + h0 - 1, w = (x_prc[tt] >> 16) + w0 - 1;
             const bool ok = en && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
             const unsigned addr = (unsigned)(base + x_rel[tt]);
@@ -1471,7 +1479,7 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
     for (int j = 0; j < 9; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    const bool do_bias = a.dbias != nullptr && ch_half == 0;
+    const bool do_bias = a.dbias != nullptr && ch_half == 0 && cblk == 0;
     float bsum = 0.f;
 
     for (int it = 0; it < my_tiles; ++it) {
@@ -1548,19 +1556,19 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
             }
         });
     }
-    // ---- dW (+)= : rows k = kb*32 + 8*(e>>2) + 4*hi + (e&3), column = tap*64 + ch_half*32 + l31
+    // ---- dW (+)= : rows k = kblk*64 + kb*32 + 8*(e>>2) + 4*hi + (e&3), column = tap*C + cblk*64 + ch_half*32 + l31
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        const int col = j * 64 + ch_half * 32 + l31;
+        const int col = j * a.C + cblk * 64 + ch_half * 32 + l31;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int k = kb * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+            const int k = kblk * 64 + kb * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
             atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[j][e]);
         }
     }
     if (do_bias) {
         const float tsum = bsum + __shfl_xor(bsum, 32);           // both k halves
-        if (hi == 0) atomicAdd(a.dbias + kb * 32 + l31, tsum);
+        if (hi == 0) atomicAdd(a.dbias + kblk * 64 + kb * 32 + l31, tsum);
     }
 }
 
@@ -1920,9 +1928,20 @@ int launch_gather_c8(GatherArgs& a, hipStream_t st) {
 }
 
 bool wgrad_c64_supported(const WgradArgs& a, int dtype) {
-    return dtype == ODTK_BF16 && a.C == 64 && a.ldx == 64 && a.K == 64 && a.lddy == 64 && a.R == 3 && a.S == 3 && a.dil == 1 &&
-           a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo && a.RSC == 576 &&
-           (long long)a.N * a.H * a.W * 64 * 2 < (1ll << 31);
+    if (!(dtype == ODTK_BF16 && a.C % 64 == 0 && a.K % 64 == 0 && a.C >= 64 && a.K >= 64 && a.ldx >= a.C && a.ldx % 8 == 0 && a.lddy >= a.K && a.lddy % 8 == 0 &&
+          a.R == 3 && a.S == 3 && a.dil == 1 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo && a.RSC == 9 * a.C &&
+          (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31) && (long long)a.P * a.lddy * 2 < (1ll << 31)))
+        return false;
+    if (a.C == 64 && a.K == 64) return true;                    // conv1_2: the kernel's home
+    // Round 4: one (64 x 64) block pair of dW per workgroup for the wide, large maps whose 8 x 32-pixel tiles waste little -- conv2_1 / conv2_2 at 150 x 150
+    // (5 x 19 tiles per image: 94 %): 161 -> 1xx us and 273 -> 2xx us against the 8-wave gather kernel (one x slab per tap there, one halo patch per tile here).
+    // Narrow maps (W = 75: 78 %, W = 38: 59 %) stay on the generic kernels; dbg bit 17 = off (A/B).
+    if (a.dbg & (1 << 17)) return false;
+    const int npairs = (a.C / 64) * (a.K / 64);
+    if (a.dbg & (1 << 15)) return npairs <= 16;                 // tests: the block-pair path on small / ragged problems too
+    const double eff = (double)a.W / (32.0 * ceil_div(a.W, 32)) * (double)a.H / (8.0 * ceil_div(a.H, 8));
+    const long long tiles = (long long)a.N * ceil_div(a.H, 8) * ceil_div(a.W, 32);
+    return npairs <= 8 && eff >= 0.9 && tiles * npairs >= 16 * 256;
 }
 
 int launch_wgrad_c64(WgradArgs& a, hipStream_t st) {
@@ -1930,11 +1949,14 @@ int launch_wgrad_c64(WgradArgs& a, hipStream_t st) {
     a.rev = ((unsigned)a.dbg >> 31) ? 0 : 1;
     const int tr = ceil_div(a.H, 8), tc = ceil_div(a.W, 32);
     const int tiles = a.N * tr * tc;
-    const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+    const int ncb = a.C / 64, npairs = ncb * (a.K / 64);
+    int per_pair = g_num_cu / npairs;                           // workgroups per block pair (one workgroup per CU in all)
+    if (per_pair > tiles) per_pair = tiles;
+    if (per_pair < 1) per_pair = 1;
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
-    hipLaunchKernelGGL(wgrad3x3_c64k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)),
-                       make_fastdiv((unsigned)tc));
+    hipLaunchKernelGGL(wgrad3x3_c64k64_kernel, dim3(per_pair * npairs), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)),
+                       make_fastdiv((unsigned)tc), npairs, ncb);
     return 0;
 }
 

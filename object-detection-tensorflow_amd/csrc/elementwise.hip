@@ -59,6 +59,31 @@ __global__ void preprocess_kernel(const float* __restrict__ img, long long pixel
     }
 }
 
+// bf16 rows of 8 channels (the first layer's 16-byte pixels): FOUR pixels per thread -- three 16-byte loads of 12 consecutive floats, four 16-byte
+// stores -- instead of three 4-byte loads at a 12-byte stride and eight 2-byte stores per pixel (57 us for 80 MB at batch 32, round 3).  Same
+// arithmetic per element (x - mean, one rounding to bf16).
+__global__ void __launch_bounds__(256) preprocess_bf16x8_kernel(const float* __restrict__ img, long long pixels, float m0, float m1, float m2,
+                                                                bf16_t* __restrict__ x) {
+    const long long quads = pixels >> 2;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < quads; i += step) {
+        const float4* p = reinterpret_cast<const float4*>(img + i * 12);
+        const float4 a = p[0], b = p[1], c = p[2];
+        const float v[12] = {a.x - m0, a.y - m1, a.z - m2, a.w - m0, b.x - m1, b.y - m2, b.z - m0, b.w - m1, c.x - m2, c.y - m0, c.z - m1, c.w - m2};
+        uint4* o = reinterpret_cast<uint4*>(x + i * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o[q] = make_uint4((unsigned)f32_to_bf16(v[3 * q]) | ((unsigned)f32_to_bf16(v[3 * q + 1]) << 16), (unsigned)f32_to_bf16(v[3 * q + 2]), 0u, 0u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (pixels & 3)) {            // the last pixels % 4
+        const long long px = (quads << 2) + threadIdx.x;
+        bf16_t* o = x + px * 8;
+        o[0] = f32_to_bf16(img[px * 3] - m0); o[1] = f32_to_bf16(img[px * 3 + 1] - m1); o[2] = f32_to_bf16(img[px * 3 + 2] - m2);
+        for (int c = 3; c < 8; ++c) o[c] = 0;
+    }
+}
+
 // ------------------------------------------------------------------ max pool
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
@@ -1269,6 +1294,12 @@ extern "C" int odtk_preprocess(const float* images, long long pixels, const floa
                                void* x, void* stream) {
     ODTK_REQUIRE(images && x && mean3 && ldx >= 3, "preprocess: bad argument");
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == ODTK_BF16 && ldx == 8 && ((uintptr_t)images & 15) == 0 && ((uintptr_t)x & 15) == 0) {
+        hipLaunchKernelGGL(preprocess_bf16x8_kernel, dim3(grid_for((pixels + 3) / 4, 256)), dim3(256), 0, st, images, pixels, mean3[0], mean3[1], mean3[2],
+                           (bf16_t*)x);
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(preprocess_kernel<T>, dim3(grid_for(pixels, 256)), dim3(256), 0, st,
                                            images, pixels, mean3[0], mean3[1], mean3[2], ldx, (T*)x);)
     ODTK_LAUNCH_CHECK();

@@ -558,6 +558,14 @@ class SSD300:
                 fn()                                             # (whatever fn returns is not a status code)
             rec.append((replay, ()))
 
+    _phases = None           # tools/phase_times.py: list of (name, event) of the current step -- events on the MAIN stream at the phase boundaries of the step
+
+    def _phase(self, name):
+        if self._phases is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self._phases.append((name, ev))
+
     def _event(self, key):
         ev = self._events.get(key)
         if ev is None:
@@ -594,6 +602,7 @@ class SSD300:
                 else:
                     ops.maxpool_fwd(x.t, y.t, x.N, x.H, x.W, x.C, x.ld, y.H, y.W, k, s, pt, pt)
         c43 = a['conv4_3']
+        self._phase('fwd: conv1_1 .. conv4_3 done')
         ops.l2norm_fwd(c43.t, a['feat1'].t, c43.M, 512, c43.ld, self.param('l2norm.gamma'))
         tail = self._tail if self.sync_bn is None else None
         main = torch.cuda.current_stream() if tail is not None else None
@@ -604,20 +613,26 @@ class SSD300:
         for (name, ci, co, k, s, d) in self.EXTRA_SEQ:
             src = a[self.extra_src[name]]
             z, y = self.zbuf[name], a[name]
+            if name == 'conv8_1':
+                self._phase('fwd: conv6, conv7 done')
             self._conv_fwd(name, src, z, self.param(name + '.b'), False)
+            self._phase(f'  fwd {name}: conv done')
             sm, si = self.bnsave[name]
             self._bn_fwd(z.t, z.M, co, z.ld, self.param(name + '.gamma'), self.param(name + '.beta'),
                        self.stat(name + '.mmean'), self.stat(name + '.mvar'), sm, si, training, True,
                        y.t, y.ld, z.M, 0, self.ws)
+            self._phase(f'  fwd {name}: batch norm done')
             if tail is not None and name in self.FEAT_SRC:
                 self._py(lambda: tail.wait_stream(main))  # this feature map is final: its head may start
                 with self._on_tail():
                     self._head_fwd(self.FEAT_SRC.index(name), training)
+        self._phase('fwd: conv8_1 .. conv11_2 done (main chain)')
         if tail is not None:
             self._py(lambda: main.wait_stream(tail))      # join: pred is complete
         else:
             for i in range(self.NH):
                 self._head_fwd(i, training)
+        self._phase('fwd: heads joined')
 
     def _head_fwd(self, i, training):
         """pred<i+1>: 3x3 conv + bias + batch norm, written straight into pred [N, 8828, 25] (SSD300.py:85-90, :316-321)"""
@@ -732,14 +747,18 @@ class SSD300:
                     self._py(lambda ev=ev: ev.record(tail))
                 yield f'pred{i + 1}'                      # (outside the stream context: whoever resumes us runs on the main stream)
         # extra layers conv11_2 .. conv6
+        self._phase('loss done')
         for (name, ci, co, k, s, d) in reversed(self.EXTRA_SEQ):
             src = a[self.extra_src[name]]
             z, y = self.zbuf[name], a[name]
             sm, si = self.bnsave[name]
+            if name == 'conv7':
+                self._phase('bwd: conv11_2 .. conv8_1 done (main chain)')
             if name == self.EXTRA_SEQ[-1][0] and name in evs:
                 self._py(lambda ev=evs[name]: main.wait_event(ev))      # the last feature map: only its head wrote y.g
             self._bn_bwd(z.t, y.t, y.g, z.M, co, z.ld, y.ld, z.M, 0, self.param(name + '.gamma'), sm, si, True,
                        z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
+            self._phase(f'  bwd {name}: batch norm done')
             self._conv_bwd_params(name, src, z.g, z.ld)
             # the source already holds the head's gradient when it is a feature map
             acc = self.extra_src[name] in self.FEAT_SRC
@@ -747,9 +766,12 @@ class SSD300:
                 self._py(lambda ev=evs[self.extra_src[name]]: main.wait_event(ev))
             relu_src = src.t if name == 'conv6' else None       # pool5 output: post-ReLU values
             ops.conv2d_dgrad(self.desc[name], z.g, z.ld, self.wt[name], relu_src, src.g, acc)
+            self._phase(f'  bwd {name}: input gradient done')
             yield name
+        self._phase('bwd: conv7, conv6 done (main chain)')
         if tail is not None:
             self._py(lambda: main.wait_stream(tail))      # join: pred1 -> feat1.g is final before the trunk reads it
+        self._phase('bwd: heads joined')
         # VGG trunk
         for step in reversed(self.vgg_plan):
             if step[0] == 'pool':
@@ -772,6 +794,8 @@ class SSD300:
                 self._conv_bwd_params(name, x, y.g, y.ld)
                 if name != 'conv1_1':
                     ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
+                if name in ('conv5_1', 'conv4_1', 'conv3_1', 'conv2_1', 'conv1_1'):
+                    self._phase(f'bwd: {name[:5]} block done')
                 yield name
         if self._twg is not None and self._dp_multi_stream() and self.sync_bn is None:
             cur = torch.cuda.current_stream()

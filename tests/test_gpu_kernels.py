@@ -109,14 +109,17 @@ V3_EXTRA_CASES = [
     (6, 20, 17, 256, 512, 3, 1, 1),   # four-wave filter gradient (256 x 256 tiles, fixture wgrad-v8): two k tiles, nine column tiles, ragged last 32-pixel slab
     (5, 19, 23, 256, 256, 3, 2, 1),   # ... stride 2 with the asymmetric SAME pad (the pixel walk steps input rows / columns by 2)
     (7, 5, 3, 256, 256, 3, 1, 1),     # ... 15-pixel images: one 32-pixel slab spans three images (walk: dn = 2 images + 2 pixels)
+    (2, 40, 64, 128, 128, 3, 1, 1),   # block-pair halo filter gradient (fixture wgrad-c64-pairs): 2 x 2 pairs, whole 8 x 32 tiles
+    (3, 33, 95, 64, 192, 3, 1, 1),    # ... 1 x 3 pairs, ragged right / bottom tiles, fewer tiles than workgroups per pair
+    (1, 17, 150, 192, 64, 3, 1, 1),   # ... 3 x 1 pairs at the conv2_x width
 ]
 
 
-@pytest.fixture(params=[(2, 0), (3, 0), (2, 256 + 65536), (2, 16384 + 65536), (2, 8192 + 65536), (2, 32768 + 8192 + 65536), (2, 8192), (2, 65536), (2, 131072), (2, 1 << 30)], ids=["v3-8wave", "v4-persistent", "v3-globaldma", "v3-interleaved", "v3-nosplitk", "v5-4wave", "v6-halo-nosplitk", "v3-nohalo", "wgrad-v7", "wgrad-v8"])
+@pytest.fixture(params=[(2, 0), (2, 256 + 65536), (2, 16384 + 65536), (2, 8192 + 65536), (2, 8192), (2, 65536), (2, 1 << 30), (2, 1 << 15)], ids=["v3-8wave", "v3-globaldma", "v3-interleaved", "v3-nosplitk", "v6-halo-nosplitk", "v3-nohalo", "wgrad-v8", "wgrad-c64-pairs"])
 def v3_engine(request):
-    """Force the 8-wave (2) / persistent wave-specialised (3) conv kernels wherever they are
-    supported (odtk_debug_set key 1); key 2 bit 8 selects 64-bit global addressing for the LDS-DMA, bit 14 the
-    interleaved slab body, bit 13 turns split-K off, bit 30 lets the four-wave filter-gradient kernel (256 x 256 tiles) take short pixel ranges."""
+    """Force the 8-wave conv kernels wherever they are supported (odtk_debug_set key 1 = 2); key 2 bit 8 selects 64-bit global addressing for the LDS-DMA,
+    bit 14 the interleaved slab body, bit 13 turns split-K off, bit 30 lets the four-wave filter-gradient kernel (256 x 256 tiles) take short pixel ranges,
+    bit 15 lets the block-pair halo filter gradient (wgrad3x3_c64k64_kernel on C, K multiples of 64) take small and ragged problems."""
     ops = _ops()
     ops.debug_set(1, request.param[0])
     ops.debug_set(2, request.param[1])

@@ -43,10 +43,12 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 modes = [(m if ':' in m else int(m)) for m in sys.argv[4].split(',')] if len(sys.argv) > 4 else [1, 2]      # 'E:bits' = engine E, debug bits
 # mode >= 100: 8-wave kernels with perf-experiment bits (mode - 100) -> odtk_debug_set(2, bits); results are garbage
 dev = torch.device('cuda')
+if os.environ.get('ODTK_DBG2'):
+    ops.debug_set(6, int(os.environ['ODTK_DBG2']))          # dispatch A/B switches that leave results intact (include/odtk.h, key 6)
 tot = {m: 0.0 for m in modes}
 for name in which:
     N, H, C, K, k, s, d = LAYERS[name]
-    Kp = ops.pad_to(K, 8)
+    Kp = ops.pad_to(K, int(os.environ.get('KP_PAD', 8)))
     desc = ops.conv_desc(N, H, H, C, C, K, Kp, k, s, d, ops.BF16, ops.BF16)
     M = N * desc.Ho * desc.Wo
     x = torch.randn(N * H * H, C, device=dev).to(torch.bfloat16)

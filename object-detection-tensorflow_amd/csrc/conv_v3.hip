@@ -26,80 +26,112 @@ __device__ __forceinline__ void block_barrier() {
 }
 
 // ---------------------------------------------------------------------------------------
-// Coalesced epilogue shared by the gather kernels: acc -> (bias) -> bf16 -> swizzled LDS image
+// Coalesced epilogue shared by the gather kernels: acc -> (bias) -> bf16 -> (ReLU) -> swizzled LDS image
 // [QT pixels][PT channels] -> 16 B per lane -> (accumulate, relu, mask) -> global.
 // `smem` must be free (all slab reads done, barrier passed) and hold QT*PT*2 bytes.
+//
+// Round 4 rewrite.  Switching the epilogue off showed what it costs with one workgroup per CU and nothing to overlap it: 31 % of conv2_1, 23-31 % of conv2_2,
+// 12-19 % of conv3_2, 6-10 % of conv4_2 -- and two thirds of that was NOT the global stores but the instruction stream around them (1 376 VALU in the compiled
+// epilogue of the 128 x 256 variant: 64-bit address arithmetic and bounds tests per 16-byte chunk, f32 bias add + f32 ReLU per value).  Now:
+//   * BIAS_IN_ACC (raster-run halo kernel): the accumulators START at the bias, nothing is added here;
+//   * ReLU is a packed signed-16-bit max on the ROUNDED pair (rounding keeps the sign; -0 -> +0): one op per two values;
+//   * the image addresses of a lane are 4 PI swizzle terms + instruction-offset immediates (a 32-pixel step leaves (pixel & 15) alone);
+//   * the store pass is buffer-addressed: one per-lane byte offset, the iteration's row step in an SGPR, rows >= M and pitch-tail chunks dropped by the
+//     hardware range check -- per iteration one ds_read_b128 and one buffer_store_dwordx4 (plus the loads / chunk post-ops of a masked or accumulating pass).
 // ---------------------------------------------------------------------------------------
-template <int PT, int QT, int NTHR, int PI, int QI>
+typedef unsigned u32x4_v __attribute__((ext_vector_type(4)));
+typedef short s16x2e_v __attribute__((ext_vector_type(2)));
+
+template <int PT, int QT, int NTHR, int PI, int QI, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f32x16_v (&acc)[PI][QI],
                                               int p0, int q0, int prow0, int qrow0, int tid) {
     constexpr int RB = PT * 2;            // bytes per pixel row of the image
     constexpr int NCH = RB / 16;          // 16-B chunks per row (8 | 16)
     constexpr int NIT = (QT * NCH) / NTHR;
+    constexpr int RPI = NTHR / NCH;       // pixel rows per store-pass iteration (a multiple of NCH: the read swizzle is the same in every iteration)
+    static_assert(RPI % NCH == 0 && (QT * NCH) % NTHR == 0, "store pass: whole iterations, iteration step a multiple of the swizzle period");
     const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    // Every global load of the epilogue is issued BEFORE its first use: the bias of this lane's 4 * PI channel groups
-    // here, the accumulate / ReLU-mask operands of the store pass below in one batch.  (Loading them inside the loops
-    // exposed one full memory latency per iteration: 32 + 16 of them per tile were 12-23 % of the 4-wave kernels.)
     float4 bv[PI][4];
+    if (!BIAS_IN_ACC) {
+        // (every global load of the epilogue is issued BEFORE its first use: the bias of this lane's 4 * PI channel groups here, the accumulate /
+        //  ReLU-mask operands of the store pass below in one batch)
 #pragma unroll
-    for (int i = 0; i < PI; ++i)
+        for (int i = 0; i < PI; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = p0 + prow0 + i * 32 + 8 * g + 4 * hi;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) {
-                if (c + 3 < a.K) b = *reinterpret_cast<const float4*>(a.bias + c);
-                else {
-                    if (c < a.K) b.x = a.bias[c];
-                    if (c + 1 < a.K) b.y = a.bias[c + 1];
-                    if (c + 2 < a.K) b.z = a.bias[c + 2];
+            for (int g = 0; g < 4; ++g) {
+                const int c = p0 + prow0 + i * 32 + 8 * g + 4 * hi;
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias) {
+                    if (c + 3 < a.K) b = *reinterpret_cast<const float4*>(a.bias + c);
+                    else {
+                        if (c < a.K) b.x = a.bias[c];
+                        if (c + 1 < a.K) b.y = a.bias[c + 1];
+                        if (c + 2 < a.K) b.z = a.bias[c + 2];
+                    }
                 }
+                bv[i][g] = b;
             }
-            bv[i][g] = b;
-        }
-    const float lo = (a.relu && !a.accumulate) ? 0.f : -INFINITY;      // ReLU without accumulate is applied in f32 here
-#pragma unroll
-    for (int j = 0; j < QI; ++j) {
-        const int q = qrow0 + j * 32 + l31;
+    }
+    // ReLU without accumulate is applied here, on the rounded pair (with accumulate it follows the sum, in post_chunk)
+    const s16x2e_v floor16 = (a.relu && !a.accumulate) ? (s16x2e_v)(0) : (s16x2e_v)(-32768);
+    {
+        const int qq = (qrow0 + l31) & (NCH - 1);                     // the pixel's swizzle bits: the same for every j (32-pixel steps)
+        char* rowp = smem + (qrow0 + l31) * RB;
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = prow0 + i * 32 + 8 * g + 4 * hi;      // channel inside the tile
-                const float4 b = bv[i][g];
-                uint2 o;
-                o.x = cvt_pk_bf16(fmaxf(acc[i][j][4 * g] + b.x, lo), fmaxf(acc[i][j][4 * g + 1] + b.y, lo));
-                o.y = cvt_pk_bf16(fmaxf(acc[i][j][4 * g + 2] + b.z, lo), fmaxf(acc[i][j][4 * g + 3] + b.w, lo));
-                *reinterpret_cast<uint2*>(smem + q * RB + ((((cl >> 3) ^ q) & (NCH - 1)) << 4) + ((cl & 4) << 1)) = o;
+                char* dst = rowp + ((((cl >> 3) ^ qq) & (NCH - 1)) << 4) + ((cl & 4) << 1);
+#pragma unroll
+                for (int j = 0; j < QI; ++j) {
+                    float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                    if (!BIAS_IN_ACC) { v0 += bv[i][g].x; v1 += bv[i][g].y; v2 += bv[i][g].z; v3 += bv[i][g].w; }
+                    uint2 o;
+                    o.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2e_v, cvt_pk_bf16(v0, v1)), floor16));
+                    o.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2e_v, cvt_pk_bf16(v2, v3)), floor16));
+                    *reinterpret_cast<uint2*>(dst + j * 32 * RB) = o;
+                }
             }
         }
     }
-    // operands of the store pass (independent of the image): issue them now, they land under the barrier
+    // store pass: chunk (pixel qt + it * RPI, 16-byte column ch) per lane and iteration
+    const int qt = tid / NCH, ch = tid % NCH;
+    const int c0 = p0 + ch * 8;
+    const long long ybytes = (long long)a.M * a.ldy * 2;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y, (unsigned)ybytes);
+    // (the row step goes through the per-lane offset, not the instruction's scalar offset: the range check compares offset with num_records - soffset, which
+    //  wraps for tiles that reach more than a whole tensor past the end; a pitch-tail lane keeps its out-of-range sentinel by stepping 0)
+    const unsigned voff = c0 < a.ldy ? (unsigned)(((long long)(q0 + qt) * a.ldy + c0) * 2) : 0xFFFFFFF0u;      // (>= ybytes: rows past M are dropped / read as 0)
+    const unsigned sstep = c0 < a.ldy ? (unsigned)(RPI * a.ldy * 2) : 0u;
     const bool post = a.accumulate || a.mask;
-    uint4 oldv[NIT], mkv[NIT];
+    u32x4_v oldv[NIT], mkv[NIT];
     if (post) {
+        // operands of the store pass (independent of the image): issued now, they land under the barrier
+        const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.mask ? a.mask : a.y, (unsigned)((long long)a.M * a.ldmask * 2));
+        const unsigned moff = c0 < a.ldmask ? (unsigned)(((long long)(q0 + qt) * a.ldmask + c0) * 2) : 0xFFFFFFF0u;
+        const unsigned mstep = c0 < a.ldmask ? (unsigned)(RPI * a.ldmask * 2) : 0u;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = it * NTHR + tid;
-            const int q = idx / NCH, ch = idx % NCH;
-            const int m = q0 + q, c0 = p0 + ch * 8;
-            oldv[it] = make_uint4(0, 0, 0, 0); mkv[it] = make_uint4(0, 0, 0, 0);
-            if (m < a.M && c0 < a.ldy) {
-                if (a.accumulate) oldv[it] = *reinterpret_cast<const uint4*>(a.y + ((size_t)m * a.ldy + c0) * 2);
-                if (a.mask) mkv[it] = *reinterpret_cast<const uint4*>(a.mask + ((size_t)m * a.ldmask + c0) * 2);
-            }
+            oldv[it] = (u32x4_v)(0u); mkv[it] = (u32x4_v)(0u);
+            if (a.accumulate) oldv[it] = __builtin_amdgcn_raw_buffer_load_b128(ry, voff + it * sstep, 0, 0);
+            if (a.mask) mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(rm, moff + it * mstep, 0, 0);
         }
     }
     __syncthreads();
+    const char* src = smem + qt * RB + (((ch ^ qt) & (NCH - 1)) << 4);
+    // in batches of EB chunks: EB LDS reads in flight, then EB stores (chunk by chunk the compiler waits for every read: ~120 exposed cycles x NIT per lane)
+    constexpr int EB = NIT % 8 == 0 ? 8 : (NIT % 4 == 0 ? 4 : 1);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * NTHR + tid;
-        const int q = idx / NCH, ch = idx % NCH;
-        const int m = q0 + q, c0 = p0 + ch * 8;
-        if (m >= a.M || c0 >= a.ldy) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(smem + q * RB + (((ch ^ q) & (NCH - 1)) << 4));
-        if (post) post_chunk(v, a.accumulate != 0, a.relu != 0, oldv[it], a.mask != nullptr, mkv[it]);
-        *reinterpret_cast<uint4*>(a.y + ((size_t)m * a.ldy + c0) * 2) = v;
+    for (int it0 = 0; it0 < NIT; it0 += EB) {
+        uint4 v[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) v[e] = *reinterpret_cast<const uint4*>(src + (it0 + e) * RPI * RB);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            if (post) post_chunk(v[e], a.accumulate != 0, a.relu != 0, __builtin_bit_cast(uint4, oldv[it0 + e]), a.mask != nullptr, __builtin_bit_cast(uint4, mkv[it0 + e]));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_v, v[e]), ry, voff + (it0 + e) * sstep, 0, 0);
+        }
     }
 }
 
@@ -570,6 +602,10 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         glds16_buf_nc(rx, ((xok >> i) & 1u) ? addr : 0xFFFFFFF0u, smem_base + (unsigned)buf * PATCH + (wave_u + 4u * (unsigned)i) * 1024u);
     };
 
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) issue_x(i, 0, 0);
+    issue_w(0, 0);
+    issue_w(1, 1);
     f32x16_v acc[PI][QI];
 #pragma unroll
     for (int i = 0; i < PI; ++i)
@@ -577,10 +613,6 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         for (int j = 0; j < QI; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NPP; ++i) issue_x(i, 0, 0);
-    issue_w(0, 0);
-    issue_w(1, 1);
 
     // One tap slab.  Every slab issues the SAME number of pieces (filter slab kt+2: NP; patch pieces of chunk cs+1 by tap
     // position: 2,2,2,2,2,1,1,1,0 for 13 pieces), so the counted vmcnt in front of each barrier is a compile-time constant; past the end
@@ -1785,7 +1817,8 @@ bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype) {
     // 32-bit byte offsets in the buffer-addressed LDS-DMA: both operands must stay below 2 GiB
     return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && (a.idiv == 1 || (a.idiv == 2 && a.dil == 1)) && a.R * a.S <= 32 && a.ldy % 8 == 0 &&
            (a.mask == nullptr || a.ldmask % 8 == 0) && a.ldx % 8 == 0 && a.C % 8 == 0 &&
-           (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31) - (1ll << 21) && (long long)a.K * a.ldw * 2 < (1ll << 31) - (1ll << 21);
+           (long long)a.N * a.H * a.W * a.ldx * 2 < (1ll << 31) - (1ll << 21) && (long long)a.K * a.ldw * 2 < (1ll << 31) - (1ll << 21) &&
+           (long long)a.M * a.ldy * 2 < (1ll << 31) && (a.mask == nullptr || (long long)a.M * a.ldmask * 2 < (1ll << 31));   // buffer-addressed epilogue
 }
 
 int launch_gather_v3(GatherArgs& a, hipStream_t st) {

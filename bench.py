@@ -438,7 +438,7 @@ def main():
 def apply_debug_switches(args):
     import odtk
     if args.kernel_dbg:
-        assert args.kernel_dbg >> 26 << 26 == args.kernel_dbg, 'only the dispatch switches leave results intact'
+        assert (args.kernel_dbg & ~((1 << 15) | (1 << 16) | (1 << 17))) >> 26 << 26 == (args.kernel_dbg & ~((1 << 15) | (1 << 16) | (1 << 17))), 'only the dispatch switches leave results intact'
         odtk._lib.load().odtk_debug_set(2, args.kernel_dbg)
     for kv in filter(None, args.debug_set.split(',')):
         k, v = kv.split(':')

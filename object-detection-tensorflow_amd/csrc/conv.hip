@@ -830,7 +830,7 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
         return ODTK_OK;
     }
     if (!g_force_regstage && g_v3_mode != 1 && gather_v3_supported(a, dtype, out_dtype) &&
-        (g_v3_mode >= 2 || gather_v3_auto(a))) {
+        (g_v3_mode >= 2 || gather_v3_auto(a) || a.pool_mode)) {              // (a fused pool that reaches this point was promised by gather_v6_pool_variant)
         a.ksplit = 1;
         if (int e = launch_gather_v3(a, st)) return e;
         g_last_kernel = a.ksplit > 1 ? (a.K <= 64 ? "conv_gather_v3_kernel<64>+splitk" : "conv_gather_v3_kernel<128>+splitk")
@@ -925,7 +925,9 @@ extern "C" int odtk_conv2d_fwd_pool2x2_fused(const odtk_conv_desc* d) {
     if (check_desc(d)) return 0;
     GatherArgs a;
     fwd_args(a, d, nullptr, nullptr, nullptr, nullptr, 1);
-    return (!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && gather_c64_supported(a, d->dtype, d->out_dtype)) ? 1 : 0;
+    a.dbg = g_dbg;
+    if (!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && gather_c64_supported(a, d->dtype, d->out_dtype)) return 1;
+    return (!g_force_regstage && g_v3_mode != 1 && gather_v6_pool_variant(a, d->dtype, d->out_dtype)) ? 1 : 0;
 }
 
 extern "C" int odtk_maxpool2x2_fwd_idx(const void* x, void* y, void* idx, int N, int H, int W, int C, int ld, int Ho, int Wo, int dtype, void* stream);

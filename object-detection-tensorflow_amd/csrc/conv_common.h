@@ -151,6 +151,10 @@ struct GatherArgs {
     char* ypool;
     unsigned short* pidx;
     int ldpool, pool_mode;
+    // ... and in the raster-run halo kernel (round 4: conv2_2 + pool2, conv3_3 + pool3): a tile is `pool_rpt` (even) whole image rows of one image, so that both rows
+    // of every pooling window are in the tile's LDS image; pool_tpi = tiles per image (the last one may hold fewer rows)
+    int pool_rpt, pool_tpi;
+    FastDiv div_ptpi, div_wp;
     // Tile order of the persistent conv1_x kernels (round 3): 1 = walk the tiles from the LAST to the first.  The maps of conv1_x are 369 MB, more than the
     // 256 MB of memory-side cache: a kernel that starts where its producer STOPPED finds the producer's last ~2/3 still cached.  Forward: conv1_1 walks up,
     // conv1_2 walks down; backward: pool1's gradient is written upwards, conv1_2's filter gradient walks down, its input gradient up, conv1_1's filter gradient down.
@@ -268,7 +272,8 @@ __device__ __forceinline__ void post_chunk(uint4& v, bool accumulate, bool relu,
 // 8-wave / 3-stage LDS ring kernels (conv_v3.hip)
 bool gather_v3_supported(const GatherArgs& a, int dtype, int out_dtype);
 int launch_gather_v3(GatherArgs& a, hipStream_t st);
-bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype);   // resident-filter 64->64 3x3 kernel (the only one with the fused pool)
+bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype);   // resident-filter 64->64 3x3 kernel (with the fused pool)
+int gather_v6_pool_variant(const GatherArgs& a, int dtype, int out_dtype);   // raster-run halo kernel with the fused 2x2 pool: 0 = not covered
 int launch_gather_c64(GatherArgs& a, hipStream_t st);
 bool gather_c8_supported(const GatherArgs& a, int dtype, int out_dtype);    // first-layer (3 -> 64) 3x3 kernel
 int launch_gather_c8(GatherArgs& a, hipStream_t st);

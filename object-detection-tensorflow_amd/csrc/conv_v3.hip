@@ -42,9 +42,12 @@ __device__ __forceinline__ void block_barrier() {
 typedef unsigned u32x4_v __attribute__((ext_vector_type(4)));
 typedef short s16x2e_v __attribute__((ext_vector_type(2)));
 
-template <int PT, int QT, int NTHR, int PI, int QI, bool BIAS_IN_ACC = false>
+// POOL (raster-run halo kernel on row-pair tiles): the tile holds `rows_here` whole rows of image `pn` starting at an even row (pooled row ph0); only its first
+// rows_here * W pixels are this tile's, and after the store pass (skipped when pool_mode == 2: the un-pooled map is never stored) the 2 x 2 / stride-2
+// 'SAME' max pooling of those rows leaves from the same LDS image -- pooled chunk + recorded first arg-max, the arithmetic of conv3x3_c64k64_kernel's fused pool.
+template <int PT, int QT, int NTHR, int PI, int QI, bool BIAS_IN_ACC = false, bool POOL = false>
 __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f32x16_v (&acc)[PI][QI],
-                                              int p0, int q0, int prow0, int qrow0, int tid) {
+                                              int p0, int q0, int prow0, int qrow0, int tid, int pn = 0, int ph0 = 0, int rows_here = 0) {
     constexpr int RB = PT * 2;            // bytes per pixel row of the image
     constexpr int NCH = RB / 16;          // 16-B chunks per row (8 | 16)
     constexpr int NIT = (QT * NCH) / NTHR;
@@ -122,15 +125,65 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
     const char* src = smem + qt * RB + (((ch ^ qt) & (NCH - 1)) << 4);
     // in batches of EB chunks: EB LDS reads in flight, then EB stores (chunk by chunk the compiler waits for every read: ~120 exposed cycles x NIT per lane)
     constexpr int EB = NIT % 8 == 0 ? 8 : (NIT % 4 == 0 ? 4 : 1);
+    if (!POOL || a.pool_mode != 2) {
+        const int valid_px = POOL ? rows_here * a.W : QT;       // (row-pair tiles: the pixels behind the tile's rows belong to the next tile)
 #pragma unroll
-    for (int it0 = 0; it0 < NIT; it0 += EB) {
-        uint4 v[EB];
+        for (int it0 = 0; it0 < NIT; it0 += EB) {
+            uint4 v[EB];
 #pragma unroll
-        for (int e = 0; e < EB; ++e) v[e] = *reinterpret_cast<const uint4*>(src + (it0 + e) * RPI * RB);
+            for (int e = 0; e < EB; ++e) v[e] = *reinterpret_cast<const uint4*>(src + (it0 + e) * RPI * RB);
 #pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            if (post) post_chunk(v[e], a.accumulate != 0, a.relu != 0, __builtin_bit_cast(uint4, oldv[it0 + e]), a.mask != nullptr, __builtin_bit_cast(uint4, mkv[it0 + e]));
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_v, v[e]), ry, voff + (it0 + e) * sstep, 0, 0);
+            for (int e = 0; e < EB; ++e) {
+                if (post) post_chunk(v[e], a.accumulate != 0, a.relu != 0, __builtin_bit_cast(uint4, oldv[it0 + e]), a.mask != nullptr, __builtin_bit_cast(uint4, mkv[it0 + e]));
+                const unsigned off = (!POOL || qt + (it0 + e) * RPI < valid_px) ? voff + (it0 + e) * sstep : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_v, v[e]), ry, off, 0, 0);
+            }
+        }
+    }
+    if (POOL) {
+        typedef unsigned short u16x2p_v __attribute__((ext_vector_type(2)));
+        const int Wp = (a.W + 1) >> 1, Hp = (a.H + 1) >> 1;
+        const int ntask = ((rows_here + 1) >> 1) * Wp * NCH;
+        const int kchunks = a.K >> 3;
+        for (int task = tid; task < ntask; task += NTHR) {
+            const int pch = task % NCH, pp = task / NCH;
+            const int pr = (int)fdiv((unsigned)pp, a.div_wp), pw = pp - pr * Wp;
+            const int hl = 2 * pr, w = 2 * pw;
+            if (p0 + pch * 8 >= a.K) continue;
+            // candidates outside the image are zeroed (they can tie but never win: the values are ReLU outputs) and read the window's first pixel instead
+            const bool b1 = w + 1 < a.W, b2 = hl + 1 < rows_here;
+            const unsigned in1 = b1 ? 0xFFFFFFFFu : 0u, in2 = b2 ? 0xFFFFFFFFu : 0u;
+            const int qa0 = hl * a.W + w;
+            const int qs[4] = {qa0, b1 ? qa0 + 1 : qa0, b2 ? qa0 + a.W : qa0, (b1 && b2) ? qa0 + a.W + 1 : qa0};
+            uint4 v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4*>(smem + qs[t] * RB + (((pch ^ qs[t]) & (NCH - 1)) << 4));
+            const unsigned* u0 = reinterpret_cast<const unsigned*>(&v[0]);
+            const unsigned* u1 = reinterpret_cast<const unsigned*>(&v[1]);
+            const unsigned* u2 = reinterpret_cast<const unsigned*>(&v[2]);
+            const unsigned* u3 = reinterpret_cast<const unsigned*>(&v[3]);
+            uint4 best;
+            unsigned* ub = reinterpret_cast<unsigned*>(&best);
+            unsigned code = 0;
+            const u16x2p_v one = (u16x2p_v)(1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // non-negative bf16 order like unsigned 16-bit integers; FIRST maximum in scan order: row = (max of row 1 > max of row 0), column = (right > left)
+                const u16x2p_v x0 = __builtin_bit_cast(u16x2p_v, u0[q]), x1 = __builtin_bit_cast(u16x2p_v, u1[q] & in1);
+                const u16x2p_v x2 = __builtin_bit_cast(u16x2p_v, u2[q] & in2), x3 = __builtin_bit_cast(u16x2p_v, u3[q] & in1 & in2);
+                const u16x2p_v m01 = __builtin_elementwise_max(x0, x1), m23 = __builtin_elementwise_max(x2, x3);
+                const u16x2p_v row = __builtin_elementwise_min(__builtin_elementwise_sub_sat(m23, m01), one);
+                const u16x2p_v c01 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(x1, x0), one);
+                const u16x2p_v c23 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(x3, x2), one);
+                const u16x2p_v rmask = (u16x2p_v)(0) - row;
+                const u16x2p_v am = ((c23 & rmask) | (c01 & ~rmask)) | (row << 1);
+                const unsigned cu = __builtin_bit_cast(unsigned, am);
+                code |= ((cu | (cu >> 14)) & 0xFu) << (4 * q);
+                ub[q] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(m01, m23));
+            }
+            const size_t mo = (size_t)(pn * Hp + ph0 + pr) * Wp + pw;
+            *reinterpret_cast<uint4*>(a.ypool + (mo * a.ldpool + p0 + pch * 8) * 2) = best;
+            a.pidx[mo * kchunks + (p0 >> 3) + pch] = (unsigned short)code;
         }
     }
 }
@@ -516,7 +569,7 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 // (conv2_1's input gradient, 128 -> 64 channels at W = 150: it ran on the 8-wave gather kernel at 490 TFLOP/s).
 // (Round 4, measured and removed: a FOURTH filter stage where the patch leaves 16 KiB free -- conv4_x on an 11-group patch pair, the single-buffer variants of
 // W = 75 -- with slab kt + 3 issued and two slabs' pieces in flight across a barrier: bit-identical, 1-3 % SLOWER on every layer, profiles/r04k_*.)
-template <int NPP, bool DBUF, int G1, int G2, int WP = 2, int PI = 2, int QI = 4>
+template <int NPP, bool DBUF, int G1, int G2, int WP = 2, int PI = 2, int QI = 4, bool POOL = false>
 __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a) {
     constexpr int PT = WP * PI * 32, QT = (4 / WP) * QI * 32, NTHR = 256;
     static_assert(PT == 128 || PT == 64, "the filter slab is 128 (or 64: Cout <= 64) rows");
@@ -530,7 +583,16 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     const int wp = wave % WP, wq = wave / WP;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
-    const int p0 = tp * PT, q0 = tq * QT;
+    const int p0 = tp * PT;
+    // POOL (round 4): a tile = pool_rpt whole rows of ONE image (<= QT pixels; the rest of the tile is computed and dropped), so that the epilogue can pool them
+    int q0 = tq * QT, pn = 0, ph0 = 0, rows_here = 0;
+    if (POOL) {
+        pn = (int)fdiv((unsigned)tq, a.div_ptpi);
+        const int ti = tq - pn * a.pool_tpi;
+        q0 = pn * a.H * a.W + ti * a.pool_rpt * a.W;
+        rows_here = a.H - ti * a.pool_rpt < a.pool_rpt ? a.H - ti * a.pool_rpt : a.pool_rpt;
+        ph0 = (ti * a.pool_rpt) >> 1;
+    }
     const int ncs = a.C >> 6;                            // 64-channel chunks (9 tap slabs each)
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
@@ -713,7 +775,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     }
     wait_vmcnt<0>();                                    // the trailing (zero-fill) pieces must land before the image overwrites LDS
     block_barrier();
-    epilogue_bf16<PT, QT, NTHR, PI, QI>(a, smem, acc, p0, q0, prow0, qrow0, tid);
+    epilogue_bf16<PT, QT, NTHR, PI, QI, false, POOL>(a, smem, acc, p0, q0, prow0, qrow0, tid, pn, ph0, rows_here);
 }
 
 // sum of the split-K partial tiles (fixed order -> deterministic) + the epilogue of epilogue_bf16, 8 channels per thread
@@ -1825,6 +1887,20 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     const int PT = a.K <= 64 ? 64 : 128;
     a.tiles_p = ceil_div(a.K, PT);
     a.tiles_q = ceil_div(a.M, 256);
+    if (a.pool_mode) {                                   // the fused-pool variants (the caller checked gather_v6_pool_variant)
+        const int pv = gather_v6_pool_variant(a, ODTK_BF16, ODTK_BF16);
+        if (pv == 0) return ODTK_ERR_ARG;
+        a.pool_rpt = pv == 1 ? 2 : 4;
+        a.pool_tpi = ceil_div(a.H, a.pool_rpt);
+        a.div_ptpi = make_fastdiv((unsigned)a.pool_tpi);
+        a.div_wp = make_fastdiv((unsigned)((a.W + 1) / 2));
+        a.tiles_q = a.N * a.pool_tpi;
+        a.ksplit = -1;
+        const int grid_p = a.tiles_q * a.tiles_p;
+        if (pv == 1) hipLaunchKernelGGL((conv_gather_v6_kernel<20, false, 4, 9, 2, 2, 5, true>), dim3(grid_p), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v6_kernel<15, false, 2, 4, 2, 2, 5, true>), dim3(grid_p), dim3(256), 0, st, a);
+        return 0;
+    }
     const int tiles = a.tiles_p * a.tiles_q;
     const int nk = ceil_div(a.Kdim, 64);
     // split-K: few tiles with a long k loop leave most CUs idle and run at DMA latency; give every tile
@@ -1920,6 +1996,19 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     return 0;
 }
 
+// Raster-run halo kernel with the 2x2 pool in its epilogue (odtk_conv2d_fwd_pool2x2, round 4): 3x3 / stride 1 / SAME forward layers on C % 64 == 0 whose map
+// width lets whole row pairs fill a 320-pixel tile -- 1 = rows of 144..159 pixels (two rows per tile: conv2_2 + pool2 at 150 x 150), 2 = rows of 64..79 pixels
+// (four rows: conv3_3 + pool3 at 75 x 75; odd sizes pool with clipped windows).  0 = not covered.
+int gather_v6_pool_variant(const GatherArgs& a, int dtype, int out_dtype) {
+    if (!gather_v3_supported(a, dtype, out_dtype)) return 0;
+    if (!(a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 && a.dil == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo &&
+          a.Kdim == 9 * a.C && a.K % 8 == 0 && a.K > 64 && !a.accumulate && !a.mask && a.H >= 2)) return 0;
+    if (a.dbg & 65536) return 0;
+    if (a.W >= 144 && a.W <= 159) return 1;
+    if (a.W >= 64 && a.W <= 79) return 2;
+    return 0;
+}
+
 bool gather_c64_supported(const GatherArgs& a, int dtype, int out_dtype) {
     return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && a.C == 64 && a.ldx == 64 && a.K == 64 && a.R == 3 && a.S == 3 &&
            a.dil == 1 && a.ostride == 1 && a.idiv == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo &&
@@ -1960,6 +2049,9 @@ int launch_gather_c8(GatherArgs& a, hipStream_t st) {
     return 0;
 }
 
+static bool g_wgrad_deterministic = false;
+void set_wgrad_deterministic(bool on) { g_wgrad_deterministic = on; }
+
 bool wgrad_c64_supported(const WgradArgs& a, int dtype) {
     if (!(dtype == ODTK_BF16 && a.C % 64 == 0 && a.K % 64 == 0 && a.C >= 64 && a.K >= 64 && a.ldx >= a.C && a.ldx % 8 == 0 && a.lddy >= a.K && a.lddy % 8 == 0 &&
           a.R == 3 && a.S == 3 && a.dil == 1 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo && a.RSC == 9 * a.C &&
@@ -1969,7 +2061,7 @@ bool wgrad_c64_supported(const WgradArgs& a, int dtype) {
     // Round 4: one (64 x 64) block pair of dW per workgroup for the wide, large maps whose 8 x 32-pixel tiles waste little -- conv2_1 / conv2_2 at 150 x 150
     // (5 x 19 tiles per image: 94 %): 161 -> 1xx us and 273 -> 2xx us against the 8-wave gather kernel (one x slab per tap there, one halo patch per tile here).
     // Narrow maps (W = 75: 78 %, W = 38: 59 %) stay on the generic kernels; dbg bit 17 = off (A/B).
-    if (a.dbg & (1 << 17)) return false;
+    if ((a.dbg & (1 << 17)) || g_wgrad_deterministic) return false;      // (deterministic mode: the split-reduce kernels; this one flushes by float atomics)
     const int npairs = (a.C / 64) * (a.K / 64);
     if (a.dbg & (1 << 15)) return npairs <= 16;                 // tests: the block-pair path on small / ragged problems too
     const double eff = (double)a.W / (32.0 * ceil_div(a.W, 32)) * (double)a.H / (8.0 * ceil_div(a.H, 8));
@@ -2251,8 +2343,6 @@ __global__ void __launch_bounds__(256) conv_wgrad_v8_kernel(const WgradArgs a) {
 // run.  The default stays float atomics into dw: measured on the SSD300 step at batch 32, same box, the split-reduce costs
 // 2.5-2.7 % (3 210 | 3 186 against 3 292 | 3 284 images/s): it moves splits x |dw| bytes twice (~700 MB per step) where the
 // atomics, ~40 us per 256 x 256-tile launch as they are, move them once.
-static bool g_wgrad_deterministic = false;
-void set_wgrad_deterministic(bool on) { g_wgrad_deterministic = on; }
 static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots) {
     a.ws = nullptr; a.bws = nullptr; a.nsplit = splits; a.nbslot = bias_slots;
     if (splits < 2 || !g_wgrad_deterministic) return 0;

@@ -442,6 +442,9 @@ class SSD300:
             for step in self.vgg_plan:
                 if step[0] == 'pool' and step[1] in self.pool_idx and step[2] != 'conv4_3' and step[2] in self.desc and \
                         ops.conv2d_fwd_pool2x2_fused(self.desc[step[2]]):
+                    # (round 4: conv2_2 + pool2 and conv3_3 + pool3 in the raster-run halo kernel; config key 'fuse_pool_halo' = False keeps only conv1_2 + pool1, A/B)
+                    if self.convs[step[2]].cin != 64 and not bool(self.config.get('fuse_pool_halo', True)):
+                        continue
                     self.fused_pool[step[2]] = step[1]
         self.zbuf, self.bnsave = {}, {}
         max_ws = 0

@@ -896,6 +896,60 @@ def test_conv_relu_pool2x2_fused_equals_conv_then_pool(geom, dev):
         assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("geom", [(2, 150, 150, 64, 128), (2, 150, 150, 128, 128), (3, 75, 75, 128, 256), (1, 64, 64, 64, 200), (2, 13, 79, 64, 136),
+                                  (1, 3, 158, 64, 128), (2, 6, 144, 192, 72), (32, 150, 150, 128, 128), (32, 75, 75, 256, 256)])
+def test_conv_relu_pool2x2_fused_in_the_raster_run_halo_kernel(geom, dev):
+    """odtk_conv2d_fwd_pool2x2 on the layers the round-4 variant of the raster-run halo kernel covers (C % 64 == 0, rows of 64..79 or 144..159 pixels: conv2_2 +
+    pool2 and conv3_3 + pool3 of SSD300.py:219-252): tiles of whole row pairs, pooled in the epilogue.  Pooled map, recorded arg-max and (when kept) the
+    un-pooled map are BIT-identical to conv + pool as two launches -- same slab order per output, same rounding, first maximum in scan order -- with windows
+    that hang over the right / bottom edge (75 x 75 -> 38 x 38), a last tile of fewer rows (H = 75: 18 x 4 + 3; H = 3: 2 + 1), a ragged channel tile and two
+    channel tiles; the last two are the SSD300 layers at batch 32."""
+    ops = _ops()
+    N, H, W, C_, K = geom
+    g = torch.Generator().manual_seed(H * 1000 + W + K)
+    Kp = ops.pad_to(K, 8)
+    x = to_rows(torch.randn(N, H, W, C_, generator=g), C_, torch.bfloat16, dev)
+    w = (torch.randn(K, 3, 3, C_, generator=g) * (0.6 / math.sqrt(9 * C_))).to(torch.bfloat16).to(dev).reshape(-1).contiguous()
+    b = (torch.randn(K, generator=g) * 0.1).to(dev)
+    d = ops.conv_desc(N, H, W, C_, C_, K, Kp, 3, 1, 1)
+    assert ops.conv2d_fwd_pool2x2_fused(d)
+    Hp, Wp = (H + 1) // 2, (W + 1) // 2
+    nchunk = N * Hp * Wp * (K // 8)
+    y_ref = torch.zeros(N * H * W, Kp, dtype=torch.bfloat16, device=dev)
+    p_ref = torch.zeros(N * Hp * Wp, Kp, dtype=torch.bfloat16, device=dev)
+    i_ref = torch.zeros(nchunk, dtype=torch.int16, device=dev)
+    ops.conv2d_fwd(d, x, w, b, y_ref, True)
+    split_k = 'splitk' in ops.conv_last_kernel()               # small problems: the stand-alone convolution sums split-K partials -- another order, last-bit differences
+    res = {}
+    for keep in (True, False):
+        y = torch.full((N * H * W, Kp), 7.0, dtype=torch.bfloat16, device=dev) if keep else None
+        p = torch.zeros(N * Hp * Wp, Kp, dtype=torch.bfloat16, device=dev)
+        i = torch.full((nchunk,), -1, dtype=torch.int16, device=dev)
+        ops.conv2d_fwd_pool2x2(d, x, w, b, y, True, p, i)
+        assert ops.conv_last_kernel() == 'conv_gather_v6_kernel'
+        torch.cuda.synchronize()
+        res[keep] = (y, p, i)
+    y, p, i = res[True]
+    if split_k:
+        assert float((y.float() - y_ref.float()).abs().max()) <= 2 ** -7 * float(y_ref.float().abs().max())
+    else:
+        assert torch.equal(y, y_ref)                              # same slab order per output element, same rounding: bit-identical
+    ops.maxpool2x2_fwd_idx(y, p_ref, i_ref, N, H, W, K, Kp, Hp, Wp)          # the pool kernel on the fused launch's own un-pooled map
+    torch.cuda.synchronize()
+    if not torch.equal(p[:, :K], p_ref[:, :K]):
+        bad = (p[:, :K] != p_ref[:, :K]).nonzero()
+        raise AssertionError(f'pooled map differs: {bad.shape[0]} elements, first {bad[:6].tolist()}')
+    assert torch.equal(i, i_ref), 'arg-max codes differ'
+    assert torch.equal(res[False][1], p) and torch.equal(res[False][2], i), 'without the un-pooled output: other results'
+    if N <= 3:                                                # ... and the pair itself against plain torch
+        xr = x.float().cpu().reshape(N, H, W, C_)
+        wr = w.float().cpu().reshape(K, 3, 3, C_)
+        conv = torch.relu(_ref_conv(xr, wr, b.cpu(), 1, 1))
+        ref = F.max_pool2d(F.pad(conv.permute(0, 3, 1, 2), (0, 2 * Wp - W, 0, 2 * Hp - H), value=float('-inf')), 2, 2).permute(0, 2, 3, 1)
+        got = from_rows(p_ref, N, Hp, Wp, K)
+        assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
 def test_conv_pool2x2_unfused_shapes_run_as_two_launches(dev):
     """a shape the fused kernel does not cover (128 channels) goes through conv + pool inside the same entry point; without the un-pooled buffer it is
     refused loudly"""

@@ -102,6 +102,15 @@ int odtk_conv2d_fwd_pool2x2(const odtk_conv_desc* d, const void* x, const void* 
                             void* y_pool, int ld_pool, void* idx, void* stream);
 int odtk_conv2d_fwd_pool2x2_fused(const odtk_conv_desc* d);
 
+/* ReLU mask as SIGN BITS (round 4).  tf.nn.relu's gradient (SSD300.py:199-200 behind conv1_1) needs one bit per activation; conv1_2's input-gradient
+ * pass read the whole 369-MB bf16 activation of batch 32 for it.  odtk_conv2d_fwd_bits = odtk_conv2d_fwd that also writes relu_bits [M][ldy / 8] bytes
+ * (bit e of byte (m, j) = y[m][8 j + e] > 0); odtk_conv2d_dgrad_bits = odtk_conv2d_dgrad masked by such bits instead of relu_src.  Only the kernel pair
+ * first layer (3(8) -> 64) -> 64 -> 64 halo kernel implements them: odtk_conv2d_relu_bits_supported(producer, consumer, consumer's lddy) != 0;
+ * ODTK_ERR_ARG otherwise. */
+int odtk_conv2d_relu_bits_supported(const odtk_conv_desc* producer, const odtk_conv_desc* consumer, int consumer_lddy);
+int odtk_conv2d_fwd_bits(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu, void* relu_bits, void* stream);
+int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t, const void* relu_bits, void* dx, int accumulate, void* stream);
+
 /* dx[n,h,w,c] (+)= sum_{r,s,k} dy[n,ho,wo,k] * w[k,r,s,c]   (transposed conv of the fwd op)
  * w_t is the dgrad-layout filter produced by odtk_filter_to_dgrad: [C][R][S][Kp]
  * with taps flipped and Kp = dy pitch channels.  If relu_src != NULL the result is

@@ -51,6 +51,9 @@ SIGNATURES = {
     "odtk_conv2d_fwd_pool2x2": (_i, [_cd, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "odtk_conv2d_fwd_pool2x2_fused": (_i, [_cd]),
     "odtk_conv2d_dgrad": (_i, [_cd, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "odtk_conv2d_relu_bits_supported": (_i, [_cd, _cd, _i]),
+    "odtk_conv2d_fwd_bits": (_i, [_cd, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "odtk_conv2d_dgrad_bits": (_i, [_cd, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "odtk_conv2d_wgrad": (_i, [_cd, _vp, _vp, _i, _vp, _vp, _vp]),
     "odtk_filter_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "odtk_filter_prepare_batched": (_i, [_vp, _i, _i, _i, _vp]),

@@ -953,15 +953,8 @@ extern "C" int odtk_conv2d_fwd_pool2x2(const odtk_conv_desc* d, const void* x, c
     return odtk_maxpool_fwd(y, y_pool, d->N, d->Ho, d->Wo, d->K, d->ldy, Hp, Wp, 2, 2, 0, 0, d->out_dtype, stream);
 }
 
-extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t,
-                                 const void* relu_src, void* dx, int accumulate, void* stream) {
-    if (int e = check_desc(d)) return e;
-    ODTK_REQUIRE(dy && w_t && dx, "conv2d_dgrad: null pointer");
-    const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
-    ODTK_REQUIRE(lddy % kch == 0 && lddy >= d->K, "conv2d_dgrad: lddy=%d must be a multiple of %d", lddy, kch);
-    GatherArgs a;
+static void dgrad_args(GatherArgs& a, const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t, const void* relu_src, void* dx, int accumulate) {
     memset(&a, 0, sizeof(a));
-    // the "input" of this conv is dy [N][Ho][Wo][lddy], its "output" is dx [N][H][W][C]
     a.x = (const char*)dy; a.w = (const char*)w_t; a.bias = nullptr; a.mask = (const char*)relu_src; a.y = (char*)dx;
     a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.C = lddy; a.ldx = lddy;
     a.Ho = d->H; a.Wo = d->W; a.K = d->C; a.ldy = d->ldx; a.ldmask = d->ldx;
@@ -971,6 +964,51 @@ extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int ld
     a.idiv = d->stride;
     a.M = d->N * d->H * d->W; a.Kdim = d->R * d->S * lddy; a.ldw = a.Kdim;
     a.relu = 0; a.accumulate = accumulate;
+}
+
+extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t,
+                                 const void* relu_src, void* dx, int accumulate, void* stream) {
+    if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(dy && w_t && dx, "conv2d_dgrad: null pointer");
+    const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
+    ODTK_REQUIRE(lddy % kch == 0 && lddy >= d->K, "conv2d_dgrad: lddy=%d must be a multiple of %d", lddy, kch);
+    GatherArgs a;
+    dgrad_args(a, d, dy, lddy, w_t, relu_src, dx, accumulate);      // the "input" of this conv is dy [N][Ho][Wo][lddy], its "output" is dx [N][H][W][C]
+    return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
+}
+
+// ---- ReLU mask as sign bits between a producer's forward pass and the consumer's input-gradient pass (conv1_1 -> conv1_2 of SSD300.py:193-208)
+extern "C" int odtk_conv2d_relu_bits_supported(const odtk_conv_desc* producer, const odtk_conv_desc* consumer, int consumer_lddy) {
+    if (check_desc(producer) || check_desc(consumer)) return 0;
+    if (g_force_regstage || g_v3_mode == 1 || (g_dbg & 2048)) return 0;
+    GatherArgs f, b;
+    fwd_args(f, producer, nullptr, nullptr, nullptr, nullptr, 1);
+    dgrad_args(b, consumer, nullptr, consumer_lddy, nullptr, nullptr, nullptr, 0);
+    return (gather_c8_supported(f, producer->dtype, producer->out_dtype) && gather_c64_supported(b, consumer->dtype, consumer->out_dtype) &&
+            producer->ldy == consumer->ldx && producer->N == consumer->N && producer->Ho == consumer->H && producer->Wo == consumer->W) ? 1 : 0;
+}
+
+extern "C" int odtk_conv2d_fwd_bits(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu, void* relu_bits, void* stream) {
+    if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(x && w && y && relu_bits, "conv2d_fwd_bits: null pointer");
+    GatherArgs a;
+    fwd_args(a, d, x, w, bias, y, relu);
+    ODTK_REQUIRE(!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && gather_c8_supported(a, d->dtype, d->out_dtype),
+                 "conv2d_fwd_bits: only the first-layer kernel writes sign bits (odtk_conv2d_relu_bits_supported)");
+    a.ybits = (unsigned char*)relu_bits;
+    return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t, const void* relu_bits, void* dx, int accumulate,
+                                      void* stream) {
+    if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(dy && w_t && dx && relu_bits, "conv2d_dgrad_bits: null pointer");
+    ODTK_REQUIRE(lddy % 8 == 0 && lddy >= d->K, "conv2d_dgrad_bits: lddy=%d must be a multiple of 8", lddy);
+    GatherArgs a;
+    dgrad_args(a, d, dy, lddy, w_t, nullptr, dx, accumulate);
+    ODTK_REQUIRE(!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && gather_c64_supported(a, d->dtype, d->out_dtype),
+                 "conv2d_dgrad_bits: only the 64 -> 64 halo kernel reads sign bits (odtk_conv2d_relu_bits_supported)");
+    a.mask_bits = (const unsigned char*)relu_bits;
     return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
 }
 

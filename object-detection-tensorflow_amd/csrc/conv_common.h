@@ -159,6 +159,10 @@ struct GatherArgs {
     // 256 MB of memory-side cache: a kernel that starts where its producer STOPPED finds the producer's last ~2/3 still cached.  Forward: conv1_1 walks up,
     // conv1_2 walks down; backward: pool1's gradient is written upwards, conv1_2's filter gradient walks down, its input gradient up, conv1_1's filter gradient down.
     int rev;
+    // ReLU mask as sign bits (round 4; the 3(8) -> 64 first-layer kernel writes them, the 64 -> 64 halo kernel's input-gradient pass reads them): one byte per
+    // (pixel, 16-byte chunk), bit e = channel 8 * chunk + e of the activation is > 0.  conv1_2's dgrad read the 369-MB activation only for these signs.
+    unsigned char* ybits;            // written beside y (forward), [M][ldy / 8]
+    const unsigned char* mask_bits;  // read instead of `mask` (input gradient), [M][ldmask / 8]
 };
 
 struct WgradArgs {
@@ -243,6 +247,22 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 // fused ReLU backward on packed bf16: keep u's halves where the matching half of m is > 0
+// the same from the sign bits of the pair (bit 0 = low half, bit 1 = high half)
+__device__ __forceinline__ unsigned keep_where_bits(unsigned u, unsigned b2) {
+    const unsigned lo = (0u - (b2 & 1u)) & 0xffffu, hi = (0u - ((b2 >> 1) & 1u)) & 0xffff0000u;
+    return u & (lo | hi);
+}
+// sign bits of a 16-byte chunk of bf16 values: bit e = element e > 0
+__device__ __forceinline__ unsigned pos_bits(const uint4& v) {
+    const unsigned* u = reinterpret_cast<const unsigned*>(&v);
+    unsigned b = 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        b |= ((int)(u[h] << 16) > 0 ? 1u : 0u) << (2 * h);
+        b |= ((int)(u[h] & 0xffff0000u) > 0 ? 1u : 0u) << (2 * h + 1);
+    }
+    return b;
+}
 __device__ __forceinline__ unsigned keep_where_pos(unsigned u, unsigned m) {
     const unsigned lo = ((int)(m << 16) > 0) ? (u & 0xffffu) : 0u;
     const unsigned hi = ((int)(m & 0xffff0000u) > 0) ? (u & 0xffff0000u) : 0u;

@@ -1205,7 +1205,15 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
                 issue_piece(nn, nh0, nw0, 2 * (step >> 2) + 1, buf ^ 1, has_next && !abl_dma);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (step == 24 && a.mask) {
+            if (step == 24 && a.mask_bits) {            // ReLU mask as sign bits: one byte per chunk instead of its 16 bytes (round 4)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int idx = r * 64 + lane;
+                    const int pxl = idx >> 3, ch = idx & 7;
+                    const int h = ch0 + 2 * wave + (pxl >> 5), w = cw0 + (pxl & 31);
+                    if (h < a.H && w < a.W) mk[r].x = a.mask_bits[((size_t)(cn * a.H + h) * a.W + w) * 8 + ch];
+                }
+            } else if (step == 24 && a.mask) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int idx = r * 64 + lane;
@@ -1264,7 +1272,11 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
                 uint4 v = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
                 if (h < a.H && w < a.W) {
                     const size_t m = (size_t)(cn * a.H + h) * a.W + w;
-                    if (a.mask) post_chunk(v, false, false, mk[r], true, mk[r]);
+                    if (a.mask_bits) {
+                        unsigned* u = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) u[q] = keep_where_bits(u[q], mk[r].x >> (2 * q));
+                    } else if (a.mask) post_chunk(v, false, false, mk[r], true, mk[r]);
                     *reinterpret_cast<uint4*>(a.y + (m * a.ldy + ch * 8) * 2) = v;
                 }
             }
@@ -1458,8 +1470,11 @@ __global__ void __launch_bounds__(256) conv3x3_c8k64_kernel(const GatherArgs a, 
             const int pxl = idx >> 3, ch = idx & 7;
             const int h = ch0 + 2 * wave + (pxl >> 5), w = cw0 + (pxl & 31);
             const uint4 v = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
-            if (h < a.H && w < a.W)
-                *reinterpret_cast<uint4*>(a.y + (((size_t)(cn * a.H + h) * a.W + w) * a.ldy + ch * 8) * 2) = v;
+            if (h < a.H && w < a.W) {
+                const size_t m = (size_t)(cn * a.H + h) * a.W + w;
+                *reinterpret_cast<uint4*>(a.y + (m * a.ldy + ch * 8) * 2) = v;
+                if (a.ybits) a.ybits[m * 8 + ch] = (unsigned char)pos_bits(v);       // 64 consecutive bytes per wave instruction; the kernel is bound by its 128 B / pixel
+            }
         }
         asm volatile("" ::: "memory");
     }

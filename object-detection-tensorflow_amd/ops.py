@@ -98,6 +98,19 @@ def conv2d_dgrad(d: ConvDesc, dy, lddy: int, w_t, relu_src, dx, accumulate: bool
          _stream())
 
 
+def conv2d_relu_bits_supported(producer: ConvDesc, consumer: ConvDesc, consumer_lddy: int) -> bool:
+    """ReLU mask as sign bits between `producer`'s forward pass and `consumer`'s input-gradient pass (include/odtk.h)"""
+    return bool(_lib.load().odtk_conv2d_relu_bits_supported(C.byref(producer), C.byref(consumer), int(consumer_lddy)))
+
+
+def conv2d_fwd_bits(d: ConvDesc, x, w, bias, y, relu: bool, relu_bits):
+    call("odtk_conv2d_fwd_bits", C.byref(d), _p(x), _p(w), _p(bias), _p(y), int(relu), _p(relu_bits), _stream())
+
+
+def conv2d_dgrad_bits(d: ConvDesc, dy, lddy: int, w_t, relu_bits, dx, accumulate: bool):
+    call("odtk_conv2d_dgrad_bits", C.byref(d), _p(dy), int(lddy), _p(w_t), _p(relu_bits), _p(dx), int(accumulate), _stream())
+
+
 def conv2d_wgrad(d: ConvDesc, x, dy, lddy: int, dw, dbias=None):
     call("odtk_conv2d_wgrad", C.byref(d), _p(x), _p(dy), int(lddy), _p(dw), _p(dbias), _stream())
 

@@ -488,6 +488,13 @@ class SSD300:
             d = self.desc[name]
             kp = ops.pad_to(c.cout, 8) if name.startswith('pred') else c.cout
             self.wt[name] = torch.zeros(d.C * c.k * c.k * kp, dtype=dt, device=dev)
+        # ReLU masks as sign bits (round 4): conv1_2's input-gradient pass reads one byte per 16-byte chunk of conv1_1's activation instead of the chunk
+        # (369 MB at batch 32); written by conv1_1's forward kernel.  Config key 'relu_bits' (default on), where the kernel pair supports it.
+        self.relu_bits = {}
+        if self.mode == 'train' and bool(self.config.get('relu_bits', True)) and 'conv1_1' in self.desc and 'conv1_2' in self.desc and \
+                ops.conv2d_relu_bits_supported(self.desc['conv1_1'], self.desc['conv1_2'], self.acts['conv1_2'].ld):
+            a1 = self.acts['conv1_1']
+            self.relu_bits['conv1_1'] = torch.zeros(a1.M * (a1.ld // 8), dtype=torch.uint8, device=dev)
         # box side
         fs, nas, hw = prior_spec(self.INPUT_SIZE, self.prior_scales(), self.ASPECTS, self.FEATURE_SIZES, self.ANCHORS_PER_CELL)
         self.pri = ops.ssd_priors(self.INPUT_SIZE, fs, nas, hw, dev)       # y1x1, y2x2, yx, hw, nmsbox
@@ -591,6 +598,10 @@ class SSD300:
                     pname = self.fused_pool[name]
                     ops.conv2d_fwd_pool2x2(self.desc[name], a[prev].t, self._wslice(name + '.w', self.Pc), self.param(name + '.b'),
                                            a[name].t if self.keep_unpooled else None, True, a[pname].t, self.pool_idx[pname])
+                    continue
+                if training and name in self.relu_bits:
+                    ops.conv2d_fwd_bits(self.desc[name], a[prev].t, self._wslice(name + '.w', self.Pc), self.param(name + '.b'), a[name].t, True,
+                                        self.relu_bits[name])
                     continue
                 self._conv_fwd(name, a[prev], a[name], self.param(name + '.b'), True)
             else:
@@ -795,7 +806,9 @@ class SSD300:
                 _, name, prev = step
                 x, y = a[prev], a[name]
                 self._conv_bwd_params(name, x, y.g, y.ld)
-                if name != 'conv1_1':
+                if name != 'conv1_1' and prev in self.relu_bits:
+                    ops.conv2d_dgrad_bits(self.desc[name], y.g, y.ld, self.wt[name], self.relu_bits[prev], x.g, False)
+                elif name != 'conv1_1':
                     ops.conv2d_dgrad(self.desc[name], y.g, y.ld, self.wt[name], x.t, x.g, False)
                 if name in ('conv5_1', 'conv4_1', 'conv3_1', 'conv2_1', 'conv1_1'):
                     self._phase(f'bwd: {name[:5]} block done')

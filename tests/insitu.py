@@ -27,6 +27,7 @@ import mock_ops  # noqa: E402
 # output parameters of every launch (names of tests/mock_ops.py's signatures); 'loss_parts:K' = only column(s) K of that tensor
 OUTPUTS = {
     'conv2d_fwd': ['y'], 'conv2d_fwd_pool2x2': ['y', 'y_pool'], 'conv2d_dgrad': ['dx'], 'conv2d_wgrad': ['dw', 'dbias'],
+    'conv2d_fwd_bits': ['y'], 'conv2d_dgrad_bits': ['dx'],
     'preprocess': ['x'], 'preprocess_norm': ['x'],
     'bn_fwd': ['mmean', 'mvar', 'save_mean', 'save_invstd', 'y'], 'bn_bwd': ['dz', 'dgamma', 'dbeta'],
     'gn_fwd': ['y', 'save'], 'gn_bwd': ['dx', 'dgamma', 'dbeta'],
@@ -51,7 +52,7 @@ OUTPUTS = {
 ON_CPU = {'ssd_loss', 'yolov3_loss', 'yolov2_loss', 'retina_loss', 'fcos_loss', 'centernet_loss', 'refinedet_loss', 'lhrcnn_rpn_loss'}
 # launches that are not shadowed: the mocked box-side front ends do nothing (the mocked loss matches / mines by itself through the oracle -- the
 # real kernels' indices are compared bit for bit by the kernel-level tests), workspaces, scratch selection, constant tables
-PASS = {'conv2d_fwd_pool2x2_fused', 'ssd_match', 'softmax_ce_const', 'retina_match', 'nms_batched', 'scratch_slot', 'ssd_priors', 'retina_anchors', 'gn_workspace', 'fcos_workspace',
+PASS = {'conv2d_fwd_pool2x2_fused', 'conv2d_relu_bits_supported', 'ssd_match', 'softmax_ce_const', 'retina_match', 'nms_batched', 'scratch_slot', 'ssd_priors', 'retina_anchors', 'gn_workspace', 'fcos_workspace',
         'yolov3_workspace', 'retina_match_workspace', 'centernet_workspace', 'yolov3_decode_candidates', 'fcos_decode_candidates', 'retina_decode',
         'refinedet_decode', 'centernet_decode', 'yolov2_decode_candidates', 'lhrcnn_match', 'lhrcnn_rpn_decode', 'lhrcnn_gather_rois', 'lhrcnn_rcnn_decode'}
 WHOLE_STORAGE_MAX = 1 << 30
@@ -313,7 +314,7 @@ def default_tol(engine_dtype):
     across a rounding boundary (measured 4-7e-5); a bf16 buffer that is ACCUMULATED into is rounded twice by the engine and once by the restatement
     (measured 2.8e-3 = one bf16 rounding of the first addend).  f32 engine: accumulation order only, f32 atomics over up to 2.5 M pixels included
     (measured <= 1e-5).  Box-side losses and their gradients against the oracles on the engine's own logits: <= 1e-6 measured."""
-    twice = ('conv2d_dgrad', 'add2d', 'relu_bwd', 'upsample2x_bwd', 'resize_bilinear_fwd', 'resize_bilinear_bwd', 'copy_channels', 'l2norm_bwd', 'gn_bwd',
+    twice = ('conv2d_dgrad', 'conv2d_dgrad_bits', 'add2d', 'relu_bwd', 'upsample2x_bwd', 'resize_bilinear_fwd', 'resize_bilinear_bwd', 'copy_channels', 'l2norm_bwd', 'gn_bwd',
              'bn_bwd', 'maxpool_bwd', 'resize_bilinear2_bwd', 'resize_bilinear2_fwd')
 
     def tol(row):

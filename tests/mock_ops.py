@@ -70,6 +70,27 @@ def conv2d_fwd_pool2x2_fused(d):
     return True
 
 
+def conv2d_relu_bits_supported(producer, consumer, consumer_lddy):
+    return producer.K == 64 and consumer.C == 64 and consumer.K == 64 and consumer.R == 3 and producer.C <= 8
+
+
+def _pack_bits(y):
+    """[M][ld] activation -> [M][ld / 8] bytes, bit e = element 8 j + e > 0"""
+    m = (y.float() > 0).reshape(y.shape[0], -1, 8).to(torch.int32)
+    return (m * (2 ** torch.arange(8, dtype=torch.int32, device=y.device))).sum(-1).to(torch.uint8).reshape(-1)
+
+
+def conv2d_fwd_bits(d, x, w, bias, y, relu, relu_bits):
+    conv2d_fwd(d, x, w, bias, y, relu)
+    relu_bits.copy_(_pack_bits(y))
+
+
+def conv2d_dgrad_bits(d, dy, lddy, w_t, relu_bits, dx, accumulate):
+    b = relu_bits.reshape(dx.shape[0], -1).to(torch.int32)
+    src = ((b.unsqueeze(-1) >> torch.arange(8, dtype=torch.int32, device=b.device)) & 1).reshape(dx.shape[0], -1).to(dx.dtype)
+    conv2d_dgrad(d, dy, lddy, w_t, src, dx, accumulate)
+
+
 def conv2d_dgrad(d, dy, lddy, w_t, relu_src, dx, accumulate):
     Kp = lddy
     wt = w_t.float().reshape(d.C, d.R * d.S, Kp)

@@ -950,6 +950,45 @@ def test_conv_relu_pool2x2_fused_in_the_raster_run_halo_kernel(geom, dev):
         assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("geom", [(2, 40, 64), (3, 37, 45), (32, 300, 300)])
+def test_relu_mask_as_sign_bits_first_layer_pair(geom, dev):
+    """odtk_conv2d_fwd_bits / odtk_conv2d_dgrad_bits (round 4): conv1_1's forward kernel writes one byte of signs per 16-byte chunk beside its activation,
+    conv1_2's input-gradient kernel masks with those bytes -- the activation and the masked gradient are BIT-identical to odtk_conv2d_fwd /
+    odtk_conv2d_dgrad(relu_src = the activation), the bytes equal (y > 0) packed; ragged tiles, and the SSD300 layers at batch 32"""
+    ops = _ops()
+    N, H, W = geom
+    g = torch.Generator().manual_seed(H * 100 + W)
+    d1 = ops.conv_desc(N, H, W, 8, 8, 64, 64, 3, 1, 1)
+    d2 = ops.conv_desc(N, H, W, 64, 64, 64, 64, 3, 1, 1)
+    assert ops.conv2d_relu_bits_supported(d1, d2, 64)
+    x = torch.zeros(N * H * W, 8, dtype=torch.bfloat16, device=dev)
+    x[:, :3] = torch.randn(N * H * W, 3, generator=g).to(torch.bfloat16).to(dev)
+    w1 = (torch.randn(64, 3, 3, 8, generator=g) * 0.2).to(torch.bfloat16).to(dev).reshape(-1).contiguous()
+    b1 = (torch.randn(64, generator=g) * 0.1).to(dev)
+    y_ref = torch.zeros(N * H * W, 64, dtype=torch.bfloat16, device=dev)
+    y = torch.full_like(y_ref, 3.0)
+    bits = torch.full((N * H * W * 8,), 255, dtype=torch.uint8, device=dev)
+    ops.conv2d_fwd(d1, x, w1, b1, y_ref, True)
+    ops.conv2d_fwd_bits(d1, x, w1, b1, y, True, bits)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    want = ((y_ref.float() > 0).reshape(-1, 8).to(torch.int32) * (2 ** torch.arange(8, dtype=torch.int32, device=dev))).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    assert 0.2 < float((y_ref.float() > 0).float().mean()) < 0.8
+    w2 = (torch.randn(64, 3, 3, 64, generator=g) * 0.05)
+    wt = torch.empty(64 * 9 * 64, dtype=torch.bfloat16, device=dev)
+    ops.filter_prepare(w2.to(dev), 64, 3, 3, 64, 64, ops.BF16, None, wt)
+    dy = torch.randn(N * H * W, 64, generator=g).to(torch.bfloat16).to(dev)
+    dx_ref = torch.zeros(N * H * W, 64, dtype=torch.bfloat16, device=dev)
+    dx = torch.full_like(dx_ref, 5.0)
+    ops.conv2d_dgrad(d2, dy, 64, wt, y_ref, dx_ref, False)
+    assert ops.conv_last_kernel() == 'conv3x3_c64k64_kernel'
+    ops.conv2d_dgrad_bits(d2, dy, 64, wt, bits, dx, False)
+    assert ops.conv_last_kernel() == 'conv3x3_c64k64_kernel'
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+
+
 def test_conv_pool2x2_unfused_shapes_run_as_two_launches(dev):
     """a shape the fused kernel does not cover (128 channels) goes through conv + pool inside the same entry point; without the un-pooled buffer it is
     refused loudly"""

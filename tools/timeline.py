@@ -25,7 +25,7 @@ for f in files:
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']), r.get('Queue_Id', r.get('Stream_Id', '?')),
                          int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2].startswith('preprocess_kernel')]
+starts = [i for i, r in enumerate(rows) if r[2].startswith('preprocess')]
 assert len(starts) > back, f"only {len(starts)} steps in the trace"
 lo, hi = starts[-back - 1], starts[-back]
 step = rows[lo:hi]

@@ -569,6 +569,9 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 // (conv2_1's input gradient, 128 -> 64 channels at W = 150: it ran on the 8-wave gather kernel at 490 TFLOP/s).
 // (Round 4, measured and removed: a FOURTH filter stage where the patch leaves 16 KiB free -- conv4_x on an 11-group patch pair, the single-buffer variants of
 // W = 75 -- with slab kt + 3 issued and two slabs' pieces in flight across a barrier: bit-identical, 1-3 % SLOWER on every layer, profiles/r04k_*.)
+// (Round 4, measured and removed: a 128 x 128-tile instantiation -- four waves of 64 x 64, single-buffered 7-group patch, 76 KiB of LDS, <= 256 registers -- so that TWO
+// workgroups share a CU and fill each other's epilogue / prologue / barrier gaps: conv4_1 forward -8 %, conv4_2 -3..-4 %, conv6 forward -6 % in isolation, +10 % on
+// short launches, and 0.0 % on the step in the same-process A/B: profiles/r04t_*.)
 template <int NPP, bool DBUF, int G1, int G2, int WP = 2, int PI = 2, int QI = 4, bool POOL = false>
 __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a) {
     constexpr int PT = WP * PI * 32, QT = (4 / WP) * QI * 32, NTHR = 256;

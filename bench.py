@@ -63,7 +63,7 @@ class ConvTimer:
 
     def install(self):
         ops = self.ops
-        for kind in ('conv2d_fwd', 'conv2d_fwd_pool2x2', 'conv2d_dgrad', 'conv2d_wgrad'):
+        for kind in ('conv2d_fwd', 'conv2d_fwd_pool2x2', 'conv2d_dgrad', 'conv2d_wgrad', 'conv2d_fwd_x3', 'conv2d_dgrad_x3', 'conv2d_wgrad_x3'):
             self._orig[kind] = getattr(ops, kind)
             setattr(ops, kind, self._wrap(kind))
 
@@ -80,12 +80,13 @@ class ConvTimer:
             flops = 2.0 * d.N * d.Ho * d.Wo * k_alg * d.R * d.S * c_alg  # algorithmic: 2*M*Cout*R*S*Cin for each pass
             esz = 2 if d.dtype == 0 else 4
             # algorithmic HBM bytes: every operand once (x, y / dy, dx as bf16; filter as bf16, dW as f32)
-            abytes = (d.N * d.H * d.W * d.C + d.N * d.Ho * d.Wo * d.K) * esz + d.K * d.R * d.S * d.C * (4 if kind == 'conv2d_wgrad' else esz)
+            abytes = (d.N * d.H * d.W * d.C + d.N * d.Ho * d.Wo * d.K) * esz + d.K * d.R * d.S * d.C * (4 if kind.startswith('conv2d_wgrad') else esz)
             s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
             s.record()
             r = orig(d, *args)
             e.record()
             rkind = 'conv2d_fwd' if kind == 'conv2d_fwd_pool2x2' else kind      # conv + bias + ReLU + pool in one launch: the conv's FLOPs, its own time
+            rkind = rkind[:-3] if rkind.endswith('_x3') else rkind              # operand splitting: the call's whole time (split passes + gather + finish), the f32 conv's FLOPs
             self.records.append((rkind, self.ops.conv_last_kernel(), flops, s, e, abytes,
                                  (d.N, d.H, d.W, d.C, d.K, d.R, d.stride, d.dil)))
             return r
@@ -259,7 +260,7 @@ def main():
                     help="BASELINE.json's configuration: ssd300 = config 2 (the headline metric, the default); retinanet = config 3 (800x800, batch 16); "
                          'yolov3 = config 4 (416x416, 8 / GPU); fcos | centernet = config 5 (512x512, 16 / GPU) -- bench_configs.py')
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s)')
-    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32'], help='engine (default: the one the model class defaults to in training mode: bf16 for ssd300 / yolov3 / fcos / centernet, f32 for retinanet)')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f32x3'], help='engine (default: the one the model class defaults to in training mode: bf16 for ssd300 / yolov3 / fcos / centernet, f32 for retinanet)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region (the default at N = 1 since round 3)')
@@ -507,17 +508,20 @@ def bench_other(args, world, rank, local_rank):
     if rank == 0:
         value = B * world * args.steps / dt
         flops_step = BC.conv_flops_per_step(name, model)
-        peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
+        peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else (MFMA_PEAK_BF16 / 3 if args.dtype == 'f32x3' else MFMA_PEAK_F32)
         out = {'metric': BC.METRIC[name], 'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 2),
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
                'data': 'synthetic',
                'config': {'workload': BC.WORKLOAD[name].format(B=B), 'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                           'launch': 'hip-graph replay' if args.graph else 'eager', 'algorithmic_conv_gflop_per_image': round(flops_step / B / 1e9, 2),
-                          'engine_note': None if args.dtype == 'bf16' else 'f32 engine (the class default): exact-f32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s'}}
+                          'engine_note': None if args.dtype == 'bf16' else
+                          'f32 engine with operand splitting: every f32 product = three bf16 MFMA products (hi*hi + hi*lo + lo*hi), f32 accumulation; peak = bf16 dense / 3' if args.dtype == 'f32x3' else
+                          'f32 engine (the class default): exact-f32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s'}}
         if timer.records:
             rf = timer.roofline(ev_steps, peak, value / world * (flops_step / B) / peak)
             rf['measured_on'] = f'{ev_steps} eager steps right after the timed region (HIP events per conv launch on the launch stream; plain per-launch mean without the first)'
-            rf['peak_note'] = 'dense bf16 MFMA' if args.dtype == 'bf16' else 'f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)'
+            rf['peak_note'] = ('dense bf16 MFMA' if args.dtype == 'bf16' else 'dense bf16 MFMA / 3 (three bf16 products per f32 product)' if args.dtype == 'f32x3'
+                               else 'f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)')
             out['roofline'] = rf
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_other(name)

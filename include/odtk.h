@@ -111,6 +111,21 @@ int odtk_conv2d_relu_bits_supported(const odtk_conv_desc* producer, const odtk_c
 int odtk_conv2d_fwd_bits(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu, void* relu_bits, void* stream);
 int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t, const void* relu_bits, void* dx, int accumulate, void* stream);
 
+/* "x3" (round 4): the convolutions of an f32 model (RetinaNet's engine: its identity-free units do not survive bf16 operands, RetinaNet.py:594-643) on the bf16
+ * MFMA kernels by OPERAND SPLITTING -- a = a_hi + a_lo (two bf16), a b = a_hi b_hi + a_hi b_lo + a_lo b_hi + O(2^-16), accumulated in f32: one implicit GEMM with
+ * a three times longer reduction.  d is the F32 descriptor of the layer (x, y, dy, dx, dw all f32, the f32 engine's pitches); odtk_conv2d_x3_supported(d) != 0 for
+ * C % 8 == 0, ldx == C, stride 1 | 2; `scratch` = odtk_conv2d_x3_scratch_bytes(d) bytes (split operands + split-K partial tiles), caller-owned.
+ * odtk_filter_prepare_x3: w [K][R][S][C] f32 -> w3 [K][R][S][3 C] bf16 (per tap hi | lo | hi; forward) and wt3 [C][R][S][3 pad8(K)] (taps flipped; input
+ * gradient); either may be NULL.  fwd: y = conv(x, w) + bias (+ ReLU), pad columns zeroed.  dgrad: dx = transposed conv (no mask, no accumulate).  wgrad: dw (+)=
+ * filter gradient (float atomics into dw as odtk_conv2d_wgrad; the bias gradient is the caller's odtk_colsum of dy). */
+int odtk_conv2d_x3_supported(const odtk_conv_desc* d);
+long long odtk_conv2d_x3_scratch_bytes(const odtk_conv_desc* d);
+int odtk_filter_prepare_x3(const float* w, int K, int R, int S, int C, void* w3, void* wt3, void* stream);
+int odtk_conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const void* w3, const float* bias, float* y, int relu, void* scratch, long long scratch_bytes,
+                       void* stream);
+int odtk_conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, const void* wt3, float* dx, void* scratch, long long scratch_bytes, void* stream);
+int odtk_conv2d_wgrad_x3(const odtk_conv_desc* d, const float* x, const float* dy, int lddy, float* dw, void* scratch, long long scratch_bytes, void* stream);
+
 /* dx[n,h,w,c] (+)= sum_{r,s,k} dy[n,ho,wo,k] * w[k,r,s,c]   (transposed conv of the fwd op)
  * w_t is the dgrad-layout filter produced by odtk_filter_to_dgrad: [C][R][S][Kp]
  * with taps flipped and Kp = dy pitch channels.  If relu_src != NULL the result is

@@ -1012,6 +1012,115 @@ extern "C" int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, i
     return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
 }
 
+// ---- x3: the f32 engine's convolutions on the bf16 MFMA kernels by operand splitting (conv_v3.hip; include/odtk.h) -------------------------------------
+static inline int pad8(int v) { return (v + 7) / 8 * 8; }
+
+extern "C" int odtk_conv2d_x3_supported(const odtk_conv_desc* d) {
+    if (check_desc(d) || d->dtype != ODTK_F32 || d->out_dtype != ODTK_F32) return 0;
+    if (g_force_regstage || g_v3_mode == 1) return 0;
+    const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
+    const int ldk = pad8(d->K);
+    return (d->C % 8 == 0 && d->ldx == d->C && d->R * d->S <= 32 && (d->stride == 1 || (d->stride == 2 && d->dil == 1)) &&
+            Min * 3 * d->C * 2 < (1ll << 31) - (1ll << 21) && Mout * 3 * ldk * 2 < (1ll << 31) - (1ll << 21) &&
+            (long long)d->K * d->R * d->S * 3 * d->C * 2 < (1ll << 31) - (1ll << 21) && 3 * Min < (1ll << 31) && 3 * Mout < (1ll << 31) &&
+            Mout * d->ldy * 4 < (1ll << 31) && Min * d->ldx * 4 < (1ll << 31)) ? 1 : 0;
+}
+
+static void x3_fwd_args(GatherArgs& a, const odtk_conv_desc* d, const void* xs, const void* w3) {
+    odtk_conv_desc b = *d;
+    b.C = b.ldx = 3 * d->C;
+    fwd_args(a, &b, xs, w3, nullptr, nullptr, 0);
+    a.div_howo = make_fastdiv((unsigned)(a.Ho * a.Wo)); a.div_wo = make_fastdiv((unsigned)a.Wo);
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
+    a.w_bytes = (unsigned)((size_t)a.K * a.ldw * 2);
+}
+static void x3_dgrad_args(GatherArgs& a, const odtk_conv_desc* d, const void* dys, const void* wt3) {
+    dgrad_args(a, d, dys, 3 * pad8(d->K), wt3, nullptr, nullptr, 0);
+    a.div_howo = make_fastdiv((unsigned)(a.Ho * a.Wo)); a.div_wo = make_fastdiv((unsigned)a.Wo);
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
+    a.w_bytes = (unsigned)((size_t)a.K * a.ldw * 2);
+}
+
+extern "C" long long odtk_conv2d_x3_scratch_bytes(const odtk_conv_desc* d) {
+    if (!odtk_conv2d_x3_supported(d)) return 0;
+    const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
+    const int ldk = pad8(d->K);
+    GatherArgs f, b;
+    x3_fwd_args(f, d, nullptr, nullptr);
+    x3_dgrad_args(b, d, nullptr, nullptr);
+    const int kf = cv::gather_x3_ksplit(f), kb = cv::gather_x3_ksplit(b);
+    const long long fwd = Min * 3 * d->C * 2 + (kf > 1 ? (long long)kf * Mout * d->ldy * 4 : 0);
+    const long long bwd = Mout * 3 * ldk * 2 + (kb > 1 ? (long long)kb * Min * d->ldx * 4 : 0);
+    const long long wg = 3 * Min * d->C * 2 + 3 * Mout * ldk * 2;
+    long long m = fwd > bwd ? fwd : bwd;
+    m = m > wg ? m : wg;
+    return m + 4096;
+}
+
+extern "C" int odtk_filter_prepare_x3(const float* w, int K, int R, int S, int C, void* w3, void* wt3, void* stream) {
+    ODTK_REQUIRE(w && (w3 || wt3) && K > 0 && R > 0 && S > 0 && C > 0 && C % 8 == 0, "filter_prepare_x3: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (w3) cv::launch_split3_chan(w, (long long)K * R * S, C, C, w3, C, 2, st);              // [K][R][S][hi | lo | hi]
+    if (wt3) cv::launch_filter_dgrad_x3(w, K, R, S, C, pad8(K), wt3, st);                       // [C][R][S][hi | lo | hi of pad8(K)], taps flipped
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const void* w3, const float* bias, float* y, int relu, void* scratch,
+                                  long long scratch_bytes, void* stream) {
+    ODTK_REQUIRE(odtk_conv2d_x3_supported(d), "conv2d_fwd_x3: geometry not covered (odtk_conv2d_x3_supported)");
+    ODTK_REQUIRE(x && w3 && y && scratch && scratch_bytes >= odtk_conv2d_x3_scratch_bytes(d), "conv2d_fwd_x3: null pointer or scratch too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long long Min = (long long)d->N * d->H * d->W;
+    char* xs = (char*)scratch;
+    cv::launch_split3_chan(x, Min, d->C, d->ldx, xs, d->C, 4, st);                           // [hi | hi | lo]
+    GatherArgs a;
+    x3_fwd_args(a, d, xs, w3);
+    a.dbg = g_dbg; a.dbg2 = g_dbg2;
+    float* partials = (float*)(xs + ((Min * 3 * d->C * 2 + 255) / 256 * 256));
+    cv::launch_gather_x3(a, y, partials, bias, relu, st);
+    g_last_kernel = "conv_gather_v3_kernel<x3>";
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, const void* wt3, float* dx, void* scratch, long long scratch_bytes,
+                                    void* stream) {
+    ODTK_REQUIRE(odtk_conv2d_x3_supported(d), "conv2d_dgrad_x3: geometry not covered (odtk_conv2d_x3_supported)");
+    ODTK_REQUIRE(dy && wt3 && dx && scratch && lddy >= d->K && scratch_bytes >= odtk_conv2d_x3_scratch_bytes(d), "conv2d_dgrad_x3: null pointer or scratch too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long long Mout = (long long)d->N * d->Ho * d->Wo;
+    const int ldk = pad8(d->K);
+    char* dys = (char*)scratch;
+    cv::launch_split3_chan(dy, Mout, d->K, lddy, dys, ldk, 4, st);                           // [hi | hi | lo]
+    GatherArgs a;
+    x3_dgrad_args(a, d, dys, wt3);
+    a.dbg = g_dbg; a.dbg2 = g_dbg2;
+    float* partials = (float*)(dys + ((Mout * 3 * ldk * 2 + 255) / 256 * 256));
+    cv::launch_gather_x3(a, dx, partials, nullptr, 0, st);
+    g_last_kernel = "conv_gather_v3_kernel<x3>";
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy, float* dw, float* dbias, void* stream);
+
+extern "C" int odtk_conv2d_wgrad_x3(const odtk_conv_desc* d, const float* x, const float* dy, int lddy, float* dw, void* scratch, long long scratch_bytes,
+                                    void* stream) {
+    ODTK_REQUIRE(odtk_conv2d_x3_supported(d), "conv2d_wgrad_x3: geometry not covered (odtk_conv2d_x3_supported)");
+    ODTK_REQUIRE(x && dy && dw && scratch && lddy >= d->K && scratch_bytes >= odtk_conv2d_x3_scratch_bytes(d), "conv2d_wgrad_x3: null pointer or scratch too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
+    const int ldk = pad8(d->K);
+    char* xr = (char*)scratch;
+    char* dyr = xr + ((3 * Min * d->C * 2 + 255) / 256 * 256);
+    cv::launch_split3_rows(x, Min, d->C, d->ldx, xr, d->C, 2, st);                           // images [hi ; lo ; hi]
+    cv::launch_split3_rows(dy, Mout, d->K, lddy, dyr, ldk, 4, st);                            // images [hi ; hi ; lo]
+    odtk_conv_desc b = *d;
+    b.N = 3 * d->N; b.dtype = b.out_dtype = ODTK_BF16; b.ldy = ldk;
+    return odtk_conv2d_wgrad(&b, xr, dyr, ldk, dw, nullptr, stream);      // the bf16 filter-gradient kernels, f32 result; the bias gradient is the caller's column sum
+}
+
 extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy,
                                  float* dw, float* dbias, void* stream) {
     if (int e = check_desc(d)) return e;

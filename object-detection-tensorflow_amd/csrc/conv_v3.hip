@@ -537,9 +537,17 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = p0 + wp * (PT / 2) + i * 32 + 8 * g + 4 * hi;
-                    if (c < a.ldy)
-                        *reinterpret_cast<float4*>(wsp + (size_t)m * a.ldy + c) =
-                            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    if (c < a.ldy) {
+                        float o[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        if (a.ksplit == 1) {                // the x3 engine's single-part launch writes the f32 OUTPUT: bias / ReLU here, no finish pass
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (a.bias && c + e < a.K) o[e] += a.bias[c + e];
+                                if (a.relu) o[e] = fmaxf(o[e], 0.f);
+                            }
+                        }
+                        *reinterpret_cast<float4*>(wsp + (size_t)m * a.ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
                 }
         }
         return;
@@ -2442,6 +2450,151 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(conv_wgrad_v3_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
     wgrad_split_reduce(a, st);
     a.which = 3;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// "x3" (round 4): exact-to-2^-16 f32 convolutions on the bf16 MFMA kernels by operand splitting.  a = a_hi + a_lo with a_hi = bf16(a), a_lo = bf16(a - a_hi);
+//     a * b = a_hi b_hi + a_hi b_lo + a_lo b_hi + O(2^-16 |a b|),   accumulated in f32 by the MFMA.
+// The three partial products are ONE implicit GEMM with a three times longer reduction: the gathered operand is stored as [hi | hi | lo] along its channel axis
+// (forward: the activation, input gradient: dy) against filters stored [hi | lo | hi]; for the filter gradient, whose reduction runs over pixels, x is stacked
+// [hi ; lo ; hi] and dy [hi ; hi ; lo] along the IMAGE axis (3 N images) and the existing filter-gradient kernels run unchanged, their f32 result is dW.
+// The f32 MFMA of gfx950 runs at 1/16 of the bf16 rate (157 TFLOP/s: RetinaNet's engine, whose identity-free units do not survive bf16 OPERANDS);
+// three bf16 products are 5.3x that.  Outputs leave through the split-K partial path of the 8-wave gather kernel (f32 tiles) and a finish pass that stays in f32.
+// ---------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void split_hi_lo(float v, bf16_t& hi, bf16_t& lo) {
+    hi = f32_to_bf16(v);
+    lo = f32_to_bf16(v - __uint_as_float((unsigned)hi << 16));
+}
+// eight consecutive channels of one f32 row (zero past C) as two packed bf16x8: the high halves and the low halves
+__device__ __forceinline__ void split8(const float* __restrict__ row, int c0, int C, bool vec, uint4& vh, uint4& vl) {
+    float v[8];
+    if (vec && c0 + 8 <= C) {                              // 16-byte aligned: pitch and c0 are multiples of 4
+        const float4 a = *reinterpret_cast<const float4*>(row + c0), b = *reinterpret_cast<const float4*>(row + c0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? row[c0 + e] : 0.f;
+    }
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split_hi_lo(v[e], h[e], l[e]);
+    vh = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
+    vl = make_uint4(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16);
+}
+// dst [M][3 * ldc] (parts hi/lo by `pattern` bit i = part i is the low half) from src [M][lds] f32, C valid channels; pad columns of every part zeroed
+__global__ void __launch_bounds__(256) split3_chan_kernel(const float* __restrict__ src, long long M, int C, int lds, bf16_t* __restrict__ dst, int ldc, int pattern, FastDiv dc) {
+    const int cpr = ldc >> 3;                              // 8-channel chunks per part row
+    const long long total = M * cpr;
+    const bool vec = (lds & 3) == 0 && ((uintptr_t)src & 15) == 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = total < (1ll << 31) ? (long long)fdiv((unsigned)i, dc) : i / cpr;
+        const int c0 = (int)(i - m * cpr) * 8;
+        uint4 vh, vl;
+        split8(src + m * lds, c0, C, vec, vh, vl);
+        bf16_t* row = dst + m * 3 * ldc + c0;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(row + part * ldc) = ((pattern >> part) & 1) ? vl : vh;
+    }
+}
+// dst [3 M][ldd] (row blocks hi/lo by `pattern`) from src [M][lds] f32
+__global__ void __launch_bounds__(256) split3_rows_kernel(const float* __restrict__ src, long long M, int C, int lds, bf16_t* __restrict__ dst, int ldd, int pattern, FastDiv dc) {
+    const int cpr = ldd >> 3;
+    const long long total = M * cpr;
+    const bool vec = (lds & 3) == 0 && ((uintptr_t)src & 15) == 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = total < (1ll << 31) ? (long long)fdiv((unsigned)i, dc) : i / cpr;
+        const int c0 = (int)(i - m * cpr) * 8;
+        uint4 vh, vl;
+        split8(src + m * lds, c0, C, vec, vh, vl);
+#pragma unroll
+        for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(dst + ((long long)part * M + m) * ldd + c0) = ((pattern >> part) & 1) ? vl : vh;
+    }
+}
+// dgrad-layout split filter: wt3 [C][R][S][3 * ldk] (taps flipped), part p of the last axis = hi | lo | hi of w[k][R-1-r][S-1-s][c]; k >= K -> 0
+__global__ void __launch_bounds__(256) filter_dgrad_x3_kernel(const float* __restrict__ w, int K, int R, int S, int C, int ldk, bf16_t* __restrict__ wt3) {
+    const long long total = (long long)C * R * S * 3 * ldk;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int kk = (int)(i % (3 * ldk));
+        long long t = i / (3 * ldk);
+        const int s_ = (int)(t % S); t /= S;
+        const int r_ = (int)(t % R);
+        const int c = (int)(t / R);
+        const int part = kk / ldk, k = kk - part * ldk;
+        bf16_t hi = 0, lo = 0;
+        if (k < K) split_hi_lo(w[(((long long)k * R + (R - 1 - r_)) * S + (S - 1 - s_)) * C + c], hi, lo);
+        wt3[i] = part == 1 ? lo : hi;
+    }
+}
+// sum of the f32 partial tiles + bias (+ ReLU) -> f32 y; pad columns (>= K) zeroed.  ws may alias y when ksplit == 1.
+__global__ void __launch_bounds__(256) splitk_finish_f32_kernel(const float* ws, int ksplit, long long M, int K, int ldy, const float* __restrict__ bias, int relu, float* y) {
+    const int cpr = ldy >> 2;
+    const long long total = M * cpr;
+    const long long stride = M * ldy;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / cpr;
+        const int c0 = (int)(i - m * cpr) * 4;
+        float4 v = *reinterpret_cast<const float4*>(ws + m * ldy + c0);
+        for (int p = 1; p < ksplit; ++p) {
+            const float4 u = *reinterpret_cast<const float4*>(ws + p * stride + m * ldy + c0);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c0 + e >= K) { o[e] = 0.f; continue; }
+            if (bias) o[e] += bias[c0 + e];
+            if (relu) o[e] = fmaxf(o[e], 0.f);
+        }
+        *reinterpret_cast<float4*>(y + m * ldy + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+static int grid_1d(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+}  // namespace
+
+void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, hipStream_t st) {
+    hipLaunchKernelGGL(split3_chan_kernel, dim3(grid_1d(M * (ldc >> 3))), dim3(256), 0, st, src, M, C, lds, (bf16_t*)dst, ldc, pattern, make_fastdiv((unsigned)(ldc >> 3)));
+}
+void launch_split3_rows(const float* src, long long M, int C, int lds, void* dst, int ldd, int pattern, hipStream_t st) {
+    hipLaunchKernelGGL(split3_rows_kernel, dim3(grid_1d(M * (ldd >> 3))), dim3(256), 0, st, src, M, C, lds, (bf16_t*)dst, ldd, pattern, make_fastdiv((unsigned)(ldd >> 3)));
+}
+void launch_filter_dgrad_x3(const float* w, int K, int R, int S, int C, int ldk, void* wt3, hipStream_t st) {
+    hipLaunchKernelGGL(filter_dgrad_x3_kernel, dim3(grid_1d((long long)C * R * S * 3 * ldk)), dim3(256), 0, st, w, K, R, S, C, ldk, (bf16_t*)wt3);
+}
+// how many f32 partial tiles the x3 gather of `a` writes (1 = straight into the output)
+int gather_x3_ksplit(const GatherArgs& a) {
+    if (g_num_cu == 0) query_num_cu();
+    const int PT = a.K <= 64 ? 64 : 128;
+    const int tiles = ceil_div(a.K, PT) * ceil_div(a.M, 256);
+    const int nk = ceil_div(a.Kdim, 64);
+    int ks = 1;
+    if (tiles <= g_num_cu / 2 && nk >= 8) {
+        ks = g_num_cu / tiles;
+        if (ks > nk / 4) ks = nk / 4;
+        if (ks > 32) ks = 32;
+        if (ks < 1) ks = 1;
+    }
+    return ks;
+}
+// bf16 gather (operands already split: a.x, a.w, a.C = 3 x the logical channels) -> f32 out [M][ldy] (+ bias, ReLU); `partials` holds ksplit f32 tiles when ksplit > 1
+int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bias, int relu, hipStream_t st) {
+    const int PT = a.K <= 64 ? 64 : 128;
+    a.tiles_p = ceil_div(a.K, PT);
+    a.tiles_q = ceil_div(a.M, 256);
+    a.ksplit = gather_x3_ksplit(a);
+    a.ws = a.ksplit > 1 ? partials : out;
+    a.bias = a.ksplit > 1 ? nullptr : bias;
+    a.relu = a.ksplit > 1 ? 0 : relu;
+    a.mask = nullptr; a.accumulate = 0;
+    const int grid = a.tiles_p * a.tiles_q * a.ksplit;
+    if (PT == 64) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+    if (a.ksplit > 1)
+        hipLaunchKernelGGL(splitk_finish_f32_kernel, dim3(grid_1d((long long)a.M * (a.ldy >> 2))), dim3(256), 0, st, a.ws, a.ksplit, (long long)a.M, a.K, a.ldy, bias, relu, out);
     return 0;
 }
 

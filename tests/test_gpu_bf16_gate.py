@@ -47,3 +47,12 @@ def test_retinanet_does_not_pass_the_gate_and_keeps_f32():
     cfg.pop('compute_dtype')
     m = odtk.RetinaNet(cfg, {'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
     assert m.DT == odtk.ops.F32
+
+
+def test_retinanet_operand_splitting_engine_keeps_the_gradient_direction_at_initialisation():
+    """'f32x3' (three bf16 MFMA products per f32 product, include/odtk.h): at RANDOM INITIALISATION and the BASELINE resolution -- where the bf16 engine's input-side
+    gradients have cosine ~0.0 against the f32 engine's -- every filter gradient keeps its direction."""
+    import bf16_after_training as T
+    mn, third, dloss = T.compare_engines('retinanet', 'f32', 'f32x3', batch=2)
+    assert mn > 0.999 and third > 0.9999, (mn, third)
+    assert dloss < 1e-4, dloss

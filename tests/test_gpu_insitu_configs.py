@@ -21,7 +21,7 @@ sys.path.insert(0, HERE)
 import insitu          # noqa: E402
 import mock_ops        # noqa: E402
 
-CASES = [('retinanet', 'f32'), ('yolov3', 'bf16'), ('fcos', 'bf16'), ('centernet', 'bf16'),        # the engine each class defaults to (steady state)
+CASES = [('retinanet', 'f32'), ('retinanet', 'f32x3'), ('yolov3', 'bf16'), ('fcos', 'bf16'), ('centernet', 'bf16'),        # the engine each class defaults to (steady state)
          ('ssd300', 'bf16'), ('retinanet', 'bf16'), ('yolov3', 'f32'), ('fcos', 'f32'), ('centernet', 'f32')]
 
 
@@ -58,9 +58,11 @@ def test_every_launch_in_situ_at_baseline_shape(name, dtype):
     rows = sh.check(insitu.default_tol(dtype), verbose=True, label=f'{name} {dtype} {size0}x{size0} batch {batch0}')
     seen = {x['op'] for x in rows}
     assert {'conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad'} <= seen and any(o.endswith('_loss') for o in seen)
+    if dtype == 'f32x3':
+        assert {'conv2d_fwd_x3', 'conv2d_dgrad_x3', 'conv2d_wgrad_x3', 'filter_prepare_x3', 'colsum'} <= seen
     n_conv = len(BC.conv_layers(name, m))
     if n_conv:
-        assert sum(1 for x in rows if x['op'] in ('conv2d_fwd', 'conv2d_fwd_pool2x2') and x['out'] in ('y', 'y_pool')) >= n_conv - 1
-        assert sum(1 for x in rows if x['op'] == 'conv2d_wgrad' and x['out'] == 'dw') >= n_conv - 1
+        assert sum(1 for x in rows if x['op'] in ('conv2d_fwd', 'conv2d_fwd_pool2x2', 'conv2d_fwd_x3') and x['out'] in ('y', 'y_pool')) >= n_conv - 1
+        assert sum(1 for x in rows if x['op'] in ('conv2d_wgrad', 'conv2d_wgrad_x3') and x['out'] == 'dw') >= n_conv - 1
     del m, r
     torch.cuda.empty_cache()

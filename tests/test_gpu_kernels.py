@@ -1099,3 +1099,78 @@ def test_loss_total_and_zero(n, dev):
     ops.zero(buf[3:3 + n])
     torch.cuda.synchronize()
     assert float(buf[3:3 + n].abs().sum()) == 0.0 and bool((buf[:3] == 3.0).all()) and bool((buf[3 + n:] == 3.0).all())
+
+
+# ---- "x3": f32 convolutions on the bf16 MFMA kernels by operand splitting (include/odtk.h).  Geometries of RetinaNet.py:594-643's units (1x1 / 3x3, stride 1 | 2,
+# channel counts that are multiples of 8), the heads' 189 / 36 channels, split-K and plain tiles.  Reference: the convolution in f64.  Bound: 3e-5 of the
+# output scale (measured ~4e-6; one bf16 product would be 4e-3) -- the f32 kernels' own bound is 2e-4.
+X3_CASES = [
+    (2, 25, 25, 256, 64, 1, 1, 1),     # bottleneck 1x1
+    (2, 25, 25, 64, 64, 3, 1, 1),      # 3x3
+    (2, 26, 26, 128, 256, 3, 2, 1),    # stride-2 3x3 (asymmetric SAME pad)
+    (2, 26, 26, 256, 512, 1, 2, 1),    # stride-2 1x1 shortcut
+    (2, 13, 13, 256, 189, 3, 1, 1),    # class head: 189 = 9 x 21 channels (pitch 192)
+    (1, 7, 7, 256, 36, 3, 1, 1),       # box head on a small level: split-K
+    (3, 50, 50, 64, 256, 1, 1, 1),     # many pixel tiles
+    (1, 4, 4, 2048, 256, 1, 1, 1),     # deep reduction, 16 pixels
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_conv_x3_operand_splitting_against_f64(case, dev):
+    ops = _ops()
+    N, H, W, C, K, k, stride, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, H, W, C, generator=g) * torch.exp(torch.randn(N, H, W, 1, generator=g))          # a spread of magnitudes: the low halves matter
+    w = torch.randn(K, k, k, C, generator=g) / math.sqrt(k * k * C)
+    b = torch.randn(K, generator=g)
+    ldy = ops.pad_to(K, 4)
+    d = ops.conv_desc(N, H, W, C, C, K, ldy, k, stride, dil, ops.F32, ops.F32)
+    assert ops.conv2d_x3_supported(d)
+    Ho, Wo = d.Ho, d.Wo
+    scratch = torch.zeros(ops.conv2d_x3_scratch_bytes(d), dtype=torch.uint8, device=dev)
+    w3 = torch.zeros(K * k * k * 3 * C, dtype=torch.bfloat16, device=dev)
+    wt3 = torch.zeros(C * k * k * 3 * ops.pad_to(K, 8), dtype=torch.bfloat16, device=dev)
+    wd = w.to(dev).contiguous()
+    ops.filter_prepare_x3(wd, K, k, k, C, w3, wt3)
+    # the split copies are exactly hi | lo | hi of the filters
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    got3 = w3.cpu().reshape(K, k * k, 3, C)
+    assert torch.equal(got3[:, :, 0], hi.reshape(K, k * k, C)) and torch.equal(got3[:, :, 1], lo.reshape(K, k * k, C)) and torch.equal(got3[:, :, 2], got3[:, :, 0])
+    xd = to_rows(x, C, torch.float32, dev)
+    yd = torch.full((N * Ho * Wo, ldy), 7.0, device=dev)
+    ops.conv2d_fwd_x3(d, xd, w3, b.to(dev), yd, True, scratch)
+    torch.cuda.synchronize()
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    z_ref = _ref_conv(xr, wr, b.double(), stride, dil)
+    y_ref = F.relu(z_ref).detach()
+    y = from_rows(yd, N, Ho, Wo, K).double()
+    tol = 3e-5
+    assert float((y - y_ref).abs().max()) <= tol * (float(y_ref.abs().max()) + 1e-6), "x3 forward"
+    if ldy > K:
+        assert float(yd[:, K:].abs().max()) == 0.0
+    # the f32 kernel on the same operands: the two engines agree to the same bound
+    w_c = torch.empty(K * k * k * C, device=dev)
+    w_t = torch.empty(C * k * k * ldy, device=dev)
+    ops.filter_prepare(wd, K, k, k, C, ldy, ops.F32, w_c, w_t)
+    yf = torch.zeros_like(yd)
+    ops.conv2d_fwd(d, xd, w_c, b.to(dev), yf, True)
+    assert float((yf - yd).abs().max()) <= tol * (float(y_ref.abs().max()) + 1e-6)
+    # backward
+    dy = torch.randn(N, Ho, Wo, K, generator=g) * torch.exp(torch.randn(N, Ho, Wo, 1, generator=g))
+    z_ref.backward(dy.double())
+    dyd = to_rows(dy, ldy, torch.float32, dev)
+    dxd = torch.full((N * H * W, C), 7.0, device=dev)
+    ops.conv2d_dgrad_x3(d, dyd, ldy, wt3, dxd, scratch)
+    dwd = torch.zeros(K, k, k, C, device=dev)
+    ops.conv2d_wgrad_x3(d, xd, dyd, ldy, dwd, scratch)
+    torch.cuda.synchronize()
+    dx = from_rows(dxd, N, H, W, C).double()
+    assert float((dx - xr.grad).abs().max()) <= tol * (float(xr.grad.abs().max()) + 1e-6), "x3 input gradient"
+    assert float((dwd.cpu().double() - wr.grad).abs().max()) <= tol * (float(wr.grad.abs().max()) + 1e-6), "x3 filter gradient"
+    # accumulation into dw (the caller's zeroed gradient buffer): a second call doubles it
+    ops.conv2d_wgrad_x3(d, xd, dyd, ldy, dwd, scratch)
+    torch.cuda.synchronize()
+    assert float((dwd.cpu().double() - 2 * wr.grad).abs().max()) <= 2 * tol * (float(wr.grad.abs().max()) + 1e-6)

@@ -90,8 +90,31 @@ def run(name, steps=300, batch=4, lr=1e-3, verbose=True):
     return dict(init=init, after=after, losses=losses, loss_f32=lf, loss_bf16=lb)
 
 
+def compare_engines(name, a='f32', b='f32x3', batch=2, size=None, verbose=True):
+    """One step from the SAME (initial) weights on engines a and b: -> (min cosine, input-side-third median cosine, |loss_b - loss_a| / loss_a) over every filter
+    gradient.  Initialisation is the worst case for these stacks (see the module docstring); an engine that keeps the direction there keeps it everywhere."""
+    size = size or BC.SHAPES[name][0]
+    r = BC.make(name, batch=batch, size=size, dtype='f32', use_graph=False)
+    m = r['model']
+    probe = BC.synthetic_batch(name, batch, size, 4242)
+    p0 = m.export_params()
+    s0 = m.S.clone() if hasattr(m, 'S') else None
+    del m
+    torch.cuda.empty_cache()
+    la, ga = grads_of(name, p0, s0, batch, size, a, probe)
+    lb, gb = grads_of(name, p0, s0, batch, size, b, probe)
+    rows = compare(ga, gb)
+    if verbose:
+        print(f'{name} {size}x{size} batch {batch}: loss {a} {la:.5f} / {b} {lb:.5f}')
+    mn, third = summarize(f'  {b} against {a}, initial weights', rows)
+    return mn, third, abs(lb - la) / abs(la)
+
+
 def main():
     name = sys.argv[1]
+    if len(sys.argv) > 2 and sys.argv[2] == 'x3':
+        compare_engines(name)
+        return
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     lr = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-3

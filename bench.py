@@ -519,6 +519,9 @@ def bench_other(args, world, rank, local_rank):
                           'f32 engine (the class default): exact-f32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s'}}
         if timer.records:
             rf = timer.roofline(ev_steps, peak, value / world * (flops_step / B) / peak)
+            if args.conv_table:
+                with open(args.conv_table, 'w') as f:
+                    f.write(timer.table(ev_steps) + '\n')
             rf['measured_on'] = f'{ev_steps} eager steps right after the timed region (HIP events per conv launch on the launch stream; plain per-launch mean without the first)'
             rf['peak_note'] = ('dense bf16 MFMA' if args.dtype == 'bf16' else 'dense bf16 MFMA / 3 (three bf16 products per f32 product)' if args.dtype == 'f32x3'
                                else 'f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)')

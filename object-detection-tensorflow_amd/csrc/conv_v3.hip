@@ -580,7 +580,9 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
 // (Round 4, measured and removed: a 128 x 128-tile instantiation -- four waves of 64 x 64, single-buffered 7-group patch, 76 KiB of LDS, <= 256 registers -- so that TWO
 // workgroups share a CU and fill each other's epilogue / prologue / barrier gaps: conv4_1 forward -8 %, conv4_2 -3..-4 %, conv6 forward -6 % in isolation, +10 % on
 // short launches, and 0.0 % on the step in the same-process A/B: profiles/r04t_*.)
-template <int NPP, bool DBUF, int G1, int G2, int WP = 2, int PI = 2, int QI = 4, bool POOL = false>
+// F32OUT (round 4, the x3 engine): the f32 accumulators leave as f32 rows of a.ws [M][ldy] (+ bias, ReLU) straight from the registers, 16 bytes per lane and
+// accumulator group -- the bf16 image in LDS and everything the bf16 epilogue does (mask, accumulate, pool) do not exist in this form.
+template <int NPP, bool DBUF, int G1, int G2, int WP = 2, int PI = 2, int QI = 4, bool POOL = false, bool F32OUT = false>
 __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a) {
     constexpr int PT = WP * PI * 32, QT = (4 / WP) * QI * 32, NTHR = 256;
     static_assert(PT == 128 || PT == 64, "the filter slab is 128 (or 64: Cout <= 64) rows");
@@ -785,6 +787,29 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         });
     }
     wait_vmcnt<0>();                                    // the trailing (zero-fill) pieces must land before the image overwrites LDS
+    if constexpr (F32OUT) {
+        const int hi = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < QI; ++j) {
+            const int m = q0 + qrow0 + j * 32 + l31;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int i = 0; i < PI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = p0 + prow0 + i * 32 + 8 * g + 4 * hi;
+                    if (c >= a.ldy) continue;
+                    float o[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (a.bias && c + e < a.K) o[e] += a.bias[c + e];
+                        if (a.relu) o[e] = fmaxf(o[e], 0.f);
+                    }
+                    *reinterpret_cast<float4*>(a.ws + (size_t)m * a.ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+        }
+        return;
+    }
     block_barrier();
     epilogue_bf16<PT, QT, NTHR, PI, QI, false, POOL>(a, smem, acc, p0, q0, prow0, qrow0, tid, pn, ph0, rows_here);
 }
@@ -2590,6 +2615,35 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
     a.bias = a.ksplit > 1 ? nullptr : bias;
     a.relu = a.ksplit > 1 ? 0 : relu;
     a.mask = nullptr; a.accumulate = 0;
+    // 3x3 / stride 1 / SAME over whole 64-channel chunks (the heads' and the pyramid's 256-channel layers: 768 split channels): the raster-run halo kernel
+    const int halo = 2 * a.dil * (a.W + 1);
+    if (a.ksplit == 1 && PT == 128 && !(a.dbg & 65536) && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 && a.pad_t == a.dil &&
+        a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && a.Kdim == 9 * a.C) {
+        const int tiles = a.tiles_p * a.tiles_q;
+        const int tq512 = ceil_div(a.M, 512), tq192 = ceil_div(a.M, 192);
+        const long long cost256 = (long long)ceil_div(tiles, g_num_cu) * (256 + 32), cost192 = (long long)ceil_div(tq192 * a.tiles_p, g_num_cu) * (192 + 32);
+        a.ksplit = -1;
+        if (halo <= 160 && a.dil * a.W >= 64 && tq512 * a.tiles_p >= 2 * g_num_cu) {
+            a.tiles_q = tq512;
+            hipLaunchKernelGGL((conv_gather_v6_kernel<21, false, 2, 4, 1, 4, 4, false, true>), dim3(tq512 * a.tiles_p), dim3(256), 0, st, a);
+            return 0;
+        }
+        if (halo <= 160 && cost192 < cost256) {
+            a.tiles_q = tq192;
+            hipLaunchKernelGGL((conv_gather_v6_kernel<11, true, 0, 0, 2, 2, 3, false, true>), dim3(tq192 * a.tiles_p), dim3(256), 0, st, a);
+            return 0;
+        }
+        if (halo <= 160) { hipLaunchKernelGGL((conv_gather_v6_kernel<13, true, 0, 0, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a); return 0; }
+        if (halo <= 352 && a.dil * a.W >= 96 && a.dil * a.W < 112) {
+            hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 6, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
+            return 0;
+        }
+        if (halo <= 352 && a.dil * a.W >= 128 && a.dil * a.W < 144) {
+            hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 8, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
+            return 0;
+        }
+        a.ksplit = 1;                                     // other row lengths: the 8-wave kernel below
+    }
     const int grid = a.tiles_p * a.tiles_q * a.ksplit;
     if (PT == 64) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);

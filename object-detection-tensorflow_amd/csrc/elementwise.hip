@@ -454,10 +454,28 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ ws, in
     __shared__ float sm[2][FIN_SL][FIN_CH];
     float a1 = 0.f, a2 = 0.f;
     if (c < C) {
-        for (int s = sl; s < nsplit; s += FIN_SL) {
-            a1 += ws[((size_t)0 * nsplit + s) * C + c];
-            a2 += ws[((size_t)1 * nsplit + s) * C + c];
+        // four partial rows per trip with their eight loads in flight together (one row per trip was up to 128 dependent L2 round trips for the narrow layers
+        // with ~1 000 row splits: 20-40 us per launch in RetinaNet's / YOLOv3's steps); the summation order is fixed, so the result stays deterministic
+        const float* w1 = ws + c;
+        const float* w2 = ws + (size_t)nsplit * C + c;
+        float b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = sl;
+        for (; s + 3 * FIN_SL < nsplit; s += 4 * FIN_SL) {
+            float v1[4], v2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v1[u] = w1[(size_t)(s + u * FIN_SL) * C];
+                v2[u] = w2[(size_t)(s + u * FIN_SL) * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { b1[u] += v1[u]; b2[u] += v2[u]; }
         }
+        for (; s < nsplit; s += FIN_SL) {
+            b1[0] += w1[(size_t)s * C];
+            b2[0] += w2[(size_t)s * C];
+        }
+        a1 = (b1[0] + b1[1]) + (b1[2] + b1[3]);
+        a2 = (b2[0] + b2[1]) + (b2[2] + b2[3]);
     }
     const int cl = threadIdx.x & (FIN_CH - 1);
     sm[0][sl][cl] = a1;

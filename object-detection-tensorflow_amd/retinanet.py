@@ -326,7 +326,9 @@ class RetinaNet:
         for name, cin, cout, k, _, _, _ in self.specs[1:]:
             d = self.desc[name]
             kp = self.acts[name].ld
-            if self.x3 and ops.conv2d_x3_supported(d):
+            # (below ~20 000 multiply-adds per output pixel row -- the 7..112-channel backbone layers -- the split passes cost more than the f32 MFMA kernel:
+            #  per-layer table of both engines at 800 x 800 batch 16, profiles/r04x_*)
+            if self.x3 and ops.conv2d_x3_supported(d) and d.C * d.K * d.R * d.S >= 20000:
                 self.w3[name] = (torch.zeros(cout * k * k * 3 * d.C, dtype=torch.bfloat16, device=dev),
                                  torch.zeros(d.C * k * k * 3 * ops.pad_to(cout, 8), dtype=torch.bfloat16, device=dev) if self.mode == 'train' else None)
                 x3_bytes = max(x3_bytes, ops.conv2d_x3_scratch_bytes(d))

@@ -1113,6 +1113,12 @@ X3_CASES = [
     (1, 7, 7, 256, 36, 3, 1, 1),       # box head on a small level: split-K
     (3, 50, 50, 64, 256, 1, 1, 1),     # many pixel tiles
     (1, 4, 4, 2048, 256, 1, 1, 1),     # deep reduction, 16 pixels
+    # the raster-run halo kernel with f32 output (3x3 / stride 1 over whole 64-channel chunks, enough tiles for one part per tile), one case per variant
+    (8, 64, 64, 64, 256, 3, 1, 1),     # 256-pixel tiles, double-buffered patch
+    (8, 50, 50, 128, 256, 3, 1, 1),    # 192-pixel tiles (P4 of the 800-pixel pyramid); the input gradient (128 channels out of 768 split ones) too
+    (2, 100, 100, 128, 256, 3, 1, 1),  # rows of 96-111 pixels (P3): single patch buffer with early refill; input gradient too
+    (1, 130, 130, 64, 189, 3, 1, 1),   # rows of 128-143 pixels, a channel tail
+    (32, 64, 64, 64, 160, 3, 1, 1),    # 512-pixel tiles
 ]
 
 

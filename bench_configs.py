@@ -15,7 +15,7 @@ YOLO_PRIORS_PX = [[[10., 13.], [16, 30.], [33., 23.]], [[30., 61.], [62., 45.], 
 # name -> (input size, images per GPU, dtype the class defaults to, learning rate of the driver script)
 SHAPES = {
     'ssd300': (300, 32, 'bf16', 0.01),
-    'retinanet': (800, 16, 'f32', 1e-4),
+    'retinanet': (800, 16, 'f32x3', 1e-4),
     'yolov3': (416, 8, 'bf16', 1e-4),
     'fcos': (512, 16, 'bf16', 1e-4),          # bf16 engine by default since round 3 (steady state; a run from random initialisation warms up in f32: warmup.py)
     'centernet': (512, 16, 'bf16', 1e-4),

@@ -535,6 +535,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     const int m0 = blockIdx.y * rows_per_block;
     int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
     const bool full = c0 + KC <= C;
+#pragma unroll 2
     for (int m = m0 + rl; m < m1; m += RED_ROWS) {
         float f[KC];
         Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
@@ -618,6 +619,7 @@ __global__ void __launch_bounds__(256) bn_apply_fin_kernel(
     const int m0 = blockIdx.y * rows_per_block;
     int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
     const bool full = c0 + KC <= C;
+#pragma unroll 2
     for (int m = m0 + rl; m < m1; m += RED_ROWS) {
         float f[KC];
         Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
@@ -660,6 +662,20 @@ __device__ __forceinline__ void bn_load_dy(const TY* __restrict__ y, const TY* _
         if (relu) Chunk<bf16_t>::unpack(ld16(reinterpret_cast<const bf16_t*>(y) + oo), yv);
 #pragma unroll
         for (int e = 0; e < KC; ++e) d[e] = (relu && !(yv[e % 8] > 0.f)) ? (relu == 2 ? 0.1f * dv[e % 8] : 0.f) : dv[e % 8];
+        return;
+    }
+    if (sizeof(TY) == 4 && KC == 4 && vec_ok && c0 + KC <= C) {     // f32 engines: one 16-byte load per operand (four 4-byte loads each before round 4)
+        const float4 dv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy) + oo);
+        float dd[4] = {dv.x, dv.y, dv.z, dv.w};
+        if (relu) {
+            const float4 yv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(y) + oo);
+            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!(yy[e] > 0.f)) dd[e] = relu == 2 ? 0.1f * dd[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < KC; ++e) d[e] = dd[e % 4];
         return;
     }
 #pragma unroll
@@ -760,6 +776,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     }
     const int m0 = blockIdx.y * rows_per_block;
     int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+#pragma unroll 2
     for (int m = m0 + rl; m < m1; m += RED_ROWS) {
         float f[KC], o[KC];
         Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
@@ -819,6 +836,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fin_kernel(
     }
     const int m0 = blockIdx.y * rows_per_block;
     int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+#pragma unroll 2
     for (int m = m0 + rl; m < m1; m += RED_ROWS) {
         float f[KC], o[KC];
         Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);

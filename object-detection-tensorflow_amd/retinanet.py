@@ -112,8 +112,11 @@ class RetinaNet:
         # end of the backbone at random initialisation; 'bf16' runs (3.4x faster) but is not validated for training
         # 'f32x3' (round 4): the f32 engine with its convolutions on the bf16 MFMA kernels by operand splitting (a = a_hi + a_lo, three bf16 products per f32
         # product, f32 accumulation: include/odtk.h "x3"); every tensor stays f32, the products carry a 2^-16 relative error instead of bf16's 2^-8
-        self.x3 = config.get('compute_dtype', 'f32') == 'f32x3'
-        self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[config.get('compute_dtype', 'f32')]
+        # Default: 'f32x3' for training (it clears the gate of tests/test_gpu_bf16_gate.py at random initialisation: every filter gradient within cosine 0.997 of the
+        # f32 engine's, 1.000 after 300 steps; 1.9x the f32 engine's throughput), exact 'f32' for mode 'test'
+        engine = config.get('compute_dtype') or ('f32x3' if config['mode'] == 'train' else 'f32')
+        self.x3 = engine == 'f32x3'
+        self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[engine]
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         if self.mode == 'train':

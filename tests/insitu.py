@@ -85,6 +85,7 @@ COND = {
     ('bn_fwd', 'save_mean'): lambda a: a['z'][:a['M'], :a['C_']].float().abs().mean(0),
     ('bn_fwd', 'mmean'): lambda a: BN_MOM_ * a['mmean'].float().abs() + (1 - BN_MOM_) * a['z'][:a['M'], :a['C_']].float().abs().mean(0),
     ('conv2d_wgrad', 'dbias'): lambda a: a['dy'][:, :a['d'].K].float().abs().sum(0),
+    ('colsum', 'out'): lambda a: a['dy'][:a['M'], :a['C_']].float().abs().sum(0),        # (the x3 engine's bias gradient: the same cancelling sum)
     ('bn_bwd', 'dbeta'): lambda a: _bn_terms(a)[0].abs().sum(0),
     ('bn_bwd', 'dgamma'): lambda a: (lambda d, xh: (d * xh).abs().sum(0))(*_bn_terms(a)),
     ('l2norm_bwd', 'dgamma'): lambda a: (lambda v, d: (d * v / torch.sqrt(torch.clamp((v * v).sum(1, keepdim=True), min=1e-12))).abs().sum().view(1))(

@@ -48,13 +48,13 @@ def summarize(tag, rows):
     cos = [r[1] for r in rows]
     third = max(1, len(rows) // 3)
     first, last = rows[:third], rows[-third:]
-    print(f'{tag}: {len(rows)} filter gradients; cosine bf16 vs f32: min {min(cos):.3f} ({min(rows, key=lambda r: r[1])[0]}), median {statistics.median(cos):.3f}; '
+    print(f'{tag}: {len(rows)} filter gradients; cosine against the f32 engine: min {min(cos):.3f} ({min(rows, key=lambda r: r[1])[0]}), median {statistics.median(cos):.3f}; '
           f'first third of the layers (towards the input) median {statistics.median(r[1] for r in first):.3f}, last third median '
           f'{statistics.median(r[1] for r in last):.3f}; norm ratio median {statistics.median(r[2] for r in rows):.3f}')
     return min(cos), statistics.median(r[1] for r in first)
 
 
-def run(name, steps=300, batch=4, lr=1e-3, verbose=True):
+def run(name, steps=300, batch=4, lr=1e-3, verbose=True, engine='bf16'):
     """-> dict(init=(min cosine, input-side-third median), after=(...), losses=[...])"""
     size = BC.SHAPES[name][0]
     r = BC.make(name, batch=batch, size=size, dtype='f32', use_graph=False)
@@ -63,9 +63,9 @@ def run(name, steps=300, batch=4, lr=1e-3, verbose=True):
     p0 = m.export_params()
     s0 = m.S.clone() if hasattr(m, 'S') else None
     lf, gf = grads_of(name, p0, s0, batch, size, 'f32', probe)
-    lb, gb = grads_of(name, p0, s0, batch, size, 'bf16', probe)
+    lb, gb = grads_of(name, p0, s0, batch, size, engine, probe)
     if verbose:
-        print(f'{name} {size}x{size} batch {batch}: at initialisation loss f32 {lf:.4f} / bf16 {lb:.4f}')
+        print(f'{name} {size}x{size} batch {batch}: at initialisation loss f32 {lf:.4f} / {engine} {lb:.4f}')
     init = summarize('  initial weights', compare(gf, gb))
     pool = [BC.synthetic_batch(name, batch, size, 100 + i) for i in range(8)]
     losses = []
@@ -82,9 +82,9 @@ def run(name, steps=300, batch=4, lr=1e-3, verbose=True):
     del m
     torch.cuda.empty_cache()
     lf, gf = grads_of(name, p1, s1, batch, size, 'f32', probe)
-    lb, gb = grads_of(name, p1, s1, batch, size, 'bf16', probe)
+    lb, gb = grads_of(name, p1, s1, batch, size, engine, probe)
     if verbose:
-        print(f'  after {steps} steps: held-out loss f32 {lf:.4f} / bf16 {lb:.4f}')
+        print(f'  after {steps} steps: held-out loss f32 {lf:.4f} / {engine} {lb:.4f}')
     after = summarize(f'  after {steps} steps', compare(gf, gb))
     print(f'RESULT {name}: min cosine {init[0]:.3f} -> {after[0]:.3f}; input-side third {init[1]:.3f} -> {after[1]:.3f}')
     return dict(init=init, after=after, losses=losses, loss_f32=lf, loss_bf16=lb)
@@ -113,7 +113,7 @@ def compare_engines(name, a='f32', b='f32x3', batch=2, size=None, verbose=True):
 def main():
     name = sys.argv[1]
     if len(sys.argv) > 2 and sys.argv[2] == 'x3':
-        compare_engines(name)
+        run(name, 300, 2, 1e-3, engine='f32x3')
         return
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4

@@ -63,7 +63,7 @@ class ConvTimer:
 
     def install(self):
         ops = self.ops
-        for kind in ('conv2d_fwd', 'conv2d_fwd_pool2x2', 'conv2d_dgrad', 'conv2d_wgrad', 'conv2d_fwd_x3', 'conv2d_dgrad_x3', 'conv2d_wgrad_x3'):
+        for kind in ('conv2d_fwd', 'conv2d_fwd_pool2x2', 'conv2d_dgrad', 'conv2d_wgrad'):
             self._orig[kind] = getattr(ops, kind)
             setattr(ops, kind, self._wrap(kind))
 
@@ -80,13 +80,12 @@ class ConvTimer:
             flops = 2.0 * d.N * d.Ho * d.Wo * k_alg * d.R * d.S * c_alg  # algorithmic: 2*M*Cout*R*S*Cin for each pass
             esz = 2 if d.dtype == 0 else 4
             # algorithmic HBM bytes: every operand once (x, y / dy, dx as bf16; filter as bf16, dW as f32)
-            abytes = (d.N * d.H * d.W * d.C + d.N * d.Ho * d.Wo * d.K) * esz + d.K * d.R * d.S * d.C * (4 if kind.startswith('conv2d_wgrad') else esz)
+            abytes = (d.N * d.H * d.W * d.C + d.N * d.Ho * d.Wo * d.K) * esz + d.K * d.R * d.S * d.C * (4 if kind == 'conv2d_wgrad' else esz)
             s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
             s.record()
             r = orig(d, *args)
             e.record()
             rkind = 'conv2d_fwd' if kind == 'conv2d_fwd_pool2x2' else kind      # conv + bias + ReLU + pool in one launch: the conv's FLOPs, its own time
-            rkind = rkind[:-3] if rkind.endswith('_x3') else rkind              # operand splitting: the call's whole time (split passes + gather + finish), the f32 conv's FLOPs
             self.records.append((rkind, self.ops.conv_last_kernel(), flops, s, e, abytes,
                                  (d.N, d.H, d.W, d.C, d.K, d.R, d.stride, d.dil)))
             return r

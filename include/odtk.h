@@ -33,6 +33,13 @@ extern "C" {
 
 #define ODTK_BF16 0 /* bfloat16 storage, MFMA 32x32x16 bf16, f32 accumulate */
 #define ODTK_F32 1  /* float32 storage, MFMA 32x32x2 f32 (exact f32 FMA chain)  */
+/* Convolution descriptors only (round 4): float32 STORAGE on every side (x, w, y, dy, dx, dw: exactly the ODTK_F32 layouts and pitches), arithmetic by OPERAND
+ * SPLITTING on the bf16 MFMA where that is faster -- a = a_hi + a_lo (two bf16), a b = a_hi b_hi + a_hi b_lo + a_lo b_hi, accumulated in f32: one implicit GEMM with
+ * a three times longer reduction at 16x the f32 MFMA rate; products carry 2^-17 instead of 2^-24 (bf16 operands: 2^-9).  The split copies of both operands are
+ * made per call in a library-owned arena (per device and odtk_scratch_slot).  Layers where the split passes cost more than the exact kernel takes (C K R S < 20 000,
+ * the 7..112-channel backbone layers of RetinaNet.py:594-643) and geometries the bf16 kernels do not cover run on the ODTK_F32 kernels, bit for bit.  dtype and
+ * out_dtype must both be ODTK_F32X3; every other entry point takes ODTK_F32 for these tensors. */
+#define ODTK_F32X3 2
 
 const char* odtk_last_error(void);
 int odtk_version(void);
@@ -111,20 +118,9 @@ int odtk_conv2d_relu_bits_supported(const odtk_conv_desc* producer, const odtk_c
 int odtk_conv2d_fwd_bits(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu, void* relu_bits, void* stream);
 int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t, const void* relu_bits, void* dx, int accumulate, void* stream);
 
-/* "x3" (round 4): the convolutions of an f32 model (RetinaNet's engine: its identity-free units do not survive bf16 operands, RetinaNet.py:594-643) on the bf16
- * MFMA kernels by OPERAND SPLITTING -- a = a_hi + a_lo (two bf16), a b = a_hi b_hi + a_hi b_lo + a_lo b_hi + O(2^-16), accumulated in f32: one implicit GEMM with
- * a three times longer reduction.  d is the F32 descriptor of the layer (x, y, dy, dx, dw all f32, the f32 engine's pitches); odtk_conv2d_x3_supported(d) != 0 for
- * C % 8 == 0, ldx == C, stride 1 | 2; `scratch` = odtk_conv2d_x3_scratch_bytes(d) bytes (split operands + split-K partial tiles), caller-owned.
- * odtk_filter_prepare_x3: w [K][R][S][C] f32 -> w3 [K][R][S][3 C] bf16 (per tap hi | lo | hi; forward) and wt3 [C][R][S][3 pad8(K)] (taps flipped; input
- * gradient); either may be NULL.  fwd: y = conv(x, w) + bias (+ ReLU), pad columns zeroed.  dgrad: dx = transposed conv (no mask, no accumulate).  wgrad: dw (+)=
- * filter gradient (float atomics into dw as odtk_conv2d_wgrad; the bias gradient is the caller's odtk_colsum of dy). */
+/* bit 0: the forward pass and the input gradient of this ODTK_F32X3 descriptor run as split bf16 products; bit 1: the filter gradient does (C % 8 == 0 on
+ * top); 0 for every other descriptor.  Introspection only (benchmarks, tests): the conv entry points decide by themselves. */
 int odtk_conv2d_x3_supported(const odtk_conv_desc* d);
-long long odtk_conv2d_x3_scratch_bytes(const odtk_conv_desc* d);
-int odtk_filter_prepare_x3(const float* w, int K, int R, int S, int C, void* w3, void* wt3, void* stream);
-int odtk_conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const void* w3, const float* bias, float* y, int relu, void* scratch, long long scratch_bytes,
-                       void* stream);
-int odtk_conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, const void* wt3, float* dx, void* scratch, long long scratch_bytes, void* stream);
-int odtk_conv2d_wgrad_x3(const odtk_conv_desc* d, const float* x, const float* dy, int lddy, float* dw, void* scratch, long long scratch_bytes, void* stream);
 
 /* dx[n,h,w,c] (+)= sum_{r,s,k} dy[n,ho,wo,k] * w[k,r,s,c]   (transposed conv of the fwd op)
  * w_t is the dgrad-layout filter produced by odtk_filter_to_dgrad: [C][R][S][Kp]

@@ -7,7 +7,7 @@ PyTorch-ROCm tensors; all arithmetic on the hot path runs in hand-written HIP ke
 reached through the C-ABI in ``include/odtk.h`` (``libodtk.so``).
 """
 from . import _lib                      # noqa: F401
-from ._lib import BF16, F32, OdtkError  # noqa: F401
+from ._lib import BF16, F32, F32X3, OdtkError  # noqa: F401
 
 __all__ = ["BF16", "F32", "OdtkError", "SSD300", "YOLOv3", "RetinaNet", "FCOS", "CenterNet", "SSD512", "RefineDet320", "PFPNetR", "YOLOv2", "LHRCNN"]
 

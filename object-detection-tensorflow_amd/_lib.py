@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("ODTK_LIB") or os.path.join(_HERE, "libodtk.so")     #
 
 BF16 = 0
 F32 = 1
+F32X3 = 2          # conv descriptors only: f32 tensors, convolutions as three bf16 MFMA products where that is faster (include/odtk.h)
 
 
 class ConvDesc(C.Structure):
@@ -56,11 +57,6 @@ SIGNATURES = {
     "odtk_conv2d_dgrad_bits": (_i, [_cd, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "odtk_conv2d_wgrad": (_i, [_cd, _vp, _vp, _i, _vp, _vp, _vp]),
     "odtk_conv2d_x3_supported": (_i, [_cd]),
-    "odtk_conv2d_x3_scratch_bytes": (C.c_longlong, [_cd]),
-    "odtk_filter_prepare_x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "odtk_conv2d_fwd_x3": (_i, [_cd, _vp, _vp, _vp, _vp, _i, _vp, C.c_longlong, _vp]),
-    "odtk_conv2d_dgrad_x3": (_i, [_cd, _vp, _i, _vp, _vp, _vp, C.c_longlong, _vp]),
-    "odtk_conv2d_wgrad_x3": (_i, [_cd, _vp, _vp, _i, _vp, _vp, C.c_longlong, _vp]),
     "odtk_filter_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "odtk_filter_prepare_batched": (_i, [_vp, _i, _i, _i, _vp]),
     "odtk_preprocess": (_i, [_vp, _ll, C.POINTER(_f), _i, _i, _vp, _vp]),

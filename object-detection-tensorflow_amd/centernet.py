@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import heads, ops
-from ._lib import BF16, F32
+from ._lib import BF16, F32, F32X3
 from .warmup import F32Warmup
 
 MEAN = (0.485, 0.456, 0.406)                                  # CenterNet.py:52-53
@@ -117,7 +117,10 @@ class CenterNet(F32Warmup):
         # engine: bf16 by default on the GPU since round 3 (warmup.py: the first f32_warmup_steps optimizer steps of a run from random initialisation go through
         # an f32 twin); an explicit 'compute_dtype' is taken literally; the CPU stand-in of the library (host-logic tests) stays on f32
         # (mode 'test' keeps f32 unless asked otherwise, as ssd300.py does: the bf16 gate checks training gradients, not thresholded detections)
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16' if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')]
+        engine = config.get('compute_dtype', 'bf16' if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')
+        # 'f32x3': f32 tensors, convolution descriptors of dtype ODTK_F32X3 (three bf16 MFMA products per f32 product where that is faster: include/odtk.h)
+        self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[engine]
+        self.CDT = F32X3 if engine == 'f32x3' else self.DT
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0
@@ -243,11 +246,11 @@ class CenterNet(F32Warmup):
             assert not ghost and cin == src.C, (name, cin, src.C)
             ldz = ops.pad_to(cout, ch)
             if kind == 'conv':
-                d = ops.conv_desc(N, src.H, src.W, ops.pad_to(cin, ch), src.ld, cout, ldz, k, stride, 1, self.DT, self.DT)
+                d = ops.conv_desc(N, src.H, src.W, ops.pad_to(cin, ch), src.ld, cout, ldz, k, stride, 1, self.CDT, self.CDT)
                 Ho, Wo = d.Ho, d.Wo
             else:                                               # the stride-2 conv this layer is the gradient of: [2H,2W,cout] -> [H,W,cin]
                 Ho, Wo = src.H * stride, src.W * stride
-                d = ops.conv_desc(N, Ho, Wo, ldz, ldz, cin, src.ld, k, stride, 1, self.DT, self.DT)
+                d = ops.conv_desc(N, Ho, Wo, ldz, ldz, cin, src.ld, k, stride, 1, self.CDT, self.CDT)
                 assert d.Ho == src.H and d.Wo == src.W
             self.desc[name] = d
             z = _Act(name + '.z', N, Ho, Wo, cout, ldz, dt, dev)

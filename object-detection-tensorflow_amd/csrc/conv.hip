@@ -855,7 +855,8 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
 
 int check_desc(const odtk_conv_desc* d) {
     ODTK_REQUIRE(d != nullptr, "conv: null descriptor");
-    ODTK_REQUIRE(d->dtype == ODTK_BF16 || d->dtype == ODTK_F32, "conv: bad dtype %d", d->dtype);
+    ODTK_REQUIRE(d->dtype == ODTK_BF16 || d->dtype == ODTK_F32 || d->dtype == ODTK_F32X3, "conv: bad dtype %d", d->dtype);
+    ODTK_REQUIRE(d->dtype != ODTK_F32X3 || d->out_dtype == ODTK_F32X3, "conv: dtype ODTK_F32X3 goes with out_dtype ODTK_F32X3 (f32 tensors on both sides)");
     const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
     ODTK_REQUIRE(d->C % kch == 0 && d->ldx % kch == 0 && d->ldx >= d->C,
                  "conv: C=%d / ldx=%d must be multiples of %d", d->C, d->ldx, kch);
@@ -873,6 +874,12 @@ int check_desc(const odtk_conv_desc* d) {
 using namespace odtk;
 
 extern "C" const char* odtk_conv_last_kernel(void) { return g_last_kernel; }
+
+// ODTK_F32X3 descriptors (defined further down, next to the argument builders they use)
+static bool x3_runs(const odtk_conv_desc* d, int pass);
+static odtk_conv_desc as_f32(const odtk_conv_desc* d);
+static int conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu, hipStream_t st);
+static int conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, const float* w_t, const float* relu_src, float* dx, int accumulate, hipStream_t st);
 
 extern "C" int odtk_scratch_slot(int slot) {
     ODTK_REQUIRE(set_scratch_slot(slot) == 0, "scratch_slot: slot %d out of range (0..3)", slot);
@@ -896,6 +903,11 @@ extern "C" int odtk_conv2d_fwd(const odtk_conv_desc* d, const void* x, const voi
                                void* y, int relu, void* stream) {
     if (int e = check_desc(d)) return e;
     ODTK_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+    if (d->dtype == ODTK_F32X3) {
+        if (x3_runs(d, 0)) return conv2d_fwd_x3(d, (const float*)x, (const float*)w, bias, (float*)y, relu, (hipStream_t)stream);
+        const odtk_conv_desc f = as_f32(d);
+        return odtk_conv2d_fwd(&f, x, w, bias, y, relu, stream);
+    }
     GatherArgs a;
     memset(&a, 0, sizeof(a));
     a.x = (const char*)x; a.w = (const char*)w; a.bias = bias; a.mask = nullptr; a.y = (char*)y;
@@ -972,6 +984,11 @@ extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int ld
     ODTK_REQUIRE(dy && w_t && dx, "conv2d_dgrad: null pointer");
     const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
     ODTK_REQUIRE(lddy % kch == 0 && lddy >= d->K, "conv2d_dgrad: lddy=%d must be a multiple of %d", lddy, kch);
+    if (d->dtype == ODTK_F32X3) {
+        if (x3_runs(d, 0)) return conv2d_dgrad_x3(d, (const float*)dy, lddy, (const float*)w_t, (const float*)relu_src, (float*)dx, accumulate, (hipStream_t)stream);
+        const odtk_conv_desc f = as_f32(d);
+        return odtk_conv2d_dgrad(&f, dy, lddy, w_t, relu_src, dx, accumulate, stream);
+    }
     GatherArgs a;
     dgrad_args(a, d, dy, lddy, w_t, relu_src, dx, accumulate);      // the "input" of this conv is dy [N][Ho][Wo][lddy], its "output" is dx [N][H][W][C]
     return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
@@ -1012,113 +1029,98 @@ extern "C" int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, i
     return dispatch_gather(a, d->dtype, d->out_dtype, (hipStream_t)stream);
 }
 
-// ---- x3: the f32 engine's convolutions on the bf16 MFMA kernels by operand splitting (conv_v3.hip; include/odtk.h) -------------------------------------
+// ---- ODTK_F32X3: the f32 engine's convolutions on the bf16 MFMA kernels by operand splitting (conv_v3.hip; include/odtk.h) ------------------------------
 static inline int pad8(int v) { return (v + 7) / 8 * 8; }
+static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+static odtk_conv_desc as_f32(const odtk_conv_desc* d) { odtk_conv_desc f = *d; f.dtype = f.out_dtype = ODTK_F32; return f; }
+
+// Would the three passes of this layer run as split bf16 products?  pass 0 = forward / input gradient (both gather launches), 1 = filter gradient.
+// Policy (profiles/r04x_retinanet_f32_vs_f32x3_per_layer.md): below ~20 000 multiply-adds per output element row the split passes cost more than the exact
+// f32 MFMA kernel takes -- those layers stay exact.
+static bool x3_runs(const odtk_conv_desc* d, int pass) {
+    if (d->dtype != ODTK_F32X3 || g_force_regstage || g_v3_mode == 1 || (g_dbg2 & 4)) return false;
+    const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
+    const int ldc = pad8(d->C), ldk = pad8(d->K);
+    const long long lim = (1ll << 31) - (1ll << 21);
+    if ((long long)d->C * d->K * d->R * d->S < 20000 && !(g_dbg2 & 8)) return false;
+    if (!(d->R * d->S <= 32 && (d->stride == 1 || (d->stride == 2 && d->dil == 1)))) return false;
+    if (!(Min * 3 * ldc * 2 < lim && Mout * 3 * ldk * 2 < lim && (long long)d->K * d->R * d->S * 3 * ldc * 2 < lim && (long long)d->C * d->R * d->S * 3 * ldk * 2 < lim &&
+          3 * Min < (1ll << 31) && 3 * Mout < (1ll << 31) && Mout * d->ldy * 4 < (1ll << 31) && Min * d->ldx * 4 < (1ll << 31))) return false;
+    if (pass == 1 && d->C % 8 != 0) return false;          // the filter gradient's rows are [K][R][S][C]: the bf16 kernels write whole 8-channel chunks
+    return true;
+}
 
 extern "C" int odtk_conv2d_x3_supported(const odtk_conv_desc* d) {
-    if (check_desc(d) || d->dtype != ODTK_F32 || d->out_dtype != ODTK_F32) return 0;
-    if (g_force_regstage || g_v3_mode == 1) return 0;
-    const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
-    const int ldk = pad8(d->K);
-    return (d->C % 8 == 0 && d->ldx == d->C && d->R * d->S <= 32 && (d->stride == 1 || (d->stride == 2 && d->dil == 1)) &&
-            Min * 3 * d->C * 2 < (1ll << 31) - (1ll << 21) && Mout * 3 * ldk * 2 < (1ll << 31) - (1ll << 21) &&
-            (long long)d->K * d->R * d->S * 3 * d->C * 2 < (1ll << 31) - (1ll << 21) && 3 * Min < (1ll << 31) && 3 * Mout < (1ll << 31) &&
-            Mout * d->ldy * 4 < (1ll << 31) && Min * d->ldx * 4 < (1ll << 31)) ? 1 : 0;
+    if (check_desc(d)) return 0;
+    return (x3_runs(d, 0) ? 1 : 0) | (x3_runs(d, 1) ? 2 : 0);
 }
 
-static void x3_fwd_args(GatherArgs& a, const odtk_conv_desc* d, const void* xs, const void* w3) {
-    odtk_conv_desc b = *d;
-    b.C = b.ldx = 3 * d->C;
-    fwd_args(a, &b, xs, w3, nullptr, nullptr, 0);
+static void x3_finish_args(GatherArgs& a) {
     a.div_howo = make_fastdiv((unsigned)(a.Ho * a.Wo)); a.div_wo = make_fastdiv((unsigned)a.Wo);
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.w_bytes = (unsigned)((size_t)a.K * a.ldw * 2);
-}
-static void x3_dgrad_args(GatherArgs& a, const odtk_conv_desc* d, const void* dys, const void* wt3) {
-    dgrad_args(a, d, dys, 3 * pad8(d->K), wt3, nullptr, nullptr, 0);
-    a.div_howo = make_fastdiv((unsigned)(a.Ho * a.Wo)); a.div_wo = make_fastdiv((unsigned)a.Wo);
-    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
-    a.w_bytes = (unsigned)((size_t)a.K * a.ldw * 2);
+    a.dbg = g_dbg; a.dbg2 = g_dbg2;
 }
 
-extern "C" long long odtk_conv2d_x3_scratch_bytes(const odtk_conv_desc* d) {
-    if (!odtk_conv2d_x3_supported(d)) return 0;
+static int conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu, hipStream_t st) {
+    const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
+    const int ldc = pad8(d->C);
+    odtk_conv_desc b = as_f32(d);
+    b.C = b.ldx = 3 * ldc;
+    GatherArgs a;
+    fwd_args(a, &b, nullptr, nullptr, nullptr, nullptr, 0);
+    x3_finish_args(a);
+    const int ks = cv::gather_x3_ksplit(a);
+    const size_t xs_b = up256((size_t)Min * 3 * ldc * 2), w3_b = up256((size_t)d->K * d->R * d->S * 3 * ldc * 2);
+    char* base = nullptr;
+    if (int e = cv::x3_scratch(xs_b + w3_b + (ks > 1 ? (size_t)ks * Mout * d->ldy * 4 : 0), &base)) return e;
+    cv::launch_split3_chan(x, Min, d->C, d->ldx, base, ldc, 4, st);                                  // pixels [hi | hi | lo]
+    cv::launch_split3_chan(w, (long long)d->K * d->R * d->S, d->C, d->C, base + xs_b, ldc, 2, st);      // filters [K][R][S][hi | lo | hi]
+    a.x = base; a.w = base + xs_b;
+    cv::launch_gather_x3(a, y, (float*)(base + xs_b + w3_b), bias, relu, nullptr, 0, 0, st);
+    g_last_kernel = a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
+    ODTK_LAUNCH_CHECK();
+    return ODTK_OK;
+}
+
+static int conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, const float* w_t, const float* relu_src, float* dx, int accumulate, hipStream_t st) {
     const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
     const int ldk = pad8(d->K);
-    GatherArgs f, b;
-    x3_fwd_args(f, d, nullptr, nullptr);
-    x3_dgrad_args(b, d, nullptr, nullptr);
-    const int kf = cv::gather_x3_ksplit(f), kb = cv::gather_x3_ksplit(b);
-    const long long fwd = Min * 3 * d->C * 2 + (kf > 1 ? (long long)kf * Mout * d->ldy * 4 : 0);
-    const long long bwd = Mout * 3 * ldk * 2 + (kb > 1 ? (long long)kb * Min * d->ldx * 4 : 0);
-    const long long wg = 3 * Min * d->C * 2 + 3 * Mout * ldk * 2;
-    long long m = fwd > bwd ? fwd : bwd;
-    m = m > wg ? m : wg;
-    return m + 4096;
-}
-
-extern "C" int odtk_filter_prepare_x3(const float* w, int K, int R, int S, int C, void* w3, void* wt3, void* stream) {
-    ODTK_REQUIRE(w && (w3 || wt3) && K > 0 && R > 0 && S > 0 && C > 0 && C % 8 == 0, "filter_prepare_x3: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    if (w3) cv::launch_split3_chan(w, (long long)K * R * S, C, C, w3, C, 2, st);              // [K][R][S][hi | lo | hi]
-    if (wt3) cv::launch_filter_dgrad_x3(w, K, R, S, C, pad8(K), wt3, st);                       // [C][R][S][hi | lo | hi of pad8(K)], taps flipped
-    ODTK_LAUNCH_CHECK();
-    return ODTK_OK;
-}
-
-extern "C" int odtk_conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const void* w3, const float* bias, float* y, int relu, void* scratch,
-                                  long long scratch_bytes, void* stream) {
-    ODTK_REQUIRE(odtk_conv2d_x3_supported(d), "conv2d_fwd_x3: geometry not covered (odtk_conv2d_x3_supported)");
-    ODTK_REQUIRE(x && w3 && y && scratch && scratch_bytes >= odtk_conv2d_x3_scratch_bytes(d), "conv2d_fwd_x3: null pointer or scratch too small");
-    hipStream_t st = (hipStream_t)stream;
-    const long long Min = (long long)d->N * d->H * d->W;
-    char* xs = (char*)scratch;
-    cv::launch_split3_chan(x, Min, d->C, d->ldx, xs, d->C, 4, st);                           // [hi | hi | lo]
     GatherArgs a;
-    x3_fwd_args(a, d, xs, w3);
-    a.dbg = g_dbg; a.dbg2 = g_dbg2;
-    float* partials = (float*)(xs + ((Min * 3 * d->C * 2 + 255) / 256 * 256));
-    cv::launch_gather_x3(a, y, partials, bias, relu, st);
-    g_last_kernel = "conv_gather_v3_kernel<x3>";
+    odtk_conv_desc f = as_f32(d);
+    dgrad_args(a, &f, nullptr, 3 * ldk, nullptr, nullptr, nullptr, 0);
+    x3_finish_args(a);
+    const int ks = cv::gather_x3_ksplit(a);
+    const size_t dys_b = up256((size_t)Mout * 3 * ldk * 2), wt3_b = up256((size_t)d->C * d->R * d->S * 3 * ldk * 2);
+    char* base = nullptr;
+    if (int e = cv::x3_scratch(dys_b + wt3_b + (ks > 1 ? (size_t)ks * Min * d->ldx * 4 : 0), &base)) return e;
+    cv::launch_split3_chan(dy, Mout, d->K, lddy, base, ldk, 4, st);                                   // [hi | hi | lo]
+    cv::launch_split3_chan(w_t, (long long)d->C * d->R * d->S, d->K, lddy, base + dys_b, ldk, 2, st);   // the caller's [C][R][S][lddy] flipped filters -> [hi | lo | hi]
+    a.x = base; a.w = base + dys_b;
+    cv::launch_gather_x3(a, dx, (float*)(base + dys_b + wt3_b), nullptr, 0, relu_src, d->ldx, accumulate, st);
+    g_last_kernel = a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
 
-extern "C" int odtk_conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, const void* wt3, float* dx, void* scratch, long long scratch_bytes,
-                                    void* stream) {
-    ODTK_REQUIRE(odtk_conv2d_x3_supported(d), "conv2d_dgrad_x3: geometry not covered (odtk_conv2d_x3_supported)");
-    ODTK_REQUIRE(dy && wt3 && dx && scratch && lddy >= d->K && scratch_bytes >= odtk_conv2d_x3_scratch_bytes(d), "conv2d_dgrad_x3: null pointer or scratch too small");
-    hipStream_t st = (hipStream_t)stream;
-    const long long Mout = (long long)d->N * d->Ho * d->Wo;
-    const int ldk = pad8(d->K);
-    char* dys = (char*)scratch;
-    cv::launch_split3_chan(dy, Mout, d->K, lddy, dys, ldk, 4, st);                           // [hi | hi | lo]
-    GatherArgs a;
-    x3_dgrad_args(a, d, dys, wt3);
-    a.dbg = g_dbg; a.dbg2 = g_dbg2;
-    float* partials = (float*)(dys + ((Mout * 3 * ldk * 2 + 255) / 256 * 256));
-    cv::launch_gather_x3(a, dx, partials, nullptr, 0, st);
-    g_last_kernel = "conv_gather_v3_kernel<x3>";
-    ODTK_LAUNCH_CHECK();
-    return ODTK_OK;
-}
-
+extern "C" int odtk_colsum(const void* dy, int M, int C, int ld, int dtype, float* out, int accumulate, void* workspace, void* stream);
 extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy, float* dw, float* dbias, void* stream);
 
-extern "C" int odtk_conv2d_wgrad_x3(const odtk_conv_desc* d, const float* x, const float* dy, int lddy, float* dw, void* scratch, long long scratch_bytes,
-                                    void* stream) {
-    ODTK_REQUIRE(odtk_conv2d_x3_supported(d), "conv2d_wgrad_x3: geometry not covered (odtk_conv2d_x3_supported)");
-    ODTK_REQUIRE(x && dy && dw && scratch && lddy >= d->K && scratch_bytes >= odtk_conv2d_x3_scratch_bytes(d), "conv2d_wgrad_x3: null pointer or scratch too small");
+static int conv2d_wgrad_x3(const odtk_conv_desc* d, const float* x, const float* dy, int lddy, float* dw, float* dbias, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
     const int ldk = pad8(d->K);
-    char* xr = (char*)scratch;
-    char* dyr = xr + ((3 * Min * d->C * 2 + 255) / 256 * 256);
-    cv::launch_split3_rows(x, Min, d->C, d->ldx, xr, d->C, 2, st);                           // images [hi ; lo ; hi]
-    cv::launch_split3_rows(dy, Mout, d->K, lddy, dyr, ldk, 4, st);                            // images [hi ; hi ; lo]
+    const size_t xr_b = up256((size_t)3 * Min * d->C * 2), dyr_b = up256((size_t)3 * Mout * ldk * 2), cs_b = (size_t)2 * 256 * ((d->K + 63) / 64 * 64) * 4;
+    char* base = nullptr;
+    if (int e = cv::x3_scratch(xr_b + dyr_b + cs_b, &base)) return e;
+    cv::launch_split3_rows(x, Min, d->C, d->ldx, base, d->C, 2, st);                                  // images [hi ; lo ; hi]
+    cv::launch_split3_rows(dy, Mout, d->K, lddy, base + xr_b, ldk, 4, st);                             // images [hi ; hi ; lo]
     odtk_conv_desc b = *d;
-    b.N = 3 * d->N; b.dtype = b.out_dtype = ODTK_BF16; b.ldy = ldk;
-    return odtk_conv2d_wgrad(&b, xr, dyr, ldk, dw, nullptr, stream);      // the bf16 filter-gradient kernels, f32 result; the bias gradient is the caller's column sum
+    b.N = 3 * d->N; b.dtype = b.out_dtype = ODTK_BF16; b.ldx = d->C; b.ldy = ldk;
+    if (int e = odtk_conv2d_wgrad(&b, base, base + xr_b, ldk, dw, nullptr, stream)) return e;      // the bf16 filter-gradient kernels; their f32 result is dW
+    if (dbias)                                                                                       // the bias gradient is a plain f32 column sum of dy
+        return odtk_colsum(dy, (int)Mout, d->K, lddy, ODTK_F32, dbias, 1, base + xr_b + dyr_b, stream);
+    return ODTK_OK;
 }
 
 extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy,
@@ -1127,6 +1129,11 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     ODTK_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
     const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
     ODTK_REQUIRE(lddy % kch == 0 && lddy >= d->K, "conv2d_wgrad: lddy=%d must be a multiple of %d", lddy, kch);
+    if (d->dtype == ODTK_F32X3) {
+        if (x3_runs(d, 1)) return conv2d_wgrad_x3(d, (const float*)x, (const float*)dy, lddy, dw, dbias, stream);
+        const odtk_conv_desc f = as_f32(d);
+        return odtk_conv2d_wgrad(&f, x, dy, lddy, dw, dbias, stream);
+    }
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.x = (const char*)x; a.dy = (const char*)dy; a.dw = dw; a.dbias = dbias;

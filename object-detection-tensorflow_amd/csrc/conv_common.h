@@ -306,9 +306,9 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
 // x3: f32 convolutions on the bf16 MFMA kernels by operand splitting (conv_v3.hip)
 void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, hipStream_t st);
 void launch_split3_rows(const float* src, long long M, int C, int lds, void* dst, int ldd, int pattern, hipStream_t st);
-void launch_filter_dgrad_x3(const float* w, int K, int R, int S, int C, int ldk, void* wt3, hipStream_t st);
 int gather_x3_ksplit(const GatherArgs& a);
-int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bias, int relu, hipStream_t st);
+int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bias, int relu, const float* mask, int ldmask, int accumulate, hipStream_t st);
+int x3_scratch(size_t bytes, char** out);                  // the engine's own arena (per device and scratch slot), grown on demand, never moved
 void set_wgrad_deterministic(bool on);  // odtk_debug_set key 5: deterministic split-reduce instead of float atomics
 int set_scratch_slot(int slot);          // split-K partial buffers are per (device, slot); 0 on success
 

@@ -191,6 +191,26 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 // ---------------------------------------------------------------------------------------
 // gather kernel (forward conv, stride-1 dgrad)
 // ---------------------------------------------------------------------------------------
+// four consecutive f32 output channels c .. c+3 of pixel row m of the x3 engine's single-part launches: bias, ReLU, the producer's ReLU mask (f32 rows:
+// keep where mask > 0) and accumulation into what the row holds, then one 16-byte store.  (c < ldy; channels >= K hold zeros: their filter rows are masked)
+__device__ __forceinline__ void x3_store4(const GatherArgs& a, int m, int c, float (&o)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (a.bias && c + e < a.K) o[e] += a.bias[c + e];
+        if (a.relu) o[e] = fmaxf(o[e], 0.f);
+    }
+    float* dst = a.ws + (size_t)m * a.ldy + c;
+    if (a.accumulate) {
+        const float4 pv = *reinterpret_cast<const float4*>(dst);
+        o[0] += pv.x; o[1] += pv.y; o[2] += pv.z; o[3] += pv.w;
+    }
+    if (a.mask) {                                           // (input-gradient semantics of the bf16 epilogue: the mask gates the SUM)
+        const float4 mk = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mask) + (size_t)m * a.ldmask + c);
+        o[0] = mk.x > 0.f ? o[0] : 0.f; o[1] = mk.y > 0.f ? o[1] : 0.f; o[2] = mk.z > 0.f ? o[2] : 0.f; o[3] = mk.w > 0.f ? o[3] : 0.f;
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false, bool SPLIT = false, bool ILV = false>
 __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
     constexpr int QT = 256;
@@ -539,14 +559,8 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
                     const int c = p0 + wp * (PT / 2) + i * 32 + 8 * g + 4 * hi;
                     if (c < a.ldy) {
                         float o[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        if (a.ksplit == 1) {                // the x3 engine's single-part launch writes the f32 OUTPUT: bias / ReLU here, no finish pass
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (a.bias && c + e < a.K) o[e] += a.bias[c + e];
-                                if (a.relu) o[e] = fmaxf(o[e], 0.f);
-                            }
-                        }
-                        *reinterpret_cast<float4*>(wsp + (size_t)m * a.ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+                        if (a.ksplit == 1) x3_store4(a, m, c, o);      // the x3 engine's single-part launch writes the f32 OUTPUT: no finish pass
+                        else *reinterpret_cast<float4*>(wsp + (size_t)m * a.ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
                     }
                 }
         }
@@ -800,12 +814,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
                     const int c = p0 + prow0 + i * 32 + 8 * g + 4 * hi;
                     if (c >= a.ldy) continue;
                     float o[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (a.bias && c + e < a.K) o[e] += a.bias[c + e];
-                        if (a.relu) o[e] = fmaxf(o[e], 0.f);
-                    }
-                    *reinterpret_cast<float4*>(a.ws + (size_t)m * a.ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+                    x3_store4(a, m, c, o);
                 }
         }
         return;
@@ -1918,6 +1927,25 @@ static int conv_scratch(size_t bytes, float** out) {
     return ODTK_OK;
 }
 
+// the x3 engine's split operands (and the column-sum partials of its bias gradient): their own arena, because the kernels they feed take split-K /
+// filter-gradient partials from conv_scratch while the operands are still being read
+static ConvScratchOwner g_x3_scratch[16][SCRATCH_SLOTS];
+int x3_scratch(size_t bytes, char** out) {
+    int dev = 0;
+    ODTK_CHECK_HIP(hipGetDevice(&dev));
+    ODTK_REQUIRE(dev >= 0 && dev < 16, "conv: device index %d unsupported", dev);
+    ConvScratchOwner& o = g_x3_scratch[dev][g_scratch_slot];
+    if (o.bytes < bytes) {
+        size_t want = o.bytes ? 2 * o.bytes : ((size_t)64 << 20);
+        if (want < bytes) want = bytes;
+        void* p = nullptr;
+        ODTK_CHECK_HIP(hipMalloc(&p, want));
+        o.base = p; o.bytes = want;
+    }
+    *out = (char*)o.base;
+    return ODTK_OK;
+}
+
 static int g_num_cu = 0;
 static void query_num_cu() {
     int dev = 0;
@@ -2537,23 +2565,9 @@ __global__ void __launch_bounds__(256) split3_rows_kernel(const float* __restric
         for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(dst + ((long long)part * M + m) * ldd + c0) = ((pattern >> part) & 1) ? vl : vh;
     }
 }
-// dgrad-layout split filter: wt3 [C][R][S][3 * ldk] (taps flipped), part p of the last axis = hi | lo | hi of w[k][R-1-r][S-1-s][c]; k >= K -> 0
-__global__ void __launch_bounds__(256) filter_dgrad_x3_kernel(const float* __restrict__ w, int K, int R, int S, int C, int ldk, bf16_t* __restrict__ wt3) {
-    const long long total = (long long)C * R * S * 3 * ldk;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int kk = (int)(i % (3 * ldk));
-        long long t = i / (3 * ldk);
-        const int s_ = (int)(t % S); t /= S;
-        const int r_ = (int)(t % R);
-        const int c = (int)(t / R);
-        const int part = kk / ldk, k = kk - part * ldk;
-        bf16_t hi = 0, lo = 0;
-        if (k < K) split_hi_lo(w[(((long long)k * R + (R - 1 - r_)) * S + (S - 1 - s_)) * C + c], hi, lo);
-        wt3[i] = part == 1 ? lo : hi;
-    }
-}
-// sum of the f32 partial tiles + bias (+ ReLU) -> f32 y; pad columns (>= K) zeroed.  ws may alias y when ksplit == 1.
-__global__ void __launch_bounds__(256) splitk_finish_f32_kernel(const float* ws, int ksplit, long long M, int K, int ldy, const float* __restrict__ bias, int relu, float* y) {
+// sum of the f32 partial tiles + bias (+ ReLU, ReLU mask, accumulate: the semantics of x3_store4) -> f32 y; pad columns (>= K) zeroed
+__global__ void __launch_bounds__(256) splitk_finish_f32_kernel(const float* __restrict__ ws, int ksplit, long long M, int K, int ldy, const float* __restrict__ bias, int relu,
+                                                                const float* __restrict__ mask, int ldmask, int accumulate, float* y) {
     const int cpr = ldy >> 2;
     const long long total = M * cpr;
     const long long stride = M * ldy;
@@ -2566,11 +2580,16 @@ __global__ void __launch_bounds__(256) splitk_finish_f32_kernel(const float* ws,
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         float o[4] = {v.x, v.y, v.z, v.w};
+        float pv[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(y + m * ldy + c0); pv[0] = t.x; pv[1] = t.y; pv[2] = t.z; pv[3] = t.w; }
+        if (mask) { const float4 t = *reinterpret_cast<const float4*>(mask + m * ldmask + c0); mk[0] = t.x; mk[1] = t.y; mk[2] = t.z; mk[3] = t.w; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (c0 + e >= K) { o[e] = 0.f; continue; }
             if (bias) o[e] += bias[c0 + e];
             if (relu) o[e] = fmaxf(o[e], 0.f);
+            o[e] += pv[e];
+            if (!(mk[e] > 0.f)) o[e] = 0.f;
         }
         *reinterpret_cast<float4*>(y + m * ldy + c0) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -2586,9 +2605,6 @@ void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst
 }
 void launch_split3_rows(const float* src, long long M, int C, int lds, void* dst, int ldd, int pattern, hipStream_t st) {
     hipLaunchKernelGGL(split3_rows_kernel, dim3(grid_1d(M * (ldd >> 3))), dim3(256), 0, st, src, M, C, lds, (bf16_t*)dst, ldd, pattern, make_fastdiv((unsigned)(ldd >> 3)));
-}
-void launch_filter_dgrad_x3(const float* w, int K, int R, int S, int C, int ldk, void* wt3, hipStream_t st) {
-    hipLaunchKernelGGL(filter_dgrad_x3_kernel, dim3(grid_1d((long long)C * R * S * 3 * ldk)), dim3(256), 0, st, w, K, R, S, C, ldk, (bf16_t*)wt3);
 }
 // how many f32 partial tiles the x3 gather of `a` writes (1 = straight into the output)
 int gather_x3_ksplit(const GatherArgs& a) {
@@ -2606,7 +2622,7 @@ int gather_x3_ksplit(const GatherArgs& a) {
     return ks;
 }
 // bf16 gather (operands already split: a.x, a.w, a.C = 3 x the logical channels) -> f32 out [M][ldy] (+ bias, ReLU); `partials` holds ksplit f32 tiles when ksplit > 1
-int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bias, int relu, hipStream_t st) {
+int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bias, int relu, const float* mask, int ldmask, int accumulate, hipStream_t st) {
     const int PT = a.K <= 64 ? 64 : 128;
     a.tiles_p = ceil_div(a.K, PT);
     a.tiles_q = ceil_div(a.M, 256);
@@ -2614,7 +2630,9 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
     a.ws = a.ksplit > 1 ? partials : out;
     a.bias = a.ksplit > 1 ? nullptr : bias;
     a.relu = a.ksplit > 1 ? 0 : relu;
-    a.mask = nullptr; a.accumulate = 0;
+    a.mask = a.ksplit > 1 ? nullptr : (const char*)mask;
+    a.ldmask = ldmask;
+    a.accumulate = a.ksplit > 1 ? 0 : accumulate;
     // 3x3 / stride 1 / SAME over whole 64-channel chunks (the heads' and the pyramid's 256-channel layers: 768 split channels): the raster-run halo kernel
     const int halo = 2 * a.dil * (a.W + 1);
     if (a.ksplit == 1 && PT == 128 && !(a.dbg & 65536) && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 && a.pad_t == a.dil &&
@@ -2648,7 +2666,8 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
     if (PT == 64) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
     if (a.ksplit > 1)
-        hipLaunchKernelGGL(splitk_finish_f32_kernel, dim3(grid_1d((long long)a.M * (a.ldy >> 2))), dim3(256), 0, st, a.ws, a.ksplit, (long long)a.M, a.K, a.ldy, bias, relu, out);
+        hipLaunchKernelGGL(splitk_finish_f32_kernel, dim3(grid_1d((long long)a.M * (a.ldy >> 2))), dim3(256), 0, st, a.ws, a.ksplit, (long long)a.M, a.K, a.ldy, bias, relu,
+                           mask, ldmask, accumulate, out);
     return 0;
 }
 

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import heads, ops
-from ._lib import BF16, F32
+from ._lib import BF16, F32, F32X3
 from .warmup import F32Warmup
 
 MEAN_RGB = (123.68, 116.779, 103.979)
@@ -105,7 +105,10 @@ class FCOS(F32Warmup):
         # engine: bf16 by default on the GPU since round 3 (warmup.py: the first f32_warmup_steps optimizer steps of a run from random initialisation go through
         # an f32 twin); an explicit 'compute_dtype' is taken literally; the CPU stand-in of the library (host-logic tests) stays on f32
         # (mode 'test' keeps f32 unless asked otherwise, as ssd300.py does: the bf16 gate checks training gradients, not thresholded detections)
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16' if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')]
+        engine = config.get('compute_dtype', 'bf16' if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')
+        # 'f32x3': f32 tensors, convolution descriptors of dtype ODTK_F32X3 (three bf16 MFMA products per f32 product where that is faster: include/odtk.h)
+        self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[engine]
+        self.CDT = F32X3 if engine == 'f32x3' else self.DT
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         if self.mode == 'train':
@@ -221,7 +224,7 @@ class FCOS(F32Warmup):
             return a
 
         def conv_desc(name, src, cout, k, stride, ldy):
-            d = ops.conv_desc(N, src.H, src.W, src.ld, src.ld, cout, ldy, k, stride, 1, self.DT, self.DT)
+            d = ops.conv_desc(N, src.H, src.W, src.ld, src.ld, cout, ldy, k, stride, 1, self.CDT, self.CDT)
             self.desc[name] = d
             return d
 

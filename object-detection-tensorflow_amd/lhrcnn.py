@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from . import heads, ops
-from ._lib import BF16, F32
+from ._lib import BF16, F32, F32X3
 from .refinedet import RefineDet320
 
 ANCHOR_SCALES = [32, 64, 128, 256, 512]
@@ -93,9 +93,9 @@ class _Stage:
         self.fc1 = torch.zeros(rows, 2048, dtype=dt, device=dev)
         self.logits = torch.zeros(rows, self.ldl, dtype=dt, device=dev)
         self.pbbox = torch.zeros(rows, self.ldb, dtype=dt, device=dev)
-        self.desc = {'roi_feat_dense': ops.conv_desc(rows, 1, 1, self.ldr, self.ldr, 2048, 2048, 1, 1, 1, m.DT, m.DT),
-                     'rcnn_pconf': ops.conv_desc(rows, 1, 1, 2048, 2048, m.num_classes, self.ldl, 1, 1, 1, m.DT, m.DT),
-                     'rcnn_pbbox': ops.conv_desc(rows, 1, 1, 2048, 2048, 4, self.ldb, 1, 1, 1, m.DT, m.DT)}
+        self.desc = {'roi_feat_dense': ops.conv_desc(rows, 1, 1, self.ldr, self.ldr, 2048, 2048, 1, 1, 1, m.CDT, m.CDT),
+                     'rcnn_pconf': ops.conv_desc(rows, 1, 1, 2048, 2048, m.num_classes, self.ldl, 1, 1, 1, m.CDT, m.CDT),
+                     'rcnn_pbbox': ops.conv_desc(rows, 1, 1, 2048, 2048, 4, self.ldb, 1, 1, 1, m.CDT, m.CDT)}
         if pad is not None:
             self.d_logits = torch.zeros(rows, self.ldl, dtype=dt, device=dev)
             self.d_pbbox = torch.zeros(rows, self.ldb, dtype=dt, device=dev)
@@ -113,7 +113,7 @@ class _Stage:
 
 class LHRCNN(RefineDet320):
     NAME = 'LHRCNN'
-    DEFAULT_ENGINE = 'f32'
+    DEFAULT_ENGINE = 'f32x3'                # training: f32 tensors, convolutions / dense layers as three bf16 MFMA products where that is faster (440 -> 595 images/s); mode 'test': exact 'f32'
     L2_AFTER = None
     MOMENTUM_SLOT_SCOPE = 'rcnn/'           # the optimizer is created inside `with tf.variable_scope('rcnn')` (LH_RCNN.py:98, :171)
 
@@ -156,7 +156,10 @@ class LHRCNN(RefineDet320):
         # 'bf16' (opt-in, end of round 3): the engine's bf16 kernels everywhere, the head's outputs widened to f32 in front of the loss / decode kernels.  Built from
         # launches that are each verified on MI355X (bf16 storage of the depthwise / crop kernels, the bf16 convolutions, the casts) but NOT yet run as a whole on
         # the GPU, and not put through the gradient-direction gate of DESIGN.md 5: f32 stays the default.
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE)]
+        engine = config.get('compute_dtype', self.DEFAULT_ENGINE if config['mode'] == 'train' else 'f32')
+        # 'f32x3': f32 tensors, convolution descriptors of dtype ODTK_F32X3 (three bf16 MFMA products per f32 product where that is faster: include/odtk.h)
+        self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[engine]
+        self.CDT = F32X3 if engine == 'f32x3' else self.DT
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0

@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ConvDesc, call
+from ._lib import BF16, F32, F32X3, ConvDesc, call
 
 _TORCH_DT = {BF16: torch.bfloat16, F32: torch.float32}
 
@@ -111,29 +111,9 @@ def conv2d_dgrad_bits(d: ConvDesc, dy, lddy: int, w_t, relu_bits, dx, accumulate
     call("odtk_conv2d_dgrad_bits", C.byref(d), _p(dy), int(lddy), _p(w_t), _p(relu_bits), _p(dx), int(accumulate), _stream())
 
 
-# ---- x3: f32 convolutions on the bf16 MFMA kernels by operand splitting (include/odtk.h) ----
-def conv2d_x3_supported(d: ConvDesc) -> bool:
-    return bool(_lib.load().odtk_conv2d_x3_supported(C.byref(d)))
-
-
-def conv2d_x3_scratch_bytes(d: ConvDesc) -> int:
-    return int(_lib.load().odtk_conv2d_x3_scratch_bytes(C.byref(d)))
-
-
-def filter_prepare_x3(w, K, R, S, C_, w3, wt3):
-    call("odtk_filter_prepare_x3", _p(w), K, R, S, C_, _p(w3), _p(wt3), _stream())
-
-
-def conv2d_fwd_x3(d: ConvDesc, x, w3, bias, y, relu: bool, scratch):
-    call("odtk_conv2d_fwd_x3", C.byref(d), _p(x), _p(w3), _p(bias), _p(y), int(relu), _p(scratch), int(scratch.numel() * scratch.element_size()), _stream())
-
-
-def conv2d_dgrad_x3(d: ConvDesc, dy, lddy: int, wt3, dx, scratch):
-    call("odtk_conv2d_dgrad_x3", C.byref(d), _p(dy), int(lddy), _p(wt3), _p(dx), _p(scratch), int(scratch.numel() * scratch.element_size()), _stream())
-
-
-def conv2d_wgrad_x3(d: ConvDesc, x, dy, lddy: int, dw, scratch):
-    call("odtk_conv2d_wgrad_x3", C.byref(d), _p(x), _p(dy), int(lddy), _p(dw), _p(scratch), int(scratch.numel() * scratch.element_size()), _stream())
+def conv2d_x3_supported(d: ConvDesc) -> int:
+    """bit 0: forward / input gradient of this F32X3 descriptor run as split bf16 products, bit 1: the filter gradient does (include/odtk.h)"""
+    return int(_lib.load().odtk_conv2d_x3_supported(C.byref(d)))
 
 
 def conv2d_wgrad(d: ConvDesc, x, dy, lddy: int, dw, dbias=None):

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import heads, ops
-from ._lib import BF16, F32
+from ._lib import BF16, F32, F32X3
 
 MEAN_RGB = (123.68, 116.779, 103.979)
 FILTERS = (7, 14, 28, 56)                                     # RetinaNet.py:27 (sic)
@@ -110,13 +110,15 @@ class RetinaNet:
         self.dev = torch.device(config.get('device', 'cuda:0'))
         # f32 by default: the reference's identity-free residual units amplify bf16's rounding of the stored activations to O(1) by the
         # end of the backbone at random initialisation; 'bf16' runs (3.4x faster) but is not validated for training
-        # 'f32x3' (round 4): the f32 engine with its convolutions on the bf16 MFMA kernels by operand splitting (a = a_hi + a_lo, three bf16 products per f32
-        # product, f32 accumulation: include/odtk.h "x3"); every tensor stays f32, the products carry a 2^-16 relative error instead of bf16's 2^-8
-        # Default: 'f32x3' for training (it clears the gate of tests/test_gpu_bf16_gate.py at random initialisation: every filter gradient within cosine 0.997 of the
-        # f32 engine's, 1.000 after 300 steps; 1.9x the f32 engine's throughput), exact 'f32' for mode 'test'
+        # 'f32x3' (round 4): the f32 engine -- every tensor stays f32 -- whose convolution DESCRIPTORS say ODTK_F32X3: the library runs a layer's three passes as
+        # three bf16 MFMA products per f32 product (operand splitting, 2^-17 per product instead of bf16's 2^-9) where that is faster than the exact f32 MFMA
+        # kernel, i.e. on the 256-channel pyramid and heads, and exactly on the narrow backbone layers (include/odtk.h).  Default for training: it clears the gate of
+        # tests/test_gpu_bf16_gate.py at RANDOM INITIALISATION (every filter gradient within cosine 0.997 of the f32 engine's, 1.000 after 300 steps) at 1.9x the
+        # f32 engine's throughput; mode 'test' keeps the exact 'f32'.
         engine = config.get('compute_dtype') or ('f32x3' if config['mode'] == 'train' else 'f32')
         self.x3 = engine == 'f32x3'
         self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[engine]
+        self.CDT = F32X3 if self.x3 else self.DT             # what the convolution descriptors carry
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         if self.mode == 'train':
@@ -217,12 +219,6 @@ class RetinaNet:
             ops.cast_from_f32(self.P, self.Pc)
         if getattr(self, '_fp_batch', None) is not None:
             self._fp_batch.run()
-            self._prepare_x3()
-
-    def _prepare_x3(self):
-        for name, (w3, wt3) in self.w3.items():
-            d = self.desc[name]
-            ops.filter_prepare_x3(self._flat(name + '.w', self.P), d.K, d.R, d.S, d.C, w3, wt3)
 
     # ------------------------------------------------------------------ the graph
     def _build(self):
@@ -252,7 +248,7 @@ class RetinaNet:
             self._max_scr = max(self._max_scr, a.M * a.ld)
 
         def conv_desc(name, src, cout, k, stride, ldy):
-            d = ops.conv_desc(N, src.H, src.W, src.ld, src.ld, cout, ldy, k, stride, 1, self.DT, self.DT)
+            d = ops.conv_desc(N, src.H, src.W, src.ld, src.ld, cout, ldy, k, stride, 1, self.CDT, self.CDT)
             self.desc[name] = d
             return d
 
@@ -325,21 +321,12 @@ class RetinaNet:
         self.ws = torch.zeros(self._max_ws, dtype=torch.uint8, device=dev)
         # dgrad-layout filters (every conv but the stem)
         self.wt, entries = {}, []
-        self.w3, x3_bytes = {}, 0
         for name, cin, cout, k, _, _, _ in self.specs[1:]:
             d = self.desc[name]
             kp = self.acts[name].ld
-            # (below ~20 000 multiply-adds per output pixel row -- the 7..112-channel backbone layers -- the split passes cost more than the f32 MFMA kernel:
-            #  per-layer table of both engines at 800 x 800 batch 16, profiles/r04x_*)
-            if self.x3 and ops.conv2d_x3_supported(d) and d.C * d.K * d.R * d.S >= 20000:
-                self.w3[name] = (torch.zeros(cout * k * k * 3 * d.C, dtype=torch.bfloat16, device=dev),
-                                 torch.zeros(d.C * k * k * 3 * ops.pad_to(cout, 8), dtype=torch.bfloat16, device=dev) if self.mode == 'train' else None)
-                x3_bytes = max(x3_bytes, ops.conv2d_x3_scratch_bytes(d))
-                continue
             self.wt[name] = torch.zeros(d.C * k * k * kp, dtype=dt, device=dev)
             entries.append((self._flat(name + '.w', self.P), self.wt[name], cout, k, k, d.C, kp))
         self._fp_batch = ops.FilterPrepareBatch(entries, self.DT, dev)
-        self.x3_scratch = torch.zeros(x3_bytes, dtype=torch.uint8, device=dev) if x3_bytes else None
         # anchors (RetinaNet.py:328-355; x uses the H rate: data_shape[1] is read as the height, :330)
         flat = [v for s in ANCHOR_SIZES for hw in level_priors(s) for v in hw]
         self.anc = ops.retina_anchors(self.data_shape[1], self.shapes, [self.num_anchors] * 5, flat, dev)     # y1x1, y2x2, yx, hw
@@ -411,10 +398,7 @@ class RetinaNet:
             if kind == 'bnconv':
                 _, name, x, y, out = op
                 self._bn_relu(name, x, y, training)
-                if name in self.w3:
-                    ops.conv2d_fwd_x3(self.desc[name], y.t, self.w3[name][0], self.param(name + '.b'), out.t, False, self.x3_scratch)
-                else:
-                    ops.conv2d_fwd(self.desc[name], y.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), out.t, False)
+                ops.conv2d_fwd(self.desc[name], y.t, self._flat(name + '.w', self.Pc), self.param(name + '.b'), out.t, False)
             elif kind == 'add':
                 _, a, b, y = op
                 ops.add2d(a.t, a.ld, b.t, b.ld, y.t, y.ld, y.M, y.ld)
@@ -455,14 +439,9 @@ class RetinaNet:
             elif kind == 'bnconv':
                 _, name, x, y, out, acc = op
                 dz = self.grad_of(out)
+                ops.conv2d_wgrad(self.desc[name], y.t, dz, out.ld, self._flat(name + '.w', self.G), self._flat(name + '.b', self.G))
                 dy = self.scr_y[: y.M * y.ld].view(y.M, y.ld)
-                if name in self.w3:
-                    ops.conv2d_wgrad_x3(self.desc[name], y.t, dz, out.ld, self._flat(name + '.w', self.G), self.x3_scratch)
-                    ops.colsum(dz, out.M, out.C, out.ld, self._flat(name + '.b', self.G), True, self.ws)
-                    ops.conv2d_dgrad_x3(self.desc[name], dz, out.ld, self.w3[name][1], dy, self.x3_scratch)
-                else:
-                    ops.conv2d_wgrad(self.desc[name], y.t, dz, out.ld, self._flat(name + '.w', self.G), self._flat(name + '.b', self.G))
-                    ops.conv2d_dgrad(self.desc[name], dz, out.ld, self.wt[name], None, dy, False)
+                ops.conv2d_dgrad(self.desc[name], dz, out.ld, self.wt[name], None, dy, False)
                 sm, si = self.bnsave[name]
                 dx = self.scr_x[: x.M * x.ld].view(x.M, x.ld) if acc else self.grad_of(x)
                 ops.bn_bwd(x.t, y.t, dy, x.M, x.C, x.ld, y.ld, x.M, 0, self.param(name + '.gamma'), sm, si, 1, dx,
@@ -513,7 +492,6 @@ class RetinaNet:
         ops.sgd_momentum(self.P, self.Mom, self.G, lr, 0.9, self.weight_decay, 1.0, self.l2_partial, self.Pc if self.DT == BF16 else None)
         ops.sum_f32(self.l2_partial, self.l2_sum)
         self._fp_batch.run()
-        self._prepare_x3()
         self.global_step += 1
         return self.loss_parts.sum() / self.batch_size + self.weight_decay * self.l2_sum          # RetinaNet.py:205-213
 

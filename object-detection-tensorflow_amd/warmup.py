@@ -65,7 +65,9 @@ class F32Warmup:
     def _twin_get(self):
         if self._twin is None:
             cfg, prov = self._twin_args
-            self._twin = type(self)(dict(cfg, compute_dtype='f32', f32_warmup_steps=0), prov)
+            # (round 4: the twin's convolutions run as split bf16 products -- f32 tensors, ODTK_F32X3 descriptors: every filter gradient within cosine 0.998 of the exact
+            #  f32 engine's at random initialisation for all these classes (profiles/r04x_gate_f32x3_all_classes.md), 1.7-2.2x its throughput)
+            self._twin = type(self)(dict(cfg, compute_dtype='f32x3', f32_warmup_steps=0), prov)
             self._copy_state(self, self._twin)
             if self.dist is not None:
                 self._twin.attach_data_parallel(self.dist.red.group)

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import heads, ops
-from ._lib import BF16, F32
+from ._lib import BF16, F32, F32X3
 from .refinedet import RefineDet320
 
 BACKBONE = [(32, 3), 'P', (64, 3), 'P', (128, 3), (64, 1), (128, 3), 'P', (256, 3), (128, 1), (256, 3), 'P',
@@ -104,7 +104,10 @@ class YOLOv2(RefineDet320):
                 self.val_generator = data_provider['val_generator']
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', self.DEFAULT_ENGINE if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')]
+        engine = config.get('compute_dtype', self.DEFAULT_ENGINE if (self.dev.type == 'cuda' and self.mode == 'train') else 'f32')
+        # 'f32x3': f32 tensors, convolution descriptors of dtype ODTK_F32X3 (three bf16 MFMA products per f32 product where that is faster: include/odtk.h)
+        self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[engine]
+        self.CDT = F32X3 if engine == 'f32x3' else self.DT
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         self.global_step = 0

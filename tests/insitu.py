@@ -28,7 +28,7 @@ import mock_ops  # noqa: E402
 OUTPUTS = {
     'conv2d_fwd': ['y'], 'conv2d_fwd_pool2x2': ['y', 'y_pool'], 'conv2d_dgrad': ['dx'], 'conv2d_wgrad': ['dw', 'dbias'],
     'conv2d_fwd_bits': ['y'], 'conv2d_dgrad_bits': ['dx'],
-    'filter_prepare_x3': ['w3', 'wt3'], 'conv2d_fwd_x3': ['y'], 'conv2d_dgrad_x3': ['dx'], 'conv2d_wgrad_x3': ['dw'], 'colsum': ['out'],
+    'colsum': ['out'],
     'preprocess': ['x'], 'preprocess_norm': ['x'],
     'bn_fwd': ['mmean', 'mvar', 'save_mean', 'save_invstd', 'y'], 'bn_bwd': ['dz', 'dgamma', 'dbeta'],
     'gn_fwd': ['y', 'save'], 'gn_bwd': ['dx', 'dgamma', 'dbeta'],
@@ -53,7 +53,7 @@ OUTPUTS = {
 ON_CPU = {'ssd_loss', 'yolov3_loss', 'yolov2_loss', 'retina_loss', 'fcos_loss', 'centernet_loss', 'refinedet_loss', 'lhrcnn_rpn_loss'}
 # launches that are not shadowed: the mocked box-side front ends do nothing (the mocked loss matches / mines by itself through the oracle -- the
 # real kernels' indices are compared bit for bit by the kernel-level tests), workspaces, scratch selection, constant tables
-PASS = {'conv2d_fwd_pool2x2_fused', 'conv2d_x3_supported', 'conv2d_x3_scratch_bytes', 'conv2d_relu_bits_supported', 'ssd_match', 'softmax_ce_const', 'retina_match', 'nms_batched', 'scratch_slot', 'ssd_priors', 'retina_anchors', 'gn_workspace', 'fcos_workspace',
+PASS = {'conv2d_fwd_pool2x2_fused', 'conv2d_x3_supported', 'conv2d_relu_bits_supported', 'ssd_match', 'softmax_ce_const', 'retina_match', 'nms_batched', 'scratch_slot', 'ssd_priors', 'retina_anchors', 'gn_workspace', 'fcos_workspace',
         'yolov3_workspace', 'retina_match_workspace', 'centernet_workspace', 'yolov3_decode_candidates', 'fcos_decode_candidates', 'retina_decode',
         'refinedet_decode', 'centernet_decode', 'yolov2_decode_candidates', 'lhrcnn_match', 'lhrcnn_rpn_decode', 'lhrcnn_gather_rois', 'lhrcnn_rcnn_decode'}
 WHOLE_STORAGE_MAX = 1 << 30
@@ -85,7 +85,7 @@ COND = {
     ('bn_fwd', 'save_mean'): lambda a: a['z'][:a['M'], :a['C_']].float().abs().mean(0),
     ('bn_fwd', 'mmean'): lambda a: BN_MOM_ * a['mmean'].float().abs() + (1 - BN_MOM_) * a['z'][:a['M'], :a['C_']].float().abs().mean(0),
     ('conv2d_wgrad', 'dbias'): lambda a: a['dy'][:, :a['d'].K].float().abs().sum(0),
-    ('colsum', 'out'): lambda a: a['dy'][:a['M'], :a['C_']].float().abs().sum(0),        # (the x3 engine's bias gradient: the same cancelling sum)
+    ('colsum', 'out'): lambda a: a['dy'][:a['M'], :a['C_']].float().abs().sum(0),
     ('bn_bwd', 'dbeta'): lambda a: _bn_terms(a)[0].abs().sum(0),
     ('bn_bwd', 'dgamma'): lambda a: (lambda d, xh: (d * xh).abs().sum(0))(*_bn_terms(a)),
     ('l2norm_bwd', 'dgamma'): lambda a: (lambda v, d: (d * v / torch.sqrt(torch.clamp((v * v).sum(1, keepdim=True), min=1e-12))).abs().sum().view(1))(
@@ -325,7 +325,7 @@ def default_tol(engine_dtype):
     def tol(row):
         if row['op'] in ON_CPU:
             return 1e-4
-        if engine_dtype in ('f32', 'f32x3'):            # (x3: the restatement convolves with the filters the split copies hold; what is left is the 2^-17 split of the other operand)
+        if engine_dtype in ('f32', 'f32x3'):            # (x3: products carry 2^-17; in the Frobenius measure of one launch 4-8e-6 measured)
             return 5e-5
         if row['dtype'] == 'torch.bfloat16':
             return 6e-3 if row['op'] in twice else 4e-4

@@ -115,58 +115,9 @@ def conv2d_wgrad(d, x, dy, lddy, dw, dbias=None):
         dbias[: d.K] += dy[:, :d.K].float().sum(0)
 
 
-# ---- x3: f32 convolutions on the bf16 MFMA kernels by operand splitting (include/odtk.h).  The restatement is the plain f32 convolution on the filters the
-# split copies represent (hi + lo); the engine's three-product sum differs from it by O(2^-16) per product.
+# (ODTK_F32X3 descriptors -- f32 tensors, split bf16 arithmetic inside the library -- are restated as what they approximate: the plain f32 convolution)
 def conv2d_x3_supported(d):
-    return d.C % 8 == 0 and d.ldx == d.C and d.stride in (1, 2)
-
-
-def conv2d_x3_scratch_bytes(d):
-    return 64
-
-
-def _split_bf16(v):
-    hi = v.float().to(torch.bfloat16)
-    lo = (v.float() - hi.float()).to(torch.bfloat16)
-    return hi, lo
-
-
-def filter_prepare_x3(w, K, R, S, C_, w3, wt3):
-    hi, lo = _split_bf16(w.reshape(K, R * S, C_))
-    if w3 is not None:
-        w3.copy_(torch.cat([hi, lo, hi], dim=2).reshape(-1))
-    if wt3 is not None:
-        Kp = (K + 7) // 8 * 8
-        full = torch.zeros(C_, R * S, 3, Kp, dtype=torch.bfloat16, device=w.device)
-        for part, src in enumerate((hi, lo, hi)):
-            full[:, :, part, :K] = src.permute(2, 1, 0).flip(1)
-        wt3.copy_(full.reshape(-1))
-
-
-def conv2d_fwd_x3(d, x, w3, bias, y, relu, scratch):
-    w = w3.float().reshape(d.K, d.R * d.S, 3, d.C)
-    out = _conv(_nhwc(x, (d.N, d.H, d.W), d.C), (w[:, :, 0] + w[:, :, 1]).reshape(d.K, d.R, d.S, d.C), d)
-    if bias is not None:
-        out = out + bias.float()
-    if relu:
-        out = torch.relu(out)
-    y.zero_()
-    y[:, :d.K] = out.reshape(-1, d.K)
-
-
-def conv2d_dgrad_x3(d, dy, lddy, wt3, dx, scratch):
-    Kp = (d.K + 7) // 8 * 8
-    wt = wt3.float().reshape(d.C, d.R * d.S, 3, Kp)
-    w = (wt[:, :, 0] + wt[:, :, 1]).flip(1)[:, :, :d.K].permute(2, 1, 0).reshape(d.K, d.R, d.S, d.C)
-    x = torch.zeros(d.N, d.H, d.W, d.C, requires_grad=True, device=dy.device)
-    out = _conv(x, w, d)
-    g, = torch.autograd.grad(out, x, dy[:, :d.K].float().reshape(out.shape))
-    dx.zero_()
-    dx[:, :d.C] = g.reshape(-1, d.C)
-
-
-def conv2d_wgrad_x3(d, x, dy, lddy, dw, scratch):
-    conv2d_wgrad(d, x, dy, lddy, dw, None)
+    return 3 if d.dtype == 2 and d.C * d.K * d.R * d.S >= 20000 else 0
 
 
 def colsum(dy, M, C_, ld, out, accumulate, ws):

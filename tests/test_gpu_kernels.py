@@ -1113,6 +1113,8 @@ X3_CASES = [
     (1, 7, 7, 256, 36, 3, 1, 1),       # box head on a small level: split-K
     (3, 50, 50, 64, 256, 1, 1, 1),     # many pixel tiles
     (1, 4, 4, 2048, 256, 1, 1, 1),     # deep reduction, 16 pixels
+    (2, 50, 50, 28, 56, 3, 1, 1),      # 28 channels (RetinaNet.py:27's widths): not a multiple of 8 -- forward / input gradient split, filter gradient exact
+    (2, 30, 30, 100, 64, 3, 2, 1),     # 100 channels, stride 2
     # the raster-run halo kernel with f32 output (3x3 / stride 1 over whole 64-channel chunks, enough tiles for one part per tile), one case per variant
     (8, 64, 64, 64, 256, 3, 1, 1),     # 256-pixel tiles, double-buffered patch
     (8, 50, 50, 128, 256, 3, 1, 1),    # 192-pixel tiles (P4 of the 800-pixel pyramid); the input gradient (128 channels out of 768 split ones) too
@@ -1131,52 +1133,66 @@ def test_conv_x3_operand_splitting_against_f64(case, dev):
     w = torch.randn(K, k, k, C, generator=g) / math.sqrt(k * k * C)
     b = torch.randn(K, generator=g)
     ldy = ops.pad_to(K, 4)
-    d = ops.conv_desc(N, H, W, C, C, K, ldy, k, stride, dil, ops.F32, ops.F32)
-    assert ops.conv2d_x3_supported(d)
-    Ho, Wo = d.Ho, d.Wo
-    scratch = torch.zeros(ops.conv2d_x3_scratch_bytes(d), dtype=torch.uint8, device=dev)
-    w3 = torch.zeros(K * k * k * 3 * C, dtype=torch.bfloat16, device=dev)
-    wt3 = torch.zeros(C * k * k * 3 * ops.pad_to(K, 8), dtype=torch.bfloat16, device=dev)
-    wd = w.to(dev).contiguous()
-    ops.filter_prepare_x3(wd, K, k, k, C, w3, wt3)
-    # the split copies are exactly hi | lo | hi of the filters
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
-    got3 = w3.cpu().reshape(K, k * k, 3, C)
-    assert torch.equal(got3[:, :, 0], hi.reshape(K, k * k, C)) and torch.equal(got3[:, :, 1], lo.reshape(K, k * k, C)) and torch.equal(got3[:, :, 2], got3[:, :, 0])
-    xd = to_rows(x, C, torch.float32, dev)
-    yd = torch.full((N * Ho * Wo, ldy), 7.0, device=dev)
-    ops.conv2d_fwd_x3(d, xd, w3, b.to(dev), yd, True, scratch)
-    torch.cuda.synchronize()
-    xr = x.double().requires_grad_(True)
-    wr = w.double().requires_grad_(True)
-    z_ref = _ref_conv(xr, wr, b.double(), stride, dil)
-    y_ref = F.relu(z_ref).detach()
-    y = from_rows(yd, N, Ho, Wo, K).double()
-    tol = 3e-5
-    assert float((y - y_ref).abs().max()) <= tol * (float(y_ref.abs().max()) + 1e-6), "x3 forward"
-    if ldy > K:
-        assert float(yd[:, K:].abs().max()) == 0.0
-    # the f32 kernel on the same operands: the two engines agree to the same bound
-    w_c = torch.empty(K * k * k * C, device=dev)
-    w_t = torch.empty(C * k * k * ldy, device=dev)
-    ops.filter_prepare(wd, K, k, k, C, ldy, ops.F32, w_c, w_t)
-    yf = torch.zeros_like(yd)
-    ops.conv2d_fwd(d, xd, w_c, b.to(dev), yf, True)
-    assert float((yf - yd).abs().max()) <= tol * (float(y_ref.abs().max()) + 1e-6)
-    # backward
-    dy = torch.randn(N, Ho, Wo, K, generator=g) * torch.exp(torch.randn(N, Ho, Wo, 1, generator=g))
-    z_ref.backward(dy.double())
-    dyd = to_rows(dy, ldy, torch.float32, dev)
-    dxd = torch.full((N * H * W, C), 7.0, device=dev)
-    ops.conv2d_dgrad_x3(d, dyd, ldy, wt3, dxd, scratch)
-    dwd = torch.zeros(K, k, k, C, device=dev)
-    ops.conv2d_wgrad_x3(d, xd, dyd, ldy, dwd, scratch)
-    torch.cuda.synchronize()
-    dx = from_rows(dxd, N, H, W, C).double()
-    assert float((dx - xr.grad).abs().max()) <= tol * (float(xr.grad.abs().max()) + 1e-6), "x3 input gradient"
-    assert float((dwd.cpu().double() - wr.grad).abs().max()) <= tol * (float(wr.grad.abs().max()) + 1e-6), "x3 filter gradient"
-    # accumulation into dw (the caller's zeroed gradient buffer): a second call doubles it
-    ops.conv2d_wgrad_x3(d, xd, dyd, ldy, dwd, scratch)
-    torch.cuda.synchronize()
-    assert float((dwd.cpu().double() - 2 * wr.grad).abs().max()) <= 2 * tol * (float(wr.grad.abs().max()) + 1e-6)
+    d = ops.conv_desc(N, H, W, C, C, K, ldy, k, stride, dil, ops.F32X3, ops.F32X3)
+    df = ops.conv_desc(N, H, W, C, C, K, ldy, k, stride, dil, ops.F32, ops.F32)
+    ops.debug_set(6, 8)                                   # every covered geometry through the split path, also below the policy's size threshold
+    try:
+        assert ops.conv2d_x3_supported(d) == (3 if C % 8 == 0 else 1) and ops.conv2d_x3_supported(df) == 0
+        Ho, Wo = d.Ho, d.Wo
+        wd = w.to(dev).contiguous()
+        w_c = torch.empty(K * k * k * C, device=dev)
+        w_t = torch.empty(C * k * k * ldy, device=dev)
+        ops.filter_prepare(wd, K, k, k, C, ldy, ops.F32, w_c, w_t)
+        xd = to_rows(x, C, torch.float32, dev)
+        yd = torch.full((N * Ho * Wo, ldy), 7.0, device=dev)
+        ops.conv2d_fwd(d, xd, w_c, b.to(dev), yd, True)
+        assert 'x3' in ops.conv_last_kernel()
+        torch.cuda.synchronize()
+        xr = x.double().requires_grad_(True)
+        wr = w.double().requires_grad_(True)
+        z_ref = _ref_conv(xr, wr, b.double(), stride, dil)
+        y_ref = F.relu(z_ref).detach()
+        y = from_rows(yd, N, Ho, Wo, K).double()
+        tol = 3e-5
+        assert float((y - y_ref).abs().max()) <= tol * (float(y_ref.abs().max()) + 1e-6), "x3 forward"
+        if ldy > K:
+            assert float(yd[:, K:].abs().max()) == 0.0
+        # the exact f32 kernel on the same operands: the two engines agree to the same bound
+        yf = torch.zeros_like(yd)
+        ops.conv2d_fwd(df, xd, w_c, b.to(dev), yf, True)
+        assert 'x3' not in ops.conv_last_kernel()
+        assert float((yf - yd).abs().max()) <= tol * (float(y_ref.abs().max()) + 1e-6)
+        # backward
+        dy = torch.randn(N, Ho, Wo, K, generator=g) * torch.exp(torch.randn(N, Ho, Wo, 1, generator=g))
+        z_ref.backward(dy.double())
+        dyd = to_rows(dy, ldy, torch.float32, dev)
+        dxd = torch.full((N * H * W, C), 7.0, device=dev)
+        ops.conv2d_dgrad(d, dyd, ldy, w_t, None, dxd, False)
+        assert 'x3' in ops.conv_last_kernel()
+        dwd = torch.zeros(K, k, k, C, device=dev)
+        dbd = torch.zeros(K, device=dev)
+        ops.conv2d_wgrad(d, xd, dyd, ldy, dwd, dbd)
+        torch.cuda.synchronize()
+        dx = from_rows(dxd, N, H, W, C).double()
+        sx = float(xr.grad.abs().max()) + 1e-6
+        assert float((dx - xr.grad).abs().max()) <= tol * sx, "x3 input gradient"
+        sw = float(wr.grad.abs().max()) + 1e-6
+        assert float((dwd.cpu().double() - wr.grad).abs().max()) <= tol * sw, "x3 filter gradient"
+        db_ref = dy.double().reshape(-1, K).sum(0)
+        assert float((dbd.cpu().double() - db_ref).abs().max()) <= 1e-5 * float(dy.double().reshape(-1, K).abs().sum(0).max()), "bias gradient"
+        # accumulation into dw / dbias (the caller's zeroed gradient buffers): a second call doubles them
+        ops.conv2d_wgrad(d, xd, dyd, ldy, dwd, dbd)
+        torch.cuda.synchronize()
+        assert float((dwd.cpu().double() - 2 * wr.grad).abs().max()) <= 2 * tol * sw
+        assert float((dbd.cpu().double() - 2 * db_ref).abs().max()) <= 2e-5 * float(dy.double().reshape(-1, K).abs().sum(0).max())
+        # the input gradient through a producer's ReLU mask, accumulated into what dx holds ((prev + new) where src > 0, else 0)
+        src = torch.randn(N, H, W, C, generator=g)
+        prev = torch.randn(N, H, W, C, generator=g)
+        srcd = to_rows(src, C, torch.float32, dev)
+        dx2 = to_rows(prev, C, torch.float32, dev)
+        ops.conv2d_dgrad(d, dyd, ldy, w_t, srcd, dx2, True)
+        torch.cuda.synchronize()
+        exp = (xr.grad + prev.double()) * (src > 0)
+        assert float((from_rows(dx2, N, H, W, C).double() - exp).abs().max()) <= tol * (float(exp.abs().max()) + 1e-6), "masked, accumulated input gradient"
+    finally:
+        ops.debug_set(6, 0)

@@ -203,7 +203,8 @@ def _cfg(mode, batch, **kw):
     return cfg
 
 
-def test_training_steps_vs_oracle():
+@pytest.mark.parametrize('engine', ['f32', 'f32x3'])
+def test_training_steps_vs_oracle(engine):
     """two steps from the parameters of the golden fixture: both losses against oracle/lhrcnn_ref.train_step (which the reference's own class pins,
     tests/golden/lhrcnn_train.npz -- checked here as well), every parameter and moving statistic after the first step"""
     import odtk
@@ -213,7 +214,7 @@ def test_training_steps_vs_oracle():
     gt = LR.synthetic_gt(2, 320, 416, 911)
     p = LR.init_params(71)
     gold = np.load(os.path.join(GOLD, 'lhrcnn_train.npz'))
-    m = odtk.LHRCNN(_cfg('train', 2, rpn_first_step=1), {'data_shape': [320, 416, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
+    m = odtk.LHRCNN(_cfg('train', 2, rpn_first_step=1, compute_dtype=engine), {'data_shape': [320, 416, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None})
     m.load_oracle_params(p)
     m.set_batch(imgs, gt)
     q = {k: v.clone() for k, v in p.items()}
@@ -222,7 +223,9 @@ def test_training_steps_vs_oracle():
         loss = float(m.train_step(0.003))
         rpn, rcnn = LR.train_step(q, mom, imgs, gt, 0.003)
         got_rpn, got_rcnn = float(m.last_losses[0]), float(m.last_losses[1])
-        tol = 2e-4 if step == 0 else 5e-2       # step 2 starts from parameters that agree to ~1e-6: an NMS pick or a 0.5 / 0.3 IoU decision on a near-tie may flip (the
+        # ('f32x3': the FIRST step meets the exact engine's bounds -- losses 2e-4, every update's cosine > 0.999; the second step starts from an update of lr 0.003 that
+        #  takes the losses from 9 to 32, and the 2^-17 products move that overshoot by 6-9 %: measured 32.8 / 36.7 against 31.1 / 33.7)
+        tol = 2e-4 if step == 0 else (0.15 if engine == 'f32x3' else 5e-2)       # step 2 starts from parameters that agree to ~1e-6: an NMS pick or a 0.5 / 0.3 IoU decision on a near-tie may flip (the
         #                                          reference-vs-oracle fixture saw 1.3 % from one such flip), measured 3 runs: within 5e-3
         # the R-CNN loss gets a looser first-step bound than the RPN loss: crops of proposals clamped to the picture put their last sample row ON the border, where
         # the last bits of the proposal decide inside / extrapolated (tests/test_hip_cpu.py has the measurement); measured here: 2e-4 on both
@@ -312,7 +315,7 @@ def test_detections_vs_reference_class():
     assert es < 1e-3 and eb < 1e-3, (es, eb)
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f32x3'])
 def test_every_launch_in_situ_at_the_driver_shape(dtype):
     """testlhrcnn.py's shape -- 700 x 1100, batch 32 -- on the GPU: every launch of a whole training step is re-executed in plain f32 PyTorch from the engine's
     own stored inputs of that launch and compared (tests/insitu.py, as for the other classes in tests/test_gpu_insitu_configs.py): 27 convolutions / dense

@@ -53,9 +53,8 @@ def test_yolov3_training_step_host_logic():
 
 @pytest.mark.parametrize('engine', ['f32', 'f32x3'])
 def test_retinanet_training_step_host_logic(engine):
-    # 'f32x3': the stand-ins convolve with the filters the split copies hold (hi + lo: 16-17 bits of each weight), which this network's gradient at random
-    # initialisation magnifies to per cents (tests/test_gpu_retinanet_model.py) -- the wiring (split filters refreshed after the step, the caller-side bias
-    # gradient, shared scratch) is what this case checks
+    # 'f32x3': the class's descriptors say ODTK_F32X3 (f32 tensors, split bf16 products inside the library); the stand-ins restate those launches as the f32
+    # convolutions they approximate, so this case checks that nothing else of the class depends on the engine
     import odtk
     from oracle import retinanet_net_ref as NR
     from oracle import retinanet_ref as RR
@@ -64,10 +63,7 @@ def test_retinanet_training_step_host_logic(engine):
            'data_shape': [128, 128, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'data_format': 'channels_last', 'batch_size': 2,
            'gamma': 2.0, 'alpha': 0.25, 'nms_score_threshold': 0.8, 'nms_max_boxes': 10, 'nms_iou_threshold': 0.45, 'verbose': False,
            'compute_dtype': engine, 'device': 'cpu'}
-    # (x3 at 192 x 192: at 128 x 128 the coarsest level is ONE pixel and its batch norm sees two rows -- a sign function whose gradient is round-off times
-    #  1 / sqrt(eps); with perturbed filters that noise, not the signal, is what reaches the backbone through P7 -> P6 -> P5)
-    size = 192 if engine == 'f32x3' else 128
-    cfg['data_shape'] = [size, size, 3]
+    size = 128
     g = torch.Generator().manual_seed(90)
     imgs = (torch.rand(2, size, size, 3, generator=g) * 255).round()
     gt = RR.synthetic_gt(2, size, 91)
@@ -86,24 +82,19 @@ def test_retinanet_training_step_host_logic(engine):
         mom = {k: torch.zeros_like(v) for k, v in p.items() if k in NR.trainable_names(p)}
         total, data, grads = NR.train_step(q, mom, imgs, gt, 0.01, relu_masks=masks)
         x3 = engine == 'f32x3'
-        assert (len(m.w3) >= 50) == x3
-        assert abs(loss - total) < (1e-3 if x3 else 1e-4) * abs(total)
+        assert (sum(1 for d in m.desc.values() if d.dtype == 2) == len(m.desc)) == x3 and m.DT == odtk.ops.F32
+        assert abs(loss - total) < 1e-4 * abs(total)
         worst = 0.
         for k in NR.trainable_names(p):
             want = grads[k] - 1e-4 * p[k]
             if k.endswith('.b') and float(want.norm()) < 1e-4 * float(grads[k[:-2] + '.w'].norm()):
                 continue                                   # only the ten prediction convs have a live bias gradient
             worst = max(worst, _rel(m.get_param(k, m.G), want))
-            assert _rel(m.get_param(k, m.G), want) < (0.1 if x3 else 5e-3), k
+            assert _rel(m.get_param(k, m.G), want) < 5e-3, k
         print(engine, 'worst relative gradient error', worst)
         after = m.export_params()
         for k in ('l0.w', 'l30.gamma', 'l65.w', 'l76.b', 'l121.w', 'l1.mmean', 'l121.mvar'):
-            assert _rel(after[k], q[k]) < (3e-2 if x3 else 1e-4), k       # (lr 0.01 x a gradient of norm ~1e3: the step is most of the stem's weights)
-        if x3:                                            # the split copies follow the optimizer step
-            name = 'l65'
-            d = m.desc[name]
-            hi = m.param(name + '.w').reshape(d.K, d.R * d.S, d.C).to(torch.bfloat16)
-            assert torch.equal(m.w3[name][0].reshape(d.K, d.R * d.S, 3, d.C)[:, :, 0], hi)
+            assert _rel(after[k], q[k]) < 1e-4, k
 
 
 def test_fcos_training_step_host_logic():

@@ -1,5 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out/r04x
-timeout 1500 python -m pytest tests/test_gpu_insitu_configs.py -q -m gpu -k "retinanet-f32x3" -x > gpurun_out/r04x/insitu_x3.log 2>&1
-tail -3 gpurun_out/r04x/insitu_x3.log
-grep -n "in-situ retinanet" -A12 gpurun_out/r04x/insitu_x3.log | cut -c1-150
+timeout 2600 python -m pytest tests/test_gpu_lhrcnn.py tests/test_gpu_refinedet.py tests/test_gpu_refinedet_model.py tests/test_gpu_pfpnet_model.py tests/test_gpu_bf16_gate.py tests/test_gpu_yolov2.py tests/test_gpu_fcos_model.py tests/test_gpu_centernet_model.py tests/test_gpu_dist.py -q -m gpu 2>&1 > gpurun_out/r04x/affected.log
+tail -12 gpurun_out/r04x/affected.log | cut -c1-300

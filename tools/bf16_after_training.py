@@ -112,8 +112,8 @@ def compare_engines(name, a='f32', b='f32x3', batch=2, size=None, verbose=True):
 
 def main():
     name = sys.argv[1]
-    if len(sys.argv) > 2 and sys.argv[2] == 'x3':
-        run(name, 300, 2, 1e-3, engine='f32x3')
+    if len(sys.argv) > 2 and sys.argv[2] == 'x3':                       # the operand-splitting engine through the same gate
+        run(name, 300, int(sys.argv[3]) if len(sys.argv) > 3 else 2, 1e-3, engine='f32x3')
         return
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4

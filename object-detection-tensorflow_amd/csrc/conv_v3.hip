@@ -1989,7 +1989,8 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     // wide maps (conv2_x, W = 150): single-buffer variant, groups 0..3 / 4..8 of the next chunk ride on taps 3 / 6 (dbg bit 26 = off, A/B)
     // (round 2: rows of 96 .. 143 pixels too -- CenterNet / FCOS 128, YOLOv3 104, YOLOv2 120 -- with their own early-refill group counts G1, G2)
     // (and rows of 160 .. 175 pixels -- conv2_x of the 320-pixel models -- on a 608-row patch)
-    const bool v6_wide = halo > 160 && halo <= 352 && a.dil * a.W >= 96 && !(a.dbg & (1 << 26));
+    // (round 4: rows of 80 .. 95 pixels -- conv3_x of the 320-pixel models, 162 halo rows: two more than the double-buffered patch holds -- on a 448-row patch)
+    const bool v6_wide = halo > 160 && halo <= 352 && a.dil * a.W >= 80 && !(a.dbg & (1 << 26));
     const bool v6_wide_hi = v6_wide && a.dil * a.W >= 144 && halo <= 320;   // what the 512-pixel tile variants are instantiated for
     const bool v6_ok = !(a.dbg & 65536) && PT == 128 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
                        a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && (halo <= 160 || v6_wide) && a.Kdim == 9 * a.C;
@@ -2053,7 +2054,8 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         else if (a.dil * a.W >= 144) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 9>), dim3(grid), dim3(256), 0, st, a);
         else if (a.dil * a.W >= 128) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 8>), dim3(grid), dim3(256), 0, st, a);
         else if (a.dil * a.W >= 112) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 7>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 6>), dim3(grid), dim3(256), 0, st, a);
+        else if (a.dil * a.W >= 96) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 6>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v6_kernel<14, false, 2, 5>), dim3(grid), dim3(256), 0, st, a);
         return 0;
     }
     const bool db = (a.dbg & 32) == 0;      // fragment double buffering (default on; dbg bit 5 turns it off)
@@ -2652,12 +2654,14 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
             return 0;
         }
         if (halo <= 160) { hipLaunchKernelGGL((conv_gather_v6_kernel<13, true, 0, 0, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a); return 0; }
-        if (halo <= 352 && a.dil * a.W >= 96 && a.dil * a.W < 112) {
-            hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 6, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
-            return 0;
-        }
-        if (halo <= 352 && a.dil * a.W >= 128 && a.dil * a.W < 144) {
-            hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 8, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
+        if (halo <= 352 && a.dil * a.W >= 80) {             // rows of 80 .. 175 pixels: single patch buffer, early refill (the group counts of launch_gather_v3)
+            const int w = a.dil * a.W;
+            if (halo > 320) hipLaunchKernelGGL((conv_gather_v6_kernel<19, false, 5, 10, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
+            else if (w >= 144) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 9, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
+            else if (w >= 128) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 4, 8, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
+            else if (w >= 112) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 7, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
+            else if (w >= 96) hipLaunchKernelGGL((conv_gather_v6_kernel<18, false, 3, 6, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gather_v6_kernel<14, false, 2, 5, 2, 2, 4, false, true>), dim3(tiles), dim3(256), 0, st, a);
             return 0;
         }
         a.ksplit = 1;                                     // other row lengths: the 8-wave kernel below

@@ -104,6 +104,8 @@ V3_EXTRA_CASES = [
     (2, 24, 120, 128, 160, 3, 1, 1),  # ... 120 (G1 = 3, G2 = 7)
     (1, 21, 160, 128, 128, 3, 1, 1),  # ... 160 and 175: the 608-row patch (G1 = 5, G2 = 10)
     (1, 12, 175, 64, 130, 3, 1, 1),
+    (2, 50, 80, 128, 128, 3, 1, 1),   # ... rows of 80-95 pixels (round 4: conv3_x of the 320-pixel models): 448-row patch (G1 = 2, G2 = 5), two chunks
+    (2, 40, 40, 128, 160, 3, 1, 2),   # ... dilation 2 (dil * W = 80, 164 halo rows)
     (24, 75, 75, 64, 200, 3, 1, 1),   # 128 x 512 tiles of four 128 x 128 wave tiles (>= 2 rounds of 256 workgroups): ragged last tile, channel tail
     (24, 19, 19, 64, 512, 3, 1, 1),   # 128 x 192 tiles (136 workgroups of 256 pixels would leave CUs idle, 184 of 192 pixels fit one round)
     (6, 20, 17, 256, 512, 3, 1, 1),   # four-wave filter gradient (256 x 256 tiles, fixture wgrad-v8): two k tiles, nine column tiles, ragged last 32-pixel slab
@@ -1121,6 +1123,11 @@ X3_CASES = [
     (2, 100, 100, 128, 256, 3, 1, 1),  # rows of 96-111 pixels (P3): single patch buffer with early refill; input gradient too
     (1, 130, 130, 64, 189, 3, 1, 1),   # rows of 128-143 pixels, a channel tail
     (32, 64, 64, 64, 160, 3, 1, 1),    # 512-pixel tiles
+    (1, 150, 150, 64, 256, 3, 1, 1),   # rows of 144-159 pixels
+    (1, 160, 160, 64, 128, 3, 1, 1),   # rows of 160-175 pixels (conv2_x of the 320-pixel models)
+    (2, 120, 120, 64, 130, 3, 1, 1),   # rows of 112-127 pixels
+    (4, 80, 80, 64, 256, 3, 1, 1),     # rows of 80-95 pixels (conv3_x of the 320-pixel models): 448-row single patch buffer
+    (3, 95, 95, 64, 200, 3, 1, 1),     # ... its longest row: the patch is exactly full
 ]
 
 

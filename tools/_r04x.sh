@@ -1,4 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r04x
-timeout 2600 python -m pytest tests/test_gpu_lhrcnn.py tests/test_gpu_refinedet.py tests/test_gpu_refinedet_model.py tests/test_gpu_pfpnet_model.py tests/test_gpu_bf16_gate.py tests/test_gpu_yolov2.py tests/test_gpu_fcos_model.py tests/test_gpu_centernet_model.py tests/test_gpu_dist.py -q -m gpu 2>&1 > gpurun_out/r04x/affected.log
-tail -12 gpurun_out/r04x/affected.log | cut -c1-300
+timeout 1200 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "x3 or test_conv_v3_engine or legacy_engine_extra" -x 2>&1 | tail -3
+timeout 300 python tools/refinedet_bench.py f32x3 32 5 2>&1 | grep "images/s"
+timeout 300 python tools/refinedet_bench.py bf16 32 5 2>&1 | grep "images/s"
+timeout 300 python tools/pfpnet_bench.py f32x3 32 5 2>&1 | grep "images/s"

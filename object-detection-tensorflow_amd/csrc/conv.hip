@@ -1032,6 +1032,9 @@ extern "C" int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, i
 // ---- ODTK_F32X3: the f32 engine's convolutions on the bf16 MFMA kernels by operand splitting (conv_v3.hip; include/odtk.h) ------------------------------
 static inline int pad8(int v) { return (v + 7) / 8 * 8; }
 static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+// pitch (elements) of a pixel row that stores two split parts of ldc channels: 128 bytes more than the parts need, so that consecutive rows do not sit a power
+// of two apart (measured: with 2 ldc exactly -- 1 KiB rows for 256 channels -- the halo kernels' patch DMA ran 5-7 % slower than on the 1.5 KiB rows of three parts)
+static inline int x3_pitch(int ldc) { return 2 * ldc + 64; }
 static odtk_conv_desc as_f32(const odtk_conv_desc* d) { odtk_conv_desc f = *d; f.dtype = f.out_dtype = ODTK_F32; return f; }
 
 // Would the three passes of this layer run as split bf16 products?  pass 0 = forward / input gradient (both gather launches), 1 = filter gradient.
@@ -1044,7 +1047,7 @@ static bool x3_runs(const odtk_conv_desc* d, int pass) {
     const long long lim = (1ll << 31) - (1ll << 21);
     if ((long long)d->C * d->K * d->R * d->S < 20000 && !(g_dbg2 & 8)) return false;
     if (!(d->R * d->S <= 32 && (d->stride == 1 || (d->stride == 2 && d->dil == 1)))) return false;
-    if (!(Min * 3 * ldc * 2 < lim && Mout * 3 * ldk * 2 < lim && (long long)d->K * d->R * d->S * 3 * ldc * 2 < lim && (long long)d->C * d->R * d->S * 3 * ldk * 2 < lim &&
+    if (!(Min * (2 * ldc + 64) * 2 < lim && Mout * (2 * ldk + 64) * 2 < lim && 3 * Min * ldc * 2 < lim && 3 * Mout * ldk * 2 < lim && (long long)d->K * d->R * d->S * 3 * ldc * 2 < lim && (long long)d->C * d->R * d->S * 3 * ldk * 2 < lim &&
           3 * Min < (1ll << 31) && 3 * Mout < (1ll << 31) && Mout * d->ldy * 4 < (1ll << 31) && Min * d->ldx * 4 < (1ll << 31))) return false;
     if (pass == 1 && d->C % 8 != 0) return false;          // the filter gradient's rows are [K][R][S][C]: the bf16 kernels write whole 8-channel chunks
     return true;
@@ -1066,16 +1069,18 @@ static int conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const float* w
     const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
     const int ldc = pad8(d->C);
     odtk_conv_desc b = as_f32(d);
-    b.C = b.ldx = 3 * ldc;
+    b.C = 3 * ldc;                                          // the reduction sees [hi | hi | lo] ...
+    b.ldx = x3_pitch(ldc);                                  // ... of pixel rows that store [hi | lo] (GatherArgs::x3c)
     GatherArgs a;
     fwd_args(a, &b, nullptr, nullptr, nullptr, nullptr, 0);
+    a.x3c = ldc;
     x3_finish_args(a);
     const int ks = cv::gather_x3_ksplit(a);
-    const size_t xs_b = up256((size_t)Min * 3 * ldc * 2), w3_b = up256((size_t)d->K * d->R * d->S * 3 * ldc * 2);
+    const size_t xs_b = up256((size_t)Min * x3_pitch(ldc) * 2), w3_b = up256((size_t)d->K * d->R * d->S * 3 * ldc * 2);
     char* base = nullptr;
     if (int e = cv::x3_scratch(xs_b + w3_b + (ks > 1 ? (size_t)ks * Mout * d->ldy * 4 : 0), &base)) return e;
-    cv::launch_split3_chan(x, Min, d->C, d->ldx, base, ldc, 4, st);                                  // pixels [hi | hi | lo]
-    cv::launch_split3_chan(w, (long long)d->K * d->R * d->S, d->C, d->C, base + xs_b, ldc, 2, st);      // filters [K][R][S][hi | lo | hi]
+    cv::launch_split3_chan(x, Min, d->C, d->ldx, base, ldc, 2, 2, x3_pitch(ldc), st);                               // pixels [hi | lo], read as [hi | hi | lo]
+    cv::launch_split3_chan(w, (long long)d->K * d->R * d->S, d->C, d->C, base + xs_b, ldc, 2, 3, 3 * ldc, st);   // filters [K][R][S][hi | lo | hi]
     a.x = base; a.w = base + xs_b;
     cv::launch_gather_x3(a, y, (float*)(base + xs_b + w3_b), bias, relu, nullptr, 0, 0, st);
     g_last_kernel = a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
@@ -1089,13 +1094,15 @@ static int conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, c
     GatherArgs a;
     odtk_conv_desc f = as_f32(d);
     dgrad_args(a, &f, nullptr, 3 * ldk, nullptr, nullptr, nullptr, 0);
+    a.ldx = x3_pitch(ldk);                                  // dy rows store [hi | lo], the reduction (a.C = 3 ldk) reads [hi | hi | lo]
+    a.x3c = ldk;
     x3_finish_args(a);
     const int ks = cv::gather_x3_ksplit(a);
-    const size_t dys_b = up256((size_t)Mout * 3 * ldk * 2), wt3_b = up256((size_t)d->C * d->R * d->S * 3 * ldk * 2);
+    const size_t dys_b = up256((size_t)Mout * x3_pitch(ldk) * 2), wt3_b = up256((size_t)d->C * d->R * d->S * 3 * ldk * 2);
     char* base = nullptr;
     if (int e = cv::x3_scratch(dys_b + wt3_b + (ks > 1 ? (size_t)ks * Min * d->ldx * 4 : 0), &base)) return e;
-    cv::launch_split3_chan(dy, Mout, d->K, lddy, base, ldk, 4, st);                                   // [hi | hi | lo]
-    cv::launch_split3_chan(w_t, (long long)d->C * d->R * d->S, d->K, lddy, base + dys_b, ldk, 2, st);   // the caller's [C][R][S][lddy] flipped filters -> [hi | lo | hi]
+    cv::launch_split3_chan(dy, Mout, d->K, lddy, base, ldk, 2, 2, x3_pitch(ldk), st);                                // [hi | lo], read as [hi | hi | lo]
+    cv::launch_split3_chan(w_t, (long long)d->C * d->R * d->S, d->K, lddy, base + dys_b, ldk, 2, 3, 3 * ldk, st);   // the caller's [C][R][S][lddy] flipped filters -> [hi | lo | hi]
     a.x = base; a.w = base + dys_b;
     cv::launch_gather_x3(a, dx, (float*)(base + dys_b + wt3_b), nullptr, 0, relu_src, d->ldx, accumulate, st);
     g_last_kernel = a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";

@@ -141,7 +141,10 @@ struct GatherArgs {
     int tiles_p, tiles_q;
     FastDiv div_howo, div_wo;
     int dbg;           // perf experiments only (odtk_debug_set key 2): bit0 skip pixel-operand DMA, bit1 skip filter DMA after slab 0
-    int dbg2;          // dispatch A/B switches that leave results intact (odtk_debug_set key 6): none defined at present
+    int dbg2;          // dispatch A/B switches that leave results intact (odtk_debug_set key 6): bit 2 = ODTK_F32X3 descriptors on the exact f32 kernels, bit 3 = on the
+                       // split path wherever it is supported (also below the size policy: tests)
+    int x3c;                 // x3 engine: channels per split part of the PIXEL operand, stored [hi | lo]; reduction channel c reads channel c - x3c when c >= x3c (the
+                             // virtual layout [hi | hi | lo] against filters [hi | lo | hi]); 0 = plain operand
     unsigned x_bytes, w_bytes;   // extents of x and w for the buffer-addressed DMA (range check = zero fill)
     int ksplit;        // split-K: blocks per tile (1 = off) and their f32 partial tiles [ksplit][M][ldy]
     float* ws;
@@ -304,7 +307,7 @@ int launch_wgrad_c8(WgradArgs& a, hipStream_t st);
 bool wgrad_v3_supported(const WgradArgs& a, int dtype);
 int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
 // x3: f32 convolutions on the bf16 MFMA kernels by operand splitting (conv_v3.hip)
-void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, hipStream_t st);
+void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, int nparts, int ldrow, hipStream_t st);
 void launch_split3_rows(const float* src, long long M, int C, int lds, void* dst, int ldd, int pattern, hipStream_t st);
 int gather_x3_ksplit(const GatherArgs& a);
 int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bias, int relu, const float* mask, int ldmask, int accumulate, hipStream_t st);

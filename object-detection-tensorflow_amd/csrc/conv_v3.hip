@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         const long long toff = ((long long)tr * a.W + ts) * a.ldx * 2ll + (long long)kc * 2ll;
         const bool first = klin < 64;
         if (BUF) {
-            const unsigned toff32 = (unsigned)((tr * a.W + ts) * a.ldx * 2 + kc * 2);
+            const int kcx = (SPLIT && a.x3c && kc >= a.x3c) ? kc - a.x3c : kc;           // x3: the pixel operand holds [hi | lo], read as [hi | hi | lo]
+            const unsigned toff32 = (unsigned)((tr * a.W + ts) * a.ldx * 2 + kcx * 2);
             const unsigned tapbit = kv ? (1u << tap) : 0u;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -621,6 +622,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         ph0 = (ti * a.pool_rpt) >> 1;
     }
     const int ncs = a.C >> 6;                            // 64-channel chunks (9 tap slabs each)
+    const int x3nc = F32OUT ? (a.x3c >> 6) : 0;          // x3 engine: chunks per split part of the pixel operand (0 = plain; the bf16 instantiations compile it away)
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rw = make_rsrc(a.w, a.w_bytes);
@@ -687,7 +689,8 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         }
     };
     auto issue_x = [&](int i, int cs, int buf) __attribute__((always_inline)) {    // patch piece i of chunk cs
-        const unsigned addr = xoff0 + (unsigned)i * xstep + (unsigned)(cs * 128);
+        const int xcs = (x3nc && cs >= x3nc) ? cs - x3nc : cs;           // x3: chunks of the third part re-read the first part's
+        const unsigned addr = xoff0 + (unsigned)i * xstep + (unsigned)(xcs * 128);
         glds16_buf_nc(rx, ((xok >> i) & 1u) ? addr : 0xFFFFFFF0u, smem_base + (unsigned)buf * PATCH + (wave_u + 4u * (unsigned)i) * 1024u);
     };
 
@@ -717,6 +720,8 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         const unsigned pbase = smem_base + (DBUF ? (unsigned)((cs & 1) * PATCH) : 0u);
         const unsigned zrow = smem_base + ZOFF;
         const bool more_x = cs + 1 < ncs, more_w = kt + 2 < 9 * ncs;
+        // byte offset of the next chunk's channels in a pixel row (x3: chunks of the third part re-read the first part's), wave-uniform, once per slab
+        const unsigned xchunk_next = __builtin_amdgcn_readfirstlane((unsigned)(((x3nc && cs + 1 >= x3nc) ? cs + 1 - x3nc : cs + 1) * 128));
         // filter slab kt+2 = (chunk, tap) two positions ahead
         const int csn = tap < 7 ? cs : cs + 1;
         constexpr int tn = (tap + 2) % 9;
@@ -767,7 +772,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
                                 glds16_buf_nc(rw, (pok[q] && more_w) ? addr : 0xFFFFFFF0u, dW + q * 4096u);
                             } else {
                                 const int xi = XBASE + q - NP;
-                                const unsigned addr = xoff0 + (unsigned)xi * xstep + (unsigned)((cs + 1) * 128);
+                                const unsigned addr = xoff0 + (unsigned)xi * xstep + xchunk_next;
                                 glds16_buf_nc(rx, (((xok >> xi) & 1u) && more_x) ? addr : 0xFFFFFFF0u,
                                               smem_base + (DBUF ? (unsigned)(((cs + 1) & 1) * PATCH) : 0u) + (wave_u + 4u * (unsigned)xi) * 1024u);
                             }
@@ -2538,8 +2543,8 @@ __device__ __forceinline__ void split8(const float* __restrict__ row, int c0, in
     vh = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
     vl = make_uint4(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16);
 }
-// dst [M][3 * ldc] (parts hi/lo by `pattern` bit i = part i is the low half) from src [M][lds] f32, C valid channels; pad columns of every part zeroed
-__global__ void __launch_bounds__(256) split3_chan_kernel(const float* __restrict__ src, long long M, int C, int lds, bf16_t* __restrict__ dst, int ldc, int pattern, FastDiv dc) {
+// dst [M][ldrow >= nparts * ldc] (nparts = 2 | 3; parts hi/lo by `pattern` bit i = part i is the low half) from src [M][lds] f32, C valid channels; pad columns of every part zeroed
+__global__ void __launch_bounds__(256) split3_chan_kernel(const float* __restrict__ src, long long M, int C, int lds, bf16_t* __restrict__ dst, int ldc, int pattern, int nparts, int ldrow, FastDiv dc) {
     const int cpr = ldc >> 3;                              // 8-channel chunks per part row
     const long long total = M * cpr;
     const bool vec = (lds & 3) == 0 && ((uintptr_t)src & 15) == 0;
@@ -2548,9 +2553,10 @@ __global__ void __launch_bounds__(256) split3_chan_kernel(const float* __restric
         const int c0 = (int)(i - m * cpr) * 8;
         uint4 vh, vl;
         split8(src + m * lds, c0, C, vec, vh, vl);
-        bf16_t* row = dst + m * 3 * ldc + c0;
+        bf16_t* row = dst + m * ldrow + c0;
 #pragma unroll
-        for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(row + part * ldc) = ((pattern >> part) & 1) ? vl : vh;
+        for (int part = 0; part < 3; ++part)
+            if (part < nparts) *reinterpret_cast<uint4*>(row + part * ldc) = ((pattern >> part) & 1) ? vl : vh;
     }
 }
 // dst [3 M][ldd] (row blocks hi/lo by `pattern`) from src [M][lds] f32
@@ -2602,8 +2608,8 @@ static int grid_1d(long long n) {
 }
 }  // namespace
 
-void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, hipStream_t st) {
-    hipLaunchKernelGGL(split3_chan_kernel, dim3(grid_1d(M * (ldc >> 3))), dim3(256), 0, st, src, M, C, lds, (bf16_t*)dst, ldc, pattern, make_fastdiv((unsigned)(ldc >> 3)));
+void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, int nparts, int ldrow, hipStream_t st) {
+    hipLaunchKernelGGL(split3_chan_kernel, dim3(grid_1d(M * (ldc >> 3))), dim3(256), 0, st, src, M, C, lds, (bf16_t*)dst, ldc, pattern, nparts, ldrow, make_fastdiv((unsigned)(ldc >> 3)));
 }
 void launch_split3_rows(const float* src, long long M, int C, int lds, void* dst, int ldd, int pattern, hipStream_t st) {
     hipLaunchKernelGGL(split3_rows_kernel, dim3(grid_1d(M * (ldd >> 3))), dim3(256), 0, st, src, M, C, lds, (bf16_t*)dst, ldd, pattern, make_fastdiv((unsigned)(ldd >> 3)));

@@ -11,3 +11,18 @@ for c in retinanet yolov3 fcos centernet; do
   timeout 600 python bench.py --config $c --steps 10 --warmup 3 2>$O/err_$c.log | grep '^{' > $O/bench_line_$c.json
   python -c "import json;d=json.load(open('$O/bench_line_$c.json'));print('$c', d['value'], d['ms_per_step'], d['dtype'], d['roofline']['frac'])"
 done
+# the classes of SURVEY.md 8f.4 on their default engines (round 4: f32x3 for RefineDet320 / PFPNetR / LH_RCNN) and the engines next to them
+: > $O/classes.log
+for e in f32 f32x3 bf16; do
+  timeout 300 python tools/refinedet_bench.py $e 32 5 2>&1 | grep "images/s" >> $O/classes.log
+  timeout 300 python tools/pfpnet_bench.py $e 32 5 2>&1 | grep "images/s" >> $O/classes.log
+  timeout 300 python tools/yolov2_bench.py $e 32 5 2>&1 | grep "images/s" >> $O/classes.log
+done
+for e in f32 f32x3; do
+  timeout 300 python tools/fcos_bench.py $e 16 5 2>&1 | grep "images/s" >> $O/classes.log
+  timeout 300 python tools/centernet_bench.py $e 16 5 2>&1 | grep "images/s" >> $O/classes.log
+  timeout 300 python tools/lhrcnn_bench.py 32 3 700 1100 $e 2>&1 | grep -i "images/s" | cut -c1-90 >> $O/classes.log
+done
+timeout 300 python tools/ssd512_bench.py 2>&1 | grep "images/s" >> $O/classes.log
+cat $O/classes.log
+

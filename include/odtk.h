@@ -118,8 +118,9 @@ int odtk_conv2d_relu_bits_supported(const odtk_conv_desc* producer, const odtk_c
 int odtk_conv2d_fwd_bits(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu, void* relu_bits, void* stream);
 int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t, const void* relu_bits, void* dx, int accumulate, void* stream);
 
-/* bit 0: the forward pass and the input gradient of this ODTK_F32X3 descriptor run as split bf16 products; bit 1: the filter gradient does (C % 8 == 0 on
- * top); 0 for every other descriptor.  Introspection only (benchmarks, tests): the conv entry points decide by themselves. */
+/* bit 0: the forward pass of this ODTK_F32X3 descriptor runs as split bf16 products; bit 1: the filter gradient does (C % 8 == 0 on top); bit 2: the input
+ * gradient does (as the forward pass, plus every 3x3 stride-2 layer: its exact kernel is the slow one); 0 for every other descriptor.  Introspection only
+ * (benchmarks, tests): the conv entry points decide by themselves. */
 int odtk_conv2d_x3_supported(const odtk_conv_desc* d);
 
 /* dx[n,h,w,c] (+)= sum_{r,s,k} dy[n,ho,wo,k] * w[k,r,s,c]   (transposed conv of the fwd op)

@@ -985,7 +985,7 @@ extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int ld
     const int kch = d->dtype == ODTK_BF16 ? 8 : 4;
     ODTK_REQUIRE(lddy % kch == 0 && lddy >= d->K, "conv2d_dgrad: lddy=%d must be a multiple of %d", lddy, kch);
     if (d->dtype == ODTK_F32X3) {
-        if (x3_runs(d, 0)) return conv2d_dgrad_x3(d, (const float*)dy, lddy, (const float*)w_t, (const float*)relu_src, (float*)dx, accumulate, (hipStream_t)stream);
+        if (x3_runs(d, 2)) return conv2d_dgrad_x3(d, (const float*)dy, lddy, (const float*)w_t, (const float*)relu_src, (float*)dx, accumulate, (hipStream_t)stream);
         const odtk_conv_desc f = as_f32(d);
         return odtk_conv2d_dgrad(&f, dy, lddy, w_t, relu_src, dx, accumulate, stream);
     }
@@ -1037,7 +1037,7 @@ static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 static inline int x3_pitch(int ldc) { return 2 * ldc + 64; }
 static odtk_conv_desc as_f32(const odtk_conv_desc* d) { odtk_conv_desc f = *d; f.dtype = f.out_dtype = ODTK_F32; return f; }
 
-// Would the three passes of this layer run as split bf16 products?  pass 0 = forward / input gradient (both gather launches), 1 = filter gradient.
+// Would this pass of the layer run as split bf16 products?  pass 0 = forward, 1 = filter gradient, 2 = input gradient.
 // Policy (profiles/r04x_retinanet_f32_vs_f32x3_per_layer.md): below ~20 000 multiply-adds per output element row the split passes cost more than the exact
 // f32 MFMA kernel takes -- those layers stay exact.
 static bool x3_runs(const odtk_conv_desc* d, int pass) {
@@ -1045,7 +1045,9 @@ static bool x3_runs(const odtk_conv_desc* d, int pass) {
     const long long Min = (long long)d->N * d->H * d->W, Mout = (long long)d->N * d->Ho * d->Wo;
     const int ldc = pad8(d->C), ldk = pad8(d->K);
     const long long lim = (1ll << 31) - (1ll << 21);
-    if ((long long)d->C * d->K * d->R * d->S < 20000 && !(g_dbg2 & 8)) return false;
+    // (a stride-2 INPUT gradient is the exception: its exact kernel is the register-staged gather -- no LDS-DMA for the parity walk in f32 -- at 8-10 TFLOP/s;
+    //  RetinaNet's 28 -> 56 shortcut at 200 x 200: 450 -> 259 us split)
+    if ((long long)d->C * d->K * d->R * d->S < 20000 && !(g_dbg2 & 8) && !(pass == 2 && d->stride == 2 && d->R * d->S > 1)) return false;
     if (!(d->R * d->S <= 32 && (d->stride == 1 || (d->stride == 2 && d->dil == 1)))) return false;
     if (!(Min * (2 * ldc + 64) * 2 < lim && Mout * (2 * ldk + 64) * 2 < lim && 3 * Min * ldc * 2 < lim && 3 * Mout * ldk * 2 < lim && (long long)d->K * d->R * d->S * 3 * ldc * 2 < lim && (long long)d->C * d->R * d->S * 3 * ldk * 2 < lim &&
           3 * Min < (1ll << 31) && 3 * Mout < (1ll << 31) && Mout * d->ldy * 4 < (1ll << 31) && Min * d->ldx * 4 < (1ll << 31))) return false;
@@ -1055,7 +1057,7 @@ static bool x3_runs(const odtk_conv_desc* d, int pass) {
 
 extern "C" int odtk_conv2d_x3_supported(const odtk_conv_desc* d) {
     if (check_desc(d)) return 0;
-    return (x3_runs(d, 0) ? 1 : 0) | (x3_runs(d, 1) ? 2 : 0);
+    return (x3_runs(d, 0) ? 1 : 0) | (x3_runs(d, 1) ? 2 : 0) | (x3_runs(d, 2) ? 4 : 0);
 }
 
 static void x3_finish_args(GatherArgs& a) {

@@ -112,7 +112,7 @@ def conv2d_dgrad_bits(d: ConvDesc, dy, lddy: int, w_t, relu_bits, dx, accumulate
 
 
 def conv2d_x3_supported(d: ConvDesc) -> int:
-    """bit 0: forward / input gradient of this F32X3 descriptor run as split bf16 products, bit 1: the filter gradient does (include/odtk.h)"""
+    """bit 0: the forward pass of this F32X3 descriptor runs as split bf16 products, bit 1: the filter gradient, bit 2: the input gradient (include/odtk.h)"""
     return int(_lib.load().odtk_conv2d_x3_supported(C.byref(d)))
 
 

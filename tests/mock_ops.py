@@ -117,7 +117,7 @@ def conv2d_wgrad(d, x, dy, lddy, dw, dbias=None):
 
 # (ODTK_F32X3 descriptors -- f32 tensors, split bf16 arithmetic inside the library -- are restated as what they approximate: the plain f32 convolution)
 def conv2d_x3_supported(d):
-    return 3 if d.dtype == 2 and d.C * d.K * d.R * d.S >= 20000 else 0
+    return 7 if d.dtype == 2 and d.C * d.K * d.R * d.S >= 20000 else 0
 
 
 def colsum(dy, M, C_, ld, out, accumulate, ws):

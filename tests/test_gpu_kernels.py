@@ -1144,7 +1144,7 @@ def test_conv_x3_operand_splitting_against_f64(case, dev):
     df = ops.conv_desc(N, H, W, C, C, K, ldy, k, stride, dil, ops.F32, ops.F32)
     ops.debug_set(6, 8)                                   # every covered geometry through the split path, also below the policy's size threshold
     try:
-        assert ops.conv2d_x3_supported(d) == (3 if C % 8 == 0 else 1) and ops.conv2d_x3_supported(df) == 0
+        assert ops.conv2d_x3_supported(d) == (7 if C % 8 == 0 else 5) and ops.conv2d_x3_supported(df) == 0
         Ho, Wo = d.Ho, d.Wo
         wd = w.to(dev).contiguous()
         w_c = torch.empty(K * k * k * C, device=dev)

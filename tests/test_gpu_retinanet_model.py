@@ -47,7 +47,7 @@ def test_f32_model_matches_oracle_forward_loss_gradients_and_step(dev, engine):
     imgs, gt = _batch(2, 160, 90)
     m = _model('train', engine, 2, 160, _provider([(imgs, gt)]))
     from odtk import ops
-    assert (sum(1 for d in m.desc.values() if ops.conv2d_x3_supported(d) == 3) >= 50) == (engine == 'f32x3')
+    assert (sum(1 for d in m.desc.values() if ops.conv2d_x3_supported(d) == 7) >= 50) == (engine == 'f32x3')
     m.load_oracle_params(p)
     m.set_batch(imgs, gt)
     loss = float(m.train_step(0.01).item())

@@ -200,18 +200,19 @@ def test_retinanet_layer_specs_and_priors_match_oracle_and_reference_graph():
 
 def test_f32x3_descriptor_policy_is_host_logic():
     """`odtk_conv2d_x3_supported` (include/odtk.h): which passes of an ODTK_F32X3 descriptor run as split bf16 products is decided on the host -- no GPU needed.
-    bit 0 = forward / input gradient, bit 1 = filter gradient."""
+    bit 0 = forward, bit 1 = filter gradient, bit 2 = input gradient."""
     import odtk  # noqa: F401
     from odtk import ops
 
     def bits(C_, K, k, stride=1, H=50, dtype=ops.F32X3, N=2):
         return ops.conv2d_x3_supported(ops.conv_desc(N, H, H, C_, C_, K, ops.pad_to(K, 4), k, stride, 1, dtype, dtype))
-    assert bits(256, 256, 3) == 3                      # the pyramid / head layers of RetinaNet.py:594-643
-    assert bits(256, 189, 3) == 3 and bits(256, 36, 3) == 3
+    assert bits(256, 256, 3) == 7                      # the pyramid / head layers of RetinaNet.py:594-643: forward, filter gradient, input gradient
+    assert bits(256, 189, 3) == 7 and bits(256, 36, 3) == 7
     assert bits(256, 256, 3, dtype=ops.F32) == 0       # an exact-f32 descriptor never splits
-    assert bits(8, 28, 1) == 0 and bits(56, 14, 1) == 0 and bits(28, 28, 3) == 0        # C K R S < 20 000: the narrow backbone layers stay exact
-    assert bits(28, 256, 3) == 1                       # 28 channels: forward / input gradient split, the filter gradient (rows of C) exact
-    assert bits(256, 256, 3, stride=2) == 3 and bits(256, 256, 3, stride=3) == 0
-    assert bits(2048, 21, 1, H=1, N=8192) == 3         # LH_RCNN's dense head (rows as 1 x 1 images)
+    assert bits(8, 28, 1) == 0 and bits(56, 14, 1) == 0 and bits(28, 28, 3) == 0        # C K R S < 20 000: the narrow backbone layers stay exact ...
+    assert bits(28, 56, 3, stride=2) == 4 and bits(16, 14, 3, stride=2) == 4            # ... but for the input gradient of a 3x3 stride-2 layer
+    assert bits(28, 256, 3) == 5                       # 28 channels: forward / input gradient split, the filter gradient (rows of C) exact
+    assert bits(256, 256, 3, stride=2) == 7 and bits(256, 256, 3, stride=3) == 0
+    assert bits(2048, 21, 1, H=1, N=8192) == 7         # LH_RCNN's dense head (rows as 1 x 1 images)
     # the split operands are addressed with 32-bit byte offsets: a map whose [hi | lo] copy passes 2 GiB stays exact
     assert bits(256, 256, 3, H=1100, N=8) == 0

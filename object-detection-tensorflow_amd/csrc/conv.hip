@@ -204,12 +204,16 @@ template <typename T, typename TO, int PT>
 __global__ void __launch_bounds__(256) conv_gather_glds_kernel(const GatherArgs a) {
     constexpr int KCH = Mma<T>::KCH;
     constexpr int BKE = 8 * KCH;
-    constexpr int PI = PT / 64, QI = 2, PL = PT / 32;
+    // wave layout: 2 x 2 waves of (PT / 2) x 64 for PT = 64 | 128; PT = 32 (round 4: Cout <= 32, the 7..28-channel layers of RetinaNet.py:27's widths, which
+    // wasted half to 8/9 of a 64-row filter tile): 1 x 4 waves of 32 x 32
+    constexpr int WP = PT >= 64 ? 2 : 1, WQ = 4 / WP;
+    constexpr int PI = PT / (32 * WP), QI = 4 / WQ, PL = PT / 32;
     constexpr int STAGE = (PT + 128) * 128;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wp = wave & 1, wq = wave >> 1;
+    const int wp = wave % WP, wq = wave / WP;
+    const int prow0 = wp * (PT / WP), qrow0 = wq * (128 / WQ);
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
     const int p0 = tp * PT, q0 = tq * 128;
@@ -301,19 +305,19 @@ __global__ void __launch_bounds__(256) conv_gather_glds_kernel(const GatherArgs 
         __syncthreads();                                      // ... and everybody else's; slab kt-1 fully consumed
         if (kt + 1 < nk) issue((kt + 1) & 1);
         const char* sP = smem + (kt & 1) * STAGE;
-        mma_slab<T, PI, QI, true>(sP, sP + PT * 128, wp * (PT / 2), wq * 64, lane, acc);
+        mma_slab<T, PI, QI, true>(sP, sP + PT * 128, prow0, qrow0, lane, acc);
     }
 
     const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int j = 0; j < QI; ++j) {
-        const int m = q0 + wq * 64 + j * 32 + l31;
+        const int m = q0 + qrow0 + j * 32 + l31;
         if (m >= a.M) continue;
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = p0 + wp * (PT / 2) + i * 32 + 8 * g + 4 * hi;
+                const int c = p0 + prow0 + i * 32 + 8 * g + 4 * hi;
                 if (c >= a.K) continue;
                 float v[4];
 #pragma unroll
@@ -791,8 +795,10 @@ int launch_gather(const GatherArgs& a, int PT, hipStream_t st) {
     const int grid = a.tiles_p * a.tiles_q;
     const bool dma = a.idiv == 1 && a.R * a.S <= 32 && !g_force_regstage;
     if (dma) {
-        g_last_kernel = PT == 64 ? "conv_gather_glds_kernel<64>" : "conv_gather_glds_kernel<128>";
-        if (PT == 64)
+        g_last_kernel = PT == 32 ? "conv_gather_glds_kernel<32>" : PT == 64 ? "conv_gather_glds_kernel<64>" : "conv_gather_glds_kernel<128>";
+        if (PT == 32)
+            hipLaunchKernelGGL((conv_gather_glds_kernel<T, TO, 32>), dim3(grid), dim3(256), 0, st, a);
+        else if (PT == 64)
             hipLaunchKernelGGL((conv_gather_glds_kernel<T, TO, 64>), dim3(grid), dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL((conv_gather_glds_kernel<T, TO, 128>), dim3(grid), dim3(256), 0, st, a);
@@ -839,7 +845,9 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
         ODTK_LAUNCH_CHECK();
         return ODTK_OK;
     }
-    const int PT = a.K <= 64 ? 64 : 128;
+    // (PT = 32: the f32 LDS-DMA kernel only -- dbg2 bit 4 = off, A/B)
+    const bool pt32 = a.K <= 32 && dtype == ODTK_F32 && a.idiv == 1 && a.R * a.S <= 32 && !g_force_regstage && !(g_dbg2 & 16);
+    const int PT = pt32 ? 32 : a.K <= 64 ? 64 : 128;
     a.tiles_p = ceil_div(a.K, PT);
     a.tiles_q = ceil_div(a.M, 128);
     if (dtype == ODTK_BF16 && out_dtype == ODTK_BF16) launch_gather<bf16_t, bf16_t>(a, PT, st);

@@ -1161,6 +1161,13 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     a.div_howo = make_fastdiv((unsigned)(d->Ho * d->Wo));
     a.div_wo = make_fastdiv((unsigned)d->Wo);
     a.dbg = g_dbg;
+    a.dbg2 = g_dbg2;
+    if (!g_force_regstage && g_v3_mode != 1 && wgrad_f32_narrow_supported(a, d->dtype)) {
+        launch_wgrad_f32_narrow(a, (hipStream_t)stream);
+        g_last_kernel = "wgrad_f32_narrow_kernel";
+        ODTK_LAUNCH_CHECK();
+        return ODTK_OK;
+    }
     if (!g_force_regstage && g_v3_mode != 1 && !(g_dbg & 2048) && wgrad_c64_supported(a, d->dtype)) {
         launch_wgrad_c64(a, (hipStream_t)stream);
         g_last_kernel = "wgrad3x3_c64k64_kernel";

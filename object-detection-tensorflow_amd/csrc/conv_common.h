@@ -180,6 +180,7 @@ struct WgradArgs {
     int tiles_p, tiles_q, iters_per_split;
     FastDiv div_howo, div_wo;
     int dbg;         // perf experiments only (odtk_debug_set key 2): bit0/1 zero-page DMA sources, bit2 no DMA after slab 0, bit4 no atomics
+    int dbg2;        // dispatch A/B switches that leave results intact (key 6): bit 5 = narrow f32 layers on the legacy filter-gradient kernel
     unsigned x_bytes, dy_bytes;   // extents for the buffer-addressed DMA (8-wave kernel)
     // deterministic split-reduce (opt-in, odtk_debug_set key 5; 8-wave / four-wave kernels with > 1 pixel split): every block STORES its partial tile to
     // ws[split][K][RSC] (and its bias sums to bws[slot][K]); wgrad_reduce_kernel adds the splits in fixed order into dw / dbias.
@@ -301,6 +302,8 @@ int launch_gather_c64(GatherArgs& a, hipStream_t st);
 bool gather_c8_supported(const GatherArgs& a, int dtype, int out_dtype);    // first-layer (3 -> 64) 3x3 kernel
 int launch_gather_c8(GatherArgs& a, hipStream_t st);
 bool wgrad_c64_supported(const WgradArgs& a, int dtype);                      // halo-patch 64->64 3x3 wgrad
+bool wgrad_f32_narrow_supported(const WgradArgs& a, int dtype);               // f32, K / C <= 32 (3x3) | 64 (1x1): pixel-major LDS-DMA tiles, 32x32x2 MFMA
+int launch_wgrad_f32_narrow(WgradArgs& a, hipStream_t st);
 int launch_wgrad_c64(WgradArgs& a, hipStream_t st);
 bool wgrad_c8_supported(const WgradArgs& a, int dtype);                       // first layer (3(8) -> 64) filter gradient: wave-private strips
 int launch_wgrad_c8(WgradArgs& a, hipStream_t st);

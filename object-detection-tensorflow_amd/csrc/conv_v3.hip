@@ -2190,6 +2190,213 @@ int launch_wgrad_c8(WgradArgs& a, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Narrow f32 filter gradient (round 4): the 7..56-channel layers of RetinaNet.py:27's widths (and every other narrow f32 layer) on
+// conv_wgrad_kernel<float> ran at 2-45 TFLOP/s -- each of its 32-pixel iterations is two barriers around register-staged, transposing
+// loads.  v_mfma_f32_32x32x2_f32 takes ONE value per lane and operand (A: dy[pixel hi][channel l31], B: x[pixel hi][channel l31]), so both
+// operands can stay in their natural [pixel][channel] rows: an 8 x 32-pixel tile of dy and its (8 + R - 1) x (32 + S - 1) halo patch of x go HBM -> LDS by
+// LDS-DMA (two stages; out-of-image and pad-column chunks are zero-filled by the buffer range check), every tap reads the patch at a shifted row, all
+// fragment reads are 4-byte words of consecutive lanes (conflict-free).  Persistent workgroups walk the tiles with the accumulators live -- taps x KI x CI
+// tiles of 32 x 32 per wave, a wave takes a quarter of each tile's pixels -- and flush once: waves summed through LDS, then float atomics into dW
+// (and the bias gradient, summed from the A fragments, into dbias).  MFMA-bound for 3x3 (28 -> 28 at 200 x 200 x 16: 248 -> ~90 us), HBM-bound for 1x1.
+// Stride 1, dilation 1, SAME padding, R = S in {1, 3}, K <= 32 KI, C <= 32 CI.
+// ---------------------------------------------------------------------------------------
+namespace {
+template <bool R3, int KI, int CI>
+__global__ void __launch_bounds__(256) wgrad_f32_narrow_kernel(const WgradArgs a, int tiles_h, int tiles_w, int total_tiles) {
+    constexpr int TH = R3 ? 8 : 4, TW = 32, TP = TH * TW;                 // tile: TH rows of 32 pixels
+    constexpr int PH = TH + (R3 ? 2 : 0), PW = TW + (R3 ? 2 : 0), PP = PH * PW;
+    constexpr int NT = R3 ? 9 : 1;
+    constexpr int RBK = 128 * KI, RBC = 128 * CI;                           // LDS row bytes of a dy / x pixel
+    constexpr int RPK = 8 / KI, RPC = 8 / CI;                               // pixel rows per 1-KiB DMA piece
+    constexpr int NPK = TP / RPK, NPC = (PP + RPC - 1) / RPC;               // pieces per tile
+    constexpr int XOFF = TP * RBK;                                          // x patch behind the dy tile
+    constexpr int STAGE = XOFF + NPC * 1024;
+    constexpr int NQK = (NPK + 3) / 4, NQC = (NPC + 3) / 4;                 // pieces per wave
+    static_assert(2 * STAGE <= 160 * 1024, "two stages must fit the LDS");
+    static_assert(NT * KI * CI * 16 * 256 * 4 / 4 <= 2 * STAGE, "the flush image must fit");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rdy = make_rsrc(a.dy, a.dy_bytes);
+
+    // per lane and piece: position inside the tile / patch and the byte offset relative to the tile's first pixel
+    int kph[NQK], kpw[NQK], xph[NQC], xpw[NQC];
+    unsigned koff[NQK], xoff[NQC];
+    bool kon[NQK], xon[NQC];
+#pragma unroll
+    for (int i = 0; i < NQK; ++i) {
+        const int q = wave + 4 * i;
+        const int row = q * RPK + lane / (8 * KI), ch = lane % (8 * KI);
+        kph[i] = row / TW; kpw[i] = row % TW;
+        kon[i] = q < NPK && ch * 4 < a.lddy;
+        koff[i] = (unsigned)((kph[i] * a.Wo + kpw[i]) * a.lddy * 4 + ch * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NQC; ++i) {
+        const int q = wave + 4 * i;
+        const int row = q * RPC + lane / (8 * CI), ch = lane % (8 * CI);
+        xph[i] = row / PW; xpw[i] = row % PW;
+        xon[i] = q < NPC && row < PP && ch * 4 < a.ldx;
+        xoff[i] = (unsigned)((xph[i] * a.W + xpw[i]) * a.ldx * 4 + ch * 16);
+    }
+    const int tpi = tiles_h * tiles_w;
+    auto issue = [&](int tile, int stage) __attribute__((always_inline)) {
+        const int n = tile / tpi, r = tile - n * tpi;
+        const int th = r / tiles_w, tw = r - th * tiles_w;
+        const int h0 = th * TH, w0 = tw * TW;
+        const unsigned sb = smem_base + (unsigned)stage * STAGE;
+        const unsigned kbase = (unsigned)(((n * a.Ho + h0) * a.Wo + w0) * a.lddy * 4);
+        const int xh0 = h0 - a.pad_t, xw0 = w0 - a.pad_l;
+        const int xbase = ((n * a.H + xh0) * a.W + xw0) * a.ldx * 4;            // may be negative: only used with in-image pixels
+#pragma unroll
+        for (int i = 0; i < NQK; ++i) {
+            if ((int)wave_u + 4 * i >= NPK) continue;       // (wave-uniform: a piece past the tile would land in the other stage)
+            const bool ok = kon[i] && h0 + kph[i] < a.Ho && w0 + kpw[i] < a.Wo;
+            glds16_buf(rdy, ok ? kbase + koff[i] : 0xFFFFFFF0u, sb + (wave_u + 4u * (unsigned)i) * 1024u);
+        }
+#pragma unroll
+        for (int i = 0; i < NQC; ++i) {
+            if ((int)wave_u + 4 * i >= NPC) continue;
+            const bool ok = xon[i] && (unsigned)(xh0 + xph[i]) < (unsigned)a.H && (unsigned)(xw0 + xpw[i]) < (unsigned)a.W;
+            glds16_buf(rx, ok ? (unsigned)(xbase + (int)xoff[i]) : 0xFFFFFFF0u, sb + XOFF + (wave_u + 4u * (unsigned)i) * 1024u);
+        }
+    };
+
+    f32x16_v acc[NT][KI][CI];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < KI; ++i)
+#pragma unroll
+            for (int j = 0; j < CI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+    float bsum[KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) bsum[i] = 0.f;
+
+    int stage = 0;
+    int tile = blockIdx.x;
+    if (tile < total_tiles) issue(tile, 0);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        wait_vmcnt<0>();
+        block_barrier();                                   // this tile's operands landed for every wave; the other stage is free
+        if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x, stage ^ 1);
+        const char* sK = smem + stage * STAGE;
+        const char* sX = sK + XOFF;
+        const int pbase = wave * (TP / 4);
+        // fragments of step t + 1 are read while the MFMAs of step t issue (two register sets: without it every step exposed one LDS round trip in front of
+        // its first MFMA -- 154 us instead of ~110 for the 28 -> 28 layer at 200 x 200)
+        float av[2][KI], bv[2][NT][CI];
+        auto rd = [&](int t, float (&A)[KI], float (&B)[NT][CI]) __attribute__((always_inline)) {
+            const int p = pbase + 2 * t + hi;
+            const int h = p >> 5, w = p & 31;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) A[i] = *reinterpret_cast<const float*>(sK + p * RBK + (i * 32 + l31) * 4);
+            const char* xb = sX + (R3 ? h * PW + w : p) * RBC + l31 * 4;
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+                const int dr = tp / 3, ds = tp - dr * 3;
+#pragma unroll
+                for (int j = 0; j < CI; ++j) B[tp][j] = *reinterpret_cast<const float*>(xb + (R3 ? dr * PW + ds : 0) * RBC + j * 128);
+            }
+        };
+        rd(0, av[0], bv[0]);
+#pragma unroll 2
+        for (int t = 0; t < TP / 8; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < TP / 8) rd(t + 1, av[cur ^ 1], bv[cur ^ 1]);
+#pragma unroll
+            for (int i = 0; i < KI; ++i) bsum[i] += av[cur][i];
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+                for (int j = 0; j < CI; ++j)
+#pragma unroll
+                    for (int i = 0; i < KI; ++i) acc[tp][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][tp][j], acc[tp][i][j], 0, 0, 0);
+        }
+        stage ^= 1;
+    }
+    wait_vmcnt<0>();
+    __syncthreads();                                       // every wave is past its last fragment read: LDS becomes the flush image
+    // flush: the four waves' accumulators summed in LDS (wave after wave, a thread owns its slots), then float atomics by all threads
+    float* img = reinterpret_cast<float*>(smem);            // [NT * KI * CI * 16][64]
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < KI; ++i)
+#pragma unroll
+                    for (int j = 0; j < CI; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float* slot = img + (((t * KI + i) * CI + j) * 16 + e) * 64 + lane;
+                            *slot = wv == 0 ? acc[t][i][j][e] : *slot + acc[t][i][j][e];
+                        }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < NT * KI * CI * 16 * 64; idx += 256) {
+        const int ln = idx & 63, e = (idx >> 6) & 15, tij = idx >> 10;
+        const int j = tij % CI, i = (tij / CI) % KI, t = tij / (CI * KI);
+        const int k = i * 32 + 8 * (e >> 2) + 4 * (ln >> 5) + (e & 3), c = j * 32 + (ln & 31);
+        const float v = img[idx];
+        if (k < a.K && c < a.C && v != 0.f) atomicAdd(a.dw + (size_t)k * a.RSC + t * a.C + c, v);
+    }
+    if (a.dbias != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const float v = bsum[i] + __shfl_xor(bsum[i], 32);
+            if (hi == 0) img[(wave * KI + i) * 32 + l31] = v;
+        }
+        __syncthreads();
+        if (tid < 32 * KI && tid < a.K) {
+            const int i = tid >> 5, l = tid & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) v += img[(wv * KI + i) * 32 + l];
+            if (v != 0.f) atomicAdd(a.dbias + tid, v);
+        }
+    }
+}
+}  // namespace
+
+bool wgrad_f32_narrow_supported(const WgradArgs& a, int dtype) {
+    if (dtype != ODTK_F32 || g_wgrad_deterministic || (a.dbg2 & 32)) return false;
+    const bool r3 = a.R == 3 && a.S == 3 && a.pad_t == 1 && a.pad_l == 1, r1 = a.R == 1 && a.S == 1 && a.pad_t == 0 && a.pad_l == 0;
+    if (!(r3 || r1) || a.stride != 1 || a.dil != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+    if (r3 ? !(a.K <= 32 && a.C <= 32) : !(a.K <= 64 && a.C <= 64)) return false;
+    return a.ldx % 4 == 0 && a.lddy % 4 == 0 && (long long)a.N * a.H * a.W * a.ldx * 4 < (1ll << 31) && (long long)a.P * a.lddy * 4 < (1ll << 31) &&
+           (long long)a.P >= 4096;                            // (small maps: the split-pixel kernel fills the chip better than a handful of 256-pixel tiles)
+}
+
+int launch_wgrad_f32_narrow(WgradArgs& a, hipStream_t st) {
+    if (g_num_cu == 0) query_num_cu();
+    const bool r3 = a.R == 3;
+    const int TH = r3 ? 8 : 4;
+    const int tiles_h = ceil_div(a.H, TH), tiles_w = ceil_div(a.W, 32);
+    const int total = a.N * tiles_h * tiles_w;
+    a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 4);
+    a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 4);
+    const int KI = a.K <= 32 ? 1 : 2, CI = a.C <= 32 ? 1 : 2;
+    const int per_cu = r3 ? 1 : (KI * CI == 1 ? 2 : 1);
+    const int grid = total < g_num_cu * per_cu ? total : g_num_cu * per_cu;
+#define ODTK_WN(R3_, KI_, CI_) hipLaunchKernelGGL((wgrad_f32_narrow_kernel<R3_, KI_, CI_>), dim3(grid), dim3(256), 0, st, a, tiles_h, tiles_w, total)
+    if (r3) ODTK_WN(true, 1, 1);
+    else if (KI == 1 && CI == 1) ODTK_WN(false, 1, 1);
+    else if (KI == 1) ODTK_WN(false, 1, 2);
+    else if (CI == 1) ODTK_WN(false, 2, 1);
+    else ODTK_WN(false, 2, 2);
+#undef ODTK_WN
+    return 0;
+}
+
 bool wgrad_v3_supported(const WgradArgs& a, int dtype) {
     // (K = 64 with fewer than 256 columns -- conv1_1's 72 -- stays on conv_wgrad_dma_kernel: 185 us there, 208 us here, measured in round 2)
     return dtype == ODTK_BF16 && (a.K > 64 || (a.K == 64 && a.RSC >= 256)) && a.lddy % 8 == 0 && a.ldx % 8 == 0 && a.C % 8 == 0 &&

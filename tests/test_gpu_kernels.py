@@ -73,6 +73,19 @@ BACKBONE_CASES = [
     (2, 3, 3, 256, 256, 3, 2, 1),     # p7 from a 3 x 3 p6
     (2, 3, 3, 256, 256, 3, 1, 1),
     (1, 1, 1, 256, 256, 3, 1, 1),     # one pixel
+    # round 4: maps of >= 4 096 pixels -- the narrow f32 filter-gradient kernel (pixel-major LDS-DMA tiles of 8 x 32 | 4 x 32 pixels, persistent workgroups) and
+    # the 32-row filter tile of the f32 LDS-DMA gather; ragged tiles on both edges, every (KI, CI) instantiation
+    (2, 64, 64, 28, 28, 3, 1, 1),     # 3x3, 28 -> 28 (one 32 x 32 tile per tap)
+    (2, 50, 70, 7, 7, 3, 1, 1),       # 3x3, 7 -> 7: ragged tiles on both edges (50 = 6 x 8 + 2, 70 = 2 x 32 + 6)
+    (1, 90, 47, 16, 28, 3, 1, 1),     # 3x3, 16 -> 28
+    (2, 64, 64, 16, 7, 1, 1, 1),      # 1x1 (KI = CI = 1)
+    (2, 50, 70, 7, 28, 1, 1, 1),      # 1x1, ragged
+    (3, 40, 40, 28, 56, 1, 1, 1),     # 1x1, 56 output channels (KI = 2)
+    (3, 40, 40, 56, 14, 1, 1, 1),     # 1x1, 56 input channels (CI = 2)
+    (2, 48, 48, 56, 56, 1, 1, 1),     # 1x1, both (KI = CI = 2)
+    (8, 128, 128, 3, 32, 3, 1, 1),    # several tiles per persistent workgroup (512 tiles), 3 input channels in one 16-byte chunk (a first layer)
+    (8, 128, 136, 28, 28, 3, 1, 1),   # ... 28 -> 28, ragged right edge
+    (12, 128, 128, 16, 8, 1, 1, 1),   # ... 1x1 (1 536 tiles of 4 x 32 pixels)
 ]
 
 

@@ -2721,13 +2721,15 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------
-// "x3" (round 4): exact-to-2^-16 f32 convolutions on the bf16 MFMA kernels by operand splitting.  a = a_hi + a_lo with a_hi = bf16(a), a_lo = bf16(a - a_hi);
-//     a * b = a_hi b_hi + a_hi b_lo + a_lo b_hi + O(2^-16 |a b|),   accumulated in f32 by the MFMA.
-// The three partial products are ONE implicit GEMM with a three times longer reduction: the gathered operand is stored as [hi | hi | lo] along its channel axis
-// (forward: the activation, input gradient: dy) against filters stored [hi | lo | hi]; for the filter gradient, whose reduction runs over pixels, x is stacked
-// [hi ; lo ; hi] and dy [hi ; hi ; lo] along the IMAGE axis (3 N images) and the existing filter-gradient kernels run unchanged, their f32 result is dW.
-// The f32 MFMA of gfx950 runs at 1/16 of the bf16 rate (157 TFLOP/s: RetinaNet's engine, whose identity-free units do not survive bf16 OPERANDS);
-// three bf16 products are 5.3x that.  Outputs leave through the split-K partial path of the 8-wave gather kernel (f32 tiles) and a finish pass that stays in f32.
+// "x3" (round 4; the arithmetic behind ODTK_F32X3 descriptors): f32 convolutions on the bf16 MFMA kernels by operand splitting.
+//     a = a_hi + a_lo with a_hi = bf16(a), a_lo = bf16(a - a_hi);    a * b = a_hi b_hi + a_hi b_lo + a_lo b_hi + O(2^-17 |a b|),   accumulated in f32 by the MFMA.
+// The three partial products are ONE implicit GEMM with a three times longer reduction over [hi | hi | lo] x [hi | lo | hi].  The gathered operand (forward: the
+// activation, input gradient: dy) is STORED as two parts [hi | lo] (pitch 2 ldc + 64) and the kernels read its first part twice (GatherArgs::x3c); filters are stored
+// with all three parts per tap.  For the filter gradient, whose reduction runs over pixels, x is stacked [hi ; lo ; hi] and dy [hi ; hi ; lo] along the IMAGE axis
+// (3 N images) and the existing filter-gradient kernels run unchanged; their f32 result is dW.
+// The f32 MFMA of gfx950 runs at 1/16 of the bf16 rate (157 TFLOP/s; the identity-free conv + norm stacks of RetinaNet, RefineDet320, PFPNetR, LH_RCNN do not survive
+// bf16 OPERANDS); three bf16 products are 5.3x that.  Outputs leave as f32 rows straight from the accumulators (x3_store4: the raster-run halo kernel's
+// F32OUT instantiations and the 8-wave kernel's single-part launch) or, with few tiles, through split-K partial tiles and splitk_finish_f32_kernel.
 // ---------------------------------------------------------------------------------------
 namespace {
 __device__ __forceinline__ void split_hi_lo(float v, bf16_t& hi, bf16_t& lo) {

@@ -64,7 +64,9 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back;
  * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
  *         run, 2.5 % slower on the SSD300 step) instead of float atomics into dw (the default);
- * key 6 = dispatch A/B switches of the convolution kernels that leave results intact (none defined at present);
+ * key 6 = dispatch A/B switches of the convolution kernels that leave results intact (up to the engines' stated tolerances): bit 2 (4) = ODTK_F32X3 descriptors run
+ *         on the exact f32 kernels, bit 3 (8) = ... on the split path wherever it is supported, also below the size policy (tests), bit 4 (16) = no 32-row filter
+ *         tile in the f32 LDS-DMA gather, bit 5 (32) = narrow f32 filter gradients on the legacy kernel;
  * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never) */
 int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to

@@ -141,8 +141,8 @@ struct GatherArgs {
     int tiles_p, tiles_q;
     FastDiv div_howo, div_wo;
     int dbg;           // perf experiments only (odtk_debug_set key 2): bit0 skip pixel-operand DMA, bit1 skip filter DMA after slab 0
-    int dbg2;          // dispatch A/B switches that leave results intact (odtk_debug_set key 6): bit 2 = ODTK_F32X3 descriptors on the exact f32 kernels, bit 3 = on the
-                       // split path wherever it is supported (also below the size policy: tests)
+    int dbg2;          // dispatch A/B switches that leave results intact (odtk_debug_set key 6, include/odtk.h): bit 2 = ODTK_F32X3 descriptors on the exact f32 kernels,
+                       // bit 3 = on the split path wherever it is supported (also below the size policy: tests), bit 4 = no 32-row f32 filter tile
     int x3c;                 // x3 engine: channels per split part of the PIXEL operand, stored [hi | lo]; reduction channel c reads channel c - x3c when c >= x3c (the
                              // virtual layout [hi | hi | lo] against filters [hi | lo | hi]); 0 = plain operand
     unsigned x_bytes, w_bytes;   // extents of x and w for the buffer-addressed DMA (range check = zero fill)

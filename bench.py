@@ -259,7 +259,7 @@ def main():
                     help="BASELINE.json's configuration: ssd300 = config 2 (the headline metric, the default); retinanet = config 3 (800x800, batch 16); "
                          'yolov3 = config 4 (416x416, 8 / GPU); fcos | centernet = config 5 (512x512, 16 / GPU) -- bench_configs.py')
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s)')
-    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f32x3'], help='engine (default: the one the model class defaults to in training mode: bf16 for ssd300 / yolov3 / fcos / centernet, f32 for retinanet)')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f32x3'], help='engine (default: the one the model class defaults to in training mode: bf16 for ssd300 / yolov3 / fcos / centernet, f32x3 -- f32 tensors, ODTK_F32X3 convolution descriptors -- for retinanet)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region (the default at N = 1 since round 3)')

@@ -302,6 +302,9 @@ def main():
         args.batch = BC.SHAPES[args.config][1]
     if args.dtype is None:
         args.dtype = BC.SHAPES[args.config][2]
+    if args.dtype == 'f32x3' and args.config in ('ssd300', 'yolov3'):
+        raise SystemExit("bench.py: the 'f32x3' engine exists for the classes with an f32 TRAINING engine (retinanet, fcos, centernet; tools/*_bench.py for RefineDet320 / "
+                         "PFPNetR / YOLOv2 / LH_RCNN); ssd300 and yolov3 train in bf16, their f32 engines are parity references")
     if args.config != 'ssd300':
         return bench_other(args, world, rank, local_rank)
     if not torch.cuda.is_available():

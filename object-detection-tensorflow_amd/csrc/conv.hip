@@ -942,7 +942,7 @@ static void fwd_args(GatherArgs& a, const odtk_conv_desc* d, const void* x, cons
 }
 
 extern "C" int odtk_conv2d_fwd_pool2x2_fused(const odtk_conv_desc* d) {
-    if (check_desc(d)) return 0;
+    if (check_desc(d) || d->dtype == ODTK_F32X3) return 0;
     GatherArgs a;
     fwd_args(a, d, nullptr, nullptr, nullptr, nullptr, 1);
     a.dbg = g_dbg;
@@ -957,6 +957,7 @@ extern "C" int odtk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int
 extern "C" int odtk_conv2d_fwd_pool2x2(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu,
                                        void* y_pool, int ld_pool, void* idx, void* stream) {
     if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(d->dtype != ODTK_F32X3, "conv2d_fwd_pool2x2: ODTK_F32X3 descriptors go to odtk_conv2d_fwd / _dgrad / _wgrad only");
     ODTK_REQUIRE(x && w && y_pool, "conv2d_fwd_pool2x2: null pointer");
     ODTK_REQUIRE(ld_pool % 8 == 0 && ld_pool >= d->K, "conv2d_fwd_pool2x2: ld_pool=%d must be a multiple of 8 and >= K=%d", ld_pool, d->K);
     GatherArgs a;
@@ -1005,6 +1006,7 @@ extern "C" int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int ld
 // ---- ReLU mask as sign bits between a producer's forward pass and the consumer's input-gradient pass (conv1_1 -> conv1_2 of SSD300.py:193-208)
 extern "C" int odtk_conv2d_relu_bits_supported(const odtk_conv_desc* producer, const odtk_conv_desc* consumer, int consumer_lddy) {
     if (check_desc(producer) || check_desc(consumer)) return 0;
+    if (producer->dtype == ODTK_F32X3 || consumer->dtype == ODTK_F32X3) return 0;
     if (g_force_regstage || g_v3_mode == 1 || (g_dbg & 2048)) return 0;
     GatherArgs f, b;
     fwd_args(f, producer, nullptr, nullptr, nullptr, nullptr, 1);
@@ -1015,6 +1017,7 @@ extern "C" int odtk_conv2d_relu_bits_supported(const odtk_conv_desc* producer, c
 
 extern "C" int odtk_conv2d_fwd_bits(const odtk_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int relu, void* relu_bits, void* stream) {
     if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(d->dtype != ODTK_F32X3, "conv2d_fwd_bits: ODTK_F32X3 descriptors go to odtk_conv2d_fwd / _dgrad / _wgrad only");
     ODTK_REQUIRE(x && w && y && relu_bits, "conv2d_fwd_bits: null pointer");
     GatherArgs a;
     fwd_args(a, d, x, w, bias, y, relu);
@@ -1027,6 +1030,7 @@ extern "C" int odtk_conv2d_fwd_bits(const odtk_conv_desc* d, const void* x, cons
 extern "C" int odtk_conv2d_dgrad_bits(const odtk_conv_desc* d, const void* dy, int lddy, const void* w_t, const void* relu_bits, void* dx, int accumulate,
                                       void* stream) {
     if (int e = check_desc(d)) return e;
+    ODTK_REQUIRE(d->dtype != ODTK_F32X3, "conv2d_dgrad_bits: ODTK_F32X3 descriptors go to odtk_conv2d_fwd / _dgrad / _wgrad only");
     ODTK_REQUIRE(dy && w_t && dx && relu_bits, "conv2d_dgrad_bits: null pointer");
     ODTK_REQUIRE(lddy % 8 == 0 && lddy >= d->K, "conv2d_dgrad_bits: lddy=%d must be a multiple of 8", lddy);
     GatherArgs a;

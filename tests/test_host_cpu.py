@@ -216,3 +216,19 @@ def test_f32x3_descriptor_policy_is_host_logic():
     assert bits(2048, 21, 1, H=1, N=8192) == 7         # LH_RCNN's dense head (rows as 1 x 1 images)
     # the split operands are addressed with 32-bit byte offsets: a map whose [hi | lo] copy passes 2 GiB stays exact
     assert bits(256, 256, 3, H=1100, N=8) == 0
+
+
+def test_f32x3_descriptors_are_refused_by_the_fused_entry_points():
+    """ODTK_F32X3 is a property of the three plain convolution passes: the fused conv + pool / sign-bit entry points say so (argument checks run before any launch: no GPU needed)"""
+    import odtk  # noqa: F401
+    from odtk import _lib, ops
+    d = ops.conv_desc(2, 64, 64, 64, 64, 64, 64, 3, 1, 1, ops.F32X3, ops.F32X3)
+    assert ops.conv2d_fwd_pool2x2_fused(d) is False or ops.conv2d_fwd_pool2x2_fused(d) == 0
+    assert not ops.conv2d_relu_bits_supported(d, d, 64)
+    lib = _lib.load()
+    import ctypes as C
+    rc = lib.odtk_conv2d_fwd_bits(C.byref(d), None, None, None, None, 1, None, None)
+    assert rc != 0 and b'ODTK_F32X3' in lib.odtk_last_error()
+    # a descriptor that mixes the engine with another storage type is refused as well
+    bad = ops.conv_desc(2, 64, 64, 64, 64, 64, 64, 3, 1, 1, ops.F32X3, ops.F32)
+    assert lib.odtk_conv2d_fwd(C.byref(bad), None, None, None, None, 0, None) != 0 and b'ODTK_F32X3' in lib.odtk_last_error()

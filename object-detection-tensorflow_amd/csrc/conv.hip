@@ -840,6 +840,8 @@ int dispatch_gather(GatherArgs& a, int dtype, int out_dtype, hipStream_t st) {
         a.ksplit = 1;
         if (int e = launch_gather_v3(a, st)) return e;
         g_last_kernel = a.ksplit > 1 ? (a.K <= 64 ? "conv_gather_v3_kernel<64>+splitk" : "conv_gather_v3_kernel<128>+splitk")
+                        : a.ksplit == -9 ? "conv_gather_v9_kernel"
+                        : a.ksplit == -6 ? "conv_gather_v6_kernel+splitk"
                         : a.ksplit < 0 ? "conv_gather_v6_kernel"
                                        : (a.K <= 64 ? "conv_gather_v3_kernel<64>" : "conv_gather_v3_kernel<128>");
         ODTK_LAUNCH_CHECK();

@@ -166,6 +166,20 @@ struct GatherArgs {
     // (pixel, 16-byte chunk), bit e = channel 8 * chunk + e of the activation is > 0.  conv1_2's dgrad read the 369-MB activation only for these signs.
     unsigned char* ybits;            // written beside y (forward), [M][ldy / 8]
     const unsigned char* mask_bits;  // read instead of `mask` (input gradient), [M][ldmask / 8]
+    // Round 5: split-K of the raster-run halo kernel over whole 64-channel CHUNKS (its F32OUT instantiations only): `cs_split` consecutive blocks share a tile, block
+    // `part` reduces chunks [part * ncs / cs_split, (part + 1) * ncs / cs_split) and stores its f32 partial tile to ws[part]; splitk_finish_kernel sums them.  0 | 1 = off.
+    int cs_split;
+    // Round 5: the small-map gather kernel (conv_v9.hip).  Stride-2 input gradients run as FOUR parity phases in one launch: phase (ph, pw) owns the output pixels
+    // (2 i + ph, 2 j + pw), whose taps all have one row / column parity -- only those taps' k-slabs are walked (1, 2, 2 and 4 of the 9 taps of a 3 x 3 filter instead of 9
+    // slabs of which 5 .. 8 multiply zeros).  v9_phases = 0: plain launch; 4: the table below is valid.
+    int v9_phases;
+    struct V9Phase {
+        int tile0;          // first q-tile of this phase in the launch's q-tile order
+        int Hq, Wq, Mq;     // the phase's pixel grid (rows ph, ph + 2, ... of Ho; columns pw, pw + 2, ... of Wo) and N * Hq * Wq
+        int r0, s0;         // parity of the taps that reach this phase
+        int nk;             // k-slabs of the phase: taps x (C / 64)
+        FastDiv d_hw, d_w;
+    } v9[4];
 };
 
 struct WgradArgs {
@@ -314,6 +328,9 @@ void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst
 void launch_split3_rows(const float* src, long long M, int C, int lds, void* dst, int ldd, int pattern, hipStream_t st);
 int gather_x3_ksplit(const GatherArgs& a);
 int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bias, int relu, const float* mask, int ldmask, int accumulate, hipStream_t st);
+// small-map gather kernel (conv_v9.hip): 64 x 64 tiles, four waves, deep LDS-DMA ring, no split-K; parity phases for stride-2 input gradients
+bool gather_v9_wanted(const GatherArgs& a, int num_cu);
+int launch_gather_v9(GatherArgs& a, hipStream_t st, int num_cu);
 int x3_scratch(size_t bytes, char** out);                  // the engine's own arena (per device and scratch slot), grown on demand, never moved
 void set_wgrad_deterministic(bool on);  // odtk_debug_set key 5: deterministic split-reduce instead of float atomics
 int set_scratch_slot(int slot);          // split-K partial buffers are per (device, slot); 0 on success

@@ -609,7 +609,11 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     __shared__ __attribute__((aligned(16))) char smem[ZOFF + 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave % WP, wq = wave / WP;
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    // chunk-range split-K (round 5, F32OUT instantiations only: GatherArgs::cs_split): `cs_split` consecutive blocks share a tile
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int nsplit = (F32OUT && a.cs_split > 1) ? a.cs_split : 1;
+    const int part = nsplit > 1 ? lin % nsplit : 0;
+    const int vb = nsplit > 1 ? lin / nsplit : lin;
     const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
     const int p0 = tp * PT;
     // POOL (round 4): a tile = pool_rpt whole rows of ONE image (<= QT pixels; the rest of the tile is computed and dropped), so that the epilogue can pool them
@@ -622,6 +626,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         ph0 = (ti * a.pool_rpt) >> 1;
     }
     const int ncs = a.C >> 6;                            // 64-channel chunks (9 tap slabs each)
+    const int cs_begin = nsplit > 1 ? part * ncs / nsplit : 0, cs_end = nsplit > 1 ? (part + 1) * ncs / nsplit : ncs;     // this block's chunks
     const int x3nc = F32OUT ? (a.x3c >> 6) : 0;          // x3 engine: chunks per split part of the pixel operand (0 = plain; the bf16 instantiations compile it away)
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);
@@ -695,9 +700,9 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     };
 
 #pragma unroll
-    for (int i = 0; i < NPP; ++i) issue_x(i, 0, 0);
-    issue_w(0, 0);
-    issue_w(1, 1);
+    for (int i = 0; i < NPP; ++i) issue_x(i, cs_begin, 0);
+    issue_w(cs_begin * 9, 0);
+    issue_w(cs_begin * 9 + 1, 1);
     f32x16_v acc[PI][QI];
 #pragma unroll
     for (int i = 0; i < PI; ++i)
@@ -717,9 +722,9 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         constexpr int XBASE = DBUF ? tap * (NPP / 8) + (tap < NPP % 8 ? tap : NPP % 8) : (tap == 3 ? 0 : G1);
         constexpr int NPC = NP + NX;
         const char* sP = smem + WBASE + st_c * WST;
-        const unsigned pbase = smem_base + (DBUF ? (unsigned)((cs & 1) * PATCH) : 0u);
+        const unsigned pbase = smem_base + (DBUF ? (unsigned)(((cs - cs_begin) & 1) * PATCH) : 0u);
         const unsigned zrow = smem_base + ZOFF;
-        const bool more_x = cs + 1 < ncs, more_w = kt + 2 < 9 * ncs;
+        const bool more_x = cs + 1 < cs_end, more_w = kt + 2 < 9 * cs_end;
         // byte offset of the next chunk's channels in a pixel row (x3: chunks of the third part re-read the first part's), wave-uniform, once per slab
         const unsigned xchunk_next = __builtin_amdgcn_readfirstlane((unsigned)(((x3nc && cs + 1 >= x3nc) ? cs + 1 - x3nc : cs + 1) * 128));
         // filter slab kt+2 = (chunk, tap) two positions ahead
@@ -774,21 +779,21 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
                                 const int xi = XBASE + q - NP;
                                 const unsigned addr = xoff0 + (unsigned)xi * xstep + xchunk_next;
                                 glds16_buf_nc(rx, (((xok >> xi) & 1u) && more_x) ? addr : 0xFFFFFFF0u,
-                                              smem_base + (DBUF ? (unsigned)(((cs + 1) & 1) * PATCH) : 0u) + (wave_u + 4u * (unsigned)xi) * 1024u);
+                                              smem_base + (DBUF ? (unsigned)(((cs + 1 - cs_begin) & 1) * PATCH) : 0u) + (wave_u + 4u * (unsigned)xi) * 1024u);
                             }
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
         });
     };
-    int st_c = 0, st_n = 2, kt = 0;
-    for (int cs = 0; cs < ncs; ++cs) {
+    int st_c = 0, st_n = 2, kt = cs_begin * 9;
+    for (int cs = cs_begin; cs < cs_end; ++cs) {
         static_for<9>([&](auto TAPC) __attribute__((always_inline)) {
             constexpr int tap = decltype(TAPC)::value;
             // may stay in flight: what the PREVIOUS slab issued (filter slab kt+1 and the patch pieces of its position)
             constexpr int PREV = (tap + 8) % 9;
             constexpr int NXP = DBUF ? (PREV < 8 ? NPP / 8 + (PREV < NPP % 8 ? 1 : 0) : 0) : (PREV == 3 ? G1 : (PREV == 6 ? G2 - G1 : 0));
-            if (!DBUF && tap == 0 && cs > 0) {
+            if (!DBUF && tap == 0 && cs > cs_begin) {
                 // single patch buffer: every wave is past its last read of the old chunk (barrier), the rest of the new
                 // chunk's patch (groups G2 .. NPP-1) goes out now and must land before the first tap reads it
                 block_barrier();
@@ -819,7 +824,8 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
                     const int c = p0 + prow0 + i * 32 + 8 * g + 4 * hi;
                     if (c >= a.ldy) continue;
                     float o[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    x3_store4(a, m, c, o);
+                    if (nsplit > 1) *reinterpret_cast<float4*>(a.ws + ((size_t)part * a.M + m) * a.ldy + c) = make_float4(o[0], o[1], o[2], o[3]);   // f32 partial tile
+                    else x3_store4(a, m, c, o);
                 }
         }
         return;
@@ -1985,6 +1991,8 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((conv_gather_v6_kernel<15, false, 2, 4, 2, 2, 5, true>), dim3(grid_p), dim3(256), 0, st, a);
         return 0;
     }
+    if (g_num_cu == 0) query_num_cu();
+    if (gather_v9_wanted(a, g_num_cu)) return launch_gather_v9(a, st, g_num_cu);     // small launches, stride-2 input gradients (conv_v9.hip)
     const int tiles = a.tiles_p * a.tiles_q;
     const int nk = ceil_div(a.Kdim, 64);
     // split-K: few tiles with a long k loop leave most CUs idle and run at DMA latency; give every tile
@@ -2014,6 +2022,36 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         if (halo <= 160) hipLaunchKernelGGL((conv_gather_v6_kernel<21, false, 2, 4, 1, 2, 4>), dim3(a.tiles_q), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_gather_v6_kernel<26, false, 4, 9, 1, 2, 4>), dim3(a.tiles_q), dim3(256), 0, st, a);
         return 0;
+    }
+    // Round 5: 3 x 3 / stride 1 layers with few tiles on the RASTER-RUN HALO kernel with a split over whole 64-channel chunks instead of the 8-wave kernel's split
+    // over 64-element slabs (YOLOv3's 13 x 13 / 26 x 26 layers at 8 images, pred2 / pred3 of SSD300): one patch per chunk instead of one gathered slab per tap, four
+    // waves of 2 x 4 MFMA tiles -- the halo kernel's 1 000+ TFLOP/s instead of the 8-wave kernel's ~550.  192- or 256-pixel tiles by the same cost model as the
+    // unsplit launch; dbg2 bit 8 = off (A/B).
+    if (ksplit >= 2 && v6_ok && halo <= 160 && (a.C >> 6) >= 2 && !(a.dbg2 & 256)) {
+        const int ncs = a.C >> 6;
+        int best_qt = 0, best_split = 1;
+        long long best_cost = 0;
+        for (int qt = 256; qt >= 192; qt -= 64) {
+            const int t = ceil_div(a.M, qt) * a.tiles_p;
+            int sp = g_num_cu / t;
+            if (sp > ncs) sp = ncs;
+            if (sp < 1) sp = 1;
+            const long long cost = (long long)ceil_div(t * sp, g_num_cu) * (ceil_div(ncs, sp) * (qt + 8) + 48);     // rounds x (chunks x pixels + prologue / epilogue)
+            if (best_qt == 0 || cost < best_cost) { best_qt = qt; best_split = sp; best_cost = cost; }
+        }
+        if (best_split >= 2) {
+            float* ws = nullptr;
+            if (int e = conv_scratch((size_t)best_split * a.M * a.ldy * sizeof(float), &ws)) return e;
+            a.ws = ws; a.cs_split = best_split;
+            a.tiles_q = ceil_div(a.M, best_qt);
+            const int grid = a.tiles_p * a.tiles_q * best_split;
+            if (best_qt == 192) hipLaunchKernelGGL((conv_gather_v6_kernel<11, true, 0, 0, 2, 2, 3, false, true>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gather_v6_kernel<13, true, 0, 0, 2, 2, 4, false, true>), dim3(grid), dim3(256), 0, st, a);
+            a.ksplit = best_split;                        // what splitk_finish_kernel sums (same [part][M][ldy] layout)
+            hipLaunchKernelGGL(splitk_finish_kernel, dim3(ceil_div(a.M * (a.ldy / 8), 256)), dim3(256), 0, st, a);
+            a.ksplit = -6;                                // odtk_conv_last_kernel: "conv_gather_v6_kernel+splitk"
+            return 0;
+        }
     }
     if (ksplit >= 2) {
         float* ws = nullptr;

@@ -158,6 +158,66 @@ def test_conv_legacy_engine_extra(case, dev):
         ops.debug_set(1, 0)
 
 
+# Round 5: the small-map gather kernel (csrc/conv_v9.hip: 64 x 64 tiles, whole reduction per workgroup, parity phases for stride-2 input gradients) and the
+# chunk-range split-K of the raster-run halo kernel.  odtk_debug_set key 6: bit 7 = the small-map kernel wherever it is supported (every case below, whatever
+# its size), bit 6 = never (the same cases on the kernels it replaced: the 3 x 3 / stride 1 ones with few tiles then take the halo kernel's chunk split).
+V9_EXTRA_CASES = [
+    (1, 8, 8, 64, 64, 3, 2, 1),       # stride 2 on an even map (asymmetric SAME pad: the tap parities of the four phases swap)
+    (3, 13, 17, 128, 64, 3, 2, 1),    # ... odd x odd, ragged phase grids (7 x 9, 7 x 8, 6 x 9, 6 x 8), tiles straddle images
+    (2, 12, 12, 64, 128, 1, 2, 1),    # ... 1 x 1 / stride 2: three of the four phases have NO tap (zeros, still masked / accumulated)
+    (2, 26, 26, 64, 128, 3, 2, 1),    # ... DarkNet-53 down-sampling geometry
+    (1, 7, 9, 192, 96, 5, 2, 1),      # ... 5 x 5 taps: 9, 6, 6, 4 taps per phase
+    (1, 1, 1, 64, 64, 3, 2, 1),       # ... a single pixel: three empty phases
+    (4, 5, 5, 256, 128, 1, 1, 1),     # 1 x 1 on a 5 x 5 map: two tiles straddling four images
+    (2, 3, 3, 256, 100, 3, 1, 1),     # 18 pixels: one ragged tile, channel tail 100 = 64 + 36
+    (2, 10, 10, 72, 150, 3, 1, 1),    # C % 64 != 0: the per-lane tap walk (a slab straddles taps), channel tail
+    (1, 9, 11, 24, 40, 3, 1, 1),      # ... 24 channels: 2.67 taps per slab, 216-element reduction = 3.4 slabs (zero-filled k tail)
+    (2, 19, 19, 512, 512, 3, 1, 1),   # long reduction (72 slabs) through the four-stage ring
+    (2, 19, 19, 1024, 150, 3, 1, 1),  # 144 slabs
+    (3, 13, 13, 192, 256, 3, 1, 1),   # halo kernel's chunk split when the small-map kernel is off: three chunks over <= 3 parts
+]
+
+
+@pytest.fixture(params=[128, 64], ids=["v9-forced", "v9-off"])
+def v9_engine(request):
+    ops = _ops()
+    ops.debug_set(6, request.param)
+    yield
+    ops.debug_set(6, 0)
+
+
+@pytest.mark.parametrize("case", V9_EXTRA_CASES + V3_EXTRA_CASES[:12])
+def test_conv_v9_engine(case, dev, v9_engine):
+    _conv_case(case, "bf16", dev)
+    assert _ops().conv_last_kernel() != ""
+
+
+def test_conv_v9_is_taken_where_expected(dev):
+    """the dispatch itself: SSD300's small layers at batch 32 and every stride-2 input gradient on whole 64-channel chunks run on the small-map kernel,
+    the 13 x 13 / 3 x 3 layer of DarkNet-53 at 8 images on the halo kernel's chunk split, the trunk where it was"""
+    ops = _ops()
+
+    def kernels(N, H, C, K, k, s, d=1):
+        Kp = ops.pad_to(K, 8)
+        desc = ops.conv_desc(N, H, H, C, C, K, Kp, k, s, d, ops.BF16, ops.BF16)
+        M = N * desc.Ho * desc.Wo
+        x = torch.zeros(N * H * H, C, dtype=torch.bfloat16, device=dev)
+        w = torch.zeros(K * k * k * C, dtype=torch.bfloat16, device=dev)
+        wt = torch.zeros(C * k * k * Kp, dtype=torch.bfloat16, device=dev)
+        y = torch.zeros(M, Kp, dtype=torch.bfloat16, device=dev)
+        ops.conv2d_fwd(desc, x, w, torch.zeros(K, device=dev), y, True)
+        f = ops.conv_last_kernel()
+        ops.conv2d_dgrad(desc, y, Kp, wt, None, x, False)
+        return f, ops.conv_last_kernel()
+    assert kernels(32, 5, 128, 256, 3, 1) == ("conv_gather_v9_kernel", "conv_gather_v9_kernel")
+    assert kernels(32, 10, 512, 128, 1, 1) == ("conv_gather_v9_kernel", "conv_gather_v9_kernel")
+    assert kernels(32, 19, 256, 512, 3, 2)[1] == "conv_gather_v9_kernel"          # parity phases at any size
+    assert kernels(8, 208, 64, 128, 3, 2)[1] == "conv_gather_v9_kernel"
+    assert kernels(8, 13, 512, 1024, 3, 1) == ("conv_gather_v6_kernel+splitk", "conv_gather_v6_kernel+splitk")
+    assert kernels(32, 38, 512, 512, 3, 1) == ("conv_gather_v6_kernel", "conv_gather_v6_kernel")
+    torch.cuda.synchronize()
+
+
 # every distinct convolution geometry of SSD300 (SSD300.py:192-314, heads :85-90) at batch 2, through the AUTO dispatch:
 # first-layer kernel, 64->64 halo kernels, 8-wave gather, raster-run halo gather (also dilated), split-K, strided dgrad
 SSD300_LAYER_CASES = [

@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         rows_here = a.H - ti * a.pool_rpt < a.pool_rpt ? a.H - ti * a.pool_rpt : a.pool_rpt;
         ph0 = (ti * a.pool_rpt) >> 1;
     }
-    const int ncs = a.C >> 6;                            // 64-channel chunks (9 tap slabs each)
+    const int ncs = (a.C + 63) >> 6;                     // 64-channel chunks (9 tap slabs each); round 5: the last one may be partial (C % 8 == 0)
     const int cs_begin = nsplit > 1 ? part * ncs / nsplit : 0, cs_end = nsplit > 1 ? (part + 1) * ncs / nsplit : ncs;     // this block's chunks
     const int x3nc = F32OUT ? (a.x3c >> 6) : 0;          // x3 engine: chunks per split part of the pixel operand (0 = plain; the bf16 instantiations compile it away)
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
@@ -650,6 +650,9 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     const int xrow0 = wave * 8 + (lane >> 3);
     const unsigned xoff0 = (unsigned)((q0 - a.dil * (a.W + 1) + xrow0) * a.ldx * 2 + (((lane & 7) ^ ((xrow0 >> 1) & 7)) * 16));
     const unsigned xstep = (unsigned)(64 * a.ldx);
+    // channels left of this lane's 16-byte column in a chunk: chunk cs is fetched iff cs * 64 < xcmax.  With C % 64 != 0 (the heads' input gradients: 104, 152
+    // channels of dy) the columns past C of the last chunk are zero-filled by the range check; what the filter slab holds there (the next tap's rows) meets zeros.
+    const int xcmax = a.C - (((lane & 7) ^ ((xrow0 >> 1) & 7)) << 3);
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
         const int g = q0 - a.dil * (a.W + 1) + xrow0 + 32 * i;
@@ -696,7 +699,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
     auto issue_x = [&](int i, int cs, int buf) __attribute__((always_inline)) {    // patch piece i of chunk cs
         const int xcs = (x3nc && cs >= x3nc) ? cs - x3nc : cs;           // x3: chunks of the third part re-read the first part's
         const unsigned addr = xoff0 + (unsigned)i * xstep + (unsigned)(xcs * 128);
-        glds16_buf_nc(rx, ((xok >> i) & 1u) ? addr : 0xFFFFFFF0u, smem_base + (unsigned)buf * PATCH + (wave_u + 4u * (unsigned)i) * 1024u);
+        glds16_buf_nc(rx, (((xok >> i) & 1u) && xcs * 64 < xcmax) ? addr : 0xFFFFFFF0u, smem_base + (unsigned)buf * PATCH + (wave_u + 4u * (unsigned)i) * 1024u);
     };
 
 #pragma unroll
@@ -724,7 +727,7 @@ __global__ void __launch_bounds__(256) conv_gather_v6_kernel(const GatherArgs a)
         const char* sP = smem + WBASE + st_c * WST;
         const unsigned pbase = smem_base + (DBUF ? (unsigned)(((cs - cs_begin) & 1) * PATCH) : 0u);
         const unsigned zrow = smem_base + ZOFF;
-        const bool more_x = cs + 1 < cs_end, more_w = kt + 2 < 9 * cs_end;
+        const bool more_x = cs + 1 < cs_end && (cs + 1) * 64 < xcmax, more_w = kt + 2 < 9 * cs_end;
         // byte offset of the next chunk's channels in a pixel row (x3: chunks of the third part re-read the first part's), wave-uniform, once per slab
         const unsigned xchunk_next = __builtin_amdgcn_readfirstlane((unsigned)(((x3nc && cs + 1 >= x3nc) ? cs + 1 - x3nc : cs + 1) * 128));
         // filter slab kt+2 = (chunk, tap) two positions ahead
@@ -2005,7 +2008,9 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     // (round 4: rows of 80 .. 95 pixels -- conv3_x of the 320-pixel models, 162 halo rows: two more than the double-buffered patch holds -- on a 448-row patch)
     const bool v6_wide = halo > 160 && halo <= 352 && a.dil * a.W >= 80 && !(a.dbg & (1 << 26));
     const bool v6_wide_hi = v6_wide && a.dil * a.W >= 144 && halo <= 320;   // what the 512-pixel tile variants are instantiated for
-    const bool v6_ok = !(a.dbg & 65536) && PT == 128 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
+    // (round 5: C % 64 != 0 with a zero-filled last chunk where at least 70 % of the chunks' channels are real -- 104 of 128, 152 of 192; dbg2 bit 10 = off)
+    const bool c_ok = a.C % 64 == 0 || (a.C > 64 && a.C % 8 == 0 && 10 * a.C >= 7 * 64 * ceil_div(a.C, 64) && !(a.dbg2 & 1024));
+    const bool v6_ok = !(a.dbg & 65536) && PT == 128 && c_ok && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 &&
                        a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && (halo <= 160 || v6_wide) && a.Kdim == 9 * a.C;
     const int v6_min_tiles = (a.dbg >> 18) & 255;         // A/B (dbg bits 18-25): halo kernel instead of split-K from this many tiles on
     if (tiles <= 128 && nk >= 8 && !(a.dbg & 8192) && !(v6_ok && v6_min_tiles && tiles >= v6_min_tiles)) {
@@ -2027,8 +2032,8 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     // over 64-element slabs (YOLOv3's 13 x 13 / 26 x 26 layers at 8 images, pred2 / pred3 of SSD300): one patch per chunk instead of one gathered slab per tap, four
     // waves of 2 x 4 MFMA tiles -- the halo kernel's 1 000+ TFLOP/s instead of the 8-wave kernel's ~550.  192- or 256-pixel tiles by the same cost model as the
     // unsplit launch; dbg2 bit 8 = off (A/B).
-    if (ksplit >= 2 && v6_ok && halo <= 160 && (a.C >> 6) >= 2 && !(a.dbg2 & 256)) {
-        const int ncs = a.C >> 6;
+    if (ksplit >= 2 && v6_ok && halo <= 160 && ceil_div(a.C, 64) >= 2 && !(a.dbg2 & 256)) {
+        const int ncs = ceil_div(a.C, 64);
         int best_qt = 0, best_split = 1;
         long long best_cost = 0;
         for (int qt = 256; qt >= 192; qt -= 64) {

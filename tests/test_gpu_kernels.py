@@ -175,6 +175,9 @@ V9_EXTRA_CASES = [
     (2, 19, 19, 512, 512, 3, 1, 1),   # long reduction (72 slabs) through the four-stage ring
     (2, 19, 19, 1024, 150, 3, 1, 1),  # 144 slabs
     (3, 13, 13, 192, 256, 3, 1, 1),   # halo kernel's chunk split when the small-map kernel is off: three chunks over <= 3 parts
+    (2, 19, 19, 104, 256, 3, 1, 1),   # ... with a PARTIAL last chunk (104 = 64 + 40 channels: the columns past C are zero-filled by the range check)
+    (24, 19, 19, 104, 512, 3, 1, 1),  # ... the unsplit halo kernel on 104 channels (136 tiles), and its input gradient on 512
+    (6, 38, 38, 152, 128, 3, 1, 1),   # ... 152 = 2 x 64 + 24
 ]
 
 

@@ -10,15 +10,20 @@ images/GPU already resident in HBM.  Weak scaling: every rank keeps batch 32 (ea
 exactly the reference computation, local BatchNorm; SURVEY.md 8e option A).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the DOMINANT device kernel of the step (largest summed duration; the 8-wave
-                  implicit-GEMM gather kernel that serves conv forward and dgrad), HIP-event timed
-                  inside the timed region on the launch stream: algorithmic FLOPs per launch / average
+  roofline     -- the DOMINANT device kernel of the step (largest summed duration; the raster-run
+                  halo implicit-GEMM kernel that serves conv forward and dgrad), HIP-event timed
+                  right after the timed region on the launch stream: algorithmic FLOPs per launch / average
                   launch duration vs the dense bf16 MFMA peak (2.5 PFLOP/s).  `traffic` = HBM bytes
-                  per launch of that kernel from the committed rocprofv3 PMC passes (profiles/*.json,
-                  FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE).  `family` = the same
-                  ratio over every conv kernel (fwd + dgrad + wgrad, all layers).
+                  per launch of that kernel from two `rocprofv3 --pmc` child passes run NOW (round 5:
+                  FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; null when rocprofv3 is
+                  missing -- never a committed constant).  `family` = the same ratio over every conv
+                  kernel (fwd + dgrad + wgrad, all layers).
   cpu_baseline -- the CPU oracle (PyTorch-CPU restatement of the reference graph; TF 1.13 cannot
                   run here) timed on this box's host cores on a bounded sample (N=1 only).
+After the headline fields are final (N = 1, default configuration; `--no-extras` skips them):
+  sustained    -- the same step for >= 250 steps (~2 s) between two synchronisations
+  inference    -- SSD300.test_one_image latency per engine (f32 = the test-mode default, f32x3, bf16), CPU oracle beside it
+  configs      -- compact records of BASELINE.json's configurations 3-5 (yolov3, fcos, centernet, retinanet), one child run each
 """
 import argparse
 import json
@@ -148,7 +153,7 @@ class ConvTimer:
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
         fl, t, n, ab = per_kernel[dom]
         t_trim = trimmed_kernel[dom][1]
-        pmc = pmc_traffic(dom) if getattr(self, 'use_pmc', True) else None       # (the committed PMC passes are of the SSD300 command only)
+        pmc = None                                  # HBM traffic / MFMA-busy counters: measured live after the timed region (live_pmc_traffic), never read from a file
         tot_f = sum(v[0] for v in per_kernel.values()); tot_t = sum(v[1] for v in per_kernel.values())
         return {
             'bound': 'mfma', 'kernel': dom,
@@ -173,30 +178,6 @@ class ConvTimer:
                         for k, v in per_pass.items()},
             'whole_step_frac_of_mfma_peak': round(whole_step_frac, 4),
         }
-
-
-def pmc_traffic(kernel):
-    """HBM bytes and MFMA-busy cycles per launch of `kernel` from the newest committed PMC summary (profiles/*pmc*.json): the dispatch-weighted
-    mean over the template variants of that kernel (the bench groups launches by the name odtk_conv_last_kernel reports, without template arguments),
-    or None when no profile names the kernel."""
-    import glob
-    base = kernel.split('<')[0]
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc*.json')), reverse=True):
-        try:
-            d = json.load(open(f))
-        except Exception:                                         # noqa: BLE001
-            continue
-        rows = [(name, e) for name, e in d.items()
-                if name.split('<')[0].split('::')[-1] == base and 'hbm_read_bytes_corrected' in e and 'hbm_write_bytes' in e and e.get('_dispatches', 0) > 0]
-        if rows:
-            n = sum(e['_dispatches'] for _, e in rows)
-            avg = lambda key: sum(e.get(key, 0.0) * e['_dispatches'] for _, e in rows) / n        # noqa: E731
-            rd, wr = avg('hbm_read_bytes_corrected'), avg('hbm_write_bytes')
-            return {'hbm_read_bytes': int(rd), 'hbm_write_bytes': int(wr), 'hbm_bytes': int(rd + wr),
-                    'mfma_busy_cycles': avg('SQ_VALU_MFMA_BUSY_CYCLES'),
-                    'source': 'STATIC (committed rocprofv3 --pmc passes of this command, not re-measured in this run): '
-                              + os.path.relpath(f, ROOT) + f' :: dispatch-weighted mean over {len(rows)} template variant(s) of {base}, {n} launches'}
-    return None
 
 
 class ClockSampler:
@@ -262,6 +243,8 @@ def main():
     ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f32x3'], help='engine (default: the one the model class defaults to in training mode: bf16 for ssd300 / yolov3 / fcos / centernet, f32x3 -- f32 tensors, ODTK_F32X3 convolution descriptors -- for retinanet)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='N = 1, ssd300: skip what follows the headline measurement (sustained run, live PMC traffic passes, '
+                                                             'test_one_image latency, the compact records of configurations 3-5)')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay in the timed region (the default at N = 1 since round 3)')
     ap.add_argument('--launch-list', action='store_true', help="N = 1: use_graph='list' -- the step's C-ABI calls replayed from a recorded list of pre-bound argument "
                                                               'tuples (no Python wrappers, plain launches in stream order)')
@@ -302,9 +285,6 @@ def main():
         args.batch = BC.SHAPES[args.config][1]
     if args.dtype is None:
         args.dtype = BC.SHAPES[args.config][2]
-    if args.dtype == 'f32x3' and args.config in ('ssd300', 'yolov3'):
-        raise SystemExit("bench.py: the 'f32x3' engine exists for the classes with an f32 TRAINING engine (retinanet, fcos, centernet; tools/*_bench.py for RefineDet320 / "
-                         "PFPNetR / YOLOv2 / LH_RCNN); ssd300 and yolov3 train in bf16, their f32 engines are parity references")
     if args.config != 'ssd300':
         return bench_other(args, world, rank, local_rank)
     if not torch.cuda.is_available():
@@ -417,7 +397,7 @@ def main():
                                                                         else f'hip-graph replay (fwd+loss; bwd as {len(model._g_back_segs or [])} '
                                                                              'bucket graphs with RCCL all-reduces between them)')},
         }
-        peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
+        peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else (MFMA_PEAK_BF16 / 3 if args.dtype == 'f32x3' else MFMA_PEAK_F32)
         if timer.records:
             out['roofline'] = timer.roofline(min(args.steps, 5) + 1, peak, value / world * 188.0e9 / peak)
             if args.conv_table:
@@ -432,10 +412,165 @@ def main():
             out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
+        if world == 1 and not args.no_extras and not args.dp_world1:
+            # Everything below runs AFTER the headline measurement and outside its timed region; the headline fields above are final.
+            t_extras = time.perf_counter()
+            try:
+                out['sustained'] = sustained_run(model, lr, B, local_rank)
+            except Exception as e:                                       # noqa: BLE001
+                out['sustained'] = {'error': f'{type(e).__name__}: {e}'}
+            if 'roofline' in out and not args.no_conv_events:
+                out['roofline'].update(live_pmc_traffic(out['roofline']))
+            try:
+                out['inference'] = inference_bench(dev, with_cpu=not args.no_cpu_baseline)
+            except Exception as e:                                       # noqa: BLE001
+                out['inference'] = {'error': f'{type(e).__name__}: {e}'}
+            out['configs'] = configs_bench(budget_s=170.0 - (time.perf_counter() - t_extras))
+            out['extras_s'] = round(time.perf_counter() - t_extras, 1)
         print(json.dumps(out), flush=True)
     if use_pg:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def sustained_run(model, lr, B, local_rank, min_steps=250):
+    """The same eager step for >= 250 steps (~2 s: long enough for an outside sampler -- rocm-smi, the driver's gpu_busy -- to see the GPU busy, and for the
+    clock / power state to settle) between two device synchronisations.  Reported NEXT to the headline, never instead of it."""
+    torch.cuda.synchronize()
+    clock = ClockSampler(local_rank)
+    clock.start()
+    t0 = time.perf_counter()
+    for _ in range(min_steps):
+        model.train_step(lr)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    clock.stop()
+    return {'steps': min_steps, 'seconds': round(dt, 3), 'ms_per_step': round(dt / min_steps * 1e3, 3), 'images_per_sec': round(B * min_steps / dt, 1),
+            'sclk_mhz': clock.summary()}
+
+
+def _rocprof_pass(counters, tag, timeout_s=150):
+    """one `rocprofv3 --pmc` pass (counters only: no trace domains) over a 2-step child run of this script; -> {kernel short name: {counter: mean per dispatch, '_n': dispatches}}"""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None, 'rocprofv3 not on PATH'
+    d = tempfile.mkdtemp(prefix=f'odtk_pmc_{tag}_', dir='/tmp')
+    cmd = [exe, '--pmc'] + counters + ['-f', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '3', '--no-cpu-baseline',
+                                       '--no-conv-events', '--eager', '--no-extras']
+    try:
+        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        if r.returncode != 0:
+            return None, f'rocprofv3 exit code {r.returncode}: ' + r.stderr.decode(errors='replace')[-200:]
+        acc = {}
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            with open(f, newline='') as fh:
+                for row in csv.DictReader(fh):
+                    k = re.sub(r'\(anonymous namespace\)::', '', row['Kernel_Name'])
+                    k = re.sub(r'^void ', '', k).split('(')[0].split('<')[0].split('::')[-1]
+                    e = acc.setdefault(k, {}).setdefault(row['Counter_Name'], [0.0, 0])
+                    e[0] += float(row['Counter_Value']); e[1] += 1
+        return {k: dict({c: v[0] / max(v[1], 1) for c, v in cs.items()}, _n=max(v[1] for v in cs.values())) for k, cs in acc.items()}, None
+    except Exception as e:                                               # noqa: BLE001
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def live_pmc_traffic(rf):
+    """HBM bytes and MFMA-busy cycles per launch of the dominant kernel, measured NOW: two `rocprofv3 --pmc` child passes of this command at 2 steps
+    (FETCH_SIZE + SQ_VALU_MFMA_BUSY_CYCLES; WRITE_SIZE -- the two TCC counters do not fit one pass), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
+    (KiB units; FETCH_SIZE doubled on gfx950 for wide coalesced reads).  Null with the reason when rocprofv3 is missing or a pass fails -- never a committed constant."""
+    base = rf['kernel'].split('<')[0].split('+')[0]
+    a, ea = _rocprof_pass(['FETCH_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'], 'a')
+    b, eb = (None, 'skipped') if a is None else _rocprof_pass(['WRITE_SIZE'], 'b')
+    if a is None or b is None or base not in a or base not in b:
+        return {'traffic': None, 'traffic_note': 'no live PMC pass: ' + str(ea or eb or f'{base} not in the counter output')}
+    rd = 2.0 * a[base]['FETCH_SIZE'] * 1024.0
+    wr = b[base]['WRITE_SIZE'] * 1024.0
+    t = rf['avg_launch_us'] * 1e-6
+    return {'traffic': {'hbm_read_bytes': int(rd), 'hbm_write_bytes': int(wr), 'hbm_bytes': int(rd + wr), 'mfma_busy_cycles': a[base].get('SQ_VALU_MFMA_BUSY_CYCLES'),
+                        'launches_counted': int(a[base]['_n']),
+                        'source': 'THIS RUN: two rocprofv3 --pmc child passes of `bench.py --steps 2 --warmup 3 --eager` right after the timed region (mean per launch over every '
+                                  f'template variant of {base}; FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024)'},
+            'mfma_busy_pct': None if not a[base].get('SQ_VALU_MFMA_BUSY_CYCLES') else round(100.0 * a[base]['SQ_VALU_MFMA_BUSY_CYCLES'] / (t * 2.4e9 * 1024), 1),
+            'hbm_gbps': round((rd + wr) / t / 1e9, 1), 'hbm_frac_of_8TBps': round((rd + wr) / t / 8e12, 4)}
+
+
+def inference_bench(dev, with_cpu=True, reps=20):
+    """`SSD300.test_one_image` (SSD300.py:486-488; the one thing the reference times itself: YOLOv3.py:459-462): forward + decode + per-class NMS + the copy of the
+    detections to the host, one 300 x 300 image, random-init weights (score threshold 0.5 as testSSD300.py), median wall time of `reps` calls per engine --
+    'f32' is the class's default in test mode (exact f32 MFMA), 'f32x3' the operand-splitting engine, 'bf16' for contrast (it misses north_star's 1e-3)."""
+    import numpy as np
+    import odtk
+    cfg = {'mode': 'test', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+           'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '', 'verbose': False, 'seed': 0}
+    g = torch.Generator().manual_seed(5)
+    img = (torch.rand(1, 300, 300, 3, generator=g) * 255.).numpy()
+    res = {'what': 'SSD300.test_one_image, 1 image 300x300, random-init weights; median ms of %d calls (host wall time incl. the device-to-host copy of the detections)' % reps}
+    for engine in ('f32', 'f32x3', 'bf16'):
+        m = odtk.SSD300(dict(cfg, compute_dtype=engine), None)
+        for _ in range(3):
+            out = m.test_one_image(img)
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = m.test_one_image(img)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        res[engine] = {'ms': round(ts[len(ts) // 2], 3), 'min_ms': round(ts[0], 3), 'detections': int(len(out[0])), 'default_test_engine': engine == 'f32'}
+        del m
+    if with_cpu:
+        from oracle import ssd300_ref as R
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        p = R.init_params(0)
+        x = torch.from_numpy(np.asarray(img))
+        R.test_one_image(p, x)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 1 or (time.perf_counter() - t0 < 5 and n < 5):
+            R.test_one_image(p, x)
+            n += 1
+        res['cpu_baseline'] = {'ms': round((time.perf_counter() - t0) / n * 1e3, 1), 'cores': cores, 'kind': 'port',
+                               'sample': f'{n} call(s) of the PyTorch-CPU oracle\'s test_one_image on the same image'}
+    return res
+
+
+def configs_bench(budget_s=120.0):
+    """BASELINE.json's configurations 3-5, one child `python bench.py --config <name> --steps 10 --warmup 3 --no-cpu-baseline` each (its own process: a failure there
+    cannot touch the headline line), reduced to a compact record: images/s, ms/step, engine, dominant kernel and its fraction of the engine's MFMA peak, the conv
+    family's fraction.  Stops starting children when the time budget of the default run is spent."""
+    import subprocess
+    res = {}
+    t0 = time.perf_counter()
+    for name in ('yolov3', 'fcos', 'centernet', 'retinanet'):
+        left = budget_s - (time.perf_counter() - t0)
+        if left < 25:
+            res[name] = {'skipped': 'time budget of the default run spent'}
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--config', name, '--steps', '10', '--warmup', '3', '--no-cpu-baseline'],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=min(left, 90))
+            line = [ln for ln in r.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+            if r.returncode != 0 or not line:
+                res[name] = {'error': f'exit code {r.returncode}: ' + r.stderr.decode(errors='replace')[-200:]}
+                continue
+            d = json.loads(line[-1])
+            rf = d.get('roofline', {})
+            res[name] = {'metric': d['metric'], 'images_per_sec': d['value'], 'ms_per_step': d['ms_per_step'], 'dtype': d['dtype'], 'batch_per_gpu': d['config']['global_batch'],
+                         'dominant_kernel': rf.get('kernel'), 'dominant_TFLOPs': rf.get('achieved'), 'dominant_frac': rf.get('frac'),
+                         'conv_family_frac': rf.get('family', {}).get('frac'), 'conv_ms_per_step': rf.get('family', {}).get('conv_ms_per_step'),
+                         'peak_TFLOPs': rf.get('peak'), 'final_loss': d['config'].get('final_loss')}
+        except Exception as e:                                           # noqa: BLE001
+            res[name] = {'error': f'{type(e).__name__}: {e}'}
+    return res
 
 
 def apply_debug_switches(args):
@@ -473,7 +608,6 @@ def bench_other(args, world, rank, local_rank):
     model.set_batch(r['images'], r['gt'])
     alg = {id(d): (cin, cout) for d, cin, cout, _ in BC.conv_layers(name, model)}
     timer = ConvTimer(ops, alg)
-    timer.use_pmc = False
     timer.install()
 
     def barrier():

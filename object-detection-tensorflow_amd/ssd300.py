@@ -11,7 +11,7 @@ is a re-iterable (or a `(initializer, iterable)` pair, mirroring the reference t
 `(images f32 [B,300,300,3] RGB 0..255, ground_truth f32 [B,pad,5] = [yc,xc,h,w,cls] px, pad rows -1)`
 as torch tensors or numpy arrays -- exactly what utils/image_augmentor.py:24-27 documents.
 
-Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' | 'f32'; default bf16 in train mode, f32 in test mode),
+Extra, optional config keys (absent in the reference): 'compute_dtype' ('bf16' | 'f32' | 'f32x3'; default bf16 in train mode, f32 in test mode),
 'device', 'seed', 'verbose', 'test_subtract_mean' (False = reproduce the reference's test-mode feed quirk),
 'use_graph' (False, default since round 3: eager launches -- measured 1-3 % FASTER than graph replay on every box once the step was down to ~200
 launches (profiles/r03e_launch_mode_ab.md) | True: replay the step's kernel launches from HIP graphs after two eager steps | 'auto' = the faster of the two,
@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import BF16, F32
+from ._lib import BF16, F32, F32X3
 
 INPUT_SIZE = 300
 MEAN_RGB = (123.68, 116.779, 103.979)            # reference SSD300.py:55 (sic: 103.979)
@@ -185,9 +185,13 @@ class SSD300:
 
         # training defaults to the bf16 engine (the benchmarked configuration); inference to f32: north_star's 1e-3 bound on
         # boxes / scores holds for the f32 engine only (tests/test_gpu_ssd300_b32.py::test_bf16_test_one_image_vs_oracle)
+        # 'f32x3' (round 5, the engine the other seven classes have had since round 4): f32 tensors, convolution descriptors of dtype ODTK_F32X3 -- the library runs
+        # a layer's passes as three bf16 MFMA products per f32 product (hi*hi + hi*lo + lo*hi, f32 accumulation: 3e-5 of the exact f32 result) where that is
+        # faster than the exact-f32 MFMA: the engine that meets north_star's 1e-3 on boxes / scores at a multiple of the exact engine's rate
         cd = config.get('compute_dtype', 'bf16' if config['mode'] == 'train' else 'f32')
-        assert cd in ('bf16', 'f32')
+        assert cd in ('bf16', 'f32', 'f32x3')
         self.DT = BF16 if cd == 'bf16' else F32
+        self.CDT = F32X3 if cd == 'f32x3' else self.DT       # what the convolution descriptors carry
         self.tdt = ops.torch_dtype(self.DT)
         self.chunk = ops.chunk(self.DT)
         self.verbose = config.get('verbose', True)
@@ -416,7 +420,7 @@ class SSD300:
             name = item[0]
             if name.startswith('conv'):
                 c = self.convs[name]
-                self.desc[name] = ops.conv_desc(N, H, H, cur_c, cur_c, c.cout, c.cout, 3, 1, 1, self.DT, self.DT)
+                self.desc[name] = ops.conv_desc(N, H, H, cur_c, cur_c, c.cout, c.cout, 3, 1, 1, self.CDT, self.CDT)
                 self.acts[name] = _Act(N, H, H, c.cout, c.cout, dt, dev)
                 self.vgg_plan.append(('conv', name, prev))
                 cur_c = c.cout
@@ -450,7 +454,7 @@ class SSD300:
         max_ws = 0
         for (name, ci, co, k, s, d) in self.EXTRA_SEQ:
             src = self.acts[prev]
-            self.desc[name] = ops.conv_desc(N, src.H, src.W, ci, src.ld, co, co, k, s, d, self.DT, self.DT)
+            self.desc[name] = ops.conv_desc(N, src.H, src.W, ci, src.ld, co, co, k, s, d, self.CDT, self.CDT)
             Ho = self.desc[name].Ho
             self.zbuf[name] = _Act(N, Ho, Ho, co, co, dt, dev)
             self.acts[name] = _Act(N, Ho, Ho, co, co, dt, dev)
@@ -469,7 +473,7 @@ class SSD300:
             src = self.acts[src_name]
             c = self.convs[name]
             kp = ops.pad_to(c.cout, 8)
-            self.desc[name] = ops.conv_desc(N, src.H, src.W, src.C, src.ld, c.cout, kp, 3, 1, 1, self.DT, self.DT)
+            self.desc[name] = ops.conv_desc(N, src.H, src.W, src.C, src.ld, c.cout, kp, 3, 1, 1, self.CDT, self.CDT)
             self.zbuf[name] = _Act(N, src.H, src.W, c.cout, kp, dt, dev)
             self.bnsave[name] = (torch.zeros(c.cout, device=dev), torch.zeros(c.cout, device=dev))
             max_ws = max(max_ws, ops.bn_workspace_bytes(src.M, c.cout))

@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from . import heads, ops
-from ._lib import BF16, F32
+from ._lib import BF16, F32, F32X3
 
 MEAN_RGB = (123.68, 116.779, 103.979)                                       # YOLOv3.py:65
 DARKNET_BLOCKS = ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4))         # :391-395
@@ -74,7 +74,10 @@ class YOLOv3:
         self.final_units = (self.num_classes + 5) * self.num_priors
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
-        self.DT = {'bf16': BF16, 'f32': F32}[config.get('compute_dtype', 'bf16')]
+        # 'f32x3' (round 5): f32 tensors, convolution descriptors of dtype ODTK_F32X3 (three bf16 MFMA products per f32 product where that is faster: include/odtk.h)
+        engine = config.get('compute_dtype', 'bf16')
+        self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[engine]
+        self.CDT = F32X3 if engine == 'f32x3' else self.DT
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
         self.chunk = ops.chunk(self.DT)
         h, w, c = self.data_shape
@@ -210,7 +213,7 @@ class YOLOv3:
             name, cin, cout, k, stride, act = next(it)
             assert cin == src.C, (name, cin, src.C)
             ldz = ops.pad_to(cout, self.chunk)
-            d = ops.conv_desc(N, src.H, src.W, ops.pad_to(cin, self.chunk), src.ld, cout, ldz, k, stride, 1, self.DT, self.DT)
+            d = ops.conv_desc(N, src.H, src.W, ops.pad_to(cin, self.chunk), src.ld, cout, ldz, k, stride, 1, self.CDT, self.CDT)
             self.desc[name] = d
             z = _Act(name + '.z', N, d.Ho, d.Wo, cout, ldz, dt, dev)
             y = _Act(name, N, d.Ho, d.Wo, cout, cout if out_f32 else ldz, torch.float32 if out_f32 else dt, dev)

@@ -29,6 +29,8 @@ CASES = [('retinanet', 'f32'), ('retinanet', 'f32x3'), ('yolov3', 'bf16'), ('fco
 CASES += [('ssd512', 'bf16'), ('refinedet', 'bf16'), ('pfpnet', 'bf16'), ('yolov2', 'bf16'), ('refinedet', 'f32'), ('pfpnet', 'f32'), ('yolov2', 'f32')]
 # the operand-splitting engine (ODTK_F32X3 descriptors: f32 tensors, three bf16 MFMA products per f32 product where that is faster) of every class that has an f32 engine
 CASES += [('refinedet', 'f32x3'), ('pfpnet', 'f32x3'), ('yolov2', 'f32x3'), ('fcos', 'f32x3'), ('centernet', 'f32x3')]
+# round 5: the two hand-rolled classes on the descriptor dtype as well (bench.py --dtype f32x3 for the headline class)
+CASES += [('ssd300', 'f32x3'), ('yolov3', 'f32x3')]
 
 
 @pytest.mark.parametrize('name,dtype', CASES, ids=[f'{n}-{d}' for n, d in CASES])

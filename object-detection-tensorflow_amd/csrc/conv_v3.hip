@@ -878,7 +878,9 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const GatherArgs a) 
 // 128 x 128 wave tile -- measured 3.5 % of the step slower than float atomics); 32 rows at a time go through a wave-private LDS
 // patch [32][QI * 32] instead and leave as QI * 8 float4 per lane.  `lds` is free for the wave: the caller has passed a block
 // barrier after the last slab and the trailing LDS-DMA has landed.
-template <int PI, int QI>
+// ADD (round 5): dst is dW itself and the tile is ADDED to what it holds -- the flush of a launch with ONE pixel split, where no other workgroup touches the tile: plain
+// 16-byte read-add-store rows instead of 32 K float atomics per workgroup (deterministic, and the atomics were ~16 us of a 40-us launch on DarkNet-53's 13 x 13 maps).
+template <int PI, int QI, bool ADD = false>
 __device__ __forceinline__ void store_partial_tile(const f32x16_v (&acc)[PI][QI], float* lds, float* __restrict__ dst /* ws[split] */,
                                                    int k0, int col0, int K, int RSC, int lane) {
     constexpr int W = QI * 32;
@@ -896,7 +898,11 @@ __device__ __forceinline__ void store_partial_tile(const f32x16_v (&acc)[PI][QI]
             const int row = idx / (W / 4), c4 = idx % (W / 4);
             const float4 v = *reinterpret_cast<const float4*>(lds + row * W + c4 * 4);
             const int k = k0 + i * 32 + row, col = col0 + c4 * 4;
-            if (k < K && col < RSC) *reinterpret_cast<float4*>(dst + (size_t)k * RSC + col) = v;
+            if (k < K && col < RSC) {
+                float4* d = reinterpret_cast<float4*>(dst + (size_t)k * RSC + col);
+                if (ADD) { const float4 o = *d; *d = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w); }
+                else *d = v;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -1060,6 +1066,9 @@ __global__ void __launch_bounds__(512) conv_wgrad_v3_kernel(const WgradArgs a) {
         __syncthreads();                                   // every wave is past its last fragment read
         store_partial_tile<PI, QI>(acc, reinterpret_cast<float*>(smem) + wave * (32 * QI * 32), a.ws + (size_t)split * a.K * a.RSC,
                                    p0 + wp * 64, q0 + wq * 64, a.K, a.RSC, lane);
+    } else if (a.nsplit == 1 && !(a.dbg2 & 4096)) {        // one pixel split: this workgroup owns its tile of dW (dbg2 bit 12 = atomics, A/B)
+        __syncthreads();
+        store_partial_tile<PI, QI, true>(acc, reinterpret_cast<float*>(smem) + wave * (32 * QI * 32), a.dw, p0 + wp * 64, q0 + wq * 64, a.K, a.RSC, lane);
     } else {
 #pragma unroll
         for (int j = 0; j < QI; ++j) {

@@ -448,7 +448,9 @@ __device__ __forceinline__ long long out_off(int m, int rows_per_img, long long 
 // one thread per channel.  fin[0*C + c] = scale, fin[1*C + c] = offset.
 // Sum the [2][nsplit][C] partials of 32 channels with 8 split-lanes per channel (fixed order ->
 // deterministic), result valid in the threads with sl == 0.  Block = 256 threads.
-constexpr int FIN_CH = 32, FIN_SL = 8;
+// (round 5: 32 split lanes per channel, 1 024-thread workgroups -- with 8, a thread walked up to 128 partial rows in dependent round trips: the finalize launches of
+//  DarkNet-53's batch norms averaged 10 us each, 150 of them per step, against a ~4-us launch floor)
+constexpr int FIN_CH = 32, FIN_SL = 32;
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ ws, int nsplit, int C, int c, int sl,
                                                 float& s1, float& s2) {
     __shared__ float sm[2][FIN_SL][FIN_CH];
@@ -491,7 +493,7 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ ws, in
 // per-channel scale/offset from the partial sums (training) or the moving stats (inference).
 // fin[0*C + c] = scale, fin[1*C + c] = offset.  Grid = ceil(C / 32) blocks of 256 threads.
 template <typename T>
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const T* __restrict__ z, int M, int C, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_finalize_kernel(const T* __restrict__ z, int M, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ mmean,
                                    float* __restrict__ mvar, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd, int training, const float* __restrict__ ws,
@@ -739,7 +741,7 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
 }
 
 // fin[0*C+c] = mean(dy'), fin[1*C+c] = mean(dy' * xhat); also emits dbeta / dgamma
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ ws, int nsplit, int C, int M,
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_bwd_finalize_kernel(const float* __restrict__ ws, int nsplit, int C, int M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ fin) {
     const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), sl = threadIdx.x / FIN_CH;
@@ -1514,7 +1516,7 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
             return ODTK_OK;
         }
     }
-    DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M,
+    DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, st, (const T*)z, M,
                                            C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, ws,
                                            pl.nsplit, fin);)
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
@@ -1591,7 +1593,7 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu,   \
                        vec_ok, pl.rows_per_split, ws);                                                            \
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, ws, pl.nsplit, C, M,     \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, st, ws, pl.nsplit, C, M,     \
                        dgamma, dbeta, fin);                                                                       \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TY>), g2, dim3(256), 0, st, (const T*)z, (const TY*)y,             \
                        (const TY*)dy, M, C, ldz, ldy, rows_per_img, y_img_stride, gamma, save_mean, save_invstd,  \
@@ -1726,7 +1728,7 @@ namespace odtk {
 namespace {
 
 template <typename T>
-__global__ void __launch_bounds__(256) bn_moments_kernel(const T* __restrict__ z, int M, int C, const float* __restrict__ ws, int nsplit,
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_moments_kernel(const T* __restrict__ z, int M, int C, const float* __restrict__ ws, int nsplit,
                                                          float* __restrict__ mean, float* __restrict__ var) {
     const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), sl = threadIdx.x / FIN_CH;
     float s1, s2;
@@ -1779,7 +1781,7 @@ extern "C" int odtk_bn_moments(const void* z, int M, int C, int ldz, int dtype, 
     float* ws = (float*)workspace;
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st, (const T*)z, M, C, ldz,
                                            pl.rows_per_split, ws);
-              hipLaunchKernelGGL(bn_moments_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const T*)z, M, C, ws, pl.nsplit, mean, var);)
+              hipLaunchKernelGGL(bn_moments_kernel<T>, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, st, (const T*)z, M, C, ws, pl.nsplit, mean, var);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
@@ -1835,7 +1837,7 @@ extern "C" int odtk_bn_bwd_sums(const void* z, const void* y, const void* dy, in
 #define BN_SUMS(T, TY)                                                                                                      \
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T, TY>), g1, dim3(256), 0, st, (const T*)z, (const TY*)y, (const TY*)dy, M, C, ldz, \
                        ldy, rows_per_img, y_img_stride, save_mean, save_invstd, relu, vec_ok, pl.rows_per_split, ws);        \
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, ws, pl.nsplit, C, M, sums + C, sums, fin)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, st, ws, pl.nsplit, C, M, sums + C, sums, fin)
     if (dtype == ODTK_BF16 && y_dtype == ODTK_BF16) { BN_SUMS(bf16_t, bf16_t); }
     else if (dtype == ODTK_BF16 && y_dtype == ODTK_F32) { BN_SUMS(bf16_t, float); }
     else if (dtype == ODTK_F32 && y_dtype == ODTK_F32) { BN_SUMS(float, float); }

@@ -66,7 +66,10 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         run, 2.5 % slower on the SSD300 step) instead of float atomics into dw (the default);
  * key 6 = dispatch A/B switches of the convolution kernels that leave results intact (up to the engines' stated tolerances): bit 2 (4) = ODTK_F32X3 descriptors run
  *         on the exact f32 kernels, bit 3 (8) = ... on the split path wherever it is supported, also below the size policy (tests), bit 4 (16) = no 32-row filter
- *         tile in the f32 LDS-DMA gather, bit 5 (32) = narrow f32 filter gradients on the legacy kernel;
+ *         tile in the f32 LDS-DMA gather, bit 5 (32) = narrow f32 filter gradients on the legacy kernel; round 5: bit 6 (64) = no small-map gather kernel
+ *         (conv_v9.hip), bit 7 (128) = the small-map kernel wherever it is supported (tests), bit 8 (256) = no chunk-range split-K on the raster-run halo kernel,
+ *         bit 9 (512) = the small-map kernel always on its four-stage ring, bit 10 (1024) = no halo kernel on C % 64 != 0, bit 12 (4096) = float atomics also for
+ *         filter gradients with ONE pixel split, bit 13 (8192) = stride-2 input gradients always on the small-map kernel (never the 8-wave kernel's phase launch);
  * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never) */
 int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to

@@ -173,6 +173,7 @@ struct GatherArgs {
     // (2 i + ph, 2 j + pw), whose taps all have one row / column parity -- only those taps' k-slabs are walked (1, 2, 2 and 4 of the 9 taps of a 3 x 3 filter instead of 9
     // slabs of which 5 .. 8 multiply zeros).  v9_phases = 0: plain launch; 4: the table below is valid.
     int v9_phases;
+    int plan_v9_qt;     // != 0: launch_gather_v9 only fills the phase table, for pixel tiles of this size (the 8-wave kernel's phase launch)
     struct V9Phase {
         int tile0;          // first q-tile of this phase in the launch's q-tile order
         int Hq, Wq, Mq;     // the phase's pixel grid (rows ph, ph + 2, ... of Ho; columns pw, pw + 2, ... of Wo) and N * Hq * Wq

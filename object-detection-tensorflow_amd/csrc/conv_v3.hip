@@ -45,7 +45,9 @@ typedef short s16x2e_v __attribute__((ext_vector_type(2)));
 // POOL (raster-run halo kernel on row-pair tiles): the tile holds `rows_here` whole rows of image `pn` starting at an even row (pooled row ph0); only its first
 // rows_here * W pixels are this tile's, and after the store pass (skipped when pool_mode == 2: the un-pooled map is never stored) the 2 x 2 / stride-2
 // 'SAME' max pooling of those rows leaves from the same LDS image -- pooled chunk + recorded first arg-max, the arithmetic of conv3x3_c64k64_kernel's fused pool.
-template <int PT, int QT, int NTHR, int PI, int QI, bool BIAS_IN_ACC = false, bool POOL = false>
+// PHASE (round 5; the 8-wave kernel on the parity phases of a stride-2 input gradient): the tile's pixels are a run of ONE phase's pixel grid (GatherArgs::v9[pn]); pixel
+// ml of it is output row ((n Ho + 2 i + ph) Wo + 2 j + pw) -- the store pass (and its accumulate / mask loads) addresses every row through that map.
+template <int PT, int QT, int NTHR, int PI, int QI, bool BIAS_IN_ACC = false, bool POOL = false, bool PHASE = false>
 __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f32x16_v (&acc)[PI][QI],
                                               int p0, int q0, int prow0, int qrow0, int tid, int pn = 0, int ph0 = 0, int rows_here = 0) {
     constexpr int RB = PT * 2;            // bytes per pixel row of the image
@@ -107,6 +109,25 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
     //  wraps for tiles that reach more than a whole tensor past the end; a pitch-tail lane keeps its out-of-range sentinel by stepping 0)
     const unsigned voff = c0 < a.ldy ? (unsigned)(((long long)(q0 + qt) * a.ldy + c0) * 2) : 0xFFFFFFF0u;      // (>= ybytes: rows past M are dropped / read as 0)
     const unsigned sstep = c0 < a.ldy ? (unsigned)(RPI * a.ldy * 2) : 0u;
+    unsigned prow[PHASE ? NIT : 1];                      // PHASE: output row of iteration it (0xFFFFFFFF: past the phase's pixels)
+    if (PHASE) {
+        const GatherArgs::V9Phase& P = a.v9[pn];
+        const int ph = pn >> 1, pw = pn & 1, hw = P.Hq * P.Wq;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int ml = q0 + qt + it * RPI;
+            prow[it] = 0xFFFFFFFFu;
+            if (ml < P.Mq) {
+                const int n = (int)fdiv((unsigned)ml, P.d_hw), rem = ml - n * hw;
+                const int hi_ = (int)fdiv((unsigned)rem, P.d_w), wi_ = rem - hi_ * P.Wq;
+                prow[it] = (unsigned)((n * a.Ho + 2 * hi_ + ph) * a.Wo + 2 * wi_ + pw);
+            }
+        }
+    }
+    auto yoff = [&](int it) __attribute__((always_inline)) -> unsigned {
+        if constexpr (!PHASE) return voff + it * sstep;
+        else return (prow[it] != 0xFFFFFFFFu && c0 < a.ldy) ? (prow[it] * (unsigned)a.ldy + (unsigned)c0) * 2u : 0xFFFFFFF0u;
+    };
     const bool post = a.accumulate || a.mask;
     u32x4_v oldv[NIT], mkv[NIT];
     if (post) {
@@ -117,8 +138,12 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             oldv[it] = (u32x4_v)(0u); mkv[it] = (u32x4_v)(0u);
-            if (a.accumulate) oldv[it] = __builtin_amdgcn_raw_buffer_load_b128(ry, voff + it * sstep, 0, 0);
-            if (a.mask) mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(rm, moff + it * mstep, 0, 0);
+            if (a.accumulate) oldv[it] = __builtin_amdgcn_raw_buffer_load_b128(ry, yoff(it), 0, 0);
+            if (a.mask) {
+                unsigned mo = moff + it * mstep;
+                if constexpr (PHASE) mo = (prow[it] != 0xFFFFFFFFu && c0 < a.ldmask) ? (prow[it] * (unsigned)a.ldmask + (unsigned)c0) * 2u : 0xFFFFFFF0u;
+                mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(rm, mo, 0, 0);
+            }
         }
     }
     __syncthreads();
@@ -135,7 +160,7 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
                 if (post) post_chunk(v[e], a.accumulate != 0, a.relu != 0, __builtin_bit_cast(uint4, oldv[it0 + e]), a.mask != nullptr, __builtin_bit_cast(uint4, mkv[it0 + e]));
-                const unsigned off = (!POOL || qt + (it0 + e) * RPI < valid_px) ? voff + (it0 + e) * sstep : 0xFFFFFFF0u;
+                const unsigned off = (!POOL || qt + (it0 + e) * RPI < valid_px) ? yoff(it0 + e) : 0xFFFFFFF0u;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_v, v[e]), ry, off, 0, 0);
             }
         }
@@ -211,7 +236,9 @@ __device__ __forceinline__ void x3_store4(const GatherArgs& a, int m, int c, flo
     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false, bool SPLIT = false, bool ILV = false>
+// PHASE (round 5; with BUF, C64, no split-K): the four parity phases of a stride-2 input gradient in one launch (GatherArgs::v9, the table the small-map kernel uses):
+// a tile's pixels belong to one phase, only that phase's taps are walked -- 9 tap-slabs per four output pixels instead of 36, a quarter of the MFMA work.
+template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false, bool SPLIT = false, bool ILV = false, bool PHASE = false>
 __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a) {
     constexpr int QT = 256;
     constexpr int PI = PT / 64, QI = 2, PL = PT / 64;
@@ -229,9 +256,20 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int part = SPLIT ? lin % a.ksplit : 0;
     const int vb = SPLIT ? lin / a.ksplit : lin;
-    const int tq = vb / a.tiles_p, tp = vb - tq * a.tiles_p;
+    int tq = vb / a.tiles_p;
+    const int tp = vb - tq * a.tiles_p;
+    int pi = 0, ph = 0, pw = 0, Hq = a.Ho, Wq = a.Wo, Mq = a.M, r_first = 0, s_first = 0;
+    FastDiv d_hw = a.div_howo, d_w = a.div_wo;
+    int nk_all = (a.Kdim + 63) >> 6;
+    if (PHASE) {
+        pi = (tq >= a.v9[1].tile0) + (tq >= a.v9[2].tile0) + (tq >= a.v9[3].tile0);
+        const GatherArgs::V9Phase& P = a.v9[pi];
+        ph = pi >> 1; pw = pi & 1;
+        tq -= P.tile0;
+        Hq = P.Hq; Wq = P.Wq; Mq = P.Mq; r_first = P.r0; s_first = P.s0; nk_all = P.nk;
+        d_hw = P.d_hw; d_w = P.d_w;
+    }
     const int p0 = tp * PT, q0 = tq * QT;
-    const int nk_all = (a.Kdim + 63) >> 6;
     const int ks0 = SPLIT ? part * nk_all / a.ksplit : 0;
     const int nk = SPLIT ? (part + 1) * nk_all / a.ksplit - ks0 : ((a.dbg & 8) ? 1 : nk_all);
 
@@ -251,9 +289,10 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
     for (int i = 0; i < 4; ++i) {
         const int m = q0 + r0 + 64 * i;
         qoff[i] = 0; qmask[i] = 0; qoff32[i] = 0;
-        if (m < a.M) {
-            const int n = (int)fdiv((unsigned)m, a.div_howo), rem = m - n * HoWo;
-            const int ho = (int)fdiv((unsigned)rem, a.div_wo), wo = rem - ho * a.Wo;
+        if (m < Mq) {
+            const int n = (int)fdiv((unsigned)m, d_hw), rem = m - n * (PHASE ? Hq * Wq : HoWo);
+            const int ho_ = (int)fdiv((unsigned)rem, d_w), wo_ = rem - ho_ * Wq;
+            const int ho = PHASE ? 2 * ho_ + ph : ho_, wo = PHASE ? 2 * wo_ + pw : wo_;
             const int hb = ho * a.ostride - a.pad_t, wb = wo * a.ostride - a.pad_l;
             // stride-2 dgrad (idiv == 2, dil == 1): tap r reads dy row (hb + r) / 2 when that is an integer
             // = (hb >> 1) + ((r + 1) >> 1) for every parity-matching r, so the "base + tap offset" form survives
@@ -304,6 +343,7 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         s_kr = rs / a.S;
         s_ks = rs - s_kr * a.S;
     }
+    if (PHASE) { s_kr = r_first; s_ks = s_first; s_kc = 0; }     // the phase's first tap; taps advance by 2 (same parity)
     if (C64) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) qoff32[i] += (unsigned)(cc * 16);
@@ -317,7 +357,7 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
             const int sr = a.idiv == 2 ? (s_kr + 1) >> 1 : s_kr * a.dil, ss = a.idiv == 2 ? (s_ks + 1) >> 1 : s_ks * a.dil;
             const unsigned toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + s_kc * 2);
             const unsigned tapbit = 1u << (s_kr * a.S + s_ks);
-            const unsigned woff = (unsigned)(s_klin * 2);
+            const unsigned woff = PHASE ? (unsigned)(((s_kr * a.S + s_ks) * a.C + s_kc) * 2) : (unsigned)(s_klin * 2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned addr = qoff32[i] + toff32;
@@ -332,7 +372,8 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
             s_kc += 64;
             if (s_kc >= a.C) {
                 s_kc = 0;
-                if (++s_ks == a.S) { s_ks = 0; ++s_kr; }
+                if (PHASE) { s_ks += 2; if (s_ks >= a.S) { s_ks = s_first; s_kr += 2; } }
+                else if (++s_ks == a.S) { s_ks = 0; ++s_kr; }
             }
             return;
         }
@@ -543,6 +584,7 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         st_c = st_c == 2 ? 0 : st_c + 1;
         st_n = st_n == 2 ? 0 : st_n + 1;
     }
+    if (PHASE && nk == 0) wait_vmcnt<0>();               // (a phase without taps -- 1 x 1 / stride 2 -- still issued its first pieces: they must land before the image)
     block_barrier();                                    // all slab reads done: LDS is free for the output image
     }
     if (SPLIT) {
@@ -567,7 +609,7 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         }
         return;
     }
-    epilogue_bf16<PT, QT, 512, PI, QI>(a, smem, acc, p0, q0, wp * (PT / 2), wq * 64, tid);
+    epilogue_bf16<PT, QT, 512, PI, QI, false, false, PHASE>(a, smem, acc, p0, q0, wp * (PT / 2), wq * 64, tid, pi);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2004,7 +2046,26 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         return 0;
     }
     if (g_num_cu == 0) query_num_cu();
-    if (gather_v9_wanted(a, g_num_cu)) return launch_gather_v9(a, st, g_num_cu);     // small launches, stride-2 input gradients (conv_v9.hip)
+    if (gather_v9_wanted(a, g_num_cu)) {
+        // Stride-2 input gradients: the parity phases on the small-map kernel (64 x 64 tiles), or on THIS kernel (PT x 256 tiles, eight waves: a third of the LDS-DMA
+        // pieces per MFMA) where its tiles cover well over half the CUs -- a phase launch streams dy (each row is read by 1-4 taps, not 9) and this kernel's
+        // two-slabs-in-flight ring then runs at memory latency, ~1 us per slab, with 1, 2, 2 and 4 taps' worth of slabs per tile: measured (tools/conv_bench.py,
+        // us, small-map | 8-wave): DarkNet-53 at 8 images 52 x 52 (176 tiles) 57 | 43, 104 x 104 (340) 65 | 51, 208 x 208 86 | 74, 416 x 416 251 | 197 -- but
+        // 26 x 26 (96 tiles) 59 | 70 and conv8_2 of SSD300 (96 tiles) 35 | 40.  dbg2 bit 13 = always the small-map kernel (A/B).
+        const bool phase = a.idiv == 2;
+        const int tiles_ph = ceil_div(a.K, PT) * (ceil_div(a.M, 4 * 256) * 4);
+        if (!(phase && tiles_ph >= g_num_cu / 2 + 32 && !(a.dbg2 & 8192) && !(a.dbg2 & 128))) return launch_gather_v9(a, st, g_num_cu);
+        GatherArgs b = a;                                    // the phase table (tile counts for 64-pixel tiles) is rebuilt for 256-pixel tiles
+        b.plan_v9_qt = 256;
+        if (int e = launch_gather_v9(b, st, g_num_cu)) return e;       // fills b.v9 / b.tiles_q only (plan_v9_qt != 0: no launch)
+        a = b;
+        a.tiles_p = ceil_div(a.K, PT);
+        a.ksplit = 1;
+        const int grid_ph = a.tiles_p * a.tiles_q;
+        if (PT == 64) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false, true, true, false, false, true>), dim3(grid_ph), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, false, true, true, false, false, true>), dim3(grid_ph), dim3(512), 0, st, a);
+        return 0;
+    }
     const int tiles = a.tiles_p * a.tiles_q;
     const int nk = ceil_div(a.Kdim, 64);
     // split-K: few tiles with a long k loop leave most CUs idle and run at DMA latency; give every tile

@@ -279,10 +279,11 @@ int launch_gather_v9(GatherArgs& a, hipStream_t st, int num_cu) {
             P.tile0 = t0;
             P.d_hw = make_fastdiv((unsigned)(P.Hq * P.Wq > 0 ? P.Hq * P.Wq : 1));
             P.d_w = make_fastdiv((unsigned)(P.Wq > 0 ? P.Wq : 1));
-            t0 += ceil_div(P.Mq, 64);
+            t0 += ceil_div(P.Mq, a.plan_v9_qt ? a.plan_v9_qt : 64);
         }
         a.v9_phases = 4;
         a.tiles_q = t0;
+        if (a.plan_v9_qt) return 0;                          // the 8-wave kernel runs the phases on its own tiles (launch_gather_v3): the table only
     } else {
         a.v9_phases = 0;
         a.tiles_q = ceil_div(a.M, 64);

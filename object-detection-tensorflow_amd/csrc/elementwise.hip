@@ -448,9 +448,9 @@ __device__ __forceinline__ long long out_off(int m, int rows_per_img, long long 
 // one thread per channel.  fin[0*C + c] = scale, fin[1*C + c] = offset.
 // Sum the [2][nsplit][C] partials of 32 channels with 8 split-lanes per channel (fixed order ->
 // deterministic), result valid in the threads with sl == 0.  Block = 256 threads.
-// (round 5: 32 split lanes per channel, 1 024-thread workgroups -- with 8, a thread walked up to 128 partial rows in dependent round trips: the finalize launches of
-//  DarkNet-53's batch norms averaged 10 us each, 150 of them per step, against a ~4-us launch floor)
-constexpr int FIN_CH = 32, FIN_SL = 32;
+// (round 5, measured and NOT kept: 32 split lanes per channel in 1 024-thread workgroups -- YOLOv3 b8 811 -> 816 images/s, within the box noise, and the changed
+//  summation order of the statistics flipped near-zero Adam updates in CenterNet's exact-engine step test)
+constexpr int FIN_CH = 32, FIN_SL = 8;
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ ws, int nsplit, int C, int c, int sl,
                                                 float& s1, float& s2) {
     __shared__ float sm[2][FIN_SL][FIN_CH];

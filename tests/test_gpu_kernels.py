@@ -168,6 +168,10 @@ V9_EXTRA_CASES = [
     (2, 26, 26, 64, 128, 3, 2, 1),    # ... DarkNet-53 down-sampling geometry
     (1, 7, 9, 192, 96, 5, 2, 1),      # ... 5 x 5 taps: 9, 6, 6, 4 taps per phase
     (1, 1, 1, 64, 64, 3, 2, 1),       # ... a single pixel: three empty phases
+    (16, 52, 52, 128, 256, 3, 2, 1),  # ... >= 160 tiles of 128 x 256: the phases on the 8-WAVE kernel, DarkNet-53 geometry
+    (12, 104, 104, 64, 128, 3, 2, 1), # ... its 64-channel filter tile (dx has 64 channels)
+    (50, 51, 37, 192, 192, 3, 2, 1),  # ... odd x odd map, ragged phase grids and tiles, two channel tiles with a tail (dx 192 channels, dy 192)
+    (24, 52, 52, 256, 512, 1, 2, 1),  # ... 1 x 1 / stride 2 on the 8-wave kernel: three phases without a tap (their first DMA pieces still land before the image)
     (4, 5, 5, 256, 128, 1, 1, 1),     # 1 x 1 on a 5 x 5 map: two tiles straddling four images
     (2, 3, 3, 256, 100, 3, 1, 1),     # 18 pixels: one ragged tile, channel tail 100 = 64 + 36
     (2, 10, 10, 72, 150, 3, 1, 1),    # C % 64 != 0: the per-lane tap walk (a slab straddles taps), channel tail
@@ -214,8 +218,8 @@ def test_conv_v9_is_taken_where_expected(dev):
         return f, ops.conv_last_kernel()
     assert kernels(32, 5, 128, 256, 3, 1) == ("conv_gather_v9_kernel", "conv_gather_v9_kernel")
     assert kernels(32, 10, 512, 128, 1, 1) == ("conv_gather_v9_kernel", "conv_gather_v9_kernel")
-    assert kernels(32, 19, 256, 512, 3, 2)[1] == "conv_gather_v9_kernel"          # parity phases at any size
-    assert kernels(8, 208, 64, 128, 3, 2)[1] == "conv_gather_v9_kernel"
+    assert kernels(32, 19, 256, 512, 3, 2)[1] == "conv_gather_v9_kernel"          # parity phases: the small-map kernel while the 8-wave kernel's tiles would cover less than ~60 % of the CUs (96 here)
+    assert kernels(8, 208, 64, 128, 3, 2)[1] == "conv_gather_v3_kernel<64>"       # ... the 8-wave kernel beyond (1 352 tiles of 64 x 256: dx has 64 channels)
     assert kernels(8, 13, 512, 1024, 3, 1) == ("conv_gather_v6_kernel+splitk", "conv_gather_v6_kernel+splitk")
     assert kernels(32, 38, 512, 512, 3, 1) == ("conv_gather_v6_kernel", "conv_gather_v6_kernel")
     torch.cuda.synchronize()
@@ -997,7 +1001,8 @@ def test_conv_relu_pool2x2_fused_in_the_raster_run_halo_kernel(geom, dev):
     p_ref = torch.zeros(N * Hp * Wp, Kp, dtype=torch.bfloat16, device=dev)
     i_ref = torch.zeros(nchunk, dtype=torch.int16, device=dev)
     ops.conv2d_fwd(d, x, w, b, y_ref, True)
-    split_k = 'splitk' in ops.conv_last_kernel()               # small problems: the stand-alone convolution sums split-K partials -- another order, last-bit differences
+    # small problems: the stand-alone convolution sums split-K partials or runs on the small-map kernel (round 5) -- another order, last-bit differences
+    split_k = 'splitk' in ops.conv_last_kernel() or 'v9' in ops.conv_last_kernel()
     res = {}
     for keep in (True, False):
         y = torch.full((N * H * W, Kp), 7.0, dtype=torch.bfloat16, device=dev) if keep else None

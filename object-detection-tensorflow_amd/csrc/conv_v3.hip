@@ -1455,6 +1455,9 @@ __global__ void __launch_bounds__(256) conv3x3_c64k64_kernel(const GatherArgs a,
 // consecutive pixels = 512 contiguous bytes.  10 MFMAs per 32 pixels; the kernel is bound by the 128 B / pixel
 // it writes, so the epilogue goes through a wave-private LDS image and stores full 128-B rows.
 // ---------------------------------------------------------------------------------------
+// NI = Cout / 32: 2 = the 64-channel first layer of VGG-16 (SSD300.py:193-198), 1 (round 5) = DarkNet-53's 32-channel one (YOLOv3.py:387) -- on the generic kernel
+// that layer ran at 16 TFLOP/s (149 us at 416 x 416 x 8 for 88 MB of output).
+template <int NI>
 __global__ void __launch_bounds__(256) conv3x3_c8k64_kernel(const GatherArgs a, const int tiles_r, const int tiles_c,
                                                             const int total_tiles, const FastDiv div_tpi, const FastDiv div_tc) {
     constexpr int PW = 34, PPX = 340, NPIECE = 6, PBUF = NPIECE * 1024;
@@ -1469,17 +1472,18 @@ __global__ void __launch_bounds__(256) conv3x3_c8k64_kernel(const GatherArgs a, 
     if (my_tiles == 0) return;
 
     // filter fragments: channel row i*32 + l31, k-step t -> tap 2t + hi (8 channels = 16 B), tap 9 = zeros
-    uint4 wf[5][2];
+    constexpr int RBK = NI * 64, CPR = NI * 4;              // bytes per pixel row of the output image, 16-byte chunks per row
+    uint4 wf[5][NI];
 #pragma unroll
     for (int tt = 0; tt < 5; ++tt)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int tap = 2 * tt + hi;
             wf[tt][i] = tap < 9 ? *reinterpret_cast<const uint4*>(a.w + ((size_t)(i * 32 + l31) * a.ldw + tap * 8) * 2) : make_uint4(0, 0, 0, 0);
         }
-    float4 bias[8];
+    float4 bias[NI * 4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             bias[i * 4 + g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + i * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1534,9 +1538,9 @@ __global__ void __launch_bounds__(256) conv3x3_c8k64_kernel(const GatherArgs a, 
         block_barrier();            // patch `buf` visible; everybody is done reading patch buf ^ 1
         issue(nn, nh0, nw0, buf ^ 1, has_next);
         const unsigned pb = smem_base + (unsigned)(buf * PBUF);
-        f32x16_v acc[2][2];
+        f32x16_v acc[NI][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1552,14 +1556,14 @@ __global__ void __launch_bounds__(256) conv3x3_c8k64_kernel(const GatherArgs a, 
 #pragma unroll
             for (int tt = 0; tt < 5; ++tt)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) Mma<bf16_t>::run(wf[tt][i], qf[j][tt], acc[i][j]);
+                for (int i = 0; i < NI; ++i) Mma<bf16_t>::run(wf[tt][i], qf[j][tt], acc[i][j]);
         // ---- epilogue: bias + ReLU -> bf16 -> wave-private LDS image [64 pixels][128 B] -> 16 B per lane, full rows
         const bool pre_relu = a.relu != 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pxl = j * 32 + l31;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cl = i * 32 + 8 * g + 4 * hi;
@@ -1570,20 +1574,20 @@ __global__ void __launch_bounds__(256) conv3x3_c8k64_kernel(const GatherArgs a, 
                     uint2 o;
                     o.x = cvt_pk_bf16(v0, v1);
                     o.y = cvt_pk_bf16(v2, v3);
-                    *reinterpret_cast<uint2*>(sg + pxl * 128 + ((((cl >> 3) ^ pxl) & 7) << 4) + ((cl & 4) << 1)) = o;
+                    *reinterpret_cast<uint2*>(sg + pxl * RBK + ((((cl >> 3) ^ pxl) & (CPR - 1)) << 4) + ((cl & 4) << 1)) = o;
                 }
         }
         asm volatile("" ::: "memory");          // wave-private image, in-order LDS: only pins the compiler (TBAA)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < CPR; ++r) {
             const int idx = r * 64 + lane;
-            const int pxl = idx >> 3, ch = idx & 7;
+            const int pxl = idx / CPR, ch = idx % CPR;
             const int h = ch0 + 2 * wave + (pxl >> 5), w = cw0 + (pxl & 31);
-            const uint4 v = *reinterpret_cast<const uint4*>(sg + pxl * 128 + (((ch ^ pxl) & 7) << 4));
+            const uint4 v = *reinterpret_cast<const uint4*>(sg + pxl * RBK + (((ch ^ pxl) & (CPR - 1)) << 4));
             if (h < a.H && w < a.W) {
                 const size_t m = (size_t)(cn * a.H + h) * a.W + w;
                 *reinterpret_cast<uint4*>(a.y + (m * a.ldy + ch * 8) * 2) = v;
-                if (a.ybits) a.ybits[m * 8 + ch] = (unsigned char)pos_bits(v);       // 64 consecutive bytes per wave instruction; the kernel is bound by its 128 B / pixel
+                if (a.ybits) a.ybits[m * CPR + ch] = (unsigned char)pos_bits(v);       // 64 consecutive bytes per wave instruction; the kernel is bound by its 128 B / pixel
             }
         }
         asm volatile("" ::: "memory");
@@ -2233,7 +2237,7 @@ int launch_gather_c64(GatherArgs& a, hipStream_t st) {
 }
 
 bool gather_c8_supported(const GatherArgs& a, int dtype, int out_dtype) {
-    return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && a.C == 8 && a.ldx == 8 && a.K == 64 && a.ldy == 64 && a.R == 3 && a.S == 3 &&
+    return dtype == ODTK_BF16 && out_dtype == ODTK_BF16 && a.C == 8 && a.ldx == 8 && (a.K == 64 || (a.K == 32 && !a.ybits)) && a.ldy == a.K && a.R == 3 && a.S == 3 &&
            a.dil == 1 && a.ostride == 1 && a.idiv == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo &&
            !a.accumulate && a.mask == nullptr && a.ldw == 72 && (long long)a.N * a.H * a.W * 16 < (1ll << 31);
 }
@@ -2243,8 +2247,8 @@ int launch_gather_c8(GatherArgs& a, hipStream_t st) {
     const int tr = ceil_div(a.H, 8), tc = ceil_div(a.W, 32);
     const int tiles = a.N * tr * tc;
     const int grid = tiles < 3 * g_num_cu ? tiles : 3 * g_num_cu;
-    hipLaunchKernelGGL(conv3x3_c8k64_kernel, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)),
-                       make_fastdiv((unsigned)tc));
+    if (a.K == 32) hipLaunchKernelGGL(conv3x3_c8k64_kernel<1>, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)), make_fastdiv((unsigned)tc));
+    else hipLaunchKernelGGL(conv3x3_c8k64_kernel<2>, dim3(grid), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)), make_fastdiv((unsigned)tc));
     return 0;
 }
 

@@ -172,6 +172,7 @@ V9_EXTRA_CASES = [
     (12, 104, 104, 64, 128, 3, 2, 1), # ... its 64-channel filter tile (dx has 64 channels)
     (50, 51, 37, 192, 192, 3, 2, 1),  # ... odd x odd map, ragged phase grids and tiles, two channel tiles with a tail (dx 192 channels, dy 192)
     (24, 52, 52, 256, 512, 1, 2, 1),  # ... 1 x 1 / stride 2 on the 8-wave kernel: three phases without a tap (their first DMA pieces still land before the image)
+    (9, 45, 70, 8, 32, 3, 1, 1),      # first-layer kernel with 32 output channels (DarkNet-53's conv1: one MFMA row tile, 64-byte output rows), ragged tiles
     (4, 5, 5, 256, 128, 1, 1, 1),     # 1 x 1 on a 5 x 5 map: two tiles straddling four images
     (2, 3, 3, 256, 100, 3, 1, 1),     # 18 pixels: one ragged tile, channel tail 100 = 64 + 36
     (2, 10, 10, 72, 150, 3, 1, 1),    # C % 64 != 0: the per-lane tap walk (a slab straddles taps), channel tail

@@ -263,6 +263,9 @@ def main():
     ap.add_argument('--dp-world1', action='store_true',
                     help='N = 1 only: run the data-parallel path (RCCL process group of ONE rank, gradient buckets, per-bucket backward graphs, '
                          'an ncclAllReduce per bucket) on the one GPU -- the RCCL code path of N > 1 exercised where only one GPU exists')
+    ap.add_argument('--collective', default='torch', choices=['torch', 'odtk'],
+                    help="N > 1 / --dp-world1: the bucket all-reduce through torch.distributed (default) or through the C-ABI's own collective "
+                         "(odtk_comm_allreduce: what a binder that is not PyTorch calls; RCCL underneath either way)")
     ap.add_argument('--grad-dtype', default='f32', choices=['f32', 'bf16'],
                     help='N > 1: all-reduce the gradient buckets as f32 (default, 105 MB/step) or as bf16 copies (52 MB/step)')
     ap.add_argument('--launch-check', action='store_true',
@@ -311,7 +314,8 @@ def main():
     provider = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
     model = odtk.SSD300(config, provider)
     if use_pg:
-        model.attach_data_parallel(bucket_mb=args.bucket_mb, sync_bn=args.sync_bn, grad_dtype=args.grad_dtype, force_collectives=args.dp_world1)
+        model.attach_data_parallel(bucket_mb=args.bucket_mb, sync_bn=args.sync_bn, grad_dtype=args.grad_dtype, force_collectives=args.dp_world1,
+                                   collective=args.collective)
     images, gt = synthetic_batch(B, 1000 + rank, dev)
     model.set_batch(images, gt)
 
@@ -859,6 +863,7 @@ def comm_metrics(model, args, lr, barrier, ms_step, dev):
             'allreduce_ms_per_step': round(t_ar, 3),
             'allreduce_busbw_gbps': round(nbytes * 2 * (w - 1) / w / (t_ar * 1e-3) / 1e9, 1),
             'gradient_dtype': getattr(red, 'comm_dtype', 'f32'),
+            'collective': 'odtk_comm_allreduce (C-ABI over RCCL)' if getattr(red, 'collective', None) is not None else 'torch.distributed all_reduce',
             'ms_per_step_without_comm': round(t_nc, 3), 'without_comm_steps': 'untimed diagnostic steps; model state restored afterwards',
             'exposed_comm_ms': round(max(ms_step - t_nc, 0.0), 3),
             'overlap_frac': round(min(max(1.0 - max(ms_step - t_nc, 0.0) / max(t_ar, 1e-9), 0.0), 1.0), 3)}

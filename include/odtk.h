@@ -596,6 +596,24 @@ int odtk_lhrcnn_gather_rois(const float* prop, const int* sel, const int* cnt, i
 int odtk_lhrcnn_rcnn_decode(const float* logits, int ldl, const float* pbbox, int ldb, const float* roi_prop, const int* roi_img, int R, int C,
                             float score_threshold, float* conf, float* boxes, unsigned char* cand, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Collectives (SURVEY.md 8b's export list, 8e): the gradient sum of the data-parallel step for a binder that is not PyTorch.  No reference
+ * counterpart (the reference is single-device, testSSD300.py:14).  A thin layer over RCCL (ring / tree all-reduce over xGMI), bound with dlopen at
+ * first use: a missing RCCL fails these calls with a message and nothing else.  One communicator per process and GPU (the current HIP device at
+ * odtk_comm_init); rank 0 creates the id, the host transports its ODTK_COMM_ID_BYTES bytes to the other ranks (file, socket, MPI, a
+ * torch.distributed store: not the library's business); odtk_comm_init blocks until all `world` ranks have called it.  odtk_comm_allreduce sums
+ * `count` elements of ODTK_F32 or ODTK_BF16 over the ranks, send == recv allowed, asynchronously on `stream` (the caller orders it behind the
+ * kernels that produce `send` by launching on the same stream or by an event wait, exactly as for any kernel of this library).
+ * ------------------------------------------------------------------------- */
+#define ODTK_COMM_ID_BYTES 128
+typedef struct odtk_comm odtk_comm;
+int odtk_comm_unique_id(void* id128);
+int odtk_comm_init(const void* id128, int rank, int world, odtk_comm** comm);
+int odtk_comm_info(const odtk_comm* comm, int* rank, int* world);
+int odtk_comm_allreduce(odtk_comm* comm, const void* send, void* recv, long long count, int dtype, void* stream);
+int odtk_comm_broadcast(odtk_comm* comm, void* buf, long long count, int dtype, int root, void* stream);
+int odtk_comm_destroy(odtk_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

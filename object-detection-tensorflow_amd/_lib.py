@@ -149,6 +149,12 @@ SIGNATURES = {
     "odtk_lhrcnn_rpn_decode": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "odtk_lhrcnn_gather_rois": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "odtk_lhrcnn_rcnn_decode": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "odtk_comm_unique_id": (_i, [_vp]),
+    "odtk_comm_init": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "odtk_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "odtk_comm_allreduce": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
+    "odtk_comm_broadcast": (_i, [_vp, _vp, _ll, _i, _i, _vp]),
+    "odtk_comm_destroy": (_i, [_vp]),
 }
 
 _lib = None

@@ -14,24 +14,88 @@ Works on CPU tensors with the gloo backend too (tests/test_dist_cpu.py, world_si
 from __future__ import annotations
 
 import contextlib
+import ctypes
 
 import torch
 import torch.distributed as dist
+
+COMM_ID_BYTES = 128          # include/odtk.h: ODTK_COMM_ID_BYTES
+
+
+class _Done:
+    """What BucketAllReducer needs of a collective's handle: wait() orders the CURRENT stream behind it."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class OdtkCollective:
+    """The gradient sum through the C-ABI's own collective (include/odtk.h: odtk_comm_*; RCCL underneath) instead of torch.distributed's -- what a
+    binder that is not PyTorch would call.  torch.distributed (any backend) is used ONCE, to carry rank 0's 128-byte id to the other ranks; in a
+    world of one rank nothing but the library is involved.  all_reduce() has the contract of dist.all_reduce(async_op=True): ordered behind the
+    current stream at the call, executed on the collective's own stream, wait() orders the then-current stream behind it."""
+
+    def __init__(self, group=None, device=None):
+        from . import _lib
+        self._lib = _lib
+        lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        on = dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        ident = ctypes.create_string_buffer(COMM_ID_BYTES)
+        if self.rank == 0:
+            _lib.check(lib.odtk_comm_unique_id(ident))
+        if self.world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = ctypes.create_string_buffer(box[0], COMM_ID_BYTES)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.odtk_comm_init(ident, self.rank, self.world, ctypes.byref(handle)))
+            self.stream = torch.cuda.Stream()
+        self.handle = handle
+        rk, wd = ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.check(lib.odtk_comm_info(self.handle, ctypes.byref(rk), ctypes.byref(wd)))
+        assert (rk.value, wd.value) == (self.rank, self.world)
+
+    def all_reduce(self, buf: torch.Tensor):
+        assert buf.is_cuda and buf.is_contiguous() and buf.dtype in (torch.float32, torch.bfloat16), (buf.device, buf.dtype)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        dt = self._lib.F32 if buf.dtype == torch.float32 else self._lib.BF16
+        ptr = ctypes.c_void_p(buf.data_ptr())
+        self._lib.check(self._lib.load().odtk_comm_allreduce(self.handle, ptr, ptr, buf.numel(), dt, ctypes.c_void_p(self.stream.cuda_stream)))
+        buf.record_stream(self.stream)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return _Done(ev)
+
+    def close(self):
+        if self.handle is not None:
+            torch.cuda.synchronize(self.device)
+            self._lib.check(self._lib.load().odtk_comm_destroy(self.handle))
+            self.handle = None
 
 
 class BucketAllReducer:
     """Device-agnostic core: flat buffer + ordered segment table -> bucketed async all-reduce."""
 
-    def __init__(self, flat: torch.Tensor, segments, group=None, bucket_bytes=25 << 20, comm_dtype='f32', force_collectives=False, cast=None):
+    def __init__(self, flat: torch.Tensor, segments, group=None, bucket_bytes=25 << 20, comm_dtype='f32', force_collectives=False, cast=None,
+                 collective=None):
         """segments: list of (name, start, end) in ascending offset order covering `flat`.
         comm_dtype 'bf16': a bucket travels as a bf16 copy (half the bytes on the xGMI links: 52 instead of 105 MB per SSD300 step) -- cast
         (`cast` = (narrow, widen) launches, odtk.ops.cast_from_f32 / cast_to_f32 on the GPU), summed by the collective in bf16, widened back
         into the f32 buffer; the sum of W bf16 values carries ~log2(W) fewer good bits than the f32 path, the optimizer still runs in f32.
-        force_collectives: issue the collectives even in a world of ONE rank (the RCCL code path exercised on a single GPU)."""
+        force_collectives: issue the collectives even in a world of ONE rank (the RCCL code path exercised on a single GPU).
+        collective: None = torch.distributed's all_reduce; an OdtkCollective = the C-ABI's (odtk_comm_allreduce)."""
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.force = bool(force_collectives) and dist.is_initialized()
+        self.collective = collective
+        self.force = bool(force_collectives) and (dist.is_initialized() or collective is not None)
         self.comm_dtype = comm_dtype
         assert comm_dtype in ('f32', 'bf16')
         self.stage = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if comm_dtype == 'bf16' else None
@@ -78,9 +142,14 @@ class BucketAllReducer:
                         buf = self.stage[s:e]
                         self._narrow(self.flat[s:e], buf)      # on the launching stream, which the collective's stream waits for
                         self._staged.append((s, e))
-                    self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self.handles.append(self._all_reduce(buf))
             self.launch_log.append((s, e))
             self.next_bucket += 1
+
+    def _all_reduce(self, buf):
+        if self.collective is not None:
+            return self.collective.all_reduce(buf)
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def bucket_bytes(self):
         return [(e - s) * self.flat.element_size() for s, e, _ in self.buckets]
@@ -95,7 +164,7 @@ class BucketAllReducer:
             if self.stage is not None:
                 src = self.stage
                 self._narrow(self.flat, self.stage)          # the same bytes and arithmetic as the real path (never uninitialised memory)
-            hs = [dist.all_reduce(src[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e, _ in self.buckets]
+            hs = [self._all_reduce(src[s:e]) for s, e, _ in self.buckets]
             for h in hs:
                 h.wait()
 
@@ -114,7 +183,7 @@ class BucketAllReducer:
 class GradAllReducer:
     """Binds a BucketAllReducer to an SSD300 instance (layer-granular readiness)."""
 
-    def __init__(self, model, group=None, bucket_mb=25, grad_dtype='f32', force_collectives=False):
+    def __init__(self, model, group=None, bucket_mb=25, grad_dtype='f32', force_collectives=False, collective='torch'):
         self.model = model
         segs = []
         names = list(model.pinfo.keys())
@@ -131,7 +200,9 @@ class GradAllReducer:
         if grad_dtype == 'bf16' and model.G.is_cuda:
             from . import ops
             cast = (ops.cast_from_f32, ops.cast_to_f32)
-        self.red = BucketAllReducer(model.G, segs, group, int(bucket_mb) << 20, grad_dtype, force_collectives, cast)
+        assert collective in ('torch', 'odtk'), collective
+        coll = OdtkCollective(group, model.G.device) if collective == 'odtk' else None
+        self.red = BucketAllReducer(model.G, segs, group, int(bucket_mb) << 20, grad_dtype, force_collectives, cast, coll)
         self.world = self.red.world
 
     def boundary_layers(self):

@@ -842,8 +842,8 @@ class RefineDet320(F32Warmup):
         self.global_step = int(blob.get('global_step', 0))
         print('load weight', path, 'successfully')
 
-    def attach_data_parallel(self, group=None, bucket_mb=25, grad_dtype='f32', force_collectives=False):
+    def attach_data_parallel(self, group=None, bucket_mb=25, grad_dtype='f32', force_collectives=False, collective='torch'):
         from .dist import GradAllReducer
-        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
+        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives, collective)
         self.loss_divisor_batch = self.batch_size * self.dist.world
         return self.dist

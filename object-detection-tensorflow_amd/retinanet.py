@@ -623,9 +623,9 @@ class RetinaNet:
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < nb})
         print('load pretraining weight', path, 'successfully')
 
-    def attach_data_parallel(self, group=None, bucket_mb=25, grad_dtype='f32', force_collectives=False):
+    def attach_data_parallel(self, group=None, bucket_mb=25, grad_dtype='f32', force_collectives=False, collective='torch'):
         from .dist import GradAllReducer
-        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
+        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives, collective)
         self.loss_divisor_batch = self.batch_size * self.dist.world
         return self.dist
 

@@ -1218,12 +1218,13 @@ class SSD300:
         print('load weight', path, 'successfully')
 
     # ------------------------------------------------------------------ data parallel
-    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False, grad_dtype='f32', force_collectives=False):
+    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False, grad_dtype='f32', force_collectives=False, collective='torch'):
         """Shard images over ranks (one process per GPU); gradients are summed with bucketed
         RCCL all-reduce overlapped with backward.  The loss divisor becomes the GLOBAL batch.
-        grad_dtype 'bf16': the buckets travel as bf16 copies (half the xGMI bytes); force_collectives: issue them in a world of one rank too."""
+        grad_dtype 'bf16': the buckets travel as bf16 copies (half the xGMI bytes); force_collectives: issue them in a world of one rank too;
+        collective 'odtk': the sums go through the C-ABI's own collective (odtk_comm_allreduce) instead of torch.distributed's."""
         from .dist import GradAllReducer
-        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
+        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives, collective)
         self.dist.red.launch_ctx = self._comm_launch
         self._graphs_invalidate()
         self.loss_divisor_batch = self.batch_size * self.dist.world

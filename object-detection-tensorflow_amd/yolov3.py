@@ -524,12 +524,12 @@ class YOLOv3:
         self.load_oracle_params({k: v for k, v in blob.items() if int(k[1:].split('.')[0]) < 52 and k in self.pinfo})
         print('load pretraining weight', path, 'successfully')
 
-    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False, grad_dtype='f32', force_collectives=False):
+    def attach_data_parallel(self, group=None, bucket_mb=25, sync_bn=False, grad_dtype='f32', force_collectives=False, collective='torch'):
         """images sharded over ranks (one process per GPU); gradients summed with the bucketed RCCL all-reduce of dist.py,
         overlapped with the backward pass; the loss divisor becomes the GLOBAL batch.  sync_bn: batch statistics over all replicas
         (ops.SyncBN), i.e. exactly the single-device computation on the global batch"""
         from .dist import GradAllReducer
-        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives)
+        self.dist = GradAllReducer(self, group, bucket_mb, grad_dtype, force_collectives, collective)
         self.loss_divisor_batch = self.batch_size * self.dist.world
         if sync_bn:
             self.sync_bn = ops.SyncBN(group)

@@ -316,3 +316,75 @@ def test_rccl_world1_data_parallel_training_step(dev, grad_dtype, launch):
     # make two runs of the SAME configuration differ by ~0.5 % by then (measured 0.65 % between this pair), so this is a sanity bound, not a parity bound
     tol = 3e-2
     assert abs(dp['config']['final_loss'] - one['config']['final_loss']) <= tol * abs(one['config']['final_loss']), (dp['config'], one['config'])
+
+
+def test_odtk_comm_world1(dev):
+    """The C-ABI's own collective (include/odtk.h: odtk_comm_*, RCCL bound by dlopen) in a world of one rank, through ctypes as a non-PyTorch binder
+    would call it: id -> init -> all-reduce (in place, out of place, bf16) -> broadcast -> destroy; the sum over one rank is the identity, bit for bit."""
+    import ctypes as C
+    from odtk import _lib
+    lib = _lib.load()
+    ident = C.create_string_buffer(128)
+    _lib.check(lib.odtk_comm_unique_id(ident))
+    assert any(ident.raw)
+    comm = C.c_void_p()
+    _lib.check(lib.odtk_comm_init(ident, 0, 1, C.byref(comm)))
+    rk, wd = C.c_int(-1), C.c_int(-1)
+    _lib.check(lib.odtk_comm_info(comm, C.byref(rk), C.byref(wd)))
+    assert (rk.value, wd.value) == (0, 1)
+    st = torch.cuda.Stream()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.randn(1 << 20, generator=g).to(dev)
+    with torch.cuda.stream(st):
+        y = x.clone()
+        z = torch.empty_like(x)
+        sp = C.c_void_p(st.cuda_stream)
+        _lib.check(lib.odtk_comm_allreduce(comm, C.c_void_p(y.data_ptr()), C.c_void_p(y.data_ptr()), y.numel(), _lib.F32, sp))
+        _lib.check(lib.odtk_comm_allreduce(comm, C.c_void_p(x.data_ptr()), C.c_void_p(z.data_ptr()), x.numel(), _lib.F32, sp))
+        h = x.to(torch.bfloat16)
+        h0 = h.clone()
+        _lib.check(lib.odtk_comm_allreduce(comm, C.c_void_p(h.data_ptr()), C.c_void_p(h.data_ptr()), h.numel(), _lib.BF16, sp))
+        _lib.check(lib.odtk_comm_broadcast(comm, C.c_void_p(y.data_ptr()), y.numel(), _lib.F32, 0, sp))
+        _lib.check(lib.odtk_comm_allreduce(comm, None, None, 0, _lib.F32, sp))
+    st.synchronize()
+    assert torch.equal(y, x) and torch.equal(z, x) and torch.equal(h, h0)
+    assert lib.odtk_comm_allreduce(comm, C.c_void_p(y.data_ptr()), C.c_void_p(y.data_ptr()), 8, 77, None) != 0
+    assert b'dtype' in lib.odtk_last_error()
+    assert lib.odtk_comm_broadcast(comm, C.c_void_p(y.data_ptr()), 8, _lib.F32, 1, None) != 0
+    _lib.check(lib.odtk_comm_destroy(comm))
+
+
+@pytest.mark.parametrize('grad_dtype', ['f32', 'bf16'])
+def test_data_parallel_step_through_the_c_abi_collective(dev, grad_dtype):
+    """`attach_data_parallel(collective='odtk')`: the bucket sums of the SSD300 data-parallel step go through odtk_comm_allreduce (no torch.distributed
+    process group exists in this process at all).  World of one rank, deterministic filter gradients: with f32 buckets the parameters after three steps
+    are bit-identical to the plain single-device step's; with bf16 buckets (narrow -> sum -> widen) they are those of gradients rounded to bf16."""
+    import torch.distributed as dist
+    import odtk
+    from oracle import ssd300_ref as R
+    assert not dist.is_initialized()
+    B = 4
+    cfg = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
+           'batch_size': B, 'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '',
+           'verbose': False, 'compute_dtype': 'bf16', 'seed': 0, 'deterministic_wgrad': True}
+    prov = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [], 'val_generator': None}
+    imgs, gt = R.synthetic_batch(B, 7)
+    out = []
+    for dp in (False, True):
+        m = odtk.SSD300(cfg, prov)
+        if dp:
+            red = m.attach_data_parallel(bucket_mb=8, grad_dtype=grad_dtype, force_collectives=True, collective='odtk')
+            assert red.red.collective is not None and len(red.red.buckets) >= 3
+        m.set_batch(imgs, gt)
+        losses = [float(m.train_step(0.002)) for _ in range(3)]
+        torch.cuda.synchronize()
+        if dp:
+            assert len(red.red.launch_log) == len(red.red.buckets)
+            red.red.collective.close()
+        out.append((m.P.clone(), losses))
+    (p0, l0), (p1, l1) = out
+    if grad_dtype == 'f32':
+        assert torch.equal(p0, p1) and l0 == l1, (l0, l1, float((p0 - p1).abs().max()))
+    else:
+        assert abs(l0[-1] - l1[-1]) <= 2e-2 * abs(l0[-1]), (l0, l1)
+        assert float((p0 - p1).norm() / (p0.norm() * 1e-3)) < 1.0

@@ -232,3 +232,23 @@ def test_f32x3_descriptors_are_refused_by_the_fused_entry_points():
     # a descriptor that mixes the engine with another storage type is refused as well
     bad = ops.conv_desc(2, 64, 64, 64, 64, 64, 64, 3, 1, 1, ops.F32X3, ops.F32)
     assert lib.odtk_conv2d_fwd(C.byref(bad), None, None, None, None, 0, None) != 0 and b'ODTK_F32X3' in lib.odtk_last_error()
+
+
+def test_comm_entry_points_check_their_arguments_before_touching_rccl():
+    """include/odtk.h: odtk_comm_* (the C-ABI's collective).  Argument checks run before RCCL is bound or a device is touched: no GPU needed"""
+    import ctypes as C
+    import odtk  # noqa: F401
+    from odtk import _lib
+    lib = _lib.load()
+    assert lib.odtk_comm_unique_id(None) == 1 and b'null' in lib.odtk_last_error()
+    ident = C.create_string_buffer(128)
+    comm = C.c_void_p()
+    assert lib.odtk_comm_init(ident, 2, 2, C.byref(comm)) == 1 and b'rank 2 of 2' in lib.odtk_last_error()
+    assert lib.odtk_comm_init(None, 0, 1, C.byref(comm)) == 1
+    assert lib.odtk_comm_allreduce(None, None, None, 0, _lib.F32, None) == 1 and b'null communicator' in lib.odtk_last_error()
+    assert lib.odtk_comm_broadcast(None, None, 0, _lib.F32, 0, None) == 1
+    assert lib.odtk_comm_info(None, None, None) == 1
+    assert lib.odtk_comm_destroy(None) == 0            # destroying nothing is not an error
+    from odtk.dist import COMM_ID_BYTES
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'odtk.h')).read()
+    assert f'#define ODTK_COMM_ID_BYTES {COMM_ID_BYTES}' in hdr

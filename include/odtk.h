@@ -75,7 +75,8 @@ int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to
  * every later call of this thread until the slot changes.  Calls on ONE stream are ordered and share slot 0; a caller that
  * launches convolutions on several streams CONCURRENTLY (SSD300: the heads beside the extra-layer chain) selects a different
- * slot (0..3) per stream before launching on it.  Buffers are never freed or moved (captured graphs point into them). */
+ * slot (0..3) per stream before launching on it.  A buffer that a stream capture has been handed is never freed or moved (the captured graph
+ * points into it); one that no capture has seen is freed when a later call outgrows it (after a device synchronize: first steps only). */
 int odtk_scratch_slot(int slot);
 /* name of the device kernel the last odtk_conv2d_* call of this thread dispatched to (bench.py attributes
  * its HIP-event timings to kernels with it, so the roofline line and the rocprofv3 trace name the same kernel) */

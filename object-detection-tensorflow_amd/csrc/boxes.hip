@@ -248,7 +248,8 @@ constexpr int NMS_WORDS = NMS_TCAP / 64;
 struct NmsScratch {
     unsigned* sidx;                 // [B][TCAP]  original indices, best first
     NBox* sbox;                     // [B][TCAP]  their normalised boxes
-    unsigned long long* mat;        // [B][TCAP][WORDS]  bit j of word w of row i: iou(i, 64w+j) > thr
+    unsigned long long* mat;        // [B][WORDS][TCAP]  bit j of word [w][i]: iou(i, 64w+j) > thr (word-major since round 5: a column block's words of 64 rows are 512 contiguous bytes)
+    unsigned long long* flags;      // [B][WORDS]  bit cb of word rb: the 64 x 64 sub-block (row block rb, column block cb) holds a set bit (zeroed by nms_topk_kernel)
     int* info;                      // [B][4] = {lim, nvalid, mo, fallback flag}
     char* big;                      // [B][32768 * 16] or null: global-memory work area of the single-workgroup kernel for n > 16384
 };
@@ -428,6 +429,7 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_topk_kernel(const NmsArgs a, 
         return ((unsigned long long)sortable(s) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
     };
     for (int i = tid; i < 4096; i += NMS_THREADS) hist[i] = 0u;
+    if (tid < NMS_WORDS) ws.flags[(size_t)b * NMS_WORDS + tid] = 0ull;            // nms_matrix_kernel ORs into them
     if (tid == 0) { s_nvalid = 0; s_B = -1; s_cnt = 0; s_pos = 0; s_hi = 0; }
     __syncthreads();
     int myvalid = 0;
@@ -582,41 +584,59 @@ __global__ void __launch_bounds__(256) nms_matrix_kernel(const NmsScratch ws, co
             const NBox cj = s_col[wave][j];
             if (iou_nms(bx, cj) > thr) bits |= 1ull << j;
         }
-        ws.mat[((size_t)b * NMS_TCAP + row) * NMS_WORDS + cb] = bits;
+        ws.mat[((size_t)b * NMS_WORDS + cb) * NMS_TCAP + row] = bits;
+        if (cb > rb && __ballot(bits != 0ull) != 0ull && lane == 0) atomicOr(&ws.flags[(size_t)b * NMS_WORDS + rb], 1ull << cb);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
-// Greedy selection over the bit matrix: one wave per problem.  Row blocks are visited in order.  The
-// "suppressed" word of block rb is gathered column-wise: lane j ORs word rb of the rows pb*64 + j it
-// picked in every earlier block pb (independent loads, 8 in flight), then a wave OR-reduction.  Inside
-// the block the picks are resolved on the diagonal word with a wave-uniform (scalar) bit loop.
+// Greedy selection over the bit matrix: one wave per problem.  Row blocks are visited in order.  The "suppressed" word of block rb is gathered
+// column-wise: lane j ORs word rb of the rows pb*64 + j it picked in the earlier blocks pb (independent loads, 8 in flight, 512 contiguous bytes
+// each since the matrix is word-major), then a wave OR-reduction.  Round 5: only the blocks pb whose sub-block (pb, rb) holds a bit at all
+// (ws.flags, from nms_matrix_kernel) and that picked anything are visited -- hard negatives rarely overlap, so most of the nb^2 / 2 gathers of ~3 000
+// candidates (a chain of dependent L2 round trips, the kernel's whole time) disappear; the result is the same bit for bit.  Inside the block the
+// picks are resolved on the diagonal word in rounds.
 __global__ void __launch_bounds__(64) nms_scan_kernel(const NmsScratch ws, int* __restrict__ out_idx, const int cap,
                                                       int* __restrict__ out_cnt) {
     __shared__ unsigned long long s_picked[NMS_WORDS];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int lim = ws.info[b * 4 + 0], nvalid = ws.info[b * 4 + 1], mo = ws.info[b * 4 + 2];
     const unsigned* sidx = ws.sidx + (size_t)b * NMS_TCAP;
-    const unsigned long long* mat = ws.mat + (size_t)b * NMS_TCAP * NMS_WORDS;
+    const unsigned long long* mat = ws.mat + (size_t)b * NMS_WORDS * NMS_TCAP;
     int* oidx = out_idx + (long long)b * cap;
     const int nb = (lim + 63) >> 6;
+    const unsigned long long myflag = lane < nb ? ws.flags[(size_t)b * NMS_WORDS + lane] : 0ull;     // lane = row block
+    unsigned long long haspick = 0ull;                           // wave-uniform: blocks that picked anything
     int count = 0;
+    // the diagonal word and the index of row block 0; those of block rb + 1 are fetched under the work of block rb
+    unsigned long long diag_n = lane < lim ? mat[(size_t)0 * NMS_TCAP + lane] : 0ull;
+    unsigned idx_n = lane < lim ? sidx[lane] : 0u;
     for (int rb = 0; rb < nb && count < mo; ++rb) {
         const int row = rb * 64 + lane;
-        const unsigned long long diag = row < lim ? mat[(size_t)row * NMS_WORDS + rb] : 0ull;
-        const unsigned myidx = row < lim ? sidx[row] : 0u;
+        const unsigned long long diag = diag_n;
+        const unsigned myidx = idx_n;
+        if (rb + 1 < nb) {
+            const int rn = row + 64;
+            diag_n = rn < lim ? mat[(size_t)(rb + 1) * NMS_TCAP + rn] : 0ull;
+            idx_n = rn < lim ? sidx[rn] : 0u;
+        }
         // suppressed-by-earlier-picks word of this block
+        unsigned long long need = __ballot((myflag >> rb) & 1ull) & haspick;         // wave-uniform: earlier blocks that can reach into this one
         unsigned long long acc = 0ull;
-        for (int pb0 = 0; pb0 < rb; pb0 += 8) {
+        const unsigned long long* col = mat + (size_t)rb * NMS_TCAP;
+        while (need) {
+            int pbs[8];
             unsigned long long v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int pb = pb0 + u < rb ? pb0 + u : rb - 1;            // clamp: always a valid row
-                v[u] = mat[(size_t)(pb * 64 + lane) * NMS_WORDS + rb];
+                pbs[u] = need ? (int)__builtin_ctzll(need) : -1;
+                if (need) need &= need - 1ull;
             }
 #pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(pbs[u] < 0 ? 0 : pbs[u]) * 64 + lane];
+#pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (pb0 + u < rb && ((s_picked[pb0 + u] >> lane) & 1ull)) acc |= v[u];
+                if (pbs[u] >= 0 && ((s_picked[pbs[u]] >> lane) & 1ull)) acc |= v[u];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
@@ -664,6 +684,7 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const NmsScratch ws, int* 
         const int base = count - __popcll(picked);
         if ((picked >> lane) & 1ull) oidx[base + __popcll(picked & ((1ull << lane) - 1ull))] = (int)myidx;
         if (lane == 0) s_picked[rb] = picked;
+        if (picked) haspick |= 1ull << rb;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // single wave: LDS is in order, this pins the compiler
     }
     if (lane == 0) {
@@ -697,6 +718,23 @@ struct LossArgs {
     float* parts;      // [N][LOSS_SPLIT][3] partial sums (library scratch)
 };
 
+// exp(z - max) of one row of C <= MAXC logits and their sum (c = 0 .. C-1 in order).  Fixed trip counts with predicates: e[] stays in REGISTERS (with the
+// loops bounded by the run-time C the array was indexed dynamically and lived in scratch memory -- round 5)
+__device__ __forceinline__ void softmax_row(const float* __restrict__ z, int C, float (&e)[MAXC], float& m, float& s) {
+    float v[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) v[c] = c < C ? z[c] : -INFINITY;
+    m = v[0];
+#pragma unroll
+    for (int c = 1; c < MAXC; ++c) m = fmaxf(m, v[c]);
+    s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        e[c] = c < C ? expf(v[c] - m) : 0.f;
+        if (c < C) s += e[c];
+    }
+}
+
 // one positive row: CE vs label, smooth-L1 on (yx, hw); adds its gradient into dpred
 __device__ __forceinline__ void positive_row(const LossArgs& a, int n, int anchor, int g, float inv_np,
                                              float& ce_sum, float& coord_sum) {
@@ -704,14 +742,13 @@ __device__ __forceinline__ void positive_row(const LossArgs& a, int n, int ancho
     float* dz = a.dpred + ((size_t)n * a.A + anchor) * a.ld;
     const float* gb = a.gt + ((size_t)n * a.P + g) * 5;
     const int label = (int)gb[4];
-    float m = z[0];
-    for (int c = 1; c < a.C; ++c) m = fmaxf(m, z[c]);
-    float e[MAXC];
-    float s = 0.f;
-    for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - m); s += e[c]; }
+    float e[MAXC], m, s;
+    softmax_row(z, a.C, e, m, s);
     ce_sum += logf(s) - (z[label] - m);
     const float gsc = a.grad_scale * inv_np;
-    for (int c = 0; c < a.C; ++c) atomicAdd(dz + c, (e[c] / s - (c == label ? 1.f : 0.f)) * gsc);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < a.C) atomicAdd(dz + c, (e[c] / s - (c == label ? 1.f : 0.f)) * gsc);
     const float ayx[2] = {a.yx[2 * anchor], a.yx[2 * anchor + 1]};
     const float ahw[2] = {a.hw[2 * anchor], a.hw[2 * anchor + 1]};
     float cl = 0.f;
@@ -753,13 +790,12 @@ __global__ void __launch_bounds__(LOSS_THREADS) ssd_loss_kernel(const LossArgs a
         neg_sum += a.negloss[(size_t)n * a.A + anchor];
         const float* z = a.pred + ((size_t)n * a.A + anchor) * a.ld;
         float* dz = a.dpred + ((size_t)n * a.A + anchor) * a.ld;
-        float m = z[0];
-        for (int c = 1; c < a.C; ++c) m = fmaxf(m, z[c]);
-        float e[MAXC];
-        float sum = 0.f;
-        for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - m); sum += e[c]; }
+        float e[MAXC], m, sum;
+        softmax_row(z, a.C, e, m, sum);
         const float gsc = a.grad_scale * inv_ns;
-        for (int c = 0; c < a.C; ++c) atomicAdd(dz + c, (e[c] / sum - (c == bg ? 1.f : 0.f)) * gsc);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < a.C) atomicAdd(dz + c, (e[c] / sum - (c == bg ? 1.f : 0.f)) * gsc);
     }
     // positives: the G best-anchor rows, then every status==1 anchor (SSD300.py:436-450)
     float ce_sum = 0.f, coord_sum = 0.f;
@@ -862,7 +898,7 @@ static int nms_scratch(int B, NmsScratch* ws, bool need_big) {
     if (o.B < B) {
         int want = o.B ? 2 * o.B : 64;
         if (want < B) want = B;
-        const size_t per = (size_t)NMS_TCAP * (4 + 16 + NMS_WORDS * 8) + 64;
+        const size_t per = (size_t)NMS_TCAP * (4 + 16 + NMS_WORDS * 8) + NMS_WORDS * 8 + 64;
         void* p = nullptr;
         ODTK_CHECK_HIP(hipMalloc(&p, per * want));
         o.base = p; o.B = want;                          // the previous buffer stays allocated (retired, see above)
@@ -871,6 +907,7 @@ static int nms_scratch(int B, NmsScratch* ws, bool need_big) {
     ws->mat = (unsigned long long*)p; p += (size_t)o.B * NMS_TCAP * NMS_WORDS * 8;
     ws->sbox = (NBox*)p;              p += (size_t)o.B * NMS_TCAP * 16;
     ws->sidx = (unsigned*)p;          p += (size_t)o.B * NMS_TCAP * 4;
+    ws->flags = (unsigned long long*)p; p += (size_t)o.B * NMS_WORDS * 8;
     ws->info = (int*)p;
     ws->big = nullptr;
     if (need_big) {
@@ -971,7 +1008,7 @@ extern "C" int odtk_nms_batched(const float* boxes, long long box_stride, const 
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    NmsScratch ws = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    NmsScratch ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (int e = nms_scratch(B, &ws, big)) return e;
     if (g_nms_legacy) {
         if (big) hipLaunchKernelGGL((nms_kernel<0, true>), dim3(B), dim3(NMS_THREADS), 0, st, a, ws, 0);

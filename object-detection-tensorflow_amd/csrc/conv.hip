@@ -1094,7 +1094,7 @@ static int conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const float* w
     const int ks = cv::gather_x3_ksplit(a);
     const size_t xs_b = up256((size_t)Min * x3_pitch(ldc) * 2), w3_b = up256((size_t)d->K * d->R * d->S * 3 * ldc * 2);
     char* base = nullptr;
-    if (int e = cv::x3_scratch(xs_b + w3_b + (ks > 1 ? (size_t)ks * Mout * d->ldy * 4 : 0), &base)) return e;
+    if (int e = cv::x3_scratch(xs_b + w3_b + (ks > 1 ? (size_t)ks * Mout * d->ldy * 4 : 0), st, &base)) return e;
     cv::launch_split3_chan(x, Min, d->C, d->ldx, base, ldc, 2, 2, x3_pitch(ldc), st);                               // pixels [hi | lo], read as [hi | hi | lo]
     cv::launch_split3_chan(w, (long long)d->K * d->R * d->S, d->C, d->C, base + xs_b, ldc, 2, 3, 3 * ldc, st);   // filters [K][R][S][hi | lo | hi]
     a.x = base; a.w = base + xs_b;
@@ -1116,7 +1116,7 @@ static int conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, c
     const int ks = cv::gather_x3_ksplit(a);
     const size_t dys_b = up256((size_t)Mout * x3_pitch(ldk) * 2), wt3_b = up256((size_t)d->C * d->R * d->S * 3 * ldk * 2);
     char* base = nullptr;
-    if (int e = cv::x3_scratch(dys_b + wt3_b + (ks > 1 ? (size_t)ks * Min * d->ldx * 4 : 0), &base)) return e;
+    if (int e = cv::x3_scratch(dys_b + wt3_b + (ks > 1 ? (size_t)ks * Min * d->ldx * 4 : 0), st, &base)) return e;
     cv::launch_split3_chan(dy, Mout, d->K, lddy, base, ldk, 2, 2, x3_pitch(ldk), st);                                // [hi | lo], read as [hi | hi | lo]
     cv::launch_split3_chan(w_t, (long long)d->C * d->R * d->S, d->K, lddy, base + dys_b, ldk, 2, 3, 3 * ldk, st);   // the caller's [C][R][S][lddy] flipped filters -> [hi | lo | hi]
     a.x = base; a.w = base + dys_b;
@@ -1135,7 +1135,7 @@ static int conv2d_wgrad_x3(const odtk_conv_desc* d, const float* x, const float*
     const int ldk = pad8(d->K);
     const size_t xr_b = up256((size_t)3 * Min * d->C * 2), dyr_b = up256((size_t)3 * Mout * ldk * 2), cs_b = (size_t)2 * 256 * ((d->K + 63) / 64 * 64) * 4;
     char* base = nullptr;
-    if (int e = cv::x3_scratch(xr_b + dyr_b + cs_b, &base)) return e;
+    if (int e = cv::x3_scratch(xr_b + dyr_b + cs_b, st, &base)) return e;
     cv::launch_split3_rows(x, Min, d->C, d->ldx, base, d->C, 2, st);                                  // images [hi ; lo ; hi]
     cv::launch_split3_rows(dy, Mout, d->K, lddy, base + xr_b, ldk, 4, st);                             // images [hi ; hi ; lo]
     odtk_conv_desc b = *d;

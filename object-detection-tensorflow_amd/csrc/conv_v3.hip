@@ -1969,9 +1969,11 @@ __global__ void __launch_bounds__(256) wgrad3x3_c8k64_kernel(const WgradArgs a, 
 }  // namespace
 
 // per-device f32 scratch of the split-K path, grown on demand.  Calls are stream-ordered by the caller like everything
-// else in this library.  A buffer that was handed out is NEVER freed or moved: a captured HIP graph may still replay
-// kernels that point into it, so growth allocates a new, at least twice as large buffer and retires the old one.
-struct ConvScratchOwner { void* base = nullptr; size_t bytes = 0; };
+// else in this library.  A buffer whose address a CAPTURED HIP graph may hold is never freed or moved (the graph would replay kernels that point
+// into it): growth then allocates a new, at least twice as large buffer and retires the old one for good.  A buffer that no capture has ever been
+// handed (hipStreamIsCapturing at every request) is freed when it is outgrown, after a device synchronize -- round-4 advisory: the doubling
+// sequence 64 -> 128 -> 256 -> 512 MB of the first ODTK_F32X3 step used to strand as much again as the arena ends up holding.
+struct ConvScratchOwner { void* base = nullptr; size_t bytes = 0; bool captured = false; };
 constexpr int SCRATCH_SLOTS = 4;
 static ConvScratchOwner g_conv_scratch[16][SCRATCH_SLOTS];
 static thread_local int g_scratch_slot = 0;            // odtk_scratch_slot(): one slot per stream the caller launches on concurrently
@@ -1980,40 +1982,36 @@ int set_scratch_slot(int slot) {
     g_scratch_slot = slot;
     return 0;
 }
-static int conv_scratch(size_t bytes, float** out) {
+static int scratch_get(ConvScratchOwner (&arena)[16][SCRATCH_SLOTS], size_t bytes, hipStream_t st, void** out) {
     int dev = 0;
     ODTK_CHECK_HIP(hipGetDevice(&dev));
     ODTK_REQUIRE(dev >= 0 && dev < 16, "conv: device index %d unsupported", dev);
-    ConvScratchOwner& o = g_conv_scratch[dev][g_scratch_slot];
+    ConvScratchOwner& o = arena[dev][g_scratch_slot];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     if (o.bytes < bytes) {
+        ODTK_REQUIRE(!capturing, "conv: library scratch must grow (%zu -> %zu bytes) inside a stream capture: run one eager step first", o.bytes, bytes);
         size_t want = o.bytes ? 2 * o.bytes : ((size_t)64 << 20);
         if (want < bytes) want = bytes;
+        if (o.base && !o.captured) {                  // nobody can still hold the old address once the device is idle
+            ODTK_CHECK_HIP(hipDeviceSynchronize());
+            ODTK_CHECK_HIP(hipFree(o.base));
+            o.base = nullptr; o.bytes = 0;
+        }
         void* p = nullptr;
-        ODTK_CHECK_HIP(hipMalloc(&p, want));          // fails inside a stream capture: run one eager step first
-        o.base = p; o.bytes = want;
+        ODTK_CHECK_HIP(hipMalloc(&p, want));
+        o.base = p; o.bytes = want; o.captured = false;
     }
-    *out = (float*)o.base;
+    if (capturing) o.captured = true;
+    *out = o.base;
     return ODTK_OK;
 }
+static int conv_scratch(size_t bytes, hipStream_t st, float** out) { return scratch_get(g_conv_scratch, bytes, st, (void**)out); }
 
 // the x3 engine's split operands (and the column-sum partials of its bias gradient): their own arena, because the kernels they feed take split-K /
 // filter-gradient partials from conv_scratch while the operands are still being read
 static ConvScratchOwner g_x3_scratch[16][SCRATCH_SLOTS];
-int x3_scratch(size_t bytes, char** out) {
-    int dev = 0;
-    ODTK_CHECK_HIP(hipGetDevice(&dev));
-    ODTK_REQUIRE(dev >= 0 && dev < 16, "conv: device index %d unsupported", dev);
-    ConvScratchOwner& o = g_x3_scratch[dev][g_scratch_slot];
-    if (o.bytes < bytes) {
-        size_t want = o.bytes ? 2 * o.bytes : ((size_t)64 << 20);
-        if (want < bytes) want = bytes;
-        void* p = nullptr;
-        ODTK_CHECK_HIP(hipMalloc(&p, want));
-        o.base = p; o.bytes = want;
-    }
-    *out = (char*)o.base;
-    return ODTK_OK;
-}
+int x3_scratch(size_t bytes, hipStream_t st, char** out) { return scratch_get(g_x3_scratch, bytes, st, (void**)out); }
 
 static int g_num_cu = 0;
 static void query_num_cu() {
@@ -2120,7 +2118,7 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
         }
         if (best_split >= 2) {
             float* ws = nullptr;
-            if (int e = conv_scratch((size_t)best_split * a.M * a.ldy * sizeof(float), &ws)) return e;
+            if (int e = conv_scratch((size_t)best_split * a.M * a.ldy * sizeof(float), st, &ws)) return e;
             a.ws = ws; a.cs_split = best_split;
             a.tiles_q = ceil_div(a.M, best_qt);
             const int grid = a.tiles_p * a.tiles_q * best_split;
@@ -2134,7 +2132,7 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     }
     if (ksplit >= 2) {
         float* ws = nullptr;
-        if (int e = conv_scratch((size_t)ksplit * a.M * a.ldy * sizeof(float), &ws)) return e;
+        if (int e = conv_scratch((size_t)ksplit * a.M * a.ldy * sizeof(float), st, &ws)) return e;
         a.ksplit = ksplit; a.ws = ws;
         const int grid = tiles * ksplit;
         if (PT == 64) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
@@ -2753,12 +2751,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_v8_kernel(const WgradArgs a) {
 // run.  The default stays float atomics into dw: measured on the SSD300 step at batch 32, same box, the split-reduce costs
 // 2.5-2.7 % (3 210 | 3 186 against 3 292 | 3 284 images/s): it moves splits x |dw| bytes twice (~700 MB per step) where the
 // atomics, ~40 us per 256 x 256-tile launch as they are, move them once.
-static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots) {
+static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots, hipStream_t st) {
     a.ws = nullptr; a.bws = nullptr; a.nsplit = splits; a.nbslot = bias_slots;
     if (splits < 2 || !g_wgrad_deterministic) return 0;
     float* base = nullptr;
     const size_t wbytes = (size_t)splits * a.K * a.RSC * sizeof(float);
-    if (int e = conv_scratch(wbytes + (size_t)bias_slots * a.K * sizeof(float), &base)) return e;
+    if (int e = conv_scratch(wbytes + (size_t)bias_slots * a.K * sizeof(float), st, &base)) return e;
     a.ws = base;
     a.bws = bias_slots ? base + (size_t)splits * a.K * a.RSC : nullptr;
     return 0;
@@ -2797,7 +2795,7 @@ bool launch_wgrad_v8(WgradArgs& a, hipStream_t st) {
     const int splits = ceil_div(iters_total, a.iters_per_split);
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
-    if (wgrad_split_scratch(a, splits, a.dbias ? splits * tiles_q * 2 : 0)) return false;
+    if (wgrad_split_scratch(a, splits, a.dbias ? splits * tiles_q * 2 : 0, st)) return false;
     hipLaunchKernelGGL(conv_wgrad_v8_kernel<2>, dim3(tiles * splits), dim3(256), 0, st, a);
     wgrad_split_reduce(a, st);
     a.which = 8;
@@ -2830,7 +2828,7 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st) {
     const int splits = ceil_div(iters_total, a.iters_per_split);
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
-    if (int e = wgrad_split_scratch(a, splits, a.dbias ? splits : 0)) return e;
+    if (int e = wgrad_split_scratch(a, splits, a.dbias ? splits : 0, st)) return e;
     hipLaunchKernelGGL(conv_wgrad_v3_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
     wgrad_split_reduce(a, st);
     a.which = 3;

@@ -49,7 +49,9 @@ def test_bf16_engine_tracks_f32_engine(kind):
     # (round 4: 6e-2, was 2e-2.  RefineDet320's bf16 loss moves by 2-4 % when numerically EQUIVALENT kernels are swapped -- raster-run halo kernel against the 8-wave kernel
     #  on conv2_x / conv3_x: 1e-4 of the outputs differ by one bf16 ulp, error against f64 identical to 9 digits -- 21.12 / 20.74 / 20.30 against the f32 engine's 21.14
     #  with 0 / 2 / 5 layers on the halo kernel; the split-f32 engine on the very same halo kernels reads 21.141.  The bound has to sit above that spread.)
-    assert abs(lb - lf) <= 6e-2 * abs(lf), (lb, lf)
+    # YOLOv2 (one trunk, no VGG front on the halo kernels) keeps the round-3 bounds: 2e-2 on the loss, 1.5 on the norm ratio (round-4 advisory).
+    loss_tol, ratio_max = (2e-2, 1.5) if kind == 'yolov2' else (6e-2, 1.8)
+    assert abs(lb - lf) <= loss_tol * abs(lf), (lb, lf)
     worst_c, worst_r, worst_last = ('', 1.0), ('', 1.0), ('', 1.0)
     last = ('pred.w',) if kind == 'yolov2' else tuple(f'{h}{l}.{o}.w' for h in ('arm', 'odm') for l in range(1, 5) for o in ('loc', 'conf'))
     for k, gf in res['f32'][1].items():
@@ -66,4 +68,4 @@ def test_bf16_engine_tracks_f32_engine(kind):
     print(kind, 'loss f32 / bf16', lf, lb, 'worst cosine', worst_c, 'of the output layers', worst_last, 'worst norm ratio', worst_r)
     assert worst_c[1] > 0.4, worst_c                           # measured 0.51 (RefineDet conv3_3), 0.52 (YOLOv2 b1)
     assert worst_last[1] > 0.75, worst_last                    # measured 0.80 (RefineDet odm4.loc), 0.95 (YOLOv2 pred)
-    assert worst_r[1] < 1.8, worst_r                           # measured 1.33 -- 1.53 (RefineDet trunk: bf16 norm 0.65-0.8 of f32; moves with the loss, see above)
+    assert worst_r[1] < ratio_max, worst_r                           # measured 1.33 -- 1.53 (RefineDet trunk: bf16 norm 0.65-0.8 of f32; moves with the loss, see above)

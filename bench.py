@@ -300,6 +300,10 @@ def main():
 
     import odtk
     from odtk import ops
+    collective = args.collective
+    if use_pg and collective == 'odtk' and not os.environ.get('ODTK_BENCH_LATE_COMM'):      # (the variable: communicator created at attach time, A/B)
+        from odtk.dist import OdtkCollective
+        collective = OdtkCollective(None, dev)                  # the communicator BEFORE the model's streams see their first launch (odtk/dist.py)
     B = args.batch
     apply_debug_switches(args)
     config = {
@@ -315,7 +319,7 @@ def main():
     model = odtk.SSD300(config, provider)
     if use_pg:
         model.attach_data_parallel(bucket_mb=args.bucket_mb, sync_bn=args.sync_bn, grad_dtype=args.grad_dtype, force_collectives=args.dp_world1,
-                                   collective=args.collective)
+                                   collective=collective)
     images, gt = synthetic_batch(B, 1000 + rank, dev)
     model.set_batch(images, gt)
 

@@ -205,8 +205,14 @@ class GradAllReducer:
         if grad_dtype == 'bf16' and model.G.is_cuda:
             from . import ops
             cast = (ops.cast_from_f32, ops.cast_to_f32)
-        assert collective in ('torch', 'odtk'), collective
-        coll = OdtkCollective(group, model.G.device, getattr(model, '_side', None)) if collective == 'odtk' else None
+        # collective: 'torch' | 'odtk' | an OdtkCollective the caller created earlier (bench.py does, BEFORE the model: see OdtkCollective)
+        if isinstance(collective, OdtkCollective):
+            coll = collective
+            if coll.stream is None:
+                coll.stream = getattr(model, '_side', None)
+        else:
+            assert collective in ('torch', 'odtk'), collective
+            coll = OdtkCollective(group, model.G.device, getattr(model, '_side', None)) if collective == 'odtk' else None
         self.red = BucketAllReducer(model.G, segs, group, int(bucket_mb) << 20, grad_dtype, force_collectives, cast, coll)
         self.world = self.red.world
 

@@ -63,7 +63,9 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         (statistics, finalize, apply); value -2 = two (apply with the finalize folded in: measured slower, A/B only), -1 = back to three;
  *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back;
  * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
- *         run, 2.5 % slower on the SSD300 step) instead of float atomics into dw (the default);
+ *         run, 8 % slower on the SSD300 step: 8.44 against 7.78 ms, r05u) instead of float atomics into dw (the default); round 5: the 64 -> 64 and first-layer
+ *         kernels (one partial per workgroup / wave) and the scalar gamma gradient of odtk_l2norm_bwd follow the switch too, so a
+ *         whole SSD300 step is reproducible bit for bit;
  * key 6 = dispatch A/B switches of the convolution kernels that leave results intact (up to the engines' stated tolerances): bit 2 (4) = ODTK_F32X3 descriptors run
  *         on the exact f32 kernels, bit 3 (8) = ... on the split path wherever it is supported, also below the size policy (tests), bit 4 (16) = no 32-row filter
  *         tile in the f32 LDS-DMA gather, bit 5 (32) = narrow f32 filter gradients on the legacy kernel; round 5: bit 6 (64) = no small-map gather kernel

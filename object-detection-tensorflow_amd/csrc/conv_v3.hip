@@ -1780,18 +1780,25 @@ __global__ void __launch_bounds__(256) wgrad3x3_c64k64_kernel(const WgradArgs a,
         });
     }
     // ---- dW (+)= : rows k = kblk*64 + kb*32 + 8*(e>>2) + 4*hi + (e&3), column = tap*C + cblk*64 + ch_half*32 + l31
+    // a.ws (deterministic mode, one block pair only): this workgroup's 64 x 576 partial goes to ws[slot] with plain stores and wgrad_reduce_kernel adds
+    // the slots in order -- the tile walk of a slot is fixed, so the result is bit-identical from run to run (round 5; the atomics below are not)
+    float* const wdst = a.ws ? a.ws + (size_t)slot * a.K * a.RSC : a.dw;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         const int col = j * a.C + cblk * 64 + ch_half * 32 + l31;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int k = kblk * 64 + kb * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-            atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[j][e]);
+            if (a.ws) wdst[(size_t)k * a.RSC + col] = acc[j][e];
+            else atomicAdd(wdst + (size_t)k * a.RSC + col, acc[j][e]);
         }
     }
     if (do_bias) {
         const float tsum = bsum + __shfl_xor(bsum, 32);           // both k halves
-        if (hi == 0) atomicAdd(a.dbias + kblk * 64 + kb * 32 + l31, tsum);
+        if (hi == 0) {
+            if (a.bws) a.bws[(size_t)slot * a.K + kblk * 64 + kb * 32 + l31] = tsum;
+            else atomicAdd(a.dbias + kblk * 64 + kb * 32 + l31, tsum);
+        }
     }
 }
 
@@ -1935,6 +1942,25 @@ __global__ void __launch_bounds__(256) wgrad3x3_c8k64_kernel(const WgradArgs a, 
     }
     wait_vmcnt<0>();
     block_barrier();
+    if (a.ws) {
+        // deterministic mode (round 5): every WAVE stores its own 64 x 72 partial (+ 64 bias sums) with plain stores; wgrad_reduce_kernel adds the
+        // workers' partials in worker order.  (The LDS meeting below uses ds_add_f32 from four waves and global float atomics: neither has an order.)
+        float* wp = a.ws + (size_t)worker * (64 * 72);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const int col = 32 * cb + l31;
+                if (col < 72) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) wp[(kb * 32 + 8 * (e >> 2) + 4 * hi + (e & 3)) * 72 + col] = acc[kb][cb][e];
+                }
+            }
+            const float t = bsum[kb] + __shfl_xor(bsum[kb], 32);
+            if (a.bws && hi == 0) a.bws[(size_t)worker * 64 + kb * 32 + l31] = t;
+        }
+        return;
+    }
     // ---- the four waves' partial sums meet in LDS (the ring is dead now), then 64 x 72 + 64 float atomics per workgroup
     float* red = reinterpret_cast<float*>(smem);
     for (int i = tid; i < 64 * 72 + 64; i += 256) red[i] = 0.f;
@@ -2252,6 +2278,10 @@ int launch_gather_c8(GatherArgs& a, hipStream_t st) {
 
 static bool g_wgrad_deterministic = false;
 void set_wgrad_deterministic(bool on) { g_wgrad_deterministic = on; }
+bool get_wgrad_deterministic() { return g_wgrad_deterministic; }
+
+static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots, hipStream_t st);
+static void wgrad_split_reduce(const WgradArgs& a, hipStream_t st);
 
 bool wgrad_c64_supported(const WgradArgs& a, int dtype) {
     if (!(dtype == ODTK_BF16 && a.C % 64 == 0 && a.K % 64 == 0 && a.C >= 64 && a.K >= 64 && a.ldx >= a.C && a.ldx % 8 == 0 && a.lddy >= a.K && a.lddy % 8 == 0 &&
@@ -2281,8 +2311,11 @@ int launch_wgrad_c64(WgradArgs& a, hipStream_t st) {
     if (per_pair < 1) per_pair = 1;
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    // deterministic mode (only the 64 -> 64 layer gets here in it: one block pair): one partial per workgroup + the fixed-order reduction launch
+    if (int e = wgrad_split_scratch(a, npairs == 1 ? per_pair : 1, (npairs == 1 && a.dbias) ? per_pair : 0, st)) return e;
     hipLaunchKernelGGL(wgrad3x3_c64k64_kernel, dim3(per_pair * npairs), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)),
                        make_fastdiv((unsigned)tc), npairs, ncb);
+    wgrad_split_reduce(a, st);
     return 0;
 }
 
@@ -2301,7 +2334,9 @@ int launch_wgrad_c8(WgradArgs& a, hipStream_t st) {
     if (grid < 1) grid = 1;
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
+    if (int e = wgrad_split_scratch(a, grid * 4, a.dbias ? grid * 4 : 0, st)) return e;          // deterministic mode: one partial per wave
     hipLaunchKernelGGL(wgrad3x3_c8k64_kernel, dim3(grid), dim3(256), 0, st, a, sc, spi, total, make_fastdiv((unsigned)spi), make_fastdiv((unsigned)sc));
+    wgrad_split_reduce(a, st);
     return 0;
 }
 

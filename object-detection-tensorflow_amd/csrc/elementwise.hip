@@ -1117,7 +1117,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          T* __restrict__ dx, int M, int C, int ld,
                                                          const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                         int accumulate, const T* __restrict__ relu_src) {
+                                                         int accumulate, const T* __restrict__ relu_src, float* __restrict__ part,
+                                                         unsigned* __restrict__ ticket) {
     constexpr int KC = Chunk<T>::N;
     __shared__ float sdg[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1163,7 +1164,24 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const T* __restrict__ x
     }
     if (lane == 0) sdg[wave] = dg;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dgamma, (sdg[0] + sdg[1]) + (sdg[2] + sdg[3]));
+    if (threadIdx.x == 0) {
+        const float v = (sdg[0] + sdg[1]) + (sdg[2] + sdg[3]);
+        if (part == nullptr) {
+            atomicAdd(dgamma, v);
+        } else {
+            // deterministic mode (odtk_debug_set key 5, round 5): the blocks' sums are added in BLOCK order by whichever block arrives last
+            __hip_atomic_store(part + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                __threadfence();
+                float sum = 0.f;
+                for (unsigned b = 0; b < gridDim.x; ++b) sum += __hip_atomic_load(part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *dgamma += sum;
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch (stream order)
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ optimizer
@@ -1326,6 +1344,7 @@ inline RedPlan red_plan_capped(int M, int C, int kc, int maxsplit) {
 }  // namespace odtk
 
 using namespace odtk;
+namespace odtk { namespace cv { bool get_wgrad_deterministic(); } }
 
 static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0).  (1 408, so that YOLOv3's 13 x 13 maps at 8 images -- 1 352 rows x 512 / 1 024 channels --
                                           // take the single launch, was measured SLOWER there: 11.24 vs 11.13 ms/step, gpurun r03o)
@@ -1626,8 +1645,26 @@ extern "C" int odtk_l2norm_bwd(const void* x, const void* dy, void* dx, int M, i
     if (int e = pool_check(C, ld, dtype)) return e;
     hipStream_t st = (hipStream_t)stream;
     int grid = ceil_div(M, 4); if (grid > 1024) grid = 1024;
+    // deterministic mode (key 5): per-block partial sums + a ticket in a small per-device buffer (launches of this entry point on ONE device are assumed
+    // stream-ordered among themselves in that mode: SSD300 has one L2-norm layer)
+    float* part = nullptr;
+    unsigned* ticket = nullptr;
+    if (cv::get_wgrad_deterministic()) {
+        static float* s_part[16] = {nullptr};
+        int dev = 0;
+        ODTK_CHECK_HIP(hipGetDevice(&dev));
+        ODTK_REQUIRE(dev >= 0 && dev < 16, "l2norm_bwd: device index %d unsupported", dev);
+        if (!s_part[dev]) {
+            void* p = nullptr;
+            ODTK_CHECK_HIP(hipMalloc(&p, (1024 + 16) * sizeof(float)));
+            ODTK_CHECK_HIP(hipMemset(p, 0, (1024 + 16) * sizeof(float)));
+            s_part[dev] = (float*)p;
+        }
+        part = s_part[dev];
+        ticket = reinterpret_cast<unsigned*>(s_part[dev] + 1024);
+    }
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(l2norm_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy,
-                                           (T*)dx, M, C, ld, gamma, dgamma, accumulate, (const T*)relu_src);)
+                                           (T*)dx, M, C, ld, gamma, dgamma, accumulate, (const T*)relu_src, part, ticket);)
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -74,6 +74,7 @@ inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; retur
 inline unsigned atomicMax(unsigned* p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
 inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
 inline unsigned atomicOr(unsigned* p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
+inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }
 inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 
@@ -227,5 +228,7 @@ inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+template <typename T, typename V> inline T hipcpu_fetch_add(T* p, V v) { const T o = *p; *p = o + (T)v; return o; }
+#define __hip_atomic_fetch_add(p, v, order, scope) hipcpu_fetch_add((p), (v))
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipcpu::launch((grid), (block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); })

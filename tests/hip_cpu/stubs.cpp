@@ -11,12 +11,17 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 int zero_async(void* p, size_t bytes, hipStream_t) { memset(p, 0, bytes); return 0; }
+namespace cv {
+static bool g_deterministic = false;
+bool get_wgrad_deterministic() { return g_deterministic; }      // (csrc/conv_v3.hip's switch: elementwise.hip's L2-norm gamma gradient follows it)
+}  // namespace cv
 }  // namespace odtk
 extern "C" const char* odtk_last_error(void) { return odtk::g_err; }
 
 // the three host-side entry points of csrc/conv.hip / api.hip that the emulated files' tests use (the convolution files themselves are not built)
 extern "C" int odtk_debug_set(int key, int value) {
     if (key == 3) { odtk::set_nms_legacy(value != 0); return ODTK_OK; }
+    if (key == 5) { odtk::cv::g_deterministic = value != 0; return ODTK_OK; }
     if (key == 4) { odtk::set_bn_small_rows(value); return ODTK_OK; }      // (incl. -7 / -8: the ticket finalize)
     if (key == 7) { odtk::set_gn_small_rows(value); return ODTK_OK; }
     odtk::set_error("debug_set (CPU emulation): key %d belongs to the convolution files", key);

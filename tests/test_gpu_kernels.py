@@ -532,6 +532,20 @@ def test_l2norm_colsum_sgd(dt, dev):
     tolb = 1e-4 if dt == "f32" else 3e-2
     assert float((dxd.float().cpu() - exp).abs().max()) <= tolb * float(exp.abs().max())
     assert abs(float(dgd.cpu()) - float(gr.grad)) <= 2e-3 * abs(float(gr.grad)) + 1e-3
+    # deterministic mode (odtk_debug_set key 5): the blocks' gamma sums in block order instead of float atomics -- twice the same bits, accumulated into dgamma
+    ops.debug_set(5, 1)
+    try:
+        outs = []
+        for _ in range(2):
+            dg2 = torch.full((1,), 0.5, device=dev)
+            dx2 = prev.clone().to(dev)
+            ops.l2norm_bwd(xd, dy.to(dtype).to(dev), dx2, M, C, C, gamma.to(dev), dg2, True, xd)
+            torch.cuda.synchronize()
+            outs.append(float(dg2.cpu()))
+            assert torch.equal(dx2, dxd)
+    finally:
+        ops.debug_set(5, 0)
+    assert outs[0] == outs[1] and abs(outs[0] - 0.5 - float(gr.grad)) <= 2e-3 * abs(float(gr.grad)) + 1e-3, outs
     # colsum
     ws = torch.zeros(ops.bn_workspace_bytes(M, C), dtype=torch.uint8, device=dev)
     out = torch.ones(C, device=dev)
@@ -829,7 +843,9 @@ def test_wgrad_split_reduce_is_deterministic_and_matches_the_atomics(dev):
     bit-identical; the atomic path agrees to f32 round-off; dw is ACCUMULATED into (FCOS shares its head filters over 5 levels)."""
     ops = _ops()
     for (N, H, W, C, K, k, s, dil), v8 in [((6, 38, 38, 128, 256, 3, 1, 1), False), ((6, 20, 17, 256, 512, 3, 1, 1), True),
-                                             ((8, 19, 19, 64, 100, 3, 1, 1), False)]:
+                                             ((8, 19, 19, 64, 100, 3, 1, 1), False),
+                                             # round 5: the 64 -> 64 halo kernel (one partial per workgroup) and the first-layer kernel (one per wave)
+                                             ((3, 41, 50, 64, 64, 3, 1, 1), False), ((3, 41, 50, 8, 64, 3, 1, 1), False)]:
         Kp = ops.pad_to(K, 8)
         desc = ops.conv_desc(N, H, W, C, C, K, Kp, k, s, dil, ops.BF16, ops.BF16)
         M = N * desc.Ho * desc.Wo

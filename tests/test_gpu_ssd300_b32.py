@@ -415,7 +415,9 @@ def test_deterministic_filter_gradients_at_batch32(dev):
     import odtk
     p = R.init_params(5)
     imgs, gt = R.synthetic_batch(B, 77)
-    names = ['conv2_2.w', 'conv3_1.w', 'conv3_3.w', 'conv4_2.w', 'conv5_3.w', 'conv6.w', 'conv7.w', 'conv8_2.w', 'pred1.w', 'pred2.w', 'conv3_3.b', 'conv6.b']
+    names = ['conv2_2.w', 'conv3_1.w', 'conv3_3.w', 'conv4_2.w', 'conv5_3.w', 'conv6.w', 'conv7.w', 'conv8_2.w', 'pred1.w', 'pred2.w', 'conv3_3.b', 'conv6.b',
+             # round 5: the first two layers' kernels and the L2-norm's scalar gamma follow the switch too -- the WHOLE gradient buffer is reproducible (below)
+             'conv1_1.w', 'conv1_1.b', 'conv1_2.w', 'conv1_2.b', 'l2norm.gamma']
     runs = {}
     try:
         for det in (True, False):
@@ -428,6 +430,7 @@ def test_deterministic_filter_gradients_at_batch32(dev):
                 m._backward()
                 torch.cuda.synchronize()
                 got.append({k: m.param(k, m.G).clone() for k in names if k in m.pinfo})
+                got[-1]['(whole gradient buffer)'] = m.G.clone()
                 del m
             runs[det] = got
     finally:

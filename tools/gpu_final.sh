@@ -11,15 +11,17 @@ for c in retinanet yolov3 fcos centernet; do
   timeout 600 python bench.py --config $c --steps 10 --warmup 3 2>$O/err_$c.log | grep '^{' > $O/bench_line_$c.json
   python -c "import json;d=json.load(open('$O/bench_line_$c.json'));print('$c', d['value'], d['ms_per_step'], d['dtype'], d['roofline']['frac'])"
 done
-# YOLOv3 (BASELINE config 4's per-GPU share): kernel trace + the PMC passes of the same command (round-4 review, item 1)
-YCMD="python bench.py --config yolov3 --steps 4 --warmup 3 --no-cpu-baseline --no-conv-events"
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/ytrace -- $YCMD > $O/ytrace.log 2>&1
-python tools/summarize_trace_csv.py $O/ytrace 7 > $O/yolov3_trace.md; rm -rf $O/ytrace
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d $O/ypmcA -- $YCMD > $O/ypmcA.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -f csv -d $O/ypmcB -- $YCMD > $O/ypmcB.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -f csv -d $O/ypmcC -- $YCMD > $O/ypmcC.log 2>&1
-python tools/pmc_summary.py $O/yolov3_pmc.json $O/ypmcA $O/ypmcB $O/ypmcC > $O/yolov3_pmc.md 2>&1; rm -rf $O/ypmcA $O/ypmcB $O/ypmcC
-head -8 $O/yolov3_trace.md
+# BASELINE configurations 3-5 (per-GPU shares): kernel trace + the PMC passes of the same command (round-4 review: "none has a PMC set")
+for c in yolov3 fcos centernet retinanet; do
+  YCMD="python bench.py --config $c --steps 4 --warmup 3 --no-cpu-baseline --no-conv-events"
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/ytrace -- $YCMD > $O/ytrace.log 2>&1
+  python tools/summarize_trace_csv.py $O/ytrace 7 > $O/${c}_trace.md; rm -rf $O/ytrace
+  timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d $O/ypmcA -- $YCMD > $O/ypmcA.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -f csv -d $O/ypmcB -- $YCMD > $O/ypmcB.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -f csv -d $O/ypmcC -- $YCMD > $O/ypmcC.log 2>&1
+  python tools/pmc_summary.py $O/${c}_pmc.json $O/ypmcA $O/ypmcB $O/ypmcC > $O/${c}_pmc.md 2>&1; rm -rf $O/ypmcA $O/ypmcB $O/ypmcC
+  head -4 $O/${c}_trace.md
+done
 # the classes of SURVEY.md 8f.4 on their default engines (round 4: f32x3 for RefineDet320 / PFPNetR / LH_RCNN) and the engines next to them
 : > $O/classes.log
 for e in f32 f32x3 bf16; do

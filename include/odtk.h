@@ -63,7 +63,7 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         (statistics, finalize, apply); value -2 = two (apply with the finalize folded in: measured slower, A/B only), -1 = back to three;
  *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back;
  * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
- *         run, 8 % slower on the SSD300 step: 8.44 against 7.78 ms, r05u) instead of float atomics into dw (the default); round 5: the 64 -> 64 and first-layer
+ *         run, 5 % slower on the SSD300 step: 8.16 against 7.75 ms, r05u) instead of float atomics into dw (the default); round 5: the 64 -> 64 and first-layer
  *         kernels (one partial per workgroup / wave) and the scalar gamma gradient of odtk_l2norm_bwd follow the switch too, so a
  *         whole SSD300 step is reproducible bit for bit;
  * key 6 = dispatch A/B switches of the convolution kernels that leave results intact (up to the engines' stated tolerances): bit 2 (4) = ODTK_F32X3 descriptors run

@@ -1175,6 +1175,52 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     d4[i] = o;
 }
 
+// The same for MANY partials of a SMALL gradient (round 5: the 64 -> 64 kernel's 256 per-workgroup partials of 64 x 576, the first-layer kernel's 1 024
+// per-wave partials of 64 x 72): one thread per output walked a chain of nsplit dependent-latency loads in 5 .. 36 blocks (64 + 256 us on the step's critical
+// path).  Here 16 lanes share an output: lane group g sums the partials g, g + 16, .. in order, the 16 group sums meet in LDS and are added in group order --
+// a fixed order again, 16 x the loads in flight and 16 x the blocks.  The bias slots likewise.
+__global__ void __launch_bounds__(256) wgrad_reduce_wide_kernel(const float* __restrict__ ws, int nsplit, long long n4, float* __restrict__ dw,
+                                                                const float* __restrict__ bws, int nbslot, int K, float* __restrict__ dbias,
+                                                                int wblocks) {
+    constexpr int G = 16, OPB = 256 / G;
+    __shared__ float4 sm[256];
+    const int tid = threadIdx.x, g = tid / OPB, o = tid % OPB;
+    if ((int)blockIdx.x >= wblocks) {
+        const int k = ((int)blockIdx.x - wblocks) * OPB + o;
+        float t = 0.f;
+        if (k < K)
+            for (int s = g; s < nbslot; s += G) t += bws[(size_t)s * K + k];
+        sm[tid].x = t;
+        __syncthreads();
+        if (g == 0 && k < K) {
+            float r = sm[o].x;
+#pragma unroll
+            for (int q = 1; q < G; ++q) r += sm[q * OPB + o].x;
+            dbias[k] += r;
+        }
+        return;
+    }
+    const long long i = (long long)blockIdx.x * OPB + o;
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4)
+        for (int s = g; s < nsplit; s += G) {
+            const float4 v = w4[(long long)s * n4 + i];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+    sm[tid] = t;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+        float4 r = sm[o];
+#pragma unroll
+        for (int q = 1; q < G; ++q) { const float4 v = sm[q * OPB + o]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        float4* d4 = reinterpret_cast<float4*>(dw);
+        float4 cur = d4[i];
+        cur.x += r.x; cur.y += r.y; cur.z += r.z; cur.w += r.w;
+        d4[i] = cur;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (conv1_2 forward and its dgrad:
 // 300x300 maps, 2.9 M pixels -- HBM-heavy, and a 64-wide tile starves the generic kernels).
@@ -2799,6 +2845,11 @@ static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots, hipStre
 static void wgrad_split_reduce(const WgradArgs& a, hipStream_t st) {
     if (!a.ws) return;
     const long long n4 = (long long)a.K * a.RSC / 4;
+    if (a.nsplit >= 64) {                                  // many partials of a small gradient: 16 lanes per output
+        const int wb = (int)((n4 + 15) / 16), bb = a.bws ? ceil_div(a.K, 16) : 0;
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(wb + bb), dim3(256), 0, st, a.ws, a.nsplit, n4, a.dw, a.bws, a.nbslot, a.K, a.dbias, wb);
+        return;
+    }
     const int wblocks = (int)((n4 + 255) / 256), bblocks = a.bws ? ceil_div(a.K, 256) : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, a.ws, a.nsplit, n4, a.dw, a.bws, a.nbslot, a.K,
                        a.dbias, wblocks);

@@ -232,7 +232,7 @@ class SSD300:
         # full-chip kernels with one workgroup per CU), so it is off by default; config key 'wgrad_stream'.
         on_gpu = self.dev.type == 'cuda'      # (a 'cpu' device only gets past ops._p with the mocked library of tests/mock_ops.py: host-logic tests)
         # config key 'deterministic_wgrad': filter gradients by partial tiles + a fixed-order reduction instead of float atomics
-        # (the whole step bit-identical from run to run, 8 % slower -- 8.44 against 7.78 ms, gpurun r05u; a process-wide switch of the library: include/odtk.h, odtk_debug_set key 5)
+        # (the whole step bit-identical from run to run, 5 % slower -- 8.16 against 7.75 ms, gpurun r05u; a process-wide switch of the library: include/odtk.h, odtk_debug_set key 5)
         if on_gpu and 'deterministic_wgrad' in config:
             ops.debug_set(5, 1 if config['deterministic_wgrad'] else 0)
         self.wgrad_stream = _side_stream(self.dev, 'wgrad') if (on_gpu and config.get('wgrad_stream', False)) else None

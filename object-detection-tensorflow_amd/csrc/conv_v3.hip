@@ -2176,6 +2176,20 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
     // over 64-element slabs (YOLOv3's 13 x 13 / 26 x 26 layers at 8 images, pred2 / pred3 of SSD300): one patch per chunk instead of one gathered slab per tap, four
     // waves of 2 x 4 MFMA tiles -- the halo kernel's 1 000+ TFLOP/s instead of the 8-wave kernel's ~550.  192- or 256-pixel tiles by the same cost model as the
     // unsplit launch; dbg2 bit 8 = off (A/B).
+    // Round 5 (late): the same layers where 128 x 128 tiles give at least ~2/3 of a workgroup per CU -- four waves of 64 x 64, a single-buffered 224-row patch
+    // (128 + 2 (W + 1) <= 224: W <= 47), 76 KiB of LDS, so TWO workgroups share a CU and cover each other's patch loads / epilogues; whole reduction per
+    // workgroup: no f32 partials, no finish launch.  (The round-4 experiment r04t put this shape on the MANY-tile layers of SSD300 and gained nothing in the
+    // step; here it replaces a split launch + its finish.)  dbg2 bit 14 (16384) = off (A/B).
+    if (ksplit >= 2 && v6_ok && halo <= 96 && a.dil == 1 && a.C % 64 == 0 && !(a.dbg2 & 16384)) {
+        const int tq128 = ceil_div(a.M, 128);
+        if (tq128 * a.tiles_p >= (2 * g_num_cu) / 3) {
+            a.tiles_q = tq128;
+            a.ksplit = -1;
+            if (a.W >= 32) hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 1, 2, 2, 2, 2>), dim3(tq128 * a.tiles_p), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 0, 0, 2, 2, 2>), dim3(tq128 * a.tiles_p), dim3(256), 0, st, a);
+            return 0;
+        }
+    }
     if (ksplit >= 2 && v6_ok && halo <= 160 && ceil_div(a.C, 64) >= 2 && !(a.dbg2 & 256)) {
         const int ncs = ceil_div(a.C, 64);
         int best_qt = 0, best_split = 1;

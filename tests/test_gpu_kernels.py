@@ -200,6 +200,27 @@ def test_conv_v9_engine(case, dev, v9_engine):
     assert _ops().conv_last_kernel() != ""
 
 
+# Round 5 (late): 3 x 3 / stride 1 layers that would be split over channel chunks run on 128 x 128 tiles of the halo kernel (two workgroups per CU, whole reduction
+# per workgroup) when those tiles give >= 2/3 of a workgroup per CU and the row is <= 47 pixels; odtk_debug_set(6, 16384) = off
+HALO128_CASES = [
+    (8, 26, 26, 256, 512, 3, 1, 1),     # DarkNet-53 at 8 images: 172 tiles, rows of 26 (the no-early-refill instantiation)
+    (32, 19, 19, 1024, 150, 3, 1, 1),   # SSD300 pred2: 182 tiles, channel tail 150 = 128 + 22, 144 slabs
+    (4, 40, 40, 128, 512, 3, 1, 1),     # rows of 40: the instantiation that refills patch groups 0 / 1 early
+    (5, 33, 47, 192, 320, 3, 1, 1),     # rows of 47 = the largest patch (224 rows), ragged pixel and channel tiles, three chunks
+]
+
+
+@pytest.mark.parametrize("off", [0, 16384], ids=["tiles128", "tiles128-off"])
+@pytest.mark.parametrize("case", HALO128_CASES)
+def test_conv_halo_kernel_on_128x128_tiles(case, off, dev):
+    ops = _ops()
+    ops.debug_set(6, off)
+    try:
+        _conv_case(case, "bf16", dev)
+    finally:
+        ops.debug_set(6, 0)
+
+
 def test_conv_v9_is_taken_where_expected(dev):
     """the dispatch itself: SSD300's small layers at batch 32 and every stride-2 input gradient on whole 64-channel chunks run on the small-map kernel,
     the 13 x 13 / 3 x 3 layer of DarkNet-53 at 8 images on the halo kernel's chunk split, the trunk where it was"""
@@ -222,6 +243,7 @@ def test_conv_v9_is_taken_where_expected(dev):
     assert kernels(32, 19, 256, 512, 3, 2)[1] == "conv_gather_v9_kernel"          # parity phases: the small-map kernel while the 8-wave kernel's tiles would cover less than ~60 % of the CUs (96 here)
     assert kernels(8, 208, 64, 128, 3, 2)[1] == "conv_gather_v3_kernel<64>"       # ... the 8-wave kernel beyond (1 352 tiles of 64 x 256: dx has 64 channels)
     assert kernels(8, 13, 512, 1024, 3, 1) == ("conv_gather_v6_kernel+splitk", "conv_gather_v6_kernel+splitk")
+    assert kernels(8, 26, 256, 512, 3, 1) == ("conv_gather_v6_kernel", "conv_gather_v6_kernel+splitk")      # forward: 172 tiles of 128 x 128, no split; dx has 256 channels: 86
     assert kernels(32, 38, 512, 512, 3, 1) == ("conv_gather_v6_kernel", "conv_gather_v6_kernel")
     torch.cuda.synchronize()
 

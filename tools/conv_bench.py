@@ -39,6 +39,7 @@ LAYERS = {  # name: (N, H, C, K, k, stride, dil)   (C = padded input channels)
     # DarkNet-53 at 8 images (BASELINE config 4's per-GPU share)
     'y13_3': (8, 13, 512, 1024, 3, 1, 1), 'y13_1': (8, 13, 1024, 512, 1, 1, 1), 'y26_3': (8, 26, 256, 512, 3, 1, 1), 'y26_1': (8, 26, 512, 256, 1, 1, 1),
     'y52_3': (8, 52, 128, 256, 3, 1, 1), 'y52_1': (8, 52, 256, 128, 1, 1, 1), 'y26_s2': (8, 26, 512, 1024, 3, 2, 1), 'y52_s2': (8, 52, 256, 512, 3, 2, 1),
+    'f32_3': (16, 32, 256, 256, 3, 1, 1), 'f16_3': (16, 16, 256, 256, 3, 1, 1),      # FCOS 512 x 512 at 16 images: the towers on P4 / P5
     'y104_s2': (8, 104, 128, 256, 3, 2, 1), 'y208_s2': (8, 208, 64, 128, 3, 2, 1), 'y416_s2': (8, 416, 32, 64, 3, 2, 1),
 }
 which = list(LAYERS) if len(sys.argv) < 2 or sys.argv[1] == 'all' else sys.argv[1].split(',')

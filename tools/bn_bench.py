@@ -8,6 +8,11 @@ from odtk import ops
 dev = torch.device('cuda')
 SHAPES = {'conv6/conv7': (32 * 19 * 19, 1024, True), 'conv8_1': (32 * 19 * 19, 256, True), 'conv8_2': (3200, 512, True), 'conv9_1': (3200, 128, True),
           'conv9_2': (800, 256, True), 'conv11_2': (288, 256, True), 'pred1': (32 * 38 * 38, 100, False), 'pred2': (32 * 19 * 19, 150, False)}
+if len(sys.argv) > 1 and sys.argv[1] == 'big':       # the large maps of the other configurations: DarkNet-53 at 416 x 416 x 8 (bf16, leaky ReLU), RetinaNet / CenterNet-like f32
+    SHAPES = {'y416x32': (8 * 416 * 416, 32, True), 'y208x64': (8 * 208 * 208, 64, True), 'y208x32': (8 * 208 * 208, 32, True), 'y104x128': (8 * 104 * 104, 128, True),
+              'y104x64': (8 * 104 * 104, 64, True), 'y52x256': (8 * 52 * 52, 256, True), 'y52x128': (8 * 52 * 52, 128, True), 'y26x512': (8 * 26 * 26, 512, True)}
+if os.environ.get('ODTK_BN_COOP') == '0':
+    ops.debug_set(4, -9)                                 # the three-launch path for mid-size maps (A/B)
 def timeit(f, n=30):
     for _ in range(3):
         f()

@@ -72,7 +72,7 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         (conv_v9.hip), bit 7 (128) = the small-map kernel wherever it is supported (tests), bit 8 (256) = no chunk-range split-K on the raster-run halo kernel,
  *         bit 9 (512) = the small-map kernel always on its four-stage ring, bit 10 (1024) = no halo kernel on C % 64 != 0, bit 12 (4096) = float atomics also for
  *         filter gradients with ONE pixel split, bit 13 (8192) = stride-2 input gradients always on the small-map kernel (never the 8-wave kernel's phase launch),
- *         bit 14 (16384) = no 128 x 128-tile launch of the raster-run halo kernel (the chunk-range split-K instead);
+ *         bit 14 (16384) = no 128 x 128- / 64 x 128-tile launch of the raster-run halo kernel (the chunk-range split-K instead), bit 15 (32768) = no 64 x 128 tiles;
  * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never) */
 int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to

@@ -2189,6 +2189,17 @@ int launch_gather_v3(GatherArgs& a, hipStream_t st) {
             else hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 0, 0, 2, 2, 2>), dim3(tq128 * a.tiles_p), dim3(256), 0, st, a);
             return 0;
         }
+        // ... and 64 (channels) x 128 (pixels) tiles where only those reach that count (DarkNet-53's 26 x 26 input gradients: dx has 256 channels; its 13 x 13
+        // forward): four waves of 64 x 32, the same patch and residency, half the filter slab; dbg2 bit 15 (32768) = off (A/B)
+        const int tp64 = ceil_div(a.K, 64);
+        if (tq128 * tp64 >= (2 * g_num_cu) / 3 && !(a.dbg2 & 32768)) {
+            a.tiles_q = tq128;
+            a.tiles_p = tp64;
+            a.ksplit = -1;
+            if (a.W >= 32) hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 1, 2, 1, 2, 1>), dim3(tq128 * tp64), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 0, 0, 1, 2, 1>), dim3(tq128 * tp64), dim3(256), 0, st, a);
+            return 0;
+        }
     }
     if (ksplit >= 2 && v6_ok && halo <= 160 && ceil_div(a.C, 64) >= 2 && !(a.dbg2 & 256)) {
         const int ncs = ceil_div(a.C, 64);

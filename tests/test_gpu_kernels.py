@@ -207,6 +207,9 @@ HALO128_CASES = [
     (32, 19, 19, 1024, 150, 3, 1, 1),   # SSD300 pred2: 182 tiles, channel tail 150 = 128 + 22, 144 slabs
     (4, 40, 40, 128, 512, 3, 1, 1),     # rows of 40: the instantiation that refills patch groups 0 / 1 early
     (5, 33, 47, 192, 320, 3, 1, 1),     # rows of 47 = the largest patch (224 rows), ragged pixel and channel tiles, three chunks
+    (8, 26, 26, 512, 256, 3, 1, 1),     # 64 x 128 tiles: the forward has 256 output channels (2 x 43 tiles of 128 x 128, 4 x 43 of 64 x 128); its input gradient 128 x 128
+    (8, 13, 13, 512, 1024, 3, 1, 1),    # ... DarkNet-53's 13 x 13 forward (16 x 11 tiles of 64 x 128); the input gradient (8 x 11) stays on the chunk split
+    (6, 40, 33, 128, 200, 3, 1, 1),     # ... rows of 33 (early patch refill), channel tail 200 = 3 x 64 + 8
 ]
 
 
@@ -242,8 +245,8 @@ def test_conv_v9_is_taken_where_expected(dev):
     assert kernels(32, 10, 512, 128, 1, 1) == ("conv_gather_v9_kernel", "conv_gather_v9_kernel")
     assert kernels(32, 19, 256, 512, 3, 2)[1] == "conv_gather_v9_kernel"          # parity phases: the small-map kernel while the 8-wave kernel's tiles would cover less than ~60 % of the CUs (96 here)
     assert kernels(8, 208, 64, 128, 3, 2)[1] == "conv_gather_v3_kernel<64>"       # ... the 8-wave kernel beyond (1 352 tiles of 64 x 256: dx has 64 channels)
-    assert kernels(8, 13, 512, 1024, 3, 1) == ("conv_gather_v6_kernel+splitk", "conv_gather_v6_kernel+splitk")
-    assert kernels(8, 26, 256, 512, 3, 1) == ("conv_gather_v6_kernel", "conv_gather_v6_kernel+splitk")      # forward: 172 tiles of 128 x 128, no split; dx has 256 channels: 86
+    assert kernels(8, 13, 512, 1024, 3, 1) == ("conv_gather_v6_kernel", "conv_gather_v6_kernel+splitk")     # forward: 176 tiles of 64 x 128, no split; dx has 512 channels: 88 -> chunk split
+    assert kernels(8, 26, 256, 512, 3, 1) == ("conv_gather_v6_kernel", "conv_gather_v6_kernel")             # 172 tiles of 128 x 128 forward, of 64 x 128 for dx (256 channels)
     assert kernels(32, 38, 512, 512, 3, 1) == ("conv_gather_v6_kernel", "conv_gather_v6_kernel")
     torch.cuda.synchronize()
 

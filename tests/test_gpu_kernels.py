@@ -210,6 +210,7 @@ HALO128_CASES = [
     (8, 26, 26, 512, 256, 3, 1, 1),     # 64 x 128 tiles: the forward has 256 output channels (2 x 43 tiles of 128 x 128, 4 x 43 of 64 x 128); its input gradient 128 x 128
     (8, 13, 13, 512, 1024, 3, 1, 1),    # ... DarkNet-53's 13 x 13 forward (16 x 11 tiles of 64 x 128); the input gradient (8 x 11) stays on the chunk split
     (6, 40, 33, 128, 200, 3, 1, 1),     # ... rows of 33 (early patch refill), channel tail 200 = 3 x 64 + 8
+    (8, 19, 19, 512, 512, 3, 1, 1),     # ... SSD300's conv5_x at batch 8 (what smoke() runs): 8 x 23 tiles of 64 x 128, 72 slabs
 ]
 
 

@@ -62,6 +62,70 @@ def test_bucketed_allreduce_world2():
     assert res[0][2] >= 3          # several buckets -> overlap opportunities
 
 
+def _hook_worker(rank, world, port, q):
+    """BucketAllReducer's `collective=` hook (what OdtkCollective plugs into on the GPU) in a world of TWO ranks: an object with all_reduce(buf) -> handle
+    stands in for the C-ABI collective (here over gloo), for f32 and bf16 buckets; the sums and the launch order equal the torch.distributed path's."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import odtk  # noqa: F401
+    from odtk.dist import BucketAllReducer
+
+    class Handle:
+        def __init__(self, work, log): self.work, self.log = work, log
+        def wait(self): self.work.wait(); self.log.append('wait')
+
+    class Loopback:                                       # the interface of odtk.dist.OdtkCollective
+        def __init__(self): self.calls, self.log = [], []
+        def all_reduce(self, buf):
+            self.calls.append((buf.data_ptr(), buf.numel(), buf.dtype))
+            return Handle(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), self.log)
+
+    sizes = [64, 1000, 64, 50000, 128, 30000, 64, 7000, 192]
+    segs, off = [], 0
+    for i, n in enumerate(sizes):
+        segs.append((f'l{i}', off, off + n)); off += n
+    ok = True
+    for comm_dtype in ('f32', 'bf16'):
+        outs = []
+        for coll in (None, Loopback()):
+            flat = torch.zeros(off)
+            red = BucketAllReducer(flat, segs, None, bucket_bytes=100_000, comm_dtype=comm_dtype, collective=coll)
+            red.begin_step()
+            for i in reversed(range(len(segs))):
+                name, s, e = segs[i]
+                flat[s:e] = torch.arange(s, e, dtype=torch.float32) * 0.001 * (rank + 1)
+                red.segment_ready(name)
+            red.finish_step()
+            outs.append((flat.clone(), list(red.launch_log)))
+            if coll is not None:
+                ok = ok and len(coll.calls) == len(red.buckets) and coll.log == ['wait'] * len(red.buckets)
+                ok = ok and all(dt == (torch.float32 if comm_dtype == 'f32' else torch.bfloat16) for _, _, dt in coll.calls)
+                ok = ok and [n for _, n, _ in coll.calls] == [e - s for s, e in red.launch_log]
+        ok = ok and torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+        exp = torch.arange(0, off, dtype=torch.float32) * 0.001 * 3
+        ok = ok and torch.allclose(outs[1][0], exp, rtol=2e-2 if comm_dtype == 'bf16' else 1e-6, atol=1e-3 if comm_dtype == 'bf16' else 1e-6)
+    q.put((rank, ok, 0))
+    dist.destroy_process_group()
+
+
+def test_bucket_reducer_collective_hook_world2():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hook_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+
+
 def test_single_process_is_a_noop():
     import odtk  # noqa: F401
     from odtk.dist import BucketAllReducer

@@ -318,6 +318,17 @@ def test_rccl_world1_data_parallel_training_step(dev, grad_dtype, launch):
     assert abs(dp['config']['final_loss'] - one['config']['final_loss']) <= tol * abs(one['config']['final_loss']), (dp['config'], one['config'])
 
 
+def test_rccl_world1_data_parallel_step_is_bit_identical_in_deterministic_mode(dev):
+    """The same pair of bench.py runs (plain | --dp-world1: RCCL process group of one rank, gradient buckets all-reduced by torch.distributed from the
+    filter-gradient stream) with odtk_debug_set(5, 1): since round 5 the whole step is reproducible bit for bit in that mode, so the loss after
+    seven optimizer steps at batch 32 is not "within 3 %" (the test above: float atomics) but EQUAL."""
+    base = ['--gpus', '1', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-conv-events', '--no-extras', '--debug-set', '5:1']
+    dp = _bench_json(base + ['--dp-world1'])
+    one = _bench_json(base)
+    assert dp['comm']['backend'] == 'nccl' and dp['comm']['buckets'] >= 3 and dp['config']['launch'] == 'eager'
+    assert dp['config']['final_loss'] == one['config']['final_loss'], (dp['config']['final_loss'], one['config']['final_loss'])
+
+
 def test_odtk_comm_world1(dev):
     """The C-ABI's own collective (include/odtk.h: odtk_comm_*, RCCL bound by dlopen) in a world of one rank, through ctypes as a non-PyTorch binder
     would call it: id -> init -> all-reduce (in place, out of place, bf16) -> broadcast -> destroy; the sum over one rank is the identity, bit for bit."""

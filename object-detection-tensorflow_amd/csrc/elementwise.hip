@@ -380,6 +380,32 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_idx_kernel(const unsigned 
 // Deterministic: partials to ws[slot][split][C], reduced in a fixed order by the consumer.
 constexpr int RED_ROWS = 32;
 
+// Narrow bf16 maps (8, 16 or 32 channels: one 16-byte chunk lane out of 8, 4 or 2 would have work -- DLA-34's and DarkNet-53's first layers, the LARGEST maps
+// of their steps): the block is 256 / CPR row lanes x CPR chunk lanes instead of 32 x 8, so every lane streams (round 5, late).  bn_lane_cpr() = chunk lanes
+// per row for this launch; rl = tid / cpr, cl = tid % cpr, row stride 256 / cpr.  With cpr = 8 everything below is what it was, bit for bit.
+template <typename T>
+__device__ __forceinline__ int bn_lane_cpr(int C, int ld) {
+    return (sizeof(T) == 2 && gridDim.x == 1 && ld == C && (C == 8 || C == 16 || C == 32)) ? C / 8 : 8;
+}
+// tree over the row lanes of a [256 / cpr][cpr][NV] block; the sums of chunk lane cl end up in every thread with that cl (same order as the 32 x 8 form for cpr = 8)
+template <int NV>
+__device__ __forceinline__ void block_rowlane_reduce_cpr(float (&v)[NV], float* sm /*[256][NV]*/, int cl, int cpr) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) sm[tid * NV + e] = v[e];
+    __syncthreads();
+    for (int s = 128; s >= cpr; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) sm[tid * NV + e] += sm[(tid + s) * NV + e];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = sm[cl * NV + e];
+    __syncthreads();
+}
+
 template <int NV>
 __device__ __forceinline__ void block_rowlane_reduce(float (&v)[NV], float* sm /*[32][8][NV]*/, int rl, int cl) {
     // sm layout [rl][cl][NV]
@@ -404,7 +430,8 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ z, 
                                                        int rows_per_split, float* __restrict__ ws) {
     constexpr int KC = Chunk<T>::N;
     __shared__ float sm[RED_ROWS * 8 * 2 * KC];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int cpr = bn_lane_cpr<T>(C, ldz), rstride = 256 / cpr;
+    const int cl = threadIdx.x & (cpr - 1), rl = threadIdx.x / cpr;
     const int c0 = (blockIdx.x * 8 + cl) * KC;
     const int split = blockIdx.y, nsplit = gridDim.y;
     float acc[2 * KC];
@@ -416,7 +443,7 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ z, 
         const int m0 = split * rows_per_split;
         int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
 #pragma unroll 4
-        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+        for (int m = m0 + rl; m < m1; m += rstride) {
             float f[KC];
             Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
 #pragma unroll
@@ -427,7 +454,7 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ z, 
             }
         }
     }
-    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    block_rowlane_reduce_cpr<2 * KC>(acc, sm, cl, cpr);
     if (rl == 0 && c0 < C) {
 #pragma unroll
         for (int e = 0; e < KC; ++e) {
@@ -525,7 +552,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     const T* __restrict__ z, int M, int C, int ldz, int relu, TY* __restrict__ y, int ldy, int rows_per_img,
     long long y_img_stride, int vec_ok, const float* __restrict__ fin, int rows_per_block) {
     constexpr int KC = Chunk<T>::N;
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int cpr = bn_lane_cpr<T>(C, ldz), rstride = 256 / cpr;
+    const int cl = threadIdx.x & (cpr - 1), rl = threadIdx.x / cpr;
     const int c0 = (blockIdx.x * 8 + cl) * KC;
     if (c0 >= C) return;
     float sc[KC], of[KC];
@@ -538,7 +566,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
     const bool full = c0 + KC <= C;
 #pragma unroll 2
-    for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+    for (int m = m0 + rl; m < m1; m += rstride) {
         float f[KC];
         Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
 #pragma unroll
@@ -698,7 +726,8 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
     const float* __restrict__ save_invstd, int relu, int vec_ok, int rows_per_split, float* __restrict__ ws) {
     constexpr int KC = Chunk<T>::N;
     __shared__ float sm[RED_ROWS * 8 * 2 * KC];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int cpr = bn_lane_cpr<T>(C, ldz), rstride = 256 / cpr;
+    const int cl = threadIdx.x & (cpr - 1), rl = threadIdx.x / cpr;
     const int c0 = (blockIdx.x * 8 + cl) * KC;
     const int split = blockIdx.y, nsplit = gridDim.y;
     float acc[2 * KC];
@@ -714,7 +743,7 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
         const int m0 = split * rows_per_split;
         int m1 = m0 + rows_per_split; if (m1 > M) m1 = M;
 #pragma unroll 2
-        for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+        for (int m = m0 + rl; m < m1; m += rstride) {
             float f[KC];
             Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
             const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
@@ -728,7 +757,7 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(
             }
         }
     }
-    block_rowlane_reduce<2 * KC>(acc, sm, rl, cl);
+    block_rowlane_reduce_cpr<2 * KC>(acc, sm, cl, cpr);
     if (rl == 0 && c0 < C) {
 #pragma unroll
         for (int e = 0; e < KC; ++e) {
@@ -761,7 +790,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, int vec_ok, T* __restrict__ dz,
     const float* __restrict__ fin, int rows_per_block) {
     constexpr int KC = Chunk<T>::N;
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int cpr = bn_lane_cpr<T>(C, ldz), rstride = 256 / cpr;
+    const int cl = threadIdx.x & (cpr - 1), rl = threadIdx.x / cpr;
     const int c0 = (blockIdx.x * 8 + cl) * KC;
     if (c0 >= ldz) return;
     float mu[KC], iv[KC], gs[KC], k1[KC], k2[KC];
@@ -779,7 +809,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const int m0 = blockIdx.y * rows_per_block;
     int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
 #pragma unroll 2
-    for (int m = m0 + rl; m < m1; m += RED_ROWS) {
+    for (int m = m0 + rl; m < m1; m += rstride) {
         float f[KC], o[KC];
         Chunk<T>::unpack(ld16(z + (size_t)m * ldz + c0), f);
         const long long oo = out_off(m, rows_per_img, y_img_stride, ldy) + c0;
@@ -1311,6 +1341,11 @@ inline int grid_for(long long total, int threads, int cap = 8192) {
     return (int)b;
 }
 
+// rows of partials the batch-norm workspace holds per sum: 256 at >= 256 channels, more below (the same 2 x 256 x 256 floats)
+inline int bn_ws_rows(int C) {
+    const int cpad = (C + 63) / 64 * 64;
+    return cpad < 256 ? 256 * (256 / cpad) : 256;
+}
 struct RedPlan { int colgroups, nsplit, rows_per_split; };
 inline RedPlan red_plan(int M, int C, int kc) {
     RedPlan p;
@@ -1320,9 +1355,10 @@ inline RedPlan red_plan(int M, int C, int kc) {
     int maxs = ceil_div(M, 4 * RED_ROWS);
     if (maxs < 1) maxs = 1;
     if (want > maxs) want = maxs;
-    // the partials live in the workspace: 2 x 256 x ceil64(C) floats (odtk_bn_workspace_bytes) = 256 splits at full width, more for narrow
-    // layers (32 channels: 512) -- Darknet's first layers are 7.4 M rows x 32 channels, 256 splits left every workgroup 900 dependent iterations
-    int cap = 256 * (((C + 63) / 64) * 64) / C;
+    // the partials live in the workspace: 2 x bn_ws_rows(C) x ceil64(C) floats (odtk_bn_workspace_bytes) = 256 splits from 256 channels on, up to 1 024 for
+    // narrow layers (round 5: with ONE column group 256 splits are one workgroup per CU -- too few loads in flight to stream; Darknet's and DLA's first layers
+    // are 1.4 - 4.2 M rows x 16 - 64 channels)
+    int cap = bn_ws_rows(C) * (((C + 63) / 64) * 64) / C;
     if (cap > 1024) cap = 1024;
     if (want > cap) want = cap;
     p.rows_per_split = ceil_div(M, want);
@@ -1472,7 +1508,7 @@ extern "C" int odtk_maxpool2x2_bwd_idx(const void* idx, const void* dy, void* dx
 
 extern "C" long long odtk_bn_workspace_bytes(int M, int C) {
     (void)M;
-    return (long long)(2 * 256 + 2) * (long long)((C + 63) / 64 * 64) * sizeof(float);
+    return (long long)(2 * bn_ws_rows(C) + 2) * (long long)((C + 63) / 64 * 64) * sizeof(float);
 }
 
 extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, const float* gamma,
@@ -1508,7 +1544,7 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
         return ODTK_OK;
     }
     float* ws = (float*)workspace;
-    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    float* fin = ws + (size_t)2 * bn_ws_rows(C) * ((C + 63) / 64 * 64);
     if (training) {
         // Two launches (statistics; apply with the finalize folded into its prologue) where <= 32 row splits still fill the chip for the statistics pass
         // (>= 128 workgroups: the 256-1 024-channel layers of DarkNet-53 at 8 images: the finalize launch alone was 8-10 us of latency, x 150 per step)
@@ -1571,7 +1607,7 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
     const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
-    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    float* fin = ws + (size_t)2 * bn_ws_rows(C) * ((C + 63) / 64 * 64);
     dim3 g1(pl.colgroups, pl.nsplit);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
     const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;
@@ -1835,7 +1871,7 @@ extern "C" int odtk_bn_fwd_given(const void* z, int M, int C, int ldz, int dtype
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
     float* ws = (float*)workspace;
-    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    float* fin = ws + (size_t)2 * bn_ws_rows(C) * ((C + 63) / 64 * 64);
     hipLaunchKernelGGL(bn_combine_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, moments, replicas, C, (long long)M, gamma, beta, moving_mean,
                        moving_var, save_mean, save_invstd, fin);
     const size_t ysz = dtype_size(y_dtype);
@@ -1866,7 +1902,7 @@ extern "C" int odtk_bn_bwd_sums(const void* z, const void* y, const void* dy, in
     hipStream_t st = (hipStream_t)stream;
     const RedPlan pl = red_plan(M, C, kc);
     float* ws = (float*)workspace;
-    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    float* fin = ws + (size_t)2 * bn_ws_rows(C) * ((C + 63) / 64 * 64);
     dim3 g1(pl.colgroups, pl.nsplit);
     const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 && ((uintptr_t)dy) % 16 == 0 &&
@@ -1899,7 +1935,7 @@ extern "C" int odtk_bn_bwd_given(const void* z, const void* y, const void* dy, i
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
     const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
-    float* fin = ws + (size_t)2 * 256 * ((C + 63) / 64 * 64);
+    float* fin = ws + (size_t)2 * bn_ws_rows(C) * ((C + 63) / 64 * 64);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
     const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 && ((uintptr_t)dy) % 16 == 0 &&

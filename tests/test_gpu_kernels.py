@@ -448,7 +448,9 @@ def test_maxpool2x2_recorded_argmax_equals_gather_path(geom, dt, dev):
 @pytest.mark.parametrize("dt,ydt", [("f32", "f32"), ("bf16", "bf16"), ("bf16", "f32")])
 @pytest.mark.parametrize("shape", [(2 * 19 * 19, 1024, True), (2 * 38 * 38, 100, False), (3 * 5 * 5, 150, False),
                                    (2 * 3 * 3, 256, True),
-                                   (6 * 38 * 38, 100, False), (14 * 19 * 19, 256, True)])   # M > 4096: split-row path
+                                   (6 * 38 * 38, 100, False), (14 * 19 * 19, 256, True),    # M > 4096: split-row path
+                                   # round 5: narrow bf16 maps (8 / 16 / 32 channels) pack 256 / 128 / 64 row lanes per block; many row splits of one column group
+                                   (3 * 61 * 47, 16, True), (2 * 40 * 52, 32, True), (5000, 8, False), (70001, 64, True)])
 @pytest.mark.parametrize("launches", [1, 10, 2, 3, 0], ids=["one-launch", "one-launch-64ch", "two-launches", "three-launches", "auto"])
 def test_batchnorm(shape, dt, ydt, launches, dev):
     """Maps of <= 1024 rows take the single-launch kernels (statistics + finalize + apply: one workgroup per 16-byte channel chunk with 512 row lanes, or

@@ -204,12 +204,13 @@ def _run(module, name, **kw):
 
 
 _BN_SHAPES = {'a': ((2 * 19 * 19, 1024, True), 'f32', 'f32'), 'b': ((3 * 5 * 5, 150, False), 'bf16', 'bf16'), 'c': ((6 * 38 * 38, 100, False), 'bf16', 'f32'),
-              'd': ((14 * 19 * 19, 256, True), 'bf16', 'bf16')}
+              'd': ((14 * 19 * 19, 256, True), 'bf16', 'bf16'), 'e': ((3 * 61 * 47, 16, True), 'bf16', 'bf16'), 'f': ((2 * 40 * 52, 32, True), 'bf16', 'f32'),
+              'g': ((5000, 8, False), 'bf16', 'bf16')}
 _BN_MODES = {'one-launch': 1, 'one-launch-64ch': 10, 'two-launches': 2, 'three-launches': 3, 'auto': 0}
 
 
 @pytest.mark.parametrize('case', ['a-one-launch', 'b-one-launch', 'a-one-launch-64ch', 'a-two-launches', 'c-two-launches', 'a-three-launches', 'c-three-launches', 'd-three-launches',
-                                  'a-auto', 'd-auto'])
+                                  'a-auto', 'd-auto', 'e-three-launches', 'f-three-launches', 'g-three-launches', 'e-auto'])
 def test_batchnorm_from_source(case):
     shape, mode = case.split('-', 1)
     sh, dt, ydt = _BN_SHAPES[shape]

@@ -11,6 +11,9 @@ SHAPES = {'conv6/conv7': (32 * 19 * 19, 1024, True), 'conv8_1': (32 * 19 * 19, 2
 if len(sys.argv) > 1 and sys.argv[1] == 'big':       # the large maps of the other configurations: DarkNet-53 at 416 x 416 x 8 (bf16, leaky ReLU), RetinaNet / CenterNet-like f32
     SHAPES = {'y416x32': (8 * 416 * 416, 32, True), 'y208x64': (8 * 208 * 208, 64, True), 'y208x32': (8 * 208 * 208, 32, True), 'y104x128': (8 * 104 * 104, 128, True),
               'y104x64': (8 * 104 * 104, 64, True), 'y52x256': (8 * 52 * 52, 256, True), 'y52x128': (8 * 52 * 52, 128, True), 'y26x512': (8 * 26 * 26, 512, True)}
+if len(sys.argv) > 1 and sys.argv[1] == 'narrow':    # DLA-34 (CenterNet 512 x 512 at 16 images) and DarkNet-53's first layers: the largest maps, few channels
+    SHAPES = {'c512x16': (16 * 512 * 512, 16, True), 'c256x32': (16 * 256 * 256, 32, True), 'c128x64': (16 * 128 * 128, 64, True), 'c128x128': (16 * 128 * 128, 128, True),
+              'c64x256': (16 * 64 * 64, 256, True), 'y416x32': (8 * 416 * 416, 32, True), 'y208x64': (8 * 208 * 208, 64, True), 'y52x256': (8 * 52 * 52, 256, True)}
 def timeit(f, n=30):
     for _ in range(3):
         f()

@@ -62,6 +62,7 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  * key 4 = batch norm: maps of up to `value` rows run statistics + finalize + apply in ONE launch (default 1024, 0 = never); larger maps take three
  *         (statistics, finalize, apply); value -2 = two (apply with the finalize folded in: measured slower, A/B only), -1 = back to three;
  *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back;
+ *         -20 / -21 / -22 / -23 rows per workgroup of the apply passes 128 / 512 / 1 024 / by shape (the default: 256, 1 024 for 8- / 16-channel bf16 maps);
  * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
  *         run, 5 % slower on the SSD300 step: 8.16 against 7.75 ms, r05u) instead of float atomics into dw (the default); round 5: the 64 -> 64 and first-layer
  *         kernels (one partial per workgroup / wave) and the scalar gamma gradient of odtk_l2norm_bwd follow the switch too, so a

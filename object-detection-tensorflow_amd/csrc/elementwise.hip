@@ -1386,8 +1386,15 @@ static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0). 
                                           // take the single launch, was measured SLOWER there: 11.24 vs 11.13 ms/step, gpurun r03o)
 static bool g_bn_auto_two = true;         // odtk_debug_set key 4, value -5: never pick the two-launch path by itself (round-2 behaviour; A/B); -6: back
 static bool g_bn_small_wide = false;      // odtk_debug_set key 4, value -3: the single-launch kernels in their 64-channel shape only (A/B); -4: back
+static int g_bn_rpb = 0;                  // rows per workgroup of the apply passes; odtk_debug_set key 4, values -20 .. -23: 128 / 512 / 1 024 / by shape (A/B)
+// 256 rows per workgroup of an apply pass; 1 024 for the 8- / 16-channel bf16 maps, whose blocks are 256 / 128 row lanes (one or two rows per lane and
+// workgroup otherwise: DLA-34's 512 x 512 x 16 backward 238 -> 199 us, forward 86 -> 81; every other shape is flat from 128 to 1 024, gpurun r05n)
+static inline int bn_rpb(int C, int ldz, int dtype) {
+    if (g_bn_rpb) return g_bn_rpb;
+    return (dtype == ODTK_BF16 && ldz == C && (C == 8 || C == 16)) ? 1024 : 256;
+}
 static bool g_bn_three_kernels = true;    // odtk_debug_set key 4, value -2: statistics + apply-with-finalize (two launches; A/B, tests); -1: back to three
-namespace odtk { void set_bn_small_rows(int rows) { if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else if (rows == -5) g_bn_auto_two = false; else if (rows == -6) g_bn_auto_two = true; else g_bn_small_rows = rows; } }
+namespace odtk { void set_bn_small_rows(int rows) { if (rows <= -20 && rows >= -23) g_bn_rpb = rows == -20 ? 128 : rows == -21 ? 512 : rows == -22 ? 1024 : 0; else if (rows == -1) g_bn_three_kernels = true; else if (rows == -2) g_bn_three_kernels = false; else if (rows == -3) g_bn_small_wide = true; else if (rows == -4) g_bn_small_wide = false; else if (rows == -5) g_bn_auto_two = false; else if (rows == -6) g_bn_auto_two = true; else g_bn_small_rows = rows; } }
 
 #define DT_SWITCH(dtype, T, ...)                                         \
     if ((dtype) == ODTK_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
@@ -1556,7 +1563,7 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
         DT_SWITCH(dtype, T, hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.colgroups, pl.nsplit), dim3(256), 0, st,
                                                (const T*)z, M, C, ldz, pl.rows_per_split, ws);)
         if (two) {                                       // statistics, then apply with the finalize folded in
-            const int rpb = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
+            const int rpb = pl.rows_per_split < bn_rpb(C, ldz, dtype) ? pl.rows_per_split : bn_rpb(C, ldz, dtype);
             dim3 gridf(pl.colgroups, ceil_div(M, rpb));
 #define BN_APPLY_FIN(T, TY)                                                                                                  \
     hipLaunchKernelGGL((bn_apply_fin_kernel<T, TY>), gridf, dim3(256), 0, st, (const T*)z, M, C, ldz, relu, (TY*)y, ldy,     \
@@ -1576,7 +1583,7 @@ extern "C" int odtk_bn_fwd(const void* z, int M, int C, int ldz, int dtype, cons
                                            pl.nsplit, fin);)
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
-    const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
+    const int rows_per_block = pl.rows_per_split < bn_rpb(C, ldz, dtype) ? pl.rows_per_split : bn_rpb(C, ldz, dtype);
     dim3 grid(pl.colgroups, ceil_div(M, rows_per_block));
 #define BN_APPLY(T, TY)                                                                                        \
     hipLaunchKernelGGL((bn_apply_kernel<T, TY>), grid, dim3(256), 0, st, (const T*)z, M, C, ldz, relu, (TY*)y, \
@@ -1606,7 +1613,7 @@ extern "C" int odtk_bn_bwd(const void* z, const void* y, const void* dy, int M, 
     float* ws = (float*)workspace;
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
-    const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
+    const int rows_per_block = pl.rows_per_split < bn_rpb(C, ldz, dtype) ? pl.rows_per_split : bn_rpb(C, ldz, dtype);
     float* fin = ws + (size_t)2 * bn_ws_rows(C) * ((C + 63) / 64 * 64);
     dim3 g1(pl.colgroups, pl.nsplit);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
@@ -1878,7 +1885,7 @@ extern "C" int odtk_bn_fwd_given(const void* z, int M, int C, int ldz, int dtype
     const int vec_ok = ((size_t)ldy * ysz) % 16 == 0 && ((size_t)y_img_stride * ysz) % 16 == 0 && ((uintptr_t)y % 16) == 0;
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
-    const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
+    const int rows_per_block = pl.rows_per_split < bn_rpb(C, ldz, dtype) ? pl.rows_per_split : bn_rpb(C, ldz, dtype);
     dim3 grid(pl.colgroups, ceil_div(M, rows_per_block));
 #define BN_APPLY(T, TY)                                                                                        \
     hipLaunchKernelGGL((bn_apply_kernel<T, TY>), grid, dim3(256), 0, st, (const T*)z, M, C, ldz, relu, (TY*)y, \
@@ -1934,7 +1941,7 @@ extern "C" int odtk_bn_bwd_given(const void* z, const void* y, const void* dy, i
     float* ws = (float*)workspace;
     // the apply pass is elementwise: many short workgroups keep more loads in flight than one long one per CU (the statistics
     // pass keeps <= 256 row splits because its partials live in the workspace)
-    const int rows_per_block = pl.rows_per_split < 256 ? pl.rows_per_split : 256;
+    const int rows_per_block = pl.rows_per_split < bn_rpb(C, ldz, dtype) ? pl.rows_per_split : bn_rpb(C, ldz, dtype);
     float* fin = ws + (size_t)2 * bn_ws_rows(C) * ((C + 63) / 64 * 64);
     dim3 g2(ceil_div(ldz, 8 * kc), ceil_div(M, rows_per_block));
     const size_t ysz = y_dtype == ODTK_BF16 ? 2 : 4;

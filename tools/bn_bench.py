@@ -14,6 +14,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'big':       # the large maps of the oth
 if len(sys.argv) > 1 and sys.argv[1] == 'narrow':    # DLA-34 (CenterNet 512 x 512 at 16 images) and DarkNet-53's first layers: the largest maps, few channels
     SHAPES = {'c512x16': (16 * 512 * 512, 16, True), 'c256x32': (16 * 256 * 256, 32, True), 'c128x64': (16 * 128 * 128, 64, True), 'c128x128': (16 * 128 * 128, 128, True),
               'c64x256': (16 * 64 * 64, 256, True), 'y416x32': (8 * 416 * 416, 32, True), 'y208x64': (8 * 208 * 208, 64, True), 'y52x256': (8 * 52 * 52, 256, True)}
+if os.environ.get('ODTK_BN_RPB'):
+    ops.debug_set(4, int(os.environ['ODTK_BN_RPB']))      # -20 .. -23: 128 / 512 / 1 024 / 256 rows per workgroup of the apply passes (A/B)
 def timeit(f, n=30):
     for _ in range(3):
         f()

@@ -252,3 +252,20 @@ def test_comm_entry_points_check_their_arguments_before_touching_rccl():
     from odtk.dist import COMM_ID_BYTES
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'odtk.h')).read()
     assert f'#define ODTK_COMM_ID_BYTES {COMM_ID_BYTES}' in hdr
+
+
+def test_bn_workspace_holds_the_partials_of_every_plan():
+    """odtk_bn_workspace_bytes (host logic): two sums x the row splits a launch may use x the padded channels, + the finalized scale / offset rows.  From 256
+    channels on that is 256 splits; narrow layers get the same 2 x 256 x 256 floats, i.e. up to 1 024 splits for one column group (round 5)."""
+    import odtk  # noqa: F401
+    from odtk import _lib
+    lib = _lib.load()
+    for C in (3, 8, 16, 32, 64, 100, 128, 150, 255, 256, 257, 512, 1000, 1024, 2048):
+        cpad = (C + 63) // 64 * 64
+        b = lib.odtk_bn_workspace_bytes(1 << 20, C)
+        assert b == lib.odtk_bn_workspace_bytes(7, C)                     # independent of the row count
+        assert b >= (2 * 256 + 2) * cpad * 4                             # what every release of the library has needed
+        rows = min(1024, 256 * max(1, 256 // cpad) * cpad // C)          # row splits the statistics kernels may use for this width
+        assert b >= (2 * rows * C + 2 * cpad) * 4, (C, b, rows)
+        if cpad < 256:
+            assert b >= 2 * 256 * 256 * 4

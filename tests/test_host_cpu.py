@@ -267,5 +267,5 @@ def test_bn_workspace_holds_the_partials_of_every_plan():
         assert b >= (2 * 256 + 2) * cpad * 4                             # what every release of the library has needed
         rows = min(1024, 256 * max(1, 256 // cpad) * cpad // C)          # row splits the statistics kernels may use for this width
         assert b >= (2 * rows * C + 2 * cpad) * 4, (C, b, rows)
-        if cpad < 256:
+        if cpad in (64, 128):                                             # (192 = 3 x 64 does not divide 256: it keeps 256 rows)
             assert b >= 2 * 256 * 256 * 4

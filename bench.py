@@ -181,13 +181,17 @@ class ConvTimer:
 
 
 class ClockSampler:
-    """Shader clock of the visible GPU over the timed region: the amdgpu hwmon file `freq1_input` of the card whose PCI address is HIP device
-    `index`, read every 10 ms by a daemon thread (one small file read per sample).  `summary()` is None where the box has no such sysfs file."""
+    """Shader clock, board power and temperatures of the visible GPU over the timed region: the amdgpu hwmon files `freq1_input`, `power1_average` (or
+    `power1_input`) and `temp{1,2,3}_input` (edge / junction / memory) of the card whose PCI address is HIP device `index`, read every 10 ms by a daemon
+    thread (a few small file reads per sample).  `summary()` is None where the box has no such sysfs files; `board()` likewise (round-5 review, item 6: a 1 %
+    move of the headline is unreadable without the power / thermal state next to the clock)."""
 
     def __init__(self, index):
         import glob
         self.path = None
+        self.extra = {}                  # name -> (path, scale)
         self.samples = []
+        self.extra_samples = {}
         self._stop = False
         self._thread = None
         try:
@@ -200,16 +204,32 @@ class ClockSampler:
                     f = os.path.join(h, 'freq1_input')
                     if os.path.exists(f):
                         self.path = f
+                    for name, files, scale in (('power_w', ('power1_average', 'power1_input'), 1e-6), ('temp_edge_c', ('temp1_input',), 1e-3),
+                                               ('temp_junction_c', ('temp2_input',), 1e-3), ('temp_mem_c', ('temp3_input',), 1e-3)):
+                        for fn in files:
+                            q = os.path.join(h, fn)
+                            if name not in self.extra and os.path.exists(q):
+                                self.extra[name] = (q, scale)
         except Exception:                                        # noqa: BLE001
             self.path = None
+        self.extra_samples = {k: [] for k in self.extra}
 
     def _run(self):
+        i = 0
         while not self._stop:
             try:
                 with open(self.path) as f:
                     self.samples.append(int(f.read().strip()) / 1e6)
             except Exception:                                    # noqa: BLE001
                 pass
+            if i % 5 == 0:                                       # power / temperature every 50 ms (they are averaged by the SMU anyway)
+                for k, (q, scale) in self.extra.items():
+                    try:
+                        with open(q) as f:
+                            self.extra_samples[k].append(int(f.read().strip()) * scale)
+                    except Exception:                            # noqa: BLE001
+                        pass
+            i += 1
             time.sleep(0.01)
 
     def start(self):
@@ -229,6 +249,17 @@ class ClockSampler:
         v = sorted(self.samples)
         return {'median': round(v[len(v) // 2], 0), 'min': round(v[0], 0), 'max': round(v[-1], 0), 'samples': len(v),
                 'source': 'amdgpu hwmon freq1_input of the visible device, 10 ms period, over the timed region'}
+
+    def board(self):
+        out = {}
+        for k, v in self.extra_samples.items():
+            if v:
+                w = sorted(v)
+                out[k] = {'median': round(w[len(w) // 2], 1), 'max': round(w[-1], 1), 'samples': len(w)}
+        if not out:
+            return None
+        out['source'] = 'amdgpu hwmon power1_average / temp{1,2,3}_input of the visible device, 50 ms period, over the same region as sclk_mhz'
+        return out
 
 
 def main():
@@ -416,6 +447,7 @@ def main():
                                               'without the first eager step; *_trimmed additionally drops the slowest sample of every launch)')
             out['roofline']['single_stream_ms_per_step'] = round(single_stream_ms, 3)   # incl. the event records: an upper bound of conv_ms_per_step
         out['sclk_mhz'] = clock.summary()
+        out['board'] = clock.board()
         if comm is not None:
             out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
@@ -433,7 +465,11 @@ def main():
                 out['inference'] = inference_bench(dev, with_cpu=not args.no_cpu_baseline)
             except Exception as e:                                       # noqa: BLE001
                 out['inference'] = {'error': f'{type(e).__name__}: {e}'}
-            out['configs'] = configs_bench(budget_s=170.0 - (time.perf_counter() - t_extras))
+            try:
+                out['epoch'] = epoch_bench(model, lr, B)
+            except Exception as e:                                       # noqa: BLE001
+                out['epoch'] = {'error': f'{type(e).__name__}: {e}'}
+            out['configs'] = configs_bench(budget_s=300.0 - (time.perf_counter() - t_extras))
             out['extras_s'] = round(time.perf_counter() - t_extras, 1)
         print(json.dumps(out), flush=True)
     if use_pg:
@@ -454,10 +490,13 @@ def sustained_run(model, lr, B, local_rank, min_steps=250):
     dt = time.perf_counter() - t0
     clock.stop()
     return {'steps': min_steps, 'seconds': round(dt, 3), 'ms_per_step': round(dt / min_steps * 1e3, 3), 'images_per_sec': round(B * min_steps / dt, 1),
-            'sclk_mhz': clock.summary()}
+            'sclk_mhz': clock.summary(), 'board': clock.board()}
 
 
-def _rocprof_pass(counters, tag, timeout_s=150):
+PMC_CHILD_STEPS, PMC_CHILD_WARMUP = 2, 3
+
+
+def _rocprof_pass(counters, tag, timeout_s=150, child_args=()):
     """one `rocprofv3 --pmc` pass (counters only: no trace domains) over a 2-step child run of this script; -> {kernel short name: {counter: mean per dispatch, '_n': dispatches}}"""
     import csv
     import glob
@@ -469,8 +508,8 @@ def _rocprof_pass(counters, tag, timeout_s=150):
     if exe is None:
         return None, 'rocprofv3 not on PATH'
     d = tempfile.mkdtemp(prefix=f'odtk_pmc_{tag}_', dir='/tmp')
-    cmd = [exe, '--pmc'] + counters + ['-f', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '3', '--no-cpu-baseline',
-                                       '--no-conv-events', '--eager', '--no-extras']
+    cmd = [exe, '--pmc'] + counters + ['-f', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__), '--steps', str(PMC_CHILD_STEPS), '--warmup', str(PMC_CHILD_WARMUP),
+                                       '--no-cpu-baseline', '--no-conv-events', '--eager', '--no-extras'] + list(child_args)
     try:
         r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
         if r.returncode != 0:
@@ -508,6 +547,71 @@ def live_pmc_traffic(rf):
                                   f'template variant of {base}; FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024)'},
             'mfma_busy_pct': None if not a[base].get('SQ_VALU_MFMA_BUSY_CYCLES') else round(100.0 * a[base]['SQ_VALU_MFMA_BUSY_CYCLES'] / (t * 2.4e9 * 1024), 1),
             'hbm_gbps': round((rd + wr) / t / 1e9, 1), 'hbm_frac_of_8TBps': round((rd + wr) / t / 8e12, 4)}
+
+
+def live_pmc_step(name, ms_per_step, budget_s):
+    """Whole-step counters of a BASELINE configuration, measured NOW (round-5 review, item 6): two `rocprofv3 --pmc` child passes of `bench.py --config <name>` at
+    2 + 3 steps; every dispatch of an odtk kernel is summed and divided by the steps the child ran (the one-off launches of the model's construction -- filter
+    re-layout, casts -- are in the sum: < 1 %).  -> hbm_bytes_per_step (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, as MI355X_MICROARCH.md prescribes), the HBM
+    rate that is of the step time, and mfma_busy_pct = sum of SQ_VALU_MFMA_BUSY_CYCLES / (step time x 2.4 GHz x 1024 SIMDs)."""
+    t0 = time.perf_counter()
+    steps = PMC_CHILD_STEPS + max(PMC_CHILD_WARMUP, 2)
+    a, ea = _rocprof_pass(['FETCH_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'], name + '_a', timeout_s=max(20, min(90, budget_s)), child_args=['--config', name])
+    if a is None:
+        return {'pmc_note': 'no live PMC pass: ' + str(ea)}
+    left = budget_s - (time.perf_counter() - t0)
+    b, eb = (None, 'time budget of the default run spent') if left < 20 else _rocprof_pass(['WRITE_SIZE'], name + '_b', timeout_s=min(90, left), child_args=['--config', name])
+
+    def total(res, counter):
+        return sum(v.get(counter, 0.0) * v['_n'] for k, v in res.items() if not k.startswith(('vectorized_', 'elementwise_', '__amd', 'reduce_')))
+    rd = 2.0 * total(a, 'FETCH_SIZE') * 1024.0 / steps
+    busy = total(a, 'SQ_VALU_MFMA_BUSY_CYCLES') / steps
+    out = {'hbm_read_bytes_per_step': int(rd), 'mfma_busy_pct': round(100.0 * busy / (ms_per_step * 1e-3 * 2.4e9 * 1024), 1),
+           'pmc_source': f'THIS RUN: rocprofv3 --pmc child passes of `bench.py --config {name} --steps {PMC_CHILD_STEPS} --warmup {PMC_CHILD_WARMUP} --eager`; sums over every '
+                         'odtk kernel dispatch / steps run; mfma_busy_pct is relative to the un-profiled step time at 2.4 GHz x 1024 SIMDs'}
+    if b is not None:
+        wr = total(b, 'WRITE_SIZE') * 1024.0 / steps
+        out.update({'hbm_write_bytes_per_step': int(wr), 'hbm_bytes_per_step': int(rd + wr), 'hbm_gbps_of_step': round((rd + wr) / (ms_per_step * 1e-3) / 1e9, 1),
+                    'hbm_frac_of_8TBps': round((rd + wr) / (ms_per_step * 1e-3) / 8e12, 4)})
+    else:
+        out['pmc_note'] = 'WRITE_SIZE pass: ' + str(eb)
+    return out
+
+
+def epoch_bench(model, lr, B, steps=30):
+    """What a user of the drop-in calls (round-5 review, item 6): `SSD300.train_one_epoch(lr)` (SSD300.py:473-484) through the PUBLIC method -- a host iterator
+    yields (images f32 [B,300,300,3], ground truth) per step, set_batch copies them to the device, one train_step, one `.item()` of the loss per step -- on the
+    benchmarked model, `steps` steps per variant: numpy arrays in pageable memory (what a tf.data replacement hands over) and torch tensors in pinned memory.
+    `h2d_ms` is the copy of one batch alone (34.6 MB of f32 pixels + the ground truth), `h2d_share` its part of the epoch's step time.  The contract's headline
+    (`value`) keeps the batch resident; this is the PCIe-inclusive rate next to it."""
+    import numpy as np
+    g = torch.Generator().manual_seed(77)
+    imgs = torch.rand(B, 300, 300, 3, generator=g) * 255.
+    _, gt = synthetic_batch(B, 1077, torch.device('cpu'))
+    saved = (model.train_iterator, model.num_train, model.train_initializer, model.verbose)
+    res = {'what': f'SSD300.train_one_epoch through the public method, {steps} steps per variant, host iterator -> set_batch (H2D) -> train_step -> float(loss)', 'steps': steps}
+    try:
+        for kind in ('numpy_pageable', 'torch_pinned'):
+            if kind == 'numpy_pageable':
+                hi, hg = np.ascontiguousarray(imgs.numpy()), np.ascontiguousarray(gt.cpu().numpy())
+            else:
+                hi, hg = imgs.pin_memory(), gt.cpu().pin_memory()
+            model.train_iterator, model.num_train, model.train_initializer, model.verbose = [(hi, hg)] * steps, steps * B, None, False
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mean_loss = model.train_one_epoch(lr)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            for _ in range(10):
+                model.set_batch(hi, hg)
+                torch.cuda.synchronize()
+            h2d = (time.perf_counter() - t1) / 10
+            res[kind] = {'images_per_sec': round(B * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 3), 'h2d_ms': round(h2d * 1e3, 3),
+                         'h2d_share': round(h2d / (dt / steps), 3), 'mean_loss': round(float(mean_loss), 4)}
+    finally:
+        model.train_iterator, model.num_train, model.train_initializer, model.verbose = saved
+    return res
 
 
 def inference_bench(dev, with_cpu=True, reps=20):
@@ -551,7 +655,7 @@ def inference_bench(dev, with_cpu=True, reps=20):
     return res
 
 
-def configs_bench(budget_s=120.0):
+def configs_bench(budget_s=120.0, pmc=True):
     """BASELINE.json's configurations 3-5, one child `python bench.py --config <name> --steps 10 --warmup 3 --no-cpu-baseline` each (its own process: a failure there
     cannot touch the headline line), reduced to a compact record: images/s, ms/step, engine, dominant kernel and its fraction of the engine's MFMA peak, the conv
     family's fraction.  Stops starting children when the time budget of the default run is spent."""
@@ -559,7 +663,12 @@ def configs_bench(budget_s=120.0):
     res = {}
     t0 = time.perf_counter()
     # (retinanet twice: its default engine since round 4, f32x3, and the exact f32 engine it replaced -- the two are different arithmetic, not one kernel made faster)
-    for name, extra in (('yolov3', []), ('fcos', []), ('centernet', []), ('retinanet', []), ('retinanet_f32', ['--dtype', 'f32'])):
+    order = (('yolov3', []), ('fcos', []), ('centernet', []), ('retinanet', []), ('retinanet_f32', ['--dtype', 'f32']))
+
+    def remaining(name):                     # configurations still to be started after `name` (each needs ~25 s for its plain child run)
+        names = [n for n, _ in order]
+        return len(names) - 1 - names.index(name)
+    for name, extra in order:
         left = budget_s - (time.perf_counter() - t0)
         if left < 25:
             res[name] = {'skipped': 'time budget of the default run spent'}
@@ -576,7 +685,11 @@ def configs_bench(budget_s=120.0):
             res[name] = {'metric': d['metric'], 'images_per_sec': d['value'], 'ms_per_step': d['ms_per_step'], 'dtype': d['dtype'], 'batch_per_gpu': d['config']['global_batch'],
                          'dominant_kernel': rf.get('kernel'), 'dominant_TFLOPs': rf.get('achieved'), 'dominant_frac': rf.get('frac'),
                          'conv_family_frac': rf.get('family', {}).get('frac'), 'conv_ms_per_step': rf.get('family', {}).get('conv_ms_per_step'),
-                         'peak_TFLOPs': rf.get('peak'), 'final_loss': d['config'].get('final_loss')}
+                         'peak_TFLOPs': rf.get('peak'), 'final_loss': d['config'].get('final_loss'), 'engine_admission': d['config'].get('engine_admission')}
+            if pmc and '_' not in name:
+                left = budget_s - (time.perf_counter() - t0)
+                res[name].update(live_pmc_step(name, d['ms_per_step'], left - 25 * remaining(name)) if left - 25 * remaining(name) >= 30 else
+                                 {'pmc_note': 'time budget of the default run spent'})
         except Exception as e:                                           # noqa: BLE001
             res[name] = {'error': f'{type(e).__name__}: {e}'}
     return res

@@ -143,9 +143,15 @@ int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int lddy, const v
                       const void* relu_src, void* dx, int accumulate, void* stream);
 
 /* dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (float32, KRSC, pitch R*S*C)
- * Split over pixels with float atomics: dw must be zeroed (or hold the value to
- * accumulate onto) by the caller.  dbias (optional, f32 [K]) += column sums of dy -- the
- * bias gradient, fused so dy is not read a second time. */
+ * dw must be zeroed (or hold the value to accumulate onto) by the caller.  dbias (optional,
+ * f32 [K]) += column sums of dy -- the bias gradient, fused so dy is not read a second time.
+ * How the sum reaches dw depends on the launch: several pixel splits add with float atomics
+ * (or, in deterministic mode -- odtk_debug_set key 5 -- through partial tiles and a fixed-order
+ * reduction launch); ONE pixel split adds its tile with plain 16-byte read-add-store rows.
+ * Hence: (1) launches that accumulate into the SAME dw (a head whose filter is shared by
+ * several pyramid levels) must be ordered on one stream or by events -- two of them in flight
+ * at once race; (2) dw should be 16-byte aligned: an unaligned dw is served by the atomic
+ * flush only, and deterministic mode returns an error for it. */
 int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const void* dy, int lddy,
                       float* dw, float* dbias, void* stream);
 
@@ -312,7 +318,9 @@ int odtk_rows_from_f32(const float* y, int ldy, int rows_per_img, long long y_im
 /* tf.nn.l2_normalize(axis=C) * scalar gamma (SSD300.py:74-83). */
 int odtk_l2norm_fwd(const void* x, void* y, int M, int C, int ld, int dtype, const float* gamma,
                     void* stream);
-/* dx += (accumulate) ; dgamma[0] += sum (caller zeroes). relu_src masks like dgrad. */
+/* dx += (accumulate) ; dgamma[0] += sum (caller zeroes). relu_src masks like dgrad.
+ * Deterministic mode (odtk_debug_set key 5): the block sums go through a small buffer per (device, scratch slot): launches in
+ * flight at once must come from threads on different slots (odtk_scratch_slot), like the convolutions' scratch. */
 int odtk_l2norm_bwd(const void* x, const void* dy, void* dx, int M, int C, int ld, int dtype,
                     const float* gamma, float* dgamma, int accumulate, const void* relu_src,
                     void* stream);

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and enums only: no RCCL symbol is linked
 
+#include <cstdio>
+#include <cstring>
 #include <mutex>
 
 #include "../../include/odtk.h"
@@ -23,6 +25,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
     bool ok = false;
+    char why[256] = "symbols missing";          // dlopen's message for librccl.so.1, captured once (dlerror() is consumed by the call that reads it)
 };
 
 Rccl g_rccl;
@@ -33,8 +36,13 @@ void bind_rccl() {
     for (const char* n : names) {
         g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.lib) break;
+        if (n == names[0]) {
+            const char* e = dlerror();
+            snprintf(g_rccl.why, sizeof g_rccl.why, "%s", e ? e : "dlopen failed");
+        }
     }
     if (!g_rccl.lib) return;
+    snprintf(g_rccl.why, sizeof g_rccl.why, "symbols missing");
     g_rccl.get_unique_id = (decltype(g_rccl.get_unique_id))dlsym(g_rccl.lib, "ncclGetUniqueId");
     g_rccl.comm_init_rank = (decltype(g_rccl.comm_init_rank))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.all_reduce = (decltype(g_rccl.all_reduce))dlsym(g_rccl.lib, "ncclAllReduce");
@@ -47,7 +55,7 @@ void bind_rccl() {
 int need_rccl() {
     std::call_once(g_once, bind_rccl);
     if (!g_rccl.ok) {
-        odtk::set_error("odtk_comm: RCCL not available (dlopen librccl.so.1: %s)", g_rccl.lib ? "symbols missing" : dlerror());
+        odtk::set_error("odtk_comm: RCCL not available (dlopen librccl.so.1: %s)", g_rccl.why);
         return ODTK_ERR_HIP;
     }
     return ODTK_OK;
@@ -98,6 +106,14 @@ extern "C" int odtk_comm_info(const odtk_comm* comm, int* rank, int* world) {
     return ODTK_OK;
 }
 
+// the communicator belongs to the device that was current in odtk_comm_init; a collective enqueued with another device current would launch on the wrong GPU
+static int on_comm_device(const odtk_comm* comm, const char* what) {
+    int dev = -1;
+    ODTK_CHECK_HIP(hipGetDevice(&dev));
+    ODTK_REQUIRE(dev == comm->device, "%s: current device %d, the communicator was created on device %d", what, dev, comm->device);
+    return ODTK_OK;
+}
+
 static int rccl_dtype(int dtype, ncclDataType_t* t) {
     if (dtype == ODTK_F32) { *t = ncclFloat32; return ODTK_OK; }
     if (dtype == ODTK_BF16) { *t = ncclBfloat16; return ODTK_OK; }
@@ -111,6 +127,7 @@ extern "C" int odtk_comm_allreduce(odtk_comm* comm, const void* send, void* recv
     ncclDataType_t t;
     if (int e = rccl_dtype(dtype, &t)) return e;
     if (count == 0) return ODTK_OK;
+    if (int e = on_comm_device(comm, "comm_allreduce")) return e;
     ODTK_CHECK_RCCL(g_rccl.all_reduce(send, recv, (size_t)count, t, ncclSum, comm->comm, (hipStream_t)stream));
     return ODTK_OK;
 }
@@ -121,13 +138,19 @@ extern "C" int odtk_comm_broadcast(odtk_comm* comm, void* buf, long long count, 
     ncclDataType_t t;
     if (int e = rccl_dtype(dtype, &t)) return e;
     if (count == 0) return ODTK_OK;
+    if (int e = on_comm_device(comm, "comm_broadcast")) return e;
     ODTK_CHECK_RCCL(g_rccl.broadcast(buf, buf, (size_t)count, t, root, comm->comm, (hipStream_t)stream));
     return ODTK_OK;
 }
 
 extern "C" int odtk_comm_destroy(odtk_comm* comm) {
     if (!comm) return ODTK_OK;
-    if (comm->comm) ODTK_CHECK_RCCL(g_rccl.comm_destroy(comm->comm));
-    delete comm;
+    ncclResult_t r = ncclSuccess;
+    if (comm->comm) r = g_rccl.comm_destroy(comm->comm);
+    delete comm;                                  // the handle is gone whatever RCCL answered
+    if (r != ncclSuccess) {
+        odtk::set_error("odtk_comm_destroy: ncclCommDestroy -> %s", g_rccl.error_string(r));
+        return ODTK_ERR_HIP;
+    }
     return ODTK_OK;
 }

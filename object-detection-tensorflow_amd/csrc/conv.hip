@@ -1168,6 +1168,12 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     a.div_wo = make_fastdiv((unsigned)d->Wo);
     a.dbg = g_dbg;
     a.dbg2 = g_dbg2;
+    if ((uintptr_t)dw & 15) {
+        // the single-split flush and the fixed-order reduction move dW as 16-byte rows (round-5 advisory): a gradient buffer that is not 16-byte aligned takes
+        // the float-atomic flush, and the deterministic mode refuses it
+        ODTK_REQUIRE(!cv::get_wgrad_deterministic(), "conv2d_wgrad: deterministic mode needs dw aligned to 16 bytes (got %p)", (void*)dw);
+        a.dbg2 |= 4096;
+    }
     if (!g_force_regstage && g_v3_mode != 1 && wgrad_f32_narrow_supported(a, d->dtype)) {
         launch_wgrad_f32_narrow(a, (hipStream_t)stream);
         g_last_kernel = "wgrad_f32_narrow_kernel";

@@ -335,6 +335,7 @@ int launch_gather_v9(GatherArgs& a, hipStream_t st, int num_cu);
 int x3_scratch(size_t bytes, hipStream_t st, char** out);   // the engine's own arena (per device and scratch slot), grown on demand; never moved once a captured graph holds it
 bool get_wgrad_deterministic();        // (elementwise.hip: the scalar gamma gradient of the L2 norm follows the same switch)
 void set_wgrad_deterministic(bool on);  // odtk_debug_set key 5: deterministic split-reduce instead of float atomics
+int get_scratch_slot();                  // the calling thread's slot (0..3)
 int set_scratch_slot(int slot);          // split-K partial buffers are per (device, slot); 0 on success
 
 }  // namespace cv

@@ -11,6 +11,7 @@
 //   * epilogue: accumulators (+bias) are rounded to bf16 into an XOR-swizzled [pixel][channel]
 //     LDS image and leave as full 16-byte-per-lane row segments (256 B contiguous per pixel);
 //     accumulate / ReLU / ReLU-mask are applied on that coalesced pass.
+#include <mutex>
 #include "conv_common.h"
 
 namespace odtk {
@@ -2054,18 +2055,27 @@ int set_scratch_slot(int slot) {
     g_scratch_slot = slot;
     return 0;
 }
+int get_scratch_slot() { return g_scratch_slot; }
+// (round-5 advisory) The arenas are process-global: the bookkeeping is under a mutex, and once ANY request of this process has come from a capturing stream
+// nothing is freed any more (a capture running on another stream or thread would be invalidated by the device synchronize in front of the free) -- an
+// outgrown buffer is then retired as before round 5.  Two threads that launch on the same (device, slot) at the same time still share one buffer: one slot
+// per concurrently used stream is the caller's contract (odtk_scratch_slot, include/odtk.h).
+static std::mutex g_scratch_mutex;
+static bool g_scratch_capture_seen = false;
 static int scratch_get(ConvScratchOwner (&arena)[16][SCRATCH_SLOTS], size_t bytes, hipStream_t st, void** out) {
     int dev = 0;
     ODTK_CHECK_HIP(hipGetDevice(&dev));
     ODTK_REQUIRE(dev >= 0 && dev < 16, "conv: device index %d unsupported", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     ConvScratchOwner& o = arena[dev][g_scratch_slot];
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (capturing) g_scratch_capture_seen = true;
     if (o.bytes < bytes) {
         ODTK_REQUIRE(!capturing, "conv: library scratch must grow (%zu -> %zu bytes) inside a stream capture: run one eager step first", o.bytes, bytes);
         size_t want = o.bytes ? 2 * o.bytes : ((size_t)64 << 20);
         if (want < bytes) want = bytes;
-        if (o.base && !o.captured) {                  // nobody can still hold the old address once the device is idle
+        if (o.base && !o.captured && !g_scratch_capture_seen) {                  // nobody can still hold the old address once the device is idle
             ODTK_CHECK_HIP(hipDeviceSynchronize());
             ODTK_CHECK_HIP(hipFree(o.base));
             o.base = nullptr; o.bytes = 0;

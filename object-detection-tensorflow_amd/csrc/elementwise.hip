@@ -5,6 +5,7 @@
 // Reference call sites: SSD300.py:52-63 (mean subtraction), :539-547 (max_pooling2d SAME),
 // :506-512 (batch_normalization), :74-83 (l2_normalize * scalar), :149-154 (MomentumOptimizer
 // + l2_loss over all trainables).
+#include <mutex>
 #include <initializer_list>
 #include "common.h"
 
@@ -1380,7 +1381,7 @@ inline RedPlan red_plan_capped(int M, int C, int kc, int maxsplit) {
 }  // namespace odtk
 
 using namespace odtk;
-namespace odtk { namespace cv { bool get_wgrad_deterministic(); } }
+namespace odtk { namespace cv { bool get_wgrad_deterministic(); int get_scratch_slot(); } }
 
 static int g_bn_small_rows = 1024;        // odtk_debug_set key 4 (value >= 0).  (1 408, so that YOLOv3's 13 x 13 maps at 8 images -- 1 352 rows x 512 / 1 024 channels --
                                           // take the single launch, was measured SLOWER there: 11.24 vs 11.13 ms/step, gpurun r03o)
@@ -1688,23 +1689,30 @@ extern "C" int odtk_l2norm_bwd(const void* x, const void* dy, void* dx, int M, i
     if (int e = pool_check(C, ld, dtype)) return e;
     hipStream_t st = (hipStream_t)stream;
     int grid = ceil_div(M, 4); if (grid > 1024) grid = 1024;
-    // deterministic mode (key 5): per-block partial sums + a ticket in a small per-device buffer (launches of this entry point on ONE device are assumed
-    // stream-ordered among themselves in that mode: SSD300 has one L2-norm layer)
+    // deterministic mode (key 5): per-block partial sums + a ticket in a small buffer per (device, scratch slot) -- like the convolutions' scratch, launches
+    // that are in flight at the same time must come from threads on different slots (odtk_scratch_slot; round-5 advisory).  The buffer is allocated on first
+    // use (not inside a stream capture: run one eager step first) and zeroed on the caller's stream; the kernel leaves the ticket at zero.
     float* part = nullptr;
     unsigned* ticket = nullptr;
     if (cv::get_wgrad_deterministic()) {
-        static float* s_part[16] = {nullptr};
+        static float* s_part[16][4] = {{nullptr}};
+        static std::mutex s_mutex;
         int dev = 0;
         ODTK_CHECK_HIP(hipGetDevice(&dev));
         ODTK_REQUIRE(dev >= 0 && dev < 16, "l2norm_bwd: device index %d unsupported", dev);
-        if (!s_part[dev]) {
+        const int slot = cv::get_scratch_slot() & 3;
+        std::lock_guard<std::mutex> lock(s_mutex);
+        if (!s_part[dev][slot]) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            ODTK_REQUIRE(!(hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone),
+                         "l2norm_bwd: the deterministic mode's partial buffer must be allocated outside a stream capture: run one eager step first");
             void* p = nullptr;
             ODTK_CHECK_HIP(hipMalloc(&p, (1024 + 16) * sizeof(float)));
-            ODTK_CHECK_HIP(hipMemset(p, 0, (1024 + 16) * sizeof(float)));
-            s_part[dev] = (float*)p;
+            ODTK_CHECK_HIP(hipMemsetAsync(p, 0, (1024 + 16) * sizeof(float), st));
+            s_part[dev][slot] = (float*)p;
         }
-        part = s_part[dev];
-        ticket = reinterpret_cast<unsigned*>(s_part[dev] + 1024);
+        part = s_part[dev][slot];
+        ticket = reinterpret_cast<unsigned*>(s_part[dev][slot] + 1024);
     }
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(l2norm_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy,
                                            (T*)dx, M, C, ld, gamma, dgamma, accumulate, (const T*)relu_src, part, ticket);)

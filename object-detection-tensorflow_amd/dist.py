@@ -206,6 +206,10 @@ class GradAllReducer:
             from . import ops
             cast = (ops.cast_from_f32, ops.cast_to_f32)
         # collective: 'torch' | 'odtk' | an OdtkCollective the caller created earlier (bench.py does, BEFORE the model: see OdtkCollective)
+        # NOTE (round-5 advisory): the C-ABI collective is enqueued on the model's `_side` stream -- the stream box matching and the filter refresh run on
+        # under the forward pass -- unless the OdtkCollective was built with its own: the bucket sums of step t are therefore ordered BEFORE the box matching
+        # of step t + 1 on that stream (they do not overlap each other; both overlap the main chain).  Give OdtkCollective(stream=...) a stream of its
+        # own to lift that; measured neutral in a world of one rank (profiles/r05w).
         if isinstance(collective, OdtkCollective):
             coll = collective
             if coll.stream is None:

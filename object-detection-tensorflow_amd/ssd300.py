@@ -351,8 +351,8 @@ class SSD300:
         else:
             dst.copy_(value.to(self.dev).view(dst.shape))
 
-    def get_param(self, name):
-        v = self.param(name).detach().cpu().clone()
+    def get_param(self, name, buf=None):
+        v = self.param(name, buf).detach().cpu().clone()
         if name.endswith('.w'):
             v = v[..., : self.convs[name[:-2]].cin].contiguous()
         return v

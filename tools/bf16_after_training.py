@@ -54,8 +54,34 @@ def summarize(tag, rows):
     return min(cos), statistics.median(r[1] for r in first)
 
 
-def run(name, steps=300, batch=4, lr=1e-3, verbose=True, engine='bf16'):
-    """-> dict(init=(min cosine, input-side-third median), after=(...), losses=[...])"""
+def state_hash(params, stats):
+    """sha256 over the exported parameters (and moving statistics): equal hashes <=> bit-identical training runs"""
+    import hashlib
+    h = hashlib.sha256()
+    for k in params:
+        h.update(k.encode())
+        h.update(params[k].detach().cpu().contiguous().numpy().tobytes())
+    if stats is not None:
+        h.update(stats.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()[:16]
+
+
+def run(name, steps=300, batch=4, lr=1e-3, verbose=True, engine='bf16', deterministic=True, checkpoints=None):
+    """-> dict(init=(min cosine, input-side-third median), after=(...), losses=[...], hash=..., table={steps: (min, third, hash)})
+
+    `deterministic` (default since round 6): the library's fixed-order filter-gradient reduction (odtk_debug_set key 5) for the f32 training AND both
+    comparison steps, so that the trained weights -- and with them every number returned -- are bit-identical from run to run and from box to box
+    (`hash` says so: sha256 of the trained parameters + moving statistics).  `checkpoints`: the comparison is repeated at each of these step counts
+    (the last one is `steps`)."""
+    from odtk import ops
+    ops.debug_set(5, 1 if deterministic else 0)
+    try:
+        return _run(name, steps, batch, lr, verbose, engine, sorted(set(list(checkpoints or []) + [steps])))
+    finally:
+        ops.debug_set(5, 0)
+
+
+def _run(name, steps, batch, lr, verbose, engine, checkpoints):
     size = BC.SHAPES[name][0]
     r = BC.make(name, batch=batch, size=size, dtype='f32', use_graph=False)
     m = r['model']
@@ -65,29 +91,32 @@ def run(name, steps=300, batch=4, lr=1e-3, verbose=True, engine='bf16'):
     lf, gf = grads_of(name, p0, s0, batch, size, 'f32', probe)
     lb, gb = grads_of(name, p0, s0, batch, size, engine, probe)
     if verbose:
-        print(f'{name} {size}x{size} batch {batch}: at initialisation loss f32 {lf:.4f} / {engine} {lb:.4f}')
+        print(f'{name} {size}x{size} batch {batch}: at initialisation loss f32 {lf:.4f} / {engine} {lb:.4f}   (state {state_hash(p0, s0)})')
     init = summarize('  initial weights', compare(gf, gb))
     pool = [BC.synthetic_batch(name, batch, size, 100 + i) for i in range(8)]
-    losses = []
+    losses, table, after = [], {}, None
     for i in range(steps):
         m.set_batch(*pool[i % len(pool)])
         loss = m.train_step(lr)
         if i % max(1, steps // 6) == 0 or i == steps - 1:
             losses.append((i, round(float(loss), 4)))
-    torch.cuda.synchronize()
+        if i + 1 in checkpoints:
+            torch.cuda.synchronize()
+            p1 = m.export_params()
+            s1 = m.S.clone() if hasattr(m, 'S') else None
+            h = state_hash(p1, s1)
+            lf, gf = grads_of(name, p1, s1, batch, size, 'f32', probe)
+            lb, gb = grads_of(name, p1, s1, batch, size, engine, probe)
+            if verbose:
+                print(f'  after {i + 1} steps: held-out loss f32 {lf:.4f} / {engine} {lb:.4f}   (state {h})')
+            after = summarize(f'  after {i + 1} steps', compare(gf, gb))
+            table[i + 1] = (after[0], after[1], h)
     if verbose:
         print(f'  f32 training, lr {lr}: loss {losses}')
-    p1 = m.export_params()
-    s1 = m.S.clone() if hasattr(m, 'S') else None
     del m
     torch.cuda.empty_cache()
-    lf, gf = grads_of(name, p1, s1, batch, size, 'f32', probe)
-    lb, gb = grads_of(name, p1, s1, batch, size, engine, probe)
-    if verbose:
-        print(f'  after {steps} steps: held-out loss f32 {lf:.4f} / {engine} {lb:.4f}')
-    after = summarize(f'  after {steps} steps', compare(gf, gb))
-    print(f'RESULT {name}: min cosine {init[0]:.3f} -> {after[0]:.3f}; input-side third {init[1]:.3f} -> {after[1]:.3f}')
-    return dict(init=init, after=after, losses=losses, loss_f32=lf, loss_bf16=lb)
+    print(f'RESULT {name}: min cosine {init[0]:.3f} -> {after[0]:.3f}; input-side third {init[1]:.3f} -> {after[1]:.3f}; state {table[steps][2]}')
+    return dict(init=init, after=after, losses=losses, loss_f32=lf, loss_bf16=lb, hash=table[steps][2], table=table)
 
 
 def compare_engines(name, a='f32', b='f32x3', batch=2, size=None, verbose=True):

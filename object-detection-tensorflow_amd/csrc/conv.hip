@@ -524,7 +524,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int g = 0; g < NPG; ++g) t += red[g * PT + tid];
-            atomicAdd(a.dbias + p0 + tid, t);
+            if (a.bws) a.bws[(size_t)split * a.K + p0 + tid] = t;      // deterministic mode: one bias slot per pixel split
+            else atomicAdd(a.dbias + p0 + tid, t);
         }
     }
 
@@ -538,7 +539,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = p0 + wp * (PT / 2) + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                if (k < a.K) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                if (k < a.K) {
+                    // deterministic mode (round 6: the f32 engines and the odd bf16 layouts that end up here): plain stores of the partial tile to ws[split],
+                    // summed in split order by the reduction launch
+                    if (a.ws) a.ws[((size_t)split * a.K + k) * a.RSC + col] = acc[i][j][e];
+                    else atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                }
             }
         }
     }
@@ -701,7 +707,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = p0 + wp * 64 + i * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                if (k < a.K && !(a.dbg & 16)) atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                if (k < a.K && !(a.dbg & 16)) {
+                    if (a.ws) a.ws[((size_t)split * a.K + k) * a.RSC + col] = acc[i][j][e];      // deterministic mode: see conv_wgrad_kernel
+                    else atomicAdd(a.dw + (size_t)k * a.RSC + col, acc[i][j][e]);
+                }
             }
         }
     }
@@ -710,7 +719,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(const WgradArgs a) 
         for (int i = 0; i < PI; ++i) {
             const float t = bsum[i] + __shfl_xor(bsum[i], 32);       // both k halves
             const int k = p0 + wp * 64 + i * 32 + l31;
-            if (hi == 0 && k < a.K) atomicAdd(a.dbias + k, t);
+            if (hi == 0 && k < a.K) {
+                if (a.bws) a.bws[(size_t)split * a.K + k] = t;
+                else atomicAdd(a.dbias + k, t);
+            }
         }
     }
 }
@@ -1216,6 +1228,7 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
     a.dbg = g_dbg;
     dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
+    if (int e = cv::wgrad_split_scratch(a, splits, dbias ? splits : 0, st)) return e;      // deterministic mode (key 5) with > 1 pixel split: partial tiles + reduction launch
     g_last_kernel = (d->dtype == ODTK_BF16 && !g_force_regstage && !(PT == 64 && g_v3_mode == 1)) ? "conv_wgrad_dma_kernel" : "conv_wgrad_kernel";
     if (d->dtype == ODTK_BF16) {
         if (PT == 64 && (g_v3_mode == 1 || g_force_regstage)) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), grid, dim3(256), 0, st, a);
@@ -1225,6 +1238,7 @@ extern "C" int odtk_conv2d_wgrad(const odtk_conv_desc* d, const void* x, const v
         if (PT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<float, 64>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<float, 128>), grid, dim3(256), 0, st, a);
     }
+    cv::wgrad_split_reduce(a, st);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

@@ -333,6 +333,11 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
 bool gather_v9_wanted(const GatherArgs& a, int num_cu);
 int launch_gather_v9(GatherArgs& a, hipStream_t st, int num_cu);
 int x3_scratch(size_t bytes, hipStream_t st, char** out);   // the engine's own arena (per device and scratch slot), grown on demand; never moved once a captured graph holds it
+// deterministic filter-gradient flush (odtk_debug_set key 5), shared by every filter-gradient kernel since round 6: wgrad_split_scratch points a.ws / a.bws at
+// `splits` dW-shaped partial buffers (+ `bias_slots` x K bias partials) of the per-(device, slot) scratch when the mode is on and splits > 1 (null otherwise: the
+// kernel adds into dW itself); wgrad_split_reduce launches the fixed-order sum of the partials into dW / dbias (nothing when a.ws is null)
+int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots, hipStream_t st);
+void wgrad_split_reduce(const WgradArgs& a, hipStream_t st);
 bool get_wgrad_deterministic();        // (elementwise.hip: the scalar gamma gradient of the L2 norm follows the same switch)
 void set_wgrad_deterministic(bool on);  // odtk_debug_set key 5: deterministic split-reduce instead of float atomics
 int get_scratch_slot();                  // the calling thread's slot (0..3)

@@ -2361,8 +2361,6 @@ static bool g_wgrad_deterministic = false;
 void set_wgrad_deterministic(bool on) { g_wgrad_deterministic = on; }
 bool get_wgrad_deterministic() { return g_wgrad_deterministic; }
 
-static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots, hipStream_t st);
-static void wgrad_split_reduce(const WgradArgs& a, hipStream_t st);
 
 bool wgrad_c64_supported(const WgradArgs& a, int dtype) {
     if (!(dtype == ODTK_BF16 && a.C % 64 == 0 && a.K % 64 == 0 && a.C >= 64 && a.K >= 64 && a.ldx >= a.C && a.ldx % 8 == 0 && a.lddy >= a.K && a.lddy % 8 == 0 &&
@@ -2373,7 +2371,7 @@ bool wgrad_c64_supported(const WgradArgs& a, int dtype) {
     // Round 4: one (64 x 64) block pair of dW per workgroup for the wide, large maps whose 8 x 32-pixel tiles waste little -- conv2_1 / conv2_2 at 150 x 150
     // (5 x 19 tiles per image: 94 %): 161 -> 1xx us and 273 -> 2xx us against the 8-wave gather kernel (one x slab per tap there, one halo patch per tile here).
     // Narrow maps (W = 75: 78 %, W = 38: 59 %) stay on the generic kernels; dbg bit 17 = off (A/B).
-    if ((a.dbg & (1 << 17)) || g_wgrad_deterministic) return false;      // (deterministic mode: the split-reduce kernels; this one flushes by float atomics)
+    if (a.dbg & (1 << 17)) return false;      // (deterministic mode, round 6: one partial per workgroup in its block of a dW-shaped slot buffer + the reduction launch, like 64 -> 64)
     const int npairs = (a.C / 64) * (a.K / 64);
     if (a.dbg & (1 << 15)) return npairs <= 16;                 // tests: the block-pair path on small / ragged problems too
     const double eff = (double)a.W / (32.0 * ceil_div(a.W, 32)) * (double)a.H / (8.0 * ceil_div(a.H, 8));
@@ -2392,8 +2390,10 @@ int launch_wgrad_c64(WgradArgs& a, hipStream_t st) {
     if (per_pair < 1) per_pair = 1;
     a.x_bytes = (unsigned)((size_t)a.N * a.H * a.W * a.ldx * 2);
     a.dy_bytes = (unsigned)((size_t)a.P * a.lddy * 2);
-    // deterministic mode (only the 64 -> 64 layer gets here in it: one block pair): one partial per workgroup + the fixed-order reduction launch
-    if (int e = wgrad_split_scratch(a, npairs == 1 ? per_pair : 1, (npairs == 1 && a.dbias) ? per_pair : 0, st)) return e;
+    // deterministic mode: one partial per workgroup + the fixed-order reduction launch.  Workgroup `slot` of block pair (kblk, cblk) stores its 64 x 576 partial into
+    // ITS block of the dW-shaped buffer ws[slot]; the per_pair workgroups of every pair fill the per_pair buffers completely, so the reduction launch sums
+    // ws[0 .. per_pair) in slot order into dW like pixel splits (round 6: conv2_x left this kernel in deterministic mode before -- 200 us of the mode's 5 %)
+    if (int e = wgrad_split_scratch(a, per_pair, a.dbias ? per_pair : 0, st)) return e;
     hipLaunchKernelGGL(wgrad3x3_c64k64_kernel, dim3(per_pair * npairs), dim3(256), 0, st, a, tr, tc, tiles, make_fastdiv((unsigned)(tr * tc)),
                        make_fastdiv((unsigned)tc), npairs, ncb);
     wgrad_split_reduce(a, st);
@@ -2572,12 +2572,18 @@ __global__ void __launch_bounds__(256) wgrad_f32_narrow_kernel(const WgradArgs a
         }
         __syncthreads();
     }
+    // deterministic mode (round 6): this workgroup's whole K x RSC partial goes to ws[workgroup] with plain stores (zeros included) and the reduction launch adds
+    // the workgroups in order; the tile walk of a workgroup is fixed, so the result is bit-identical from run to run
+    float* const wdst = a.ws ? a.ws + (size_t)blockIdx.x * a.K * a.RSC : a.dw;
     for (int idx = tid; idx < NT * KI * CI * 16 * 64; idx += 256) {
         const int ln = idx & 63, e = (idx >> 6) & 15, tij = idx >> 10;
         const int j = tij % CI, i = (tij / CI) % KI, t = tij / (CI * KI);
         const int k = i * 32 + 8 * (e >> 2) + 4 * (ln >> 5) + (e & 3), c = j * 32 + (ln & 31);
         const float v = img[idx];
-        if (k < a.K && c < a.C && v != 0.f) atomicAdd(a.dw + (size_t)k * a.RSC + t * a.C + c, v);
+        if (k < a.K && c < a.C) {
+            if (a.ws) wdst[(size_t)k * a.RSC + t * a.C + c] = v;
+            else if (v != 0.f) atomicAdd(wdst + (size_t)k * a.RSC + t * a.C + c, v);
+        }
     }
     if (a.dbias != nullptr) {
         __syncthreads();
@@ -2592,14 +2598,15 @@ __global__ void __launch_bounds__(256) wgrad_f32_narrow_kernel(const WgradArgs a
             float v = 0.f;
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) v += img[(wv * KI + i) * 32 + l];
-            if (v != 0.f) atomicAdd(a.dbias + tid, v);
+            if (a.bws) a.bws[(size_t)blockIdx.x * a.K + tid] = v;
+            else if (v != 0.f) atomicAdd(a.dbias + tid, v);
         }
     }
 }
 }  // namespace
 
 bool wgrad_f32_narrow_supported(const WgradArgs& a, int dtype) {
-    if (dtype != ODTK_F32 || g_wgrad_deterministic || (a.dbg2 & 32)) return false;
+    if (dtype != ODTK_F32 || (a.dbg2 & 32)) return false;      // (deterministic mode, round 6: one partial per workgroup + the reduction launch)
     const bool r3 = a.R == 3 && a.S == 3 && a.pad_t == 1 && a.pad_l == 1, r1 = a.R == 1 && a.S == 1 && a.pad_t == 0 && a.pad_l == 0;
     if (!(r3 || r1) || a.stride != 1 || a.dil != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if (r3 ? !(a.K <= 32 && a.C <= 32) : !(a.K <= 64 && a.C <= 64)) return false;
@@ -2618,6 +2625,7 @@ int launch_wgrad_f32_narrow(WgradArgs& a, hipStream_t st) {
     const int KI = a.K <= 32 ? 1 : 2, CI = a.C <= 32 ? 1 : 2;
     const int per_cu = r3 ? 1 : (KI * CI == 1 ? 2 : 1);
     const int grid = total < g_num_cu * per_cu ? total : g_num_cu * per_cu;
+    if (int e = wgrad_split_scratch(a, grid, a.dbias ? grid : 0, st)) return e;
 #define ODTK_WN(R3_, KI_, CI_) hipLaunchKernelGGL((wgrad_f32_narrow_kernel<R3_, KI_, CI_>), dim3(grid), dim3(256), 0, st, a, tiles_h, tiles_w, total)
     if (r3) ODTK_WN(true, 1, 1);
     else if (KI == 1 && CI == 1) ODTK_WN(false, 1, 1);
@@ -2625,6 +2633,7 @@ int launch_wgrad_f32_narrow(WgradArgs& a, hipStream_t st) {
     else if (CI == 1) ODTK_WN(false, 2, 1);
     else ODTK_WN(false, 2, 2);
 #undef ODTK_WN
+    wgrad_split_reduce(a, st);
     return 0;
 }
 
@@ -2867,7 +2876,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_v8_kernel(const WgradArgs a) {
 // run.  The default stays float atomics into dw: measured on the SSD300 step at batch 32, same box, the split-reduce costs
 // 2.5-2.7 % (3 210 | 3 186 against 3 292 | 3 284 images/s): it moves splits x |dw| bytes twice (~700 MB per step) where the
 // atomics, ~40 us per 256 x 256-tile launch as they are, move them once.
-static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots, hipStream_t st) {
+int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots, hipStream_t st) {
     a.ws = nullptr; a.bws = nullptr; a.nsplit = splits; a.nbslot = bias_slots;
     if (splits < 2 || !g_wgrad_deterministic) return 0;
     float* base = nullptr;
@@ -2877,7 +2886,7 @@ static int wgrad_split_scratch(WgradArgs& a, int splits, int bias_slots, hipStre
     a.bws = bias_slots ? base + (size_t)splits * a.K * a.RSC : nullptr;
     return 0;
 }
-static void wgrad_split_reduce(const WgradArgs& a, hipStream_t st) {
+void wgrad_split_reduce(const WgradArgs& a, hipStream_t st) {
     if (!a.ws) return;
     const long long n4 = (long long)a.K * a.RSC / 4;
     if (a.nsplit >= 64) {                                  // many partials of a small gradient: 16 lanes per output

@@ -778,6 +778,7 @@ class SSD300:
                        z.g, self._grad(name + '.gamma'), self._grad(name + '.beta'), self.ws)
             self._phase(f'  bwd {name}: batch norm done')
             self._conv_bwd_params(name, src, z.g, z.ld)
+            self._dp_grad_point(name)
             # the source already holds the head's gradient when it is a feature map
             acc = self.extra_src[name] in self.FEAT_SRC
             if acc and self.extra_src[name] in evs:
@@ -810,6 +811,7 @@ class SSD300:
                 _, name, prev = step
                 x, y = a[prev], a[name]
                 self._conv_bwd_params(name, x, y.g, y.ld)
+                self._dp_grad_point(name)
                 if name != 'conv1_1' and prev in self.relu_bits:
                     ops.conv2d_dgrad_bits(self.desc[name], y.g, y.ld, self.wt[name], self.relu_bits[prev], x.g, False)
                 elif name != 'conv1_1':
@@ -839,11 +841,31 @@ class SSD300:
     def _mark_ready(self, layer_name):
         if self.dist is not None:
             self.dist.layer_ready(layer_name)
+        self._dp_point = None                             # a point belongs to the layer it was recorded for
 
     def _dp_multi_stream(self):
         """True when the backward pass may use the head / filter-gradient streams: always on one device; under data parallel with eager launches
         (the default) too -- only the per-bucket graph replay keeps the single-stream backward (a captured segment cannot end with a forked stream)"""
         return self.dist is None or not self.use_graph
+
+    _dp_point = None         # event on the main stream behind the last GRADIENT launch of the layer being handed to the data-parallel hooks (None: none recorded)
+
+    def _dp_grad_point(self, name):
+        """Data parallel with the step's streams on (round-5 review, item 8): record, on the launching stream, the point behind the last gradient-producing launch
+        of layer `name` -- called in front of the layer's INPUT-gradient launch, which no bucket waits for.  _comm_launch makes the collective's stream wait for
+        this event instead of `wait_stream(main)`, i.e. instead of everything the main chain holds when the bucket closes (the boundary layer's input gradient,
+        100-250 us on the trunk).  One event per layer, created once."""
+        if self.dist is None or not self._dp_multi_stream() or (self._tail is None and self._twg is None and self.wgrad_stream is None):
+            return
+        evs = self.__dict__.setdefault('_dp_point_events', {})
+        ev = evs.get(name)
+        if ev is None:
+            ev = evs[name] = torch.cuda.Event()
+
+        def rec(ev=ev):
+            ev.record(torch.cuda.current_stream())
+            self._dp_point = ev
+        self._py(rec)
 
     @contextlib.contextmanager
     def _comm_launch(self):
@@ -858,9 +880,13 @@ class SSD300:
             return
         main = torch.cuda.current_stream()
         c = self._twg if self._twg is not None else (self.wgrad_stream if self.wgrad_stream is not None else main)
+        point, self._dp_point = self._dp_point, None
         for st in (main, self._tail, self._twg, self.wgrad_stream):
             if st is not None and st != c:
-                c.wait_stream(st)
+                if st is main and point is not None:
+                    c.wait_event(point)                   # the main chain up to the closing layer's last gradient launch, not its input gradient behind it
+                else:
+                    c.wait_stream(st)
         with torch.cuda.stream(c):
             yield
 

@@ -428,12 +428,19 @@ def _ssd300_dp_worker(rank, world, port, out_dir):
 
         def wait_event(self, ev):
             log.append(('wait', self.name, ev.on))
+            log.append(('wait_event', self.name, ev.seq))
 
     class FakeEvent:
         on = None
+        seq = None
+
+        def __init__(self, *a, **k):
+            pass
 
         def record(self, st):
             self.on = st.name
+            self.seq = len(log)
+            log.append(('record', st.name, self.seq))
 
     main = FakeStream('main')
     cur = [main]
@@ -459,6 +466,11 @@ def _ssd300_dp_worker(rank, world, port, out_dir):
         del log[:]
         with mock_ops.installed(), mock.patch.object(torch.cuda, 'current_stream', lambda *a: cur[0]), mock.patch.object(torch.cuda, 'stream', on_stream), \
                 mock.patch.object(torch.cuda, 'Event', FakeEvent), mock.patch.object(dist, 'all_reduce', spy):
+            for fname in ('conv2d_dgrad', 'conv2d_dgrad_bits'):           # where the input-gradient launches sit between the records, waits and collectives
+                def logged(*a, _f=getattr(odtk.ops, fname), **k):
+                    log.append(('dgrad', cur[0].name))
+                    return _f(*a, **k)
+                setattr(odtk.ops, fname, logged)
             m = odtk.SSD300(cfg, {'data_shape': [300, 300, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [], 'val_generator': None})
             if mode == 'streams':                          # what the GPU build has: head stream + tail filter-gradient stream
                 m._tail, m._twg = FakeStream('tail'), FakeStream('twg')
@@ -502,8 +514,20 @@ def test_ssd300_data_parallel_step_keeps_its_streams_world2(tmp_path):
         # where the collectives were launched from, and what that stream waited for right before
         ar = [i for i, e in enumerate(s['log']) if e[0] == 'all_reduce']
         assert len(ar) == s['nbuckets'] and all(s['log'][i][1] == 'twg' for i in ar)
+        behind_dgrad = 0
         for i in ar:
-            assert ('wait', 'twg', 'main') in s['log'][max(0, i - 3):i] and ('wait', 'twg', 'tail') in s['log'][max(0, i - 3):i]
+            win = s['log'][max(0, i - 4):i]
+            assert ('wait', 'twg', 'main') in win and ('wait', 'twg', 'tail') in win
+            # round 6: the main chain is waited for through a per-layer EVENT recorded behind the closing layer's last gradient launch and IN FRONT OF its
+            # input-gradient launch -- the collective's stream does not wait for that input gradient (ssd300._dp_grad_point)
+            we = [e for e in win if e[0] == 'wait_event' and e[1] == 'twg']
+            if we:
+                seq = we[-1][2]
+                assert s['log'][seq] == ('record', 'main', seq)
+                if ('dgrad', 'main') in s['log'][seq:i]:                            # enqueued after the record, before the collective: not waited for
+                    behind_dgrad += 1
+        # (all but a bucket that closes on a head layer -- nothing on the main chain to point at -- and the last one: conv1_1 has no input gradient)
+        assert behind_dgrad >= max(1, len(ar) - 2), (behind_dgrad, len(ar))
         assert not any(e[0] == 'wait' and e[1] == 'main' and e[2] == 'twg' for e in s['log'][:ar[0]])
         assert all(e[1] == 'main' for e in o['log'] if e[0] == 'all_reduce')
     assert torch.equal(a['streams']['P'], b['streams']['P']) and torch.equal(a['streams']['G'], b['streams']['G'])

@@ -873,7 +873,10 @@ def test_wgrad_split_reduce_is_deterministic_and_matches_the_atomics(dev):
     for (N, H, W, C, K, k, s, dil), v8 in [((6, 38, 38, 128, 256, 3, 1, 1), False), ((6, 20, 17, 256, 512, 3, 1, 1), True),
                                              ((8, 19, 19, 64, 100, 3, 1, 1), False),
                                              # round 5: the 64 -> 64 halo kernel (one partial per workgroup) and the first-layer kernel (one per wave)
-                                             ((3, 41, 50, 64, 64, 3, 1, 1), False), ((3, 41, 50, 8, 64, 3, 1, 1), False)]:
+                                             ((3, 41, 50, 64, 64, 3, 1, 1), False), ((3, 41, 50, 8, 64, 3, 1, 1), False),
+                                             # round 6: the block-pair halo kernel (conv2_x; dbg bit 15 takes it on small problems): one partial per workgroup in its
+                                             # block of a dW-shaped slot buffer
+                                             ((3, 41, 50, 128, 128, 3, 1, 1), 1 << 15), ((2, 33, 64, 64, 128, 3, 1, 1), 1 << 15)]:
         Kp = ops.pad_to(K, 8)
         desc = ops.conv_desc(N, H, W, C, C, K, Kp, k, s, dil, ops.BF16, ops.BF16)
         M = N * desc.Ho * desc.Wo
@@ -884,12 +887,14 @@ def test_wgrad_split_reduce_is_deterministic_and_matches_the_atomics(dev):
         outs = []
         for mode in (1, 1, 0):
             ops.debug_set(5, mode)
-            ops.debug_set(2, (1 << 30) if v8 else 0)
+            ops.debug_set(2, (1 << 30) if v8 is True else int(v8))
             try:
                 dw = torch.full((K, k, k, C), 0.5, device=dev)
                 db = torch.full((K,), -2.0, device=dev)
                 ops.conv2d_wgrad(desc, x, dy, Kp, dw, db)
                 torch.cuda.synchronize()
+                if v8 == 1 << 15:
+                    assert ops.conv_last_kernel() == 'wgrad3x3_c64k64_kernel', ops.conv_last_kernel()
             finally:
                 ops.debug_set(5, 0)
                 ops.debug_set(2, 0)

@@ -2094,6 +2094,9 @@ static int conv_scratch(size_t bytes, hipStream_t st, float** out) { return scra
 // filter-gradient partials from conv_scratch while the operands are still being read
 static ConvScratchOwner g_x3_scratch[16][SCRATCH_SLOTS];
 int x3_scratch(size_t bytes, hipStream_t st, char** out) { return scratch_get(g_x3_scratch, bytes, st, (void**)out); }
+// small per-launch partial sums of the box-side kernels (round 6: RetinaNet's loss sums leave in workgroup order instead of by float atomics)
+static ConvScratchOwner g_misc_scratch[16][SCRATCH_SLOTS];
+int misc_scratch(size_t bytes, hipStream_t st, char** out) { return scratch_get(g_misc_scratch, bytes, st, (void**)out); }
 
 static int g_num_cu = 0;
 static void query_num_cu() {

@@ -10,6 +10,7 @@
 // with -ffp-contract=off and uses IEEE division) so indices are bit-identical to the CPU oracle.
 #include "common.h"
 #include <math.h>
+namespace odtk { namespace cv { int misc_scratch(size_t bytes, hipStream_t st, char** out); } }      // conv_v3.hip: per-(device, slot) arena
 
 namespace odtk {
 namespace {
@@ -214,6 +215,8 @@ struct RLossArgs {
     const int* ngt; const int* best; const unsigned char* status; const int* rgindex; const int* counts;
     float alpha, gamma, grad_scale;
     float* loss_parts; float* dconf; float* dbox;
+    float* parts;        // [N][workgroups of the loss pass][2] loss sums of the workgroups: added in workgroup order by retina_best_rows_kernel (round 6: the loss
+                         // VALUE used to leave by float atomics -- the gradients never did -- and differed in the last bit from run to run)
 };
 
 // focal term of one row and its gradient w.r.t. the logits (RetinaNet.py:457-474); `add` accumulates (best rows).
@@ -338,14 +341,16 @@ __global__ void __launch_bounds__(RL_THREADS) retina_loss_kernel(const RLossArgs
     if (tid == 0) {
         float c0 = 0.f, c1 = 0.f;
         for (int w = 0; w < RL_THREADS / 64; ++w) { c0 += s_red[0][w]; c1 += s_red[1][w]; }
-        atomicAdd(a.loss_parts + n * 2 + 0, c0 * inv_np);
-        atomicAdd(a.loss_parts + n * 2 + 1, c1 * inv_np);
+        float* pp = a.parts + ((size_t)n * gridDim.x + blockIdx.x) * 2;
+        pp[0] = c0 * inv_np;
+        pp[1] = c1 * inv_np;
     }
 }
 
 // the G "best" rows of every image (duplicates allowed: two GT may pick one anchor) -- accumulated on top of
 // the zeros written by retina_loss_kernel, hence a second launch
-__global__ void __launch_bounds__(RL_MAX_GT) retina_best_rows_kernel(const RLossArgs a) {
+__global__ void __launch_bounds__(RL_MAX_GT) retina_best_rows_kernel(const RLossArgs a, const int nparts) {
+    __shared__ float s_w[2][RL_MAX_GT / 64];
     const int n = blockIdx.x, g = threadIdx.x;
     const int G = a.ngt[n];
     float conf = 0.f, coord = 0.f;
@@ -359,9 +364,14 @@ __global__ void __launch_bounds__(RL_MAX_GT) retina_best_rows_kernel(const RLoss
         coord = box_row(a, n, an, g, a.pbox + row * 4, a.dbox + row * 4, gs, true);
     }
     for (int o = 32; o > 0; o >>= 1) { conf += __shfl_xor(conf, o); coord += __shfl_xor(coord, o); }
-    if ((g & 63) == 0) {
-        atomicAdd(a.loss_parts + n * 2 + 0, conf * inv_np);
-        atomicAdd(a.loss_parts + n * 2 + 1, coord * inv_np);
+    if ((g & 63) == 0) { s_w[0][g >> 6] = conf * inv_np; s_w[1][g >> 6] = coord * inv_np; }
+    __syncthreads();
+    if (g < 2) {                                       // fixed order: the loss pass's workgroups, then this launch's waves
+        float t = 0.f;
+        const float* pp = a.parts + (size_t)n * nparts * 2 + g;
+        for (int b = 0; b < nparts; ++b) t += pp[2 * b];
+        for (int w = 0; w < RL_MAX_GT / 64; ++w) t += s_w[g][w];
+        a.loss_parts[n * 2 + g] = t;
     }
 }
 
@@ -421,13 +431,16 @@ extern "C" int odtk_retina_loss(const float* pconf, const float* pbox, int N, in
                  "retina_loss: null pointer");
     ODTK_REQUIRE(C > 1 && C <= RL_MAXC && P > 0 && P <= RL_MAX_GT, "retina_loss: C=%d P=%d unsupported", C, P);
     hipStream_t st = (hipStream_t)stream;
-    if (int e = zero_async(loss_parts, (size_t)N * 2 * sizeof(float), st)) return e;
+    const int nparts = ceil_div(ceil_div(A, RL_THREADS), RL_LOSS_TILES);
+    char* parts = nullptr;
+    if (int e = cv::misc_scratch((size_t)N * nparts * 2 * sizeof(float), st, &parts)) return e;
     RLossArgs a;
+    a.parts = (float*)parts;
     a.pconf = pconf; a.pbox = pbox; a.N = N; a.A = A; a.C = C; a.yx = yx; a.hw = hw; a.gt = gt; a.P = P;
     a.ngt = ngt; a.best = best; a.status = status; a.rgindex = rgindex; a.counts = counts;
     a.alpha = alpha; a.gamma = gamma; a.grad_scale = grad_scale; a.loss_parts = loss_parts; a.dconf = dconf; a.dbox = dbox;
-    hipLaunchKernelGGL(retina_loss_kernel, dim3(ceil_div(ceil_div(A, RL_THREADS), RL_LOSS_TILES), N), dim3(RL_THREADS), 0, st, a);
-    hipLaunchKernelGGL(retina_best_rows_kernel, dim3(N), dim3(RL_MAX_GT), 0, st, a);
+    hipLaunchKernelGGL(retina_loss_kernel, dim3(nparts, N), dim3(RL_THREADS), 0, st, a);
+    hipLaunchKernelGGL(retina_best_rows_kernel, dim3(N), dim3(RL_MAX_GT), 0, st, a, nparts);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

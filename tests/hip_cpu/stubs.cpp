@@ -14,6 +14,14 @@ int zero_async(void* p, size_t bytes, hipStream_t) { memset(p, 0, bytes); return
 namespace cv {
 static bool g_deterministic = false;
 bool get_wgrad_deterministic() { return g_deterministic; }      // (csrc/conv_v3.hip's switch: elementwise.hip's L2-norm gamma gradient follows it)
+int get_scratch_slot() { return 0; }                            // (csrc/conv_v3.hip: the calling thread's scratch slot)
+int misc_scratch(size_t bytes, hipStream_t, char** out) {       // (csrc/conv_v3.hip: the box-side kernels' partial-sum arena; here one grow-only host buffer)
+    static char* base = nullptr;
+    static size_t have = 0;
+    if (have < bytes) { free(base); base = (char*)malloc(bytes); have = bytes; }
+    *out = base;
+    return 0;
+}
 }  // namespace cv
 }  // namespace odtk
 extern "C" const char* odtk_last_error(void) { return odtk::g_err; }

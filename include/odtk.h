@@ -63,10 +63,10 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         (statistics, finalize, apply); value -2 = two (apply with the finalize folded in: measured slower, A/B only), -1 = back to three;
  *         -3 / -4 the one-launch kernels in their 64-channel shape only / back; -5 / -6 never pick the two-launch path by shape / back;
  *         -20 / -21 / -22 / -23 rows per workgroup of the apply passes 128 / 512 / 1 024 / by shape (the default: 256, 1 024 for 8- / 16-channel bf16 maps);
- * key 5 = filter gradient: deterministic split-reduce (value != 0: partial tiles + a fixed-order reduction, bit-identical from run to
- *         run, 5 % slower on the SSD300 step: 8.16 against 7.75 ms, r05u) instead of float atomics into dw (the default); round 5: the 64 -> 64 and first-layer
- *         kernels (one partial per workgroup / wave) and the scalar gamma gradient of odtk_l2norm_bwd follow the switch too, so a
- *         whole SSD300 step is reproducible bit for bit;
+ * key 5 = filter gradient flush: 1 (THE DEFAULT since round 6) = deterministic -- every filter-gradient kernel stores partial tiles (one per pixel split /
+ *         workgroup / wave) and a reduction launch adds them in a fixed order; the scalar gamma gradient of odtk_l2norm_bwd and RetinaNet's loss sums follow:
+ *         whole training steps of every model class are reproducible bit for bit (tools/step_determinism.py); 0 = float atomics into dw (the default of
+ *         rounds 1-5).  Same step time to 0.1 % on SSD300 batch 32 (gpurun r6e: the partial stores are cheaper than the atomics, the reduction is ~18 us);
  * key 6 = dispatch A/B switches of the convolution kernels that leave results intact (up to the engines' stated tolerances): bit 2 (4) = ODTK_F32X3 descriptors run
  *         on the exact f32 kernels, bit 3 (8) = ... on the split path wherever it is supported, also below the size policy (tests), bit 4 (16) = no 32-row filter
  *         tile in the f32 LDS-DMA gather, bit 5 (32) = narrow f32 filter gradients on the legacy kernel; round 5: bit 6 (64) = no small-map gather kernel
@@ -145,9 +145,10 @@ int odtk_conv2d_dgrad(const odtk_conv_desc* d, const void* dy, int lddy, const v
 /* dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (float32, KRSC, pitch R*S*C)
  * dw must be zeroed (or hold the value to accumulate onto) by the caller.  dbias (optional,
  * f32 [K]) += column sums of dy -- the bias gradient, fused so dy is not read a second time.
- * How the sum reaches dw depends on the launch: several pixel splits add with float atomics
- * (or, in deterministic mode -- odtk_debug_set key 5 -- through partial tiles and a fixed-order
- * reduction launch); ONE pixel split adds its tile with plain 16-byte read-add-store rows.
+ * How the sum reaches dw depends on the launch: several pixel splits go through partial tiles in
+ * the library's scratch and a fixed-order reduction launch (the default, deterministic; with
+ * odtk_debug_set key 5 = 0: float atomics); ONE pixel split adds its tile with plain 16-byte
+ * read-add-store rows.
  * Hence: (1) launches that accumulate into the SAME dw (a head whose filter is shared by
  * several pyramid levels) must be ordered on one stream or by events -- two of them in flight
  * at once race; (2) dw should be 16-byte aligned: an unaligned dw is served by the atomic

@@ -1146,11 +1146,24 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
                                                            const float* __restrict__ bws, int nbslot, int K, float* __restrict__ dbias,
                                                            int wblocks) {
     if ((int)blockIdx.x >= wblocks) {
-        const int k = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
-        if (k >= K) return;
+        // bias slots (round 6): 16 lanes per output -- lane group g sums the slots g, g + 16, ... in order, the 16 group sums meet in LDS and are added in group
+        // order (a fixed order).  One thread per output walked up to splits x tiles_q x 2 = 504 slots (conv3_2) as a chain of dependent-latency loads in ONE
+        // workgroup: 66-125 us per launch, the whole deficit of the deterministic mode on the 256 x 256-tile layers (rocprof: profiles/r06d_det_wgrad_trace.md).
+        constexpr int G = 16, OPB = 256 / G;
+        __shared__ float smb[256];
+        const int tid = threadIdx.x, g = tid / OPB, o = tid % OPB;
+        const int k = ((int)blockIdx.x - wblocks) * OPB + o;
         float t = 0.f;
-        for (int s = 0; s < nbslot; ++s) t += bws[(size_t)s * K + k];
-        dbias[k] += t;
+        if (k < K)
+            for (int s = g; s < nbslot; s += G) t += bws[(size_t)s * K + k];
+        smb[tid] = t;
+        __syncthreads();
+        if (g == 0 && k < K) {
+            float r = smb[o];
+#pragma unroll
+            for (int q = 1; q < G; ++q) r += smb[q * OPB + o];
+            dbias[k] += r;
+        }
         return;
     }
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1158,6 +1171,13 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     const float4* w4 = reinterpret_cast<const float4*>(ws);
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {                      // eight 16-byte loads in flight per lane; the adds stay in split order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w4[(long long)(s + u) * n4 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+    }
     for (; s + 4 <= nsplit; s += 4) {
         const float4 v0 = w4[(long long)s * n4 + i], v1 = w4[(long long)(s + 1) * n4 + i];
         const float4 v2 = w4[(long long)(s + 2) * n4 + i], v3 = w4[(long long)(s + 3) * n4 + i];
@@ -2360,7 +2380,7 @@ int launch_gather_c8(GatherArgs& a, hipStream_t st) {
     return 0;
 }
 
-static bool g_wgrad_deterministic = false;
+static bool g_wgrad_deterministic = true;       // round 6: the default (odtk_debug_set key 5 = 0 switches to float atomics)
 void set_wgrad_deterministic(bool on) { g_wgrad_deterministic = on; }
 bool get_wgrad_deterministic() { return g_wgrad_deterministic; }
 
@@ -2897,7 +2917,7 @@ void wgrad_split_reduce(const WgradArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(wb + bb), dim3(256), 0, st, a.ws, a.nsplit, n4, a.dw, a.bws, a.nbslot, a.K, a.dbias, wb);
         return;
     }
-    const int wblocks = (int)((n4 + 255) / 256), bblocks = a.bws ? ceil_div(a.K, 256) : 0;
+    const int wblocks = (int)((n4 + 255) / 256), bblocks = a.bws ? ceil_div(a.K, 16) : 0;      // (bias: 16 outputs per workgroup, 16 lanes each)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, a.ws, a.nsplit, n4, a.dw, a.bws, a.nbslot, a.K,
                        a.dbias, wblocks);
 }

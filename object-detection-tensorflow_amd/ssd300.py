@@ -231,8 +231,10 @@ class SSD300:
         # on the dgrad chain needs its result before the optimizer).  Measured neutral on MI355X (both chains are
         # full-chip kernels with one workgroup per CU), so it is off by default; config key 'wgrad_stream'.
         on_gpu = self.dev.type == 'cuda'      # (a 'cpu' device only gets past ops._p with the mocked library of tests/mock_ops.py: host-logic tests)
-        # config key 'deterministic_wgrad': filter gradients by partial tiles + a fixed-order reduction instead of float atomics
-        # (the whole step bit-identical from run to run, 5 % slower -- 8.16 against 7.75 ms, gpurun r05u; a process-wide switch of the library: include/odtk.h, odtk_debug_set key 5)
+        # config key 'deterministic_wgrad' (default since round 6: True = what the library does anyway): filter gradients by partial tiles + a fixed-order reduction,
+        # the whole step bit-identical from run to run; False = float atomics (round 1-5's default; the step time is the same to 0.1 %: 8.107 / 8.13 / 8.12 ms
+        # against 8.097 / 8.121 / 8.117, gpurun r6e).  A process-wide switch of the library (include/odtk.h, odtk_debug_set key 5): a model built with the
+        # key sets it for every model of the process until another one does
         if on_gpu and 'deterministic_wgrad' in config:
             ops.debug_set(5, 1 if config['deterministic_wgrad'] else 0)
         self.wgrad_stream = _side_stream(self.dev, 'wgrad') if (on_gpu and config.get('wgrad_stream', False)) else None

@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 int zero_async(void* p, size_t bytes, hipStream_t) { memset(p, 0, bytes); return 0; }
 namespace cv {
-static bool g_deterministic = false;
+static bool g_deterministic = true;
 bool get_wgrad_deterministic() { return g_deterministic; }      // (csrc/conv_v3.hip's switch: elementwise.hip's L2-norm gamma gradient follows it)
 int get_scratch_slot() { return 0; }                            // (csrc/conv_v3.hip: the calling thread's scratch slot)
 int misc_scratch(size_t bytes, hipStream_t, char** out) {       // (csrc/conv_v3.hip: the box-side kernels' partial-sum arena; here one grow-only host buffer)

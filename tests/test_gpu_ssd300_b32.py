@@ -409,9 +409,9 @@ def test_bf16_engine_every_layer_in_situ_at_batch32(pair):
 
 
 def test_deterministic_filter_gradients_at_batch32(dev):
-    """config key 'deterministic_wgrad' (odtk_debug_set key 5): the filter gradients of the layers on the 8-wave / four-wave
-    kernels (conv2_x .. conv11_2 and the heads: split over pixels, reduced in fixed order) are bit-identical from run to run; with
-    the default float atomics the same two runs differ in the last bits of at least one of them."""
+    """The DEFAULT since round 6 (config key 'deterministic_wgrad' absent or True; odtk_debug_set key 5 = 1): every filter gradient -- partial tiles of the pixel
+    splits / workgroups reduced in fixed order -- is bit-identical from run to run, and so is the whole gradient buffer; with float atomics
+    ('deterministic_wgrad': False) the same two runs differ in the last bits of at least one of them."""
     import odtk
     p = R.init_params(5)
     imgs, gt = R.synthetic_batch(B, 77)
@@ -423,7 +423,7 @@ def test_deterministic_filter_gradients_at_batch32(dev):
         for det in (True, False):
             got = []
             for rep in range(2):
-                m = _model('bf16', use_graph=False, deterministic_wgrad=det)
+                m = _model('bf16', use_graph=False, **({} if det else {'deterministic_wgrad': False}))      # det: the DEFAULT mode, no key given
                 m.load_oracle_params(p)
                 m.set_batch(imgs, gt)
                 m._step_front()
@@ -434,7 +434,7 @@ def test_deterministic_filter_gradients_at_batch32(dev):
                 del m
             runs[det] = got
     finally:
-        odtk.ops.debug_set(5, 0)
+        odtk.ops.debug_set(5, 1)                           # the library's default
     for k in runs[True][0]:
         assert torch.equal(runs[True][0][k], runs[True][1][k]), k
     assert any(not torch.equal(runs[False][0][k], runs[False][1][k]) for k in runs[False][0])

@@ -19,15 +19,21 @@ import bench_configs as BC          # noqa: E402
 
 
 def grads_of(name, params, stats, batch, size, dtype, probe):
+    """`probe`: one held-out batch or a LIST of them -- the filter gradients are summed over the list (the gradient of the mean loss over len(list) x batch held-out
+    images, evaluated `batch` images at a time; moving statistics restored in front of every one); -> (mean loss, {name: gradient})"""
+    probes = probe if isinstance(probe, list) else [probe]
     r = BC.make(name, batch=batch, size=size, dtype=dtype, use_graph=False)
     m = r['model']
     m.load_oracle_params(params)
-    if stats is not None and hasattr(m, 'S'):
-        m.S.copy_(stats.to(m.S.device))
-    m.set_batch(*probe)
-    loss = float(m.train_step(0.0))
-    torch.cuda.synchronize()
-    g = {k: m.get_param(k, m.G).double().cpu() for k in m.pinfo if k.endswith('.w')}
+    loss, g = 0.0, None
+    for pb in probes:
+        if stats is not None and hasattr(m, 'S'):
+            m.S.copy_(stats.to(m.S.device))
+        m.set_batch(*pb)
+        loss += float(m.train_step(0.0)) / len(probes)
+        torch.cuda.synchronize()
+        gi = {k: m.get_param(k, m.G).double().cpu() for k in m.pinfo if k.endswith('.w')}
+        g = gi if g is None else {k: g[k] + gi[k] for k in g}
     del m
     torch.cuda.empty_cache()
     return loss, g
@@ -66,26 +72,26 @@ def state_hash(params, stats):
     return h.hexdigest()[:16]
 
 
-def run(name, steps=300, batch=4, lr=1e-3, verbose=True, engine='bf16', deterministic=True, checkpoints=None):
+def run(name, steps=300, batch=4, lr=1e-3, verbose=True, engine='bf16', deterministic=True, checkpoints=None, probes=1):
     """-> dict(init=(min cosine, input-side-third median), after=(...), losses=[...], hash=..., table={steps: (min, third, hash)})
 
     `deterministic` (default since round 6): the library's fixed-order filter-gradient reduction (odtk_debug_set key 5) for the f32 training AND both
     comparison steps, so that the trained weights -- and with them every number returned -- are bit-identical from run to run and from box to box
     (`hash` says so: sha256 of the trained parameters + moving statistics).  `checkpoints`: the comparison is repeated at each of these step counts
-    (the last one is `steps`)."""
+    (the last one is `steps`).  `probes`: held-out batches the compared gradients are summed over (grads_of)."""
     from odtk import ops
     ops.debug_set(5, 1 if deterministic else 0)
     try:
-        return _run(name, steps, batch, lr, verbose, engine, sorted(set(list(checkpoints or []) + [steps])))
+        return _run(name, steps, batch, lr, verbose, engine, sorted(set(list(checkpoints or []) + [steps])), probes)
     finally:
-        ops.debug_set(5, 0)
+        ops.debug_set(5, 1)                                # the library's default since round 6
 
 
-def _run(name, steps, batch, lr, verbose, engine, checkpoints):
+def _run(name, steps, batch, lr, verbose, engine, checkpoints, probes=1):
     size = BC.SHAPES[name][0]
     r = BC.make(name, batch=batch, size=size, dtype='f32', use_graph=False)
     m = r['model']
-    probe = BC.synthetic_batch(name, batch, size, 4242)
+    probe = BC.synthetic_batch(name, batch, size, 4242) if probes == 1 else [BC.synthetic_batch(name, batch, size, 4242 + 17 * i) for i in range(probes)]
     p0 = m.export_params()
     s0 = m.S.clone() if hasattr(m, 'S') else None
     lf, gf = grads_of(name, p0, s0, batch, size, 'f32', probe)

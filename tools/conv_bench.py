@@ -49,7 +49,7 @@ modes = [(m if ':' in m else int(m)) for m in sys.argv[4].split(',')] if len(sys
 # mode >= 100: 8-wave kernels with perf-experiment bits (mode - 100) -> odtk_debug_set(2, bits); results are garbage
 dev = torch.device('cuda')
 if os.environ.get('ODTK_WG'):
-    ops.debug_set(5, int(os.environ['ODTK_WG']))            # filter-gradient flush: 0 = float atomics (default), 1 = partial stores + reduction launch (include/odtk.h, key 5)
+    ops.debug_set(5, int(os.environ['ODTK_WG']))            # filter-gradient flush: 0 = float atomics, 1 (default since round 6) = partial stores + reduction launch (include/odtk.h, key 5)
 if os.environ.get('ODTK_DBG2'):
     ops.debug_set(6, int(os.environ['ODTK_DBG2']))          # dispatch A/B switches that leave results intact (include/odtk.h, key 6)
 tot = {m: 0.0 for m in modes}

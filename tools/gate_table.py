@@ -4,7 +4,7 @@ For each class: f32 training from the seeded initial weights on seeded synthetic
 (tools/bf16_after_training.py), the bf16-against-f32 filter-gradient comparison at initialisation and at each checkpoint, and the sha256 of the trained state
 at each checkpoint.  Run twice in one process (`repeat`), the hashes and every cosine must repeat; across boxes the printed table must be the same text.
 
-    python tools/gate_table.py [classes=ssd300,yolov3,fcos,centernet,yolov2,retinanet] [checkpoints=300,600,1000] [repeat=2]
+    python tools/gate_table.py [classes=ssd300,yolov3,fcos,centernet,yolov2,retinanet] [checkpoints=300,600,1000] [repeat=2] [probes=1]
 """
 import json
 import os
@@ -20,11 +20,12 @@ def main():
     names = (sys.argv[1] if len(sys.argv) > 1 else 'ssd300,yolov3,fcos,centernet,yolov2,retinanet').split(',')
     cps = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else '300,600,1000').split(',')]
     repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    probes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     out = {}
     for name in names:
         runs = []
         for rep in range(repeat):
-            r = T.run(name, steps=max(cps), batch=BATCH.get(name, 4), lr=1e-3, verbose=(rep == 0), checkpoints=cps)
+            r = T.run(name, steps=max(cps), batch=BATCH.get(name, 4), lr=1e-3, verbose=(rep == 0), checkpoints=cps, probes=probes)
             runs.append(r)
         same = all(r['table'] == runs[0]['table'] and r['init'] == runs[0]['init'] for r in runs)
         out[name] = dict(init=runs[0]['init'], table={str(k): v for k, v in runs[0]['table'].items()}, reproducible=same,

@@ -31,7 +31,7 @@ def one(name, engine, steps, batch):
             torch.cuda.synchronize()
             runs.append((m, gs, losses, m.P.clone()))
         finally:
-            ops.debug_set(5, 0)
+            ops.debug_set(5, 1)
     (m, g0, l0, p0), (_, g1, l1, p1) = runs
     ok = True
     for s in range(steps):

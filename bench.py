@@ -271,7 +271,7 @@ def main():
                     help="BASELINE.json's configuration: ssd300 = config 2 (the headline metric, the default); retinanet = config 3 (800x800, batch 16); "
                          'yolov3 = config 4 (416x416, 8 / GPU); fcos | centernet = config 5 (512x512, 16 / GPU) -- bench_configs.py')
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s)')
-    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f32x3'], help='engine (default: the one the model class defaults to in training mode: bf16 for ssd300 / yolov3 / fcos / centernet, f32x3 -- f32 tensors, ODTK_F32X3 convolution descriptors -- for retinanet)')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f32x3'], help='engine (default: the one the model class defaults to in training mode: bf16 for ssd300 / fcos / centernet, f32x3 -- f32 tensors, ODTK_F32X3 convolution descriptors -- for retinanet and, since round 6, yolov3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-events', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='N = 1, ssd300: skip what follows the headline measurement (sustained run, live PMC traffic passes, '
@@ -662,8 +662,9 @@ def configs_bench(budget_s=120.0, pmc=True):
     import subprocess
     res = {}
     t0 = time.perf_counter()
-    # (retinanet twice: its default engine since round 4, f32x3, and the exact f32 engine it replaced -- the two are different arithmetic, not one kernel made faster)
-    order = (('yolov3', []), ('fcos', []), ('centernet', []), ('retinanet', []), ('retinanet_f32', ['--dtype', 'f32']))
+    # (retinanet twice: its default engine since round 4, f32x3, and the exact f32 engine it replaced -- the two are different arithmetic, not one kernel made faster;
+    #  yolov3 twice since round 6: the class default f32x3 and the bf16 engine the gate does not admit, each line with its `engine_admission`)
+    order = (('yolov3', []), ('yolov3_bf16', ['--dtype', 'bf16']), ('fcos', []), ('centernet', []), ('retinanet', []), ('retinanet_f32', ['--dtype', 'f32']))
 
     def remaining(name):                     # configurations still to be started after `name` (each needs ~25 s for its plain child run)
         names = [n for n, _ in order]
@@ -772,6 +773,7 @@ def bench_other(args, world, rank, local_rank):
                'data': 'synthetic',
                'config': {'workload': BC.WORKLOAD[name].format(B=B), 'global_batch': B * world, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                           'launch': 'hip-graph replay' if args.graph else 'eager', 'algorithmic_conv_gflop_per_image': round(flops_step / B / 1e9, 2),
+                          'engine_admission': BC.ADMISSION.get((name, args.dtype)),
                           'engine_note': None if args.dtype == 'bf16' else
                           'f32 engine with operand splitting: every f32 product = three bf16 MFMA products (hi*hi + hi*lo + lo*hi), f32 accumulation; peak = bf16 dense / 3' if args.dtype == 'f32x3' else
                           'f32 engine (the class default): exact-f32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s'}}

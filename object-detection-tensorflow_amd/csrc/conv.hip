@@ -1107,8 +1107,9 @@ static int conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const float* w
     const size_t xs_b = up256((size_t)Min * x3_pitch(ldc) * 2), w3_b = up256((size_t)d->K * d->R * d->S * 3 * ldc * 2);
     char* base = nullptr;
     if (int e = cv::x3_scratch(xs_b + w3_b + (ks > 1 ? (size_t)ks * Mout * d->ldy * 4 : 0), st, &base)) return e;
-    cv::launch_split3_chan(x, Min, d->C, d->ldx, base, ldc, 2, 2, x3_pitch(ldc), st);                               // pixels [hi | lo], read as [hi | hi | lo]
-    cv::launch_split3_chan(w, (long long)d->K * d->R * d->S, d->C, d->C, base + xs_b, ldc, 2, 3, 3 * ldc, st);   // filters [K][R][S][hi | lo | hi]
+    // pixels [hi | lo] (read as [hi | hi | lo]) and filters [K][R][S][hi | lo | hi]: ONE launch (round 6)
+    cv::launch_split3_chan2(x, Min, d->C, d->ldx, base, ldc, 2, 2, x3_pitch(ldc),
+                            w, (long long)d->K * d->R * d->S, d->C, d->C, base + xs_b, ldc, 2, 3, 3 * ldc, st);
     a.x = base; a.w = base + xs_b;
     cv::launch_gather_x3(a, y, (float*)(base + xs_b + w3_b), bias, relu, nullptr, 0, 0, st);
     g_last_kernel = a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
@@ -1129,8 +1130,9 @@ static int conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, c
     const size_t dys_b = up256((size_t)Mout * x3_pitch(ldk) * 2), wt3_b = up256((size_t)d->C * d->R * d->S * 3 * ldk * 2);
     char* base = nullptr;
     if (int e = cv::x3_scratch(dys_b + wt3_b + (ks > 1 ? (size_t)ks * Min * d->ldx * 4 : 0), st, &base)) return e;
-    cv::launch_split3_chan(dy, Mout, d->K, lddy, base, ldk, 2, 2, x3_pitch(ldk), st);                                // [hi | lo], read as [hi | hi | lo]
-    cv::launch_split3_chan(w_t, (long long)d->C * d->R * d->S, d->K, lddy, base + dys_b, ldk, 2, 3, 3 * ldk, st);   // the caller's [C][R][S][lddy] flipped filters -> [hi | lo | hi]
+    // dy [hi | lo] (read as [hi | hi | lo]) and the caller's [C][R][S][lddy] flipped filters -> [hi | lo | hi]: ONE launch (round 6)
+    cv::launch_split3_chan2(dy, Mout, d->K, lddy, base, ldk, 2, 2, x3_pitch(ldk),
+                            w_t, (long long)d->C * d->R * d->S, d->K, lddy, base + dys_b, ldk, 2, 3, 3 * ldk, st);
     a.x = base; a.w = base + dys_b;
     cv::launch_gather_x3(a, dx, (float*)(base + dys_b + wt3_b), nullptr, 0, relu_src, d->ldx, accumulate, st);
     g_last_kernel = a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
@@ -1148,8 +1150,8 @@ static int conv2d_wgrad_x3(const odtk_conv_desc* d, const float* x, const float*
     const size_t xr_b = up256((size_t)3 * Min * d->C * 2), dyr_b = up256((size_t)3 * Mout * ldk * 2), cs_b = (size_t)2 * 256 * ((d->K + 63) / 64 * 64) * 4;
     char* base = nullptr;
     if (int e = cv::x3_scratch(xr_b + dyr_b + cs_b, st, &base)) return e;
-    cv::launch_split3_rows(x, Min, d->C, d->ldx, base, d->C, 2, st);                                  // images [hi ; lo ; hi]
-    cv::launch_split3_rows(dy, Mout, d->K, lddy, base + xr_b, ldk, 4, st);                             // images [hi ; hi ; lo]
+    // x images [hi ; lo ; hi] and dy images [hi ; hi ; lo]: ONE launch (round 6)
+    cv::launch_split3_rows2(x, Min, d->C, d->ldx, base, d->C, 2, dy, Mout, d->K, lddy, base + xr_b, ldk, 4, st);
     odtk_conv_desc b = *d;
     b.N = 3 * d->N; b.dtype = b.out_dtype = ODTK_BF16; b.ldx = d->C; b.ldy = ldk;
     if (int e = odtk_conv2d_wgrad(&b, base, base + xr_b, ldk, dw, nullptr, stream)) return e;      // the bf16 filter-gradient kernels; their f32 result is dW

@@ -327,6 +327,10 @@ int launch_wgrad_v3(WgradArgs& a, hipStream_t st);
 // x3: f32 convolutions on the bf16 MFMA kernels by operand splitting (conv_v3.hip)
 void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, int nparts, int ldrow, hipStream_t st);
 void launch_split3_rows(const float* src, long long M, int C, int lds, void* dst, int ldd, int pattern, hipStream_t st);
+void launch_split3_chan2(const float* src0, long long M0, int C0, int lds0, void* dst0, int ldc0, int pattern0, int nparts0, int ldrow0,
+                         const float* src1, long long M1, int C1, int lds1, void* dst1, int ldc1, int pattern1, int nparts1, int ldrow1, hipStream_t st);      // both in ONE launch
+void launch_split3_rows2(const float* src0, long long M0, int C0, int lds0, void* dst0, int ldd0, int pattern0,
+                         const float* src1, long long M1, int C1, int lds1, void* dst1, int ldd1, int pattern1, hipStream_t st);
 int gather_x3_ksplit(const GatherArgs& a);
 int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bias, int relu, const float* mask, int ldmask, int accumulate, hipStream_t st);
 // small-map gather kernel (conv_v9.hip): 64 x 64 tiles, four waves, deep LDS-DMA ring, no split-K; parity phases for stride-2 input gradients

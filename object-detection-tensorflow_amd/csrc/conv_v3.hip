@@ -3021,34 +3021,37 @@ __device__ __forceinline__ void split8(const float* __restrict__ row, int c0, in
     vl = make_uint4(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16);
 }
 // dst [M][ldrow >= nparts * ldc] (nparts = 2 | 3; parts hi/lo by `pattern` bit i = part i is the low half) from src [M][lds] f32, C valid channels; pad columns of every part zeroed
-__global__ void __launch_bounds__(256) split3_chan_kernel(const float* __restrict__ src, long long M, int C, int lds, bf16_t* __restrict__ dst, int ldc, int pattern, int nparts, int ldrow, FastDiv dc) {
-    const int cpr = ldc >> 3;                              // 8-channel chunks per part row
-    const long long total = M * cpr;
-    const bool vec = (lds & 3) == 0 && ((uintptr_t)src & 15) == 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long m = total < (1ll << 31) ? (long long)fdiv((unsigned)i, dc) : i / cpr;
+// One split job: `rows` = false -> dst rows [part 0 | part 1 | ...] of ldc channels each at pitch ldrow (split3_chan), true -> dst [3 M][ld] row blocks (split3_rows).
+// Round 6: the two operands of a pass (pixels + filter; x + dy of a filter gradient) are split by ONE launch (split3_pair_kernel: workgroups [0, j0.blocks) run job 0,
+// the rest job 1) -- the filter split is ~3 us of work behind a launch boundary of its own, ~220 times per RetinaNet / YOLOv3 step.
+struct SplitJob {
+    const float* src; long long M; int C, lds; bf16_t* dst; int ld, pattern, nparts, ldrow; FastDiv dc; int rows, blocks;
+};
+__device__ __forceinline__ void split3_job(const SplitJob& j, int bid, int nblk) {
+    const int cpr = j.ld >> 3;                             // 8-channel chunks per part row
+    const long long total = j.M * cpr;
+    const bool vec = (j.lds & 3) == 0 && ((uintptr_t)j.src & 15) == 0;
+    for (long long i = (long long)bid * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
+        const long long m = total < (1ll << 31) ? (long long)fdiv((unsigned)i, j.dc) : i / cpr;
         const int c0 = (int)(i - m * cpr) * 8;
         uint4 vh, vl;
-        split8(src + m * lds, c0, C, vec, vh, vl);
-        bf16_t* row = dst + m * ldrow + c0;
+        split8(j.src + m * j.lds, c0, j.C, vec, vh, vl);
+        if (j.rows) {
 #pragma unroll
-        for (int part = 0; part < 3; ++part)
-            if (part < nparts) *reinterpret_cast<uint4*>(row + part * ldc) = ((pattern >> part) & 1) ? vl : vh;
+            for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(j.dst + ((long long)part * j.M + m) * j.ld + c0) = ((j.pattern >> part) & 1) ? vl : vh;
+        } else {
+            bf16_t* row = j.dst + m * j.ldrow + c0;
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                if (part < j.nparts) *reinterpret_cast<uint4*>(row + part * j.ld) = ((j.pattern >> part) & 1) ? vl : vh;
+        }
     }
 }
-// dst [3 M][ldd] (row blocks hi/lo by `pattern`) from src [M][lds] f32
-__global__ void __launch_bounds__(256) split3_rows_kernel(const float* __restrict__ src, long long M, int C, int lds, bf16_t* __restrict__ dst, int ldd, int pattern, FastDiv dc) {
-    const int cpr = ldd >> 3;
-    const long long total = M * cpr;
-    const bool vec = (lds & 3) == 0 && ((uintptr_t)src & 15) == 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long m = total < (1ll << 31) ? (long long)fdiv((unsigned)i, dc) : i / cpr;
-        const int c0 = (int)(i - m * cpr) * 8;
-        uint4 vh, vl;
-        split8(src + m * lds, c0, C, vec, vh, vl);
-#pragma unroll
-        for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(dst + ((long long)part * M + m) * ldd + c0) = ((pattern >> part) & 1) ? vl : vh;
-    }
+__global__ void __launch_bounds__(256) split3_chan_kernel(const SplitJob j) { split3_job(j, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) split3_rows_kernel(const SplitJob j) { split3_job(j, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) split3_pair_kernel(const SplitJob j0, const SplitJob j1) {
+    if ((int)blockIdx.x < j0.blocks) split3_job(j0, blockIdx.x, j0.blocks);
+    else split3_job(j1, (int)blockIdx.x - j0.blocks, j1.blocks);
 }
 // sum of the f32 partial tiles + bias (+ ReLU, ReLU mask, accumulate: the semantics of x3_store4) -> f32 y; pad columns (>= K) zeroed
 __global__ void __launch_bounds__(256) splitk_finish_f32_kernel(const float* __restrict__ ws, int ksplit, long long M, int K, int ldy, const float* __restrict__ bias, int relu,
@@ -3085,11 +3088,31 @@ static int grid_1d(long long n) {
 }
 }  // namespace
 
+static SplitJob split_job(const float* src, long long M, int C, int lds, void* dst, int ld, int pattern, int nparts, int ldrow, int rows) {
+    SplitJob j;
+    j.src = src; j.M = M; j.C = C; j.lds = lds; j.dst = (bf16_t*)dst; j.ld = ld; j.pattern = pattern; j.nparts = nparts; j.ldrow = ldrow;
+    j.dc = make_fastdiv((unsigned)(ld >> 3)); j.rows = rows; j.blocks = grid_1d(M * (ld >> 3));
+    return j;
+}
 void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, int nparts, int ldrow, hipStream_t st) {
-    hipLaunchKernelGGL(split3_chan_kernel, dim3(grid_1d(M * (ldc >> 3))), dim3(256), 0, st, src, M, C, lds, (bf16_t*)dst, ldc, pattern, nparts, ldrow, make_fastdiv((unsigned)(ldc >> 3)));
+    const SplitJob j = split_job(src, M, C, lds, dst, ldc, pattern, nparts, ldrow, 0);
+    hipLaunchKernelGGL(split3_chan_kernel, dim3(j.blocks), dim3(256), 0, st, j);
 }
 void launch_split3_rows(const float* src, long long M, int C, int lds, void* dst, int ldd, int pattern, hipStream_t st) {
-    hipLaunchKernelGGL(split3_rows_kernel, dim3(grid_1d(M * (ldd >> 3))), dim3(256), 0, st, src, M, C, lds, (bf16_t*)dst, ldd, pattern, make_fastdiv((unsigned)(ldd >> 3)));
+    const SplitJob j = split_job(src, M, C, lds, dst, ldd, pattern, 3, 0, 1);
+    hipLaunchKernelGGL(split3_rows_kernel, dim3(j.blocks), dim3(256), 0, st, j);
+}
+// two channel-layout splits (pixels + filter of a forward / input-gradient pass) in one launch
+void launch_split3_chan2(const float* src0, long long M0, int C0, int lds0, void* dst0, int ldc0, int pattern0, int nparts0, int ldrow0,
+                         const float* src1, long long M1, int C1, int lds1, void* dst1, int ldc1, int pattern1, int nparts1, int ldrow1, hipStream_t st) {
+    const SplitJob j0 = split_job(src0, M0, C0, lds0, dst0, ldc0, pattern0, nparts0, ldrow0, 0), j1 = split_job(src1, M1, C1, lds1, dst1, ldc1, pattern1, nparts1, ldrow1, 0);
+    hipLaunchKernelGGL(split3_pair_kernel, dim3(j0.blocks + j1.blocks), dim3(256), 0, st, j0, j1);
+}
+// two row-block splits (x and dy of a filter gradient) in one launch
+void launch_split3_rows2(const float* src0, long long M0, int C0, int lds0, void* dst0, int ldd0, int pattern0,
+                         const float* src1, long long M1, int C1, int lds1, void* dst1, int ldd1, int pattern1, hipStream_t st) {
+    const SplitJob j0 = split_job(src0, M0, C0, lds0, dst0, ldd0, pattern0, 3, 0, 1), j1 = split_job(src1, M1, C1, lds1, dst1, ldd1, pattern1, 3, 0, 1);
+    hipLaunchKernelGGL(split3_pair_kernel, dim3(j0.blocks + j1.blocks), dim3(256), 0, st, j0, j1);
 }
 // how many f32 partial tiles the x3 gather of `a` writes (1 = straight into the output)
 int gather_x3_ksplit(const GatherArgs& a) {

@@ -31,6 +31,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import BF16, F32, F32X3
+from .warmup import F32Warmup
 
 INPUT_SIZE = 300
 MEAN_RGB = (123.68, 116.779, 103.979)            # reference SSD300.py:55 (sic: 103.979)
@@ -141,7 +142,7 @@ class _Conv:
         self.bn, self.relu = bn, relu
 
 
-class SSD300:
+class SSD300(F32Warmup):
     # the variant: SSD512 (ssd512.py) overrides these
     INPUT_SIZE = INPUT_SIZE
     FEATURE_SIZES = FEATURE_SIZES
@@ -188,6 +189,11 @@ class SSD300:
         # 'f32x3' (round 5, the engine the other seven classes have had since round 4): f32 tensors, convolution descriptors of dtype ODTK_F32X3 -- the library runs
         # a layer's passes as three bf16 MFMA products per f32 product (hi*hi + hi*lo + lo*hi, f32 accumulation: 3e-5 of the exact f32 result) where that is
         # faster than the exact-f32 MFMA: the engine that meets north_star's 1e-3 on boxes / scores at a multiple of the exact engine's rate
+        # Round 6: SSD300 went through the bf16 admission gate of the other classes (tests/test_gpu_bf16_gate.py; profiles/r06_bf16_gate_table.md): from the synthetic
+        # He initialisation the bf16 engine's filter gradients sit at cosine 0.78 (minimum) / 0.85 (input-side third) against the f32 engine's -- under the bar --
+        # and clear it after 300 f32 steps.  So, as for FCOS / CenterNet / YOLOv2 / YOLOv3 (warmup.py): when NO engine is named, training starts from random
+        # initialisation (no VGG checkpoint found, no weights loaded) and the device is a GPU, the first `f32_warmup_steps` (300) optimizer steps run on an f32x3 twin;
+        # an explicit 'compute_dtype' (bench.py, every test) is taken literally
         cd = config.get('compute_dtype', 'bf16' if config['mode'] == 'train' else 'f32')
         assert cd in ('bf16', 'f32', 'f32x3')
         self.DT = BF16 if cd == 'bf16' else F32
@@ -260,6 +266,7 @@ class SSD300:
         self._define_layers()
         self._init_parameters(config.get('seed', 0))
         self._build_buffers()
+        self._warmup_setup(config, data_provider, 'compute_dtype' in config)
         self._load_pretraining_weight()
 
     # ------------------------------------------------------------------ structure
@@ -361,6 +368,8 @@ class SSD300:
 
     def load_oracle_params(self, p):
         """Load a dict name -> tensor in the oracle's naming ([K,R,S,Cin] weights)."""
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()                                   # weights are loaded: the run does not start from random initialisation
         for k, v in p.items():
             if k in self.pinfo:
                 self.set_param(k, v)
@@ -369,6 +378,7 @@ class SSD300:
         self._refresh_operand_copies()
 
     def export_params(self):
+        self._sync_from_twin()                                     # mid-warm-up: the live weights are the twin's
         out = OrderedDict((k, self.get_param(k)) for k in self.pinfo)
         for k in self.sinfo:
             out[k] = self.stat(k).detach().cpu().clone()
@@ -402,6 +412,8 @@ class SSD300:
                 w = torch.as_tensor(np.asarray(blob[key + '/weights']), dtype=torch.float32)   # HWIO
                 self.set_param(n + '.w', w.permute(3, 0, 1, 2).contiguous())
                 self.set_param(n + '.b', torch.as_tensor(np.asarray(blob[key + '/biases'])))
+                if getattr(self, 'f32_warmup_steps', 0):
+                    self.cancel_warmup()                           # a pre-trained trunk: the run does not start from random initialisation
         self._refresh_operand_copies()
 
     # ------------------------------------------------------------------ buffers
@@ -591,10 +603,36 @@ class SSD300:
     def _conv_fwd(self, name, src, dst, bias, relu):
         ops.conv2d_fwd(self.desc[name], src.t, self._wslice(name + '.w', self.Pc), bias, dst.t, relu)
 
+    # ---- train_one_epoch: the NEXT batch's pixels cross PCIe under the running step (round 6) ----------------------------------------------------------
+    # The f32 pixels of a batch (34.6 MB at batch 32: 0.64 ms at PCIe rate, 8 % of a step) are read exactly once, by the preprocess launch that opens the step.
+    # train_one_epoch therefore hands the batch AFTER the current one to the step (`_prefetch_next`): once the forward pass is enqueued, the copy into
+    # `self.images` is queued on the side stream behind an event recorded after the preprocess launch, and the next step's preprocess waits for the copy's
+    # event.  The ground truth (38 KB) still travels at the start of its own step (matching and the loss read it all step long).  Eager launches only.
+    _prefetch_next = None        # host tensor of the next batch's pixels, consumed by _step_front
+    _img_ready = None            # event on the side stream: the prefetched pixels are in self.images
+    _img_prefetched = None       # the host object whose pixels self.images holds (set_batch skips the copy for it)
+
+    def _prefetch_issue(self, side):
+        images, self._prefetch_next = self._prefetch_next, None
+        if images is None or side is None or _lib.recording() is not None:
+            return
+        consumed = self._event('img_consumed')
+        side.wait_event(consumed)
+        with torch.cuda.stream(side):
+            self.images.copy_(images[1], non_blocking=True)
+            ev = self._event('img_ready')
+            ev.record(side)
+        self._img_ready, self._img_prefetched = ev, images[0]
+
     def _forward(self, training, subtract_mean=True):
         a = self.acts
+        if self._img_ready is not None:                       # (eager launches only: never set while a graph is captured or a launch list recorded)
+            torch.cuda.current_stream().wait_event(self._img_ready)
+            self._img_ready = None
         ops.preprocess(self.images, MEAN_RGB if subtract_mean else (0., 0., 0.), a['input'].ld, self.DT,
                        a['input'].t)
+        if self._prefetch_next is not None:
+            self._event('img_consumed').record(torch.cuda.current_stream())
         for step in self.vgg_plan:
             if step[0] == 'conv':
                 _, name, prev = step
@@ -893,12 +931,21 @@ class SSD300:
             yield
 
     # ------------------------------------------------------------------ public: training
-    def set_batch(self, images, ground_truth):
+    def _set_batch_engine(self, images, ground_truth):
+        images_in = images
         images = torch.as_tensor(images, dtype=torch.float32)
         if self.data_format == 'channels_first' and images.shape[1] == 3:
             images = images.permute(0, 2, 3, 1)
         assert tuple(images.shape) == (self.batch_size, self.INPUT_SIZE, self.INPUT_SIZE, 3), images.shape
-        self.images.copy_(images, non_blocking=True)
+        if self._img_prefetched is not None and self._img_prefetched is images_in:
+            self._img_prefetched = None                       # train_one_epoch: these pixels crossed under the previous step (_prefetch_issue)
+            if self._img_ready is not None:
+                self._img_ready.synchronize()                 # (long done; strict: the iterator may refill its host buffer in place from here on)
+        else:
+            if self._img_ready is not None:                   # a prefetched batch that is not the one being set: the new copy goes behind it
+                torch.cuda.current_stream().wait_event(self._img_ready)
+                self._img_ready = self._img_prefetched = None
+            self.images.copy_(images, non_blocking=True)
         gt = torch.as_tensor(ground_truth, dtype=torch.float32)
         if self.gt is None or self.gt.shape != gt.shape:
             self.gt = torch.zeros(gt.shape, device=self.dev)
@@ -929,6 +976,7 @@ class SSD300:
         if via_tail:
             self._py(lambda: self._tail.wait_stream(side))
         self._forward(True)
+        self._prefetch_issue(side)                            # (after the forward pass is enqueued: a pageable source blocks the host for the copy's duration)
         if not via_tail:
             self._py(lambda: main.wait_stream(side))
         self._wt_pending = False
@@ -1010,7 +1058,7 @@ class SSD300:
         self.use_graph = mode == 'graph'
         self._auto = None
         try:
-            loss = self.train_step(lr)
+            loss = self._train_step_engine(lr)
         finally:
             self._auto, self.use_graph = au, saved
         torch.cuda.synchronize()
@@ -1035,7 +1083,7 @@ class SSD300:
 
     launch_mode = None
 
-    def train_step(self, lr):
+    def _train_step_engine(self, lr):
         """One optimizer step on the batch loaded by set_batch(); returns the loss (data + L2)
         as a 1-element device tensor without synchronising."""
         use_graph = self.use_graph and self._eager_steps >= 2
@@ -1110,14 +1158,28 @@ class SSD300:
         mean_loss = []
         num_iters = self.num_train // self.batch_size
         it = iter(self.train_iterator)
-        for i in range(num_iters):
+
+        def fetch():
+            nonlocal it
             try:
-                images, gt = next(it)
+                return next(it)
             except StopIteration:
                 it = iter(self.train_iterator)
-                images, gt = next(it)
+                return next(it)
+        # eager launches on a GPU with the side stream on: the next batch's pixels are copied under the running step (_prefetch_issue)
+        overlap = (self.dev.type == 'cuda' and self._side is not None and self.use_graph is False and not getattr(self, 'use_list', False)
+                   and self.config.get('side_front', True) and self.config.get('prefetch_images', True) and self.data_format != 'channels_first')
+        nxt = fetch() if num_iters > 0 else None
+        for i in range(num_iters):
+            images, gt = nxt
             self.set_batch(images, gt)
+            nxt = fetch() if i + 1 < num_iters else None
+            if overlap and nxt is not None:
+                host = torch.as_tensor(nxt[0], dtype=torch.float32)
+                if tuple(host.shape) == tuple(self.images.shape):
+                    self._prefetch_next = (nxt[0], host)
             loss = float(self.train_step(lr).item())
+            self._prefetch_next = None
             if self.verbose:
                 sys.stdout.write('\r>> ' + 'iters ' + str(i) + str('/') + str(num_iters) + ' loss ' + str(loss))
                 sys.stdout.flush()
@@ -1170,6 +1232,7 @@ class SSD300:
         """what the reference's `tf.train.Saver()` (SSD300.py:464-466) would write: every global variable -- weights, BN
         moving statistics, global_step and the MomentumOptimizer slots, which are created inside the 'inference' scope
         (:104, :149) and therefore named inference/<variable>/Momentum."""
+        self._sync_from_twin()
         out = OrderedDict()
         for tfname, ours in self.tf_variable_map().items():
             if ours in self.pinfo:
@@ -1183,6 +1246,8 @@ class SSD300:
     def load_tf_checkpoint(self, path):
         """`saver.restore(sess, path)` (SSD300.py:502-504) from the files of a reference-trained model (or ours)."""
         from .tf_checkpoint import NewCheckpointReader
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()
         reader = NewCheckpointReader(str(path))
         names = reader.get_variable_to_shape_map()
         for tfname, ours in self.tf_variable_map().items():
@@ -1204,7 +1269,7 @@ class SSD300:
             self.global_step = int(reader.get_tensor('global_step'))
         self._refresh_operand_copies()
 
-    def save_weight(self, mode, path):
+    def _save_weight_engine(self, mode, path):
         """SSD300.py:490-500.  config['checkpoint_format'] = 'tf' writes the reference's own files
         (`<path>-<step>.index` + `.data-00000-of-00001` + `checkpoint`, readable by its `load_weight`); the default
         'torch' keeps one torch file `<path>-<step>`."""

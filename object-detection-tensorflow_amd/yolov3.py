@@ -32,6 +32,7 @@ import torch
 
 from . import heads, ops
 from ._lib import BF16, F32, F32X3
+from .warmup import F32Warmup
 
 MEAN_RGB = (123.68, 116.779, 103.979)                                       # YOLOv3.py:65
 DARKNET_BLOCKS = ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4))         # :391-395
@@ -50,7 +51,7 @@ class _Act:
         self.gid = name
 
 
-class YOLOv3:
+class YOLOv3(F32Warmup):
     def __init__(self, config, data_provider):
         assert len(config['data_shape']) == 3
         assert config['mode'] in ['train', 'test']
@@ -75,7 +76,14 @@ class YOLOv3:
         self.verbose = bool(config.get('verbose', True))
         self.dev = torch.device(config.get('device', 'cuda:0'))
         # 'f32x3' (round 5): f32 tensors, convolution descriptors of dtype ODTK_F32X3 (three bf16 MFMA products per f32 product where that is faster: include/odtk.h)
-        engine = config.get('compute_dtype', 'bf16')
+        # Round 6: the class went through the bf16 admission gate of the other classes, deterministically (tests/test_gpu_bf16_gate.py;
+        # profiles/r06_bf16_gate_table.md): filter-gradient cosine of the bf16 engine against the f32 engine on 16 held-out images, minimum over the layers / median of
+        # the input-side third -- 0.47 / 0.48 at random initialisation, 0.854 / 0.895 after 300 f32 steps, 0.853 / 0.874 after 600: the class sits AT the bar
+        # (0.8 / 0.88) and does not move away from it as training goes on, where SSD300 / FCOS / CenterNet / YOLOv2 keep rising.  By the gate's rule (admitted
+        # = above the bar at 300 AND at 600 steps) the bf16 engine is NOT the default for training: with no engine named a training instance on the GPU runs
+        # 'f32x3' (f32 tensors, three bf16 MFMA products per f32 product); 'bf16' -- 2.4x the step rate -- is an explicit choice (`compute_dtype='bf16'`,
+        # optionally with `f32_warmup_steps`), and what bench.py's yolov3_bf16 line is quoted on.  Test mode and the CPU stand-in keep their engines.
+        engine = config.get('compute_dtype', 'f32x3' if (self.dev.type == 'cuda' and self.mode == 'train') else 'bf16')
         self.DT = {'bf16': BF16, 'f32': F32, 'f32x3': F32}[engine]
         self.CDT = F32X3 if engine == 'f32x3' else self.DT
         self.tdt = torch.bfloat16 if self.DT == BF16 else torch.float32
@@ -103,6 +111,7 @@ class YOLOv3:
         self.specs = layer_specs(self.num_classes, self.num_priors)
         self._init_parameters(int(config.get('seed', 0)))
         self._build()
+        self._warmup_setup(config, data_provider, 'compute_dtype' in config)
 
     # ------------------------------------------------------------------ parameters
     @staticmethod
@@ -169,6 +178,8 @@ class YOLOv3:
 
     def load_oracle_params(self, p):
         """dict name -> tensor in the oracle's naming ([K,R,S,Cin] kernels)"""
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()                                   # weights are loaded: the run does not start from random initialisation
         for k, v in p.items():
             if k in self.pinfo:
                 self.set_param(k, v)
@@ -177,6 +188,7 @@ class YOLOv3:
         self._refresh_operand_copies()
 
     def export_params(self):
+        self._sync_from_twin()                                     # mid-warm-up: the live weights are the twin's
         out = OrderedDict((k, self.get_param(k)) for k in self.pinfo)
         for k in self.sinfo:
             out[k] = self.stat(k).detach().cpu().clone()
@@ -352,7 +364,7 @@ class YOLOv3:
                 ops.upsample2x_bwd(dcat[:, bottom.C:], y.ld, self.grad_of(lat), lat.ld, lat.N, lat.H, lat.W, lat.C, False)
 
     # ------------------------------------------------------------------ public: training
-    def set_batch(self, images, ground_truth):
+    def _set_batch_engine(self, images, ground_truth):
         images = torch.as_tensor(images, dtype=torch.float32)
         if self.data_format == 'channels_first' and images.shape[1] == 3:
             images = images.permute(0, 2, 3, 1)
@@ -371,7 +383,7 @@ class YOLOv3:
             if self.dist is not None:
                 self.dist.layer_ready(name)
 
-    def train_step(self, lr):
+    def _train_step_engine(self, lr):
         """one optimizer step on the batch of set_batch(); returns the loss (data + L2) as a 1-element device tensor.
         Single device: after two eager steps (the library's lazily grown scratch buffers exist by then) forward + loss + backward
         replay from ONE HIP graph -- ~1 000 dependent launches of 5-25 us each leave the queue without host round trips; the
@@ -440,6 +452,7 @@ class YOLOv3:
         """what the reference's `tf.train.Saver()` (YOLOv3.py:377-381) writes: every variable of its graph under its name
         (reference_variable_map), global_step, and the momentum slots `<variable>/Momentum` (the optimizer is created outside any
         variable scope, :312)"""
+        self._sync_from_twin()
         out = OrderedDict()
         for tfname, ours in reference_variable_map().items():
             if ours in self.pinfo:
@@ -454,6 +467,8 @@ class YOLOv3:
         """`saver.restore(sess, path)` from tf.train.Saver files (ours or the reference's); backbone_trainables_only: what
         `pretraining_weight_saver` restores (YOLOv3.py:377-378, :480-482: the trainable variables under 'backone')"""
         from .tf_checkpoint import NewCheckpointReader
+        if getattr(self, 'f32_warmup_steps', 0):
+            self.cancel_warmup()
         reader = NewCheckpointReader(str(path))
         names = reader.get_variable_to_shape_map()
         for tfname, ours in reference_variable_map().items():
@@ -476,7 +491,7 @@ class YOLOv3:
             self.global_step = int(reader.get_tensor('global_step'))
         self._refresh_operand_copies()
 
-    def save_weight(self, mode, path):
+    def _save_weight_engine(self, mode, path):
         """YOLOv3.py:466-475.  config['checkpoint_format'] = 'tf' writes tf.train.Saver files (tf_checkpoint.py)."""
         assert (mode in ['latest', 'best'])
         dirname = os.path.dirname(path)

@@ -306,7 +306,7 @@ def test_rccl_world1_data_parallel_training_step(dev, grad_dtype, launch):
     the filter-gradient stream while the backward pass keeps the head / filter-gradient streams of the single-device step (eager launches, the default since
     round 4); `--graph`: one backward HIP graph per bucket captured thread-locally beside RCCL's watchdog, the all-reduces between the replays; (bf16:
     narrowed / widened buckets) -- and the loss stays that of the single-device step (the sum over one rank is the identity)."""
-    base = ['--gpus', '1', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-conv-events']
+    base = ['--gpus', '1', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-conv-events', '--no-extras']
     dp = _bench_json(base + ['--dp-world1', '--grad-dtype', grad_dtype] + (['--graph'] if launch == 'graph' else []))
     one = _bench_json(base)
     assert dp['comm']['backend'] == 'nccl' and dp['comm']['world_size'] == 1 and dp['comm']['buckets'] >= 3

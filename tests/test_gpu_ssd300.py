@@ -190,6 +190,49 @@ def test_train_one_epoch_and_checkpoint(dev, tmp_path):
     assert len(out) == 3
 
 
+@pytest.mark.parametrize("source", ["numpy", "pinned", "reused_buffer"])
+def test_train_one_epoch_prefetch_equals_the_plain_loop(source, dev):
+    """Round 6: train_one_epoch copies the NEXT batch's pixels to the device under the running step (side stream, behind the preprocess launch; ssd300.py
+    _prefetch_issue).  Same batches, same order, deterministic filter gradients (the default): mean loss and every parameter after the epoch equal those of the
+    hand-written loop set_batch -> train_step -> float(loss), bit for bit -- from pageable numpy arrays, from pinned tensors, and from an iterator that hands
+    out ONE host buffer refilled in place."""
+    B, n = 2, 5
+    data = [R.synthetic_batch(B, 60 + i) for i in range(n)]
+
+    class Refill:                                             # yields the same numpy array object every time, refilled in place
+        def __iter__(self):
+            buf_i, buf_g = np.empty((B, 300, 300, 3), np.float32), np.empty(tuple(data[0][1].shape), np.float32)
+            for im, gt in data:
+                buf_i[...] = im.numpy()
+                buf_g[...] = gt.numpy()
+                yield buf_i, buf_g
+    if source == 'numpy':
+        gen = [(im.numpy(), gt.numpy()) for im, gt in data]
+    elif source == 'pinned':
+        gen = [(im.pin_memory(), gt.pin_memory()) for im, gt in data]
+    else:
+        gen = Refill()
+    prov = {'data_shape': [300, 300, 3], 'num_train': B * n, 'num_val': 0, 'train_generator': gen, 'val_generator': None}
+    m = _model('train', 'bf16', B, prov)
+    p0 = m.export_params()
+    mean = m.train_one_epoch(0.002)
+    torch.cuda.synchronize()
+    assert m.global_step == n and m._prefetch_next is None
+    ref = _model('train', 'bf16', B, dict(prov, train_generator=[]))
+    ref.load_oracle_params(p0)
+    losses = []
+    for im, gt in data:
+        ref.set_batch(im, gt)
+        losses.append(float(ref.train_step(0.002).item()))
+    assert float(mean) == float(np.mean(losses)), (float(mean), losses)
+    assert torch.equal(m.P, ref.P)
+    # ... and with the overlap switched off the public method gives the same again
+    m2 = _model('train', 'bf16', B, prov)
+    m2.config['prefetch_images'] = False
+    m2.load_oracle_params(p0)
+    assert float(m2.train_one_epoch(0.002)) == float(mean) and torch.equal(m2.P, m.P)
+
+
 def test_tf_saver_checkpoint_roundtrip_and_pretraining(dev, tmp_path):
     """checkpoint_format='tf': the files tf.train.Saver would leave (SSD300.py:490-504) -- every variable of the reference's
     graph under its name and shape (tests/golden/ssd300_variables.json, collected from the reference's own class), momentum

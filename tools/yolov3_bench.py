@@ -13,7 +13,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 416
 cfg = {'mode': 'train', 'data_shape': [size, size, 3], 'num_classes': 20, 'weight_decay': 5e-4, 'keep_prob': 0.5, 'data_format': 'channels_last',
        'batch_size': batch, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'num_priors': 3, 'nms_score_threshold': 0.5,
-       'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'verbose': False,
+       'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'verbose': False, 'compute_dtype': os.environ.get('ODTK_ENGINE', 'bf16'),      # (the class default is f32x3 since round 6)
        'priors': [[[10., 13.], [16, 30.], [33., 23.]], [[30., 61.], [62., 45.], [59., 119.]], [[116., 90.], [156., 198.], [373., 326.]]]}
 g = torch.Generator().manual_seed(0)
 imgs = (torch.rand(batch, size, size, 3, generator=g) * 255).round()

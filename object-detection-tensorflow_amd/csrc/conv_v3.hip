@@ -3143,6 +3143,27 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
     a.accumulate = a.ksplit > 1 ? 0 : accumulate;
     // 3x3 / stride 1 / SAME over whole 64-channel chunks (the heads' and the pyramid's 256-channel layers: 768 split channels): the raster-run halo kernel
     const int halo = 2 * a.dil * (a.W + 1);
+    // Round 6: few-tile 3 x 3 layers (DarkNet-53's 13 x 13 / 26 x 26 maps at 8 images -- YOLOv3 trains on this engine by default now) on the 128 x 128 / 64 x 128
+    // tiles of the halo kernel, two workgroups per CU, whole reduction per workgroup, f32 rows straight from the registers: what round 5 (r05s) gave the bf16
+    // engine instead of a split launch + its finish launch (here: the 8-wave kernel's split-K partials + splitk_finish_f32_kernel).  dbg2 bit 14 = off (A/B).
+    if (a.ksplit > 1 && PT == 128 && !(a.dbg & 65536) && !(a.dbg2 & 16384) && halo <= 96 && a.dil == 1 && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 &&
+        a.idiv == 1 && a.pad_t == 1 && a.pad_l == 1 && a.H == a.Ho && a.W == a.Wo && a.Kdim == 9 * a.C) {
+        const int tq128 = ceil_div(a.M, 128), tp64 = ceil_div(a.K, 64);
+        const bool t128 = tq128 * a.tiles_p >= (2 * g_num_cu) / 3, t64 = !t128 && tq128 * tp64 >= (2 * g_num_cu) / 3 && !(a.dbg2 & 32768);
+        if (t128 || t64) {
+            a.ksplit = -1; a.ws = out; a.bias = bias; a.relu = relu; a.mask = (const char*)mask; a.accumulate = accumulate;
+            a.tiles_q = tq128;
+            if (t128) {
+                if (a.W >= 32) hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 1, 2, 2, 2, 2, false, true>), dim3(tq128 * a.tiles_p), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 0, 0, 2, 2, 2, false, true>), dim3(tq128 * a.tiles_p), dim3(256), 0, st, a);
+            } else {
+                a.tiles_p = tp64;
+                if (a.W >= 32) hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 1, 2, 1, 2, 1, false, true>), dim3(tq128 * tp64), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((conv_gather_v6_kernel<7, false, 0, 0, 1, 2, 1, false, true>), dim3(tq128 * tp64), dim3(256), 0, st, a);
+            }
+            return 0;
+        }
+    }
     if (a.ksplit == 1 && PT == 128 && !(a.dbg & 65536) && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 && a.pad_t == a.dil &&
         a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && a.Kdim == 9 * a.C) {
         const int tiles = a.tiles_p * a.tiles_q;

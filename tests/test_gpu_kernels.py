@@ -1259,6 +1259,11 @@ X3_CASES = [
     (2, 120, 120, 64, 130, 3, 1, 1),   # rows of 112-127 pixels
     (4, 80, 80, 64, 256, 3, 1, 1),     # rows of 80-95 pixels (conv3_x of the 320-pixel models): 448-row single patch buffer
     (3, 95, 95, 64, 200, 3, 1, 1),     # ... its longest row: the patch is exactly full
+    # round 6: few-tile 3x3 layers on the 128 x 128 / 64 x 128 halo tiles with f32 output instead of split-K + finish (DarkNet-53 at 8 images: YOLOv3's default engine)
+    (8, 26, 26, 256, 512, 3, 1, 1),    # 26 x 26: 43 x 4 tiles of 128 x 128 (W < 32: no early patch refill); its input gradient: 256 channels out -> 64 x 128 tiles
+    (8, 13, 13, 512, 1024, 3, 1, 1),   # 13 x 13: 11 x 8 tiles of 128 x 128 < 2/3 of the CUs -> 64 x 128 tiles (11 x 16)
+    (8, 40, 40, 128, 256, 3, 1, 1),    # rows of 32-47 pixels: the early-refill instantiation, 100 x 2 tiles
+    (5, 20, 37, 64, 300, 3, 1, 1),     # ragged: channel tail 300 = 2 x 128 + 44, tiles straddling images, one 64-channel chunk (x 3 parts)
 ]
 
 

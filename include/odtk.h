@@ -74,6 +74,8 @@ int odtk_device_info(int* num_cu, char* name_buf, int name_buf_len);
  *         bit 9 (512) = the small-map kernel always on its four-stage ring, bit 10 (1024) = no halo kernel on C % 64 != 0, bit 12 (4096) = float atomics also for
  *         filter gradients with ONE pixel split, bit 13 (8192) = stride-2 input gradients always on the small-map kernel (never the 8-wave kernel's phase launch),
  *         bit 14 (16384) = no 128 x 128- / 64 x 128-tile launch of the raster-run halo kernel (the chunk-range split-K instead), bit 15 (32768) = no 64 x 128 tiles;
+ *         bit 17 (131072) = EXPERIMENT, changes results: the ODTK_F32X3 splits write zeros for the low halves -- f32 tensors with ONE bf16 product per f32 product,
+ *         the numerics of a cheaper mixed engine at the x3 engine's cost (tools/gate_table.py ... f32x1sim; profiles/r06l_f32x1_numerics_experiment.md);
  * key 7 = group norm: maps of up to `value` pixels per sample run statistics + apply in ONE launch (default 1024, 0 = never) */
 int odtk_debug_set(int key, int value);
 /* Library-owned scratch (the split-K partial tiles of the small-map convolutions) is one buffer per (device, slot), handed to

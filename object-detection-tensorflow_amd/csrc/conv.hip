@@ -912,7 +912,7 @@ extern "C" int odtk_debug_set(int key, int value) {
     if (key == 0) { g_force_regstage = value != 0; return ODTK_OK; }
     if (key == 1) { g_v3_mode = value; return ODTK_OK; }
     if (key == 2) { g_dbg = value; return ODTK_OK; }
-    if (key == 6) { g_dbg2 = value; return ODTK_OK; }
+    if (key == 6) { g_dbg2 = value; cv::set_x3_zero_lo((value & (1 << 17)) != 0); return ODTK_OK; }
     if (key == 3) { set_nms_legacy(value != 0); return ODTK_OK; }
     if (key == 4) { set_bn_small_rows(value); return ODTK_OK; }
     if (key == 5) { cv::set_wgrad_deterministic(value != 0); return ODTK_OK; }

@@ -336,6 +336,7 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
 // small-map gather kernel (conv_v9.hip): 64 x 64 tiles, four waves, deep LDS-DMA ring, no split-K; parity phases for stride-2 input gradients
 bool gather_v9_wanted(const GatherArgs& a, int num_cu);
 int launch_gather_v9(GatherArgs& a, hipStream_t st, int num_cu);
+void set_x3_zero_lo(bool on);   // EXPERIMENT (odtk_debug_set key 6 bit 17): the x3 engine's splits write zeros for the low halves = the numerics of ONE bf16 product per f32 product
 int misc_scratch(size_t bytes, hipStream_t st, char** out); // small partial-sum buffers of the box-side kernels, same per-(device, slot) arena rules
 int x3_scratch(size_t bytes, hipStream_t st, char** out);   // the engine's own arena (per device and scratch slot), grown on demand; never moved once a captured graph holds it
 // deterministic filter-gradient flush (odtk_debug_set key 5), shared by every filter-gradient kernel since round 6: wgrad_split_scratch points a.ws / a.bws at

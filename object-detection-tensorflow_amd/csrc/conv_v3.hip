@@ -3025,7 +3025,7 @@ __device__ __forceinline__ void split8(const float* __restrict__ row, int c0, in
 // Round 6: the two operands of a pass (pixels + filter; x + dy of a filter gradient) are split by ONE launch (split3_pair_kernel: workgroups [0, j0.blocks) run job 0,
 // the rest job 1) -- the filter split is ~3 us of work behind a launch boundary of its own, ~220 times per RetinaNet / YOLOv3 step.
 struct SplitJob {
-    const float* src; long long M; int C, lds; bf16_t* dst; int ld, pattern, nparts, ldrow; FastDiv dc; int rows, blocks;
+    const float* src; long long M; int C, lds; bf16_t* dst; int ld, pattern, nparts, ldrow; FastDiv dc; int rows, blocks, zero_lo;
 };
 __device__ __forceinline__ void split3_job(const SplitJob& j, int bid, int nblk) {
     const int cpr = j.ld >> 3;                             // 8-channel chunks per part row
@@ -3036,6 +3036,7 @@ __device__ __forceinline__ void split3_job(const SplitJob& j, int bid, int nblk)
         const int c0 = (int)(i - m * cpr) * 8;
         uint4 vh, vl;
         split8(j.src + m * j.lds, c0, j.C, vec, vh, vl);
+        if (j.zero_lo) vl = make_uint4(0u, 0u, 0u, 0u);        // experiment switch: see set_x3_zero_lo
         if (j.rows) {
 #pragma unroll
             for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(j.dst + ((long long)part * j.M + m) * j.ld + c0) = ((j.pattern >> part) & 1) ? vl : vh;
@@ -3088,10 +3089,14 @@ static int grid_1d(long long n) {
 }
 }  // namespace
 
+// EXPERIMENT (round 6, odtk_debug_set key 6 bit 17): with the low halves zeroed the x3 engine computes hi x hi only -- f32 tensors, ONE bf16 product per f32 product:
+// the numerics a cheaper mixed engine would have, at the x3 engine's cost; used to put those numerics through the bf16 gate before building that engine.
+static bool g_x3_zero_lo = false;
+void set_x3_zero_lo(bool on) { g_x3_zero_lo = on; }
 static SplitJob split_job(const float* src, long long M, int C, int lds, void* dst, int ld, int pattern, int nparts, int ldrow, int rows) {
     SplitJob j;
     j.src = src; j.M = M; j.C = C; j.lds = lds; j.dst = (bf16_t*)dst; j.ld = ld; j.pattern = pattern; j.nparts = nparts; j.ldrow = ldrow;
-    j.dc = make_fastdiv((unsigned)(ld >> 3)); j.rows = rows; j.blocks = grid_1d(M * (ld >> 3));
+    j.dc = make_fastdiv((unsigned)(ld >> 3)); j.rows = rows; j.blocks = grid_1d(M * (ld >> 3)); j.zero_lo = g_x3_zero_lo ? 1 : 0;
     return j;
 }
 void launch_split3_chan(const float* src, long long M, int C, int lds, void* dst, int ldc, int pattern, int nparts, int ldrow, hipStream_t st) {

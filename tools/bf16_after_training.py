@@ -22,6 +22,18 @@ def grads_of(name, params, stats, batch, size, dtype, probe):
     """`probe`: one held-out batch or a LIST of them -- the filter gradients are summed over the list (the gradient of the mean loss over len(list) x batch held-out
     images, evaluated `batch` images at a time; moving statistics restored in front of every one); -> (mean loss, {name: gradient})"""
     probes = probe if isinstance(probe, list) else [probe]
+    sim = dtype == 'f32x1sim'          # EXPERIMENT: the x3 engine with the low halves of both operands zeroed (odtk_debug_set key 6 bits 17 + 3) = f32 tensors, ONE bf16 product
+    if sim:
+        from odtk import ops
+        ops.debug_set(6, (1 << 17) | 8)
+    try:
+        return _grads_of(name, params, stats, batch, size, 'f32x3' if sim else dtype, probes)
+    finally:
+        if sim:
+            ops.debug_set(6, 0)
+
+
+def _grads_of(name, params, stats, batch, size, dtype, probes):
     r = BC.make(name, batch=batch, size=size, dtype=dtype, use_graph=False)
     m = r['model']
     m.load_oracle_params(params)

@@ -21,11 +21,12 @@ def main():
     cps = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else '300,600,1000').split(',')]
     repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     probes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    engine = sys.argv[5] if len(sys.argv) > 5 else 'bf16'
     out = {}
     for name in names:
         runs = []
         for rep in range(repeat):
-            r = T.run(name, steps=max(cps), batch=BATCH.get(name, 4), lr=1e-3, verbose=(rep == 0), checkpoints=cps, probes=probes)
+            r = T.run(name, steps=max(cps), batch=BATCH.get(name, 4), lr=1e-3, verbose=(rep == 0), checkpoints=cps, probes=probes, engine=engine)
             runs.append(r)
         same = all(r['table'] == runs[0]['table'] and r['init'] == runs[0]['init'] for r in runs)
         out[name] = dict(init=runs[0]['init'], table={str(k): v for k, v in runs[0]['table'].items()}, reproducible=same,

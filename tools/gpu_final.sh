@@ -11,6 +11,9 @@ for c in retinanet yolov3 fcos centernet; do
   timeout 600 python bench.py --config $c --steps 10 --warmup 3 2>$O/err_$c.log | grep '^{' > $O/bench_line_$c.json
   python -c "import json;d=json.load(open('$O/bench_line_$c.json'));print('$c', d['value'], d['ms_per_step'], d['dtype'], d['roofline']['frac'])"
 done
+# (round 6: YOLOv3's class default is f32x3; the bf16 engine the gate does not admit, next to it)
+timeout 600 python bench.py --config yolov3 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline 2>$O/err_yolov3_bf16.log | grep '^{' > $O/bench_line_yolov3_bf16.json
+python -c "import json;d=json.load(open('$O/bench_line_yolov3_bf16.json'));print('yolov3 bf16', d['value'], d['ms_per_step'], d['dtype'], d['roofline']['frac'])"
 # BASELINE configurations 3-5 (per-GPU shares): kernel trace + the PMC passes of the same command (round-4 review: "none has a PMC set")
 for c in yolov3 fcos centernet retinanet; do
   YCMD="python bench.py --config $c --steps 4 --warmup 3 --no-cpu-baseline --no-conv-events"

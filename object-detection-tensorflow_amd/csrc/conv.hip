@@ -1112,7 +1112,7 @@ static int conv2d_fwd_x3(const odtk_conv_desc* d, const float* x, const float* w
                             w, (long long)d->K * d->R * d->S, d->C, d->C, base + xs_b, ldc, 2, 3, 3 * ldc, st);
     a.x = base; a.w = base + xs_b;
     cv::launch_gather_x3(a, y, (float*)(base + xs_b + w3_b), bias, relu, nullptr, 0, 0, st);
-    g_last_kernel = a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
+    g_last_kernel = a.ksplit == -9 ? "conv_gather_v9_kernel<x3>" : a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
@@ -1135,7 +1135,7 @@ static int conv2d_dgrad_x3(const odtk_conv_desc* d, const float* dy, int lddy, c
                             w_t, (long long)d->C * d->R * d->S, d->K, lddy, base + dys_b, ldk, 2, 3, 3 * ldk, st);
     a.x = base; a.w = base + dys_b;
     cv::launch_gather_x3(a, dx, (float*)(base + dys_b + wt3_b), nullptr, 0, relu_src, d->ldx, accumulate, st);
-    g_last_kernel = a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
+    g_last_kernel = a.ksplit == -9 ? "conv_gather_v9_kernel<x3>" : a.ksplit < 0 ? "conv_gather_v6_kernel<x3>" : "conv_gather_v3_kernel<x3>";
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }

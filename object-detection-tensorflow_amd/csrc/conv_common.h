@@ -247,6 +247,26 @@ __device__ __forceinline__ uint2 lds_tr16(unsigned lds_byte_addr) {
     return __builtin_bit_cast(uint2, v);
 }
 
+// four consecutive f32 output channels c .. c+3 of pixel row m of the x3 engine's single-part launches: bias, ReLU, the producer's ReLU mask (f32 rows:
+// keep where mask > 0) and accumulation into what the row holds, then one 16-byte store.  (c < ldy; channels >= K hold zeros: their filter rows are masked)
+__device__ __forceinline__ void x3_store4(const GatherArgs& a, int m, int c, float (&o)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (a.bias && c + e < a.K) o[e] += a.bias[c + e];
+        if (a.relu) o[e] = fmaxf(o[e], 0.f);
+    }
+    float* dst = a.ws + (size_t)m * a.ldy + c;
+    if (a.accumulate) {
+        const float4 pv = *reinterpret_cast<const float4*>(dst);
+        o[0] += pv.x; o[1] += pv.y; o[2] += pv.z; o[3] += pv.w;
+    }
+    if (a.mask) {                                           // (input-gradient semantics of the bf16 epilogue: the mask gates the SUM)
+        const float4 mk = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mask) + (size_t)m * a.ldmask + c);
+        o[0] = mk.x > 0.f ? o[0] : 0.f; o[1] = mk.y > 0.f ? o[1] : 0.f; o[2] = mk.z > 0.f ? o[2] : 0.f; o[3] = mk.w > 0.f ? o[3] : 0.f;
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // acc + lo(v) + hi(v) of a packed bf16 pair in ONE VALU op (v_dot2c_f32_bf16 against (1, 1))
 typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2_bf16_ones(unsigned v, float acc) {
@@ -336,6 +356,7 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
 // small-map gather kernel (conv_v9.hip): 64 x 64 tiles, four waves, deep LDS-DMA ring, no split-K; parity phases for stride-2 input gradients
 bool gather_v9_wanted(const GatherArgs& a, int num_cu);
 int launch_gather_v9(GatherArgs& a, hipStream_t st, int num_cu);
+bool launch_gather_v9_x3(GatherArgs& a, hipStream_t st, int num_cu);      // conv_v9.hip: the small-map kernel with f32 output on the x3 engine's split operands (true = launched)
 void set_x3_zero_lo(bool on);   // EXPERIMENT (odtk_debug_set key 6 bit 17): the x3 engine's splits write zeros for the low halves = the numerics of ONE bf16 product per f32 product
 int misc_scratch(size_t bytes, hipStream_t st, char** out); // small partial-sum buffers of the box-side kernels, same per-(device, slot) arena rules
 int x3_scratch(size_t bytes, hipStream_t st, char** out);   // the engine's own arena (per device and scratch slot), grown on demand; never moved once a captured graph holds it

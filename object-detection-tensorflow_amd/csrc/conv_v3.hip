@@ -217,26 +217,6 @@ __device__ __forceinline__ void epilogue_bf16(const GatherArgs& a, char* smem, f
 // ---------------------------------------------------------------------------------------
 // gather kernel (forward conv, stride-1 dgrad)
 // ---------------------------------------------------------------------------------------
-// four consecutive f32 output channels c .. c+3 of pixel row m of the x3 engine's single-part launches: bias, ReLU, the producer's ReLU mask (f32 rows:
-// keep where mask > 0) and accumulation into what the row holds, then one 16-byte store.  (c < ldy; channels >= K hold zeros: their filter rows are masked)
-__device__ __forceinline__ void x3_store4(const GatherArgs& a, int m, int c, float (&o)[4]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (a.bias && c + e < a.K) o[e] += a.bias[c + e];
-        if (a.relu) o[e] = fmaxf(o[e], 0.f);
-    }
-    float* dst = a.ws + (size_t)m * a.ldy + c;
-    if (a.accumulate) {
-        const float4 pv = *reinterpret_cast<const float4*>(dst);
-        o[0] += pv.x; o[1] += pv.y; o[2] += pv.z; o[3] += pv.w;
-    }
-    if (a.mask) {                                           // (input-gradient semantics of the bf16 epilogue: the mask gates the SUM)
-        const float4 mk = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mask) + (size_t)m * a.ldmask + c);
-        o[0] = mk.x > 0.f ? o[0] : 0.f; o[1] = mk.y > 0.f ? o[1] : 0.f; o[2] = mk.z > 0.f ? o[2] : 0.f; o[3] = mk.w > 0.f ? o[3] : 0.f;
-    }
-    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-}
-
 // PHASE (round 5; with BUF, C64, no split-K): the four parity phases of a stride-2 input gradient in one launch (GatherArgs::v9, the table the small-map kernel uses):
 // a tile's pixels belong to one phase, only that phase's taps are walked -- 9 tap-slabs per four output pixels instead of 36, a quarter of the MFMA work.
 template <int PT, bool DB, bool EARLY, bool BUF, bool C64 = false, bool SPLIT = false, bool ILV = false, bool PHASE = false>
@@ -3168,6 +3148,13 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
             }
             return 0;
         }
+    }
+    // Round 6: what is left with few tiles -- the 1 x 1 layers of the small maps above all -- on the small-map kernel (conv_v9.hip: 64 x 64 tiles, whole reduction per
+    // workgroup) with f32 output, instead of split-K partial tiles + splitk_finish_f32_kernel
+    if (a.ksplit > 1 && !(a.dbg & 65536)) {
+        GatherArgs b = a;
+        b.ksplit = 1; b.ws = out; b.bias = bias; b.relu = relu; b.mask = (const char*)mask; b.accumulate = accumulate;
+        if (launch_gather_v9_x3(b, st, g_num_cu)) { a = b; return 0; }
     }
     if (a.ksplit == 1 && PT == 128 && !(a.dbg & 65536) && a.C % 64 == 0 && a.R == 3 && a.S == 3 && a.ostride == 1 && a.idiv == 1 && a.pad_t == a.dil &&
         a.pad_l == a.dil && a.H == a.Ho && a.W == a.Wo && a.Kdim == 9 * a.C) {

@@ -30,8 +30,12 @@ __device__ __forceinline__ void v9_barrier() {
 typedef short s16x2v9 __attribute__((ext_vector_type(2)));
 
 // C64: C % 64 == 0 and Kdim % 64 == 0 -- a k-slab never straddles a tap, the tap walk is wave-uniform.  PHASE (implies C64): parity phases of a stride-2 input gradient.
-template <int NST, bool C64, bool PHASE>
+// F32OUT (round 6, implies C64, no PHASE): the x3 engine's form -- the pixel operand stores [hi | lo] per row and is read as [hi | hi | lo] (GatherArgs::x3c) against
+// filters stored [hi | lo | hi]; the f32 accumulators leave as f32 rows straight from the registers (x3_store4: bias, ReLU, ReLU mask, accumulate).  What the small maps'
+// 1 x 1 layers of DarkNet-53 run on since YOLOv3 trains on f32x3 by default (they took the 8-wave kernel's split-K partials + splitk_finish_f32_kernel before).
+template <int NST, bool C64, bool PHASE, bool F32OUT = false>
 __global__ void __launch_bounds__(256) conv_gather_v9_kernel(const GatherArgs a) {
+    static_assert(!F32OUT || (C64 && !PHASE), "F32OUT: whole 64-channel chunks, no parity phases");
     constexpr int PT = 64, QT = 64;
     constexpr int STAGE = (PT + QT) * 128;             // 16 KiB: filter rows, then pixel rows
     constexpr int NDMA = 4;                            // LDS-DMA pieces per wave and slab
@@ -120,7 +124,8 @@ __global__ void __launch_bounds__(256) conv_gather_v9_kernel(const GatherArgs a)
         if (C64) {
             const bool live = issued < nk;
             const int sr = a.idiv == 2 ? (cur_r + 1) >> 1 : cur_r * a.dil, ss = a.idiv == 2 ? (cur_s + 1) >> 1 : cur_s * a.dil;
-            const unsigned toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + cur_c * 2);
+            const int xc = (F32OUT && a.x3c && cur_c >= a.x3c) ? cur_c - a.x3c : cur_c;       // x3: the third part re-reads the first part's channels
+            const unsigned toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + xc * 2);
             const unsigned tapbit = live ? 1u << (cur_r * a.S + cur_s) : 0u;
             const unsigned woff = (unsigned)(((cur_r * a.S + cur_s) * a.C + cur_c) * 2);
 #pragma unroll
@@ -183,6 +188,19 @@ __global__ void __launch_bounds__(256) conv_gather_v9_kernel(const GatherArgs a)
         st_n = st_n == NST - 1 ? 0 : st_n + 1;
     }
     v9_wait_vmcnt<0>();                                // the trailing zero-fill pieces must land before the image overwrites the ring
+    if constexpr (F32OUT) {
+        const int m = q0 + qrow;
+        if (m < Mq) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = p0 + wp * 32 + 8 * g + 4 * hi;
+                if (c >= a.ldy) continue;
+                float o[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                x3_store4(a, m, c, o);
+            }
+        }
+        return;
+    }
     v9_barrier();
 
     // ---- epilogue: acc (+ bias) -> bf16 (ReLU) -> swizzled [pixel][channel] image -> 16 bytes per lane (+ accumulate, ReLU mask) -> y
@@ -257,6 +275,26 @@ bool gather_v9_wanted(const GatherArgs& a, int num_cu) {
     const int tiles256 = ceil_div(a.K, a.K <= 64 ? 64 : 128) * ceil_div(a.M, 256);
     const double flops = 2.0 * a.M * a.K * a.Kdim;
     return tiles256 <= num_cu / 2 && flops < 8.0e9;
+}
+
+// the x3 engine's launch (a.x / a.w = the split operands, a.C = 3 x the logical channels, a.ws = the f32 output): true = launched
+bool launch_gather_v9_x3(GatherArgs& a, hipStream_t st, int num_cu) {
+    if ((a.dbg2 & 64) || a.pool_mode || a.ybits || a.mask_bits || a.idiv != 1 || a.R * a.S > 32 || a.K < 1) return false;
+    if (!(a.C % 64 == 0 && a.x3c % 64 == 0 && a.Kdim == a.R * a.S * a.C)) return false;
+    const int tiles256 = ceil_div(a.K, a.K <= 64 ? 64 : 128) * ceil_div(a.M, 256);
+    const double flops = 2.0 * a.M * a.K * a.Kdim;
+    // (long reductions stay on the split-K form: RetinaNet's 3 x 3 / 256-channel heads on P5-P7 -- 108 slabs per tile -- measured 0.5 % of the step SLOWER here,
+    //  DarkNet-53's 1 x 1 layers -- 12-48 slabs -- 2.5 % faster: gpurun r6n)
+    if (!(a.dbg2 & 128) && !(tiles256 <= num_cu / 2 && flops < 8.0e9 && a.Kdim <= 64 * 64)) return false;
+    a.tiles_p = ceil_div(a.K, 64);
+    a.tiles_q = ceil_div(a.M, 64);
+    a.v9_phases = 0;
+    a.ksplit = -9;
+    const int grid = a.tiles_p * a.tiles_q;
+    if (grid <= 0) return true;
+    if (grid <= num_cu && !(a.dbg2 & 512)) hipLaunchKernelGGL((conv_gather_v9_kernel<8, true, false, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_gather_v9_kernel<4, true, false, true>), dim3(grid), dim3(256), 0, st, a);
+    return true;
 }
 
 int launch_gather_v9(GatherArgs& a, hipStream_t st, int num_cu) {

@@ -1264,6 +1264,11 @@ X3_CASES = [
     (8, 13, 13, 512, 1024, 3, 1, 1),   # 13 x 13: 11 x 8 tiles of 128 x 128 < 2/3 of the CUs -> 64 x 128 tiles (11 x 16)
     (8, 40, 40, 128, 256, 3, 1, 1),    # rows of 32-47 pixels: the early-refill instantiation, 100 x 2 tiles
     (5, 20, 37, 64, 300, 3, 1, 1),     # ragged: channel tail 300 = 2 x 128 + 44, tiles straddling images, one 64-channel chunk (x 3 parts)
+    # round 6: the small-map kernel (64 x 64 tiles, whole reduction per workgroup) with f32 output on the split operands: DarkNet-53's 1 x 1 layers at 8 images
+    (8, 13, 13, 1024, 512, 1, 1, 1),   # 22 x 8 tiles, 48 slabs (3 x 1 024 channels); input gradient 16 x 22 tiles over 3 x 512
+    (8, 26, 26, 512, 256, 1, 1, 1),    # 85 x 4 tiles: the four-stage ring (more tiles than CUs)
+    (8, 52, 52, 256, 128, 1, 1, 1),    # 338 x 2 tiles
+    (3, 9, 11, 64, 100, 3, 1, 1),      # 3 x 3 on a map too small for the halo tiles: nine taps x 3 chunks through the tap walk (27 slabs), channel tail 100, ragged last tile
 ]
 
 

@@ -336,7 +336,8 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         const unsigned sQ = sP + PT * 128;
         if (C64) {
             const int sr = a.idiv == 2 ? (s_kr + 1) >> 1 : s_kr * a.dil, ss = a.idiv == 2 ? (s_ks + 1) >> 1 : s_ks * a.dil;
-            const unsigned toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + s_kc * 2);
+            const int xkc = (SPLIT && a.x3c && s_kc >= a.x3c) ? s_kc - a.x3c : s_kc;       // x3 (round 6: the phase launch): the third part re-reads the first part's channels
+            const unsigned toff32 = (unsigned)((sr * a.W + ss) * a.ldx * 2 + xkc * 2);
             const unsigned tapbit = 1u << (s_kr * a.S + s_ks);
             const unsigned woff = PHASE ? (unsigned)(((s_kr * a.S + s_ks) * a.C + s_kc) * 2) : (unsigned)(s_klin * 2);
 #pragma unroll
@@ -574,8 +575,13 @@ __global__ void __launch_bounds__(512) conv_gather_v3_kernel(const GatherArgs a)
         float* wsp = a.ws + (size_t)part * a.M * a.ldy;
 #pragma unroll
         for (int j = 0; j < QI; ++j) {
-            const int m = q0 + wq * 64 + j * 32 + l31;
-            if (m >= a.M) continue;
+            int m = q0 + wq * 64 + j * 32 + l31;
+            if (m >= Mq) continue;
+            if (PHASE) {                                  // x3 phase launch (round 6, single part): the tile's pixels are a run of ONE phase's grid -> output row
+                const int n = (int)fdiv((unsigned)m, d_hw), rem = m - n * (Hq * Wq);
+                const int hq_ = (int)fdiv((unsigned)rem, d_w), wq_ = rem - hq_ * Wq;
+                m = (n * a.Ho + 2 * hq_ + ph) * a.Wo + 2 * wq_ + pw;
+            }
 #pragma unroll
             for (int i = 0; i < PI; ++i)
 #pragma unroll
@@ -3128,6 +3134,23 @@ int launch_gather_x3(GatherArgs& a, float* out, float* partials, const float* bi
     a.accumulate = a.ksplit > 1 ? 0 : accumulate;
     // 3x3 / stride 1 / SAME over whole 64-channel chunks (the heads' and the pyramid's 256-channel layers: 768 split channels): the raster-run halo kernel
     const int halo = 2 * a.dil * (a.W + 1);
+    // Round 6: stride-2 input gradients on whole 64-channel chunks as four PARITY PHASES in one launch of the 8-wave kernel (what round 5 gave the bf16 engine: a phase
+    // walks only the taps of its row / column parity -- 9 tap-slabs per four pixels instead of 36, none of them multiplying zeros), whole reduction per workgroup,
+    // f32 rows from the registers.  DarkNet-53's five down-sampling layers; dbg2 bit 13 = off (A/B)
+    if (a.idiv == 2 && a.dil == 1 && a.ostride == 1 && a.C % 64 == 0 && a.x3c % 64 == 0 && a.Kdim == a.R * a.S * a.C && a.R * a.S <= 32 && !(a.dbg & 65536) && !(a.dbg2 & 8192)) {
+        GatherArgs b = a;
+        b.plan_v9_qt = 256;
+        if (int e = launch_gather_v9(b, st, g_num_cu)) return e;       // fills b.v9 / b.tiles_q only (plan_v9_qt != 0: no launch)
+        if (ceil_div(b.K, PT) * b.tiles_q >= g_num_cu / 2) {                        // (few tiles: the split-K form below keeps more CUs busy)
+            a = b;
+            a.tiles_p = ceil_div(a.K, PT);
+            a.ksplit = 1; a.ws = out; a.bias = bias; a.relu = relu; a.mask = (const char*)mask; a.accumulate = accumulate;
+            const int grid_ph = a.tiles_p * a.tiles_q;
+            if (PT == 64) hipLaunchKernelGGL((conv_gather_v3_kernel<64, true, false, true, true, true, false, true>), dim3(grid_ph), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((conv_gather_v3_kernel<128, true, false, true, true, true, false, true>), dim3(grid_ph), dim3(512), 0, st, a);
+            return 0;
+        }
+    }
     // Round 6: few-tile 3 x 3 layers (DarkNet-53's 13 x 13 / 26 x 26 maps at 8 images -- YOLOv3 trains on this engine by default now) on the 128 x 128 / 64 x 128
     // tiles of the halo kernel, two workgroups per CU, whole reduction per workgroup, f32 rows straight from the registers: what round 5 (r05s) gave the bf16
     // engine instead of a split launch + its finish launch (here: the 8-wave kernel's split-K partials + splitk_finish_f32_kernel).  dbg2 bit 14 = off (A/B).

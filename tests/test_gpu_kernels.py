@@ -1268,6 +1268,11 @@ X3_CASES = [
     (8, 13, 13, 1024, 512, 1, 1, 1),   # 22 x 8 tiles, 48 slabs (3 x 1 024 channels); input gradient 16 x 22 tiles over 3 x 512
     (8, 26, 26, 512, 256, 1, 1, 1),    # 85 x 4 tiles: the four-stage ring (more tiles than CUs)
     (8, 52, 52, 256, 128, 1, 1, 1),    # 338 x 2 tiles
+    # round 6: stride-2 input gradients as four parity phases on the 8-wave kernel with f32 output (>= 128 tiles; DarkNet-53's down-sampling layers)
+    (8, 104, 104, 64, 128, 3, 2, 1),   # dx has 64 channels: the 64-channel filter tile, 4 x 85 tiles
+    (16, 52, 52, 128, 256, 3, 2, 1),   # 128-channel tile
+    (6, 51, 37, 192, 192, 3, 2, 1),    # odd x odd map: ragged phase grids and tiles, two channel tiles with a tail
+    (24, 52, 52, 256, 512, 1, 2, 1),   # 1 x 1 / stride 2: three of the four phases have no tap (zeros, still masked / accumulated)
     (3, 9, 11, 64, 100, 3, 1, 1),      # 3 x 3 on a map too small for the halo tiles: nine taps x 3 chunks through the tap walk (27 slabs), channel tail 100, ragged last tile
 ]
 

@@ -162,6 +162,40 @@ def test_ssd300_training_step_host_logic():
             assert _rel(after[k] - p[k], step) < 3e-2, k
 
 
+def test_ssd300_train_one_epoch_consumes_the_iterator_in_order():
+    """Round 6: SSD300.train_one_epoch fetches ONE batch ahead (on the GPU the next batch's pixels are copied under the running step).  Host logic on the mocked
+    library: exactly num_train // batch_size batches are taken, in order, wrapping around an iterator that is shorter than the epoch (SSD300.py:473-484's
+    behaviour with a re-initialised tf.data iterator); the returned value is the mean of the per-step losses of exactly those batches; on a CPU device nothing is
+    prefetched."""
+    import numpy as np
+    import odtk
+    from oracle import ssd300_ref as R
+    torch.set_num_threads(8)
+    cfg = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+           'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '', 'verbose': False,
+           'compute_dtype': 'f32', 'seed': 0, 'use_graph': False, 'device': 'cpu'}
+    data = [R.synthetic_batch(1, 70 + i) for i in range(2)]
+    taken = []
+
+    class Gen:
+        def __iter__(self):
+            for i, (im, gt) in enumerate(data):
+                taken.append(i)
+                yield im.numpy(), gt.numpy()
+    with mock_ops.installed():
+        m = odtk.SSD300(cfg, {'data_shape': [300, 300, 3], 'num_train': 3, 'num_val': 0, 'train_generator': Gen(), 'val_generator': None})
+        p0 = m.export_params()
+        mean = m.train_one_epoch(0.01)
+        assert taken == [0, 1, 0] and m.global_step == 3 and m._prefetch_next is None and m._img_prefetched is None
+        ref = odtk.SSD300(cfg, {'data_shape': [300, 300, 3], 'num_train': 3, 'num_val': 0, 'train_generator': [], 'val_generator': None})
+        ref.load_oracle_params(p0)
+        losses = []
+        for i in (0, 1, 0):
+            ref.set_batch(*data[i])
+            losses.append(float(ref.train_step(0.01)))
+        assert abs(float(mean) - float(np.mean(losses))) < 1e-6 * abs(float(mean)) and torch.equal(m.P, ref.P)
+
+
 def test_inference_tails_host_logic():
     """test_one_image of YOLOv3, RetinaNet and FCOS on the CPU (forward in inference mode + heads.py: decode -> threshold -> batched per-class
     NMS -> [scores, bbox, class_id] in the reference's order) against the oracles' detections"""

@@ -56,6 +56,11 @@ CONV_CASES = [
 # transposed convolution is the dgrad of a 4x4 / stride-2 convolution
 BACKBONE_CASES = [
     (2, 64, 64, 3, 16, 7, 2, 1),      # stem: 3 real channels in one chunk, 7x7, stride 2 (asymmetric SAME pad 2 / 3)
+    # round 6: more 49-tap geometries (the stems of the ResNet / DLA classes; they run on the register-staged kernels: the LDS-DMA gathers' tap masks are 32 bits --
+    # widened to 64 and measured, the stems were SLOWER there: CenterNet 535 -> 590 us, FCOS 141 -> 224, RetinaNet 760 -> 721)
+    (2, 40, 52, 3, 16, 7, 1, 1),      # ... 7x7 / stride 1 (CenterNet's DLA stem), ragged tiles
+    (2, 64, 64, 3, 64, 7, 2, 1),      # ... 64 output channels (the ResNet stem of FCOS)
+    (1, 20, 22, 16, 24, 7, 1, 1),     # ... 16 input channels: the input gradient walks 49 taps x 24 channels too
     (2, 32, 32, 16, 7, 1, 1, 1),      # bottleneck 1x1 to 7 channels (pitch 8)
     (2, 32, 32, 7, 7, 3, 1, 1),       # 7 -> 7, 3x3
     (2, 32, 32, 7, 28, 1, 1, 1),      # 7 -> 28 (pitch 32)

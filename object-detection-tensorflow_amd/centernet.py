@@ -346,7 +346,15 @@ class CenterNet(F32Warmup):
             if a.g is None and a is not self.input:
                 a.g = torch.zeros(a.M, a.ld, dtype=dt, device=dev)
             return acc
+        # Round 6: an input of a sum whose ONLY consumer is that sum has d(input) = d(sum) exactly: it SHARES the sum's gradient buffer instead of receiving a
+        # copy of it (DLA's aggregation nodes and residual sums: 85 add2d launches per step were 6.5 % of the step, a good part of them such copies).  Nobody
+        # writes into a shared buffer again -- every reader (the producer's batch-norm / pool backward, another sum) only reads d(output).
+        consumers = {}
+        for op in self.plan:
+            for a in ([op[3]] if op[0] == 'layer' else op[1] if op[0] == 'add' else [op[1]]):
+                consumers[id(a)] = consumers.get(id(a), 0) + 1
         self.bplan = []
+        self.shared_grads = 0
         for op in reversed(self.plan):
             kind = op[0]
             if kind == 'layer':
@@ -356,7 +364,15 @@ class CenterNet(F32Warmup):
             elif kind == 'add':
                 _, ins, y = op
                 assert id(y) in written
-                self.bplan.append(('add', [(a, emit(a)) for a in ins], y))
+                todo = []
+                for a in ins:
+                    if consumers[id(a)] == 1 and a.g is None and a is not self.input and (a.M, a.ld) == (y.M, y.ld) and self.config.get('share_sum_gradients', True):
+                        a.g = y.g                                  # shared: no launch
+                        written.add(id(a))
+                        self.shared_grads += 1
+                    else:
+                        todo.append((a, emit(a)))
+                self.bplan.append(('add', todo, y))
             else:
                 _, x, y = op
                 assert id(y) in written

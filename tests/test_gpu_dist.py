@@ -391,7 +391,7 @@ def test_data_parallel_step_through_the_c_abi_collective(dev, grad_dtype):
         torch.cuda.synchronize()
         if dp:
             assert len(red.red.launch_log) == len(red.red.buckets)
-            assert len(m.__dict__.get('_dp_point_events', {})) >= 20           # round 6: the collectives wait for per-layer events on the main chain (ssd300._dp_grad_point)
+            assert 1 <= len(m.__dict__.get('_dp_point_events', {})) <= len(red.red.buckets)   # round 6: the collectives wait for per-layer events on the main chain, one per bucket-closing layer of the main chain (ssd300._dp_grad_point)
             red.red.collective.close()
         out.append((m.P.clone(), losses))
     (p0, l0), (p1, l1) = out

@@ -233,6 +233,34 @@ def test_train_one_epoch_prefetch_equals_the_plain_loop(source, dev):
     assert float(m2.train_one_epoch(0.002)) == float(mean) and torch.equal(m2.P, m.P)
 
 
+def test_default_engine_warms_up_on_an_f32x3_twin_and_hands_over(dev):
+    """Round 6 (the bf16 gate's consequence for SSD300, tests/test_gpu_bf16_gate.py): with NO engine named a training instance is the bf16 engine behind an f32x3
+    twin for its first `f32_warmup_steps` steps (300 by default; 2 here).  The warm-up steps ARE f32x3 steps (losses bit-identical to an explicit f32x3 model's:
+    deterministic filter gradients), the state moves over bit for bit, and step 3 runs on the bf16 engine."""
+    import odtk
+    B = 2
+    imgs, gt = R.synthetic_batch(B, 91)
+    prov = {'data_shape': [300, 300, 3], 'num_train': B, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None}
+    cfg = dict(CONFIG, mode='train', batch_size=B, use_graph=False)
+    cfg.pop('compute_dtype', None)
+    assert odtk.SSD300(dict(cfg), prov).f32_warmup_steps == 300
+    m = odtk.SSD300(dict(cfg, f32_warmup_steps=2), prov)
+    ref = odtk.SSD300(dict(cfg, compute_dtype='f32x3'), prov)
+    ref.load_oracle_params(m.export_params())
+    assert m.DT == odtk.ops.BF16 and m.f32_warmup_steps == 2 and ref.f32_warmup_steps == 0
+    m.set_batch(imgs, gt); ref.set_batch(imgs, gt)
+    l_ref = [float(ref.train_step(0.002)) for _ in range(2)]
+    l0 = float(m.train_step(0.002))
+    assert m._twin is not None and m._twin.DT == odtk.ops.F32 and m._twin.CDT == odtk.ops.F32X3 and m.global_step == 1
+    l1 = float(m.train_step(0.002))
+    assert [l0, l1] == l_ref, ([l0, l1], l_ref)
+    assert m._twin is None and m.global_step == 2
+    a, b = m.export_params(), ref.export_params()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    l2, l2_ref = float(m.train_step(0.002)), float(ref.train_step(0.002))        # bf16 engine against f32x3 from identical weights
+    assert np.isfinite(l2) and abs(l2 - l2_ref) <= 5e-2 * abs(l2_ref) and m.global_step == 3
+
+
 def test_tf_saver_checkpoint_roundtrip_and_pretraining(dev, tmp_path):
     """checkpoint_format='tf': the files tf.train.Saver would leave (SSD300.py:490-504) -- every variable of the reference's
     graph under its name and shape (tests/golden/ssd300_variables.json, collected from the reference's own class), momentum

@@ -474,7 +474,7 @@ def test_yolov2_training_step_host_logic():
             assert _rel(after[k], q[k]) < 1e-3 or float((after[k] - q[k]).abs().max()) < 1e-6, k
 
 
-@pytest.mark.parametrize('kind', ['fcos', 'centernet', 'yolov2'])
+@pytest.mark.parametrize('kind', ['fcos', 'centernet', 'yolov2', 'ssd300', 'yolov3'])      # (round 6: SSD300 joined the warm-up classes; YOLOv3 has the mixin for an explicit f32_warmup_steps)
 def test_bf16_default_with_f32_warmup_hands_over_to_the_bf16_engine(kind, tmp_path):
     """warmup.py: with `f32_warmup_steps = n` the first n optimizer steps of a bf16 model run on an f32 twin -- step for step what a pure f32 model does -- then
     parameters, optimizer state (momentum | Adam moments + step) and moving statistics move over bit for bit and the bf16 engine continues; a checkpoint written
@@ -489,6 +489,23 @@ def test_bf16_default_with_f32_warmup_hands_over_to_the_bf16_engine(kind, tmp_pa
         imgs, gt = (torch.rand(2, 64, 64, 3, generator=g) * 255).round(), FR.synthetic_gt(2, 64, 64, 8)
         prov = {'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None}
         cls, lr, state = odtk.FCOS, 0.01, ('Mom',)
+    elif kind == 'ssd300':
+        from oracle import ssd300_ref as R3
+        cfg = {'mode': 'train', 'data_format': 'channels_last', 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5, 'batch_size': 1,
+               'nms_score_threshold': 0.5, 'nms_max_boxes': 20, 'nms_iou_threshold': 0.5, 'pretraining_weight': '', 'verbose': False, 'use_graph': False,
+               'device': 'cpu', 'seed': 3}
+        imgs, gt = R3.synthetic_batch(1, 52)
+        prov = {'data_shape': [300, 300, 3], 'num_train': 1, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None}
+        cls, lr, state = odtk.SSD300, 0.002, ('Mom',)
+    elif kind == 'yolov3':
+        from oracle import yolov3_ref as YR3
+        cfg = {'mode': 'train', 'data_shape': [64, 64, 3], 'num_classes': 20, 'weight_decay': 5e-4, 'keep_prob': 0.5, 'data_format': 'channels_last',
+               'batch_size': 2, 'coord_scale': 1, 'noobj_scale': 1, 'obj_scale': 5., 'class_scale': 1., 'num_priors': 3, 'nms_score_threshold': 0.5,
+               'nms_max_boxes': 10, 'nms_iou_threshold': 0.5, 'priors': YR3.PRIORS_PX, 'verbose': False, 'use_graph': False, 'device': 'cpu', 'seed': 3}
+        g = torch.Generator().manual_seed(11)
+        imgs, gt = (torch.rand(2, 64, 64, 3, generator=g) * 255).round(), YR3.synthetic_gt(2, 64, 12, max_obj=3)
+        prov = {'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None}
+        cls, lr, state = odtk.YOLOv3, 0.001, ('Mom',)
     elif kind == 'yolov2':
         from oracle import yolov2_ref as YR2
         cfg = {'mode': 'train', 'is_pretraining': False, 'data_shape': [64, 64, 3], 'num_classes': 20, 'weight_decay': 1e-4, 'keep_prob': 0.5,
@@ -507,7 +524,8 @@ def test_bf16_default_with_f32_warmup_hands_over_to_the_bf16_engine(kind, tmp_pa
         prov = {'data_shape': [128, 128, 3], 'num_train': 2, 'num_val': 0, 'train_generator': [(imgs, gt)], 'val_generator': None}
         cls, lr, state = odtk.CenterNet, 1e-3, ('M1', 'M2')
     with mock_ops.installed():
-        assert cls(dict(cfg), prov).DT == odtk.ops.F32                          # the CPU stand-in keeps the f32 default; on the GPU the default is bf16 + warm-up
+        if kind not in ('ssd300', 'yolov3'):                                    # (these two keep their engine default on the CPU stand-in: bf16)
+            assert cls(dict(cfg), prov).DT == odtk.ops.F32                      # the CPU stand-in keeps the f32 default; on the GPU the default is bf16 + warm-up
         ref = cls(dict(cfg, compute_dtype='f32'), prov)
         m = cls(dict(cfg, compute_dtype='bf16', f32_warmup_steps=2), prov)
         assert m.DT == odtk.ops.BF16 and m.f32_warmup_steps == 2 and cls(dict(cfg, compute_dtype='bf16'), prov).f32_warmup_steps == 0

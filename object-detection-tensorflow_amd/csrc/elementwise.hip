@@ -1148,8 +1148,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          T* __restrict__ dx, int M, int C, int ld,
                                                          const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                         int accumulate, const T* __restrict__ relu_src, float* __restrict__ part,
-                                                         unsigned* __restrict__ ticket) {
+                                                         int accumulate, const T* __restrict__ relu_src, float* __restrict__ part) {
     constexpr int KC = Chunk<T>::N;
     __shared__ float sdg[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1200,18 +1199,26 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const T* __restrict__ x
         if (part == nullptr) {
             atomicAdd(dgamma, v);
         } else {
-            // deterministic mode (odtk_debug_set key 5, round 5): the blocks' sums are added in BLOCK order by whichever block arrives last
-            __hip_atomic_store(part + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == gridDim.x - 1) {
-                __threadfence();
-                float sum = 0.f;
-                for (unsigned b = 0; b < gridDim.x; ++b) sum += __hip_atomic_load(part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *dgamma += sum;
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch (stream order)
-            }
+            // deterministic mode (the default since round 6): this block's sum goes to part[block] with a plain store; l2norm_dgamma_reduce_kernel adds the blocks in
+            // order.  (Round 5 had the last block to arrive do it behind a device-scope fence + ticket: 211 us per launch against 48 with the atomic -- the fence in
+            // 1 024 workgroups costs more than the second launch; found in round 6's end-of-round trace.)
+            part[blockIdx.x] = v;
         }
+    }
+}
+
+// dgamma += part[0] + part[1] + ... in a fixed order: 256 threads take consecutive runs, the run sums meet in LDS and are added in thread order
+__global__ void __launch_bounds__(256) l2norm_dgamma_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ dgamma) {
+    __shared__ float sm[256];
+    const int per = (n + 255) / 256, b0 = threadIdx.x * per;
+    float t = 0.f;
+    for (int i = b0; i < b0 + per && i < n; ++i) t += part[i];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sum = 0.f;
+        for (int i = 0; i < 256; ++i) sum += sm[i];
+        *dgamma += sum;
     }
 }
 
@@ -1689,11 +1696,10 @@ extern "C" int odtk_l2norm_bwd(const void* x, const void* dy, void* dx, int M, i
     if (int e = pool_check(C, ld, dtype)) return e;
     hipStream_t st = (hipStream_t)stream;
     int grid = ceil_div(M, 4); if (grid > 1024) grid = 1024;
-    // deterministic mode (key 5): per-block partial sums + a ticket in a small buffer per (device, scratch slot) -- like the convolutions' scratch, launches
-    // that are in flight at the same time must come from threads on different slots (odtk_scratch_slot; round-5 advisory).  The buffer is allocated on first
-    // use (not inside a stream capture: run one eager step first) and zeroed on the caller's stream; the kernel leaves the ticket at zero.
+    // deterministic mode (key 5, the default): per-block partial sums in a small buffer per (device, scratch slot), added in block order by a second, tiny launch --
+    // like the convolutions' scratch, launches that are in flight at the same time must come from threads on different slots (odtk_scratch_slot; round-5
+    // advisory).  The buffer is allocated on first use (not inside a stream capture: run one eager step first).
     float* part = nullptr;
-    unsigned* ticket = nullptr;
     if (cv::get_wgrad_deterministic()) {
         static float* s_part[16][4] = {{nullptr}};
         static std::mutex s_mutex;
@@ -1704,15 +1710,14 @@ extern "C" int odtk_l2norm_bwd(const void* x, const void* dy, void* dx, int M, i
         std::lock_guard<std::mutex> lock(s_mutex);
         if (!s_part[dev][slot]) {
             void* p = nullptr;                       // (inside a stream capture hipMalloc fails and says so: run one eager step first)
-            ODTK_CHECK_HIP(hipMalloc(&p, (1024 + 16) * sizeof(float)));
-            ODTK_CHECK_HIP(hipMemsetAsync(p, 0, (1024 + 16) * sizeof(float), st));
+            ODTK_CHECK_HIP(hipMalloc(&p, 1024 * sizeof(float)));
             s_part[dev][slot] = (float*)p;
         }
         part = s_part[dev][slot];
-        ticket = reinterpret_cast<unsigned*>(s_part[dev][slot] + 1024);
     }
     DT_SWITCH(dtype, T, hipLaunchKernelGGL(l2norm_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy,
-                                           (T*)dx, M, C, ld, gamma, dgamma, accumulate, (const T*)relu_src, part, ticket);)
+                                           (T*)dx, M, C, ld, gamma, dgamma, accumulate, (const T*)relu_src, part);)
+    if (part) hipLaunchKernelGGL(l2norm_dgamma_reduce_kernel, dim3(1), dim3(256), 0, st, part, grid, dgamma);
     ODTK_LAUNCH_CHECK();
     return ODTK_OK;
 }
